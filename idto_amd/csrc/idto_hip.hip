@@ -1,0 +1,501 @@
+// idto_hip.hip — C-ABI (include/idto_hip.h) over the gfx950 kernels in kernels.h.
+// Owns the HBM-resident state of one trajectory-optimisation problem:
+//   q, N+, v, a | slab (dtau/dq + tau, t-major) | g, H bands | factors | step
+// Nothing in here falls back to the CPU: if no HIP device is present every
+// entry point fails with a negative status.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "idto_hip.h"
+#include "kernels.h"
+
+using namespace idto_dev;
+
+namespace {
+thread_local std::string g_err;
+
+#define HIP_OK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      g_err = std::string(#expr) + ": " + hipGetErrorString(e_);                                  \
+      return -2;                                                                                  \
+    }                                                                                             \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+}  // namespace
+
+struct idto_hip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int nb = 0, nq = 0, nv = 0, N = 0, npaths = 1, maxc = 1;
+  double dt = 0;
+  std::vector<void*> allocs;
+  DevModel M;
+  DevContact cp;
+  DevProblem P;
+  // problem arrays (device)
+  double *d_vinit = nullptr, *d_qnom = nullptr, *d_vnom = nullptr;
+  double* d_w[10] = {nullptr};
+  // state
+  double *q = nullptr, *v = nullptr, *a = nullptr, *nplus = nullptr, *slab = nullptr;
+  double *g = nullptr, *HA = nullptr, *HB = nullptr, *HC = nullptr, *step = nullptr, *cost = nullptr;
+  double *Kst = nullptr, *LUst = nullptr, *Yst = nullptr, *Zst = nullptr;
+  int* pivst = nullptr;
+  int slab_stride = 0;
+  int k_begin = 0, k_end = 0;
+  // launch geometry
+  int fd_threads = 256, fd_lds = 0, tau_lds = 0, asm_lds = 0, penta_lds = 0, solve_lds = 0, cost_lds = 0;
+  // timing
+  bool timing = false;
+  struct Timed { hipEvent_t a, b; int which; };
+  std::vector<Timed> pending;
+  double tsum[3] = {0, 0, 0};
+  int tcnt[3] = {0, 0, 0};
+};
+
+namespace {
+
+template <class T>
+int Upload(idto_hip_ctx* c, const T* host, size_t count, T** dev) {
+  void* p = nullptr;
+  HIP_OK(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+  c->allocs.push_back(p);
+  if (count) HIP_OK(hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice));
+  *dev = static_cast<T*>(p);
+  return 0;
+}
+template <class T>
+int Alloc(idto_hip_ctx* c, size_t count, T** dev) {
+  void* p = nullptr;
+  HIP_OK(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+  HIP_OK(hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T)));
+  c->allocs.push_back(p);
+  *dev = static_cast<T*>(p);
+  return 0;
+}
+
+int UploadProblemArrays(idto_hip_ctx* c, const idto_problem_t* p, bool first) {
+  const int nq = c->nq, nv = c->nv, N = c->N;
+  const double dt = c->dt;
+  auto scaled = [](const double* W, size_t n, double s1, double s2) {
+    std::vector<double> out(n);
+    for (size_t i = 0; i < n; ++i) out[i] = (s1 * W[i]) * s2;  // reference TO.cc:1103-1107
+    return out;
+  };
+  const std::vector<double> w[10] = {
+      scaled(p->Qq, (size_t)nq * nq, 2, dt), scaled(p->Qv, (size_t)nv * nv, 2, dt), scaled(p->R, (size_t)nv * nv, 2, dt),
+      scaled(p->Qf_q, (size_t)nq * nq, 2, 1), scaled(p->Qf_v, (size_t)nv * nv, 2, 1),
+      std::vector<double>(p->Qq, p->Qq + (size_t)nq * nq), std::vector<double>(p->Qv, p->Qv + (size_t)nv * nv),
+      std::vector<double>(p->R, p->R + (size_t)nv * nv), std::vector<double>(p->Qf_q, p->Qf_q + (size_t)nq * nq),
+      std::vector<double>(p->Qf_v, p->Qf_v + (size_t)nv * nv)};
+  if (first) {
+    if (Upload(c, p->v_init, nv, &c->d_vinit)) return -2;
+    if (Upload(c, p->q_nom, (size_t)(N + 1) * nq, &c->d_qnom)) return -2;
+    if (Upload(c, p->v_nom, (size_t)(N + 1) * nv, &c->d_vnom)) return -2;
+    for (int i = 0; i < 10; ++i)
+      if (Upload(c, w[i].data(), w[i].size(), &c->d_w[i])) return -2;
+  } else {
+    HIP_OK(hipMemcpyAsync(c->d_vinit, p->v_init, nv * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(c->d_qnom, p->q_nom, (size_t)(N + 1) * nq * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(c->d_vnom, p->v_nom, (size_t)(N + 1) * nv * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    for (int i = 0; i < 10; ++i)
+      HIP_OK(hipMemcpyAsync(c->d_w[i], w[i].data(), w[i].size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));  // host staging vectors die at scope exit
+  }
+  DevProblem& P = c->P;
+  P.N = N; P.dt = dt; P.v_init = c->d_vinit; P.q_nom = c->d_qnom; P.v_nom = c->d_vnom;
+  P.Qq = c->d_w[0]; P.Qv = c->d_w[1]; P.R = c->d_w[2]; P.Qfq = c->d_w[3]; P.Qfv = c->d_w[4];
+  P.Qq0 = c->d_w[5]; P.Qv0 = c->d_w[6]; P.R0 = c->d_w[7]; P.Qfq0 = c->d_w[8]; P.Qfv0 = c->d_w[9];
+  return 0;
+}
+
+int BuildModel(idto_hip_ctx* c, const idto_model_t* m) {
+  const int nb = m->nbodies, K = m->npaths;
+  if (K < 1 || K > IDTO_MAX_PATHS || (K & (K - 1))) { g_err = "npaths must be a power of two <= 8"; return -1; }
+  // star decomposition tables
+  std::vector<int> chain((size_t)K * IDTO_MAX_CHAIN, -1), nchain(K, 0), pkind((size_t)K * IDTO_MAX_CHAIN, 0);
+  std::vector<int> slot_of(nb, -3);
+  for (int i = 0; i < nb; ++i) {
+    if (i == m->common_body) { slot_of[i] = -1; continue; }
+    const int p = m->body_path[i];
+    if (p < 0 || p >= K) { g_err = "body without a valid path"; return -1; }
+    const int s = nchain[p]++;
+    if (s >= IDTO_MAX_CHAIN) { g_err = "chain longer than IDTO_MAX_CHAIN"; return -1; }
+    chain[(size_t)p * IDTO_MAX_CHAIN + s] = i;
+    slot_of[i] = s;
+    const int par = m->parent[i];
+    int kind;
+    if (par < 0) kind = PK_WORLD;
+    else if (par == m->common_body) kind = PK_COMMON;
+    else if (s > 0 && chain[(size_t)p * IDTO_MAX_CHAIN + s - 1] == par) kind = PK_PREV;
+    else { g_err = "model is not a star decomposition (body parent is neither world, common nor previous in path)"; return -1; }
+    pkind[(size_t)p * IDTO_MAX_CHAIN + s] = kind;
+  }
+  int maxc = 1;
+  for (int p = 0; p < K; ++p) maxc = std::max(maxc, nchain[p]);
+  c->maxc = maxc;
+  std::vector<int> path_npairs(K, 0);
+  for (int i = 0; i < m->npairs; ++i) path_npairs[m->pair_path[i]]++;
+  int maxpp = 1;
+  for (int p = 0; p < K; ++p) maxpp = std::max(maxpp, path_npairs[p]);
+  std::vector<int> path_pairs((size_t)K * maxpp, 0), fill(K, 0), sa(m->npairs), sb(m->npairs);
+  for (int i = 0; i < m->npairs; ++i) {
+    const int p = m->pair_path[i];
+    path_pairs[(size_t)p * maxpp + fill[p]++] = i;
+    const int ba = m->geom_body[m->pair_a[i]], bb = m->geom_body[m->pair_b[i]];
+    sa[i] = ba < 0 ? -2 : slot_of[ba];
+    sb[i] = bb < 0 ? -2 : slot_of[bb];
+    for (int b : {ba, bb})
+      if (b >= 0 && b != m->common_body && m->body_path[b] != p) { g_err = "pair touches a body outside its path"; return -1; }
+  }
+  DevModel& M = c->M;
+  M.nb = nb; M.nq = m->nq; M.nv = m->nv; M.npaths = K; M.common_body = m->common_body;
+  M.ngeoms = m->ngeoms; M.npairs = m->npairs; M.maxpp = maxpp;
+  for (int i = 0; i < 3; ++i) M.gravity[i] = m->gravity[i];
+  int* ip; double* dp;
+#define UPI(field, src, n) if (Upload(c, src, n, &ip)) return -2; M.field = ip;
+#define UPD(field, src, n) if (Upload(c, src, n, &dp)) return -2; M.field = dp;
+  UPI(parent, m->parent, nb) UPI(jtype, m->jtype, nb) UPI(qstart, m->qstart, nb) UPI(vstart, m->vstart, nb)
+  UPD(X_PF, m->X_PF, (size_t)12 * nb) UPD(axis, m->axis, (size_t)3 * nb) UPD(mass, m->mass, nb)
+  UPD(com, m->com, (size_t)3 * nb) UPD(inertia, m->inertia, (size_t)6 * nb) UPD(damping, m->damping, m->nv)
+  UPI(geom_type, m->geom_type, m->ngeoms) UPD(geom_X, m->geom_X, (size_t)12 * m->ngeoms)
+  UPD(geom_size, m->geom_size, (size_t)3 * m->ngeoms)
+  UPI(chain, chain.data(), chain.size()) UPI(nchain, nchain.data(), nchain.size())
+  UPI(pkind, pkind.data(), pkind.size()) UPI(path_npairs, path_npairs.data(), path_npairs.size())
+  UPI(path_pairs, path_pairs.data(), path_pairs.size())
+  UPI(pair_ga, m->pair_a, m->npairs) UPI(pair_gb, m->pair_b, m->npairs)
+  UPI(pair_sa, sa.data(), sa.size()) UPI(pair_sb, sb.data(), sb.size())
+#undef UPI
+#undef UPD
+  return 0;
+}
+
+int LaunchFd(idto_hip_ctx* c, int mode, int kb, int ke) {
+  if (ke <= kb) return 0;
+  dim3 grid(ke - kb), block(mode == 1 ? c->fd_threads : 64);
+  const int lds = mode == 1 ? c->fd_lds : c->tau_lds;
+#define FD_LAUNCH(MC)                                                                                         \
+  hipLaunchKernelGGL(fd_kernel<MC>, grid, block, lds, c->stream, c->M, c->cp, c->P, c->q, c->slab,             \
+                     c->slab_stride, c->v, c->a, c->nplus, kb, mode)
+  if (c->maxc <= 2) FD_LAUNCH(2);
+  else if (c->maxc <= 3) FD_LAUNCH(3);
+  else if (c->maxc <= 4) FD_LAUNCH(4);
+  else FD_LAUNCH(8);
+#undef FD_LAUNCH
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int TimeBegin(idto_hip_ctx* c, int which) {
+  if (!c->timing) return 0;
+  idto_hip_ctx::Timed t;
+  t.which = which;
+  HIP_OK(hipEventCreate(&t.a));
+  HIP_OK(hipEventCreate(&t.b));
+  HIP_OK(hipEventRecord(t.a, c->stream));
+  c->pending.push_back(t);
+  return 0;
+}
+int TimeEnd(idto_hip_ctx* c) {
+  if (!c->timing) return 0;
+  HIP_OK(hipEventRecord(c->pending.back().b, c->stream));
+  return 0;
+}
+int TimeDrain(idto_hip_ctx* c) {
+  for (auto& t : c->pending) {
+    HIP_OK(hipEventSynchronize(t.b));
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, t.a, t.b));
+    c->tsum[t.which] += ms;
+    c->tcnt[t.which] += 1;
+    (void)hipEventDestroy(t.a);
+    (void)hipEventDestroy(t.b);
+  }
+  c->pending.clear();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* idto_hip_last_error(void) { return g_err.c_str(); }
+
+int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem, const idto_contact_params_t* contact,
+                    int device, idto_hip_ctx** out) {
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    g_err = "no HIP device available (the product path has no CPU fallback)";
+    return -3;
+  }
+  HIP_OK(hipSetDevice(device));
+  idto_hip_ctx* c = new idto_hip_ctx();
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_err = "hipStreamCreate failed"; delete c; return -2; }
+  c->own_stream = true;
+  c->nb = model->nbodies; c->nq = model->nq; c->nv = model->nv; c->N = problem->num_steps;
+  c->dt = problem->time_step; c->npaths = model->npaths;
+  const int nq = c->nq, nv = c->nv, N = c->N;
+  int rc = BuildModel(c, model);
+  if (rc) { idto_hip_destroy(c); return rc; }
+  c->cp.k = contact->contact_stiffness; c->cp.vd = contact->dissipation_velocity;
+  c->cp.vs = contact->stiction_velocity; c->cp.mu = contact->friction_coefficient;
+  c->cp.sigma = contact->smoothing_factor;
+  {  // reference TO.cc:266-269, evaluated with the same deterministic exp/log as the device code
+    const double eps = std::sqrt(2.220446049250313e-16);
+    c->cp.threshold = -c->cp.sigma * idto::detmath::log(idto::detmath::exp(eps / (c->cp.sigma * c->cp.k)) - 1.0);
+  }
+  rc = UploadProblemArrays(c, problem, true);
+  if (rc) { idto_hip_destroy(c); return rc; }
+  const size_t bsz = (size_t)nv * nq, qq = (size_t)nq * nq;
+  c->slab_stride = (int)(3 * bsz + nv);
+  bool bad = false;
+  bad |= Alloc(c, (size_t)(N + 1) * nq, &c->q) != 0;
+  bad |= Alloc(c, (size_t)(N + 1) * nv, &c->v) != 0;
+  bad |= Alloc(c, (size_t)N * nv, &c->a) != 0;
+  bad |= Alloc(c, (size_t)(N + 1) * bsz, &c->nplus) != 0;
+  bad |= Alloc(c, (size_t)N * c->slab_stride, &c->slab) != 0;
+  bad |= Alloc(c, (size_t)(N + 1) * nq, &c->g) != 0;
+  bad |= Alloc(c, (size_t)(N + 1) * qq, &c->HA) != 0;
+  bad |= Alloc(c, (size_t)(N + 1) * qq, &c->HB) != 0;
+  bad |= Alloc(c, (size_t)(N + 1) * qq, &c->HC) != 0;
+  bad |= Alloc(c, (size_t)(N + 1) * nq, &c->step) != 0;
+  bad |= Alloc(c, (size_t)1, &c->cost) != 0;
+  bad |= Alloc(c, (size_t)(N + 1) * qq, &c->Kst) != 0;
+  bad |= Alloc(c, (size_t)(N + 1) * qq, &c->LUst) != 0;
+  bad |= Alloc(c, (size_t)(N + 1) * qq, &c->Yst) != 0;
+  bad |= Alloc(c, (size_t)(N + 1) * qq, &c->Zst) != 0;
+  bad |= Alloc(c, (size_t)(N + 1) * nq, &c->pivst) != 0;
+  if (bad) { idto_hip_destroy(c); return -2; }
+  c->k_begin = 0; c->k_end = N;
+
+  // launch geometry
+  const int K = c->npaths;
+  const int E = 1 + 2 * nq + nv;
+  int threads = ((E * K + 63) / 64) * 64;
+  if (threads > 256) threads = 256;  // one wave per SIMD: the evaluation keeps its bodies in up to 512 VGPRs
+  c->fd_threads = threads;
+  auto fd_lds = [&](int Ecount) { return (int)sizeof(double) * (3 * nq + 2 * (int)bsz + 3 * nv + Ecount + Ecount * nq + 3 * Ecount * nv + nv); };
+  c->fd_lds = fd_lds(E);
+  c->tau_lds = fd_lds(1);
+  c->asm_lds = (int)sizeof(double) * (3 * nq + 5 * (int)bsz + 4 * nv + nq + std::max(nq, nv) + (int)bsz + 3 * (int)qq + nq);
+  const int n = N + 1;
+  c->penta_lds = (int)sizeof(double) * (10 * (int)qq + nq * (3 * nq + 1) + (n + 2) * nq + nq) + (int)sizeof(int) * nq + 16;
+  c->solve_lds = (int)sizeof(double) * ((n + 2) * nq + nq);
+  c->cost_lds = (int)sizeof(double) * (3 * N + 2);
+  const int max_lds = 160 * 1024;
+  if (c->fd_lds > max_lds || c->asm_lds > max_lds || c->penta_lds > max_lds) {
+    g_err = "problem too large for the 160 KiB LDS carve-up of the v1 kernels";
+    idto_hip_destroy(c);
+    return -1;
+  }
+  // kernels that need more than the default 64 KiB of dynamic LDS must opt in
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fd_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  (void)hipGetLastError();
+  *out = c;
+  return 0;
+}
+
+void idto_hip_destroy(idto_hip_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto& t : c->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+  for (void* p : c->allocs) (void)hipFree(p);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int idto_hip_set_problem(idto_hip_ctx* c, const idto_problem_t* p) {
+  if (p->num_steps != c->N || p->time_step != c->dt) { g_err = "num_steps / time_step cannot change"; return -1; }
+  HIP_OK(hipSetDevice(c->device));
+  return UploadProblemArrays(c, p, false);
+}
+
+int idto_hip_set_stream(idto_hip_ctx* c, void* s) {
+  if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+  c->stream = static_cast<hipStream_t>(s);
+  c->own_stream = false;
+  return 0;
+}
+void* idto_hip_get_stream(idto_hip_ctx* c) { return c->stream; }
+
+int idto_hip_set_shard(idto_hip_ctx* c, int kb, int ke) {
+  if (kb < 0 || ke > c->N || kb > ke) { g_err = "bad shard range"; return -1; }
+  c->k_begin = kb; c->k_end = ke;
+  return 0;
+}
+
+int idto_hip_set_q(idto_hip_ctx* c, const double* q_host) {
+  HIP_OK(hipSetDevice(c->device));
+  HIP_OK(hipMemcpyAsync(c->q, q_host, (size_t)(c->N + 1) * c->nq * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_OK(hipStreamSynchronize(c->stream));  // the host buffer may be reused by the caller
+  return 0;
+}
+int idto_hip_set_q_device(idto_hip_ctx* c, const double* q_dev) {
+  HIP_OK(hipSetDevice(c->device));
+  HIP_OK(hipMemcpyAsync(c->q, q_dev, (size_t)(c->N + 1) * c->nq * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
+int idto_hip_eval_tau(idto_hip_ctx* c) {
+  HIP_OK(hipSetDevice(c->device));
+  int rc = LaunchFd(c, 0, 0, c->N);
+  if (rc) return rc;
+  hipLaunchKernelGGL(cost_kernel, dim3(1), dim3(128), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
+                     c->slab_stride, c->cost);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int idto_hip_eval_partials(idto_hip_ctx* c) {
+  HIP_OK(hipSetDevice(c->device));
+  if (TimeBegin(c, 0)) return -2;
+  int rc = LaunchFd(c, 1, c->k_begin, c->k_end);
+  if (rc) return rc;
+  return TimeEnd(c);
+}
+
+int idto_hip_grad_hess(idto_hip_ctx* c) {
+  HIP_OK(hipSetDevice(c->device));
+  if (TimeBegin(c, 1)) return -2;
+  hipLaunchKernelGGL(assemble_kernel, dim3(c->N + 1), dim3(256), c->asm_lds, c->stream, c->M, c->P, c->q, c->slab,
+                     c->slab_stride, c->g, c->HA, c->HB, c->HC);
+  HIP_OK(hipGetLastError());
+  return TimeEnd(c);
+}
+
+int idto_hip_factor_solve(idto_hip_ctx* c, const double* rhs, int nrhs, double* x) {
+  HIP_OK(hipSetDevice(c->device));
+  const int n = c->N + 1, k = c->nq;
+  const double* b = rhs ? rhs : c->g;
+  double* xo = rhs ? x : c->step;
+  if (rhs && nrhs < 1) { g_err = "nrhs < 1"; return -1; }
+  if (TimeBegin(c, 2)) return -2;
+  hipLaunchKernelGGL(penta_kernel, dim3(1), dim3(256), c->penta_lds, c->stream, n, k, c->HA, c->HB, c->HC, b,
+                     rhs ? 1.0 : -1.0, xo, c->Kst, c->LUst, c->pivst, c->Yst, c->Zst);
+  HIP_OK(hipGetLastError());
+  if (TimeEnd(c)) return -2;
+  if (rhs && nrhs > 1) {
+    hipLaunchKernelGGL(penta_solve_kernel, dim3(nrhs - 1), dim3(64), c->solve_lds, c->stream, n, k, c->HA, c->Kst,
+                       c->LUst, c->pivst, c->Yst, c->Zst, rhs + (size_t)n * k, x + (size_t)n * k);
+    HIP_OK(hipGetLastError());
+  }
+  return 0;
+}
+
+int idto_hip_gn_step(idto_hip_ctx* c) {
+  int rc = idto_hip_eval_partials(c);
+  if (rc) return rc;
+  rc = idto_hip_grad_hess(c);
+  if (rc) return rc;
+  return idto_hip_factor_solve(c, nullptr, 1, nullptr);
+}
+
+int idto_hip_timing_enable(idto_hip_ctx* c, int enable) { c->timing = enable != 0; return 0; }
+int idto_hip_timing_reset(idto_hip_ctx* c) {
+  if (TimeDrain(c)) return -2;
+  for (int i = 0; i < 3; ++i) { c->tsum[i] = 0; c->tcnt[i] = 0; }
+  return 0;
+}
+int idto_hip_timing_get(idto_hip_ctx* c, int which, double* avg_ms, int* launches) {
+  if (which < 0 || which > 2) { g_err = "bad kernel index"; return -1; }
+  if (TimeDrain(c)) return -2;
+  *launches = c->tcnt[which];
+  *avg_ms = c->tcnt[which] ? c->tsum[which] / c->tcnt[which] : 0.0;
+  return 0;
+}
+
+int idto_hip_sync(idto_hip_ctx* c) {
+  HIP_OK(hipSetDevice(c->device));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+long idto_hip_array_size(idto_hip_ctx* c, int what) {
+  const long nq = c->nq, nv = c->nv, N = c->N, bsz = nv * nq, qq = nq * nq;
+  switch (what) {
+    case IDTO_ARR_Q: return (N + 1) * nq;
+    case IDTO_ARR_V: return (N + 1) * nv;
+    case IDTO_ARR_A: case IDTO_ARR_TAU: return N * nv;
+    case IDTO_ARR_NPLUS: return (N + 1) * bsz;
+    case IDTO_ARR_DTAU_DQM: case IDTO_ARR_DTAU_DQT: case IDTO_ARR_DTAU_DQP: return N * bsz;
+    case IDTO_ARR_GRADIENT: case IDTO_ARR_STEP: return (N + 1) * nq;
+    case IDTO_ARR_H_A: case IDTO_ARR_H_B: case IDTO_ARR_H_C: return (N + 1) * qq;
+    case IDTO_ARR_COST: return 1;
+    case IDTO_ARR_SLAB: return N * (long)c->slab_stride;
+    default: return -1;
+  }
+}
+int idto_hip_slab_stride(idto_hip_ctx* c) { return c->slab_stride; }
+
+void* idto_hip_device_ptr(idto_hip_ctx* c, int what) {
+  switch (what) {
+    case IDTO_ARR_Q: return c->q;
+    case IDTO_ARR_V: return c->v;
+    case IDTO_ARR_A: return c->a;
+    case IDTO_ARR_NPLUS: return c->nplus;
+    case IDTO_ARR_GRADIENT: return c->g;
+    case IDTO_ARR_H_A: return c->HA;
+    case IDTO_ARR_H_B: return c->HB;
+    case IDTO_ARR_H_C: return c->HC;
+    case IDTO_ARR_STEP: return c->step;
+    case IDTO_ARR_COST: return c->cost;
+    case IDTO_ARR_SLAB: return c->slab;
+    default: return nullptr;  // tau and the three partials live strided inside the slab
+  }
+}
+
+int idto_hip_get(idto_hip_ctx* c, int what, double* out) {
+  HIP_OK(hipSetDevice(c->device));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  const long count = idto_hip_array_size(c, what);
+  if (count < 0) { g_err = "unknown array id"; return -1; }
+  const size_t bsz = (size_t)c->nv * c->nq;
+  if (what == IDTO_ARR_TAU || (what >= IDTO_ARR_DTAU_DQM && what <= IDTO_ARR_DTAU_DQP)) {
+    const size_t off = what == IDTO_ARR_TAU ? 3 * bsz : (size_t)(what - IDTO_ARR_DTAU_DQM) * bsz;
+    const size_t width = what == IDTO_ARR_TAU ? (size_t)c->nv : bsz;
+    HIP_OK(hipMemcpy2D(out, width * sizeof(double), c->slab + off, (size_t)c->slab_stride * sizeof(double),
+                       width * sizeof(double), c->N, hipMemcpyDeviceToHost));
+    return 0;
+  }
+  void* p = idto_hip_device_ptr(c, what);
+  HIP_OK(hipMemcpy(out, p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int idto_hip_math_probe(int device, const double* x, int n, double* sq, double* rc, double* sn, double* cs, double* ex,
+                        double* lg) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_err = "no HIP device available"; return -3; }
+  HIP_OK(hipSetDevice(device));
+  double* d[7];
+  for (int i = 0; i < 7; ++i) HIP_OK(hipMalloc((void**)&d[i], (size_t)n * sizeof(double)));
+  HIP_OK(hipMemcpy(d[0], x, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(math_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, d[0], n, d[1], d[2], d[3], d[4], d[5], d[6]);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipDeviceSynchronize());
+  double* outs[6] = {sq, rc, sn, cs, ex, lg};
+  for (int i = 0; i < 6; ++i) HIP_OK(hipMemcpy(outs[i], d[i + 1], (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 7; ++i) (void)hipFree(d[i]);
+  return 0;
+}
+
+}  // extern "C"

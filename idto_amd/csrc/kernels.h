@@ -1,0 +1,695 @@
+// kernels.h — the three kernels of one Gauss-Newton iteration on gfx950:
+//   fd_kernel        N+ / v / a / tau and the finite-difference partials  (a1-a9 of SURVEY.md §8a)
+//   assemble_kernel  gradient and Gauss-Newton Hessian bands              (a11, a12)
+//   penta_kernel     block-Thomas factorisation + solve                   (a14, a15)
+// plus small helpers (cost, multi-RHS solve).  fp64 throughout; compiled with
+// -ffp-contract=off; every sum has the association order of DESIGN.md §3.2.
+#pragma once
+
+#include "id_eval.h"
+
+namespace idto_dev {
+
+struct DevProblem {
+  int N;
+  double dt;
+  const double* v_init;  // nv
+  const double* q_nom;   // (N+1) nq
+  const double* v_nom;   // (N+1) nv
+  // weights pre-scaled on the host exactly as reference TO.cc:1103-1107:
+  const double* Qq;   // (2 Qq) dt     nq x nq column-major
+  const double* Qv;   // (2 Qv) dt     nv x nv
+  const double* R;    // (2 R) dt
+  const double* Qfq;  // 2 Qf_q
+  const double* Qfv;  // 2 Qf_v
+  // unscaled weights for the cost (TO.cc:147-176)
+  const double* Qq0; const double* Qv0; const double* R0; const double* Qfq0; const double* Qfv0;
+};
+
+// ---------------------------------------------------------------------------
+// N+(q) for one configuration into LDS (nv x nq column-major); restates
+// oracle Dynamics::Nplus / reference TO.cc:1633-1647.  Called by all threads.
+IDTO_DEV void nplus_block(const DevModel& M, const double* q, double* Nout, int tid, int nthreads) {
+  const int sz = M.nv * M.nq;
+  for (int i = tid; i < sz; i += nthreads) Nout[i] = 0.0;
+  __syncthreads();
+  for (int b = tid; b < M.nb; b += nthreads) {
+    const int qs = M.qstart[b], vs = M.vstart[b], jt = M.jtype[b], nv = M.nv;
+    if (jt == IDTO_JOINT_REVOLUTE || jt == IDTO_JOINT_PRISMATIC) {
+      Nout[qs * nv + vs] = 1.0;
+    } else if (jt == IDTO_JOINT_PLANAR) {
+      for (int k = 0; k < 3; ++k) Nout[(qs + k) * nv + vs + k] = 1.0;
+    } else {
+      const double* qq = q + qs;
+      const double nrm = __builtin_sqrt(((qq[0] * qq[0] + qq[1] * qq[1]) + qq[2] * qq[2]) + qq[3] * qq[3]);
+      const double t0 = qq[0] / nrm, t1 = qq[1] / nrm, t2 = qq[2] / nrm, t3 = qq[3] / nrm;
+      const double t[4] = {t0, t1, t2, t3};
+      const double w2 = 2.0 * t0, x2 = 2.0 * t1, y2 = 2.0 * t2, z2 = 2.0 * t3;
+      const double LT[3][4] = {{-x2, w2, -z2, y2}, {-y2, z2, w2, -x2}, {-z2, -y2, x2, w2}};
+      double D[4][4];
+      for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) D[r][c] = ((r == c ? 1.0 : 0.0) - t[r] * t[c]) / nrm;
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) {
+          double acc = LT[r][0] * D[0][c];
+          for (int k = 1; k < 4; ++k) acc += LT[r][k] * D[k][c];
+          Nout[(qs + c) * nv + vs + r] = acc;
+        }
+      for (int k = 0; k < 3; ++k) Nout[(qs + 4 + k) * nv + vs + 3 + k] = 1.0;
+    }
+  }
+  __syncthreads();
+}
+
+// v = N (qa - qb) / dt  (TO.cc:187-190); threads r < nv
+IDTO_DEV void velocity_block(const DevModel& M, const double* N, const double* qa, const double* qb, double dt,
+                             double* vout, int tid, int nthreads) {
+  for (int r = tid; r < M.nv; r += nthreads) {
+    double acc = N[r] * (qa[0] - qb[0]);
+    for (int c = 1; c < M.nq; ++c) acc += N[c * M.nv + r] * (qa[c] - qb[c]);
+    vout[r] = acc / dt;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// fd_kernel: block <-> tau index k.  Produces slab_k = [dtau_k/dq_{k-1} |
+// dtau_k/dq_k | dtau_k/dq_{k+1} | tau_k] plus v_{k+1}, a_k, N+_{k+1}.
+// mode 0: tau only (one evaluation); mode 1: forward differences (TO.cc:426-563).
+// Dynamic LDS layout (doubles): see the carve-up below.
+template <int MAXC>
+__global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevProblem P, const double* __restrict__ q,
+                          double* __restrict__ slab, int slab_stride, double* __restrict__ v_out,
+                          double* __restrict__ a_out, double* __restrict__ nplus_out, int k_begin, int mode) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int k = k_begin + blockIdx.x;
+  const int nq = M.nq, nv = M.nv, K = M.npaths;
+  const int bsz = nv * nq;
+  const double dt = P.dt;
+
+  const int nP = (mode == 1) ? nq : 0;
+  const int nT = (mode == 1) ? nq : 0;
+  const int nM = (mode == 1) ? nv : 0;
+  const int E = 1 + nP + nT + nM;
+
+  double* qm1 = lds;            // q_{k-1}
+  double* q0 = qm1 + nq;        // q_k
+  double* q1 = q0 + nq;         // q_{k+1}
+  double* N0 = q1 + nq;         // N+_k
+  double* N1 = N0 + bsz;        // N+_{k+1}
+  double* v0 = N1 + bsz;        // v_k
+  double* v1 = v0 + nv;         // v_{k+1}
+  double* a0 = v1 + nv;         // a_k
+  double* edq = a0 + nv;        // [E]
+  double* eq = edq + E;         // [E][nq]
+  double* ev = eq + E * nq;     // [E][nv]
+  double* ea = ev + E * nv;     // [E][nv]
+  double* etau = ea + E * nv;   // [E][nv]
+  double* edump = etau + E * nv; // [nv] write-only dump row for surplus lanes
+
+  for (int i = tid; i < nq; i += nt) {
+    qm1[i] = (k > 0) ? q[(k - 1) * nq + i] : 0.0;
+    q0[i] = q[k * nq + i];
+    q1[i] = q[(k + 1) * nq + i];
+  }
+  __syncthreads();
+  nplus_block(M, q0, N0, tid, nt);
+  nplus_block(M, q1, N1, tid, nt);
+  if (k > 0) velocity_block(M, N0, q0, qm1, dt, v0, tid, nt);
+  else
+    for (int r = tid; r < nv; r += nt) v0[r] = P.v_init[r];
+  velocity_block(M, N1, q1, q0, dt, v1, tid, nt);
+  __syncthreads();
+  for (int r = tid; r < nv; r += nt) a0[r] = (v1[r] - v0[r]) / dt;
+  __syncthreads();
+
+  // trajectory outputs
+  for (int r = tid; r < nv; r += nt) {
+    v_out[(k + 1) * nv + r] = v1[r];
+    a_out[k * nv + r] = a0[r];
+    if (k == 0) v_out[r] = v0[r];
+  }
+  for (int i = tid; i < bsz; i += nt) {
+    nplus_out[(size_t)(k + 1) * bsz + i] = N1[i];
+    if (k == 0) nplus_out[i] = N0[i];
+  }
+
+  // ---- evaluation inputs (TO.cc:501-521)
+  const double eps = 1.4901161193847656e-08;  // sqrt(DBL_EPSILON) = 2^-26
+  for (int e = tid; e < E; e += nt) {
+    double dq = 1.0;
+    if (e >= 1 && e < 1 + nP + nT) {
+      const int i = (e - 1) % nq;
+      const double qi = (e < 1 + nP) ? q1[i] : q0[i];
+      dq = eps * __builtin_fmax(1.0, __builtin_fabs(qi));
+      const double temp = qi + dq;
+      dq = temp - qi;
+    }
+    edq[e] = dq;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < E * nq; idx += nt) {
+    const int e = idx / nq, c = idx - e * nq;
+    double val = q1[c];
+    if (e >= 1 && e < 1 + nP && c == e - 1) val = q1[c] + edq[e];
+    eq[idx] = val;
+  }
+  for (int idx = tid; idx < E * nv; idx += nt) {
+    const int e = idx / nv, j = idx - e * nv;
+    double vv = v1[j], aa = a0[j];
+    if (e >= 1 && e < 1 + nP) {
+      const int i = e - 1;
+      const double dv = edq[e] / dt, da = dv / dt;
+      const double n1 = N1[i * nv + j];
+      vv = v1[j] + dv * n1;
+      aa = a0[j] + da * n1;
+    } else if (e >= 1 + nP && e < 1 + nP + nT) {
+      const int i = e - 1 - nP;
+      const double dv = edq[e] / dt, da = dv / dt;
+      const double n1 = N1[i * nv + j], n0 = N0[i * nv + j];
+      vv = v1[j] - dv * n1;
+      aa = a0[j] - da * (n1 + n0);
+    } else if (e >= 1 + nP + nT) {
+      vv = 0.0;
+      aa = (j == e - 1 - nP - nT) ? 1.0 : 0.0;
+    }
+    ev[idx] = vv;
+    ea[idx] = aa;
+  }
+  __syncthreads();
+
+  // ---- the evaluations: lane = (evaluation, path)
+  // Surplus groups (e >= E) re-run evaluation 0 into a dump row so that every lane
+  // of a wavefront takes part in the butterfly sums inside id_eval.
+  const int groups = nt / K;
+  for (int e0 = 0; e0 < E; e0 += groups) {
+    const int e = e0 + tid / K;
+    const int path = tid % K;
+    const int ee = (e < E) ? e : 0;
+    const bool full = ee < 1 + nP + nT;
+    double* tau_dst = (e < E) ? etau + ee * nv : edump;
+    id_eval<MAXC>(M, cp, path, full, eq + ee * nq, ev + ee * nv, ea + ee * nv, tau_dst);
+  }
+  __syncthreads();
+
+  // ---- outputs
+  double* sl = slab + (size_t)k * slab_stride;
+  double* Mk = sl;
+  double* Tk = sl + bsz;
+  double* Pk = sl + 2 * bsz;
+  double* tauk = sl + 3 * bsz;
+  for (int r = tid; r < nv; r += nt) tauk[r] = etau[r];
+  if (mode == 1) {
+    for (int idx = tid; idx < bsz; idx += nt) {
+      const int i = idx / nv, r = idx - i * nv;
+      Pk[idx] = (etau[(1 + i) * nv + r] - etau[r]) / edq[1 + i];                      // TO.cc:531
+      Tk[idx] = (k >= 1) ? (etau[(1 + nP + i) * nv + r] - etau[r]) / edq[1 + nP + i]  // TO.cc:539
+                         : 0.0;
+    }
+    // dtau_k/dq_{k-1} = (1/dt^2) M(q_{k+1}) N+_k   (TO.cc:556-561)
+    if (k >= 2) {
+      const double sc = 1 / dt / dt;
+      const double* Mcols = etau + (1 + nP + nT) * nv;  // column j = tau of mass evaluation j
+      for (int idx = tid; idx < bsz; idx += nt) {
+        const int c = idx / nv, r = idx - c * nv;
+        double acc = (sc * Mcols[r]) * N0[c * nv];
+        for (int j = 1; j < nv; ++j) acc += (sc * Mcols[j * nv + r]) * N0[c * nv + j];
+        Mk[idx] = acc;
+      }
+    } else {
+      const double fill = (k == 0) ? __builtin_nan("") : 0.0;
+      for (int idx = tid; idx < bsz; idx += nt) Mk[idx] = fill;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Cost L(q) from resident q, v, tau (TO.cc:147-176).  One block; the final sum
+// is accumulated serially in the reference's order.
+__global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__ q, const double* __restrict__ v,
+                            const double* __restrict__ slab, int slab_stride, double* __restrict__ cost_out) {
+  extern __shared__ double lds[];
+  const int N = P.N, nq = M.nq, nv = M.nv, tid = threadIdx.x, nt = blockDim.x;
+  double* terms = lds;  // [N][3] + [2]
+  auto quad = [](const double* e, const double* enom, const double* W, int n) {
+    double tot = 0;
+    for (int c = 0; c < n; ++c) {
+      double acc = 0;
+      for (int r = 0; r < n; ++r) acc += (e[r] - (enom ? enom[r] : 0.0)) * W[c * n + r];
+      tot += acc * (e[c] - (enom ? enom[c] : 0.0));
+    }
+    return tot;
+  };
+  for (int idx = tid; idx < 3 * N + 2; idx += nt) {
+    double val;
+    if (idx < 3 * N) {
+      const int t = idx / 3, w = idx - 3 * t;
+      if (w == 0) val = quad(q + t * nq, P.q_nom + t * nq, P.Qq0, nq);
+      else if (w == 1) val = quad(v + t * nv, P.v_nom + t * nv, P.Qv0, nv);
+      else val = quad(slab + (size_t)t * slab_stride + 3 * nv * nq, nullptr, P.R0, nv);
+    } else if (idx == 3 * N) {
+      val = quad(q + N * nq, P.q_nom + N * nq, P.Qfq0, nq);
+    } else {
+      val = quad(v + N * nv, P.v_nom + N * nv, P.Qfv0, nv);
+    }
+    terms[idx] = val;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double cost = 0;
+    for (int i = 0; i < 3 * N; ++i) cost += terms[i];
+    cost *= P.dt;
+    cost += terms[3 * N];
+    cost += terms[3 * N + 1];
+    *cost_out = cost;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// assemble_kernel: block <-> block row i of the Hessian (and g_i).
+// Restates TO.cc:1021-1081 and :1093-1165 row by row (see DESIGN.md §4.2 for
+// the re-indexing from the reference's column-wise loop).
+IDTO_DEV void acc_atwb(const double* A, const double* W, const double* B, double* AtW, double* out, bool init,
+                       bool lower_only, int nq, int nv, int tid, int nt) {
+  // AtW = A^T W  (nq x nv), then out (+)= AtW B
+  for (int idx = tid; idx < nq * nv; idx += nt) {
+    const int c = idx / nq, r = idx - c * nq;
+    double acc = A[r * nv] * W[c * nv];
+    for (int l = 1; l < nv; ++l) acc += A[r * nv + l] * W[c * nv + l];
+    AtW[c * nq + r] = acc;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < nq * nq; idx += nt) {
+    const int c = idx / nq, r = idx - c * nq;
+    if (lower_only && r < c) continue;
+    double acc = AtW[r] * B[c * nv];
+    for (int l = 1; l < nv; ++l) acc += AtW[l * nq + r] * B[c * nv + l];
+    out[c * nq + r] = init ? acc : out[c * nq + r] + acc;
+  }
+  __syncthreads();
+}
+
+IDTO_DEV void acc_vec_w_mat(const double* e, const double* W, const double* J, double* tmp, double* out, bool init,
+                            int nq, int n, int tid, int nt) {
+  for (int r = tid; r < n; r += nt) {
+    double acc = e[0] * W[r * n];
+    for (int i = 1; i < n; ++i) acc += e[i] * W[r * n + i];
+    tmp[r] = acc;
+  }
+  __syncthreads();
+  for (int j = tid; j < nq; j += nt) {
+    double acc = tmp[0] * J[j * n];
+    for (int r = 1; r < n; ++r) acc += tmp[r] * J[j * n + r];
+    out[j] = init ? acc : out[j] + acc;
+  }
+  __syncthreads();
+}
+
+__global__ void assemble_kernel(DevModel M, DevProblem P, const double* __restrict__ q,
+                                const double* __restrict__ slab, int slab_stride, double* __restrict__ g,
+                                double* __restrict__ HA, double* __restrict__ HB, double* __restrict__ HC) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int i = blockIdx.x, N = P.N, nq = M.nq, nv = M.nv;
+  const int bsz = nv * nq, qq = nq * nq;
+  const double dt = P.dt;
+
+  double* qm1 = lds;
+  double* q0 = qm1 + nq;
+  double* q1 = q0 + nq;
+  double* N0 = q1 + nq;       // N+_i
+  double* N1 = N0 + bsz;      // N+_{i+1}
+  double* Vi = N1 + bsz;      // dv_i/dq_i
+  double* Wi = Vi + bsz;      // dv_i/dq_{i-1}
+  double* Wi1 = Wi + bsz;     // dv_{i+1}/dq_i
+  double* v0 = Wi1 + bsz;     // v_i
+  double* v1 = v0 + nv;       // v_{i+1}
+  double* ve = v1 + nv;       // v_i - vnom_i
+  double* vep = ve + nv;      // v_{i+1} - vnom_{i+1}
+  double* qe = vep + nv;      // q_i - qnom_i
+  double* tmp = qe + nq;      // [max(nq,nv)]
+  double* AtW = tmp + (nq > nv ? nq : nv);  // nq x nv
+  double* Cb = AtW + bsz;     // nq x nq
+  double* Bb = Cb + qq;
+  double* Ab = Bb + qq;
+  double* gb = Ab + qq;       // nq
+
+  double* Cg = HC + (size_t)i * qq;
+  double* Bg = HB + (size_t)i * qq;
+  double* Ag = HA + (size_t)i * qq;
+
+  if (i == 0) {  // q_0 is fixed: C_0 = I, g_0 = 0 (TO.cc:1124, 1044)
+    for (int idx = tid; idx < qq; idx += nt) {
+      Cg[idx] = (idx / nq == idx % nq) ? 1.0 : 0.0;
+      Bg[idx] = 0.0;
+      Ag[idx] = 0.0;
+    }
+    for (int j = tid; j < nq; j += nt) g[j] = 0.0;
+    return;
+  }
+
+  for (int c = tid; c < nq; c += nt) {
+    qm1[c] = q[(i - 1) * nq + c];
+    q0[c] = q[i * nq + c];
+    q1[c] = (i < N) ? q[(i + 1) * nq + c] : 0.0;
+  }
+  __syncthreads();
+  nplus_block(M, q0, N0, tid, nt);
+  velocity_block(M, N0, q0, qm1, dt, v0, tid, nt);
+  if (i < N) {
+    nplus_block(M, q1, N1, tid, nt);
+    velocity_block(M, N1, q1, q0, dt, v1, tid, nt);
+  }
+  __syncthreads();
+  const double idt = 1 / dt, midt = -1 / dt;
+  for (int idx = tid; idx < bsz; idx += nt) {
+    Vi[idx] = idt * N0[idx];
+    Wi[idx] = midt * N0[idx];
+    Wi1[idx] = (i < N) ? midt * N1[idx] : 0.0;
+  }
+  for (int r = tid; r < nv; r += nt) {
+    ve[r] = v0[r] - P.v_nom[i * nv + r];
+    vep[r] = (i < N) ? v1[r] - P.v_nom[(i + 1) * nv + r] : 0.0;
+  }
+  for (int c = tid; c < nq; c += nt) qe[c] = q0[c] - P.q_nom[i * nq + c];
+  __syncthreads();
+
+  auto Mk = [&](int k) { return slab + (size_t)k * slab_stride; };
+  auto Tk = [&](int k) { return slab + (size_t)k * slab_stride + bsz; };
+  auto Pk = [&](int k) { return slab + (size_t)k * slab_stride + 2 * bsz; };
+  auto tauk = [&](int k) { return slab + (size_t)k * slab_stride + 3 * bsz; };
+
+  // ---- diagonal block C_i (lower triangle computed, mirrored on store)
+  if (i < N) {
+    for (int idx = tid; idx < qq; idx += nt) Cb[idx] = P.Qq[idx];                       // :1128
+    __syncthreads();
+    acc_atwb(Vi, P.Qv, Vi, AtW, Cb, false, true, nq, nv, tid, nt);                      // :1129
+    acc_atwb(Pk(i - 1), P.R, Pk(i - 1), AtW, Cb, false, true, nq, nv, tid, nt);         // :1130
+    acc_atwb(Tk(i), P.R, Tk(i), AtW, Cb, false, true, nq, nv, tid, nt);                 // :1131
+    if (i < N - 1) {
+      acc_atwb(Mk(i + 1), P.R, Mk(i + 1), AtW, Cb, false, true, nq, nv, tid, nt);       // :1133
+      acc_atwb(Wi1, P.Qv, Wi1, AtW, Cb, false, true, nq, nv, tid, nt);                  // :1134
+    } else {
+      acc_atwb(Wi1, P.Qfv, Wi1, AtW, Cb, false, true, nq, nv, tid, nt);                 // :1136
+    }
+  } else {
+    for (int idx = tid; idx < qq; idx += nt) Cb[idx] = P.Qfq[idx];                      // :1158
+    __syncthreads();
+    acc_atwb(Vi, P.Qfv, Vi, AtW, Cb, false, true, nq, nv, tid, nt);                     // :1159
+    acc_atwb(Pk(N - 1), P.R, Pk(N - 1), AtW, Cb, false, true, nq, nv, tid, nt);         // :1160-1161
+  }
+  // ---- B_i = d g_i / d q_{i-1}   (reference index t = i-1, TO.cc:1140-1147)
+  if (i >= 2) {
+    acc_atwb(Pk(i - 1), P.R, Tk(i - 1), AtW, Bb, true, false, nq, nv, tid, nt);         // :1141
+    if (i < N) {
+      acc_atwb(Tk(i), P.R, Mk(i), AtW, Bb, false, false, nq, nv, tid, nt);              // :1143
+      acc_atwb(Vi, P.Qv, Wi, AtW, Bb, false, false, nq, nv, tid, nt);                   // :1144
+    } else {
+      acc_atwb(Vi, P.Qfv, Wi, AtW, Bb, false, false, nq, nv, tid, nt);                  // :1146
+    }
+  } else {
+    for (int idx = tid; idx < qq; idx += nt) Bb[idx] = 0.0;
+  }
+  // ---- A_i = d g_i / d q_{i-2}   (reference index t = i-2, TO.cc:1150-1153)
+  if (i >= 3) {
+    acc_atwb(Pk(i - 1), P.R, Mk(i - 1), AtW, Ab, true, false, nq, nv, tid, nt);         // :1152
+  } else {
+    for (int idx = tid; idx < qq; idx += nt) Ab[idx] = 0.0;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < qq; idx += nt) {
+    const int c = idx / nq, r = idx - c * nq;
+    Cg[idx] = (r >= c) ? Cb[idx] : Cb[r * nq + c];  // MakeSymmetric: upper <- lower^T (penta_diagonal_matrix.cc:71-76)
+    Bg[idx] = Bb[idx];
+    Ag[idx] = Ab[idx];
+  }
+
+  // ---- gradient block g_i (TO.cc:1046-1080)
+  if (i < N) {
+    for (int j = tid; j < nq; j += nt) {                                                // :1050
+      double acc = qe[0] * P.Qq[j * nq];
+      for (int c = 1; c < nq; ++c) acc += qe[c] * P.Qq[j * nq + c];
+      gb[j] = acc;
+    }
+    __syncthreads();
+    acc_vec_w_mat(ve, P.Qv, Vi, tmp, gb, false, nq, nv, tid, nt);                                   // :1053
+    acc_vec_w_mat(vep, (i == N - 1) ? P.Qfv : P.Qv, Wi1, tmp, gb, false, nq, nv, tid, nt);          // :1054-1061
+    acc_vec_w_mat(tauk(i - 1), P.R, Pk(i - 1), tmp, gb, false, nq, nv, tid, nt);                    // :1064
+    acc_vec_w_mat(tauk(i), P.R, Tk(i), tmp, gb, false, nq, nv, tid, nt);                            // :1065
+    if (i != N - 1) acc_vec_w_mat(tauk(i + 1), P.R, Mk(i + 1), tmp, gb, false, nq, nv, tid, nt);    // :1068
+  } else {
+    acc_vec_w_mat(tauk(N - 1), P.R, Pk(N - 1), tmp, gb, true, nq, nv, tid, nt);                     // :1075-1076
+    for (int j = tid; j < nq; j += nt) {                                                            // :1077-1078
+      double acc = qe[0] * P.Qfq[j * nq];
+      for (int c = 1; c < nq; ++c) acc += qe[c] * P.Qfq[j * nq + c];
+      gb[j] = gb[j] + acc;
+    }
+    __syncthreads();
+    acc_vec_w_mat(ve, P.Qfv, Vi, tmp, gb, false, nq, nv, tid, nt);                                  // :1079-1080
+  }
+  for (int j = tid; j < nq; j += nt) g[(size_t)i * nq + j] = gb[j];
+}
+
+// ---------------------------------------------------------------------------
+// penta_kernel (v1): block-Thomas factorisation of the symmetric block
+// penta-diagonal H (lower bands A, B, C in HBM) fused with the solve of one
+// right-hand side.  Restates penta_diagonal_solver.h:124-248 with the per-block
+// LU (partial pivoting, first maximum) of oracle/penta.h.  One workgroup; the
+// factors (K, LU(G), pivots, Y, Z) are also stored for later multi-RHS solves.
+//   rhs_sign: +1 rhs = b ; -1 rhs = -b (the Gauss-Newton step solves H p = -g).
+IDTO_DEV void blk_sub_mul(const double* X, const double* L, const double* R, double* out, int k, int tid, int nt) {
+  for (int idx = tid; idx < k * k; idx += nt) {
+    const int c = idx / k, r = idx - c * k;
+    double acc = L[r] * R[c * k];
+    for (int j = 1; j < k; ++j) acc += L[j * k + r] * R[c * k + j];
+    out[idx] = X[idx] - acc;
+  }
+}
+
+__global__ void penta_kernel(int n, int k, const double* __restrict__ HA, const double* __restrict__ HB,
+                             const double* __restrict__ HC, const double* __restrict__ b, double rhs_sign,
+                             double* __restrict__ x, double* __restrict__ Kst, double* __restrict__ LUst,
+                             int* __restrict__ pivst, double* __restrict__ Yst, double* __restrict__ Zst) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int kk = k * k;
+  const int ncols = 3 * k + 1;
+  double* Ai = lds;
+  double* Bi = Ai + kk;
+  double* Ci = Bi + kk;
+  double* Di = Ci + kk;
+  double* Ki = Di + kk;
+  double* Tm = Ki + kk;
+  double* Ym2 = Tm + kk;
+  double* Ym1 = Ym2 + kk;
+  double* Zm2 = Ym1 + kk;
+  double* Zm1 = Zm2 + kk;
+  double* W = Zm1 + kk;              // k x ncols, column-major: [G | Y | Z | r]
+  double* rv = W + k * ncols;        // (n+2) k : r_{i-2} storage with the +2 offset of the reference
+  double* tvec = rv + (n + 2) * k;   // k
+  int* ipiv = (int*)(tvec + k);      // k ints
+
+  for (int idx = tid; idx < kk; idx += nt) { Ym2[idx] = 0; Ym1[idx] = 0; Zm2[idx] = 0; Zm1[idx] = 0; }
+  for (int idx = tid; idx < (n + 2) * k; idx += nt)
+    rv[idx] = (idx < 2 * k) ? 0.0 : rhs_sign * b[idx - 2 * k];
+  __syncthreads();
+
+  for (int i = 0; i < n; ++i) {
+    double* G = W;
+    double* Yw = W + kk;
+    double* Zw = W + 2 * kk;
+    double* rw = W + 3 * kk;
+    for (int idx = tid; idx < kk; idx += nt) {
+      const int c = idx / k, r = idx - c * k;
+      Ai[idx] = HA[(size_t)i * kk + idx];
+      Bi[idx] = HB[(size_t)i * kk + idx];
+      Ci[idx] = HC[(size_t)i * kk + idx];
+      Di[idx] = (i < n - 1) ? HB[(size_t)(i + 1) * kk + r * k + c] : 0.0;  // D_i = B_{i+1}^T
+      Zw[idx] = (i < n - 2) ? HA[(size_t)(i + 2) * kk + r * k + c] : 0.0;  // E_i = A_{i+2}^T
+    }
+    __syncthreads();
+    blk_sub_mul(Bi, Ai, Ym2, Ki, k, tid, nt);   // K = B - A Y_{i-2}
+    blk_sub_mul(Ci, Ai, Zm2, Tm, k, tid, nt);   // G' = C - A Z_{i-2}
+    for (int r = tid; r < k; r += nt) {         // r_i -= A r_{i-2}
+      const double* rim2 = rv + i * k;
+      double acc = Ai[r] * rim2[0];
+      for (int c = 1; c < k; ++c) acc += Ai[c * k + r] * rim2[c];
+      tvec[r] = rv[(i + 2) * k + r] - acc;
+    }
+    __syncthreads();
+    blk_sub_mul(Tm, Ki, Ym1, G, k, tid, nt);    // G = G' - K Y_{i-1}
+    blk_sub_mul(Di, Ki, Zm1, Yw, k, tid, nt);   // Y' = D - K Z_{i-1}
+    for (int r = tid; r < k; r += nt) {         // r_i -= K r_{i-1}
+      const double* rim1 = rv + (i + 1) * k;
+      double acc = Ki[r] * rim1[0];
+      for (int c = 1; c < k; ++c) acc += Ki[c * k + r] * rim1[c];
+      rw[r] = tvec[r] - acc;
+    }
+    __syncthreads();
+    // LU with partial pivoting of G, elimination applied to [Y' | E | r] as well
+    for (int j = 0; j < k; ++j) {
+      int p = j;
+      double best = __builtin_fabs(G[j * k + j]);
+      for (int r = j + 1; r < k; ++r) {
+        const double a = __builtin_fabs(G[j * k + r]);
+        if (a > best) { best = a; p = r; }
+      }
+      if (tid == 0) ipiv[j] = p;
+      __syncthreads();
+      if (p != j)
+        for (int c = tid; c < ncols; c += nt) {
+          const double t = W[c * k + j];
+          W[c * k + j] = W[c * k + p];
+          W[c * k + p] = t;
+        }
+      __syncthreads();
+      const double d = G[j * k + j];
+      for (int r = j + 1 + tid; r < k; r += nt) G[j * k + r] = G[j * k + r] / d;
+      __syncthreads();
+      const int nr = k - j - 1, nc = ncols - j - 1;
+      for (int idx = tid; idx < nr * nc; idx += nt) {
+        const int cc = idx / nr, rr = idx - cc * nr;
+        const int c = j + 1 + cc, r = j + 1 + rr;
+        W[c * k + r] = W[c * k + r] - G[j * k + r] * W[c * k + j];
+      }
+      __syncthreads();
+    }
+    // back substitution, one thread per right-hand-side column
+    for (int c = k + tid; c < ncols; c += nt) {
+      double* xc = W + c * k;
+      for (int j = k - 1; j >= 0; --j) {
+        xc[j] = xc[j] / G[j * k + j];
+        const double xj = xc[j];
+        for (int r = 0; r < j; ++r) xc[r] = xc[r] - G[j * k + r] * xj;
+      }
+    }
+    __syncthreads();
+    // store the factors, rotate Y/Z
+    for (int idx = tid; idx < kk; idx += nt) {
+      Kst[(size_t)i * kk + idx] = Ki[idx];
+      LUst[(size_t)i * kk + idx] = G[idx];
+      Yst[(size_t)i * kk + idx] = Yw[idx];
+      Zst[(size_t)i * kk + idx] = Zw[idx];
+      Ym2[idx] = Ym1[idx];
+      Zm2[idx] = Zm1[idx];
+    }
+    for (int r = tid; r < k; r += nt) {
+      rv[(i + 2) * k + r] = rw[r];
+      pivst[i * k + r] = ipiv[r];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < kk; idx += nt) { Ym1[idx] = Yw[idx]; Zm1[idx] = Zw[idx]; }
+    __syncthreads();
+  }
+
+  // backward substitution (penta_diagonal_solver.h:228-247): x lives in rv (+2 offset)
+  for (int i = n - 2; i >= 0; --i) {
+    const double* Yi = Yst + (size_t)i * kk;
+    const double* Zi = Zst + (size_t)i * kk;
+    const double* xp1 = rv + (i + 3) * k;
+    const double* xp2 = rv + (i + 4) * k;
+    for (int r = tid; r < k; r += nt) {
+      double acc = Yi[r] * xp1[0];
+      for (int c = 1; c < k; ++c) acc += Yi[c * k + r] * xp1[c];
+      double val = rv[(i + 2) * k + r] - acc;
+      if (i <= n - 3) {
+        double acc2 = Zi[r] * xp2[0];
+        for (int c = 1; c < k; ++c) acc2 += Zi[c * k + r] * xp2[c];
+        val = val - acc2;
+      }
+      tvec[r] = val;
+    }
+    __syncthreads();
+    for (int r = tid; r < k; r += nt) rv[(i + 2) * k + r] = tvec[r];
+    __syncthreads();
+  }
+  for (int idx = tid; idx < n * k; idx += nt) x[idx] = rv[2 * k + idx];
+}
+
+// Multi-RHS solve with the stored factors: block <-> right-hand side.
+__global__ void penta_solve_kernel(int n, int k, const double* __restrict__ HA, const double* __restrict__ Kst,
+                                   const double* __restrict__ LUst, const int* __restrict__ pivst,
+                                   const double* __restrict__ Yst, const double* __restrict__ Zst,
+                                   const double* __restrict__ b, double* __restrict__ x) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int kk = k * k;
+  double* rv = lds;                 // (n+2) k
+  double* tvec = rv + (n + 2) * k;  // k
+  const double* bb = b + (size_t)blockIdx.x * n * k;
+  double* xx = x + (size_t)blockIdx.x * n * k;
+  for (int idx = tid; idx < (n + 2) * k; idx += nt) rv[idx] = (idx < 2 * k) ? 0.0 : bb[idx - 2 * k];
+  __syncthreads();
+  for (int i = 0; i < n; ++i) {
+    const double* Ai = HA + (size_t)i * kk;
+    const double* Ki = Kst + (size_t)i * kk;
+    const double* LU = LUst + (size_t)i * kk;
+    const int* piv = pivst + i * k;
+    for (int r = tid; r < k; r += nt) {
+      const double* rim2 = rv + i * k;
+      const double* rim1 = rv + (i + 1) * k;
+      double acc = Ai[r] * rim2[0];
+      for (int c = 1; c < k; ++c) acc += Ai[c * k + r] * rim2[c];
+      double val = rv[(i + 2) * k + r] - acc;
+      double acc2 = Ki[r] * rim1[0];
+      for (int c = 1; c < k; ++c) acc2 += Ki[c * k + r] * rim1[c];
+      tvec[r] = val - acc2;
+    }
+    __syncthreads();
+    if (tid == 0) {  // G^{-1} via the stored LU: swaps, unit-lower solve, upper solve
+      for (int j = 0; j < k; ++j)
+        if (piv[j] != j) { const double t = tvec[j]; tvec[j] = tvec[piv[j]]; tvec[piv[j]] = t; }
+      for (int j = 0; j < k; ++j) {
+        const double xj = tvec[j];
+        for (int r = j + 1; r < k; ++r) tvec[r] = tvec[r] - LU[j * k + r] * xj;
+      }
+      for (int j = k - 1; j >= 0; --j) {
+        tvec[j] = tvec[j] / LU[j * k + j];
+        const double xj = tvec[j];
+        for (int r = 0; r < j; ++r) tvec[r] = tvec[r] - LU[j * k + r] * xj;
+      }
+    }
+    __syncthreads();
+    for (int r = tid; r < k; r += nt) rv[(i + 2) * k + r] = tvec[r];
+    __syncthreads();
+  }
+  for (int i = n - 2; i >= 0; --i) {
+    const double* Yi = Yst + (size_t)i * kk;
+    const double* Zi = Zst + (size_t)i * kk;
+    const double* xp1 = rv + (i + 3) * k;
+    const double* xp2 = rv + (i + 4) * k;
+    for (int r = tid; r < k; r += nt) {
+      double acc = Yi[r] * xp1[0];
+      for (int c = 1; c < k; ++c) acc += Yi[c * k + r] * xp1[c];
+      double val = rv[(i + 2) * k + r] - acc;
+      if (i <= n - 3) {
+        double acc2 = Zi[r] * xp2[0];
+        for (int c = 1; c < k; ++c) acc2 += Zi[c * k + r] * xp2[c];
+        val = val - acc2;
+      }
+      tvec[r] = val;
+    }
+    __syncthreads();
+    for (int r = tid; r < k; r += nt) rv[(i + 2) * k + r] = tvec[r];
+    __syncthreads();
+  }
+  for (int idx = tid; idx < n * k; idx += nt) xx[idx] = rv[2 * k + idx];
+}
+
+// probe of device arithmetic (tests/test_gpu_math.py)
+__global__ void math_probe_kernel(const double* x, int n, double* sq, double* rc, double* sn, double* cs, double* ex,
+                                  double* lg) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double v = x[i];
+  sq[i] = __builtin_sqrt(__builtin_fabs(v));
+  rc[i] = 1.0 / v;
+  double s, c;
+  idto::detmath::sincos(v, &s, &c);
+  sn[i] = s;
+  cs[i] = c;
+  ex[i] = idto::detmath::exp(v);
+  lg[i] = idto::detmath::log(__builtin_fabs(v));
+}
+
+}  // namespace idto_dev

@@ -1,0 +1,198 @@
+"""ctypes binding of libidto_hip.so (include/idto_hip.h): the MI355X implementation
+of IDTO's per-iteration gradient/Hessian path.
+
+There is no CPU fallback: loading fails loudly if the library has not been built
+(`./build.sh` or `__graft_entry__.build()`), and creating a context fails if no
+HIP device is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .model import CContactParams, CModel, CProblem, Model, dptr
+from .problem import ProblemDefinition, SolverParameters
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libidto_hip.so")
+
+ARR = dict(q=0, v=1, a=2, tau=3, nplus=4, dtau_dqm=5, dtau_dqt=6, dtau_dqp=7, gradient=8, H_A=9, H_B=10, H_C=11,
+           step=12, cost=13, slab=14)
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: build the HIP extension first (./build.sh). "
+                "idto_amd has no CPU fallback for the hot path.")
+        L = C.CDLL(LIB_PATH)
+        L.idto_hip_last_error.restype = C.c_char_p
+        L.idto_hip_create.argtypes = [C.POINTER(CModel), C.POINTER(CProblem), C.POINTER(CContactParams), C.c_int,
+                                      C.POINTER(C.c_void_p)]
+        L.idto_hip_destroy.argtypes = [C.c_void_p]
+        L.idto_hip_set_problem.argtypes = [C.c_void_p, C.POINTER(CProblem)]
+        L.idto_hip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.idto_hip_get_stream.argtypes = [C.c_void_p]
+        L.idto_hip_get_stream.restype = C.c_void_p
+        L.idto_hip_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.idto_hip_set_q.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.idto_hip_set_q_device.argtypes = [C.c_void_p, C.c_void_p]
+        for f in ("eval_tau", "eval_partials", "grad_hess", "gn_step", "sync", "timing_reset"):
+            getattr(L, "idto_hip_" + f).argtypes = [C.c_void_p]
+        L.idto_hip_factor_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.idto_hip_timing_enable.argtypes = [C.c_void_p, C.c_int]
+        L.idto_hip_timing_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.idto_hip_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        L.idto_hip_device_ptr.argtypes = [C.c_void_p, C.c_int]
+        L.idto_hip_device_ptr.restype = C.c_void_p
+        L.idto_hip_array_size.argtypes = [C.c_void_p, C.c_int]
+        L.idto_hip_array_size.restype = C.c_long
+        L.idto_hip_slab_stride.argtypes = [C.c_void_p]
+        L.idto_hip_math_probe.argtypes = [C.c_int, C.POINTER(C.c_double), C.c_int] + [C.POINTER(C.c_double)] * 6
+        _lib = L
+    return _lib
+
+
+EXPORTED_SYMBOLS = [
+    "idto_hip_last_error", "idto_hip_create", "idto_hip_destroy", "idto_hip_set_problem", "idto_hip_set_stream",
+    "idto_hip_get_stream", "idto_hip_set_shard", "idto_hip_set_q", "idto_hip_set_q_device", "idto_hip_eval_tau",
+    "idto_hip_eval_partials", "idto_hip_grad_hess", "idto_hip_factor_solve", "idto_hip_gn_step",
+    "idto_hip_timing_enable", "idto_hip_timing_reset", "idto_hip_timing_get", "idto_hip_sync", "idto_hip_get",
+    "idto_hip_device_ptr", "idto_hip_array_size", "idto_hip_slab_stride", "idto_hip_math_probe",
+]
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _chk(rc):
+    if rc != 0:
+        raise HipError(f"idto_hip error {rc}: {lib().idto_hip_last_error().decode()}")
+
+
+class HipPath:
+    """One problem resident on one MI355X: the device side of TrajectoryOptimizer."""
+
+    def __init__(self, model: Model, prob: ProblemDefinition, params: SolverParameters, device: int = 0):
+        L = lib()
+        self.model, self.prob, self.params = model, prob, params
+        self.nq, self.nv, self.N = model.nq, model.nv, prob.num_steps
+        cm, self._k1 = model.to_c()
+        cp, self._k2 = prob.to_c()
+        cc = params.contact_to_c()
+        h = C.c_void_p()
+        _chk(L.idto_hip_create(C.byref(cm), C.byref(cp), C.byref(cc), int(device), C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().idto_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- inputs
+    def set_q(self, q):
+        q = np.ascontiguousarray(np.asarray(q, dtype=np.float64))
+        assert q.size == (self.N + 1) * self.nq
+        _chk(lib().idto_hip_set_q(self.h, dptr(q)))
+
+    def set_q_device(self, ptr: int):
+        _chk(lib().idto_hip_set_q_device(self.h, C.c_void_p(ptr)))
+
+    def set_problem(self, prob: ProblemDefinition):
+        cp, self._k2 = prob.to_c()
+        self.prob = prob
+        _chk(lib().idto_hip_set_problem(self.h, C.byref(cp)))
+
+    def set_stream(self, stream_ptr: int):
+        _chk(lib().idto_hip_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def set_shard(self, k_begin: int, k_end: int):
+        _chk(lib().idto_hip_set_shard(self.h, int(k_begin), int(k_end)))
+
+    # ---- path pieces (asynchronous on the context's stream)
+    def eval_tau(self):
+        _chk(lib().idto_hip_eval_tau(self.h))
+
+    def eval_partials(self):
+        _chk(lib().idto_hip_eval_partials(self.h))
+
+    def grad_hess(self):
+        _chk(lib().idto_hip_grad_hess(self.h))
+
+    def factor_solve(self, rhs_ptr: int | None = None, nrhs: int = 1, x_ptr: int | None = None):
+        _chk(lib().idto_hip_factor_solve(self.h, C.c_void_p(rhs_ptr) if rhs_ptr else None, int(nrhs),
+                                         C.c_void_p(x_ptr) if x_ptr else None))
+
+    def gn_step(self):
+        _chk(lib().idto_hip_gn_step(self.h))
+
+    def sync(self):
+        _chk(lib().idto_hip_sync(self.h))
+
+    # ---- timing (HIP events on the context's stream)
+    def timing_enable(self, on=True):
+        _chk(lib().idto_hip_timing_enable(self.h, int(on)))
+
+    def timing_reset(self):
+        _chk(lib().idto_hip_timing_reset(self.h))
+
+    def timing_get(self, which: int):
+        ms, n = C.c_double(), C.c_int()
+        _chk(lib().idto_hip_timing_get(self.h, which, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # ---- outputs
+    def array_size(self, name):
+        return lib().idto_hip_array_size(self.h, ARR[name])
+
+    def device_ptr(self, name):
+        return lib().idto_hip_device_ptr(self.h, ARR[name])
+
+    @property
+    def slab_stride(self):
+        return lib().idto_hip_slab_stride(self.h)
+
+    def get(self, name):
+        out = np.zeros(self.array_size(name))
+        _chk(lib().idto_hip_get(self.h, ARR[name], dptr(out)))
+        N, nq, nv = self.N, self.nq, self.nv
+        if name == "q":
+            return out.reshape(N + 1, nq)
+        if name == "v":
+            return out.reshape(N + 1, nv)
+        if name in ("a", "tau"):
+            return out.reshape(N, nv)
+        if name == "nplus":
+            return out.reshape(N + 1, nq, nv).transpose(0, 2, 1).copy()
+        if name.startswith("dtau"):
+            return out.reshape(N, nq, nv).transpose(0, 2, 1).copy()  # [t, row(nv), col(nq)]
+        if name.startswith("H_"):
+            return out.reshape(N + 1, nq, nq).transpose(0, 2, 1).copy()  # [blk, row, col]
+        if name == "cost":
+            return float(out[0])
+        return out
+
+
+def math_probe(x, device=0):
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+    outs = [np.zeros_like(x) for _ in range(6)]
+    _chk(lib().idto_hip_math_probe(device, dptr(x), x.size, *[dptr(o) for o in outs]))
+    return dict(zip(("sqrt", "recip", "sin", "cos", "exp", "log"), outs))

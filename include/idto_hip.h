@@ -1,0 +1,121 @@
+/* idto_hip.h — C-ABI of libidto_hip.so, the MI355X (gfx950) implementation of
+ * IDTO's per-iteration gradient/Hessian path.
+ *
+ * The reference (ToyotaResearchInstitute/idto) has no FFI layer: this path lives
+ * in private C++ methods of `TrajectoryOptimizer<double>` that call Drake.  The
+ * entry points below are what a binding for that path replaces, one per
+ * reference routine (file:line under /root/reference):
+ *
+ *   idto_hip_eval_tau        CalcNplus                optimizer/trajectory_optimizer.cc:1633-1647
+ *                            CalcVelocities           :178-191
+ *                            CalcAccelerations        :193-202
+ *                            CalcInverseDynamics      :204-226  (+ :228-245, contact :247-386)
+ *                            CalcCost                 :147-176
+ *   idto_hip_eval_partials   CalcInverseDynamicsPartialsFiniteDiff :426-563
+ *                            CalcVelocityPartials     :962-973
+ *   idto_hip_grad_hess       CalcGradient             :1021-1081
+ *                            CalcHessian              :1093-1165
+ *   idto_hip_factor_solve    PentaDiagonalFactorization::Factorize   optimizer/penta_diagonal_solver.h:124-197
+ *                            PentaDiagonalFactorization::SolveInPlace :199-248
+ *                            SolveLinearSystemInPlace optimizer/trajectory_optimizer.cc:2077-2096
+ *   idto_hip_gn_step         the chain above, i.e. what the first CalcDoglegPoint after an
+ *                            accepted step computes (:2108-2140) with scaling and equality
+ *                            constraints off — the unit of BASELINE.json's metric.
+ *
+ * Data contract: fp64 everywhere; trajectories are t-major flat arrays
+ * (q: (N+1)*nq, v: (N+1)*nv, a/tau: N*nv); per-timestep blocks are column-major
+ * (Eigen's default), stored t-major and contiguous.  Everything stays resident
+ * in HBM inside the context between calls; `idto_hip_get` copies out.
+ * All functions return 0 on success and a negative code on failure
+ * (`idto_hip_last_error()` describes it); nothing throws across the boundary.
+ * Calls on one context must come from one thread at a time (the reference's
+ * optimizer is likewise single-caller: SURVEY.md §8b "Threading").
+ */
+#ifndef IDTO_HIP_H_
+#define IDTO_HIP_H_
+
+#include "idto_model.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct idto_hip_ctx idto_hip_ctx;
+
+enum idto_hip_array {
+  IDTO_ARR_Q = 0,        /* (N+1)*nq */
+  IDTO_ARR_V = 1,        /* (N+1)*nv */
+  IDTO_ARR_A = 2,        /* N*nv */
+  IDTO_ARR_TAU = 3,      /* N*nv */
+  IDTO_ARR_NPLUS = 4,    /* (N+1) blocks nv x nq */
+  IDTO_ARR_DTAU_DQM = 5, /* N blocks nv x nq ; block 0 is NaN, block 1 is 0 (inverse_dynamics_partials.h:35-42) */
+  IDTO_ARR_DTAU_DQT = 6, /* N blocks ; block 0 is 0 */
+  IDTO_ARR_DTAU_DQP = 7, /* N blocks */
+  IDTO_ARR_GRADIENT = 8, /* (N+1)*nq */
+  IDTO_ARR_H_A = 9,      /* (N+1) blocks nq x nq: two below the diagonal */
+  IDTO_ARR_H_B = 10,     /* one below the diagonal */
+  IDTO_ARR_H_C = 11,     /* diagonal (symmetric, both triangles filled) */
+  IDTO_ARR_STEP = 12,    /* (N+1)*nq : solution of the last factor_solve / gn_step */
+  IDTO_ARR_COST = 13,    /* 1 */
+  IDTO_ARR_SLAB = 14     /* N * slab_stride: per tau-index k [dtau_dqm | dtau_dqt | dtau_dqp | tau_k] — the
+                            buffer a multi-GPU run all-gathers (contiguous in k) */
+};
+
+const char* idto_hip_last_error(void);
+
+/* Creates a context on HIP device `device` for the given model, problem and
+ * contact parameters (copied).  `gradients_method`: 0 forward differences. */
+int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem,
+                    const idto_contact_params_t* contact, int device, idto_hip_ctx** out);
+void idto_hip_destroy(idto_hip_ctx* ctx);
+
+/* Replaces q_init/v_init/weights/q_nom/v_nom (ResetInitialConditions /
+ * UpdateNominalTrajectory, reference trajectory_optimizer.h:429-470). num_steps and
+ * time_step must not change. */
+int idto_hip_set_problem(idto_hip_ctx* ctx, const idto_problem_t* problem);
+
+/* All work of the context is enqueued on this hipStream_t (default: a private stream). */
+int idto_hip_set_stream(idto_hip_ctx* ctx, void* hip_stream);
+void* idto_hip_get_stream(idto_hip_ctx* ctx);
+
+/* Restricts eval_partials to tau-indices k in [k_begin, k_end) (multi-GPU t-range
+ * sharding); the caller all-gathers IDTO_ARR_SLAB before grad_hess. */
+int idto_hip_set_shard(idto_hip_ctx* ctx, int k_begin, int k_end);
+
+int idto_hip_set_q(idto_hip_ctx* ctx, const double* q_host);         /* H2D copy */
+int idto_hip_set_q_device(idto_hip_ctx* ctx, const double* q_device); /* D2D copy */
+
+int idto_hip_eval_tau(idto_hip_ctx* ctx);
+int idto_hip_eval_partials(idto_hip_ctx* ctx);
+int idto_hip_grad_hess(idto_hip_ctx* ctx);
+/* Factorises the resident Hessian and solves H x = rhs for `nrhs` right-hand
+ * sides given as DEVICE pointers (column-major (N+1)*nq each); rhs == NULL means
+ * rhs = -gradient, result in IDTO_ARR_STEP. */
+int idto_hip_factor_solve(idto_hip_ctx* ctx, const double* rhs_device, int nrhs, double* x_device);
+int idto_hip_gn_step(idto_hip_ctx* ctx);
+
+/* Device-side timing of the last `idto_hip_gn_step`-shaped launches: average
+ * milliseconds per launch of kernel `which` (0 fd, 1 assemble, 2 factor_solve)
+ * over the launches recorded since idto_hip_timing_reset, measured with HIP
+ * events on the context's stream. */
+int idto_hip_timing_enable(idto_hip_ctx* ctx, int enable);
+int idto_hip_timing_reset(idto_hip_ctx* ctx);
+int idto_hip_timing_get(idto_hip_ctx* ctx, int which, double* avg_ms, int* launches);
+
+int idto_hip_sync(idto_hip_ctx* ctx);
+/* Synchronises and copies array `what` to host memory (sizes above). */
+int idto_hip_get(idto_hip_ctx* ctx, int what, double* host_out);
+/* Raw device pointer / element count of a resident array (for zero-copy interop). */
+void* idto_hip_device_ptr(idto_hip_ctx* ctx, int what);
+long idto_hip_array_size(idto_hip_ctx* ctx, int what);
+int idto_hip_slab_stride(idto_hip_ctx* ctx);
+
+/* Self-test of device arithmetic the bit-exactness argument relies on: evaluates
+ * sqrt, division and idto::detmath on `n` inputs on the device (outputs to host arrays). */
+int idto_hip_math_probe(int device, const double* x, int n, double* sqrt_out, double* recip_out,
+                        double* sin_out, double* cos_out, double* exp_out, double* log_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IDTO_HIP_H_ */
