@@ -13,6 +13,7 @@
 
 #include "idto_hip.h"
 #include "kernels.h"
+#include "penta_spd.h"
 
 using namespace idto_dev;
 
@@ -54,6 +55,9 @@ struct idto_hip_ctx {
   int* pivst = nullptr;
   int slab_stride = 0;
   int k_begin = 0, k_end = 0;
+  bool weights_diagonal = false;
+  bool reference_solver = false;  // bit-exact pivoted-LU block Thomas (kernels.h penta_kernel)
+  int asm_diag_lds = 0;
   // launch geometry
   int fd_threads = 256, fd_lds = 0, tau_lds = 0, asm_lds = 0, penta_lds = 0, solve_lds = 0, cost_lds = 0;
   // timing
@@ -113,6 +117,14 @@ int UploadProblemArrays(idto_hip_ctx* c, const idto_problem_t* p, bool first) {
       HIP_OK(hipMemcpyAsync(c->d_w[i], w[i].data(), w[i].size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));  // host staging vectors die at scope exit
   }
+  auto is_diag = [](const double* W, int n) {
+    for (int c2 = 0; c2 < n; ++c2)
+      for (int r = 0; r < n; ++r)
+        if (r != c2 && W[(size_t)c2 * n + r] != 0.0) return false;
+    return true;
+  };
+  c->weights_diagonal = is_diag(p->Qq, nq) && is_diag(p->Qv, nv) && is_diag(p->R, nv) && is_diag(p->Qf_q, nq) &&
+                        is_diag(p->Qf_v, nv);
   DevProblem& P = c->P;
   P.N = N; P.dt = dt; P.v_init = c->d_vinit; P.q_nom = c->d_qnom; P.v_nom = c->d_vnom;
   P.Qq = c->d_w[0]; P.Qv = c->d_w[1]; P.R = c->d_w[2]; P.Qfq = c->d_w[3]; P.Qfv = c->d_w[4];
@@ -291,6 +303,7 @@ int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem, co
   c->fd_lds = fd_lds(E);
   c->tau_lds = fd_lds(1);
   c->asm_lds = (int)sizeof(double) * (3 * nq + 5 * (int)bsz + 4 * nv + nq + std::max(nq, nv) + (int)bsz + 3 * (int)qq + nq);
+  c->asm_diag_lds = (int)sizeof(double) * (11 * (int)bsz + 10 * nv + 6 * nq);
   const int n = N + 1;
   c->penta_lds = (int)sizeof(double) * (10 * (int)qq + nq * (3 * nq + 1) + (n + 2) * nq + nq) + (int)sizeof(int) * nq + 16;
   c->solve_lds = (int)sizeof(double) * ((n + 2) * nq + nq);
@@ -308,6 +321,15 @@ int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem, co
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+#define SPD_ATTR(KM)                                                                                          \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_spd_kernel<KM, 256>),                         \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                              \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_spd_kernel<KM, 1024>),                        \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  SPD_ATTR(8) SPD_ATTR(20) SPD_ATTR(24) SPD_ATTR(32)
+#undef SPD_ATTR
+  if (const char* e = getenv("IDTO_SOLVER_REFERENCE")) c->reference_solver = (e[0] == '1');
   (void)hipGetLastError();
   *out = c;
   return 0;
@@ -376,10 +398,42 @@ int idto_hip_eval_partials(idto_hip_ctx* c) {
 int idto_hip_grad_hess(idto_hip_ctx* c) {
   HIP_OK(hipSetDevice(c->device));
   if (TimeBegin(c, 1)) return -2;
-  hipLaunchKernelGGL(assemble_kernel, dim3(c->N + 1), dim3(256), c->asm_lds, c->stream, c->M, c->P, c->q, c->slab,
-                     c->slab_stride, c->g, c->HA, c->HB, c->HC);
+  if (c->weights_diagonal)
+    hipLaunchKernelGGL(assemble_diag_kernel, dim3(c->N + 1), dim3(256), c->asm_diag_lds, c->stream, c->M, c->P, c->q,
+                       c->slab, c->slab_stride, c->g, c->HA, c->HB, c->HC);
+  else
+    hipLaunchKernelGGL(assemble_kernel, dim3(c->N + 1), dim3(256), c->asm_lds, c->stream, c->M, c->P, c->q, c->slab,
+                       c->slab_stride, c->g, c->HA, c->HB, c->HC);
   HIP_OK(hipGetLastError());
   return TimeEnd(c);
+}
+
+static int LaunchSpd(idto_hip_ctx* c, const double* b, double sign, int nrhs, double* xo) {
+  const int n = c->N + 1, k = c->nq;
+  if (k > 32) { g_err = "fast solver supports nq <= 32"; return -1; }
+  const int per_wave = 64 - k, ncr = 2 * k + nrhs;
+  const int gj_waves = (ncr + per_wave - 1) / per_wave;
+  if (gj_waves > 16) { g_err = "too many right-hand sides for one launch"; return -1; }
+  const int threads = std::max(256, 64 * gj_waves);
+  const PentaSpdLds L = penta_spd_layout(n, k, nrhs);
+  const int lds = L.end * (int)sizeof(double);
+  if (lds > 160 * 1024) { g_err = "right-hand sides do not fit the LDS carve-up"; return -1; }
+#define SPD_LAUNCH(KM)                                                                                        \
+  do {                                                                                                        \
+    if (threads <= 256)                                                                                       \
+      hipLaunchKernelGGL((penta_spd_kernel<KM, 256>), dim3(1), dim3(threads), lds, c->stream, n, k, c->HA, c->HB, \
+                         c->HC, b, sign, nrhs, xo, c->Yst, c->Zst);                                            \
+    else                                                                                                      \
+      hipLaunchKernelGGL((penta_spd_kernel<KM, 1024>), dim3(1), dim3(threads), lds, c->stream, n, k, c->HA,    \
+                         c->HB, c->HC, b, sign, nrhs, xo, c->Yst, c->Zst);                                     \
+  } while (0)
+  if (k <= 8) SPD_LAUNCH(8);
+  else if (k <= 20) SPD_LAUNCH(20);
+  else if (k <= 24) SPD_LAUNCH(24);
+  else SPD_LAUNCH(32);
+#undef SPD_LAUNCH
+  HIP_OK(hipGetLastError());
+  return 0;
 }
 
 int idto_hip_factor_solve(idto_hip_ctx* c, const double* rhs, int nrhs, double* x) {
@@ -387,18 +441,36 @@ int idto_hip_factor_solve(idto_hip_ctx* c, const double* rhs, int nrhs, double* 
   const int n = c->N + 1, k = c->nq;
   const double* b = rhs ? rhs : c->g;
   double* xo = rhs ? x : c->step;
-  if (rhs && nrhs < 1) { g_err = "nrhs < 1"; return -1; }
+  if (!rhs) nrhs = 1;
+  if (nrhs < 1) { g_err = "nrhs < 1"; return -1; }
   if (TimeBegin(c, 2)) return -2;
-  hipLaunchKernelGGL(penta_kernel, dim3(1), dim3(256), c->penta_lds, c->stream, n, k, c->HA, c->HB, c->HC, b,
-                     rhs ? 1.0 : -1.0, xo, c->Kst, c->LUst, c->pivst, c->Yst, c->Zst);
-  HIP_OK(hipGetLastError());
-  if (TimeEnd(c)) return -2;
-  if (rhs && nrhs > 1) {
-    hipLaunchKernelGGL(penta_solve_kernel, dim3(nrhs - 1), dim3(64), c->solve_lds, c->stream, n, k, c->HA, c->Kst,
-                       c->LUst, c->pivst, c->Yst, c->Zst, rhs + (size_t)n * k, x + (size_t)n * k);
+  if (c->reference_solver) {
+    hipLaunchKernelGGL(penta_kernel, dim3(1), dim3(256), c->penta_lds, c->stream, n, k, c->HA, c->HB, c->HC, b,
+                       rhs ? 1.0 : -1.0, xo, c->Kst, c->LUst, c->pivst, c->Yst, c->Zst);
     HIP_OK(hipGetLastError());
+    if (TimeEnd(c)) return -2;
+    if (nrhs > 1) {
+      hipLaunchKernelGGL(penta_solve_kernel, dim3(nrhs - 1), dim3(64), c->solve_lds, c->stream, n, k, c->HA, c->Kst,
+                         c->LUst, c->pivst, c->Yst, c->Zst, rhs + (size_t)n * k, x + (size_t)n * k);
+      HIP_OK(hipGetLastError());
+    }
+    return 0;
   }
-  return 0;
+  // fast SPD path: chunks of right-hand sides that fit one launch (each chunk re-factorises)
+  const int per_wave = 64 - k;
+  const int max_rhs = std::max(1, 16 * per_wave - 2 * k);
+  for (int j0 = 0; j0 < nrhs; j0 += max_rhs) {
+    const int cnt = std::min(max_rhs, nrhs - j0);
+    int rc = LaunchSpd(c, b + (size_t)j0 * n * k, rhs ? 1.0 : -1.0, cnt, xo + (size_t)j0 * n * k);
+    if (rc) return rc;
+  }
+  return TimeEnd(c);
+}
+
+int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
+  if (std::strcmp(name, "reference_solver") == 0) { c->reference_solver = value != 0; return 0; }
+  g_err = std::string("unknown option ") + name;
+  return -1;
 }
 
 int idto_hip_gn_step(idto_hip_ctx* c) {

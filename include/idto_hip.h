@@ -94,6 +94,11 @@ int idto_hip_grad_hess(idto_hip_ctx* ctx);
 int idto_hip_factor_solve(idto_hip_ctx* ctx, const double* rhs_device, int nrhs, double* x_device);
 int idto_hip_gn_step(idto_hip_ctx* ctx);
 
+/* Options: "reference_solver" = 1 selects the bit-exact restatement of the reference's
+ * pivoted-LU block Thomas (slow) instead of the SPD Gauss-Jordan solver (default 0; the
+ * environment variable IDTO_SOLVER_REFERENCE=1 sets it at creation). */
+int idto_hip_set_option(idto_hip_ctx* ctx, const char* name, int value);
+
 /* Device-side timing of the last `idto_hip_gn_step`-shaped launches: average
  * milliseconds per launch of kernel `which` (0 fd, 1 assemble, 2 factor_solve)
  * over the launches recorded since idto_hip_timing_reset, measured with HIP
