@@ -322,12 +322,13 @@ int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem, co
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-#define SPD_ATTR(KM)                                                                                          \
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_spd_kernel<KM, 256>),                         \
+#define SPD_ATTR(KM, EX)                                                                                      \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_spd_kernel<KM, 256, EX>),                      \
                             hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                              \
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_spd_kernel<KM, 1024>),                        \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_spd_kernel<KM, 1024, EX>),                     \
                             hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-  SPD_ATTR(8) SPD_ATTR(20) SPD_ATTR(24) SPD_ATTR(32)
+  SPD_ATTR(8, false) SPD_ATTR(20, false) SPD_ATTR(24, false) SPD_ATTR(32, false)
+  SPD_ATTR(2, true) SPD_ATTR(3, true) SPD_ATTR(5, true) SPD_ATTR(19, true) SPD_ATTR(23, true)
 #undef SPD_ATTR
   if (const char* e = getenv("IDTO_SOLVER_REFERENCE")) c->reference_solver = (e[0] == '1');
   (void)hipGetLastError();
@@ -418,19 +419,25 @@ static int LaunchSpd(idto_hip_ctx* c, const double* b, double sign, int nrhs, do
   const PentaSpdLds L = penta_spd_layout(n, k, nrhs);
   const int lds = L.end * (int)sizeof(double);
   if (lds > 160 * 1024) { g_err = "right-hand sides do not fit the LDS carve-up"; return -1; }
-#define SPD_LAUNCH(KM)                                                                                        \
+#define SPD_LAUNCH(KM, EX)                                                                                    \
   do {                                                                                                        \
     if (threads <= 256)                                                                                       \
-      hipLaunchKernelGGL((penta_spd_kernel<KM, 256>), dim3(1), dim3(threads), lds, c->stream, n, k, c->HA, c->HB, \
-                         c->HC, b, sign, nrhs, xo, c->Yst, c->Zst);                                            \
+      hipLaunchKernelGGL((penta_spd_kernel<KM, 256, EX>), dim3(1), dim3(threads), lds, c->stream, n, k, c->HA, \
+                         c->HB, c->HC, b, sign, nrhs, xo, c->Yst, c->Zst);                                     \
     else                                                                                                      \
-      hipLaunchKernelGGL((penta_spd_kernel<KM, 1024>), dim3(1), dim3(threads), lds, c->stream, n, k, c->HA,    \
+      hipLaunchKernelGGL((penta_spd_kernel<KM, 1024, EX>), dim3(1), dim3(threads), lds, c->stream, n, k, c->HA, \
                          c->HB, c->HC, b, sign, nrhs, xo, c->Yst, c->Zst);                                     \
   } while (0)
-  if (k <= 8) SPD_LAUNCH(8);
-  else if (k <= 20) SPD_LAUNCH(20);
-  else if (k <= 24) SPD_LAUNCH(24);
-  else SPD_LAUNCH(32);
+  // the block sizes of the reference's five example models get fully unrolled kernels
+  if (k == 2) SPD_LAUNCH(2, true);
+  else if (k == 3) SPD_LAUNCH(3, true);
+  else if (k == 5) SPD_LAUNCH(5, true);
+  else if (k == 19) SPD_LAUNCH(19, true);
+  else if (k == 23) SPD_LAUNCH(23, true);
+  else if (k <= 8) SPD_LAUNCH(8, false);
+  else if (k <= 20) SPD_LAUNCH(20, false);
+  else if (k <= 24) SPD_LAUNCH(24, false);
+  else SPD_LAUNCH(32, false);
 #undef SPD_LAUNCH
   HIP_OK(hipGetLastError());
   return 0;

@@ -577,6 +577,7 @@ assemble_diag_kernel(DevModel M, DevProblem P, const double* __restrict__ q, con
     const double* B = ops + t.b * bsz + c * nv;
     const double* w = wts + t.w * nv;
     double acc = (A[0] * w[0]) * B[0];
+#pragma unroll 6
     for (int l = 1; l < nv; ++l) acc += (A[l] * w[l]) * B[l];
     return acc;
   };
@@ -604,6 +605,7 @@ assemble_diag_kernel(DevModel M, DevProblem P, const double* __restrict__ q, con
   if (j >= 0 && j < nq) {
     auto vwm = [&](const double* e, const double* w, const double* J) {  // sum_r (e_r w_r) J[r][j]
       double acc = (e[0] * w[0]) * J[j * nv];
+#pragma unroll 6
       for (int r = 1; r < nv; ++r) acc += (e[r] * w[r]) * J[j * nv + r];
       return acc;
     };

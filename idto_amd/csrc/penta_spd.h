@@ -36,20 +36,24 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 
 // Gauss-Jordan on the columns held by this wavefront: lanes 0..k-1 hold the columns of
 // the SPD block S, the other lanes right-hand-side columns; on exit those hold S^{-1} rhs.
-template <int KMAX>
+template <int KMAX, bool EXACT>
 __device__ __forceinline__ void gauss_jordan_wave(double (&xr)[KMAX], int k) {
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) {
-    if (j < k) {
+    if (EXACT || j < k) {
       const double d = readlane_f64(xr[j], j);
       const double inv = 1.0 / d;
       const double t = xr[j] * inv;
+      // the whole pivot column first (wave-uniform values, they live in SGPRs), then the
+      // FMAs: one SGPR-hazard wait per pivot instead of one per row.  Row j+1 is updated
+      // first so that the next pivot's reciprocal can overlap the remaining updates.
+      double m[KMAX];
 #pragma unroll
-      for (int r = 0; r < KMAX; ++r) {
-        if (r != j && r < k) {
-          const double m = readlane_f64(xr[r], j);
-          xr[r] = __builtin_fma(-m, t, xr[r]);
-        }
+      for (int r = 0; r < KMAX; ++r) m[r] = (r != j && (EXACT || r < k)) ? readlane_f64(xr[r], j) : 0.0;
+#pragma unroll
+      for (int rr = 1; rr < KMAX; ++rr) {
+        const int r = (j + rr) % KMAX;
+        if (EXACT || r < k) xr[r] = __builtin_fma(-m[r], t, xr[r]);
       }
       xr[j] = t;
     }
@@ -80,7 +84,7 @@ __host__ __device__ inline PentaSpdLds penta_spd_layout(int n, int k, int nrhs) 
 
 // b: [nrhs][n*k] right-hand sides (rhs = rhs_sign * b), x: [nrhs][n*k] solutions.
 // Yst, Zst: [n][k*k] (column-major blocks), kept for later solves / inspection.
-template <int KMAX, int NT>
+template <int KMAX, int NT, bool EXACT>
 __global__ void __launch_bounds__(NT)
 penta_spd_kernel(int n, int k, const double* __restrict__ HA, const double* __restrict__ HB,
                  const double* __restrict__ HC, const double* __restrict__ b, double rhs_sign, int nrhs,
@@ -151,17 +155,61 @@ penta_spd_kernel(int n, int k, const double* __restrict__ HA, const double* __re
     __syncthreads();
 
     // ---- augmented matrix [S | H | E | r] (column-major, stride ks)
+    if (EXACT) {
+      // thread = (row r, column group): row r of A_i and of K_i = H_{i-1}^T stay in registers
+      // and are reused for every column of the group; Y/Z/rt columns are LDS broadcasts.
+      constexpr int K = KMAX;
+      const int r = tid % K, cg = tid / K, ncg = nt / K;
+      if (cg < ncg) {
+        double arow[K], hrow[K];
+#pragma unroll
+        for (int m = 0; m < K; ++m) { arow[m] = Ai[m * K + r]; hrow[m] = Hp[r * ks + m]; }
+        const int ncomp = 2 * K + nrhs;  // computed columns: S (K), H (K), rhs
+        for (int cc = cg; cc < ncomp; cc += ncg) {
+          double a0 = 0.0, a1 = 0.0;
+          if (cc < K) {  // S_i
+            const double* zc = Zpp + cc * ks;
+            const double* yc = Yp + cc * ks;
+#pragma unroll
+            for (int m = 0; m < K; ++m) { a0 = __builtin_fma(arow[m], zc[m], a0); a1 = __builtin_fma(hrow[m], yc[m], a1); }
+            Wm[cc * ks + r] = (Ci[cc * K + r] - a0) - a1;
+          } else if (cc < 2 * K) {  // H_i
+            const int c2 = cc - K;
+            const double* zc = Zp + c2 * ks;
+#pragma unroll
+            for (int m = 0; m < K; ++m) a0 = __builtin_fma(hrow[m], zc[m], a0);
+            const double val = Bn[r * K + c2] - a0;
+            Wm[cc * ks + r] = val;
+            Hn[c2 * ks + r] = val;
+          } else {  // right-hand sides
+            const int j = cc - 2 * K;
+            const double* r2 = rtpp + j * K;
+            const double* r1 = rtp + j * K;
+#pragma unroll
+            for (int m = 0; m < K; ++m) { a0 = __builtin_fma(arow[m], r2[m], a0); a1 = __builtin_fma(hrow[m], r1[m], a1); }
+            const double bval = L.bl_size ? lds[L.bl + j * (int)nk + i * K + r]
+                                          : rhs_sign * b[(size_t)j * nk + (size_t)i * K + r];
+            Wm[(3 * K + j) * ks + r] = (bval - a0) - a1;
+          }
+        }
+        // E_i = A_{i+2}^T
+        for (int cc = cg; cc < K; cc += ncg) Wm[(2 * K + cc) * ks + r] = An2[r * K + cc];
+      }
+    } else {
     for (int idx = tid; idx < (k + ncr) * k; idx += nt) {
       const int c = idx / k, r = idx - c * k;
       double val;
       if (c < k) {  // S_i
         double acc = Ci[c * k + r];
+#pragma unroll 4
         for (int m = 0; m < k; ++m) acc = __builtin_fma(-Ai[m * k + r], Zpp[c * ks + m], acc);
+#pragma unroll 4
         for (int m = 0; m < k; ++m) acc = __builtin_fma(-Hp[r * ks + m], Yp[c * ks + m], acc);
         val = acc;
       } else if (c < 2 * k) {  // H_i
         const int cc = c - k;
         double acc = Bn[r * k + cc];  // B_{i+1}^T
+#pragma unroll 4
         for (int m = 0; m < k; ++m) acc = __builtin_fma(-Hp[r * ks + m], Zp[cc * ks + m], acc);
         val = acc;
         Hn[cc * ks + r] = acc;
@@ -171,11 +219,14 @@ penta_spd_kernel(int n, int k, const double* __restrict__ HA, const double* __re
         const int j = c - 3 * k;
         double acc = L.bl_size ? lds[L.bl + j * (int)nk + i * k + r]
                                : rhs_sign * b[(size_t)j * nk + (size_t)i * k + r];
+#pragma unroll 4
         for (int m = 0; m < k; ++m) acc = __builtin_fma(-Ai[m * k + r], rtpp[j * k + m], acc);
+#pragma unroll 4
         for (int m = 0; m < k; ++m) acc = __builtin_fma(-Hp[r * ks + m], rtp[j * k + m], acc);
         val = acc;
       }
       Wm[c * ks + r] = val;
+    }
     }
     __syncthreads();
 
@@ -187,7 +238,7 @@ penta_spd_kernel(int n, int k, const double* __restrict__ HA, const double* __re
       double xr[KMAX];
 #pragma unroll
       for (int r = 0; r < KMAX; ++r) xr[r] = (r < k) ? Wm[col * ks + r] : 0.0;
-      gauss_jordan_wave<KMAX>(xr, k);
+      gauss_jordan_wave<KMAX, EXACT>(xr, k);
       if (is_rhs) {
         if (rc < k) {
 #pragma unroll
