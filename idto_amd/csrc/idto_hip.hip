@@ -13,7 +13,7 @@
 
 #include "idto_hip.h"
 #include "kernels.h"
-#include "penta_spd.h"
+#include "penta_ldl.h"
 
 using namespace idto_dev;
 
@@ -53,6 +53,9 @@ struct idto_hip_ctx {
   double *g = nullptr, *HA = nullptr, *HB = nullptr, *HC = nullptr, *step = nullptr, *cost = nullptr;
   double *Kst = nullptr, *LUst = nullptr, *Yst = nullptr, *Zst = nullptr;
   int* pivst = nullptr;
+  double *Ust = nullptr, *Hst = nullptr, *Est = nullptr, *Dst = nullptr;  // LDL^T factors (padded K x K blocks)
+  double* dbg = nullptr;  // cycle stamps of the solver (8 per block row)
+  bool solver_debug = false;
   int slab_stride = 0;
   int k_begin = 0, k_end = 0;
   bool weights_diagonal = false;
@@ -290,6 +293,11 @@ int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem, co
   bad |= Alloc(c, (size_t)(N + 1) * qq, &c->Yst) != 0;
   bad |= Alloc(c, (size_t)(N + 1) * qq, &c->Zst) != 0;
   bad |= Alloc(c, (size_t)(N + 1) * nq, &c->pivst) != 0;
+  bad |= Alloc(c, (size_t)(N + 3) * 8, &c->dbg) != 0;
+  bad |= Alloc(c, (size_t)(N + 1) * 32 * 32, &c->Ust) != 0;
+  bad |= Alloc(c, (size_t)(N + 1) * 32 * 32, &c->Hst) != 0;
+  bad |= Alloc(c, (size_t)(N + 1) * 32 * 32, &c->Est) != 0;
+  bad |= Alloc(c, (size_t)(N + 1) * 32, &c->Dst) != 0;
   if (bad) { idto_hip_destroy(c); return -2; }
   c->k_begin = 0; c->k_end = N;
 
@@ -322,14 +330,13 @@ int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem, co
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-#define SPD_ATTR(KM, EX)                                                                                      \
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_spd_kernel<KM, 256, EX>),                      \
+#define LDL_ATTR(KM)                                                                                          \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_ldl_kernel<KM, 256>),                         \
                             hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                              \
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_spd_kernel<KM, 1024, EX>),                     \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_ldl_kernel<KM, 1024>),                        \
                             hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-  SPD_ATTR(8, false) SPD_ATTR(20, false) SPD_ATTR(24, false) SPD_ATTR(32, false)
-  SPD_ATTR(2, true) SPD_ATTR(3, true) SPD_ATTR(5, true) SPD_ATTR(19, true) SPD_ATTR(23, true)
-#undef SPD_ATTR
+  LDL_ATTR(2) LDL_ATTR(3) LDL_ATTR(5) LDL_ATTR(8) LDL_ATTR(16) LDL_ATTR(19) LDL_ATTR(23) LDL_ATTR(24) LDL_ATTR(32)
+#undef LDL_ATTR
   if (const char* e = getenv("IDTO_SOLVER_REFERENCE")) c->reference_solver = (e[0] == '1');
   (void)hipGetLastError();
   *out = c;
@@ -409,36 +416,40 @@ int idto_hip_grad_hess(idto_hip_ctx* c) {
   return TimeEnd(c);
 }
 
-static int LaunchSpd(idto_hip_ctx* c, const double* b, double sign, int nrhs, double* xo) {
+static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, int nrhs, double* xo) {
   const int n = c->N + 1, k = c->nq;
   if (k > 32) { g_err = "fast solver supports nq <= 32"; return -1; }
-  const int per_wave = 64 - k, ncr = 2 * k + nrhs;
+  // block sizes of the reference's example models are instantiated exactly, others are padded
+  const int K = (k == 2 || k == 3 || k == 5 || k == 19 || k == 23) ? k : (k <= 8 ? 8 : k <= 16 ? 16 : k <= 24 ? 24 : 32);
+  const int per_wave = 64 - K, ncr = 2 * K + nrhs;
   const int gj_waves = (ncr + per_wave - 1) / per_wave;
-  if (gj_waves > 16) { g_err = "too many right-hand sides for one launch"; return -1; }
-  const int threads = std::max(256, 64 * gj_waves);
-  const PentaSpdLds L = penta_spd_layout(n, k, nrhs);
+  if (gj_waves > 15) { g_err = "too many right-hand sides for one launch"; return -1; }
+  const int threads = (gj_waves + 1 <= 4) ? 256 : 1024;
+  const PentaLdlLds L = penta_ldl_layout(n, K, nrhs);
   const int lds = L.end * (int)sizeof(double);
   if (lds > 160 * 1024) { g_err = "right-hand sides do not fit the LDS carve-up"; return -1; }
-#define SPD_LAUNCH(KM, EX)                                                                                    \
+  double* dbg = c->solver_debug ? c->dbg : nullptr;
+#define LDL_LAUNCH(KM)                                                                                        \
   do {                                                                                                        \
-    if (threads <= 256)                                                                                       \
-      hipLaunchKernelGGL((penta_spd_kernel<KM, 256, EX>), dim3(1), dim3(threads), lds, c->stream, n, k, c->HA, \
-                         c->HB, c->HC, b, sign, nrhs, xo, c->Yst, c->Zst);                                     \
+    if (threads == 256)                                                                                       \
+      hipLaunchKernelGGL((penta_ldl_kernel<KM, 256>), dim3(1), dim3(256), lds, c->stream, n, k, c->HA, c->HB,  \
+                         c->HC, b, sign, nrhs, xo, c->Ust, c->Hst, c->Est, c->Dst, dbg);                       \
     else                                                                                                      \
-      hipLaunchKernelGGL((penta_spd_kernel<KM, 1024, EX>), dim3(1), dim3(threads), lds, c->stream, n, k, c->HA, \
-                         c->HB, c->HC, b, sign, nrhs, xo, c->Yst, c->Zst);                                     \
+      hipLaunchKernelGGL((penta_ldl_kernel<KM, 1024>), dim3(1), dim3(1024), lds, c->stream, n, k, c->HA,       \
+                         c->HB, c->HC, b, sign, nrhs, xo, c->Ust, c->Hst, c->Est, c->Dst, dbg);                \
   } while (0)
-  // the block sizes of the reference's five example models get fully unrolled kernels
-  if (k == 2) SPD_LAUNCH(2, true);
-  else if (k == 3) SPD_LAUNCH(3, true);
-  else if (k == 5) SPD_LAUNCH(5, true);
-  else if (k == 19) SPD_LAUNCH(19, true);
-  else if (k == 23) SPD_LAUNCH(23, true);
-  else if (k <= 8) SPD_LAUNCH(8, false);
-  else if (k <= 20) SPD_LAUNCH(20, false);
-  else if (k <= 24) SPD_LAUNCH(24, false);
-  else SPD_LAUNCH(32, false);
-#undef SPD_LAUNCH
+  switch (K) {
+    case 2: LDL_LAUNCH(2); break;
+    case 3: LDL_LAUNCH(3); break;
+    case 5: LDL_LAUNCH(5); break;
+    case 8: LDL_LAUNCH(8); break;
+    case 16: LDL_LAUNCH(16); break;
+    case 19: LDL_LAUNCH(19); break;
+    case 23: LDL_LAUNCH(23); break;
+    case 24: LDL_LAUNCH(24); break;
+    default: LDL_LAUNCH(32); break;
+  }
+#undef LDL_LAUNCH
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -464,11 +475,12 @@ int idto_hip_factor_solve(idto_hip_ctx* c, const double* rhs, int nrhs, double* 
     return 0;
   }
   // fast SPD path: chunks of right-hand sides that fit one launch (each chunk re-factorises)
-  const int per_wave = 64 - k;
-  const int max_rhs = std::max(1, 16 * per_wave - 2 * k);
+  const int K = (k == 2 || k == 3 || k == 5 || k == 19 || k == 23) ? k : (k <= 8 ? 8 : k <= 16 ? 16 : k <= 24 ? 24 : 32);
+  int max_rhs = std::max(1, 15 * (64 - K) - 2 * K);
+  while (max_rhs > 1 && penta_ldl_layout(n, K, max_rhs).end * (int)sizeof(double) > 160 * 1024) max_rhs /= 2;
   for (int j0 = 0; j0 < nrhs; j0 += max_rhs) {
     const int cnt = std::min(max_rhs, nrhs - j0);
-    int rc = LaunchSpd(c, b + (size_t)j0 * n * k, rhs ? 1.0 : -1.0, cnt, xo + (size_t)j0 * n * k);
+    int rc = LaunchLdl(c, b + (size_t)j0 * n * k, rhs ? 1.0 : -1.0, cnt, xo + (size_t)j0 * n * k);
     if (rc) return rc;
   }
   return TimeEnd(c);
@@ -476,6 +488,7 @@ int idto_hip_factor_solve(idto_hip_ctx* c, const double* rhs, int nrhs, double* 
 
 int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "reference_solver") == 0) { c->reference_solver = value != 0; return 0; }
+  if (std::strcmp(name, "solver_debug") == 0) { c->solver_debug = value != 0; return 0; }
   g_err = std::string("unknown option ") + name;
   return -1;
 }
@@ -520,6 +533,7 @@ long idto_hip_array_size(idto_hip_ctx* c, int what) {
     case IDTO_ARR_H_A: case IDTO_ARR_H_B: case IDTO_ARR_H_C: return (N + 1) * qq;
     case IDTO_ARR_COST: return 1;
     case IDTO_ARR_SLAB: return N * (long)c->slab_stride;
+    case 15: return (N + 3) * 8;
     default: return -1;
   }
 }
@@ -538,6 +552,7 @@ void* idto_hip_device_ptr(idto_hip_ctx* c, int what) {
     case IDTO_ARR_STEP: return c->step;
     case IDTO_ARR_COST: return c->cost;
     case IDTO_ARR_SLAB: return c->slab;
+    case 15: return c->dbg;
     default: return nullptr;  // tau and the three partials live strided inside the slab
   }
 }
