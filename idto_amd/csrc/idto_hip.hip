@@ -283,9 +283,10 @@ int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem, co
   bad |= Alloc(c, (size_t)(N + 1) * bsz, &c->nplus) != 0;
   bad |= Alloc(c, (size_t)N * c->slab_stride, &c->slab) != 0;
   bad |= Alloc(c, (size_t)(N + 1) * nq, &c->g) != 0;
-  bad |= Alloc(c, (size_t)(N + 1) * qq, &c->HA) != 0;
-  bad |= Alloc(c, (size_t)(N + 1) * qq, &c->HB) != 0;
-  bad |= Alloc(c, (size_t)(N + 1) * qq, &c->HC) != 0;
+  // two extra zero blocks: the solver prefetches rows i+1, i+2 without bounds checks
+  bad |= Alloc(c, (size_t)(N + 4) * qq, &c->HA) != 0;
+  bad |= Alloc(c, (size_t)(N + 4) * qq, &c->HB) != 0;
+  bad |= Alloc(c, (size_t)(N + 4) * qq, &c->HC) != 0;
   bad |= Alloc(c, (size_t)(N + 1) * nq, &c->step) != 0;
   bad |= Alloc(c, (size_t)1, &c->cost) != 0;
   bad |= Alloc(c, (size_t)(N + 1) * qq, &c->Kst) != 0;
@@ -293,7 +294,7 @@ int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem, co
   bad |= Alloc(c, (size_t)(N + 1) * qq, &c->Yst) != 0;
   bad |= Alloc(c, (size_t)(N + 1) * qq, &c->Zst) != 0;
   bad |= Alloc(c, (size_t)(N + 1) * nq, &c->pivst) != 0;
-  bad |= Alloc(c, (size_t)(N + 3) * 8, &c->dbg) != 0;
+  bad |= Alloc(c, (size_t)(N + 4) * 8 * 16, &c->dbg) != 0;
   bad |= Alloc(c, (size_t)(N + 1) * 32 * 32, &c->Ust) != 0;
   bad |= Alloc(c, (size_t)(N + 1) * 32 * 32, &c->Hst) != 0;
   bad |= Alloc(c, (size_t)(N + 1) * 32 * 32, &c->Est) != 0;
@@ -330,12 +331,13 @@ int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem, co
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-#define LDL_ATTR(KM)                                                                                          \
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_ldl_kernel<KM, 256>),                         \
+#define LDL_ATTR(KM, PD)                                                                                          \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_ldl_kernel<KM, 256, PD>),                         \
                             hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                              \
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_ldl_kernel<KM, 1024>),                        \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_ldl_kernel<KM, 1024, PD>),                        \
                             hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-  LDL_ATTR(2) LDL_ATTR(3) LDL_ATTR(5) LDL_ATTR(8) LDL_ATTR(16) LDL_ATTR(19) LDL_ATTR(23) LDL_ATTR(24) LDL_ATTR(32)
+  LDL_ATTR(2, false) LDL_ATTR(3, false) LDL_ATTR(5, false) LDL_ATTR(19, false) LDL_ATTR(23, false)
+  LDL_ATTR(8, true) LDL_ATTR(16, true) LDL_ATTR(24, true) LDL_ATTR(32, true)
 #undef LDL_ATTR
   if (const char* e = getenv("IDTO_SOLVER_REFERENCE")) c->reference_solver = (e[0] == '1');
   (void)hipGetLastError();
@@ -429,25 +431,25 @@ static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, int nrhs, do
   const int lds = L.end * (int)sizeof(double);
   if (lds > 160 * 1024) { g_err = "right-hand sides do not fit the LDS carve-up"; return -1; }
   double* dbg = c->solver_debug ? c->dbg : nullptr;
-#define LDL_LAUNCH(KM)                                                                                        \
+#define LDL_LAUNCH(KM, PD)                                                                                        \
   do {                                                                                                        \
     if (threads == 256)                                                                                       \
-      hipLaunchKernelGGL((penta_ldl_kernel<KM, 256>), dim3(1), dim3(256), lds, c->stream, n, k, c->HA, c->HB,  \
+      hipLaunchKernelGGL((penta_ldl_kernel<KM, 256, PD>), dim3(1), dim3(256), lds, c->stream, n, k, c->HA, c->HB,  \
                          c->HC, b, sign, nrhs, xo, c->Ust, c->Hst, c->Est, c->Dst, dbg);                       \
     else                                                                                                      \
-      hipLaunchKernelGGL((penta_ldl_kernel<KM, 1024>), dim3(1), dim3(1024), lds, c->stream, n, k, c->HA,       \
+      hipLaunchKernelGGL((penta_ldl_kernel<KM, 1024, PD>), dim3(1), dim3(1024), lds, c->stream, n, k, c->HA,       \
                          c->HB, c->HC, b, sign, nrhs, xo, c->Ust, c->Hst, c->Est, c->Dst, dbg);                \
   } while (0)
   switch (K) {
-    case 2: LDL_LAUNCH(2); break;
-    case 3: LDL_LAUNCH(3); break;
-    case 5: LDL_LAUNCH(5); break;
-    case 8: LDL_LAUNCH(8); break;
-    case 16: LDL_LAUNCH(16); break;
-    case 19: LDL_LAUNCH(19); break;
-    case 23: LDL_LAUNCH(23); break;
-    case 24: LDL_LAUNCH(24); break;
-    default: LDL_LAUNCH(32); break;
+    case 2: LDL_LAUNCH(2, false); break;
+    case 3: LDL_LAUNCH(3, false); break;
+    case 5: LDL_LAUNCH(5, false); break;
+    case 8: LDL_LAUNCH(8, true); break;
+    case 16: LDL_LAUNCH(16, true); break;
+    case 19: LDL_LAUNCH(19, false); break;
+    case 23: LDL_LAUNCH(23, false); break;
+    case 24: LDL_LAUNCH(24, true); break;
+    default: LDL_LAUNCH(32, true); break;
   }
 #undef LDL_LAUNCH
   HIP_OK(hipGetLastError());
@@ -533,7 +535,7 @@ long idto_hip_array_size(idto_hip_ctx* c, int what) {
     case IDTO_ARR_H_A: case IDTO_ARR_H_B: case IDTO_ARR_H_C: return (N + 1) * qq;
     case IDTO_ARR_COST: return 1;
     case IDTO_ARR_SLAB: return N * (long)c->slab_stride;
-    case 15: return (N + 3) * 8;
+    case 15: return (N + 4) * 8 * 16;
     default: return -1;
   }
 }

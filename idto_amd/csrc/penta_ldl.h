@@ -10,26 +10,24 @@
 //   S_i = L_i D_i L_i^T (scalar elimination, no pivoting):  U_i = D_i L_i^T,  Dn_i = D_i^{-1},
 //   [Ht_i | Et_i | rt_i] = L_i^{-1} [H_i | A_{i+2}^T | y_i]
 //   backward:  U_i x_i = rt_i - Ht_i x_{i+1} - Et_i x_{i+2}
-// i.e. Y_i = S_i^{-1} H_i of the reference is kept in the factored form L_i^{-T} Dn_i Ht_i,
-// which halves the dependent elimination steps per block row (no back substitution inside the
-// factorisation).  Differences from the reference, all at round-off level:
-//   * per-block elimination without pivoting instead of Eigen::PartialPivLU (S_i is SPD);
-//   * the system is first equilibrated symmetrically with power-of-two Jacobi factors
-//     (exact scaling), which is what makes un-pivoted elimination as accurate as the
-//     pivoted LU on the badly scaled unscaled Hessians (cond ~ 1e10 on the hopper);
-//   * FMAs are used freely (this stage is not finite-difference amplified).
-// `penta_kernel` (kernels.h) remains the bit-exact restatement (option reference_solver).
+// i.e. the reference's Y_i = S_i^{-1} H_i is kept in the factored form L_i^{-T} Dn_i Ht_i:
+// this halves the dependent elimination steps per block row and — measured on the hopper,
+// cond(H) ~ 1e10 — is what keeps the residual at the level of the reference's pivoted LU
+// (forming S^{-1} H explicitly without pivoting lost 4 digits).  Differences from the
+// reference are at round-off level: no pivoting inside S_i (it is SPD), FMAs, reciprocals by
+// v_rcp_f64 + 2 Newton steps.  `penta_kernel` (kernels.h) stays the bit-exact restatement.
 //
-// Hardware mapping (one workgroup of 4 wavefronts; the recursion over i is sequential):
+// Hardware mapping (ONE workgroup of 4 wavefronts: the recursion over i is sequential, the
+// kernel is bound by the VALU issue rate of the wavefront on the critical path, ~4 cycles
+// per instruction, so the design minimises instructions there):
 //   * elimination: the augmented block [S_i | H_i | E_i | y] lives in the REGISTERS of one
-//     wavefront per (64 - K) right-hand-side columns, one column per lane, K rows per lane;
-//     a pivot step broadcasts the pivot column with v_readlane (wave-uniform values sit in
-//     SGPRs) and is otherwise per-lane FMAs: no LDS traffic and no barrier in the K dependent
-//     steps;
-//   * block products: all 256 threads, 2x2 register tiles, operands in LDS (odd column
-//     stride => conflict-free); while wavefront 0 eliminates, the other wavefronts already
-//     form E^T Dn E for the next row and write the finished factors back to HBM;
-//   * barriers order LDS only (s_waitcnt lgkmcnt(0); s_barrier): global prefetches of the
+//     wavefront per (64 - K) right-hand-side columns, one column per lane; a pivot step
+//     broadcasts the pivot column with v_readlane (wave-uniform values sit in SGPRs) and is
+//     otherwise per-lane FMAs: no LDS traffic and no barrier in the K dependent steps;
+//   * block products: 2x2 register tiles, one job per thread, job type uniform per wavefront
+//     (no divergence), all indices precomputed outside the row loop; while wavefront 0
+//     eliminates, the others form Et^T Dn Et for the next row and write factors back to HBM;
+//   * barriers order LDS only (s_waitcnt lgkmcnt(0); s_barrier): the register prefetch of the
 //     next row's blocks and the write-backs stay in flight across them.
 #pragma once
 
@@ -39,30 +37,34 @@ namespace idto_dev {
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// 2^(-round(log2(d)/2)): power-of-two Jacobi scale factor (scaling by it is exact).
-__device__ __forceinline__ double pow2_rsqrt_scale(double d) {
-  if (!(d > 0.0)) return 1.0;
-  const long long bits = __double_as_longlong(d);
-  const int e = (int)((bits >> 52) & 0x7ff) - 1023;  // d = m 2^e, 1 <= m < 2
-  const int half = (e >= 0) ? (e + 1) / 2 : -((-e) / 2);
-  return __longlong_as_double((long long)(1023 - half) << 52);
-}
-
 __device__ __forceinline__ double rdlane(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
 }
 
+// 1/d to full double precision: hardware estimate + 2 Newton steps (5 instructions instead of
+// the ~15 of an IEEE division; the factorisation is not bit-compared with the host).
+__device__ __forceinline__ double fast_rcp(double d) {
+  double x = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, x, 1.0);
+  x = __builtin_fma(x, e, x);
+  e = __builtin_fma(-d, x, 1.0);
+  x = __builtin_fma(x, e, x);
+  return x;
+}
+
 // Forward elimination of the columns held by this wavefront (lanes < K: columns of S).
-// On exit: S lanes hold U = D L^T (upper triangle), rhs lanes L^{-1} rhs; invd[j] = 1 / U[j][j].
+// On exit: S lanes hold U = D L^T (upper triangle), rhs lanes L^{-1} rhs; returns 1 / U[l][l]
+// in lane l (l < K).
 template <int K>
-__device__ __forceinline__ void ldl_eliminate_wave(double (&xr)[K], double (&invd)[K]) {
+__device__ __forceinline__ double ldl_eliminate_wave(double (&xr)[K], int lane) {
+  double myinv = 1.0;
 #pragma unroll
   for (int j = 0; j < K; ++j) {
     const double d = rdlane(xr[j], j);
-    const double inv = 1.0 / d;
-    invd[j] = inv;
+    const double inv = fast_rcp(d);
+    myinv = (lane == j) ? inv : myinv;
     const double t = xr[j] * inv;
     double m[K];
 #pragma unroll
@@ -70,27 +72,30 @@ __device__ __forceinline__ void ldl_eliminate_wave(double (&xr)[K], double (&inv
 #pragma unroll
     for (int r = j + 1; r < K; ++r) xr[r] = __builtin_fma(-m[r], t, xr[r]);
   }
+  return myinv;
 }
 
 struct PentaLdlLds {  // offsets in doubles
-  int W, Ht, Et, Iv, rt, U, G, in, sc, bl, bl_size, xall, end;
+  int W, Ht, Et, Iv, rt, U, G, in, bl, bl_size, xall, end;
   int kks, rts;
 };
 __host__ __device__ inline PentaLdlLds penta_ldl_layout(int n, int K, int nrhs) {
   PentaLdlLds L;
-  const int ks = K | 1, ncr = 2 * K + nrhs;
+  const int ks = (K + 1) & ~1, ncr = 2 * K + nrhs;  // even column stride: 16-byte aligned columns
   L.kks = K * ks;
-  L.rts = nrhs * K;
+  L.rts = nrhs * ks;
   int o = 0;
   L.W = o; o += (K + ncr) * ks;   // augmented block [S | H | E | y], column-major, stride ks
   L.Ht = o; o += 2 * L.kks;       // ring: Ht_i, Ht_{i-1}
   L.Et = o; o += 3 * L.kks;       // ring: Et_i, Et_{i-1}, Et_{i-2}
-  L.Iv = o; o += 3 * K;           // ring: 1/diag(U)
+  L.Iv = o; o += 3 * ks;          // ring: 1/diag(U) (padded to ks)
   L.rt = o; o += 3 * L.rts;       // ring: rt_i (forward) / x_i (backward)
   L.U = o; o += 2 * L.kks;        // ring: U_i, U_{i-1} (write-back staging)
   L.G = o; o += K * K;            // Et_{i-1}^T Dn Et_{i-1} for the next row
-  L.in = o; o += 4 * K * K;       // staged A_i, B_{i+1}, C_i, A_{i+2}
-  L.sc = o; o += (n + 2) * K;     // Jacobi factors
+  {                               // staged A_i, B_{i+1}, C_i, A_{i+2}; reused by the backward pass
+    const int fwd = 4 * K * K, bwd = 3 * K * ks + ks;
+    L.in = o; o += ((fwd > bwd ? fwd : bwd) + 1) & ~1;
+  }
   L.bl = o;
   L.bl_size = (nrhs * n * K <= 4096) ? nrhs * n * K : 0;
   o += L.bl_size;                 // right-hand sides staged in LDS when small ...
@@ -99,10 +104,34 @@ __host__ __device__ inline PentaLdlLds penta_ldl_layout(int n, int K, int nrhs) 
   return L;
 }
 
+// 2x2 tile of P^T diag(dn) Q over m = 0..K-1; p0/p1/q0/q1 point to the tile's columns (16-byte
+// aligned, padded with a zero row when K is odd) so that every load is a ds_read_b128: a lone
+// wavefront pays ~10 cycles per DS instruction whatever its width.
+template <int K>
+__device__ __forceinline__ void tile_ptdq(const double* p0, const double* p1, const double* q0, const double* q1,
+                                          const double* dn, double& a00, double& a01, double& a10, double& a11) {
+  a00 = a01 = a10 = a11 = 0.0;
+  constexpr int KP = (K + 1) / 2;
+  const double2* P0 = reinterpret_cast<const double2*>(p0);
+  const double2* P1 = reinterpret_cast<const double2*>(p1);
+  const double2* Q0 = reinterpret_cast<const double2*>(q0);
+  const double2* Q1 = reinterpret_cast<const double2*>(q1);
+  const double2* DN = reinterpret_cast<const double2*>(dn);
+#pragma unroll
+  for (int m = 0; m < KP; ++m) {
+    const double2 d = DN[m], u0 = P0[m], u1 = P1[m], y0 = Q0[m], y1 = Q1[m];
+    const double x0a = u0.x * d.x, x1a = u1.x * d.x, x0b = u0.y * d.y, x1b = u1.y * d.y;
+    a00 = __builtin_fma(x0a, y0.x, a00); a01 = __builtin_fma(x0a, y1.x, a01);
+    a10 = __builtin_fma(x1a, y0.x, a10); a11 = __builtin_fma(x1a, y1.x, a11);
+    a00 = __builtin_fma(x0b, y0.y, a00); a01 = __builtin_fma(x0b, y1.y, a01);
+    a10 = __builtin_fma(x1b, y0.y, a10); a11 = __builtin_fma(x1b, y1.y, a11);
+  }
+}
+
 // K = compile-time block size >= k; the k x k blocks are embedded in K x K ones padded with
 // the identity (padding rows/columns never mix with the real ones).
 // b, x: [nrhs][n*k]; Ust/Hst/Est: [n][K*K] factors (internal layout), Dst: [n][K].
-template <int K, int NT>
+template <int K, int NT, bool PADDED>
 __global__ void __launch_bounds__(NT)
 penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __restrict__ HB,
                  const double* __restrict__ HC, const double* __restrict__ b, double rhs_sign, int nrhs,
@@ -110,52 +139,74 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
                  double* __restrict__ Est, double* __restrict__ Dst, double* __restrict__ dbg) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int nt = NT, KK = K * K, ks = K | 1;
+  constexpr int nt = NT, KK = K * K, ks = (K + 1) & ~1, NW = NT / 64;
   const int kk = k * k;
   const int ncr = 2 * K + nrhs, per_wave = 64 - K;
   const int gj_waves = (ncr + per_wave - 1) / per_wave;
   const size_t nk = (size_t)n * k;
   const PentaLdlLds L = penta_ldl_layout(n, K, nrhs);
   double* Wm = lds + L.W;
-  double* sc = lds + L.sc;
   auto stamp = [&](int i, int ph) {
-    if (dbg && tid == 0) dbg[i * 8 + ph] = (double)__builtin_readcyclecounter();
+    if (dbg && lane == 0) dbg[(wave * (n + 3) + i) * 8 + ph] = (double)__builtin_readcyclecounter();
   };
 
-  // ---- setup: zero the rings, Jacobi factors from diag(C), right-hand sides
-  for (int idx = tid; idx < L.sc; idx += nt) lds[idx] = 0.0;
-  for (int idx = tid; idx < (n + 2) * K; idx += nt) {
-    const int i = idx / K, r = idx - i * K;
-    sc[idx] = (i < n && r < k) ? pow2_rsqrt_scale(HC[(size_t)i * kk + r * k + r]) : 1.0;
-  }
+  // ---- setup
+  for (int idx = tid; idx < L.bl; idx += nt) lds[idx] = 0.0;
   __syncthreads();
-  for (int idx = tid; idx < 3 * K; idx += nt) lds[L.Iv + idx] = 1.0;
+  for (int idx = tid; idx < 3 * ks; idx += nt) lds[L.Iv + idx] = ((idx % ks) < K) ? 1.0 : 0.0;
   for (int idx = tid; idx < L.bl_size; idx += nt) {  // layout [j][i][r] with K rows
     const int j = idx / (n * K), rem = idx - j * (n * K), i = rem / K, r = rem - i * K;
-    lds[L.bl + idx] = (r < k) ? rhs_sign * b[(size_t)j * nk + (size_t)i * k + r] * sc[i * K + r] : 0.0;
+    lds[L.bl + idx] = (r < k) ? rhs_sign * b[(size_t)j * nk + (size_t)i * k + r] : 0.0;
   }
 
-  // register prefetch of the next row's blocks A_i, B_{i+1}, C_i, A_{i+2} (equilibrated, padded)
+  // ---- per-thread prefetch slots of the row inputs [A_i | B_{i+1} | C_i | A_{i+2}] (fixed over
+  // rows).  HA/HB/HC are allocated with two extra zero blocks, so rows i+1, i+2 need no guard.
+  // Exact block size (k == K): the staged layout equals the source layout and a slot is just a
+  // base offset; padded (k < K): slots outside the k x k block hold the identity padding.
   constexpr int PMAX = (4 * KK + nt - 1) / nt;
   double pre[PMAX];
+  int p_off[PMAX];  // element offset of row 0 of this slot's source (in doubles); < 0: padding
+#pragma unroll
+  for (int s = 0; s < PMAX; ++s) {
+    const int idx = tid + s * nt;
+    p_off[s] = -1;
+    if (idx < 4 * KK) {
+      const int which = idx / KK, e = idx - which * KK, c = e / K, r = e - c * K;
+      const int rowshift = (which == 1) ? 1 : ((which == 3) ? 2 : 0);
+      if (!PADDED || (r < k && c < k)) p_off[s] = which * 0x1000000 + rowshift * kk + c * k + r;
+      else p_off[s] = (which == 2 && r == c) ? -2 : -1;  // -2: identity diagonal of C
+    }
+  }
   auto fetch = [&](int i) {
 #pragma unroll
     for (int s = 0; s < PMAX; ++s) {
-      const int idx = tid + s * nt;
-      double val = 0.0;
-      if (idx < 4 * KK && i < n) {
-        const int which = idx / KK, e = idx - which * KK, c = e / K, r = e - c * K;
-        const bool real = r < k && c < k;
-        const int src = c * k + r;
-        if (which == 0) val = (real) ? HA[(size_t)i * kk + src] * (sc[i * K + r] * (i >= 2 ? sc[(i - 2) * K + c] : 1.0)) : 0.0;
-        else if (which == 1) val = (real && i + 1 < n) ? HB[(size_t)(i + 1) * kk + src] * (sc[(i + 1) * K + r] * sc[i * K + c]) : 0.0;
-        else if (which == 2) val = real ? HC[(size_t)i * kk + src] * (sc[i * K + r] * sc[i * K + c]) : ((r == c) ? 1.0 : 0.0);
-        else val = (real && i + 2 < n) ? HA[(size_t)(i + 2) * kk + src] * (sc[(i + 2) * K + r] * sc[i * K + c]) : 0.0;
+      double val = (p_off[s] == -2) ? 1.0 : 0.0;
+      if (p_off[s] >= 0) {
+        const int w = p_off[s] >> 24, off = p_off[s] & 0xffffff;
+        const double* base = (w == 1) ? HB : ((w == 2) ? HC : HA);
+        val = base[(size_t)i * kk + off];
       }
       pre[s] = val;
     }
   };
   fetch(0);
+
+  // ---- per-thread product job (fixed over rows); job type is uniform per wavefront:
+  //   wave 0: tiles of S (lower triangle) ; waves 1..NW-2: tiles of H (+ E copy) ; last wave: y
+  constexpr int T = (K + 1) / 2, nS = T * (T + 1) / 2, nH = T * T;
+  constexpr int NSIT = (nS + 63) / 64;  // S tiles per lane of wavefront 0
+  int jr0[NSIT], jc0[NSIT];
+#pragma unroll
+  for (int it = 0; it < NSIT; ++it) {
+    int t = lane + 64 * it;
+    jr0[it] = -1; jc0[it] = 0;
+    if (wave == 0 && t < nS) {
+      int tr = 0, rem = t;
+      while (rem > tr) { rem -= tr + 1; ++tr; }
+      jr0[it] = 2 * tr; jc0[it] = 2 * rem;
+    }
+  }
+  constexpr int HW = (NW > 2) ? NW - 2 : 1;  // wavefronts working on H tiles
   __syncthreads();
 
   for (int i = 0; i < n; ++i) {
@@ -168,9 +219,9 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
     const double* Etp = lds + L.Et + ((i + 2) % 3) * L.kks;     // Et_{i-1}
     const double* Etpp = lds + L.Et + ((i + 1) % 3) * L.kks;    // Et_{i-2}
     double* Etn = lds + L.Et + (i % 3) * L.kks;                 // Et_i
-    const double* Ivp = lds + L.Iv + ((i + 2) % 3) * K;         // Dn_{i-1}
-    const double* Ivpp = lds + L.Iv + ((i + 1) % 3) * K;        // Dn_{i-2}
-    double* Ivn = lds + L.Iv + (i % 3) * K;
+    const double* Ivp = lds + L.Iv + ((i + 2) % 3) * ks;        // Dn_{i-1}
+    const double* Ivpp = lds + L.Iv + ((i + 1) % 3) * ks;       // Dn_{i-2}
+    double* Ivn = lds + L.Iv + (i % 3) * ks;
     const double* rtp = lds + L.rt + ((i + 2) % 3) * L.rts;
     const double* rtpp = lds + L.rt + ((i + 1) % 3) * L.rts;
     double* rtn = lds + L.rt + (i % 3) * L.rts;
@@ -180,36 +231,22 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
 
     stamp(i, 0);
 #pragma unroll
-    for (int s = 0; s < PMAX; ++s) {
-      const int idx = tid + s * nt;
-      if (idx < 4 * KK) lds[L.in + idx] = pre[s];
-    }
+    for (int s = 0; s < PMAX; ++s)
+      if (tid + s * nt < 4 * KK) lds[L.in + tid + s * nt] = pre[s];
     fetch(i + 1);
+    stamp(i, 7);
     lds_barrier();
     stamp(i, 1);
 
-    // ---- block products: 2x2 register tiles
-    {
-      constexpr int T = (K + 1) / 2;            // tiles per dimension
-      constexpr int nS = T * (T + 1) / 2;       // lower-triangular tiles of S
-      constexpr int nH = T * T;                 // tiles of H
-      const int ny = nrhs * K;                  // one job per (right-hand side, row)
-      for (int job = tid; job < nS + nH + ny; job += nt) {
-        if (job < nS) {
-          // tile (tr, tc), tr >= tc, of S = C - G - Ht^T Dn Ht
-          int tr = 0, rem = job;
-          while (rem > tr) { rem -= tr + 1; ++tr; }
-          const int tc = rem;
-          const int r0 = 2 * tr, r1 = (r0 + 1 < K) ? r0 + 1 : r0, c0 = 2 * tc, c1 = (c0 + 1 < K) ? c0 + 1 : c0;
-          double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
+    // ---- block products
+    if (wave == 0) {
 #pragma unroll
-          for (int m = 0; m < K; ++m) {
-            const double d = Ivp[m];
-            const double p0 = Htp[r0 * ks + m] * d, p1 = Htp[r1 * ks + m] * d;
-            const double q0 = Htp[c0 * ks + m], q1 = Htp[c1 * ks + m];
-            a00 = __builtin_fma(p0, q0, a00); a01 = __builtin_fma(p0, q1, a01);
-            a10 = __builtin_fma(p1, q0, a10); a11 = __builtin_fma(p1, q1, a11);
-          }
+      for (int it = 0; it < NSIT; ++it) {
+        if (jr0[it] >= 0) {  // S = C - G - Ht^T Dn Ht, tile (r0.., c0..), mirrored
+          const int r0 = jr0[it], c0 = jc0[it];
+          const int r1 = (r0 + 1 < K) ? r0 + 1 : r0, c1 = (c0 + 1 < K) ? c0 + 1 : c0;
+          double a00, a01, a10, a11;
+          tile_ptdq<K>(Htp + r0 * ks, Htp + r1 * ks, Htp + c0 * ks, Htp + c1 * ks, Ivp, a00, a01, a10, a11);
           auto put = [&](int r, int c, double acc) {
             const double val = (Ci[c * K + r] - Gb[c * K + r]) - acc;
             Wm[c * ks + r] = val;
@@ -219,42 +256,47 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
           if (c1 != c0) put(r0, c1, a01);
           if (r1 != r0) put(r1, c0, a10);
           if (r1 != r0 && c1 != c0) put(r1, c1, a11);
-        } else if (job < nS + nH) {
-          // tile of H = B_{i+1}^T - Ht^T Dn Et_{i-1}; also E_i = A_{i+2}^T
-          const int t = job - nS, tr = t / T, tc = t - tr * T;
-          const int r0 = 2 * tr, r1 = (r0 + 1 < K) ? r0 + 1 : r0, c0 = 2 * tc, c1 = (c0 + 1 < K) ? c0 + 1 : c0;
-          double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
-#pragma unroll
-          for (int m = 0; m < K; ++m) {
-            const double d = Ivp[m];
-            const double p0 = Htp[r0 * ks + m] * d, p1 = Htp[r1 * ks + m] * d;
-            const double q0 = Etp[c0 * ks + m], q1 = Etp[c1 * ks + m];
-            a00 = __builtin_fma(p0, q0, a00); a01 = __builtin_fma(p0, q1, a01);
-            a10 = __builtin_fma(p1, q0, a10); a11 = __builtin_fma(p1, q1, a11);
-          }
-          auto put = [&](int r, int c, double acc) {
-            Wm[(K + c) * ks + r] = Bn[r * K + c] - acc;       // B_{i+1}^T
-            Wm[(2 * K + c) * ks + r] = An2[r * K + c];        // A_{i+2}^T
-          };
-          put(r0, c0, a00);
-          if (c1 != c0) put(r0, c1, a01);
-          if (r1 != r0) put(r1, c0, a10);
-          if (r1 != r0 && c1 != c0) put(r1, c1, a11);
-        } else {
-          // y = r - Ht^T Dn rt_{i-1} - Et_{i-2}^T Dn rt_{i-2}: one thread per (rhs, row)
-          const int t = job - nS - nH, j = t / K, r = t - j * K;
-          double a0 = 0, a1 = 0;
-#pragma unroll
-          for (int m = 0; m < K; ++m) {
-            a0 = __builtin_fma(Htp[r * ks + m] * Ivp[m], rtp[j * K + m], a0);
-            a1 = __builtin_fma(Etpp[r * ks + m] * Ivpp[m], rtpp[j * K + m], a1);
-          }
-          const double bval = L.bl_size ? lds[L.bl + (j * n + i) * K + r]
-                                        : ((r < k) ? rhs_sign * b[(size_t)j * nk + (size_t)i * k + r] * sc[i * K + r] : 0.0);
-          Wm[(3 * K + j) * ks + r] = (bval - a0) - a1;
         }
       }
+    } else if (NW > 2 && wave <= HW) {  // H = B_{i+1}^T - Ht^T Dn Et_{i-1} ; E = A_{i+2}^T
+      for (int t = (wave - 1) * 64 + lane; t < nH; t += HW * 64) {
+        const int tr = t / T, tc = t - tr * T;
+        const int r0 = 2 * tr, r1 = (r0 + 1 < K) ? r0 + 1 : r0, c0 = 2 * tc, c1 = (c0 + 1 < K) ? c0 + 1 : c0;
+        double a00, a01, a10, a11;
+        tile_ptdq<K>(Htp + r0 * ks, Htp + r1 * ks, Etp + c0 * ks, Etp + c1 * ks, Ivp, a00, a01, a10, a11);
+        auto put = [&](int r, int c, double acc) {
+          Wm[(K + c) * ks + r] = Bn[r * K + c] - acc;
+          Wm[(2 * K + c) * ks + r] = An2[r * K + c];
+        };
+        put(r0, c0, a00);
+        if (c1 != c0) put(r0, c1, a01);
+        if (r1 != r0) put(r1, c0, a10);
+        if (r1 != r0 && c1 != c0) put(r1, c1, a11);
+      }
+    } else {  // y = r - Ht^T Dn rt_{i-1} - Et_{i-2}^T Dn rt_{i-2}: one thread per (rhs, row)
+      for (int t = lane; t < nrhs * K; t += 64) {
+        const int j = t / K, r = t - j * K;
+        double a0 = 0, a1 = 0;
+        {
+          const double2* h2 = reinterpret_cast<const double2*>(Htp + r * ks);
+          const double2* e2 = reinterpret_cast<const double2*>(Etpp + r * ks);
+          const double2* d1 = reinterpret_cast<const double2*>(Ivp);
+          const double2* d2 = reinterpret_cast<const double2*>(Ivpp);
+          const double2* r1 = reinterpret_cast<const double2*>(rtp + j * ks);
+          const double2* r2 = reinterpret_cast<const double2*>(rtpp + j * ks);
+#pragma unroll
+          for (int m = 0; m < (K + 1) / 2; ++m) {
+            const double2 hh = h2[m], ee = e2[m], da = d1[m], db = d2[m], ra = r1[m], rb = r2[m];
+            a0 = __builtin_fma(hh.x * da.x, ra.x, a0); a0 = __builtin_fma(hh.y * da.y, ra.y, a0);
+            a1 = __builtin_fma(ee.x * db.x, rb.x, a1); a1 = __builtin_fma(ee.y * db.y, rb.y, a1);
+          }
+        }
+        const double bval = L.bl_size ? lds[L.bl + (j * n + i) * K + r]
+                                      : ((r < k) ? rhs_sign * b[(size_t)j * nk + (size_t)i * k + r] : 0.0);
+        Wm[(3 * K + j) * ks + r] = (bval - a0) - a1;
+      }
     }
+    stamp(i, 5);
     lds_barrier();
     stamp(i, 2);
 
@@ -263,75 +305,67 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
       const int rc = wave * per_wave + (lane - K);
       const bool is_rhs = lane >= K && rc < ncr;
       const int col = (lane < K) ? lane : (is_rhs ? K + rc : 0);
-      double xr[K], invd[K];
+      double xr[K];
+      {
+        const double2* src = reinterpret_cast<const double2*>(Wm + col * ks);
 #pragma unroll
-      for (int r = 0; r < K; ++r) xr[r] = Wm[col * ks + r];
+        for (int r2 = 0; r2 < K / 2; ++r2) { const double2 t2 = src[r2]; xr[2 * r2] = t2.x; xr[2 * r2 + 1] = t2.y; }
+        if (K & 1) xr[K - 1] = Wm[col * ks + K - 1];
+      }
       stamp(i, 3);
-      ldl_eliminate_wave<K>(xr, invd);
+      const double myinv = ldl_eliminate_wave<K>(xr, lane);
       stamp(i, 4);
-      if (lane < K) {
-        if (wave == 0) {
+      // every lane stores its column: S lanes -> U, rhs lanes -> Ht | Et | rt
+      double* dst = nullptr;
+      if (lane < K) dst = (wave == 0) ? Un + lane * ks : nullptr;
+      else if (is_rhs) dst = (rc < K) ? Htn + rc * ks : ((rc < 2 * K) ? Etn + (rc - K) * ks : rtn + (rc - 2 * K) * ks);
+      if (dst) {
+        double2* d2 = reinterpret_cast<double2*>(dst);
 #pragma unroll
-          for (int r = 0; r < K; ++r) Un[lane * ks + r] = xr[r];
-          double mine = 1.0;
+        for (int r2 = 0; r2 < K / 2; ++r2) d2[r2] = make_double2(xr[2 * r2], xr[2 * r2 + 1]);
+        if (K & 1) dst[K - 1] = xr[K - 1];
+      }
+      if (wave == 0 && lane < K) Ivn[lane] = myinv;
+      if (is_rhs && rc >= 2 * K) {
+        const int j = rc - 2 * K;
+        if (L.bl_size) {
 #pragma unroll
-          for (int j = 0; j < K; ++j) mine = (lane == j) ? invd[j] : mine;
-          Ivn[lane] = mine;
-        }
-      } else if (is_rhs) {
-        if (rc < K) {
-#pragma unroll
-          for (int r = 0; r < K; ++r) Htn[rc * ks + r] = xr[r];
-        } else if (rc < 2 * K) {
-#pragma unroll
-          for (int r = 0; r < K; ++r) Etn[(rc - K) * ks + r] = xr[r];
+          for (int r = 0; r < K; ++r) lds[L.xall + (j * n + i) * K + r] = xr[r];
         } else {
-          const int j = rc - 2 * K;
 #pragma unroll
-          for (int r = 0; r < K; ++r) {
-            rtn[j * K + r] = xr[r];
-            if (L.bl_size) lds[L.xall + (j * n + i) * K + r] = xr[r];
-            else if (r < k) x[(size_t)j * nk + (size_t)i * k + r] = xr[r];  // parked until the backward pass
-          }
+          for (int r = 0; r < K; ++r)
+            if (r < k) x[(size_t)j * nk + (size_t)i * k + r] = xr[r];  // parked until the backward pass
         }
       }
     } else {
       // ---- idle wavefronts: G = Et_{i-1}^T Dn_{i-1} Et_{i-1} for the next row (symmetric) and
       // write-back of the previous row's factors
       const int ht = tid - gj_waves * 64, hn = nt - gj_waves * 64;
-      constexpr int T = (K + 1) / 2, nS = T * (T + 1) / 2;
       for (int job = ht; job < nS; job += hn) {
         int tr = 0, rem = job;
         while (rem > tr) { rem -= tr + 1; ++tr; }
-        const int tc = rem;
-        const int r0 = 2 * tr, r1 = (r0 + 1 < K) ? r0 + 1 : r0, c0 = 2 * tc, c1 = (c0 + 1 < K) ? c0 + 1 : c0;
-        double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
-#pragma unroll
-        for (int m = 0; m < K; ++m) {
-          const double d = Ivp[m];
-          const double p0 = Etp[r0 * ks + m] * d, p1 = Etp[r1 * ks + m] * d;
-          const double q0 = Etp[c0 * ks + m], q1 = Etp[c1 * ks + m];
-          a00 = __builtin_fma(p0, q0, a00); a01 = __builtin_fma(p0, q1, a01);
-          a10 = __builtin_fma(p1, q0, a10); a11 = __builtin_fma(p1, q1, a11);
-        }
-        // NOTE: read by the NEXT row's products (row i+1 needs Et_{i-1}), written here into a
-        // second buffer so that this row's S products (which read G) are not disturbed:
-        // G is consumed before the barrier above, so a single buffer is safe.
+        const int r0 = 2 * tr, r1 = (r0 + 1 < K) ? r0 + 1 : r0, c0 = 2 * rem, c1 = (c0 + 1 < K) ? c0 + 1 : c0;
+        double a00, a01, a10, a11;
+        tile_ptdq<K>(Etp + r0 * ks, Etp + r1 * ks, Etp + c0 * ks, Etp + c1 * ks, Ivp, a00, a01, a10, a11);
         Gb[c0 * K + r0] = a00; Gb[r0 * K + c0] = a00;
         Gb[c1 * K + r0] = a01; Gb[r0 * K + c1] = a01;
         Gb[c0 * K + r1] = a10; Gb[r1 * K + c0] = a10;
         Gb[c1 * K + r1] = a11; Gb[r1 * K + c1] = a11;
       }
       if (i > 0) {
-        for (int idx = ht; idx < KK; idx += hn) {
-          const int c = idx / K, r = idx - c * K;
-          Ust[(size_t)(i - 1) * KK + idx] = Up[c * ks + r];
-          Hst[(size_t)(i - 1) * KK + idx] = Htp[c * ks + r];
-          Est[(size_t)(i - 1) * KK + idx] = Etp[c * ks + r];
+        // factors of row i-1 for the backward pass, ROW-major (stride ks) so that a lane reads its
+        // row with 16-byte loads; U keeps only its upper triangle
+        for (int idx = ht; idx < K * ks; idx += hn) {
+          const int r = idx / ks, c = idx - r * ks;
+          const bool in = c < K;
+          Ust[(size_t)(i - 1) * K * ks + idx] = (in && r <= c) ? Up[c * ks + r] : 0.0;
+          Hst[(size_t)(i - 1) * K * ks + idx] = in ? Htp[c * ks + r] : 0.0;
+          Est[(size_t)(i - 1) * K * ks + idx] = in ? Etp[c * ks + r] : 0.0;
         }
         for (int r = ht; r < K; r += hn) Dst[(size_t)(i - 1) * K + r] = Ivp[r];
       }
     }
+    stamp(i, 6);
     lds_barrier();
   }
   {  // last row's factors
@@ -339,12 +373,13 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
     const double* Ul = lds + L.U + (i & 1) * L.kks;
     const double* Hl = lds + L.Ht + (i & 1) * L.kks;
     const double* El = lds + L.Et + (i % 3) * L.kks;
-    const double* Il = lds + L.Iv + (i % 3) * K;
-    for (int idx = tid; idx < KK; idx += nt) {
-      const int c = idx / K, r = idx - c * K;
-      Ust[(size_t)i * KK + idx] = Ul[c * ks + r];
-      Hst[(size_t)i * KK + idx] = Hl[c * ks + r];
-      Est[(size_t)i * KK + idx] = El[c * ks + r];
+    const double* Il = lds + L.Iv + (i % 3) * ks;
+    for (int idx = tid; idx < K * ks; idx += nt) {
+      const int r = idx / ks, c = idx - r * ks;
+      const bool in = c < K;
+      Ust[(size_t)i * K * ks + idx] = (in && r <= c) ? Ul[c * ks + r] : 0.0;
+      Hst[(size_t)i * K * ks + idx] = in ? Hl[c * ks + r] : 0.0;
+      Est[(size_t)i * K * ks + idx] = in ? El[c * ks + r] : 0.0;
     }
     for (int r = tid; r < K; r += nt) Dst[(size_t)i * K + r] = Il[r];
   }
@@ -354,32 +389,34 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
 
   // ---- backward pass: U_i x_i = rt_i - Ht_i x_{i+1} - Et_i x_{i+2}
   // factors of row i are staged in LDS from a one-row register prefetch; x_{i+1}, x_{i+2} live in
-  // the rt ring (slots (i+1)%3, (i+2)%3); one wavefront per right-hand side:
-  // lane = row + 32 * half for the two mat-vecs, then lane = row for the U back substitution.
-  double* Ub = lds + L.in;       // U_i   (KK, column-major, stride K)
-  double* Hb = Ub + KK;          // Ht_i
-  double* Eb = Hb + KK;          // Et_i
-  double* Db = Eb + KK;          // invd_i (K)
-  constexpr int QMAX = (KK + nt - 1) / nt;
+  // the rt ring; one wavefront per right-hand side: lane = row + 32 * half for the two
+  // mat-vecs, then lane = row for the back substitution with U_i.
+  constexpr int KS2 = K * ks;    // doubles per row-major factor block
+  double* Ub = lds + L.in;       // U_i  (row-major, stride ks, upper triangle)
+  double* Hb = Ub + KS2;         // Ht_i
+  double* Eb = Hb + KS2;         // Et_i
+  double* Db = Eb + KS2;         // invd_i (K)
+  constexpr int QMAX = (KS2 + nt - 1) / nt;
   double pu[QMAX], ph[QMAX], pe[QMAX], pd = 1.0;
   auto fetch_f = [&](int i) {
 #pragma unroll
     for (int s = 0; s < QMAX; ++s) {
       const int idx = tid + s * nt;
-      const bool ok = idx < KK && i >= 0;
-      pu[s] = ok ? Ust[(size_t)i * KK + idx] : 0.0;
-      ph[s] = ok ? Hst[(size_t)i * KK + idx] : 0.0;
-      pe[s] = ok ? Est[(size_t)i * KK + idx] : 0.0;
+      const bool ok = idx < KS2 && i >= 0;
+      pu[s] = ok ? Ust[(size_t)i * KS2 + idx] : 0.0;
+      ph[s] = ok ? Hst[(size_t)i * KS2 + idx] : 0.0;
+      pe[s] = ok ? Est[(size_t)i * KS2 + idx] : 0.0;
     }
     pd = (tid < K && i >= 0) ? Dst[(size_t)i * K + tid] : 1.0;
   };
   fetch_f(n - 1);
-  const int nwaves = nt >> 6;
+  const int r_ = lane & 31, half_ = lane >> 5;
+  constexpr int KP = (K + 1) / 2;
   for (int i = n - 1; i >= 0; --i) {
 #pragma unroll
     for (int s = 0; s < QMAX; ++s) {
       const int idx = tid + s * nt;
-      if (idx < KK) { Ub[idx] = pu[s]; Hb[idx] = ph[s]; Eb[idx] = pe[s]; }
+      if (idx < KS2) { Ub[idx] = pu[s]; Hb[idx] = ph[s]; Eb[idx] = pe[s]; }
     }
     if (tid < K) Db[tid] = pd;
     fetch_f(i - 1);
@@ -387,37 +424,50 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
     const double* x1 = lds + L.rt + ((i + 1) % 3) * L.rts;
     const double* x2 = lds + L.rt + ((i + 2) % 3) * L.rts;
     double* xi = lds + L.rt + (i % 3) * L.rts;
-    for (int j = wave; j < nrhs; j += nwaves) {
-      const int r = lane & 31, half = lane >> 5;
+    for (int j = wave; j < nrhs; j += NW) {
+      const int r = (r_ < K) ? r_ : 0, half = half_;
+      const bool live = r_ < K;
       double acc = 0.0;
-      if (r < K) {
-        const double* Mb = half ? Eb : Hb;
-        const double* xv = (half ? x2 : x1) + j * K;
+      {
+        const double2* Mb = reinterpret_cast<const double2*>((half ? Eb : Hb) + r * ks);
+        const double2* xv = reinterpret_cast<const double2*>((half ? x2 : x1) + j * ks);
         const bool use = half ? (i + 2 < n) : (i + 1 < n);
         if (use) {
 #pragma unroll
-          for (int m = 0; m < K; ++m) acc = __builtin_fma(Mb[m * K + r], xv[m], acc);
+          for (int m = 0; m < KP; ++m) {
+            const double2 a = Mb[m], xx = xv[m];
+            acc = __builtin_fma(a.x, xx.x, acc);
+            acc = __builtin_fma(a.y, xx.y, acc);
+          }
         }
       }
       acc += __shfl_xor(acc, 32);
-      // v = rt_i - acc  (lanes < K of the first half), then back substitution with U_i
-      const double rti = (r < K) ? (L.bl_size ? lds[L.xall + (j * n + i) * K + r]
-                                              : ((r < k) ? x[(size_t)j * nk + (size_t)i * k + r] : 0.0))
-                                 : 0.0;
+      const double rti = L.bl_size ? lds[L.xall + (j * n + i) * K + r]
+                                   : ((r < k) ? x[(size_t)j * nk + (size_t)i * k + r] : 0.0);
       double v = rti - acc;
-      double urow[K];
+      double urow[2 * KP];  // row r of U (zero below the diagonal and in the padding)
+      {
+        const double2* u2 = reinterpret_cast<const double2*>(Ub + r * ks);
 #pragma unroll
-      for (int m = 0; m < K; ++m) urow[m] = (r < K) ? Ub[m * K + r] : 0.0;  // row r of U
-      const double myinv = (r < K) ? Db[r] : 1.0;
+        for (int m = 0; m < KP; ++m) { const double2 t2 = u2[m]; urow[2 * m] = t2.x; urow[2 * m + 1] = t2.y; }
+      }
+      const double myinv = Db[r];
+      double iv[K];
+#pragma unroll
+      for (int jj = 0; jj < K; ++jj) iv[jj] = rdlane(myinv, jj);
+      // back substitution: x_jj = v_jj / U_jj,jj ; v_r -= U_r,jj x_jj (r < jj).  Lanes r >= jj must
+      // keep their value: U_r,jj is zero for r > jj, the diagonal lane is patched by the select.
+      double res = 0.0;
 #pragma unroll
       for (int jj = K - 1; jj >= 0; --jj) {
-        const double vj = rdlane(v, jj) * rdlane(myinv, jj);   // x_jj
-        v = (r == jj) ? vj : ((r < jj) ? __builtin_fma(-urow[jj], vj, v) : v);
+        const double vj = rdlane(v, jj) * iv[jj];
+        res = (r == jj) ? vj : res;
+        v = __builtin_fma(-urow[jj], vj, v);
       }
-      if (half == 0 && r < K) {
-        xi[j * K + r] = v;
-        if (L.bl_size) lds[L.xall + (j * n + i) * K + r] = v;
-        else if (r < k) x[(size_t)j * nk + (size_t)i * k + r] = v * sc[i * K + r];
+      if (half == 0 && live) {
+        xi[j * ks + r] = res;
+        if (L.bl_size) lds[L.xall + (j * n + i) * K + r] = res;
+        else if (r < k) x[(size_t)j * nk + (size_t)i * k + r] = res;
       }
     }
     lds_barrier();
@@ -425,7 +475,7 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
   if (L.bl_size) {
     for (int idx = tid; idx < nrhs * n * k; idx += nt) {
       const int j = idx / (n * k), rem = idx - j * (n * k), i = rem / k, r = rem - i * k;
-      x[idx] = lds[L.xall + (j * n + i) * K + r] * sc[i * K + r];
+      x[idx] = lds[L.xall + (j * n + i) * K + r];
     }
   }
   stamp(n, 1);

@@ -163,8 +163,12 @@ def test_multi_rhs_factor_solve():
         x.zero_()
         dev.factor_solve(rhs.data_ptr(), nrhs, x.data_ptr())
         dev.sync()
-        err = np.abs(x.cpu().numpy() - xe).max() / np.abs(xe).max()
-        assert err < 1e-9, err
+        xf = x.cpu().numpy()
+        Hd = ol.penta_make_dense(*bands)
+        rn = rhs.cpu().numpy()
+        res_fast = np.abs(xf @ Hd - rn).max() / np.abs(rn).max()   # H symmetric
+        res_lu = np.abs(xe @ Hd - rn).max() / np.abs(rn).max()
+        assert res_fast <= 16 * res_lu + 1e-13, (res_fast, res_lu)
     dev.close()
 
 
@@ -186,13 +190,17 @@ def test_update_problem_and_shard():
     assert np.all((s2 == slab_full) | (np.isnan(s2) & np.isnan(slab_full)))
     dev2.grad_hess()
     dev2.factor_solve()
-    assert np.array_equal(dev2.get("step"), p_full)
+    assert np.array_equal(dev2.get("step"), p_full)  # same kernels, same inputs
     # UpdateNominalTrajectory changes the gradient
     prob.q_nom = prob.q_nom + 0.1
     dev.set_problem(prob)
     dev.gn_step()
     orc = Oracle(model, prob, sp)
     g, p = orc.gn_step(q)
-    assert np.array_equal(dev.get("gradient"), g) and np.array_equal(dev.get("step"), p)
+    assert np.array_equal(dev.get("gradient"), g)
+    assert np.abs(dev.get("step") - p).max() <= 1e-6 * np.abs(p).max()
+    dev.set_option("reference_solver", 1)
+    dev.factor_solve()
+    assert np.array_equal(dev.get("step"), p)
     dev.close()
     dev2.close()
