@@ -284,9 +284,10 @@ int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem, co
   bad |= Alloc(c, (size_t)N * c->slab_stride, &c->slab) != 0;
   bad |= Alloc(c, (size_t)(N + 1) * nq, &c->g) != 0;
   // two extra zero blocks: the solver prefetches rows i+1, i+2 without bounds checks
-  bad |= Alloc(c, (size_t)(N + 4) * qq, &c->HA) != 0;
-  bad |= Alloc(c, (size_t)(N + 4) * qq, &c->HB) != 0;
-  bad |= Alloc(c, (size_t)(N + 4) * qq, &c->HC) != 0;
+  // (one allocation: the solver addresses all three bands from HA with 32-bit offsets)
+  bad |= Alloc(c, (size_t)3 * (N + 6) * qq, &c->HA) != 0;
+  c->HB = c->HA + (size_t)(N + 6) * qq;
+  c->HC = c->HB + (size_t)(N + 6) * qq;
   bad |= Alloc(c, (size_t)(N + 1) * nq, &c->step) != 0;
   bad |= Alloc(c, (size_t)1, &c->cost) != 0;
   bad |= Alloc(c, (size_t)(N + 1) * qq, &c->Kst) != 0;
@@ -331,13 +332,15 @@ int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem, co
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-#define LDL_ATTR(KM, PD)                                                                                          \
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_ldl_kernel<KM, 256, PD>),                         \
+#define LDL_ATTR(KM, PD, GW)                                                                                          \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_ldl_kernel<KM, 256, PD, GW>),                         \
                             hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                              \
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_ldl_kernel<KM, 1024, PD>),                        \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_ldl_kernel<KM, 1024, PD, 0>),                        \
                             hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-  LDL_ATTR(2, false) LDL_ATTR(3, false) LDL_ATTR(5, false) LDL_ATTR(19, false) LDL_ATTR(23, false)
-  LDL_ATTR(8, true) LDL_ATTR(16, true) LDL_ATTR(24, true) LDL_ATTR(32, true)
+  LDL_ATTR(2, false, 1) LDL_ATTR(3, false, 1) LDL_ATTR(5, false, 1) LDL_ATTR(19, false, 1) LDL_ATTR(23, false, 2)
+  LDL_ATTR(8, true, 1) LDL_ATTR(16, true, 1) LDL_ATTR(24, true, 2) LDL_ATTR(32, true, 3)
+  LDL_ATTR(2, false, 0) LDL_ATTR(3, false, 0) LDL_ATTR(5, false, 0) LDL_ATTR(19, false, 0) LDL_ATTR(23, false, 0)
+  LDL_ATTR(8, true, 0) LDL_ATTR(16, true, 0) LDL_ATTR(24, true, 0) LDL_ATTR(32, true, 0)
 #undef LDL_ATTR
   if (const char* e = getenv("IDTO_SOLVER_REFERENCE")) c->reference_solver = (e[0] == '1');
   (void)hipGetLastError();
@@ -431,25 +434,28 @@ static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, int nrhs, do
   const int lds = L.end * (int)sizeof(double);
   if (lds > 160 * 1024) { g_err = "right-hand sides do not fit the LDS carve-up"; return -1; }
   double* dbg = c->solver_debug ? c->dbg : nullptr;
-#define LDL_LAUNCH(KM, PD)                                                                                        \
+#define LDL_LAUNCH(KM, PD, GW)                                                                                \
   do {                                                                                                        \
-    if (threads == 256)                                                                                       \
-      hipLaunchKernelGGL((penta_ldl_kernel<KM, 256, PD>), dim3(1), dim3(256), lds, c->stream, n, k, c->HA, c->HB,  \
-                         c->HC, b, sign, nrhs, xo, c->Ust, c->Hst, c->Est, c->Dst, dbg);                       \
+    if (threads == 256 && gj_waves == GW)                                                                     \
+      hipLaunchKernelGGL((penta_ldl_kernel<KM, 256, PD, GW>), dim3(1), dim3(256), lds, c->stream, n, k, c->HA, \
+                         c->HB, c->HC, b, sign, nrhs, xo, c->Ust, c->Hst, c->Est, c->Dst, dbg);                \
+    else if (threads == 256)                                                                                  \
+      hipLaunchKernelGGL((penta_ldl_kernel<KM, 256, PD, 0>), dim3(1), dim3(256), lds, c->stream, n, k, c->HA,  \
+                         c->HB, c->HC, b, sign, nrhs, xo, c->Ust, c->Hst, c->Est, c->Dst, dbg);                \
     else                                                                                                      \
-      hipLaunchKernelGGL((penta_ldl_kernel<KM, 1024, PD>), dim3(1), dim3(1024), lds, c->stream, n, k, c->HA,       \
+      hipLaunchKernelGGL((penta_ldl_kernel<KM, 1024, PD, 0>), dim3(1), dim3(1024), lds, c->stream, n, k, c->HA, \
                          c->HB, c->HC, b, sign, nrhs, xo, c->Ust, c->Hst, c->Est, c->Dst, dbg);                \
   } while (0)
   switch (K) {
-    case 2: LDL_LAUNCH(2, false); break;
-    case 3: LDL_LAUNCH(3, false); break;
-    case 5: LDL_LAUNCH(5, false); break;
-    case 8: LDL_LAUNCH(8, true); break;
-    case 16: LDL_LAUNCH(16, true); break;
-    case 19: LDL_LAUNCH(19, false); break;
-    case 23: LDL_LAUNCH(23, false); break;
-    case 24: LDL_LAUNCH(24, true); break;
-    default: LDL_LAUNCH(32, true); break;
+    case 2: LDL_LAUNCH(2, false, 1); break;
+    case 3: LDL_LAUNCH(3, false, 1); break;
+    case 5: LDL_LAUNCH(5, false, 1); break;
+    case 8: LDL_LAUNCH(8, true, 1); break;
+    case 16: LDL_LAUNCH(16, true, 1); break;
+    case 19: LDL_LAUNCH(19, false, 1); break;
+    case 23: LDL_LAUNCH(23, false, 2); break;
+    case 24: LDL_LAUNCH(24, true, 2); break;
+    default: LDL_LAUNCH(32, true, 3); break;
   }
 #undef LDL_LAUNCH
   HIP_OK(hipGetLastError());

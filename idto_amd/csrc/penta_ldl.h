@@ -76,7 +76,7 @@ __device__ __forceinline__ double ldl_eliminate_wave(double (&xr)[K], int lane) 
 }
 
 struct PentaLdlLds {  // offsets in doubles
-  int W, Ht, Et, Iv, rt, U, G, in, bl, bl_size, xall, end;
+  int W, Ht, Et, Iv, rt, U, G, in, dump, bl, bl_size, xall, end;
   int kks, rts;
 };
 __host__ __device__ inline PentaLdlLds penta_ldl_layout(int n, int K, int nrhs) {
@@ -96,10 +96,12 @@ __host__ __device__ inline PentaLdlLds penta_ldl_layout(int n, int K, int nrhs) 
     const int fwd = 4 * K * K, bwd = 3 * K * ks + ks;
     L.in = o; o += ((fwd > bwd ? fwd : bwd) + 1) & ~1;
   }
+  L.dump = o; o += 2;             // write target of staging lanes without a slot
   L.bl = o;
   L.bl_size = (nrhs * n * K <= 4096) ? nrhs * n * K : 0;
   o += L.bl_size;                 // right-hand sides staged in LDS when small ...
-  L.xall = o; o += L.bl_size;     // ... and rt_i / x_i of every row
+  L.xall = o;                     // ... and rt_i / x_i of every row: [j][n + 2][ks], two leading zero rows
+  o += L.bl_size ? nrhs * (n + 2) * ks : 0;
   L.end = o;
   return L;
 }
@@ -131,7 +133,7 @@ __device__ __forceinline__ void tile_ptdq(const double* p0, const double* p1, co
 // K = compile-time block size >= k; the k x k blocks are embedded in K x K ones padded with
 // the identity (padding rows/columns never mix with the real ones).
 // b, x: [nrhs][n*k]; Ust/Hst/Est: [n][K*K] factors (internal layout), Dst: [n][K].
-template <int K, int NT, bool PADDED>
+template <int K, int NT, bool PADDED, int GJW>
 __global__ void __launch_bounds__(NT)
 penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __restrict__ HB,
                  const double* __restrict__ HC, const double* __restrict__ b, double rhs_sign, int nrhs,
@@ -142,7 +144,7 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
   constexpr int nt = NT, KK = K * K, ks = (K + 1) & ~1, NW = NT / 64;
   const int kk = k * k;
   const int ncr = 2 * K + nrhs, per_wave = 64 - K;
-  const int gj_waves = (ncr + per_wave - 1) / per_wave;
+  const int gj_waves = GJW ? GJW : (ncr + per_wave - 1) / per_wave;
   const size_t nk = (size_t)n * k;
   const PentaLdlLds L = penta_ldl_layout(n, K, nrhs);
   double* Wm = lds + L.W;
@@ -152,6 +154,7 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
 
   // ---- setup
   for (int idx = tid; idx < L.bl; idx += nt) lds[idx] = 0.0;
+  for (int idx = L.xall + tid; idx < L.end; idx += nt) lds[idx] = 0.0;
   __syncthreads();
   for (int idx = tid; idx < 3 * ks; idx += nt) lds[L.Iv + idx] = ((idx % ks) < K) ? 1.0 : 0.0;
   for (int idx = tid; idx < L.bl_size; idx += nt) {  // layout [j][i][r] with K rows
@@ -159,37 +162,70 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
     lds[L.bl + idx] = (r < k) ? rhs_sign * b[(size_t)j * nk + (size_t)i * k + r] : 0.0;
   }
 
-  // ---- per-thread prefetch slots of the row inputs [A_i | B_{i+1} | C_i | A_{i+2}] (fixed over
-  // rows).  HA/HB/HC are allocated with two extra zero blocks, so rows i+1, i+2 need no guard.
-  // Exact block size (k == K): the staged layout equals the source layout and a slot is just a
-  // base offset; padded (k < K): slots outside the k x k block hold the identity padding.
-  constexpr int PMAX = (4 * KK + nt - 1) / nt;
+  // ---- row inputs [A_i | B_{i+1} | C_i | A_{i+2}]: fetched one row ahead into registers and
+  // staged into LDS by the wavefronts that do NOT eliminate, during the elimination of the
+  // previous row: the wavefront on the critical path never waits on vmcnt.  HA/HB/HC carry two
+  // extra zero blocks, so rows i+1, i+2 need no guard.  Exact block size (k == K): the staged
+  // layout equals the source layout; padded (k < K): identity padding.
+  // helper wavefronts (those that do not eliminate): the first one forms G, the others stage /
+  // prefetch / write back; with a single helper wavefront it does everything.
+  const int nhelp = NW - gj_waves;
+  const bool g_wave = wave == gj_waves;                         // forms G
+  const int io_first = (nhelp > 1) ? gj_waves + 1 : gj_waves;   // first wavefront doing the I/O
+  const int ht = tid - io_first * 64;                           // index among the I/O threads (< 0: none)
+  const int hn = nt - io_first * 64;
+  constexpr int HN_MIN = GJW ? ((NT / 64 - GJW > 1) ? NT - (GJW + 1) * 64 : NT - GJW * 64) : 64;
+  constexpr int PMAX = (4 * KK + HN_MIN - 1) / HN_MIN;
+  // Branch-free: every I/O lane loads PMAX values per row through 32-bit offsets from HA (the
+  // three bands live in one allocation); lanes/slots without a source load element 0 and the
+  // result is discarded (m_valid) or replaced by the identity padding (m_load / m_one).
   double pre[PMAX];
-  int p_off[PMAX];  // element offset of row 0 of this slot's source (in doubles); < 0: padding
+  int p_off[PMAX];
+  unsigned long long m_valid = 0, m_load = 0, m_one = 0;
+  static_assert(PMAX <= 64, "slot masks are 64-bit");
+  const int dHB = (int)(HB - HA), dHC = (int)(HC - HA);
 #pragma unroll
   for (int s = 0; s < PMAX; ++s) {
-    const int idx = tid + s * nt;
-    p_off[s] = -1;
-    if (idx < 4 * KK) {
+    const int idx = ht + s * hn;
+    p_off[s] = 0;
+    if (ht >= 0 && idx < 4 * KK) {
+      m_valid |= 1ull << s;
       const int which = idx / KK, e = idx - which * KK, c = e / K, r = e - c * K;
       const int rowshift = (which == 1) ? 1 : ((which == 3) ? 2 : 0);
-      if (!PADDED || (r < k && c < k)) p_off[s] = which * 0x1000000 + rowshift * kk + c * k + r;
-      else p_off[s] = (which == 2 && r == c) ? -2 : -1;  // -2: identity diagonal of C
+      if (!PADDED || (r < k && c < k)) {
+        m_load |= 1ull << s;
+        p_off[s] = ((which == 1) ? dHB : ((which == 2) ? dHC : 0)) + rowshift * kk + c * k + r;
+      } else if (which == 2 && r == c) {
+        m_one |= 1ull << s;
+      }
     }
   }
   auto fetch = [&](int i) {
+    const double* base = HA + (size_t)i * kk;
+#pragma unroll
+    for (int s = 0; s < PMAX; ++s) pre[s] = base[p_off[s]];
+  };
+  auto stage = [&]() {
 #pragma unroll
     for (int s = 0; s < PMAX; ++s) {
-      double val = (p_off[s] == -2) ? 1.0 : 0.0;
-      if (p_off[s] >= 0) {
-        const int w = p_off[s] >> 24, off = p_off[s] & 0xffffff;
-        const double* base = (w == 1) ? HB : ((w == 2) ? HC : HA);
-        val = base[(size_t)i * kk + off];
-      }
-      pre[s] = val;
+      double val = pre[s];
+      if (PADDED) val = (m_load >> s & 1) ? val : ((m_one >> s & 1) ? 1.0 : 0.0);
+      const int dst = (m_valid >> s & 1) ? L.in + ht + s * hn : L.dump;
+      lds[dst] = val;
     }
   };
-  fetch(0);
+  // write-back jobs (fixed over rows): element idx = r*ks + c of the row-major factor blocks;
+  // packed: source offset c*ks + r | r << 16 | (c >= K) << 24 | (r < c < K) << 25
+  constexpr int WBMAX = (K * ks + HN_MIN - 1) / HN_MIN;
+  int wb_src[WBMAX];
+#pragma unroll
+  for (int it = 0; it < WBMAX; ++it) {
+    const int idx = (ht >= 0 ? ht : 0) + it * hn;
+    const int r = (idx / ks < K) ? idx / ks : 0, c = idx - (idx / ks) * ks;
+    const int cc = (c < K) ? c : 0;
+    wb_src[it] = (cc * ks + r) | r << 16 | (c >= K ? 1 : 0) << 24 | ((r < c && c < K) ? 1 : 0) << 25;
+  }
+  if (ht >= 0) { fetch(0); stage(); fetch(1); }
 
   // ---- per-thread product job (fixed over rows); job type is uniform per wavefront:
   //   wave 0: tiles of S (lower triangle) ; waves 1..NW-2: tiles of H (+ E copy) ; last wave: y
@@ -222,20 +258,17 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
     const double* Ivp = lds + L.Iv + ((i + 2) % 3) * ks;        // Dn_{i-1}
     const double* Ivpp = lds + L.Iv + ((i + 1) % 3) * ks;       // Dn_{i-2}
     double* Ivn = lds + L.Iv + (i % 3) * ks;
-    const double* rtp = lds + L.rt + ((i + 2) % 3) * L.rts;
-    const double* rtpp = lds + L.rt + ((i + 1) % 3) * L.rts;
-    double* rtn = lds + L.rt + (i % 3) * L.rts;
+    // rt_i of right-hand side j: ring slot, or row i+2 of xall (then the ring is not used)
+    const int rtj = L.bl_size ? (n + 2) * ks : ks;  // stride between right-hand sides
+    const double* rtp = L.bl_size ? lds + L.xall + (i + 1) * ks : lds + L.rt + ((i + 2) % 3) * L.rts;
+    const double* rtpp = L.bl_size ? lds + L.xall + i * ks : lds + L.rt + ((i + 1) % 3) * L.rts;
+    double* rtn = L.bl_size ? lds + L.xall + (i + 2) * ks : lds + L.rt + (i % 3) * L.rts;
     double* Un = lds + L.U + (i & 1) * L.kks;
     const double* Up = lds + L.U + ((i + 1) & 1) * L.kks;
     double* Gb = lds + L.G;
 
     stamp(i, 0);
-#pragma unroll
-    for (int s = 0; s < PMAX; ++s)
-      if (tid + s * nt < 4 * KK) lds[L.in + tid + s * nt] = pre[s];
-    fetch(i + 1);
     stamp(i, 7);
-    lds_barrier();
     stamp(i, 1);
 
     // ---- block products
@@ -282,8 +315,8 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
           const double2* e2 = reinterpret_cast<const double2*>(Etpp + r * ks);
           const double2* d1 = reinterpret_cast<const double2*>(Ivp);
           const double2* d2 = reinterpret_cast<const double2*>(Ivpp);
-          const double2* r1 = reinterpret_cast<const double2*>(rtp + j * ks);
-          const double2* r2 = reinterpret_cast<const double2*>(rtpp + j * ks);
+          const double2* r1 = reinterpret_cast<const double2*>(rtp + j * rtj);
+          const double2* r2 = reinterpret_cast<const double2*>(rtpp + j * rtj);
 #pragma unroll
           for (int m = 0; m < (K + 1) / 2; ++m) {
             const double2 hh = h2[m], ee = e2[m], da = d1[m], db = d2[m], ra = r1[m], rb = r2[m];
@@ -318,7 +351,7 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
       // every lane stores its column: S lanes -> U, rhs lanes -> Ht | Et | rt
       double* dst = nullptr;
       if (lane < K) dst = (wave == 0) ? Un + lane * ks : nullptr;
-      else if (is_rhs) dst = (rc < K) ? Htn + rc * ks : ((rc < 2 * K) ? Etn + (rc - K) * ks : rtn + (rc - 2 * K) * ks);
+      else if (is_rhs) dst = (rc < K) ? Htn + rc * ks : ((rc < 2 * K) ? Etn + (rc - K) * ks : rtn + (rc - 2 * K) * rtj);
       if (dst) {
         double2* d2 = reinterpret_cast<double2*>(dst);
 #pragma unroll
@@ -326,41 +359,47 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
         if (K & 1) dst[K - 1] = xr[K - 1];
       }
       if (wave == 0 && lane < K) Ivn[lane] = myinv;
-      if (is_rhs && rc >= 2 * K) {
+      if (!L.bl_size && is_rhs && rc >= 2 * K) {
         const int j = rc - 2 * K;
-        if (L.bl_size) {
 #pragma unroll
-          for (int r = 0; r < K; ++r) lds[L.xall + (j * n + i) * K + r] = xr[r];
-        } else {
-#pragma unroll
-          for (int r = 0; r < K; ++r)
-            if (r < k) x[(size_t)j * nk + (size_t)i * k + r] = xr[r];  // parked until the backward pass
-        }
+        for (int r = 0; r < K; ++r)
+          if (r < k) x[(size_t)j * nk + (size_t)i * k + r] = xr[r];  // parked until the backward pass
       }
     } else {
-      // ---- idle wavefronts: G = Et_{i-1}^T Dn_{i-1} Et_{i-1} for the next row (symmetric) and
-      // write-back of the previous row's factors
-      const int ht = tid - gj_waves * 64, hn = nt - gj_waves * 64;
-      for (int job = ht; job < nS; job += hn) {
-        int tr = 0, rem = job;
-        while (rem > tr) { rem -= tr + 1; ++tr; }
-        const int r0 = 2 * tr, r1 = (r0 + 1 < K) ? r0 + 1 : r0, c0 = 2 * rem, c1 = (c0 + 1 < K) ? c0 + 1 : c0;
-        double a00, a01, a10, a11;
-        tile_ptdq<K>(Etp + r0 * ks, Etp + r1 * ks, Etp + c0 * ks, Etp + c1 * ks, Ivp, a00, a01, a10, a11);
-        Gb[c0 * K + r0] = a00; Gb[r0 * K + c0] = a00;
-        Gb[c1 * K + r0] = a01; Gb[r0 * K + c1] = a01;
-        Gb[c0 * K + r1] = a10; Gb[r1 * K + c0] = a10;
-        Gb[c1 * K + r1] = a11; Gb[r1 * K + c1] = a11;
+      // ---- helper wavefronts
+      if (ht >= 0) {  // stage the next row's inputs, prefetch the one after
+        stage();
+        stamp(i, 3);
+        fetch(i + 2);
+        stamp(i, 4);
       }
-      if (i > 0) {
+      if (g_wave) {   // G = Et_{i-1}^T Dn_{i-1} Et_{i-1} for the next row (symmetric)
+        for (int job = lane; job < nS; job += 64) {
+          int tr = 0, rem = job;
+          while (rem > tr) { rem -= tr + 1; ++tr; }
+          const int r0 = 2 * tr, r1 = (r0 + 1 < K) ? r0 + 1 : r0, c0 = 2 * rem, c1 = (c0 + 1 < K) ? c0 + 1 : c0;
+          double a00, a01, a10, a11;
+          tile_ptdq<K>(Etp + r0 * ks, Etp + r1 * ks, Etp + c0 * ks, Etp + c1 * ks, Ivp, a00, a01, a10, a11);
+          Gb[c0 * K + r0] = a00; Gb[r0 * K + c0] = a00;
+          Gb[c1 * K + r0] = a01; Gb[r0 * K + c1] = a01;
+          Gb[c0 * K + r1] = a10; Gb[r1 * K + c0] = a10;
+          Gb[c1 * K + r1] = a11; Gb[r1 * K + c1] = a11;
+        }
+      }
+      if (ht >= 0 && i > 0) {
         // factors of row i-1 for the backward pass, ROW-major (stride ks) so that a lane reads its
-        // row with 16-byte loads; U keeps only its upper triangle
-        for (int idx = ht; idx < K * ks; idx += hn) {
-          const int r = idx / ks, c = idx - r * ks;
-          const bool in = c < K;
-          Ust[(size_t)(i - 1) * K * ks + idx] = (in && r <= c) ? Up[c * ks + r] : 0.0;
-          Hst[(size_t)(i - 1) * K * ks + idx] = in ? Htp[c * ks + r] : 0.0;
-          Est[(size_t)(i - 1) * K * ks + idx] = in ? Etp[c * ks + r] : 0.0;
+        // row with 16-byte loads; rows are scaled by 1/d_r, U keeps its strict upper triangle
+#pragma unroll
+        for (int it = 0; it < WBMAX; ++it) {
+          const int idx = ht + it * hn;
+          if (idx < K * ks) {
+            const int src = wb_src[it] & 0xffff, r = wb_src[it] >> 16 & 0xff;
+            const bool in = !(wb_src[it] >> 24 & 1), up = wb_src[it] >> 25 & 1;
+            const double dr = Ivp[r];
+            Ust[(size_t)(i - 1) * K * ks + idx] = up ? Up[src] * dr : 0.0;
+            Hst[(size_t)(i - 1) * K * ks + idx] = in ? Htp[src] * dr : 0.0;
+            Est[(size_t)(i - 1) * K * ks + idx] = in ? Etp[src] * dr : 0.0;
+          }
         }
         for (int r = ht; r < K; r += hn) Dst[(size_t)(i - 1) * K + r] = Ivp[r];
       }
@@ -377,9 +416,10 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
     for (int idx = tid; idx < K * ks; idx += nt) {
       const int r = idx / ks, c = idx - r * ks;
       const bool in = c < K;
-      Ust[(size_t)i * K * ks + idx] = (in && r <= c) ? Ul[c * ks + r] : 0.0;
-      Hst[(size_t)i * K * ks + idx] = in ? Hl[c * ks + r] : 0.0;
-      Est[(size_t)i * K * ks + idx] = in ? El[c * ks + r] : 0.0;
+      const double dr = Il[r];
+      Ust[(size_t)i * K * ks + idx] = (in && r < c) ? Ul[c * ks + r] * dr : 0.0;
+      Hst[(size_t)i * K * ks + idx] = in ? Hl[c * ks + r] * dr : 0.0;
+      Est[(size_t)i * K * ks + idx] = in ? El[c * ks + r] * dr : 0.0;
     }
     for (int r = tid; r < K; r += nt) Dst[(size_t)i * K + r] = Il[r];
   }
@@ -387,95 +427,73 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
   __threadfence_block();
   stamp(n, 0);
 
-  // ---- backward pass: U_i x_i = rt_i - Ht_i x_{i+1} - Et_i x_{i+2}
-  // factors of row i are staged in LDS from a one-row register prefetch; x_{i+1}, x_{i+2} live in
-  // the rt ring; one wavefront per right-hand side: lane = row + 32 * half for the two
-  // mat-vecs, then lane = row for the back substitution with U_i.
-  constexpr int KS2 = K * ks;    // doubles per row-major factor block
-  double* Ub = lds + L.in;       // U_i  (row-major, stride ks, upper triangle)
-  double* Hb = Ub + KS2;         // Ht_i
-  double* Eb = Hb + KS2;         // Et_i
-  double* Db = Eb + KS2;         // invd_i (K)
-  constexpr int QMAX = (KS2 + nt - 1) / nt;
-  double pu[QMAX], ph[QMAX], pe[QMAX], pd = 1.0;
-  auto fetch_f = [&](int i) {
-#pragma unroll
-    for (int s = 0; s < QMAX; ++s) {
-      const int idx = tid + s * nt;
-      const bool ok = idx < KS2 && i >= 0;
-      pu[s] = ok ? Ust[(size_t)i * KS2 + idx] : 0.0;
-      ph[s] = ok ? Hst[(size_t)i * KS2 + idx] : 0.0;
-      pe[s] = ok ? Est[(size_t)i * KS2 + idx] : 0.0;
-    }
-    pd = (tid < K && i >= 0) ? Dst[(size_t)i * K + tid] : 1.0;
-  };
-  fetch_f(n - 1);
+  // ---- backward pass: (D_i^-1 U_i) x_i = D_i^-1 rt_i - (D_i^-1 Ht_i) x_{i+1} - (D_i^-1 Et_i) x_{i+2}
+  // One wavefront per right-hand side, no LDS staging and no barrier: lane = row r (+32 for the
+  // second half).  The first half holds row r of D^-1 Ht_i, the second half row r of D^-1 Et_i,
+  // both halves row r of the unit upper triangular D^-1 U_i (strict upper part; rows are
+  // 16-byte loads straight from HBM, prefetched one block row ahead in a second register set).
+  // x_{i+1}, x_{i+2} are wave-uniform (the back substitution produces each x_j by v_readlane).
+  constexpr int KS2 = K * ks, KP = (K + 1) / 2;
   const int r_ = lane & 31, half_ = lane >> 5;
-  constexpr int KP = (K + 1) / 2;
-  for (int i = n - 1; i >= 0; --i) {
+  const int rr = (r_ < K) ? r_ : 0;
+  const bool live = r_ < K && half_ == 0;
+  for (int j = wave; j < nrhs; j += NW) {
+    double xs1[2 * KP], xs2[2 * KP];  // x_{i+1}, x_{i+2}, wave-uniform
 #pragma unroll
-    for (int s = 0; s < QMAX; ++s) {
-      const int idx = tid + s * nt;
-      if (idx < KS2) { Ub[idx] = pu[s]; Hb[idx] = ph[s]; Eb[idx] = pe[s]; }
-    }
-    if (tid < K) Db[tid] = pd;
-    fetch_f(i - 1);
-    lds_barrier();
-    const double* x1 = lds + L.rt + ((i + 1) % 3) * L.rts;
-    const double* x2 = lds + L.rt + ((i + 2) % 3) * L.rts;
-    double* xi = lds + L.rt + (i % 3) * L.rts;
-    for (int j = wave; j < nrhs; j += NW) {
-      const int r = (r_ < K) ? r_ : 0, half = half_;
-      const bool live = r_ < K;
-      double acc = 0.0;
-      {
-        const double2* Mb = reinterpret_cast<const double2*>((half ? Eb : Hb) + r * ks);
-        const double2* xv = reinterpret_cast<const double2*>((half ? x2 : x1) + j * ks);
-        const bool use = half ? (i + 2 < n) : (i + 1 < n);
-        if (use) {
+    for (int c = 0; c < 2 * KP; ++c) { xs1[c] = 0.0; xs2[c] = 0.0; }
+    double2 A0[KP], U0[KP], A1[KP], U1[KP];
+    double dv0 = 1.0, dv1 = 1.0, rt0 = 0.0, rt1 = 0.0;
+    auto load_row = [&](int i, double2 (&A)[KP], double2 (&U)[KP], double& dv, double& rtv) {
+      if (i < 0) return;
+      const double2* a = reinterpret_cast<const double2*>((half_ ? Est : Hst) + (size_t)i * KS2 + rr * ks);
+      const double2* u = reinterpret_cast<const double2*>(Ust + (size_t)i * KS2 + rr * ks);
 #pragma unroll
-          for (int m = 0; m < KP; ++m) {
-            const double2 a = Mb[m], xx = xv[m];
-            acc = __builtin_fma(a.x, xx.x, acc);
-            acc = __builtin_fma(a.y, xx.y, acc);
-          }
-        }
+      for (int m = 0; m < KP; ++m) { A[m] = a[m]; U[m] = u[m]; }
+      dv = Dst[(size_t)i * K + rr];
+      rtv = L.bl_size ? lds[L.xall + (j * (n + 2) + i + 2) * ks + rr]
+                      : ((rr < k) ? x[(size_t)j * nk + (size_t)i * k + rr] : 0.0);
+    };
+    // xa = x_{i+1}, xb = x_{i+2}; x_i overwrites xb (roles swap from row to row: no copies)
+    auto solve_row = [&](int i, const double2 (&A)[KP], const double2 (&U)[KP], double dv, double rtv,
+                         double (&xa)[2 * KP], double (&xb)[2 * KP]) {
+      double acca = 0.0, accb = 0.0;  // both products per lane (uniform operands), one select after
+#pragma unroll
+      for (int m = 0; m < KP; ++m) {
+        acca = __builtin_fma(A[m].x, xa[2 * m], acca);
+        acca = __builtin_fma(A[m].y, xa[2 * m + 1], acca);
+        accb = __builtin_fma(A[m].x, xb[2 * m], accb);
+        accb = __builtin_fma(A[m].y, xb[2 * m + 1], accb);
       }
+      double acc = half_ ? accb : acca;
       acc += __shfl_xor(acc, 32);
-      const double rti = L.bl_size ? lds[L.xall + (j * n + i) * K + r]
-                                   : ((r < k) ? x[(size_t)j * nk + (size_t)i * k + r] : 0.0);
-      double v = rti - acc;
-      double urow[2 * KP];  // row r of U (zero below the diagonal and in the padding)
-      {
-        const double2* u2 = reinterpret_cast<const double2*>(Ub + r * ks);
-#pragma unroll
-        for (int m = 0; m < KP; ++m) { const double2 t2 = u2[m]; urow[2 * m] = t2.x; urow[2 * m + 1] = t2.y; }
-      }
-      const double myinv = Db[r];
-      double iv[K];
-#pragma unroll
-      for (int jj = 0; jj < K; ++jj) iv[jj] = rdlane(myinv, jj);
-      // back substitution: x_jj = v_jj / U_jj,jj ; v_r -= U_r,jj x_jj (r < jj).  Lanes r >= jj must
-      // keep their value: U_r,jj is zero for r > jj, the diagonal lane is patched by the select.
-      double res = 0.0;
+      double v = __builtin_fma(rtv, dv, -acc);
 #pragma unroll
       for (int jj = K - 1; jj >= 0; --jj) {
-        const double vj = rdlane(v, jj) * iv[jj];
-        res = (r == jj) ? vj : res;
-        v = __builtin_fma(-urow[jj], vj, v);
+        const double xj = rdlane(v, jj);
+        xb[jj] = xj;
+        const double ujj = (jj & 1) ? U[jj / 2].y : U[jj / 2].x;
+        v = __builtin_fma(-ujj, xj, v);   // U is strictly upper: lanes >= jj keep their value
       }
-      if (half == 0 && live) {
-        xi[j * ks + r] = res;
-        if (L.bl_size) lds[L.xall + (j * n + i) * K + r] = res;
-        else if (r < k) x[(size_t)j * nk + (size_t)i * k + r] = res;
+      if (live) {
+        if (L.bl_size) lds[L.xall + (j * (n + 2) + i + 2) * ks + r_] = v;
+        else if (r_ < k) x[(size_t)j * nk + (size_t)i * k + r_] = v;
+      }
+    };
+    load_row(n - 1, A0, U0, dv0, rt0);
+    for (int i = n - 1; i >= 0; i -= 2) {
+      load_row(i - 1, A1, U1, dv1, rt1);
+      solve_row(i, A0, U0, dv0, rt0, xs1, xs2);       // x_i -> xs2
+      if (i - 1 >= 0) {
+        load_row(i - 2, A0, U0, dv0, rt0);
+        solve_row(i - 1, A1, U1, dv1, rt1, xs2, xs1);  // x_{i-1} -> xs1 ; then xs1 = x_{i-1}, xs2 = x_i
       }
     }
-    lds_barrier();
   }
+  __syncthreads();
   if (L.bl_size) {
     for (int idx = tid; idx < nrhs * n * k; idx += nt) {
       const int j = idx / (n * k), rem = idx - j * (n * k), i = rem / k, r = rem - i * k;
-      x[idx] = lds[L.xall + (j * n + i) * K + r];
+      x[idx] = lds[L.xall + (j * (n + 2) + i + 2) * ks + r];
     }
   }
   stamp(n, 1);

@@ -43,3 +43,10 @@ for w in range(4):
     rel = lambda col: np.median((rows[:, col] - base)[2:-1])
     nxt = np.median((rows[1:, 0] - base[:-1])[2:])
     print(f"  wave {w}: {rel(7):7.0f} {rel(1):7.0f} {rel(5):7.0f} {rel(2):7.0f} {rel(6):7.0f}   {nxt:7.0f}")
+
+print("helper I/O waves: [after stage, after fetch, before b3] relative to after-b2")
+for w in (2, 3):
+    d = dall[w * (n + 3) * 8:(w + 1) * (n + 3) * 8].reshape(-1, 8)
+    rows = d[:n]
+    f = lambda a, b: np.median((rows[:, a] - rows[:, b])[2:-1])
+    print(f"  wave {w}: {f(3, 2):7.0f} {f(4, 2):7.0f} {f(6, 2):7.0f}")
