@@ -8,13 +8,18 @@ factor + solve H p = -g   (reference optimizer/trajectory_optimi
 `idto_hip_gn_step` of the C-ABI.  fp64, synthetic trajectory,
 inputs resident in HBM before the timed region.
 
-Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode shard|replicas]
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode replicas|shard]
 For N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`:
-  shard    (default) the (t, i) perturbation grid is split into contiguous t-ranges, one per
-           rank; one all-gather (RCCL) of the dtau/dq slabs, then every rank assembles and
-           solves redundantly.  ONE problem: value = its iterations/s ("strong").
-  replicas every rank iterates its own copy of the problem (BASELINE config 5 style);
-           value = sum of iterations/s ("weak").
+  replicas (default) every rank iterates its own problem (same model and horizon, trajectory
+           seed = rank; BASELINE config 5 style) with no data-path collective;
+           value = total iterations/s over all ranks ("weak").  After the timed region the
+           sharded mode below is ALSO measured for a few steps and reported under
+           "shard_mode" so that the RCCL exchange has a number on the same run.
+  shard    ONE problem: the (k, column) perturbation grid is split into contiguous k-ranges,
+           one per rank; one all-gather (RCCL) of the dtau/dq slab, then every rank assembles
+           and solves redundantly; value = that problem's iterations/s ("strong").
+           One MI355X already runs all N=40 fd blocks concurrently (40 of 256 CUs), so this
+           mode cannot beat one GPU at this size: DESIGN.md §7.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -36,7 +41,7 @@ from idto_amd.model import load_model  # noqa: E402
 from idto_amd.problem import load_config, make_problem, synthetic_trajectory  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-KERNELS = ["fd_kernel", "assemble_kernel", "penta_kernel"]
+KERNELS = ["fd_kernel", "assemble_diag_kernel", "penta_ldl_kernel"]
 
 
 def algorithmic_bytes(N, nq, nv):
@@ -46,6 +51,21 @@ def algorithmic_bytes(N, nq, nv):
     asm = 8 * (part + hband + (N + 1) * nq + (N + 1) * nv + N * nv + (N + 1) * nq)
     penta = 8 * (hband + 2 * fact + 2 * (N + 1) * nq)
     return [fd, asm, penta]
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate
+    FETCH_SIZE and WRITE_SIZE runs of this same command, tools/gpu_check.sh ->
+    tools/pmc_summarize.py): FETCH_SIZE doubled per the gfx950 correction of
+    MI355X_MICROARCH.md, WRITE_SIZE raw.  None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    e = json.load(open(files[-1])).get(kernel)
+    if not e or "fetch_bytes_per_launch_x2" not in e or "write_bytes_per_launch_raw" not in e:
+        return None, None
+    return e["fetch_bytes_per_launch_x2"] + e["write_bytes_per_launch_raw"], os.path.relpath(files[-1], ROOT)
 
 
 def cpu_baseline(model, prob, sp, q, budget_s=12.0):
@@ -76,7 +96,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--mode", choices=["shard", "replicas"], default="shard")
+    ap.add_argument("--mode", choices=["shard", "replicas"], default="replicas")
     ap.add_argument("--config", default="mini_cheetah")
     ap.add_argument("--num-steps", type=int, default=40, help="horizon N")
     ap.add_argument("--no-cpu", action="store_true")
@@ -100,7 +120,9 @@ def main():
     prob, sp, _ = make_problem(cfg, model, num_steps=N)
     sp.scaling = False
     sp.equality_constraints = False
-    q = synthetic_trajectory(cfg, model, N, seed=0, lower=0.01)
+    sharded = world > 1 and args.mode == "shard"
+    # replicas: every rank its own trajectory; shard / single GPU: the BASELINE trajectory (seed 0)
+    q = synthetic_trajectory(cfg, model, N, seed=(0 if sharded else rank), lower=0.01)
     nq, nv = model.nq, model.nv
 
     dev = hip.HipPath(model, prob, sp, device=local_rank)
@@ -108,28 +130,25 @@ def main():
     dev.set_stream(stream.cuda_stream)
     dev.set_q(q)
 
-    sharded = world > 1 and args.mode == "shard"
-    slab_t = None
-    if sharded:
-        assert N % world == 0, "N must be divisible by the number of GPUs for the t-range shard"
-        per = N // world
-        dev.set_shard(rank * per, (rank + 1) * per)
-        stride = dev.slab_stride
+    exch = None
+    if world > 1:
+        from idto_amd.multi_gpu import SlabExchange, device_slab_view
+        exch = SlabExchange(dist, device_slab_view(dev, N), N, dev.slab_stride, rank, world)
 
-        class _Ptr:  # zero-copy view of the resident slab as a torch tensor
-            __cuda_array_interface__ = {"shape": (N * stride,), "typestr": "<f8",
-                                        "data": (dev.device_ptr("slab"), False), "version": 2}
-        slab_t = torch.as_tensor(_Ptr(), device=f"cuda:{local_rank}")
-        mine = slab_t[rank * per * stride:(rank + 1) * per * stride]
+    def step_sharded():
+        dev.eval_partials()
+        exch.gather()
+        dev.grad_hess()
+        dev.factor_solve()
 
     def step():
         if sharded:
-            dev.eval_partials()
-            dist.all_gather_into_tensor(slab_t, mine)
-            dev.grad_hess()
-            dev.factor_solve()
+            step_sharded()
         else:
             dev.gn_step()
+
+    if sharded:
+        dev.set_shard(exch.lo, exch.hi)
 
     def barrier():
         if dist is not None:
@@ -161,6 +180,30 @@ def main():
     g = dev.get("gradient")
     assert np.all(np.isfinite(p)) and np.all(np.isfinite(g))
 
+    shard_extra = None
+    if world > 1 and not sharded:
+        # the sharded single-problem mode on the same ranks (outside the timed region of `value`)
+        dev.set_q(synthetic_trajectory(cfg, model, N, seed=0, lower=0.01))
+        dev.gn_step()
+        p_ref = dev.get("step")
+        dev.set_shard(exch.lo, exch.hi)
+        ns = max(10, args.steps // 4)
+        for _ in range(5):
+            step_sharded()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(ns):
+            step_sharded()
+        barrier()
+        el = time.perf_counter() - t1
+        tt = torch.tensor([el], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        same = bool(np.array_equal(dev.get("step"), p_ref))   # sharded result == single-GPU result, bit for bit
+        shard_extra = {"value": ns / float(tt.item()), "unit": "GN iters/s (one problem)", "steps": ns,
+                       "ms_per_step": 1e3 * float(tt.item()) / ns, "scaling": "strong",
+                       "bit_identical_to_unsharded": same,
+                       "exchange": f"all_gather_into_tensor of {N * dev.slab_stride * 8} B slab over {world} ranks"}
+
     units = args.steps * (world if (world > 1 and not sharded) else 1)
     value = units / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
@@ -170,11 +213,12 @@ def main():
         dom = int(np.argmax([k[0] for k in kern]))
         dur_s = kern[dom][0] * 1e-3
         achieved = algb[dom] / dur_s / 1e9 if dur_s > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(KERNELS[dom])
         out = {
             "metric": "Gauss-Newton iters/sec (grad+Hessian+solve), mini_cheetah N=40",
             "value": value, "unit": "GN iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong" if (sharded or world == 1) else "weak",
+            "scaling": "strong" if sharded else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config} (nq={nq}, nv={nv}, {model.npairs} contact pairs), horizon N={N}, "
                                    f"dt={prob.time_step}, forward differences, one Gauss-Newton iteration per step",
@@ -183,12 +227,15 @@ def main():
                                         f"of the dtau/dq slabs, redundant assemble+solve" if sharded else
                                         f"{world} independent replicas"))},
             "roofline": {"bound": "hbm", "kernel": KERNELS[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algb[dom], "avg_launch_ms": kern[dom][0],
                          "launches_timed": kern[dom][1],
                          "all_kernels_avg_ms": {KERNELS[i]: kern[i][0] for i in range(3)},
                          "note": "latency/dependency-bound path (SURVEY.md §8d): HBM fraction is intrinsically small"},
         }
+        if shard_extra is not None:
+            out["shard_mode"] = shard_extra
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, prob, sp, q)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

@@ -67,6 +67,7 @@ struct idto_hip_ctx {
   bool timing = false;
   struct Timed { hipEvent_t a, b; int which; };
   std::vector<Timed> pending;
+  std::vector<hipEvent_t> event_pool;  // recycled: creating events in the timed loop costs host time
   double tsum[3] = {0, 0, 0};
   int tcnt[3] = {0, 0, 0};
 };
@@ -216,8 +217,15 @@ int TimeBegin(idto_hip_ctx* c, int which) {
   if (!c->timing) return 0;
   idto_hip_ctx::Timed t;
   t.which = which;
-  HIP_OK(hipEventCreate(&t.a));
-  HIP_OK(hipEventCreate(&t.b));
+  hipEvent_t* ev[2] = {&t.a, &t.b};
+  for (hipEvent_t* e : ev) {
+    if (c->event_pool.empty()) {
+      HIP_OK(hipEventCreate(e));
+    } else {
+      *e = c->event_pool.back();
+      c->event_pool.pop_back();
+    }
+  }
   HIP_OK(hipEventRecord(t.a, c->stream));
   c->pending.push_back(t);
   return 0;
@@ -234,8 +242,8 @@ int TimeDrain(idto_hip_ctx* c) {
     HIP_OK(hipEventElapsedTime(&ms, t.a, t.b));
     c->tsum[t.which] += ms;
     c->tcnt[t.which] += 1;
-    (void)hipEventDestroy(t.a);
-    (void)hipEventDestroy(t.b);
+    c->event_pool.push_back(t.a);
+    c->event_pool.push_back(t.b);
   }
   c->pending.clear();
   return 0;
@@ -352,7 +360,8 @@ void idto_hip_destroy(idto_hip_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (auto& t : c->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+  (void)TimeDrain(c);
+  for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
