@@ -1,0 +1,630 @@
+// trajectory_optimizer.cc — host side of idto::optimizer::TrajectoryOptimizer<double>
+// (include/idto/optimizer/trajectory_optimizer.h) written directly on the C-ABI of
+// libidto_hip.so.  What runs where:
+//   device (include/idto_hip.h): N+, v, a, tau, cost, dtau/dq, gradient, Hessian bands,
+//                                every linear solve with H;
+//   host (this file):            the O(num_vars) bookkeeping of one trust-region iteration,
+//                                following reference optimizer/trajectory_optimizer.cc
+//                                ("TO.cc") function by function (cited at each one).
+// Nothing here evaluates dynamics or factorises H: without the HIP library/device the
+// constructor throws.
+#include "idto/optimizer/trajectory_optimizer.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <limits>
+#include <string>
+
+namespace idto {
+namespace optimizer {
+
+namespace {
+
+using Vec = std::vector<double>;
+
+double Dot(const Vec& a, const Vec& b) {
+  double s = 0;
+  for (std::size_t i = 0; i < a.size(); ++i) s += a[i] * b[i];
+  return s;
+}
+double Norm(const Vec& a) { return std::sqrt(Dot(a, a)); }
+
+Vec Flatten(const std::vector<Vec>& x) {
+  Vec out;
+  for (const Vec& xi : x) out.insert(out.end(), xi.begin(), xi.end());
+  return out;
+}
+std::vector<Vec> Unflatten(const Vec& flat, int count, int width) {
+  std::vector<Vec> out((std::size_t)count, Vec((std::size_t)width));
+  for (int t = 0; t < count; ++t)
+    std::copy(flat.begin() + (std::size_t)t * width, flat.begin() + (std::size_t)(t + 1) * width, out[t].begin());
+  return out;
+}
+std::vector<MatrixXd> UnflattenBlocks(const Vec& flat, int count, int rows, int cols) {
+  std::vector<MatrixXd> out((std::size_t)count, MatrixXd(rows, cols));
+  for (int t = 0; t < count; ++t)
+    std::copy(flat.begin() + (std::size_t)t * rows * cols, flat.begin() + (std::size_t)(t + 1) * rows * cols,
+              out[t].data());
+  return out;
+}
+
+// Solves the symmetric positive (semi-)definite n x n system S x = b in place with an LDL^T
+// factorisation with diagonal pivoting (what Eigen's ldlt() does for the reference at
+// TO.cc:1395); S is column-major and is overwritten.
+void DenseLdltSolve(std::vector<double>* S_io, int n, double* b) {
+  std::vector<double>& S = *S_io;
+  std::vector<int> perm((std::size_t)n);
+  for (int i = 0; i < n; ++i) perm[i] = i;
+  auto at = [&](int r, int c) -> double& { return S[(std::size_t)c * n + r]; };
+  for (int j = 0; j < n; ++j) {
+    int p = j;
+    for (int i = j + 1; i < n; ++i)
+      if (std::fabs(at(i, i)) > std::fabs(at(p, p))) p = i;
+    if (p != j) {  // symmetric row/column swap
+      for (int i = 0; i < n; ++i) std::swap(at(i, j), at(i, p));
+      for (int i = 0; i < n; ++i) std::swap(at(j, i), at(p, i));
+      std::swap(perm[j], perm[p]);
+    }
+    const double d = at(j, j);
+    if (d == 0.0) continue;  // exactly singular direction: leave it (Eigen does the same)
+    for (int i = j + 1; i < n; ++i) at(i, j) /= d;
+    for (int c = j + 1; c < n; ++c) {
+      const double f = at(c, j) * d;
+      if (f == 0.0) continue;
+      for (int r = c; r < n; ++r) at(r, c) -= at(r, j) * f;
+    }
+    for (int c = j + 1; c < n; ++c)  // keep the full matrix symmetric for later swaps
+      for (int r = c + 1; r < n; ++r) at(c, r) = at(r, c);
+  }
+  std::vector<double> y((std::size_t)n);
+  for (int i = 0; i < n; ++i) y[i] = b[perm[i]];
+  for (int j = 0; j < n; ++j)
+    for (int i = j + 1; i < n; ++i) y[i] -= at(i, j) * y[j];
+  for (int j = 0; j < n; ++j) y[j] = (at(j, j) != 0.0) ? y[j] / at(j, j) : 0.0;
+  for (int j = n - 1; j >= 0; --j)
+    for (int i = j + 1; i < n; ++i) y[j] -= at(i, j) * y[i];
+  for (int i = 0; i < n; ++i) b[perm[i]] = y[i];
+}
+
+}  // namespace
+
+using TO = TrajectoryOptimizer<double>;
+
+void TO::Check(int rc) const {
+  if (rc != 0) throw std::runtime_error(std::string("idto_hip: ") + idto_hip_last_error());
+}
+
+TO::TrajectoryOptimizer(const idto_model_t& model, double time_step, const ProblemDefinition& prob,
+                        const SolverParameters& params, int device)
+    : time_step_(time_step), prob_(prob), params_(params) {
+  // same run-time checks as the reference constructor / CalcInverseDynamicsPartials (TO.cc:37-74, 400-424)
+  if (params_.gradients_method != kForwardDifferences)
+    throw std::runtime_error("TrajectoryOptimizer (HIP): only gradients_method = kForwardDifferences is implemented");
+  if (params_.exact_hessian) throw std::runtime_error("TrajectoryOptimizer (HIP): exact_hessian needs autodiff");
+  for (int b = 0; b < model.nbodies; ++b) {
+    const int jt = model.jtype[b];
+    if (jt == IDTO_JOINT_FLOATING) quaternion_starts_.push_back(nq_);
+    nq_ += (jt == IDTO_JOINT_FLOATING) ? 7 : (jt == IDTO_JOINT_PLANAR ? 3 : 1);
+    nv_ += (jt == IDTO_JOINT_FLOATING) ? 6 : (jt == IDTO_JOINT_PLANAR ? 3 : 1);
+  }
+  if ((int)prob_.q_init.size() != nq_ || (int)prob_.v_init.size() != nv_ || (int)prob_.q_nom.size() != num_steps() + 1 ||
+      (int)prob_.v_nom.size() != num_steps() + 1)
+    throw std::runtime_error("TrajectoryOptimizer: problem definition has the wrong sizes");
+  // unactuated dofs: rows of B that are zero; a model without any actuator counts as fully
+  // actuated (TO.cc:63-72)
+  bool any = false;
+  for (int j = 0; j < nv_; ++j) any |= model.actuated[j] != 0;
+  if (any)
+    for (int j = 0; j < nv_; ++j)
+      if (!model.actuated[j]) unactuated_dofs_.push_back(j);
+
+  const Vec qn = Flatten(prob_.q_nom), vn = Flatten(prob_.v_nom);
+  idto_problem_t p = {};
+  p.num_steps = num_steps(); p.time_step = time_step_;
+  p.q_init = prob_.q_init.data(); p.v_init = prob_.v_init.data();
+  p.Qq = prob_.Qq.data(); p.Qv = prob_.Qv.data(); p.Qf_q = prob_.Qf_q.data(); p.Qf_v = prob_.Qf_v.data();
+  p.R = prob_.R.data(); p.q_nom = qn.data(); p.v_nom = vn.data();
+  idto_contact_params_t c = {params_.contact_stiffness, params_.dissipation_velocity, params_.stiction_velocity,
+                             params_.friction_coefficient, params_.smoothing_factor};
+  Check(idto_hip_create(&model, &p, &c, device, &hip_));
+}
+
+TO::~TrajectoryOptimizer() { idto_hip_destroy(hip_); }
+
+void TO::UploadProblem() {
+  const Vec qn = Flatten(prob_.q_nom), vn = Flatten(prob_.v_nom);
+  idto_problem_t p = {};
+  p.num_steps = num_steps(); p.time_step = time_step_;
+  p.q_init = prob_.q_init.data(); p.v_init = prob_.v_init.data();
+  p.Qq = prob_.Qq.data(); p.Qv = prob_.Qv.data(); p.Qf_q = prob_.Qf_q.data(); p.Qf_v = prob_.Qf_v.data();
+  p.R = prob_.R.data(); p.q_nom = qn.data(); p.v_nom = vn.data();
+  Check(idto_hip_set_problem(hip_, &p));
+  resident_ = nullptr;  // every cached device result depends on the problem data
+  device_level_ = 0;
+}
+
+// TO.h:429-450
+void TO::ResetInitialConditions(const VectorXd& q_init, const VectorXd& v_init) {
+  if ((int)q_init.size() != nq_ || (int)v_init.size() != nv_) throw std::runtime_error("ResetInitialConditions: wrong size");
+  prob_.q_init = q_init;
+  prob_.v_init = v_init;
+  UploadProblem();
+}
+// TO.h:452-470
+void TO::UpdateNominalTrajectory(const std::vector<VectorXd>& q_nom, const std::vector<VectorXd>& v_nom) {
+  if ((int)q_nom.size() != num_steps() + 1 || (int)v_nom.size() != num_steps() + 1)
+    throw std::runtime_error("UpdateNominalTrajectory: wrong size");
+  prob_.q_nom = q_nom;
+  prob_.v_nom = v_nom;
+  UploadProblem();
+}
+
+// ---- device residency: level 0 = q, 1 = + tau/cost, 2 = + partials, 3 = + gradient/Hessian
+void TO::EnsureDevice(const TrajectoryOptimizerState<T>& state, int level) const {
+  if (resident_ != &state || !state.cache_.uploaded) {
+    const Vec q = Flatten(state.q());
+    Check(idto_hip_set_q(hip_, q.data()));
+    resident_ = &state;
+    state.cache_.uploaded = true;
+    device_level_ = 0;
+  }
+  if (level >= 1 && device_level_ < 1) { Check(idto_hip_eval_tau(hip_)); device_level_ = 1; }
+  if (level >= 2 && device_level_ < 2) { Check(idto_hip_eval_partials(hip_)); device_level_ = 2; }
+  if (level >= 3 && device_level_ < 3) { Check(idto_hip_grad_hess(hip_)); device_level_ = 3; }
+}
+
+Vec TO::Fetch(int what) const {
+  Vec out((std::size_t)idto_hip_array_size(hip_, what));
+  Check(idto_hip_get(hip_, what, out.data()));
+  return out;
+}
+
+// TO.cc:1463-1480 (v, a, tau, N+) + CalcCost :147-176
+void TO::CalcTrajectoryData(const TrajectoryOptimizerState<T>& state) const {
+  auto& c = state.cache_;
+  if (c.traj) return;
+  EnsureDevice(state, 1);
+  const int N = num_steps();
+  c.v = Unflatten(Fetch(IDTO_ARR_V), N + 1, nv_);
+  c.a = Unflatten(Fetch(IDTO_ARR_A), N, nv_);
+  c.tau = Unflatten(Fetch(IDTO_ARR_TAU), N, nv_);
+  c.nplus = UnflattenBlocks(Fetch(IDTO_ARR_NPLUS), N + 1, nv_, nq_);
+  c.cost = Fetch(IDTO_ARR_COST)[0];
+  c.traj = true;
+}
+
+// TO.cc:400-563 and :962-973
+void TO::CalcDerivatives(const TrajectoryOptimizerState<T>& state) const {
+  auto& c = state.cache_;
+  if (c.deriv) return;
+  CalcTrajectoryData(state);
+  EnsureDevice(state, 2);
+  const int N = num_steps();
+  c.id_partials.dtau_dqm = UnflattenBlocks(Fetch(IDTO_ARR_DTAU_DQM), N, nv_, nq_);
+  c.id_partials.dtau_dqt = UnflattenBlocks(Fetch(IDTO_ARR_DTAU_DQT), N, nv_, nq_);
+  c.id_partials.dtau_dqp = UnflattenBlocks(Fetch(IDTO_ARR_DTAU_DQP), N, nv_, nq_);
+  c.v_partials.dvt_dqt.assign((std::size_t)N + 1, MatrixXd(nv_, nq_));
+  c.v_partials.dvt_dqm.assign((std::size_t)N + 1, MatrixXd(nv_, nq_));
+  for (int t = 0; t <= N; ++t)
+    for (int col = 0; col < nq_; ++col)
+      for (int r = 0; r < nv_; ++r) {
+        c.v_partials.dvt_dqt[t](r, col) = c.nplus[t](r, col) / time_step_;
+        if (t > 0) c.v_partials.dvt_dqm[t](r, col) = -c.nplus[t](r, col) / time_step_;
+      }
+  c.deriv = true;
+}
+
+// TO.cc:1021-1081 and :1093-1165
+void TO::CalcGradHess(const TrajectoryOptimizerState<T>& state) const {
+  auto& c = state.cache_;
+  if (c.grad && c.hess) return;
+  CalcDerivatives(state);
+  EnsureDevice(state, 3);
+  c.gradient = Fetch(IDTO_ARR_GRADIENT);
+  c.hessian = PentaDiagonalMatrix<T>(num_steps() + 1, nq_);
+  c.hessian.mutable_A() = Fetch(IDTO_ARR_H_A);
+  c.hessian.mutable_B() = Fetch(IDTO_ARR_H_B);
+  c.hessian.mutable_C() = Fetch(IDTO_ARR_H_C);
+  c.grad = c.hess = true;
+}
+
+const std::vector<VectorXd>& TO::EvalV(const TrajectoryOptimizerState<T>& s) const { CalcTrajectoryData(s); return s.cache_.v; }
+const std::vector<VectorXd>& TO::EvalA(const TrajectoryOptimizerState<T>& s) const { CalcTrajectoryData(s); return s.cache_.a; }
+const std::vector<VectorXd>& TO::EvalTau(const TrajectoryOptimizerState<T>& s) const { CalcTrajectoryData(s); return s.cache_.tau; }
+const std::vector<MatrixXd>& TO::EvalNplus(const TrajectoryOptimizerState<T>& s) const { CalcTrajectoryData(s); return s.cache_.nplus; }
+double TO::EvalCost(const TrajectoryOptimizerState<T>& s) const { CalcTrajectoryData(s); return s.cache_.cost; }
+const VelocityPartials<double>& TO::EvalVelocityPartials(const TrajectoryOptimizerState<T>& s) const {
+  CalcDerivatives(s);
+  return s.cache_.v_partials;
+}
+const InverseDynamicsPartials<double>& TO::EvalInverseDynamicsPartials(const TrajectoryOptimizerState<T>& s) const {
+  CalcDerivatives(s);
+  return s.cache_.id_partials;
+}
+const VectorXd& TO::EvalGradient(const TrajectoryOptimizerState<T>& s) const { CalcGradHess(s); return s.cache_.gradient; }
+const PentaDiagonalMatrix<double>& TO::EvalHessian(const TrajectoryOptimizerState<T>& s) const {
+  CalcGradHess(s);
+  return s.cache_.hessian;
+}
+
+// TO.cc:1225-1255
+const VectorXd& TO::EvalScaleFactors(const TrajectoryOptimizerState<T>& s) const {
+  auto& c = s.cache_;
+  if (!c.scale) {
+    Vec d;
+    EvalHessian(s).ExtractDiagonal(&d);
+    Vec& D = c.scale_factors;
+    if ((int)D.size() != num_vars()) D.assign((std::size_t)num_vars(), 1.0);
+    for (int i = 0; i < num_vars(); ++i) {
+      switch (params_.scaling_method) {
+        case kSqrt: D[i] = std::min(1.0, 1 / std::sqrt(d[i])); break;
+        case kAdaptiveSqrt: D[i] = std::min(D[i], 1 / std::sqrt(d[i])); break;
+        case kDoubleSqrt: D[i] = std::min(1.0, 1 / std::sqrt(std::sqrt(d[i]))); break;
+        case kAdaptiveDoubleSqrt: D[i] = std::min(D[i], 1 / std::sqrt(std::sqrt(d[i]))); break;
+      }
+    }
+    c.scale = true;
+  }
+  return c.scale_factors;
+}
+// TO.cc:1181-1202
+const PentaDiagonalMatrix<double>& TO::EvalScaledHessian(const TrajectoryOptimizerState<T>& s) const {
+  if (!params_.scaling) return EvalHessian(s);
+  auto& c = s.cache_;
+  if (!c.shess) {
+    c.scaled_hessian = EvalHessian(s);
+    c.scaled_hessian.ScaleByDiagonal(EvalScaleFactors(s));
+    c.shess = true;
+  }
+  return c.scaled_hessian;
+}
+// TO.cc:1204-1223
+const VectorXd& TO::EvalScaledGradient(const TrajectoryOptimizerState<T>& s) const {
+  if (!params_.scaling) return EvalGradient(s);
+  auto& c = s.cache_;
+  if (!c.sgrad) {
+    const Vec& g = EvalGradient(s);
+    const Vec& D = EvalScaleFactors(s);
+    c.scaled_gradient.resize(g.size());
+    for (std::size_t i = 0; i < g.size(); ++i) c.scaled_gradient[i] = D[i] * g[i];
+    c.sgrad = true;
+  }
+  return c.scaled_gradient;
+}
+// TO.cc:1267-1290
+const VectorXd& TO::EvalEqualityConstraintViolations(const TrajectoryOptimizerState<T>& s) const {
+  auto& c = s.cache_;
+  if (!c.h) {
+    const auto& tau = EvalTau(s);
+    const int nu = (int)unactuated_dofs_.size();
+    c.h_viol.assign((std::size_t)nu * num_steps(), 0.0);
+    for (int t = 0; t < num_steps(); ++t)
+      for (int j = 0; j < nu; ++j) c.h_viol[(std::size_t)t * nu + j] = tau[t][unactuated_dofs_[j]];
+    c.h = true;
+  }
+  return c.h_viol;
+}
+// TO.cc:1292-1345
+const MatrixXd& TO::EvalEqualityConstraintJacobian(const TrajectoryOptimizerState<T>& s) const {
+  auto& c = s.cache_;
+  if (!c.J) {
+    const auto& P = EvalInverseDynamicsPartials(s);
+    const int nu = (int)unactuated_dofs_.size(), N = num_steps();
+    c.J_unscaled = MatrixXd(nu * N, num_vars());
+    for (int t = 0; t < N; ++t)
+      for (int i = 0; i < nu; ++i) {
+        const int row = t * nu + i, dof = unactuated_dofs_[i];
+        for (int col = 0; col < nq_; ++col) {
+          c.J_unscaled(row, (t + 1) * nq_ + col) = P.dtau_dqp[t](dof, col);
+          if (t > 0) c.J_unscaled(row, t * nq_ + col) = P.dtau_dqt[t](dof, col);
+          if (t > 1) c.J_unscaled(row, (t - 1) * nq_ + col) = P.dtau_dqm[t](dof, col);
+        }
+      }
+    c.J_scaled = c.J_unscaled;
+    if (params_.scaling) {  // J~ = J D (:1330-1333)
+      const Vec& D = EvalScaleFactors(s);
+      for (int col = 0; col < num_vars(); ++col)
+        for (int r = 0; r < nu * N; ++r) c.J_scaled(r, col) *= D[col];
+    }
+    c.J = true;
+  }
+  return c.J_scaled;
+}
+
+// H^-1 [J^T | g] with the unscaled H and J: ONE multi-right-hand-side device solve per state.
+// Everything the iteration needs from a factorisation of H (or of the scaled H~ = D H D) is a
+// linear combination of these columns:  H~^-1 J~^T = D^-1 H^-1 J^T,  H~^-1 g~ = D^-1 H^-1 g.
+const MatrixXd& TO::EvalHinvJTg(const TrajectoryOptimizerState<T>& s) const {
+  auto& c = s.cache_;
+  if (!c.hinv) {
+    const Vec& g = EvalGradient(s);
+    const int neq = params_.equality_constraints ? num_equality_constraints() : 0, n = num_vars();
+    MatrixXd rhs(n, neq + 1);
+    if (neq > 0) {
+      EvalEqualityConstraintJacobian(s);
+      for (int r = 0; r < neq; ++r)
+        for (int col = 0; col < n; ++col) rhs(col, r) = c.J_unscaled(r, col);
+    }
+    for (int i = 0; i < n; ++i) rhs(i, neq) = g[i];
+    EnsureDevice(s, 3);
+    c.Hinv_JT_g = MatrixXd(n, neq + 1);
+    Check(idto_hip_solve_host(hip_, rhs.data(), neq + 1, c.Hinv_JT_g.data()));
+    c.hinv = true;
+  }
+  return c.Hinv_JT_g;
+}
+
+// TO.cc:1371-1396 : lambda = (J~ H~^-1 J~^T)^-1 (h - J~ H~^-1 g~) = (J H^-1 J^T)^-1 (h - J H^-1 g)
+const VectorXd& TO::EvalLagrangeMultipliers(const TrajectoryOptimizerState<T>& s) const {
+  auto& c = s.cache_;
+  if (!c.lambda) {
+    const Vec& h = EvalEqualityConstraintViolations(s);
+    const MatrixXd& Y = EvalHinvJTg(s);
+    EvalEqualityConstraintJacobian(s);
+    const int neq = num_equality_constraints(), nu = (int)unactuated_dofs_.size();
+    std::vector<double> S((std::size_t)neq * neq, 0.0);
+    Vec rhs((std::size_t)neq);
+    for (int r = 0; r < neq; ++r) {
+      // row r of J is non-zero only in the three blocks around its time step
+      const int t = r / nu;
+      const int c0 = std::max(0, (t - 1) * nq_), c1 = (t + 2) * nq_;
+      for (int col = 0; col <= neq; ++col) {
+        double acc = 0;
+        for (int k = c0; k < c1; ++k) acc += c.J_unscaled(r, k) * Y(k, col);
+        if (col < neq) S[(std::size_t)col * neq + r] = acc;
+        else rhs[r] = h[r] - acc;
+      }
+    }
+    for (int cc = 0; cc < neq; ++cc)  // symmetrise (J H^-1 J^T is symmetric up to round-off)
+      for (int r = cc + 1; r < neq; ++r) S[(std::size_t)cc * neq + r] = S[(std::size_t)r * neq + cc] =
+          0.5 * (S[(std::size_t)cc * neq + r] + S[(std::size_t)r * neq + cc]);
+    DenseLdltSolve(&S, neq, rhs.data());
+    c.lambda_v = rhs;
+    c.lambda = true;
+  }
+  return c.lambda_v;
+}
+// TO.cc:1411-1433
+double TO::EvalMeritFunction(const TrajectoryOptimizerState<T>& s) const {
+  if (!params_.equality_constraints) return EvalCost(s);
+  auto& c = s.cache_;
+  if (!c.merit) {
+    c.merit_v = EvalCost(s) + Dot(EvalEqualityConstraintViolations(s), EvalLagrangeMultipliers(s));
+    c.merit = true;
+  }
+  return c.merit_v;
+}
+// TO.cc:1435-1456
+const VectorXd& TO::EvalMeritFunctionGradient(const TrajectoryOptimizerState<T>& s) const {
+  if (!params_.equality_constraints) return EvalScaledGradient(s);
+  auto& c = s.cache_;
+  if (!c.mgrad) {
+    const Vec& g = EvalScaledGradient(s);
+    const Vec& lam = EvalLagrangeMultipliers(s);
+    const MatrixXd& J = EvalEqualityConstraintJacobian(s);
+    const int neq = num_equality_constraints();
+    c.merit_gradient.resize((std::size_t)num_vars());
+    for (int col = 0; col < num_vars(); ++col) {
+      double acc = 0;
+      for (int r = 0; r < neq; ++r) acc += J(r, col) * lam[r];
+      c.merit_gradient[col] = g[col] + acc;
+    }
+    c.mgrad = true;
+  }
+  return c.merit_gradient;
+}
+
+// TO.cc:2691-2707
+void TO::NormalizeQuaternions(TrajectoryOptimizerState<T>* state) const {
+  std::vector<Vec> q = state->q();
+  for (int qs : quaternion_starts_)
+    for (Vec& qt : q) {
+      const double n = std::sqrt(qt[qs] * qt[qs] + qt[qs + 1] * qt[qs + 1] + qt[qs + 2] * qt[qs + 2] + qt[qs + 3] * qt[qs + 3]);
+      for (int k = 0; k < 4; ++k) qt[qs + k] /= n;
+    }
+  state->set_q(q);
+}
+
+namespace {
+// TO.cc:2037-2066
+double SolveDoglegQuadratic(double a, double b, double c) {
+  if (!(a > 0)) throw std::runtime_error("dogleg: a <= 0");
+  double s;
+  if (a < std::numeric_limits<double>::epsilon()) {
+    s = -c / b;
+  } else {
+    const double bt = b / a, ct = c / a;
+    const double det = bt * bt - 4 * ct;
+    if (!(det > 0)) throw std::runtime_error("dogleg: determinant <= 0");
+    s = (-bt + std::sqrt(det)) / 2;
+  }
+  if (!(0 < s && s < 1)) throw std::runtime_error("dogleg: s not in (0,1)");
+  return s;
+}
+}  // namespace
+
+// TO.cc:2108-2202
+bool TO::CalcDoglegPoint(const TrajectoryOptimizerState<T>& s, double Delta, VectorXd* dq, VectorXd* dqH) const {
+  const PentaDiagonalMatrix<T>& H = EvalScaledHessian(s);
+  const Vec& g = EvalMeritFunctionGradient(s);
+  const int n = num_vars();
+  Vec Hg;
+  H.MultiplyBy(g, &Hg);
+  const double gHg = Dot(g, Hg);
+  // pH = H~^-1 (-g~_merit / Delta) from the cached device solve (:2139-2149)
+  const MatrixXd& Y = EvalHinvJTg(s);
+  const int neq = params_.equality_constraints ? num_equality_constraints() : 0;
+  Vec pH((std::size_t)n);
+  {
+    const Vec* lam = neq ? &EvalLagrangeMultipliers(s) : nullptr;
+    const Vec* D = params_.scaling ? &EvalScaleFactors(s) : nullptr;
+    for (int i = 0; i < n; ++i) {
+      double acc = Y(i, neq);
+      for (int r = 0; r < neq; ++r) acc += Y(i, r) * (*lam)[r];
+      pH[i] = -(D ? acc / (*D)[i] : acc) / Delta;
+    }
+  }
+  dqH->resize((std::size_t)n);
+  for (int i = 0; i < n; ++i) (*dqH)[i] = pH[i] * Delta;  // :2152
+  Vec pU((std::size_t)n);
+  const double coef = -(Dot(g, g) / gHg);
+  for (int i = 0; i < n; ++i) pU[i] = coef * g[i] / Delta;  // :2157
+  dq->resize((std::size_t)n);
+  auto apply_scaling = [&]() {
+    if (params_.scaling) {
+      const Vec& D = EvalScaleFactors(s);
+      for (int i = 0; i < n; ++i) (*dq)[i] = D[i] * (*dq)[i];
+    }
+  };
+  const double pUn = Norm(pU);
+  if (1.0 <= pUn) {  // :2160-2168
+    for (int i = 0; i < n; ++i) (*dq)[i] = (Delta / pUn) * pU[i];
+    apply_scaling();
+    return true;
+  }
+  if (1.0 >= Norm(pH)) {  // :2171-2178
+    for (int i = 0; i < n; ++i) (*dq)[i] = pH[i] * Delta;
+    apply_scaling();
+    return false;
+  }
+  Vec d((std::size_t)n);
+  for (int i = 0; i < n; ++i) d[i] = pH[i] - pU[i];
+  const double a = Dot(d, d), b = 2 * Dot(pU, d), c = Dot(pU, pU) - 1.0;  // :2192-2194
+  const double sq = SolveDoglegQuadratic(a, b, c);
+  for (int i = 0; i < n; ++i) (*dq)[i] = (pU[i] + sq * d[i]) * Delta;  // :2197
+  apply_scaling();
+  return true;
+}
+
+// TO.cc:1979-2035
+double TO::CalcTrustRatio(const TrajectoryOptimizerState<T>& s, const VectorXd& dq,
+                          TrajectoryOptimizerState<T>* scratch) const {
+  const double merit_k = EvalMeritFunction(s);
+  const Vec& g_tilde_k = EvalMeritFunctionGradient(s);
+  const PentaDiagonalMatrix<T>& H_k = EvalScaledHessian(s);
+  if (params_.equality_constraints) EvalLagrangeMultipliers(s);
+  scratch->set_q(s.q());
+  scratch->AddToQ(dq);
+  if (params_.normalize_quaternions) NormalizeQuaternions(scratch);
+  double merit_kp = EvalCost(*scratch);
+  if (params_.equality_constraints)
+    merit_kp += Dot(EvalEqualityConstraintViolations(*scratch), EvalLagrangeMultipliers(s));
+  const int n = num_vars();
+  Vec dqs((std::size_t)n), Hdq;
+  if (params_.scaling) {
+    const Vec& D = EvalScaleFactors(s);
+    for (int i = 0; i < n; ++i) dqs[i] = (1.0 / D[i]) * dq[i];
+  } else {
+    dqs = dq;
+  }
+  H_k.MultiplyBy(dqs, &Hdq);
+  const double hessian_term = 0.5 * Dot(dqs, Hdq);
+  const double gradient_term = Dot(g_tilde_k, dqs);
+  const double predicted = -gradient_term - hessian_term;
+  const double actual = merit_k - merit_kp;
+  const double eps = 10 * std::numeric_limits<double>::epsilon() / time_step_ / time_step_;
+  if (predicted < eps && actual < eps) return 0.5;
+  return actual / predicted;
+}
+
+// TO.cc:2653-2689
+ConvergenceReason TO::VerifyConvergenceCriteria(const TrajectoryOptimizerState<T>& s, double previous_cost,
+                                                const VectorXd& dq) const {
+  const auto& tol = params_.convergence_tolerances;
+  int reason = kNoConvergenceCriteriaSatisfied;
+  const double cost = EvalCost(s);
+  if (std::fabs(previous_cost - cost) < tol.abs_cost_reduction + tol.rel_cost_reduction * cost)
+    reason |= kCostReductionCriterionSatisfied;
+  const Vec& g = EvalMeritFunctionGradient(s);
+  if (std::fabs(Dot(g, dq)) < tol.abs_gradient_along_dq + tol.rel_gradient_along_dq * cost)
+    reason |= kGradientCriterionSatisfied;
+  if (Norm(dq) < tol.abs_state_change + tol.rel_state_change * s.norm()) reason |= kSateCriterionSatisfied;
+  return static_cast<ConvergenceReason>(reason);
+}
+
+// TO.cc:2213-2234
+SolverFlag TO::Solve(const std::vector<VectorXd>& q_guess, TrajectoryOptimizerSolution<T>* solution,
+                     TrajectoryOptimizerStats<T>* stats, ConvergenceReason* reason) const {
+  if (!stats->is_empty()) throw std::runtime_error("Solve: stats must be empty (TO.cc:2225)");
+  if (params_.method != kTrustRegion)
+    throw std::runtime_error("Solve (HIP): only method = kTrustRegion is implemented on the device path");
+  if ((int)q_guess.size() != num_steps() + 1) throw std::runtime_error("Solve: q_guess has the wrong length");
+  std::unique_ptr<WarmStart> ws = CreateWarmStart(q_guess);
+  return SolveFromWarmStart(ws.get(), solution, stats, reason);
+}
+
+// TO.cc:2449-2651
+SolverFlag TO::SolveFromWarmStart(WarmStart* ws, TrajectoryOptimizerSolution<T>* solution,
+                                  TrajectoryOptimizerStats<T>* stats, ConvergenceReason* reason_out) const {
+  using clock = std::chrono::high_resolution_clock;
+  if (params_.method != kTrustRegion) throw std::runtime_error("warm start requires the trust-region method");
+  const auto start_time = clock::now();
+  auto iter_start = clock::now();
+  TrajectoryOptimizerState<T>& state = ws->state;
+  TrajectoryOptimizerState<T>& scratch = ws->scratch_state;
+  Vec& dq = ws->dq;
+  Vec& dqH = ws->dqH;
+  const double eta = 0.0;  // trust ratio threshold (:2466)
+  int k = 0;
+  double& Delta = ws->Delta;
+  double previous_cost = EvalCost(state);
+  if (params_.verbose) {
+    std::printf("-------------------------------------------------------------------------------------\n");
+    std::printf("|  iter  |   cost   |    Δ    |    ρ    |  time (s)  |  |g|/cost  |    dL_dq   |    |h|     |\n");
+    std::printf("-------------------------------------------------------------------------------------\n");
+  }
+  while (k < params_.max_iterations) {
+    const bool active = CalcDoglegPoint(state, Delta, &dq, &dqH);  // :2497
+    const Vec& g = EvalMeritFunctionGradient(state);
+    const Vec& h = EvalEqualityConstraintViolations(state);
+    const double cost = EvalCost(state);
+    const double merit = EvalMeritFunction(state);
+    const double q_norm = state.norm();
+    double dL_dq;
+    if (params_.scaling) {
+      const Vec& D = EvalScaleFactors(state);
+      double acc = 0;
+      for (std::size_t i = 0; i < dq.size(); ++i) acc += g[i] * ((1.0 / D[i]) * dq[i]);
+      dL_dq = acc / cost;
+    } else {
+      dL_dq = Dot(g, dq) / cost;
+    }
+    const double rho = CalcTrustRatio(state, dq, &scratch);  // :2526
+    if (!(dL_dq < std::numeric_limits<double>::epsilon()))
+      throw std::runtime_error("step is not a descent direction (TO.cc:2531)");
+    const double g_norm = Norm(g), h_norm = Norm(h), dq_norm = Norm(dq), dqH_norm = Norm(dqH);
+    if (rho > eta) {  // :2550-2553
+      state.AddToQ(dq);
+      if (params_.normalize_quaternions) NormalizeQuaternions(&state);
+    }
+    const double iter_time = std::chrono::duration<double>(clock::now() - iter_start).count();
+    iter_start = clock::now();
+    if (params_.verbose)
+      std::printf("| %6d | %8.3g | %7.2g | %7.3g | %10.5g | %10.5g | %10.4g | %10.4g |\n", k, cost, Delta, rho, iter_time,
+                  g_norm / cost, dL_dq, h_norm);
+    stats->push_data(iter_time, cost, 0, std::numeric_limits<double>::quiet_NaN(), Delta, q_norm, dq_norm, dqH_norm, rho,
+                     g_norm, dL_dq, h_norm, merit);  // :2586-2598
+    ConvergenceReason reason = kNoConvergenceCriteriaSatisfied;
+    if (params_.check_convergence && rho > eta) {
+      reason = VerifyConvergenceCriteria(state, previous_cost, dq);
+      previous_cost = EvalCost(state);
+      stats->convergence_reason = reason;
+      if (reason_out) *reason_out = reason;
+    }
+    if (reason != kNoConvergenceCriteriaSatisfied) break;
+    if (rho < 0.25) Delta *= 0.25;                                                   // :2614-2617
+    else if (rho > 0.75 && active) Delta = std::min(2 * Delta, params_.Delta_max);   // :2618-2622
+    ++k;
+  }
+  stats->solve_time = std::chrono::duration<double>(clock::now() - start_time).count();
+  solution->q = state.q();
+  solution->v = EvalV(state);
+  solution->tau = EvalTau(state);
+  if (k == params_.max_iterations) return SolverFlag::kMaxIterationsReached;
+  return SolverFlag::kSuccess;
+}
+
+}  // namespace optimizer
+}  // namespace idto

@@ -67,6 +67,8 @@ struct idto_hip_ctx {
   bool timing = false;
   struct Timed { hipEvent_t a, b; int which; };
   std::vector<Timed> pending;
+  double *stage_rhs = nullptr, *stage_x = nullptr;  // idto_hip_solve_host
+  size_t stage_count = 0;
   std::vector<hipEvent_t> event_pool;  // recycled: creating events in the timed loop costs host time
   double tsum[3] = {0, 0, 0};
   int tcnt[3] = {0, 0, 0};
@@ -501,6 +503,23 @@ int idto_hip_factor_solve(idto_hip_ctx* c, const double* rhs, int nrhs, double* 
     if (rc) return rc;
   }
   return TimeEnd(c);
+}
+
+int idto_hip_solve_host(idto_hip_ctx* c, const double* rhs_host, int nrhs, double* x_host) {
+  HIP_OK(hipSetDevice(c->device));
+  if (!rhs_host || !x_host || nrhs < 1) { g_err = "solve_host: bad arguments"; return -1; }
+  const size_t count = (size_t)nrhs * (c->N + 1) * c->nq;
+  if (count > c->stage_count) {  // staging buffers grow on demand and are reused
+    double *a = nullptr, *b = nullptr;
+    if (Alloc(c, count, &a) || Alloc(c, count, &b)) return -2;
+    c->stage_rhs = a; c->stage_x = b; c->stage_count = count;
+  }
+  HIP_OK(hipMemcpyAsync(c->stage_rhs, rhs_host, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  int rc = idto_hip_factor_solve(c, c->stage_rhs, nrhs, c->stage_x);
+  if (rc) return rc;
+  HIP_OK(hipMemcpyAsync(x_host, c->stage_x, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  return 0;
 }
 
 int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {

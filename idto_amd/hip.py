@@ -53,6 +53,7 @@ def lib():
         for f in ("eval_tau", "eval_partials", "grad_hess", "gn_step", "sync", "timing_reset"):
             getattr(L, "idto_hip_" + f).argtypes = [C.c_void_p]
         L.idto_hip_factor_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.idto_hip_solve_host.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double)]
         L.idto_hip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.idto_hip_timing_enable.argtypes = [C.c_void_p, C.c_int]
         L.idto_hip_timing_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -70,7 +71,8 @@ def lib():
 EXPORTED_SYMBOLS = [
     "idto_hip_last_error", "idto_hip_create", "idto_hip_destroy", "idto_hip_set_problem", "idto_hip_set_stream",
     "idto_hip_get_stream", "idto_hip_set_shard", "idto_hip_set_q", "idto_hip_set_q_device", "idto_hip_eval_tau",
-    "idto_hip_eval_partials", "idto_hip_grad_hess", "idto_hip_factor_solve", "idto_hip_gn_step", "idto_hip_set_option",
+    "idto_hip_eval_partials", "idto_hip_grad_hess", "idto_hip_factor_solve", "idto_hip_gn_step", "idto_hip_solve_host",
+    "idto_hip_set_option",
     "idto_hip_timing_enable", "idto_hip_timing_reset", "idto_hip_timing_get", "idto_hip_sync", "idto_hip_get",
     "idto_hip_device_ptr", "idto_hip_array_size", "idto_hip_slab_stride", "idto_hip_math_probe",
 ]
@@ -144,6 +146,13 @@ class HipPath:
     def factor_solve(self, rhs_ptr: int | None = None, nrhs: int = 1, x_ptr: int | None = None):
         _chk(lib().idto_hip_factor_solve(self.h, C.c_void_p(rhs_ptr) if rhs_ptr else None, int(nrhs),
                                          C.c_void_p(x_ptr) if x_ptr else None))
+
+    def solve_host(self, rhs):
+        """H X = rhs for host right-hand sides [nrhs, (N+1)*nq]"""
+        rhs = np.ascontiguousarray(np.atleast_2d(np.asarray(rhs, dtype=np.float64)))
+        x = np.zeros_like(rhs)
+        _chk(lib().idto_hip_solve_host(self.h, dptr(rhs), rhs.shape[0], dptr(x)))
+        return x
 
     def set_option(self, name: str, value: int):
         _chk(lib().idto_hip_set_option(self.h, name.encode(), int(value)))

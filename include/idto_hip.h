@@ -93,6 +93,11 @@ int idto_hip_grad_hess(idto_hip_ctx* ctx);
  * rhs = -gradient, result in IDTO_ARR_STEP. */
 int idto_hip_factor_solve(idto_hip_ctx* ctx, const double* rhs_device, int nrhs, double* x_device);
 int idto_hip_gn_step(idto_hip_ctx* ctx);
+/* Same solve with HOST right-hand sides / solutions ((N+1)*nq doubles each, nrhs of them,
+ * contiguous), staged through buffers the context owns; synchronises.  This is how the
+ * host-side trust-region loop obtains H^-1 [J^T | g] for CalcLagrangeMultipliers
+ * (optimizer/trajectory_optimizer.cc:1371-1396) and CalcDoglegPoint (:2108-2202). */
+int idto_hip_solve_host(idto_hip_ctx* ctx, const double* rhs_host, int nrhs, double* x_host);
 
 /* Options: "reference_solver" = 1 selects the bit-exact restatement of the reference's
  * pivoted-LU block Thomas (slow) instead of the SPD Gauss-Jordan solver (default 0; the

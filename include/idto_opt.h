@@ -1,0 +1,62 @@
+/* idto_opt.h — C-ABI of libidto_opt.so: the host-side TrajectoryOptimizer
+ * (include/idto/optimizer/trajectory_optimizer.h, C++) for bindings that cannot consume
+ * C++ (ctypes, cgo, JNI ...).  One entry point per public method of the reference class
+ * (optimizer/trajectory_optimizer.h:41-483) that the reference's own pybind11 module exports
+ * (python_bindings/trajectory_optimizer_py.cc:34-59: constructor, time_step, num_steps, Solve,
+ * SolveFromWarmStart, CreateWarmStart, ResetInitialConditions, UpdateNominalTrajectory, params,
+ * prob) plus the Eval* accessors the reference's tests use.  All heavy work happens in
+ * libidto_hip.so (include/idto_hip.h); return value 0 = ok, negative = failure described by
+ * idto_opt_last_error(); C++ exceptions never cross this boundary. */
+#ifndef IDTO_OPT_H_
+#define IDTO_OPT_H_
+
+#include "idto_model.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct idto_opt idto_opt;
+typedef struct idto_opt_warm_start idto_opt_warm_start;
+
+const char* idto_opt_last_error(void);
+
+/* TrajectoryOptimizer(diagram, plant, prob, params) (trajectory_optimizer.h:56-72) with the
+ * plant replaced by model tables + time step. */
+int idto_opt_create(const idto_model_t* model, const idto_problem_t* problem, const idto_contact_params_t* contact,
+                    const idto_solver_params_t* params, int device, idto_opt** out);
+void idto_opt_destroy(idto_opt* opt);
+
+int idto_opt_num_steps(const idto_opt* opt);
+double idto_opt_time_step(const idto_opt* opt);
+int idto_opt_num_equality_constraints(const idto_opt* opt);
+
+/* Solve (trajectory_optimizer.h:176-194).  q_guess: (N+1)*nq; outputs sized (N+1)*nq, (N+1)*nv,
+ * N*nv.  *flag receives the SolverFlag, *reason the ConvergenceReason bitmask. */
+int idto_opt_solve(idto_opt* opt, const double* q_guess, double* sol_q, double* sol_v, double* sol_tau,
+                   idto_stats_t* stats, int* flag, int* reason);
+
+/* CreateWarmStart / SolveFromWarmStart (trajectory_optimizer.h:156-211, warm_start.h:23-76) */
+int idto_opt_ws_create(idto_opt* opt, const double* q_guess, idto_opt_warm_start** out);
+void idto_opt_ws_destroy(idto_opt_warm_start* ws);
+int idto_opt_ws_set_q(idto_opt* opt, idto_opt_warm_start* ws, const double* q);
+int idto_opt_ws_get(idto_opt* opt, idto_opt_warm_start* ws, double* q, double* Delta);
+int idto_opt_ws_solve(idto_opt* opt, idto_opt_warm_start* ws, double* sol_q, double* sol_v, double* sol_tau,
+                      idto_stats_t* stats, int* flag, int* reason);
+
+/* ResetInitialConditions / UpdateNominalTrajectory (trajectory_optimizer.h:429-470) */
+int idto_opt_reset_initial_conditions(idto_opt* opt, const double* q_init, const double* v_init);
+int idto_opt_update_nominal_trajectory(idto_opt* opt, const double* q_nom, const double* v_nom);
+
+/* Eval* at a given q (a fresh state is created per call): cost, gradient ((N+1)*nq),
+ * lagrange multipliers (num_equality_constraints), merit; NULL outputs are skipped. */
+int idto_opt_eval(idto_opt* opt, const double* q, double* cost, double* gradient, double* scaled_gradient,
+                  double* scale_factors, double* lambda, double* merit, double* merit_gradient);
+/* CalcDoglegPoint / CalcTrustRatio (TO.cc:2108-2202, 1979-2035) for the property tests */
+int idto_opt_dogleg(idto_opt* opt, const double* q, double Delta, double* dq, double* dqH, int* active);
+int idto_opt_trust_ratio(idto_opt* opt, const double* q, const double* dq, double* rho);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IDTO_OPT_H_ */

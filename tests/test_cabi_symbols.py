@@ -31,6 +31,48 @@ def test_header_symbols_are_exported():
     assert sorted(hip.EXPORTED_SYMBOLS) == declared
 
 
+def test_optimizer_header_symbols_are_exported():
+    """include/idto_opt.h (host-side TrajectoryOptimizer) <-> libidto_opt.so"""
+    from idto_amd import optimizer
+    if not os.path.exists(optimizer.LIB_PATH):
+        pytest.fail(f"{optimizer.LIB_PATH} missing: run ./build.sh")
+    text = open(os.path.join(ROOT, "include", "idto_opt.h")).read()
+    declared = sorted(set(re.findall(r"\b(idto_opt_[a-z_0-9]+)\s*\(", text)))
+    L = optimizer.lib()
+    for s in declared:
+        assert hasattr(L, s), f"{s} declared in include/idto_opt.h but not exported"
+    assert sorted(optimizer.EXPORTED_SYMBOLS) == declared
+
+
+def test_optimizer_has_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from idto_amd.optimizer import TrajectoryOptimizer
+    cfg = load_config("spinner")
+    model = load_model("spinner")
+    prob, sp, _ = make_problem(cfg, model)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        TrajectoryOptimizer(model, prob, sp)
+
+
+def test_host_api_headers_compile_standalone(tmp_path):
+    """the C++ host API (include/idto/optimizer/*.h) is self-contained C++17"""
+    import subprocess
+    src = tmp_path / "t.cc"
+    src.write_text('#include "idto/optimizer/trajectory_optimizer.h"\n'
+                   'using namespace idto::optimizer;\n'
+                   'int main() { SolverParameters p; ProblemDefinition d; TrajectoryOptimizerStats<double> s;\n'
+                   '  return (p.max_iterations == 100 && p.scaling && p.equality_constraints && p.Delta0 == 0.1 &&\n'
+                   '          p.method == kTrustRegion && p.scaling_method == kDoubleSqrt && s.is_empty() &&\n'
+                   '          d.num_steps == 0) ? 0 : 1; }\n')
+    exe = tmp_path / "t"
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                           "-o", str(exe), "-L", os.path.join(ROOT, "idto_amd"), "-lidto_opt", "-lidto_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "idto_amd")])
+    assert subprocess.call([str(exe)]) == 0
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():

@@ -1,0 +1,167 @@
+"""The host-side TrajectoryOptimizer (libidto_opt.so -> libidto_hip.so) against the reference's
+own Python tests (python_bindings/test/trajectory_optimizer_test.py, warm_start_test.py), the
+property tests of optimizer/test/trajectory_optimizer_test.cc ("TO_test.cc") and the CPU
+oracle's Solve on identical problems.
+
+The outer loop reuses one device factorisation per state and the production solver is the
+banded LDL^T, so iterates agree with the oracle to round-off amplified by cond(H), not bit for
+bit: tolerances are stated per test."""
+import numpy as np
+import pytest
+
+from idto_amd.model import load_model
+from idto_amd.optimizer import (TrajectoryOptimizer, TrajectoryOptimizerSolution, TrajectoryOptimizerStats)
+from idto_amd.problem import ProblemDefinition, SolverParameters, load_config, make_problem
+from oracle_lib import Oracle
+from test_oracle_trajopt import mk as mk_oracle
+from test_oracle_trajopt import pendulum, spinner_python_test_problem
+
+pytestmark = pytest.mark.gpu
+EPS = np.finfo(float).eps
+SQRT_EPS = np.sqrt(EPS)
+
+
+def solve(opt, q_guess):
+    sol, st = TrajectoryOptimizerSolution(), TrajectoryOptimizerStats()
+    flag = opt.Solve(q_guess, sol, st)
+    return sol, st, flag
+
+
+def test_spinner_end_to_end_golden():
+    """expected_qN = [0.287, 1.497, 1.995] +- 1e-3 "from CPP version"
+    (python_bindings/test/trajectory_optimizer_test.py:17-91)"""
+    model, prob, sp, q_guess = spinner_python_test_problem()
+    opt = TrajectoryOptimizer(model, prob, sp)
+    assert opt.time_step() == 0.05 and opt.num_steps() == 40
+    sol, st, flag = solve(opt, q_guess)
+    assert sol.q.shape == (41, 3) and sol.v.shape == (41, 3) and sol.tau.shape == (40, 3)
+    assert np.linalg.norm(sol.q[-1] - np.array([0.287, 1.497, 1.995])) < 1e-3
+    assert flag == "kMaxIterationsReached" and st.iteration_costs.size == 200
+    assert st.solve_time > 0
+
+
+@pytest.mark.parametrize("name,iters", [("acrobot", 10), ("spinner", 10), ("hopper", 10), ("mini_cheetah", 5),
+                                         ("allegro_hand", 3)])
+def test_solve_tracks_the_oracle(name, iters):
+    """Every example config (reference examples/*/*.yaml; scaling and equality constraints ON as
+    in the YAMLs): the device-backed Solve follows the CPU oracle's iterates.  Tolerance: cost and
+    trust-region radius sequences equal to 1e-6 relative; the reference's own Python test accepts
+    1e-3 on q for CPP vs Python."""
+    cfg = load_config(name)
+    model = load_model(name)
+    prob, sp, q_guess = make_problem(cfg, model)
+    sp.max_iterations, sp.verbose, sp.num_threads = iters, False, 1
+    ref = Oracle(model, prob, sp).solve(q_guess)
+    opt = TrajectoryOptimizer(model, prob, sp)
+    assert opt.num_equality_constraints() == Oracle(model, prob, sp).num_eq
+    sol, st, flag = solve(opt, q_guess)
+    assert st.iteration_costs.size == iters and flag == "kMaxIterationsReached"
+    rc = ref["stats"]
+    assert np.allclose(st.iteration_costs, rc.iteration_costs, rtol=1e-6), (st.iteration_costs, rc.iteration_costs)
+    assert np.allclose(st.trust_region_radii, rc.trust_region_radii, rtol=1e-12)
+    assert np.allclose(st.h_norms, rc.h_norms, rtol=1e-5, atol=1e-9)
+    assert np.abs(sol.q - ref["q"]).max() <= 1e-5 * max(1.0, np.abs(ref["q"]).max())
+    assert st.iteration_costs[-1] <= st.iteration_costs[0]
+
+
+def test_eval_matches_oracle():
+    """gradient bit-exact (device == oracle); scaling, multipliers and merit to round-off"""
+    cfg = load_config("hopper")
+    model = load_model("hopper")
+    prob, sp, q_guess = make_problem(cfg, model, num_steps=12)
+    sp.verbose = False
+    from idto_amd.problem import synthetic_trajectory
+    q = synthetic_trajectory(cfg, model, 12, seed=2, lower=0.02)
+    opt, orc = TrajectoryOptimizer(model, prob, sp), Oracle(model, prob, sp)
+    got, want = opt.eval(q), orc.eval_all(q)
+    g_ref, _ = orc.grad_hess(q)
+    assert got["cost"] == orc.eval_traj(q)[3]
+    assert np.array_equal(got["gradient"], g_ref)
+    assert np.array_equal(got["scale_factors"], want["D"])
+    assert np.array_equal(got["scaled_gradient"], want["g_scaled"])
+    lam, lam_ref = got["lagrange_multipliers"], want["lam"]
+    assert lam.size == orc.num_eq > 0
+    assert np.abs(lam - lam_ref).max() <= 1e-6 * np.abs(lam_ref).max()
+    assert abs(got["merit"] - want["merit"]) <= 1e-8 * abs(want["merit"])
+    assert np.abs(got["merit_gradient"] - want["merit_grad"]).max() <= 1e-6 * np.abs(want["merit_grad"]).max()
+
+
+def test_dogleg_point():  # TO_test.cc:285-362
+    N, dt = 2, 5e-2
+    model = pendulum()
+    o, prob, sp = mk_oracle(model, N, dt, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 1.0, 0.0, 0.0, scaling=False)
+    opt = TrajectoryOptimizer(model, prob, sp)
+    q = np.array([[0.0], [1.5], [1.5]])
+    tol = EPS / dt
+    dq_s, _, act = opt.dogleg(q, 1e-3)
+    assert act and abs(np.linalg.norm(dq_s) - 1e-3) < tol
+    dq_l, _, act = opt.dogleg(q, 1e3)
+    assert not act and np.linalg.norm(dq_l) > np.linalg.norm(dq_s)
+    dq_m, _, act = opt.dogleg(q, 1.0)
+    assert act and abs(np.linalg.norm(dq_m) - 1.0) < tol
+    assert np.linalg.norm(dq_l) > np.linalg.norm(dq_m) > np.linalg.norm(dq_s)
+
+
+def test_trust_ratio_is_one_for_linear_system():  # TO_test.cc:369-429
+    N, dt = 5, 5e-2
+    model = pendulum(False)
+    o, prob, sp = mk_oracle(model, N, dt, 0.1, 0.0, 1.0, 2.0, 3.0, 4.0, 5.0, np.pi, -0.3)
+    opt = TrajectoryOptimizer(model, prob, sp)
+    q = np.array([0.1 + 0.01 * t for t in range(N + 1)]).reshape(-1, 1)
+    dq, _, active = opt.dogleg(q, 1e3)   # inside the trust region: the full Gauss-Newton step, unscaled
+    assert not active
+    assert abs(opt.trust_ratio(q, dq) - 1.0) < SQRT_EPS
+
+
+@pytest.mark.parametrize("target", [np.pi, -1.2])
+def test_pendulum_swingup_and_update_nominal(target):  # TO_test.cc:434-490, 1754-1827
+    N, dt = 20, 5e-2
+    model = pendulum()
+    _, prob, sp = mk_oracle(model, N, dt, 0.1, 0.0, 1.0, 0.1, 1000, 1, 0.01, np.pi, 0.0, max_iterations=20,
+                            check_convergence=True, rel_cost_reduction=1e-5)
+    opt = TrajectoryOptimizer(model, prob, sp)
+    if target != np.pi:
+        opt.UpdateNominalTrajectory(np.full((N + 1, 1), target), np.zeros((N + 1, 1)))
+    sol, st, flag = solve(opt, np.full((N + 1, 1), 0.1))
+    assert flag == "kSuccess"
+    assert abs(sol.q[N, 0] - target) < 1e-3
+
+
+def test_warm_start_equivalence():
+    """10 iterations in one Solve == 10 x SolveFromWarmStart(max_iterations=1)
+    (python_bindings/test/warm_start_test.py:165-182; same process, same device arithmetic =>
+    identical to round-off)"""
+    model, prob, sp, q_guess = spinner_python_test_problem()
+    sp.max_iterations = 10
+    _, full, _ = solve(TrajectoryOptimizer(model, prob, sp), q_guess)
+    sp1 = SolverParameters(**{**sp.__dict__, "max_iterations": 1})
+    o1 = TrajectoryOptimizer(model, prob, sp1)
+    ws = o1.CreateWarmStart(q_guess)
+    costs, radii = [], []
+    for _ in range(10):
+        sol, st = TrajectoryOptimizerSolution(), TrajectoryOptimizerStats()
+        o1.SolveFromWarmStart(ws, sol, st)
+        costs.append(st.iteration_costs[0])
+        radii.append(st.trust_region_radii[0])
+    assert np.allclose(costs, full.iteration_costs, rtol=0, atol=1e-8)
+    assert np.allclose(radii, full.trust_region_radii, rtol=0, atol=1e-8)
+    assert np.array_equal(ws.get_q(), sol.q)
+
+
+def test_reset_initial_conditions():  # python_bindings/test/warm_start_test.py:119-139
+    model, prob, sp, q_guess = spinner_python_test_problem()
+    sp.max_iterations = 2
+    opt = TrajectoryOptimizer(model, prob, sp)
+    q0, v0 = np.array([0.35, 1.45, 0.05]), np.array([0.1, -0.1, 0.2])
+    opt.ResetInitialConditions(q0, v0)
+    ws = opt.CreateWarmStart(np.tile(q0, (41, 1)))
+    sol, st = TrajectoryOptimizerSolution(), TrajectoryOptimizerStats()
+    opt.SolveFromWarmStart(ws, sol, st)
+    assert np.array_equal(sol.q[0], q0) and np.array_equal(sol.v[0], v0)
+
+
+def test_unsupported_options_fail_loudly():
+    model, prob, sp, _ = spinner_python_test_problem()
+    sp.gradients_method = "central_differences"
+    with pytest.raises(RuntimeError, match="kForwardDifferences"):
+        TrajectoryOptimizer(model, prob, sp)
