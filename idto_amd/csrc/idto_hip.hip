@@ -67,6 +67,11 @@ struct idto_hip_ctx {
   bool timing = false;
   struct Timed { hipEvent_t a, b; int which; };
   std::vector<Timed> pending;
+  bool two_sided = true;                  // solver: two workgroups eliminating from both ends
+  double* xch = nullptr;                  // their exchange buffer / flags
+  unsigned* flags = nullptr;
+  size_t xch_count = 0, flag_count = 0;
+  unsigned epoch = 0;
   double *stage_rhs = nullptr, *stage_x = nullptr;  // idto_hip_solve_host
   size_t stage_count = 0;
   std::vector<hipEvent_t> event_pool;  // recycled: creating events in the timed loop costs host time
@@ -305,10 +310,10 @@ int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem, co
   bad |= Alloc(c, (size_t)(N + 1) * qq, &c->Yst) != 0;
   bad |= Alloc(c, (size_t)(N + 1) * qq, &c->Zst) != 0;
   bad |= Alloc(c, (size_t)(N + 1) * nq, &c->pivst) != 0;
-  bad |= Alloc(c, (size_t)(N + 4) * 8 * 16, &c->dbg) != 0;
-  bad |= Alloc(c, (size_t)(N + 1) * 32 * 32, &c->Ust) != 0;
-  bad |= Alloc(c, (size_t)(N + 1) * 32 * 32, &c->Hst) != 0;
-  bad |= Alloc(c, (size_t)(N + 1) * 32 * 32, &c->Est) != 0;
+  bad |= Alloc(c, (size_t)(N + 4) * 8 * 32, &c->dbg) != 0;
+  bad |= Alloc(c, (size_t)(N + 1) * 32 * 36, &c->Ust) != 0;
+  bad |= Alloc(c, (size_t)(N + 1) * 32 * 36, &c->Hst) != 0;
+  bad |= Alloc(c, (size_t)(N + 1) * 32 * 36, &c->Est) != 0;
   bad |= Alloc(c, (size_t)(N + 1) * 32, &c->Dst) != 0;
   if (bad) { idto_hip_destroy(c); return -2; }
   c->k_begin = 0; c->k_end = N;
@@ -442,20 +447,40 @@ static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, int nrhs, do
   if (gj_waves > 15) { g_err = "too many right-hand sides for one launch"; return -1; }
   const int threads = (gj_waves + 1 <= 4) ? 256 : 1024;
   const PentaLdlLds L = penta_ldl_layout(n, K, nrhs);
-  const int lds = L.end * (int)sizeof(double);
+  int lds = L.end * (int)sizeof(double);
   if (lds > 160 * 1024) { g_err = "right-hand sides do not fit the LDS carve-up"; return -1; }
   double* dbg = c->solver_debug ? c->dbg : nullptr;
+  // two-sided elimination (two workgroups meeting at block rows m, m+1) once the horizon is long
+  // enough to pay for the hand-over; exchange buffer: 2 augmented blocks + [nrhs][2][K]
+  const int m_split = (c->two_sided && n >= 10) ? (n - 1) / 2 : 0;
+  const dim3 grid(m_split > 0 ? 2 : 1);
+  // the two workgroups must not share a CU (each is one wavefront per SIMD, issue-bound): ask for
+  // more than half of the 160 KB LDS so that the dispatcher cannot co-locate them
+  if (m_split > 0) lds = std::max(lds, 84 * 1024);
+  if (m_split > 0) {
+    const size_t need = 2 * (size_t)(K + ncr) * ldl_ks(K) + (size_t)nrhs * 2 * K, nflags = (size_t)nrhs + 1;
+    if (need > c->xch_count) {
+      if (Alloc(c, need, &c->xch)) return -2;
+      c->xch_count = need;
+    }
+    if (nflags > c->flag_count) {
+      if (Alloc(c, nflags, &c->flags)) return -2;
+      HIP_OK(hipMemsetAsync(c->flags, 0, nflags * sizeof(unsigned), c->stream));
+      c->flag_count = nflags;
+      c->epoch = 0;
+    }
+    ++c->epoch;
+  }
+#define LDL_ARGS n, k, c->HA, c->HB, c->HC, b, sign, nrhs, xo, c->Ust, c->Hst, c->Est, c->Dst, dbg, m_split, c->xch, \
+                 c->flags, c->epoch
 #define LDL_LAUNCH(KM, PD, GW)                                                                                \
   do {                                                                                                        \
     if (threads == 256 && gj_waves == GW)                                                                     \
-      hipLaunchKernelGGL((penta_ldl_kernel<KM, 256, PD, GW>), dim3(1), dim3(256), lds, c->stream, n, k, c->HA, \
-                         c->HB, c->HC, b, sign, nrhs, xo, c->Ust, c->Hst, c->Est, c->Dst, dbg);                \
+      hipLaunchKernelGGL((penta_ldl_kernel<KM, 256, PD, GW>), grid, dim3(256), lds, c->stream, LDL_ARGS);       \
     else if (threads == 256)                                                                                  \
-      hipLaunchKernelGGL((penta_ldl_kernel<KM, 256, PD, 0>), dim3(1), dim3(256), lds, c->stream, n, k, c->HA,  \
-                         c->HB, c->HC, b, sign, nrhs, xo, c->Ust, c->Hst, c->Est, c->Dst, dbg);                \
+      hipLaunchKernelGGL((penta_ldl_kernel<KM, 256, PD, 0>), grid, dim3(256), lds, c->stream, LDL_ARGS);        \
     else                                                                                                      \
-      hipLaunchKernelGGL((penta_ldl_kernel<KM, 1024, PD, 0>), dim3(1), dim3(1024), lds, c->stream, n, k, c->HA, \
-                         c->HB, c->HC, b, sign, nrhs, xo, c->Ust, c->Hst, c->Est, c->Dst, dbg);                \
+      hipLaunchKernelGGL((penta_ldl_kernel<KM, 1024, PD, 0>), grid, dim3(1024), lds, c->stream, LDL_ARGS);      \
   } while (0)
   switch (K) {
     case 2: LDL_LAUNCH(2, false, 1); break;
@@ -469,6 +494,7 @@ static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, int nrhs, do
     default: LDL_LAUNCH(32, true, 3); break;
   }
 #undef LDL_LAUNCH
+#undef LDL_ARGS
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -525,6 +551,7 @@ int idto_hip_solve_host(idto_hip_ctx* c, const double* rhs_host, int nrhs, doubl
 int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "reference_solver") == 0) { c->reference_solver = value != 0; return 0; }
   if (std::strcmp(name, "solver_debug") == 0) { c->solver_debug = value != 0; return 0; }
+  if (std::strcmp(name, "two_sided") == 0) { c->two_sided = value != 0; return 0; }
   g_err = std::string("unknown option ") + name;
   return -1;
 }
@@ -569,7 +596,7 @@ long idto_hip_array_size(idto_hip_ctx* c, int what) {
     case IDTO_ARR_H_A: case IDTO_ARR_H_B: case IDTO_ARR_H_C: return (N + 1) * qq;
     case IDTO_ARR_COST: return 1;
     case IDTO_ARR_SLAB: return N * (long)c->slab_stride;
-    case 15: return (N + 4) * 8 * 16;
+    case 15: return (N + 4) * 8 * 32;
     default: return -1;
   }
 }

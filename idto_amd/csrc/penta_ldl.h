@@ -43,6 +43,13 @@ __device__ __forceinline__ double rdlane(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// v[LANE] = val (val wave-uniform, LANE an inline constant: one SGPR operand at most); clang has
+// no builtin for v_writelane_b32
+template <int LANE>
+__device__ __forceinline__ void wrlane(int& v, int val) {
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(val), "n"(LANE));
+}
+
 // 1/d to full double precision: hardware estimate + 2 Newton steps (5 instructions instead of
 // the ~15 of an IEEE division; the factorisation is not bit-compared with the host).
 __device__ __forceinline__ double fast_rcp(double d) {
@@ -54,26 +61,56 @@ __device__ __forceinline__ double fast_rcp(double d) {
   return x;
 }
 
+// One pivot step (J is a template parameter so that v_writelane can take the lane as an inline
+// constant).  The pivots d_J are wave-uniform (SGPR pairs); lane J keeps its own with v_writelane
+// (2 instructions per pivot, no compare/select chain) and inverts it once at the end.
+// Software-pipelined: the reciprocal of pivot J+1 (broadcast + v_rcp + 2 Newton steps, ~60 cycles
+// of dependent latency) only needs row J+1 of the update by pivot J, so that row is updated first
+// and the reciprocal chain overlaps with the remaining FMAs of pivot J.
+template <int K, int J>
+__device__ __forceinline__ void ldl_pivot(double (&xr)[K], double d, double inv, int& dlo, int& dhi) {
+  wrlane<J>(dlo, __double2loint(d));
+  wrlane<J>(dhi, __double2hiint(d));
+  const double t = xr[J] * inv;
+  // multipliers are wave-uniform (SGPR pairs): broadcast them in chunks so that at most CH pairs
+  // are live at a time (the kernel is short of SGPRs; spills cost v_readlane's on this path)
+  constexpr int CH = 8;
+  double inv_next = 1.0, d_next = 1.0;
+  if constexpr (J + 1 < K) {
+    const double m1 = rdlane(xr[J + 1], J);
+    xr[J + 1] = __builtin_fma(-m1, t, xr[J + 1]);
+    d_next = rdlane(xr[J + 1], J + 1);
+    inv_next = fast_rcp(d_next);
+  }
+#pragma unroll
+  for (int r0 = J + 2; r0 < K; r0 += CH) {
+    double m[CH];
+#pragma unroll
+    for (int q = 0; q < CH; ++q)
+      if (r0 + q < K) m[q] = rdlane(xr[r0 + q], J);
+#pragma unroll
+    for (int q = 0; q < CH; ++q)
+      if (r0 + q < K) xr[r0 + q] = __builtin_fma(-m[q], t, xr[r0 + q]);
+  }
+  if constexpr (J + 1 < K) ldl_pivot<K, J + 1>(xr, d_next, inv_next, dlo, dhi);
+}
+
 // Forward elimination of the columns held by this wavefront (lanes < K: columns of S).
 // On exit: S lanes hold U = D L^T (upper triangle), rhs lanes L^{-1} rhs; returns 1 / U[l][l]
 // in lane l (l < K).
 template <int K>
 __device__ __forceinline__ double ldl_eliminate_wave(double (&xr)[K], int lane) {
-  double myinv = 1.0;
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    const double d = rdlane(xr[j], j);
-    const double inv = fast_rcp(d);
-    myinv = (lane == j) ? inv : myinv;
-    const double t = xr[j] * inv;
-    double m[K];
-#pragma unroll
-    for (int r = j + 1; r < K; ++r) m[r] = rdlane(xr[r], j);
-#pragma unroll
-    for (int r = j + 1; r < K; ++r) xr[r] = __builtin_fma(-m[r], t, xr[r]);
-  }
-  return myinv;
+  int dlo = 0, dhi = 0x3ff00000;  // 1.0 in the lanes that hold no pivot
+  const double d = rdlane(xr[0], 0);
+  ldl_pivot<K, 0>(xr, d, fast_rcp(d), dlo, dhi);
+  return fast_rcp(__hiloint2double(dhi, dlo));
 }
+
+// Column stride (in doubles) of every K-row block kept in LDS and of the row-major factor blocks:
+// even (16-byte aligned columns for ds_read_b128) and = 2 mod 4, i.e. an odd number of 16-byte
+// units, so that consecutive columns start in different LDS bank groups (a stride of 20 doubles
+// put the 10 even columns of the K = 19 tiles on only 4 of the 16 groups).
+__host__ __device__ constexpr int ldl_ks(int K) { return (((K + 1) & ~1) % 4 == 0) ? ((K + 1) & ~1) + 2 : ((K + 1) & ~1); }
 
 struct PentaLdlLds {  // offsets in doubles
   int W, Ht, Et, Iv, rt, U, G, in, dump, bl, bl_size, xall, end;
@@ -81,7 +118,7 @@ struct PentaLdlLds {  // offsets in doubles
 };
 __host__ __device__ inline PentaLdlLds penta_ldl_layout(int n, int K, int nrhs) {
   PentaLdlLds L;
-  const int ks = (K + 1) & ~1, ncr = 2 * K + nrhs;  // even column stride: 16-byte aligned columns
+  const int ks = ldl_ks(K), ncr = 2 * K + nrhs;
   L.kks = K * ks;
   L.rts = nrhs * ks;
   int o = 0;
@@ -138,10 +175,25 @@ __global__ void __launch_bounds__(NT)
 penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __restrict__ HB,
                  const double* __restrict__ HC, const double* __restrict__ b, double rhs_sign, int nrhs,
                  double* __restrict__ x, double* __restrict__ Ust, double* __restrict__ Hst,
-                 double* __restrict__ Est, double* __restrict__ Dst, double* __restrict__ dbg) {
+                 double* __restrict__ Est, double* __restrict__ Dst, double* __restrict__ dbg,
+                 int m_split, double* __restrict__ xch, unsigned* __restrict__ flags, unsigned epoch) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int nt = NT, KK = K * K, ks = (K + 1) & ~1, NW = NT / 64;
+  // ---- two-sided ("twisted") elimination, m_split > 0, grid of 2 workgroups: workgroup 0
+  // eliminates block rows 0 .. m-1 top-down, workgroup 1 rows n-1 .. m+2 bottom-up with the
+  // mirrored recursion (the reversed matrix has B'_{i'} = B_{n-i'}^T, A'_{i'} = A_{n+1-i'}^T: the
+  // prefetch reads the bands transposed, nothing else changes).  Rows m, m+1 are the join: the
+  // bottom workgroup runs two product-only pseudo-rows whose augmented blocks W are exactly its
+  // Schur-complement contributions to rows m+1 and m, hands them over through `xch` + a flag,
+  // and the top workgroup adds them before eliminating rows m and m+1.  Back substitution runs
+  // outwards from the join in both workgroups (x_m, x_{m+1} handed to the bottom one).  The
+  // dependent chain is ~n/2 block rows instead of n in both passes.
+  const int side = blockIdx.x;
+  const bool two = m_split > 0;
+  const int nloc = two ? (side ? n - m_split - 2 : m_split + 2) : n;  // block rows eliminated here
+  const int nfwd = nloc + ((two && side) ? 2 : 0);                    // + pseudo-rows (bottom)
+  auto orig = [&](int il) { const int o = side ? n - 1 - il : il; return o < 0 ? 0 : o; };
+  constexpr int nt = NT, KK = K * K, ks = ldl_ks(K), NW = NT / 64;
   const int kk = k * k;
   const int ncr = 2 * K + nrhs, per_wave = 64 - K;
   const int gj_waves = GJW ? GJW : (ncr + per_wave - 1) / per_wave;
@@ -149,7 +201,8 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
   const PentaLdlLds L = penta_ldl_layout(n, K, nrhs);
   double* Wm = lds + L.W;
   auto stamp = [&](int i, int ph) {
-    if (dbg && lane == 0) dbg[(wave * (n + 3) + i) * 8 + ph] = (double)__builtin_readcyclecounter();
+    if (dbg && lane == 0)
+      dbg[((side * (NT / 64) + wave) * (n + 3) + i) * 8 + ph] = (double)__builtin_readcyclecounter();
   };
 
   // ---- setup
@@ -159,7 +212,7 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
   for (int idx = tid; idx < 3 * ks; idx += nt) lds[L.Iv + idx] = ((idx % ks) < K) ? 1.0 : 0.0;
   for (int idx = tid; idx < L.bl_size; idx += nt) {  // layout [j][i][r] with K rows
     const int j = idx / (n * K), rem = idx - j * (n * K), i = rem / K, r = rem - i * K;
-    lds[L.bl + idx] = (r < k) ? rhs_sign * b[(size_t)j * nk + (size_t)i * k + r] : 0.0;
+    lds[L.bl + idx] = (r < k && i < nloc) ? rhs_sign * b[(size_t)j * nk + (size_t)orig(i) * k + r] : 0.0;
   }
 
   // ---- row inputs [A_i | B_{i+1} | C_i | A_{i+2}]: fetched one row ahead into registers and
@@ -175,41 +228,52 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
   const int ht = tid - io_first * 64;                           // index among the I/O threads (< 0: none)
   const int hn = nt - io_first * 64;
   constexpr int HN_MIN = GJW ? ((NT / 64 - GJW > 1) ? NT - (GJW + 1) * 64 : NT - GJW * 64) : 64;
-  constexpr int PMAX = (4 * KK + HN_MIN - 1) / HN_MIN;
+  constexpr int PMAX = (3 * KK + HN_MIN - 1) / HN_MIN;
   // Branch-free: every I/O lane loads PMAX values per row through 32-bit offsets from HA (the
   // three bands live in one allocation); lanes/slots without a source load element 0 and the
   // result is discarded (m_valid) or replaced by the identity padding (m_load / m_one).
   double pre[PMAX];
   int p_off[PMAX];
-  unsigned long long m_valid = 0, m_load = 0, m_one = 0;
+  unsigned long long m_valid = 0, m_load = 0, m_one = 0, m_isA = 0, m_isB = 0;
   static_assert(PMAX <= 64, "slot masks are 64-bit");
   const int dHB = (int)(HB - HA), dHC = (int)(HC - HA);
 #pragma unroll
   for (int s = 0; s < PMAX; ++s) {
     const int idx = ht + s * hn;
     p_off[s] = 0;
-    if (ht >= 0 && idx < 4 * KK) {
+    if (ht >= 0 && idx < 3 * KK) {  // staged blocks: 0 B_{i+1}, 1 C_i, 2 A_{i+2} (top-down naming)
       m_valid |= 1ull << s;
       const int which = idx / KK, e = idx - which * KK, c = e / K, r = e - c * K;
-      const int rowshift = (which == 1) ? 1 : ((which == 3) ? 2 : 0);
+      if (which == 0) m_isB |= 1ull << s;
+      if (which == 2) m_isA |= 1ull << s;
       if (!PADDED || (r < k && c < k)) {
         m_load |= 1ull << s;
-        p_off[s] = ((which == 1) ? dHB : ((which == 2) ? dHC : 0)) + rowshift * kk + c * k + r;
-      } else if (which == 2 && r == c) {
+        if (which == 1) p_off[s] = dHC + c * k + r;
+        else if (!side) p_off[s] = ((which == 0) ? dHB + kk : 2 * kk) + c * k + r;  // B_{i+1}, A_{i+2}
+        else p_off[s] = ((which == 0) ? dHB : 0) + r * k + c;                        // B_i^T, A_i^T
+      } else if (which == 1 && r == c) {
         m_one |= 1ull << s;
       }
     }
   }
   auto fetch = [&](int i) {
-    const double* base = HA + (size_t)i * kk;
+    const double* base = HA + (size_t)orig(i) * kk;
 #pragma unroll
     for (int s = 0; s < PMAX; ++s) pre[s] = base[p_off[s]];
   };
-  auto stage = [&]() {
+  auto stage = [&](int il) {  // il = the local row being staged
+    // join rows of the top workgroup have no coupling to rows m+2.. (eliminated by the other
+    // workgroup); pseudo-rows of the bottom workgroup have all-zero inputs
+    unsigned long long kill = 0;
+    if (two) {
+      if (!side) kill = (il >= m_split ? m_isA : 0ull) | (il >= m_split + 1 ? m_isB : 0ull);
+      else if (il >= nloc) kill = ~0ull;
+    }
 #pragma unroll
     for (int s = 0; s < PMAX; ++s) {
       double val = pre[s];
       if (PADDED) val = (m_load >> s & 1) ? val : ((m_one >> s & 1) ? 1.0 : 0.0);
+      val = (kill >> s & 1) ? 0.0 : val;
       const int dst = (m_valid >> s & 1) ? L.in + ht + s * hn : L.dump;
       lds[dst] = val;
     }
@@ -225,7 +289,7 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
     const int cc = (c < K) ? c : 0;
     wb_src[it] = (cc * ks + r) | r << 16 | (c >= K ? 1 : 0) << 24 | ((r < c && c < K) ? 1 : 0) << 25;
   }
-  if (ht >= 0) { fetch(0); stage(); fetch(1); }
+  if (ht >= 0) { fetch(0); stage(0); fetch(1); }
 
   // ---- per-thread product job (fixed over rows); job type is uniform per wavefront:
   //   wave 0: tiles of S (lower triangle) ; waves 1..NW-2: tiles of H (+ E copy) ; last wave: y
@@ -245,9 +309,9 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
   constexpr int HW = (NW > 2) ? NW - 2 : 1;  // wavefronts working on H tiles
   __syncthreads();
 
-  for (int i = 0; i < n; ++i) {
-    double* Ai = lds + L.in;
-    double* Bn = Ai + KK;
+  for (int i = 0; i < nfwd; ++i) {
+    const bool pseudo = i >= nloc;  // bottom workgroup: product-only rows forming the join contributions
+    double* Bn = lds + L.in;
     double* Ci = Bn + KK;
     double* An2 = Ci + KK;
     const double* Htp = lds + L.Ht + ((i + 1) & 1) * L.kks;     // Ht_{i-1}
@@ -325,13 +389,36 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
           }
         }
         const double bval = L.bl_size ? lds[L.bl + (j * n + i) * K + r]
-                                      : ((r < k) ? rhs_sign * b[(size_t)j * nk + (size_t)i * k + r] : 0.0);
+                                      : ((r < k && !pseudo) ? rhs_sign * b[(size_t)j * nk + (size_t)orig(i) * k + r] : 0.0);
         Wm[(3 * K + j) * ks + r] = (bval - a0) - a1;
       }
     }
     stamp(i, 5);
     lds_barrier();
     stamp(i, 2);
+
+    if (two && !side && i >= m_split) {
+      // ---- join: add the other workgroup's Schur-complement contributions to [S | H | . | y]
+      if (i == m_split) {
+        if (tid == 0)
+          while (__hip_atomic_load(flags, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+            __builtin_amdgcn_s_sleep(2);
+        __syncthreads();
+        (void)__hip_atomic_load(flags, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);  // every wavefront acquires
+      }
+      const int wsz = (K + ncr) * ks;
+      const double* X0 = xch;         // pseudo-row 0: contributions to row m+1 (and the (m+1, m) coupling)
+      const double* X1 = xch + wsz;   // pseudo-row 1: contributions to row m
+      const double* Xs = (i == m_split) ? X1 : X0;
+      for (int idx = tid; idx < K * ks; idx += nt) Wm[idx] += Xs[idx];                       // S
+      for (int idx = tid; idx < nrhs * ks; idx += nt) Wm[3 * K * ks + idx] += Xs[3 * K * ks + idx];  // y
+      if (i == m_split)
+        for (int idx = tid; idx < KK; idx += nt) {  // H(r, c) += H'(c, r)
+          const int c = idx / K, r = idx - c * K;
+          Wm[(K + c) * ks + r] += X0[(K + r) * ks + c];
+        }
+      lds_barrier();
+    }
 
     if (wave < gj_waves) {
       // ---- forward elimination in registers
@@ -346,7 +433,19 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
         if (K & 1) xr[K - 1] = Wm[col * ks + K - 1];
       }
       stamp(i, 3);
-      const double myinv = ldl_eliminate_wave<K>(xr, lane);
+      double myinv = 1.0;
+      if (!pseudo) {
+        myinv = ldl_eliminate_wave<K>(xr, lane);
+      } else {
+        // hand the column over (layout of W) and continue the recursion with a zero row
+        if (lane < K || is_rhs) {
+          double* dstg = xch + (size_t)(i - nloc) * (K + ncr) * ks + (size_t)col * ks;
+#pragma unroll
+          for (int r = 0; r < K; ++r) dstg[r] = xr[r];
+        }
+#pragma unroll
+        for (int r = 0; r < K; ++r) xr[r] = 0.0;
+      }
       stamp(i, 4);
       // every lane stores its column: S lanes -> U, rhs lanes -> Ht | Et | rt
       double* dst = nullptr;
@@ -363,12 +462,12 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
         const int j = rc - 2 * K;
 #pragma unroll
         for (int r = 0; r < K; ++r)
-          if (r < k) x[(size_t)j * nk + (size_t)i * k + r] = xr[r];  // parked until the backward pass
+          if (r < k && !pseudo) x[(size_t)j * nk + (size_t)orig(i) * k + r] = xr[r];  // parked until the backward pass
       }
     } else {
       // ---- helper wavefronts
       if (ht >= 0) {  // stage the next row's inputs, prefetch the one after
-        stage();
+        stage(i + 1);
         stamp(i, 3);
         fetch(i + 2);
         stamp(i, 4);
@@ -386,7 +485,7 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
           Gb[c1 * K + r1] = a11; Gb[r1 * K + c1] = a11;
         }
       }
-      if (ht >= 0 && i > 0) {
+      if (ht >= 0 && i > 0 && i <= nloc) {
         // factors of row i-1 for the backward pass, ROW-major (stride ks) so that a lane reads its
         // row with 16-byte loads; rows are scaled by 1/d_r, U keeps its strict upper triangle
 #pragma unroll
@@ -396,19 +495,19 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
             const int src = wb_src[it] & 0xffff, r = wb_src[it] >> 16 & 0xff;
             const bool in = !(wb_src[it] >> 24 & 1), up = wb_src[it] >> 25 & 1;
             const double dr = Ivp[r];
-            Ust[(size_t)(i - 1) * K * ks + idx] = up ? Up[src] * dr : 0.0;
-            Hst[(size_t)(i - 1) * K * ks + idx] = in ? Htp[src] * dr : 0.0;
-            Est[(size_t)(i - 1) * K * ks + idx] = in ? Etp[src] * dr : 0.0;
+            Ust[(size_t)orig(i - 1) * K * ks + idx] = up ? Up[src] * dr : 0.0;
+            Hst[(size_t)orig(i - 1) * K * ks + idx] = in ? Htp[src] * dr : 0.0;
+            Est[(size_t)orig(i - 1) * K * ks + idx] = in ? Etp[src] * dr : 0.0;
           }
         }
-        for (int r = ht; r < K; r += hn) Dst[(size_t)(i - 1) * K + r] = Ivp[r];
+        for (int r = ht; r < K; r += hn) Dst[(size_t)orig(i - 1) * K + r] = Ivp[r];
       }
     }
     stamp(i, 6);
     lds_barrier();
   }
-  {  // last row's factors
-    const int i = n - 1;
+  if (nfwd == nloc) {  // last row's factors (the bottom workgroup wrote them during its pseudo-rows)
+    const int i = nloc - 1;
     const double* Ul = lds + L.U + (i & 1) * L.kks;
     const double* Hl = lds + L.Ht + (i & 1) * L.kks;
     const double* El = lds + L.Et + (i % 3) * L.kks;
@@ -417,15 +516,20 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
       const int r = idx / ks, c = idx - r * ks;
       const bool in = c < K;
       const double dr = Il[r];
-      Ust[(size_t)i * K * ks + idx] = (in && r < c) ? Ul[c * ks + r] * dr : 0.0;
-      Hst[(size_t)i * K * ks + idx] = in ? Hl[c * ks + r] * dr : 0.0;
-      Est[(size_t)i * K * ks + idx] = in ? El[c * ks + r] * dr : 0.0;
+      Ust[(size_t)orig(i) * K * ks + idx] = (in && r < c) ? Ul[c * ks + r] * dr : 0.0;
+      Hst[(size_t)orig(i) * K * ks + idx] = in ? Hl[c * ks + r] * dr : 0.0;
+      Est[(size_t)orig(i) * K * ks + idx] = in ? El[c * ks + r] * dr : 0.0;
     }
-    for (int r = tid; r < K; r += nt) Dst[(size_t)i * K + r] = Il[r];
+    for (int r = tid; r < K; r += nt) Dst[(size_t)orig(i) * K + r] = Il[r];
+  }
+  if (two && side) {  // publish the join contributions
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flags, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();  // factors written by this block are re-read below: drain the stores
   __threadfence_block();
-  stamp(n, 0);
+  stamp(nfwd, 0);
 
   // ---- backward pass: (D_i^-1 U_i) x_i = D_i^-1 rt_i - (D_i^-1 Ht_i) x_{i+1} - (D_i^-1 Et_i) x_{i+2}
   // One wavefront per right-hand side, no LDS staging and no barrier: lane = row r (+32 for the
@@ -443,15 +547,17 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
     for (int c = 0; c < 2 * KP; ++c) { xs1[c] = 0.0; xs2[c] = 0.0; }
     double2 A0[KP], U0[KP], A1[KP], U1[KP];
     double dv0 = 1.0, dv1 = 1.0, rt0 = 0.0, rt1 = 0.0;
+    double* xjoin = xch + 2 * (size_t)(K + ncr) * ks;  // [nrhs][2][K]: x_m, x_{m+1}
     auto load_row = [&](int i, double2 (&A)[KP], double2 (&U)[KP], double& dv, double& rtv) {
       if (i < 0) return;
-      const double2* a = reinterpret_cast<const double2*>((half_ ? Est : Hst) + (size_t)i * KS2 + rr * ks);
-      const double2* u = reinterpret_cast<const double2*>(Ust + (size_t)i * KS2 + rr * ks);
+      const size_t io = (size_t)orig(i);
+      const double2* a = reinterpret_cast<const double2*>((half_ ? Est : Hst) + io * KS2 + rr * ks);
+      const double2* u = reinterpret_cast<const double2*>(Ust + io * KS2 + rr * ks);
 #pragma unroll
       for (int m = 0; m < KP; ++m) { A[m] = a[m]; U[m] = u[m]; }
-      dv = Dst[(size_t)i * K + rr];
+      dv = Dst[io * K + rr];
       rtv = L.bl_size ? lds[L.xall + (j * (n + 2) + i + 2) * ks + rr]
-                      : ((rr < k) ? x[(size_t)j * nk + (size_t)i * k + rr] : 0.0);
+                      : ((rr < k) ? x[(size_t)j * nk + io * k + rr] : 0.0);
     };
     // xa = x_{i+1}, xb = x_{i+2}; x_i overwrites xb (roles swap from row to row: no copies)
     auto solve_row = [&](int i, const double2 (&A)[KP], const double2 (&U)[KP], double dv, double rtv,
@@ -476,27 +582,45 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
       }
       if (live) {
         if (L.bl_size) lds[L.xall + (j * (n + 2) + i + 2) * ks + r_] = v;
-        else if (r_ < k) x[(size_t)j * nk + (size_t)i * k + r_] = v;
+        else if (r_ < k) x[(size_t)j * nk + (size_t)orig(i) * k + r_] = v;
+        // the join rows' solution is what the other workgroup's back substitution starts from
+        if (two && !side && i >= m_split) xjoin[(size_t)(j * 2 + (i - m_split)) * K + r_] = v;
       }
     };
-    load_row(n - 1, A0, U0, dv0, rt0);
-    for (int i = n - 1; i >= 0; i -= 2) {
+    if (two && side) {
+      // x of local rows nloc (= row m+1) and nloc+1 (= row m) come from the top workgroup
+      if (lane == 0)
+        while (__hip_atomic_load(flags + 1 + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+          __builtin_amdgcn_s_sleep(2);
+      (void)__hip_atomic_load(flags + 1 + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int c = 0; c < K; ++c) {
+        xs1[c] = rdlane(xjoin[(size_t)(j * 2 + 1) * K + c], 0);  // wave-uniform: keep them in SGPRs
+        xs2[c] = rdlane(xjoin[(size_t)(j * 2 + 0) * K + c], 0);
+      }
+    }
+    load_row(nloc - 1, A0, U0, dv0, rt0);
+    for (int i = nloc - 1; i >= 0; i -= 2) {
       load_row(i - 1, A1, U1, dv1, rt1);
       solve_row(i, A0, U0, dv0, rt0, xs1, xs2);       // x_i -> xs2
       if (i - 1 >= 0) {
         load_row(i - 2, A0, U0, dv0, rt0);
         solve_row(i - 1, A1, U1, dv1, rt1, xs2, xs1);  // x_{i-1} -> xs1 ; then xs1 = x_{i-1}, xs2 = x_i
       }
+      if (two && !side && i == nloc - 1) {  // rows m+1 and m are solved: release the other workgroup
+        __threadfence();
+        if (lane == 0) __hip_atomic_store(flags + 1 + j, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
   __syncthreads();
   if (L.bl_size) {
-    for (int idx = tid; idx < nrhs * n * k; idx += nt) {
-      const int j = idx / (n * k), rem = idx - j * (n * k), i = rem / k, r = rem - i * k;
-      x[idx] = lds[L.xall + (j * (n + 2) + i + 2) * ks + r];
+    for (int idx = tid; idx < nrhs * nloc * k; idx += nt) {
+      const int j = idx / (nloc * k), rem = idx - j * (nloc * k), i = rem / k, r = rem - i * k;
+      x[(size_t)j * nk + (size_t)orig(i) * k + r] = lds[L.xall + (j * (n + 2) + i + 2) * ks + r];
     }
   }
-  stamp(n, 1);
+  stamp(nfwd, 1);
 }
 
 }  // namespace idto_dev
