@@ -49,7 +49,31 @@ struct DevModel {
   const int* pair_gb;
   const int* pair_sa;      // body slot of geometry A: -2 world, -1 common, >= 0 chain slot
   const int* pair_sb;
+  // all tables above live in ONE device buffer (doubles first, then the int tables) so that a
+  // kernel can stage the whole model into LDS with one coalesced copy and rebase the pointers
+  const double* blob;
+  int blob_n;              // size in doubles
 };
+
+// The model with every table pointer rebased from the global blob to a copy at `dst`
+// (LDS: the per-body tables sit on the dependent chain of id_eval; from L2 each access costs
+// ~1-2 us of exposed latency, from LDS ~100 cycles).
+IDTO_DEV DevModel rebase_model(const DevModel& M, const double* dst) {
+  DevModel L = M;
+  auto d = [&](const double* p) { return dst + (p - M.blob); };
+  auto i = [&](const int* p) {
+    return reinterpret_cast<const int*>(dst) + (p - reinterpret_cast<const int*>(M.blob));
+  };
+  L.parent = i(M.parent); L.jtype = i(M.jtype); L.qstart = i(M.qstart); L.vstart = i(M.vstart);
+  L.X_PF = d(M.X_PF); L.axis = d(M.axis); L.mass = d(M.mass); L.com = d(M.com); L.inertia = d(M.inertia);
+  L.damping = d(M.damping);
+  L.geom_type = i(M.geom_type); L.geom_X = d(M.geom_X); L.geom_size = d(M.geom_size);
+  L.chain = i(M.chain); L.nchain = i(M.nchain); L.pkind = i(M.pkind);
+  L.path_npairs = i(M.path_npairs); L.path_pairs = i(M.path_pairs);
+  L.pair_ga = i(M.pair_ga); L.pair_gb = i(M.pair_gb); L.pair_sa = i(M.pair_sa); L.pair_sb = i(M.pair_sb);
+  L.blob = dst;
+  return L;
+}
 
 struct DevContact {
   double k, vd, vs, mu, sigma, threshold;

@@ -67,6 +67,7 @@ struct idto_hip_ctx {
   bool timing = false;
   struct Timed { hipEvent_t a, b; int which; };
   std::vector<Timed> pending;
+  int asm_stop = 0;                       // profiling aid: truncate the assembly kernel after a phase
   bool two_sided = true;                  // solver: two workgroups eliminating from both ends
   double* xch = nullptr;                  // their exchange buffer / flags
   unsigned* flags = nullptr;
@@ -186,23 +187,37 @@ int BuildModel(idto_hip_ctx* c, const idto_model_t* m) {
   M.nb = nb; M.nq = m->nq; M.nv = m->nv; M.npaths = K; M.common_body = m->common_body;
   M.ngeoms = m->ngeoms; M.npairs = m->npairs; M.maxpp = maxpp;
   for (int i = 0; i < 3; ++i) M.gravity[i] = m->gravity[i];
-  int* ip; double* dp;
-#define UPI(field, src, n) if (Upload(c, src, n, &ip)) return -2; M.field = ip;
-#define UPD(field, src, n) if (Upload(c, src, n, &dp)) return -2; M.field = dp;
-  UPI(parent, m->parent, nb) UPI(jtype, m->jtype, nb) UPI(qstart, m->qstart, nb) UPI(vstart, m->vstart, nb)
-  UPD(X_PF, m->X_PF, (size_t)12 * nb) UPD(axis, m->axis, (size_t)3 * nb) UPD(mass, m->mass, nb)
-  UPD(com, m->com, (size_t)3 * nb) UPD(inertia, m->inertia, (size_t)6 * nb) UPD(damping, m->damping, m->nv)
-  UPI(geom_type, m->geom_type, m->ngeoms) UPD(geom_X, m->geom_X, (size_t)12 * m->ngeoms)
-  UPD(geom_size, m->geom_size, (size_t)3 * m->ngeoms)
-  UPI(chain, chain.data(), chain.size()) UPI(nchain, nchain.data(), nchain.size())
-  UPI(pkind, pkind.data(), pkind.size()) UPI(path_npairs, path_npairs.data(), path_npairs.size())
-  UPI(path_pairs, path_pairs.data(), path_pairs.size())
-  UPI(pair_ga, m->pair_a, m->npairs) UPI(pair_gb, m->pair_b, m->npairs)
-  UPI(pair_sa, sa.data(), sa.size()) UPI(pair_sb, sb.data(), sb.size())
-#undef UPI
-#undef UPD
+  // one blob: double tables, then int tables (two per double slot)
+  std::vector<double> dbl;
+  std::vector<int> ints;
+  auto addd = [&](const double* src, size_t n) { const size_t o = dbl.size(); dbl.insert(dbl.end(), src, src + n); return o; };
+  auto addi = [&](const int* src, size_t n) { const size_t o = ints.size(); ints.insert(ints.end(), src, src + n); return o; };
+  const size_t o_XPF = addd(m->X_PF, (size_t)12 * nb), o_axis = addd(m->axis, (size_t)3 * nb), o_mass = addd(m->mass, nb),
+               o_com = addd(m->com, (size_t)3 * nb), o_in = addd(m->inertia, (size_t)6 * nb),
+               o_damp = addd(m->damping, m->nv), o_gX = addd(m->geom_X, (size_t)12 * m->ngeoms),
+               o_gs = addd(m->geom_size, (size_t)3 * m->ngeoms);
+  const size_t i_par = addi(m->parent, nb), i_jt = addi(m->jtype, nb), i_qs = addi(m->qstart, nb),
+               i_vs = addi(m->vstart, nb), i_gt = addi(m->geom_type, m->ngeoms), i_ch = addi(chain.data(), chain.size()),
+               i_nch = addi(nchain.data(), nchain.size()), i_pk = addi(pkind.data(), pkind.size()),
+               i_pnp = addi(path_npairs.data(), path_npairs.size()), i_pp = addi(path_pairs.data(), path_pairs.size()),
+               i_ga = addi(m->pair_a, m->npairs), i_gb = addi(m->pair_b, m->npairs), i_sa = addi(sa.data(), sa.size()),
+               i_sb = addi(sb.data(), sb.size());
+  const size_t nd = dbl.size(), ni = ints.size();
+  std::vector<double> blob(nd + (ni + 1) / 2 + 1, 0.0);
+  std::memcpy(blob.data(), dbl.data(), nd * sizeof(double));
+  std::memcpy(blob.data() + nd, ints.data(), ni * sizeof(int));
+  double* bd = nullptr;
+  if (Upload(c, blob.data(), blob.size(), &bd)) return -2;
+  const int* bi = reinterpret_cast<const int*>(bd + nd);
+  M.blob = bd; M.blob_n = (int)blob.size();
+  M.X_PF = bd + o_XPF; M.axis = bd + o_axis; M.mass = bd + o_mass; M.com = bd + o_com; M.inertia = bd + o_in;
+  M.damping = bd + o_damp; M.geom_X = bd + o_gX; M.geom_size = bd + o_gs;
+  M.parent = bi + i_par; M.jtype = bi + i_jt; M.qstart = bi + i_qs; M.vstart = bi + i_vs; M.geom_type = bi + i_gt;
+  M.chain = bi + i_ch; M.nchain = bi + i_nch; M.pkind = bi + i_pk; M.path_npairs = bi + i_pnp; M.path_pairs = bi + i_pp;
+  M.pair_ga = bi + i_ga; M.pair_gb = bi + i_gb; M.pair_sa = bi + i_sa; M.pair_sb = bi + i_sb;
   return 0;
 }
+
 
 int LaunchFd(idto_hip_ctx* c, int mode, int kb, int ke) {
   if (ke <= kb) return 0;
@@ -324,11 +339,11 @@ int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem, co
   int threads = ((E * K + 63) / 64) * 64;
   if (threads > 256) threads = 256;  // one wave per SIMD: the evaluation keeps its bodies in up to 512 VGPRs
   c->fd_threads = threads;
-  auto fd_lds = [&](int Ecount) { return (int)sizeof(double) * (3 * nq + 2 * (int)bsz + 3 * nv + Ecount + Ecount * nq + 3 * Ecount * nv + nv); };
+  auto fd_lds = [&](int Ecount) { return (int)sizeof(double) * (3 * nq + 2 * (int)bsz + 3 * nv + Ecount + Ecount * nq + 3 * Ecount * nv + nv + c->M.blob_n + 2); };
   c->fd_lds = fd_lds(E);
   c->tau_lds = fd_lds(1);
   c->asm_lds = (int)sizeof(double) * (3 * nq + 5 * (int)bsz + 4 * nv + nq + std::max(nq, nv) + (int)bsz + 3 * (int)qq + nq);
-  c->asm_diag_lds = (int)sizeof(double) * (11 * (int)bsz + 10 * nv + 6 * nq);
+  c->asm_diag_lds = (int)sizeof(double) * (14 * ((nv + 1) & ~1) * nq + 2 * (int)bsz + 10 * nv + 6 * nq + 2);
   const int n = N + 1;
   c->penta_lds = (int)sizeof(double) * (10 * (int)qq + nq * (3 * nq + 1) + (n + 2) * nq + nq) + (int)sizeof(int) * nq + 16;
   c->solve_lds = (int)sizeof(double) * ((n + 2) * nq + nq);
@@ -428,8 +443,8 @@ int idto_hip_grad_hess(idto_hip_ctx* c) {
   HIP_OK(hipSetDevice(c->device));
   if (TimeBegin(c, 1)) return -2;
   if (c->weights_diagonal)
-    hipLaunchKernelGGL(assemble_diag_kernel, dim3(c->N + 1), dim3(256), c->asm_diag_lds, c->stream, c->M, c->P, c->q,
-                       c->slab, c->slab_stride, c->g, c->HA, c->HB, c->HC);
+    hipLaunchKernelGGL(assemble_diag_kernel, dim3(c->N + 1, 4), dim3(256), c->asm_diag_lds, c->stream, c->M, c->P, c->q,
+                       c->slab, c->slab_stride, c->g, c->HA, c->HB, c->HC, c->asm_stop);
   else
     hipLaunchKernelGGL(assemble_kernel, dim3(c->N + 1), dim3(256), c->asm_lds, c->stream, c->M, c->P, c->q, c->slab,
                        c->slab_stride, c->g, c->HA, c->HB, c->HC);
@@ -457,6 +472,7 @@ static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, int nrhs, do
   // the two workgroups must not share a CU (each is one wavefront per SIMD, issue-bound): ask for
   // more than half of the 160 KB LDS so that the dispatcher cannot co-locate them
   if (m_split > 0) lds = std::max(lds, 84 * 1024);
+  if (lds > 160 * 1024) { g_err = "LDS carve-up too large"; return -1; }
   if (m_split > 0) {
     const size_t need = 2 * (size_t)(K + ncr) * ldl_ks(K) + (size_t)nrhs * 2 * K, nflags = (size_t)nrhs + 1;
     if (need > c->xch_count) {
@@ -552,6 +568,7 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "reference_solver") == 0) { c->reference_solver = value != 0; return 0; }
   if (std::strcmp(name, "solver_debug") == 0) { c->solver_debug = value != 0; return 0; }
   if (std::strcmp(name, "two_sided") == 0) { c->two_sided = value != 0; return 0; }
+  if (std::strcmp(name, "asm_stop") == 0) { c->asm_stop = value; return 0; }  // profiling aid
   g_err = std::string("unknown option ") + name;
   return -1;
 }

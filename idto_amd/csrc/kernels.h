@@ -106,19 +106,23 @@ __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevP
   double* ea = ev + E * nv;     // [E][nv]
   double* etau = ea + E * nv;   // [E][nv]
   double* edump = etau + E * nv; // [nv] write-only dump row for surplus lanes
+  double* mblob = edump + nv;    // [M.blob_n] the model tables
 
+  // stage the model into LDS and use that copy from here on
+  for (int i = tid; i < M.blob_n; i += nt) mblob[i] = M.blob[i];
   for (int i = tid; i < nq; i += nt) {
     qm1[i] = (k > 0) ? q[(k - 1) * nq + i] : 0.0;
     q0[i] = q[k * nq + i];
     q1[i] = q[(k + 1) * nq + i];
   }
   __syncthreads();
-  nplus_block(M, q0, N0, tid, nt);
-  nplus_block(M, q1, N1, tid, nt);
-  if (k > 0) velocity_block(M, N0, q0, qm1, dt, v0, tid, nt);
+  const DevModel Ml = rebase_model(M, mblob);
+  nplus_block(Ml, q0, N0, tid, nt);
+  nplus_block(Ml, q1, N1, tid, nt);
+  if (k > 0) velocity_block(Ml, N0, q0, qm1, dt, v0, tid, nt);
   else
     for (int r = tid; r < nv; r += nt) v0[r] = P.v_init[r];
-  velocity_block(M, N1, q1, q0, dt, v1, tid, nt);
+  velocity_block(Ml, N1, q1, q0, dt, v1, tid, nt);
   __syncthreads();
   for (int r = tid; r < nv; r += nt) a0[r] = (v1[r] - v0[r]) / dt;
   __syncthreads();
@@ -188,7 +192,7 @@ __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevP
     const int ee = (e < E) ? e : 0;
     const bool full = ee < 1 + nP + nT;
     double* tau_dst = (e < E) ? etau + ee * nv : edump;
-    id_eval<MAXC>(M, cp, path, full, eq + ee * nq, ev + ee * nv, ea + ee * nv, tau_dst);
+    id_eval<MAXC>(Ml, cp, path, full, eq + ee * nq, ev + ee * nv, ea + ee * nv, tau_dst);
   }
   __syncthreads();
 
@@ -458,35 +462,42 @@ __global__ void assemble_kernel(DevModel M, DevProblem P, const double* __restri
 // exact zeros), so both kernels produce identical results.  All operands are staged in
 // LDS once; each thread owns a few output elements and runs their terms in the
 // reference's order without intermediate barriers.
-struct AsmTerm { int a, b, w; };  // operand slots and weight slot
-
+// Grid (N + 1, 4): block row i is split over four workgroups (41 block rows alone would use 41
+// of 256 CUs): part 0 the diagonal block C_i (lower triangle, mirrored), parts 1 and 2 the two
+// column halves of B_i, part 3 A_i and the gradient block g_i.  Every part stages all operands
+// (they are L2-resident).  The weighted operands (A(l, r) * w_l) are formed once per block in
+// LDS - the same product the inline expression yields - so that the inner loops are pure
+// 16-byte LDS reads + mul + add in the reference's term order.
 __global__ void __launch_bounds__(256)
 assemble_diag_kernel(DevModel M, DevProblem P, const double* __restrict__ q, const double* __restrict__ slab,
                      int slab_stride, double* __restrict__ g, double* __restrict__ HA, double* __restrict__ HB,
-                     double* __restrict__ HC) {
+                     double* __restrict__ HC, int stop_after) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int i = blockIdx.x, N = P.N, nq = M.nq, nv = M.nv;
+  const int i = blockIdx.x, part = blockIdx.y, N = P.N, nq = M.nq, nv = M.nv;
   const int bsz = nv * nq, qq = nq * nq;
+  const int nvp = (nv + 1) & ~1;      // padded column length: 16-byte aligned columns in LDS
+  const int psz = nvp * nq;
   const double dt = P.dt;
   double* Cg = HC + (size_t)i * qq;
   double* Bg = HB + (size_t)i * qq;
   double* Ag = HA + (size_t)i * qq;
   if (i == 0) {
-    for (int idx = tid; idx < qq; idx += nt) {
-      Cg[idx] = (idx / nq == idx % nq) ? 1.0 : 0.0;
-      Bg[idx] = 0.0;
-      Ag[idx] = 0.0;
+    if (part == 0) {
+      for (int idx = tid; idx < qq; idx += nt) {
+        Cg[idx] = (idx / nq == idx % nq) ? 1.0 : 0.0;
+        Bg[idx] = 0.0;
+        Ag[idx] = 0.0;
+      }
+      for (int j = tid; j < nq; j += nt) g[j] = 0.0;
     }
-    for (int j = tid; j < nq; j += nt) g[j] = 0.0;
     return;
   }
-  // operand slots (nv x nq each)
-  enum { S_PM1 = 0, S_TM1, S_T0, S_MM1, S_M0, S_MP1, S_V, S_W, S_W1, S_COUNT };
-  // weight slots (vectors)
+  // operand slots (nv x nq each, column stride nvp): raw, then weighted
+  enum { S_PM1 = 0, S_TM1, S_T0, S_MM1, S_M0, S_MP1, S_V, S_W, S_W1, X_V, X_P, X_T, X_M, X_W1, S_COUNT };
   enum { W_QV = 0, W_R, W_QFV, W_COUNT };
-  double* ops = lds;                       // S_COUNT * bsz
-  double* wts = ops + S_COUNT * bsz;       // W_COUNT * nv
+  double* ops = lds;                       // S_COUNT * psz
+  double* wts = ops + S_COUNT * psz;       // W_COUNT * nv
   double* wq = wts + W_COUNT * nv;         // Qq' diag (nq)
   double* wfq = wq + nq;                   // Qfq' diag (nq)
   double* qm1 = wfq + nq;
@@ -503,12 +514,13 @@ assemble_diag_kernel(DevModel M, DevProblem P, const double* __restrict__ q, con
 
   auto blk = [&](int k, int which) { return slab + (size_t)k * slab_stride + which * bsz; };  // 0 M, 1 T, 2 P
   for (int idx = tid; idx < bsz; idx += nt) {
-    ops[S_PM1 * bsz + idx] = blk(i - 1, 2)[idx];
-    ops[S_TM1 * bsz + idx] = blk(i - 1, 1)[idx];
-    ops[S_MM1 * bsz + idx] = (i >= 3) ? blk(i - 1, 0)[idx] : 0.0;
-    ops[S_T0 * bsz + idx] = (i < N) ? blk(i, 1)[idx] : 0.0;
-    ops[S_M0 * bsz + idx] = (i < N && i >= 2) ? blk(i, 0)[idx] : 0.0;
-    ops[S_MP1 * bsz + idx] = (i < N - 1) ? blk(i + 1, 0)[idx] : 0.0;
+    const int c = idx / nv, l = idx - c * nv, o = c * nvp + l;
+    ops[S_PM1 * psz + o] = blk(i - 1, 2)[idx];
+    ops[S_TM1 * psz + o] = blk(i - 1, 1)[idx];
+    ops[S_MM1 * psz + o] = (i >= 3) ? blk(i - 1, 0)[idx] : 0.0;
+    ops[S_T0 * psz + o] = (i < N) ? blk(i, 1)[idx] : 0.0;
+    ops[S_M0 * psz + o] = (i < N && i >= 2) ? blk(i, 0)[idx] : 0.0;
+    ops[S_MP1 * psz + o] = (i < N - 1) ? blk(i + 1, 0)[idx] : 0.0;
   }
   for (int r = tid; r < nv; r += nt) {
     wts[W_QV * nv + r] = P.Qv[r * nv + r];
@@ -526,6 +538,7 @@ assemble_diag_kernel(DevModel M, DevProblem P, const double* __restrict__ q, con
     q1[c] = (i < N) ? q[(i + 1) * nq + c] : 0.0;
   }
   __syncthreads();
+  if (stop_after == 1) return;  // (profiling aid: phase timing by truncation)
   nplus_block(M, q0, N0, tid, nt);
   velocity_block(M, N0, q0, qm1, dt, v0, tid, nt);
   if (i < N) {
@@ -533,11 +546,23 @@ assemble_diag_kernel(DevModel M, DevProblem P, const double* __restrict__ q, con
     velocity_block(M, N1, q1, q0, dt, v1, tid, nt);
   }
   __syncthreads();
+  if (stop_after == 2) return;
   const double idt = 1 / dt, midt = -1 / dt;
+  // weights of the V- and W1-terms depend on the row (TO.cc:1127-1161): Qv, or Qf_v at the end
+  const double* wV = wts + ((i < N) ? W_QV : W_QFV) * nv;
+  const double* wW1 = wts + ((i < N - 1) ? W_QV : W_QFV) * nv;
+  const double* wR = wts + W_R * nv;
   for (int idx = tid; idx < bsz; idx += nt) {
-    ops[S_V * bsz + idx] = idt * N0[idx];
-    ops[S_W * bsz + idx] = midt * N0[idx];
-    ops[S_W1 * bsz + idx] = (i < N) ? midt * N1[idx] : 0.0;
+    const int c = idx / nv, l = idx - c * nv, o = c * nvp + l;
+    const double vv = idt * N0[idx], w1 = (i < N) ? midt * N1[idx] : 0.0;
+    ops[S_V * psz + o] = vv;
+    ops[S_W * psz + o] = midt * N0[idx];
+    ops[S_W1 * psz + o] = w1;
+    ops[X_V * psz + o] = vv * wV[l];
+    ops[X_W1 * psz + o] = w1 * wW1[l];
+    ops[X_P * psz + o] = ops[S_PM1 * psz + o] * wR[l];
+    ops[X_T * psz + o] = ops[S_T0 * psz + o] * wR[l];
+    ops[X_M * psz + o] = ops[S_MP1 * psz + o] * wR[l];
   }
   for (int r = tid; r < nv; r += nt) {
     ve[r] = v0[r] - P.v_nom[i * nv + r];
@@ -545,84 +570,90 @@ assemble_diag_kernel(DevModel M, DevProblem P, const double* __restrict__ q, con
   }
   for (int c = tid; c < nq; c += nt) qe[c] = q0[c] - P.q_nom[i * nq + c];
   __syncthreads();
+  if (stop_after == 3) return;
 
-  // term lists in the reference's order (TO.cc:1127-1161), as functions of (band, t)
-  const int nC = (i < N) ? ((i < N - 1) ? 5 : 4) : 2;
-  const int nB = (i >= 2) ? ((i < N) ? 3 : 2) : 0;
-  const int nA = (i >= 3) ? 1 : 0;
-  auto c_term = [&](int t) {
-    AsmTerm x;
-    if (i < N) {
-      if (t == 0) x = {S_V, S_V, W_QV};
-      else if (t == 1) x = {S_PM1, S_PM1, W_R};
-      else if (t == 2) x = {S_T0, S_T0, W_R};
-      else if (i < N - 1) { if (t == 3) x = {S_MP1, S_MP1, W_R}; else x = {S_W1, S_W1, W_QV}; }
-      else x = {S_W1, S_W1, W_QFV};
-    } else {
-      if (t == 0) x = {S_V, S_V, W_QFV}; else x = {S_PM1, S_PM1, W_R};
+  // sum_l X(l, r) * B(l, c), l ascending, products and sums rounded separately (no FMA)
+  auto term = [&](int xa, int sb, int r, int c) {
+    const double* A = ops + xa * psz + r * nvp;
+    const double* B = ops + sb * psz + c * nvp;
+    const double2* A2 = reinterpret_cast<const double2*>(A);
+    const double2* B2 = reinterpret_cast<const double2*>(B);
+    double2 a = A2[0], b = B2[0];
+    double acc = a.x * b.x;
+    if (nv > 1) acc = acc + a.y * b.y;
+    const int np = nv >> 1;
+#pragma unroll 4
+    for (int m = 1; m < np; ++m) {
+      a = A2[m]; b = B2[m];
+      acc = acc + a.x * b.x;
+      acc = acc + a.y * b.y;
     }
-    return x;
-  };
-  auto b_term = [&](int t) {
-    AsmTerm x;
-    if (t == 0) x = {S_PM1, S_TM1, W_R};
-    else if (i < N) { if (t == 1) x = {S_T0, S_M0, W_R}; else x = {S_V, S_W, W_QV}; }
-    else x = {S_V, S_W, W_QFV};
-    return x;
-  };
-  const AsmTerm a_term = {S_PM1, S_MM1, W_R};
-
-  auto term = [&](const AsmTerm& t, int r, int c) {
-    const double* A = ops + t.a * bsz + r * nv;
-    const double* B = ops + t.b * bsz + c * nv;
-    const double* w = wts + t.w * nv;
-    double acc = (A[0] * w[0]) * B[0];
-#pragma unroll 6
-    for (int l = 1; l < nv; ++l) acc += (A[l] * w[l]) * B[l];
+    if ((nv & 1) && nv > 1) acc = acc + A[nv - 1] * B[nv - 1];
     return acc;
   };
-  // outputs: C (lower triangle, mirrored), B, A
-  const int total = 3 * qq;
-  for (int idx = tid; idx < total; idx += nt) {
-    const int which = idx / qq, e = idx - which * qq;
-    const int c = e / nq, r = e - c * nq;
-    if (which == 0) {
-      if (r < c) continue;
+
+  if (part == 0) {
+    // C_i, lower triangle (TO.cc:1127-1137 / :1157-1161), mirrored (MakeSymmetric)
+    const int ntri = nq * (nq + 1) / 2;
+    for (int t = tid; t < ntri; t += nt) {
+      int c = 0, rem = t;
+      while (rem >= nq - c) { rem -= nq - c; ++c; }
+      const int r = c + rem;
       double out = (i < N) ? P.Qq[c * nq + r] : P.Qfq[c * nq + r];  // TO.cc:1128 / :1158
-      for (int t = 0; t < nC; ++t) out = out + term(c_term(t), r, c);
+      out = out + term(X_V, S_V, r, c);
+      out = out + term(X_P, S_PM1, r, c);
+      if (i < N) {
+        out = out + term(X_T, S_T0, r, c);
+        if (i < N - 1) out = out + term(X_M, S_MP1, r, c);
+        out = out + term(X_W1, S_W1, r, c);
+      }
       Cg[c * nq + r] = out;
       Cg[r * nq + c] = out;
-    } else if (which == 1) {
+    }
+  } else if (part <= 2) {
+    // B_i (TO.cc:1140-1147): columns [c_lo, c_hi)
+    const int half = (nq + 1) / 2, c_lo = (part == 1) ? 0 : half, c_hi = (part == 1) ? half : nq;
+    for (int idx = c_lo * nq + tid; idx < c_hi * nq; idx += nt) {
+      const int c = idx / nq, r = idx - c * nq;
       double out = 0.0;
-      for (int t = 0; t < nB; ++t) out = (t == 0) ? term(b_term(t), r, c) : out + term(b_term(t), r, c);
-      Bg[e] = out;
-    } else {
-      Ag[e] = (nA > 0) ? term(a_term, r, c) : 0.0;
+      if (i >= 2) {
+        out = term(X_P, S_TM1, r, c);
+        if (i < N) out = out + term(X_T, S_M0, r, c);
+        out = out + term(X_V, S_W, r, c);
+      }
+      Bg[idx] = out;
     }
-  }
-  // gradient block (TO.cc:1046-1080), threads of the last wave
-  const int j = tid - (nt - 64);
-  if (j >= 0 && j < nq) {
-    auto vwm = [&](const double* e, const double* w, const double* J) {  // sum_r (e_r w_r) J[r][j]
-      double acc = (e[0] * w[0]) * J[j * nv];
+  } else {
+    // A_i (TO.cc:1150-1153)
+    for (int idx = tid; idx < qq; idx += nt) {
+      const int c = idx / nq, r = idx - c * nq;
+      Ag[idx] = (i >= 3) ? term(X_P, S_MM1, r, c) : 0.0;
+    }
+    // gradient block (TO.cc:1046-1080), threads of the last wave
+    const int j = tid - (nt - 64);
+    if (j >= 0 && j < nq) {
+      auto vwm = [&](const double* e, const double* w, int slot) {  // sum_r (e_r w_r) J[r][j]
+        const double* J = ops + slot * psz + j * nvp;
+        double acc = (e[0] * w[0]) * J[0];
 #pragma unroll 6
-      for (int r = 1; r < nv; ++r) acc += (e[r] * w[r]) * J[j * nv + r];
-      return acc;
-    };
-    double gj;
-    if (i < N) {
-      gj = qe[j] * wq[j];
-      gj = gj + vwm(ve, wts + W_QV * nv, ops + S_V * bsz);
-      gj = gj + vwm(vep, wts + ((i == N - 1) ? W_QFV : W_QV) * nv, ops + S_W1 * bsz);
-      gj = gj + vwm(taus, wts + W_R * nv, ops + S_PM1 * bsz);
-      gj = gj + vwm(taus + nv, wts + W_R * nv, ops + S_T0 * bsz);
-      if (i != N - 1) gj = gj + vwm(taus + 2 * nv, wts + W_R * nv, ops + S_MP1 * bsz);
-    } else {
-      gj = vwm(taus, wts + W_R * nv, ops + S_PM1 * bsz);
-      gj = gj + qe[j] * wfq[j];
-      gj = gj + vwm(ve, wts + W_QFV * nv, ops + S_V * bsz);
+        for (int r = 1; r < nv; ++r) acc += (e[r] * w[r]) * J[r];
+        return acc;
+      };
+      double gj;
+      if (i < N) {
+        gj = qe[j] * wq[j];
+        gj = gj + vwm(ve, wts + W_QV * nv, S_V);
+        gj = gj + vwm(vep, wts + ((i == N - 1) ? W_QFV : W_QV) * nv, S_W1);
+        gj = gj + vwm(taus, wts + W_R * nv, S_PM1);
+        gj = gj + vwm(taus + nv, wts + W_R * nv, S_T0);
+        if (i != N - 1) gj = gj + vwm(taus + 2 * nv, wts + W_R * nv, S_MP1);
+      } else {
+        gj = vwm(taus, wts + W_R * nv, S_PM1);
+        gj = gj + qe[j] * wfq[j];
+        gj = gj + vwm(ve, wts + W_QFV * nv, S_V);
+      }
+      g[(size_t)i * nq + j] = gj;
     }
-    g[(size_t)i * nq + j] = gj;
   }
 }
 
