@@ -65,6 +65,9 @@ struct idto_hip_ctx {
   int fd_threads = 256, fd_lds = 0, tau_lds = 0, asm_lds = 0, penta_lds = 0, solve_lds = 0, cost_lds = 0;
   // timing
   bool timing = false;
+  int timing_stride = 1;     // record events on every timing_stride-th launch of each kernel
+  unsigned timing_tick[3] = {0, 0, 0};
+  bool timing_open = false;  // TimeBegin recorded an event that TimeEnd must close
   struct Timed { hipEvent_t a, b; int which; };
   std::vector<Timed> pending;
   int asm_stop = 0;                       // profiling aid: truncate the assembly kernel after a phase
@@ -236,7 +239,10 @@ int LaunchFd(idto_hip_ctx* c, int mode, int kb, int ke) {
 }
 
 int TimeBegin(idto_hip_ctx* c, int which) {
+  c->timing_open = false;
   if (!c->timing) return 0;
+  if ((c->timing_tick[which]++ % (unsigned)c->timing_stride) != 0) return 0;
+  c->timing_open = true;
   idto_hip_ctx::Timed t;
   t.which = which;
   hipEvent_t* ev[2] = {&t.a, &t.b};
@@ -253,7 +259,8 @@ int TimeBegin(idto_hip_ctx* c, int which) {
   return 0;
 }
 int TimeEnd(idto_hip_ctx* c) {
-  if (!c->timing) return 0;
+  if (!c->timing || !c->timing_open) return 0;
+  c->timing_open = false;
   HIP_OK(hipEventRecord(c->pending.back().b, c->stream));
   return 0;
 }
@@ -581,7 +588,12 @@ int idto_hip_gn_step(idto_hip_ctx* c) {
   return idto_hip_factor_solve(c, nullptr, 1, nullptr);
 }
 
-int idto_hip_timing_enable(idto_hip_ctx* c, int enable) { c->timing = enable != 0; return 0; }
+int idto_hip_timing_enable(idto_hip_ctx* c, int enable) {
+  c->timing = enable != 0;
+  c->timing_stride = enable > 1 ? enable : 1;  // enable = s > 1: sample every s-th launch
+  for (unsigned& t : c->timing_tick) t = 0;
+  return 0;
+}
 int idto_hip_timing_reset(idto_hip_ctx* c) {
   if (TimeDrain(c)) return -2;
   for (int i = 0; i < 3; ++i) { c->tsum[i] = 0; c->tcnt[i] = 0; }

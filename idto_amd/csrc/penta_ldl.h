@@ -67,11 +67,19 @@ __device__ __forceinline__ double fast_rcp(double d) {
 // Software-pipelined: the reciprocal of pivot J+1 (broadcast + v_rcp + 2 Newton steps, ~60 cycles
 // of dependent latency) only needs row J+1 of the update by pivot J, so that row is updated first
 // and the reciprocal chain overlaps with the remaining FMAs of pivot J.
-template <int K, int J>
-__device__ __forceinline__ void ldl_pivot(double (&xr)[K], double d, double inv, int& dlo, int& dhi) {
+// YP ("y-push", single right-hand side held by lane 3K): the column lanes also accumulate
+// sum_j x[j][c] * (rt_j / d_j), i.e. lane K + c ends with (Ht_i^T Dn rt_i)[c] and lane 2K + c with
+// (Et_i^T Dn rt_i)[c] - the contributions of this block row to the right-hand sides of the next
+// two rows, obtained for 3 instructions per pivot instead of a separate mat-vec phase.
+template <int K, int J, bool YP>
+__device__ __forceinline__ void ldl_pivot(double (&xr)[K], double d, double inv, int& dlo, int& dhi, double& yacc) {
   wrlane<J>(dlo, __double2loint(d));
   wrlane<J>(dhi, __double2hiint(d));
   const double t = xr[J] * inv;
+  if constexpr (YP) {
+    const double trhs = rdlane(t, 3 * K);  // (Dn rt)_J: row J of the right-hand side is final here
+    yacc = __builtin_fma(xr[J], trhs, yacc);
+  }
   // multipliers are wave-uniform (SGPR pairs): broadcast them in chunks so that at most CH pairs
   // are live at a time (the kernel is short of SGPRs; spills cost v_readlane's on this path)
   constexpr int CH = 8;
@@ -92,28 +100,29 @@ __device__ __forceinline__ void ldl_pivot(double (&xr)[K], double d, double inv,
     for (int q = 0; q < CH; ++q)
       if (r0 + q < K) xr[r0 + q] = __builtin_fma(-m[q], t, xr[r0 + q]);
   }
-  if constexpr (J + 1 < K) ldl_pivot<K, J + 1>(xr, d_next, inv_next, dlo, dhi);
+  if constexpr (J + 1 < K) ldl_pivot<K, J + 1, YP>(xr, d_next, inv_next, dlo, dhi, yacc);
 }
 
 // Forward elimination of the columns held by this wavefront (lanes < K: columns of S).
 // On exit: S lanes hold U = D L^T (upper triangle), rhs lanes L^{-1} rhs; returns 1 / U[l][l]
 // in lane l (l < K).
-template <int K>
-__device__ __forceinline__ double ldl_eliminate_wave(double (&xr)[K], int lane) {
+template <int K, bool YP>
+__device__ __forceinline__ double ldl_eliminate_wave(double (&xr)[K], int lane, double& yacc) {
   int dlo = 0, dhi = 0x3ff00000;  // 1.0 in the lanes that hold no pivot
   const double d = rdlane(xr[0], 0);
-  ldl_pivot<K, 0>(xr, d, fast_rcp(d), dlo, dhi);
+  yacc = 0.0;
+  ldl_pivot<K, 0, YP>(xr, d, fast_rcp(d), dlo, dhi, yacc);
   return fast_rcp(__hiloint2double(dhi, dlo));
 }
 
 // Column stride (in doubles) of every K-row block kept in LDS and of the row-major factor blocks:
-// even (16-byte aligned columns for ds_read_b128) and = 2 mod 4, i.e. an odd number of 16-byte
-// units, so that consecutive columns start in different LDS bank groups (a stride of 20 doubles
-// put the 10 even columns of the K = 19 tiles on only 4 of the 16 groups).
-__host__ __device__ constexpr int ldl_ks(int K) { return (((K + 1) & ~1) % 4 == 0) ? ((K + 1) & ~1) + 2 : ((K + 1) & ~1); }
+// even (16-byte aligned columns for ds_read_b128), = 2 mod 4, i.e. an odd number of 16-byte
+// units, so that consecutive columns start in different LDS bank groups, and >= 4 ceil(K/4): the
+// MFMA k-steps read rows up to 4 ceil(K/4) - 1 of a column (zero pad rows).
+__host__ __device__ constexpr int ldl_ks(int K) { return 4 * ((K + 3) / 4) + 2; }
 
 struct PentaLdlLds {  // offsets in doubles
-  int W, Ht, Et, Iv, rt, U, G, in, dump, bl, bl_size, xall, end;
+  int W, Ht, Et, Iv, rt, U, G, in, dump, yh, ye, bl, bl_size, xall, end;
   int kks, rts;
 };
 __host__ __device__ inline PentaLdlLds penta_ldl_layout(int n, int K, int nrhs) {
@@ -134,6 +143,8 @@ __host__ __device__ inline PentaLdlLds penta_ldl_layout(int n, int K, int nrhs) 
     L.in = o; o += ((fwd > bwd ? fwd : bwd) + 1) & ~1;
   }
   L.dump = o; o += 2;             // write target of staging lanes without a slot
+  L.yh = o; o += 2 * ks;          // y-push rings: (Ht_i^T Dn rt_i) of the last two rows ...
+  L.ye = o; o += 3 * ks;          // ... and (Et_i^T Dn rt_i) of the last three
   L.bl = o;
   L.bl_size = (nrhs * n * K <= 4096) ? nrhs * n * K : 0;
   o += L.bl_size;                 // right-hand sides staged in LDS when small ...
@@ -291,22 +302,29 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
   }
   if (ht >= 0) { fetch(0); stage(0); fetch(1); }
 
-  // ---- per-thread product job (fixed over rows); job type is uniform per wavefront:
-  //   wave 0: tiles of S (lower triangle) ; waves 1..NW-2: tiles of H (+ E copy) ; last wave: y
-  constexpr int T = (K + 1) / 2, nS = T * (T + 1) / 2, nH = T * T;
-  constexpr int NSIT = (nS + 63) / 64;  // S tiles per lane of wavefront 0
-  int jr0[NSIT], jc0[NSIT];
+  // ---- block products on the matrix cores: v_mfma_f64_16x16x4 computes a 16x16 tile of
+  // X^T diag(dn) Y per SK = ceil(K/4) instructions.  Operand layout (one f64 per lane):
+  //   A[i][kq] = X(4s + kq, 16 tr + i),  B[kq][j] = dn(4s + kq) Y(4s + kq, 16 tc + j),
+  //   i, j = lane & 15, kq = lane >> 4;  D[(lane >> 4) + 4 reg][lane & 15], reg = 0..3.
+  // Blocks are K-row columns with stride ks in LDS, so A and B fragments are both
+  // X[(16 t + (lane & 15)) * ks + 4 s + (lane >> 4)]: one ds_read_b64 per (tile index, k-step).
+  // Columns >= K of a tile read whatever follows the block in LDS; they only feed outputs that
+  // are never stored.  Rows >= K (the zero pad of every column, and dn = 0 there) add nothing.
+  using d4 = __attribute__((ext_vector_type(4))) double;
+  constexpr int SK = (K + 3) / 4;    // k-steps per tile
+  constexpr int TT = (K + 15) / 16;  // 16-wide tiles per dimension (1 or 2: K <= 32)
+  static_assert(4 * SK <= ks, "k-steps run into the next column");
+  const int fl = lane & 15, fk = lane >> 4;
+  auto ldop = [&](const double* Xp, int t, double (&a)[SK]) {
+    const double* pp = Xp + (16 * t + fl) * ks + fk;
 #pragma unroll
-  for (int it = 0; it < NSIT; ++it) {
-    int t = lane + 64 * it;
-    jr0[it] = -1; jc0[it] = 0;
-    if (wave == 0 && t < nS) {
-      int tr = 0, rem = t;
-      while (rem > tr) { rem -= tr + 1; ++tr; }
-      jr0[it] = 2 * tr; jc0[it] = 2 * rem;
-    }
-  }
-  constexpr int HW = (NW > 2) ? NW - 2 : 1;  // wavefronts working on H tiles
+    for (int sq = 0; sq < SK; ++sq) a[sq] = pp[4 * sq];
+  };
+  auto mma = [&](const double (&a)[SK], const double (&bq)[SK], const double (&dnv)[SK], d4& acc) {
+#pragma unroll
+    for (int sq = 0; sq < SK; ++sq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[sq], bq[sq] * dnv[sq], acc, 0, 0, 0);
+  };
+  const bool ypush = (nrhs == 1 && gj_waves == 1 && 3 * K < 64);
   __syncthreads();
 
   for (int i = 0; i < nfwd; ++i) {
@@ -335,43 +353,100 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
     stamp(i, 7);
     stamp(i, 1);
 
-    // ---- block products
-    if (wave == 0) {
+    // ---- block products (MFMA); tiles per wavefront, TT = 2:  0: S(0,0)          1: S(1,0) H(1,0)
+    //                                                            2: H(0,0) S(1,1)   3: H(0,1) H(1,1)
+    //                                                  TT = 1:  0: S(0,0)          1: H(0,0)
+    {
+      // epilogues: all LDS reads first, then all writes (the compiler cannot move a read above a
+      // write to the same address space, and a lone wavefront pays the full LDS latency per
+      // dependent read -> write pair)
+      auto put_s = [&](int tr, int tc, const d4& acc) {  // S = C - G - Ht^T Dn Ht (lower part, mirrored)
+        double cv[4], gv[4];
 #pragma unroll
-      for (int it = 0; it < NSIT; ++it) {
-        if (jr0[it] >= 0) {  // S = C - G - Ht^T Dn Ht, tile (r0.., c0..), mirrored
-          const int r0 = jr0[it], c0 = jc0[it];
-          const int r1 = (r0 + 1 < K) ? r0 + 1 : r0, c1 = (c0 + 1 < K) ? c0 + 1 : c0;
-          double a00, a01, a10, a11;
-          tile_ptdq<K>(Htp + r0 * ks, Htp + r1 * ks, Htp + c0 * ks, Htp + c1 * ks, Ivp, a00, a01, a10, a11);
-          auto put = [&](int r, int c, double acc) {
-            const double val = (Ci[c * K + r] - Gb[c * K + r]) - acc;
+        for (int rg = 0; rg < 4; ++rg) {
+          const int r = 16 * tr + fk + 4 * rg, c = 16 * tc + fl;
+          const bool on = r < K && c < K && r >= c;
+          cv[rg] = on ? Ci[c * K + r] : 0.0;
+          gv[rg] = on ? Gb[c * K + r] : 0.0;
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int r = 16 * tr + fk + 4 * rg, c = 16 * tc + fl;
+          if (r < K && c < K && r >= c) {
+            const double val = (cv[rg] - gv[rg]) - acc[rg];
             Wm[c * ks + r] = val;
-            Wm[r * ks + c] = val;
-          };
-          put(r0, c0, a00);
-          if (c1 != c0) put(r0, c1, a01);
-          if (r1 != r0) put(r1, c0, a10);
-          if (r1 != r0 && c1 != c0) put(r1, c1, a11);
+            if (r != c) Wm[r * ks + c] = val;
+          }
+        }
+      };
+      auto put_h = [&](int tr, int tc, const d4& acc) {  // H = B_{i+1}^T - Ht^T Dn Et_{i-1} ; E = A_{i+2}^T
+        double bv[4], av[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int r = 16 * tr + fk + 4 * rg, c = 16 * tc + fl;
+          const bool on = r < K && c < K;
+          bv[rg] = on ? Bn[r * K + c] : 0.0;
+          av[rg] = on ? An2[r * K + c] : 0.0;
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int r = 16 * tr + fk + 4 * rg, c = 16 * tc + fl;
+          if (r < K && c < K) {
+            Wm[(K + c) * ks + r] = bv[rg] - acc[rg];
+            Wm[(2 * K + c) * ks + r] = av[rg];
+          }
+        }
+      };
+      double dnv[SK];
+      if (wave < 4) {
+#pragma unroll
+        for (int sq = 0; sq < SK; ++sq) dnv[sq] = Ivp[4 * sq + fk];
+      }
+      const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
+      if (TT == 1) {
+        if (wave == 0) {
+          double a0[SK]; ldop(Htp, 0, a0);
+          d4 acc = zero4; mma(a0, a0, dnv, acc); put_s(0, 0, acc);
+        } else if (wave == 1) {
+          double a0[SK], e0[SK]; ldop(Htp, 0, a0); ldop(Etp, 0, e0);
+          d4 acc = zero4; mma(a0, e0, dnv, acc); put_h(0, 0, acc);
+        }
+      } else {
+        if (wave == 0) {  // the wavefront that eliminates next gets the least
+          double a0[SK]; ldop(Htp, 0, a0);
+          d4 s00 = zero4;
+          mma(a0, a0, dnv, s00);
+          put_s(0, 0, s00);
+        } else if (wave == 1) {
+          double a0[SK], a1[SK], e0[SK]; ldop(Htp, 1, a1); ldop(Htp, 0, a0); ldop(Etp, 0, e0);
+          d4 s10 = zero4, h10 = zero4;
+          mma(a1, a0, dnv, s10); mma(a1, e0, dnv, h10);
+          put_s(1, 0, s10); put_h(1, 0, h10);
+        } else if (wave == 2) {
+          double a0[SK], a1[SK], e0[SK]; ldop(Htp, 0, a0); ldop(Etp, 0, e0); ldop(Htp, 1, a1);
+          d4 h00 = zero4, s11 = zero4;
+          mma(a0, e0, dnv, h00); mma(a1, a1, dnv, s11);
+          put_h(0, 0, h00); put_s(1, 1, s11);
+        } else if (wave == 3) {
+          double a0[SK], a1[SK], e1[SK]; ldop(Htp, 0, a0); ldop(Htp, 1, a1); ldop(Etp, 1, e1);
+          d4 h01 = zero4, h11 = zero4;
+          mma(a0, e1, dnv, h01); mma(a1, e1, dnv, h11);
+          put_h(0, 1, h01); put_h(1, 1, h11);
         }
       }
-    } else if (NW > 2 && wave <= HW) {  // H = B_{i+1}^T - Ht^T Dn Et_{i-1} ; E = A_{i+2}^T
-      for (int t = (wave - 1) * 64 + lane; t < nH; t += HW * 64) {
-        const int tr = t / T, tc = t - tr * T;
-        const int r0 = 2 * tr, r1 = (r0 + 1 < K) ? r0 + 1 : r0, c0 = 2 * tc, c1 = (c0 + 1 < K) ? c0 + 1 : c0;
-        double a00, a01, a10, a11;
-        tile_ptdq<K>(Htp + r0 * ks, Htp + r1 * ks, Etp + c0 * ks, Etp + c1 * ks, Ivp, a00, a01, a10, a11);
-        auto put = [&](int r, int c, double acc) {
-          Wm[(K + c) * ks + r] = Bn[r * K + c] - acc;
-          Wm[(2 * K + c) * ks + r] = An2[r * K + c];
-        };
-        put(r0, c0, a00);
-        if (c1 != c0) put(r0, c1, a01);
-        if (r1 != r0) put(r1, c0, a10);
-        if (r1 != r0 && c1 != c0) put(r1, c1, a11);
+    }
+    // ---- right-hand side column
+    if (ypush) {
+      // y = r - (Ht_{i-1}^T Dn rt_{i-1}) - (Et_{i-2}^T Dn rt_{i-2}): both products were accumulated by
+      // the elimination wavefront of the previous two rows (y-push), only the subtraction is left
+      if (wave == 2 && lane < K) {
+        const double bval = L.bl_size ? lds[L.bl + i * K + lane]
+                                      : ((lane < k && !pseudo) ? rhs_sign * b[(size_t)orig(i) * k + lane] : 0.0);
+        Wm[3 * K * ks + lane] = (bval - lds[L.yh + ((i + 1) & 1) * ks + lane]) - lds[L.ye + ((i + 1) % 3) * ks + lane];
       }
-    } else {  // y = r - Ht^T Dn rt_{i-1} - Et_{i-2}^T Dn rt_{i-2}: one thread per (rhs, row)
-      for (int t = lane; t < nrhs * K; t += 64) {
+    } else if (wave >= 2 || NW < 3) {  // one thread per (rhs, row), spread over the wavefronts >= 2
+      const int w2 = (NW < 3) ? wave : wave - 2, nw2 = (NW < 3) ? NW : NW - 2;
+      for (int t = w2 * 64 + lane; t < nrhs * K; t += nw2 * 64) {
         const int j = t / K, r = t - j * K;
         double a0 = 0, a1 = 0;
         {
@@ -433,9 +508,10 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
         if (K & 1) xr[K - 1] = Wm[col * ks + K - 1];
       }
       stamp(i, 3);
-      double myinv = 1.0;
+      double myinv = 1.0, yacc = 0.0;
       if (!pseudo) {
-        myinv = ldl_eliminate_wave<K>(xr, lane);
+        if (ypush) myinv = ldl_eliminate_wave<K, true>(xr, lane, yacc);
+        else myinv = ldl_eliminate_wave<K, false>(xr, lane, yacc);
       } else {
         // hand the column over (layout of W) and continue the recursion with a zero row
         if (lane < K || is_rhs) {
@@ -458,6 +534,10 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
         if (K & 1) dst[K - 1] = xr[K - 1];
       }
       if (wave == 0 && lane < K) Ivn[lane] = myinv;
+      if (ypush) {  // contributions of this row to the right-hand sides of rows i+1 (lanes K..2K-1), i+2
+        if (lane >= K && lane < 2 * K) lds[L.yh + (i & 1) * ks + lane - K] = yacc;
+        else if (lane >= 2 * K && lane < 3 * K) lds[L.ye + (i % 3) * ks + lane - 2 * K] = yacc;
+      }
       if (!L.bl_size && is_rhs && rc >= 2 * K) {
         const int j = rc - 2 * K;
 #pragma unroll
@@ -472,17 +552,31 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
         fetch(i + 2);
         stamp(i, 4);
       }
-      if (g_wave) {   // G = Et_{i-1}^T Dn_{i-1} Et_{i-1} for the next row (symmetric)
-        for (int job = lane; job < nS; job += 64) {
-          int tr = 0, rem = job;
-          while (rem > tr) { rem -= tr + 1; ++tr; }
-          const int r0 = 2 * tr, r1 = (r0 + 1 < K) ? r0 + 1 : r0, c0 = 2 * rem, c1 = (c0 + 1 < K) ? c0 + 1 : c0;
-          double a00, a01, a10, a11;
-          tile_ptdq<K>(Etp + r0 * ks, Etp + r1 * ks, Etp + c0 * ks, Etp + c1 * ks, Ivp, a00, a01, a10, a11);
-          Gb[c0 * K + r0] = a00; Gb[r0 * K + c0] = a00;
-          Gb[c1 * K + r0] = a01; Gb[r0 * K + c1] = a01;
-          Gb[c0 * K + r1] = a10; Gb[r1 * K + c0] = a10;
-          Gb[c1 * K + r1] = a11; Gb[r1 * K + c1] = a11;
+      if (g_wave) {   // G = Et_{i-1}^T Dn_{i-1} Et_{i-1} for the next row (symmetric), MFMA
+        double dnv[SK], e0[SK];
+#pragma unroll
+        for (int sq = 0; sq < SK; ++sq) dnv[sq] = Ivp[4 * sq + fk];
+        ldop(Etp, 0, e0);
+        auto put_g = [&](int tr, int tc, const d4& acc) {
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int r = 16 * tr + fk + 4 * rg, c = 16 * tc + fl;
+            if (r < K && c < K && r >= c) {
+              Gb[c * K + r] = acc[rg];
+              if (r != c) Gb[r * K + c] = acc[rg];
+            }
+          }
+        };
+        const d4 zero4 = {0.0, 0.0, 0.0, 0.0};
+        d4 g00 = zero4;
+        mma(e0, e0, dnv, g00);
+        put_g(0, 0, g00);
+        if (TT == 2) {
+          double e1[SK];
+          ldop(Etp, 1, e1);
+          d4 g10 = zero4, g11 = zero4;
+          mma(e1, e0, dnv, g10); mma(e1, e1, dnv, g11);
+          put_g(1, 0, g10); put_g(1, 1, g11);
         }
       }
       if (ht >= 0 && i > 0 && i <= nloc) {

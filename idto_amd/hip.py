@@ -165,6 +165,7 @@ class HipPath:
 
     # ---- timing (HIP events on the context's stream)
     def timing_enable(self, on=True):
+        """True / 1: time every launch; s > 1: every s-th launch; False / 0: off"""
         _chk(lib().idto_hip_timing_enable(self.h, int(on)))
 
     def timing_reset(self):

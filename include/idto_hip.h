@@ -107,7 +107,9 @@ int idto_hip_set_option(idto_hip_ctx* ctx, const char* name, int value);
 /* Device-side timing of the last `idto_hip_gn_step`-shaped launches: average
  * milliseconds per launch of kernel `which` (0 fd, 1 assemble, 2 factor_solve)
  * over the launches recorded since idto_hip_timing_reset, measured with HIP
- * events on the context's stream. */
+ * events on the context's stream.  enable = 1 times every launch, enable = s > 1 every
+ * s-th launch (an event pair costs ~4 us of stream time: sampling keeps the timed
+ * region representative), 0 switches timing off. */
 int idto_hip_timing_enable(idto_hip_ctx* ctx, int enable);
 int idto_hip_timing_reset(idto_hip_ctx* ctx);
 int idto_hip_timing_get(idto_hip_ctx* ctx, int which, double* avg_ms, int* launches);
