@@ -100,8 +100,11 @@ int idto_hip_gn_step(idto_hip_ctx* ctx);
 int idto_hip_solve_host(idto_hip_ctx* ctx, const double* rhs_host, int nrhs, double* x_host);
 
 /* Options: "reference_solver" = 1 selects the bit-exact restatement of the reference's
- * pivoted-LU block Thomas (slow) instead of the SPD Gauss-Jordan solver (default 0; the
- * environment variable IDTO_SOLVER_REFERENCE=1 sets it at creation). */
+ * pivoted-LU block Thomas (slow) instead of the banded block LDL^T solver (default 0; the
+ * environment variable IDTO_SOLVER_REFERENCE=1 sets it at creation); "two_sided" = 0 keeps the
+ * LDL^T solver on one workgroup (default 1: two workgroups eliminate from both ends of the
+ * horizon); "solver_debug" = 1 records per-phase cycle stamps (IDTO_ARR 15, tools/solver_phases.py);
+ * "asm_stop" truncates the assembly kernel after a phase (tools/asm_phases.py). */
 int idto_hip_set_option(idto_hip_ctx* ctx, const char* name, int value);
 
 /* Device-side timing of the last `idto_hip_gn_step`-shaped launches: average

@@ -85,7 +85,7 @@ def test_hot_path_bit_exact(name, N, seed, lower):
     dev.set_option("reference_solver", 1)
     dev.factor_solve()
     assert same(dev.get("step"), p), np.abs(dev.get("step") - p).max()
-    # (ii) the production solver (SPD Gauss-Jordan, no pivoting): same recursion, different
+    # (ii) the production solver (banded block LDL^T, no pivoting): same recursion, different
     # elimination order => agreement to round-off.  Tolerance: the backward error
     # |H p + g| must be as small as the pivoted LU's (x16 slack), and the forward error
     # below 1e-9 relative to |p| scaled by the growth the LU itself shows vs. a residual
