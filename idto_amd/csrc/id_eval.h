@@ -272,17 +272,23 @@ IDTO_DEV void inertial_wrench(const DevModel& M, int b, const M3& R, V3 w, V3 al
 IDTO_DEV void put_tau(int j, double t, bool full, const double* damping, const double* v, double* tau) {
   tau[j] = full ? t + damping[j] * v[j] : t;
 }
-IDTO_DEV void project_tau(int jtype, int vs, const M3& R_WF, V3 hW, V3 f, V3 n, bool full, const double* damping,
+// Planar and floating joints are attached to the world (checked when the model is built), so
+// their joint frame R_WF = I * R_PF is re-formed here from the model table (the same expression
+// the forward pass evaluates) instead of being kept in 9 registers per body across the contact
+// phase: that was what pushed the kernel over 512 registers per lane.
+IDTO_DEV void project_tau(int jtype, int vs, const double* xpf, V3 hW, V3 f, V3 n, bool full, const double* damping,
                           const double* v, double* tau) {
   if (jtype == IDTO_JOINT_REVOLUTE) {
     put_tau(vs, dot(hW, n), full, damping, v, tau);
   } else if (jtype == IDTO_JOINT_PRISMATIC) {
     put_tau(vs, dot(hW, f), full, damping, v, tau);
   } else if (jtype == IDTO_JOINT_PLANAR) {
+    const M3 R_WF = ident3() * ldm3(xpf);
     put_tau(vs, dot(col(R_WF, 0), f), full, damping, v, tau);
     put_tau(vs + 1, dot(col(R_WF, 1), f), full, damping, v, tau);
     put_tau(vs + 2, dot(col(R_WF, 2), n), full, damping, v, tau);
   } else {
+    const M3 R_WF = ident3() * ldm3(xpf);
     const V3 nF = tmul(R_WF, n), fF = tmul(R_WF, f);
     put_tau(vs, nF.x, full, damping, v, tau);
     put_tau(vs + 1, nF.y, full, damping, v, tau);
@@ -308,11 +314,10 @@ IDTO_DEV void id_eval(const DevModel& M, const DevContact& cp, int path, bool fu
   BodyState cb;
   cb.R = ident3(); cb.p = zero; cb.w = zero; cb.v = zero;
   V3 cb_al = zero, cb_a = zero, cb_fin = zero, cb_nin = zero;
-  M3 cb_RWF = ident3();
   V3 cb_hW = zero;
   const int cbody = M.common_body;
   if (cbody >= 0) {
-    cb_RWF = ldm3(M.X_PF + 12 * cbody);  // parent is the world: I * R_PF
+    const M3 cb_RWF = ldm3(M.X_PF + 12 * cbody);  // parent is the world: I * R_PF
     const V3 d1 = ldv3(M.X_PF + 12 * cbody + 9);
     const JointOut j = joint_kin(M.jtype[cbody], cb_RWF, ldv3(M.axis + 3 * cbody), q + M.qstart[cbody],
                                  v + M.vstart[cbody], a + M.vstart[cbody]);
@@ -329,14 +334,12 @@ IDTO_DEV void id_eval(const DevModel& M, const DevContact& cp, int path, bool fu
   // ---- own chain: forward pass
   BodyState bs[MAXC];
   V3 r[MAXC], hW[MAXC], fin[MAXC], nin[MAXC], fext[MAXC], next[MAXC];
-  M3 RWF[MAXC];
   const int nch = M.nchain[path];
   V3 al_prev = zero, a_prev = zero;
 #pragma unroll
   for (int s = 0; s < MAXC; ++s) {
     bs[s].R = ident3(); bs[s].p = zero; bs[s].w = zero; bs[s].v = zero;
     r[s] = zero; hW[s] = zero; fin[s] = zero; nin[s] = zero; fext[s] = zero; next[s] = zero;
-    RWF[s] = ident3();
     if (s < nch) {
       const int b = M.chain[path * IDTO_MAX_CHAIN + s];
       const int kind = M.pkind[path * IDTO_MAX_CHAIN + s];
@@ -351,7 +354,6 @@ IDTO_DEV void id_eval(const DevModel& M, const DevContact& cp, int path, bool fu
       const V3 d1 = Rp * ldv3(M.X_PF + 12 * b + 9);
       const JointOut j = joint_kin(M.jtype[b], R_WF, ldv3(M.axis + 3 * b), q + M.qstart[b], v + M.vstart[b],
                                    a + M.vstart[b]);
-      RWF[s] = R_WF;
       hW[s] = j.hW;
       bs[s].R = R_WF * j.R_FM;
       r[s] = d1 + j.d2;
@@ -410,7 +412,7 @@ IDTO_DEV void id_eval(const DevModel& M, const DevContact& cp, int path, bool fu
         const bool has_child = (s + 1 < nch) && (M.pkind[path * IDTO_MAX_CHAIN + (s + 1 < MAXC ? s + 1 : s)] == PK_PREV);
         if (has_child) { f = f + child_f; n = n + child_n; }
       }
-      project_tau(M.jtype[b], M.vstart[b], RWF[s], hW[s], f, n, full, M.damping, v, tau);
+      project_tau(M.jtype[b], M.vstart[b], M.X_PF + 12 * b, hW[s], f, n, full, M.damping, v, tau);
       const int kind = M.pkind[path * IDTO_MAX_CHAIN + s];
       const V3 cf = f, cn = n + cross(r[s], f);
       if (kind == PK_PREV) { child_f = cf; child_n = cn; }
@@ -426,7 +428,7 @@ IDTO_DEV void id_eval(const DevModel& M, const DevContact& cp, int path, bool fu
     const V3 ch_n = tree_sum(root_n, M.npaths);
     const V3 f = (cb_fin - ext_f) + ch_f;
     const V3 n = (cb_nin - ext_n) + ch_n;
-    if (path == 0) project_tau(M.jtype[cbody], M.vstart[cbody], cb_RWF, cb_hW, f, n, full, M.damping, v, tau);
+    if (path == 0) project_tau(M.jtype[cbody], M.vstart[cbody], M.X_PF + 12 * cbody, cb_hW, f, n, full, M.damping, v, tau);
   }
 }
 

@@ -153,6 +153,12 @@ int BuildModel(idto_hip_ctx* c, const idto_model_t* m) {
   // star decomposition tables
   std::vector<int> chain((size_t)K * IDTO_MAX_CHAIN, -1), nchain(K, 0), pkind((size_t)K * IDTO_MAX_CHAIN, 0);
   std::vector<int> slot_of(nb, -3);
+  for (int i = 0; i < nb; ++i)
+    if ((m->jtype[i] == IDTO_JOINT_PLANAR || m->jtype[i] == IDTO_JOINT_FLOATING) && m->parent[i] >= 0) {
+      g_err = "planar and floating joints must be attached to the world";
+      return -1;
+    }
+  if (m->common_body >= 0 && m->parent[m->common_body] >= 0) { g_err = "the common body must be attached to the world"; return -1; }
   for (int i = 0; i < nb; ++i) {
     if (i == m->common_body) { slot_of[i] = -1; continue; }
     const int p = m->body_path[i];
@@ -354,7 +360,7 @@ int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem, co
   const int n = N + 1;
   c->penta_lds = (int)sizeof(double) * (10 * (int)qq + nq * (3 * nq + 1) + (n + 2) * nq + nq) + (int)sizeof(int) * nq + 16;
   c->solve_lds = (int)sizeof(double) * ((n + 2) * nq + nq);
-  c->cost_lds = (int)sizeof(double) * (3 * N + 2);
+  c->cost_lds = (int)sizeof(double) * (3 * N + 2) * (1 + std::max(nq, nv));
   const int max_lds = 160 * 1024;
   if (c->fd_lds > max_lds || c->asm_lds > max_lds || c->penta_lds > max_lds) {
     g_err = "problem too large for the 160 KiB LDS carve-up of the v1 kernels";
@@ -432,8 +438,8 @@ int idto_hip_eval_tau(idto_hip_ctx* c) {
   HIP_OK(hipSetDevice(c->device));
   int rc = LaunchFd(c, 0, 0, c->N);
   if (rc) return rc;
-  hipLaunchKernelGGL(cost_kernel, dim3(1), dim3(128), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
-                     c->slab_stride, c->cost);
+  hipLaunchKernelGGL(cost_kernel, dim3(1), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
+                     c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0);
   HIP_OK(hipGetLastError());
   return 0;
 }

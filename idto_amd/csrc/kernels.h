@@ -231,32 +231,48 @@ __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevP
 // Cost L(q) from resident q, v, tau (TO.cc:147-176).  One block; the final sum
 // is accumulated serially in the reference's order.
 __global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__ q, const double* __restrict__ v,
-                            const double* __restrict__ slab, int slab_stride, double* __restrict__ cost_out) {
+                            const double* __restrict__ slab, int slab_stride, double* __restrict__ cost_out,
+                            int diag) {
+  // e^T W e per term as the reference's Eigen expression evaluates it: tot = sum_c (sum_r e_r W[r][c]) e_c.
+  // One thread per (term, column c); `diag`: the weights are diagonal, the inner sum is its one
+  // non-zero product (the others are exact zeros).  Then one thread per term adds the columns in
+  // order, and thread 0 the terms in order (TO.cc:147-176).
   extern __shared__ double lds[];
   const int N = P.N, nq = M.nq, nv = M.nv, tid = threadIdx.x, nt = blockDim.x;
-  double* terms = lds;  // [N][3] + [2]
-  auto quad = [](const double* e, const double* enom, const double* W, int n) {
-    double tot = 0;
-    for (int c = 0; c < n; ++c) {
+  const int nterms = 3 * N + 2, nmax = nq > nv ? nq : nv;
+  double* terms = lds;               // [nterms]
+  double* cols = terms + nterms;     // [nterms][nmax]
+  for (int idx = tid; idx < nterms * nmax; idx += nt) {
+    const int term = idx / nmax, c = idx - term * nmax;
+    // kind of the term: 0 q_t, 1 v_t, 2 tau_t (running), 3 q_N, 4 v_N (terminal)
+    const int kind = (term < 3 * N) ? term % 3 : 3 + (term - 3 * N);
+    const int t = (term < 3 * N) ? term / 3 : N;
+    const int n = (kind == 0 || kind == 3) ? nq : nv;
+    auto err = [&](int r) {  // e_r - nominal_r
+      if (kind == 0 || kind == 3) return q[t * nq + r] - P.q_nom[t * nq + r];
+      if (kind == 1 || kind == 4) return v[t * nv + r] - P.v_nom[t * nv + r];
+      return slab[(size_t)t * slab_stride + 3 * nv * nq + r] - 0.0;
+    };
+    const double* W = (kind == 0) ? P.Qq0 : (kind == 1) ? P.Qv0 : (kind == 2) ? P.R0 : (kind == 3) ? P.Qfq0 : P.Qfv0;
+    double val = 0.0;
+    if (c < n) {
+      const double dc = err(c);
       double acc = 0;
-      for (int r = 0; r < n; ++r) acc += (e[r] - (enom ? enom[r] : 0.0)) * W[c * n + r];
-      tot += acc * (e[c] - (enom ? enom[c] : 0.0));
+      if (diag) {
+        acc += dc * W[c * n + c];
+      } else {
+        for (int r = 0; r < n; ++r) acc += err(r) * W[c * n + r];
+      }
+      val = acc * dc;
     }
-    return tot;
-  };
-  for (int idx = tid; idx < 3 * N + 2; idx += nt) {
-    double val;
-    if (idx < 3 * N) {
-      const int t = idx / 3, w = idx - 3 * t;
-      if (w == 0) val = quad(q + t * nq, P.q_nom + t * nq, P.Qq0, nq);
-      else if (w == 1) val = quad(v + t * nv, P.v_nom + t * nv, P.Qv0, nv);
-      else val = quad(slab + (size_t)t * slab_stride + 3 * nv * nq, nullptr, P.R0, nv);
-    } else if (idx == 3 * N) {
-      val = quad(q + N * nq, P.q_nom + N * nq, P.Qfq0, nq);
-    } else {
-      val = quad(v + N * nv, P.v_nom + N * nv, P.Qfv0, nv);
-    }
-    terms[idx] = val;
+    cols[idx] = val;
+  }
+  __syncthreads();
+  for (int term = tid; term < nterms; term += nt) {
+    const int n = (term < 3 * N) ? ((term % 3 == 0) ? nq : nv) : ((term == 3 * N) ? nq : nv);
+    double tot = 0;
+    for (int c = 0; c < n; ++c) tot += cols[term * nmax + c];
+    terms[term] = tot;
   }
   __syncthreads();
   if (tid == 0) {

@@ -122,7 +122,7 @@ __device__ __forceinline__ double ldl_eliminate_wave(double (&xr)[K], int lane, 
 __host__ __device__ constexpr int ldl_ks(int K) { return 4 * ((K + 3) / 4) + 2; }
 
 struct PentaLdlLds {  // offsets in doubles
-  int W, Ht, Et, Iv, rt, U, G, in, dump, yh, ye, bl, bl_size, xall, end;
+  int W, Ht, Et, Iv, rt, U, G, in, dump, yh, ye, Eb, bl, bl_size, xall, end;
   int kks, rts;
 };
 __host__ __device__ inline PentaLdlLds penta_ldl_layout(int n, int K, int nrhs) {
@@ -145,6 +145,7 @@ __host__ __device__ inline PentaLdlLds penta_ldl_layout(int n, int K, int nrhs) 
   L.dump = o; o += 2;             // write target of staging lanes without a slot
   L.yh = o; o += 2 * ks;          // y-push rings: (Ht_i^T Dn rt_i) of the last two rows ...
   L.ye = o; o += 3 * ks;          // ... and (Et_i^T Dn rt_i) of the last three
+  L.Eb = o; o += 2 * L.kks;       // E_i = A_{i+2}^T staged straight in column layout (row parity)
   L.bl = o;
   L.bl_size = (nrhs * n * K <= 4096) ? nrhs * n * K : 0;
   o += L.bl_size;                 // right-hand sides staged in LDS when small ...
@@ -245,6 +246,7 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
   // result is discarded (m_valid) or replaced by the identity padding (m_load / m_one).
   double pre[PMAX];
   int p_off[PMAX];
+  unsigned p_col[(PMAX + 3) / 4] = {0};  // staged column (8 bits per slot) of the A-block slots
   unsigned long long m_valid = 0, m_load = 0, m_one = 0, m_isA = 0, m_isB = 0;
   static_assert(PMAX <= 64, "slot masks are 64-bit");
   const int dHB = (int)(HB - HA), dHC = (int)(HC - HA);
@@ -256,7 +258,7 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
       m_valid |= 1ull << s;
       const int which = idx / KK, e = idx - which * KK, c = e / K, r = e - c * K;
       if (which == 0) m_isB |= 1ull << s;
-      if (which == 2) m_isA |= 1ull << s;
+      if (which == 2) { m_isA |= 1ull << s; p_col[s / 4] |= c << (8 * (s & 3)); }
       if (!PADDED || (r < k && c < k)) {
         m_load |= 1ull << s;
         if (which == 1) p_off[s] = dHC + c * k + r;
@@ -285,7 +287,14 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
       double val = pre[s];
       if (PADDED) val = (m_load >> s & 1) ? val : ((m_one >> s & 1) ? 1.0 : 0.0);
       val = (kill >> s & 1) ? 0.0 : val;
-      const int dst = (m_valid >> s & 1) ? L.in + ht + s * hn : L.dump;
+      // B and C keep the source layout; A_{i+2} goes transposed into the E columns' layout
+      // (element (row r, col c) of the staged block is E(c, r)): Eb[r * ks + c]
+      int dst = L.in + ht + s * hn;
+      if (m_isA >> s & 1) {
+        const int e = ht + s * hn - 2 * KK, c = (p_col[s / 4] >> (8 * (s & 3))) & 0xff;
+        dst = L.Eb + (il & 1) * L.kks + e * ks - c * (K * ks - 1);
+      }
+      dst = (m_valid >> s & 1) ? dst : L.dump;
       lds[dst] = val;
     }
   };
@@ -379,22 +388,17 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
           }
         }
       };
-      auto put_h = [&](int tr, int tc, const d4& acc) {  // H = B_{i+1}^T - Ht^T Dn Et_{i-1} ; E = A_{i+2}^T
-        double bv[4], av[4];
+      auto put_h = [&](int tr, int tc, const d4& acc) {  // H = B_{i+1}^T - Ht^T Dn Et_{i-1}
+        double bv[4];
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const int r = 16 * tr + fk + 4 * rg, c = 16 * tc + fl;
-          const bool on = r < K && c < K;
-          bv[rg] = on ? Bn[r * K + c] : 0.0;
-          av[rg] = on ? An2[r * K + c] : 0.0;
+          bv[rg] = (r < K && c < K) ? Bn[r * K + c] : 0.0;
         }
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const int r = 16 * tr + fk + 4 * rg, c = 16 * tc + fl;
-          if (r < K && c < K) {
-            Wm[(K + c) * ks + r] = bv[rg] - acc[rg];
-            Wm[(2 * K + c) * ks + r] = av[rg];
-          }
+          if (r < K && c < K) Wm[(K + c) * ks + r] = bv[rg] - acc[rg];
         }
       };
       double dnv[SK];
@@ -502,10 +506,12 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
       const int col = (lane < K) ? lane : (is_rhs ? K + rc : 0);
       double xr[K];
       {
-        const double2* src = reinterpret_cast<const double2*>(Wm + col * ks);
+        // columns of [S | H | . | y] from W, the E columns straight from their staging buffer
+        const double* colp = (col >= 2 * K && col < 3 * K) ? lds + L.Eb + (i & 1) * L.kks + (col - 2 * K) * ks : Wm + col * ks;
+        const double2* src = reinterpret_cast<const double2*>(colp);
 #pragma unroll
         for (int r2 = 0; r2 < K / 2; ++r2) { const double2 t2 = src[r2]; xr[2 * r2] = t2.x; xr[2 * r2 + 1] = t2.y; }
-        if (K & 1) xr[K - 1] = Wm[col * ks + K - 1];
+        if (K & 1) xr[K - 1] = colp[K - 1];
       }
       stamp(i, 3);
       double myinv = 1.0, yacc = 0.0;
