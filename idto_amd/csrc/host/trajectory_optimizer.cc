@@ -181,18 +181,28 @@ Vec TO::Fetch(int what) const {
   return out;
 }
 
-// TO.cc:1463-1480 (v, a, tau, N+) + CalcCost :147-176
+// TO.cc:1463-1480 (v, a, tau, N+) + CalcCost :147-176.  Every idto_hip_get is a synchronising
+// device-to-host copy (~20 us), so the cache is filled in few, large pieces: tau + cost here (all a
+// trial point needs), v / a / N+ only when somebody asks, the whole slab (dtau/dq + tau) and the
+// three Hessian bands in one copy each.
 void TO::CalcTrajectoryData(const TrajectoryOptimizerState<T>& state) const {
   auto& c = state.cache_;
   if (c.traj) return;
   EnsureDevice(state, 1);
+  c.tau = Unflatten(Fetch(IDTO_ARR_TAU), num_steps(), nv_);
+  c.cost = Fetch(IDTO_ARR_COST)[0];
+  c.traj = true;
+}
+void TO::CalcKinematics(const TrajectoryOptimizerState<T>& state) const {
+  auto& c = state.cache_;
+  if (c.kin) return;
+  CalcTrajectoryData(state);
+  EnsureDevice(state, 1);
   const int N = num_steps();
   c.v = Unflatten(Fetch(IDTO_ARR_V), N + 1, nv_);
   c.a = Unflatten(Fetch(IDTO_ARR_A), N, nv_);
-  c.tau = Unflatten(Fetch(IDTO_ARR_TAU), N, nv_);
   c.nplus = UnflattenBlocks(Fetch(IDTO_ARR_NPLUS), N + 1, nv_, nq_);
-  c.cost = Fetch(IDTO_ARR_COST)[0];
-  c.traj = true;
+  c.kin = true;
 }
 
 // TO.cc:400-563 and :962-973
@@ -202,9 +212,24 @@ void TO::CalcDerivatives(const TrajectoryOptimizerState<T>& state) const {
   CalcTrajectoryData(state);
   EnsureDevice(state, 2);
   const int N = num_steps();
-  c.id_partials.dtau_dqm = UnflattenBlocks(Fetch(IDTO_ARR_DTAU_DQM), N, nv_, nq_);
-  c.id_partials.dtau_dqt = UnflattenBlocks(Fetch(IDTO_ARR_DTAU_DQT), N, nv_, nq_);
-  c.id_partials.dtau_dqp = UnflattenBlocks(Fetch(IDTO_ARR_DTAU_DQP), N, nv_, nq_);
+  const Vec slab = Fetch(IDTO_ARR_SLAB);  // per k: [dtau_dqm | dtau_dqt | dtau_dqp | tau_k]
+  const int stride = idto_hip_slab_stride(hip_), bsz = nv_ * nq_;
+  c.id_partials.dtau_dqm.assign((std::size_t)N, MatrixXd(nv_, nq_));
+  c.id_partials.dtau_dqt.assign((std::size_t)N, MatrixXd(nv_, nq_));
+  c.id_partials.dtau_dqp.assign((std::size_t)N, MatrixXd(nv_, nq_));
+  for (int k = 0; k < N; ++k) {
+    const double* rec = slab.data() + (std::size_t)k * stride;
+    std::copy(rec, rec + bsz, c.id_partials.dtau_dqm[k].data());
+    std::copy(rec + bsz, rec + 2 * bsz, c.id_partials.dtau_dqt[k].data());
+    std::copy(rec + 2 * bsz, rec + 3 * bsz, c.id_partials.dtau_dqp[k].data());
+  }
+  c.deriv = true;
+}
+void TO::CalcVelocityPartials(const TrajectoryOptimizerState<T>& state) const {
+  auto& c = state.cache_;
+  if (c.vpart) return;
+  CalcKinematics(state);
+  const int N = num_steps();
   c.v_partials.dvt_dqt.assign((std::size_t)N + 1, MatrixXd(nv_, nq_));
   c.v_partials.dvt_dqm.assign((std::size_t)N + 1, MatrixXd(nv_, nq_));
   for (int t = 0; t <= N; ++t)
@@ -213,7 +238,7 @@ void TO::CalcDerivatives(const TrajectoryOptimizerState<T>& state) const {
         c.v_partials.dvt_dqt[t](r, col) = c.nplus[t](r, col) / time_step_;
         if (t > 0) c.v_partials.dvt_dqm[t](r, col) = -c.nplus[t](r, col) / time_step_;
       }
-  c.deriv = true;
+  c.vpart = true;
 }
 
 // TO.cc:1021-1081 and :1093-1165
@@ -223,20 +248,22 @@ void TO::CalcGradHess(const TrajectoryOptimizerState<T>& state) const {
   CalcDerivatives(state);
   EnsureDevice(state, 3);
   c.gradient = Fetch(IDTO_ARR_GRADIENT);
+  const Vec bands = Fetch(IDTO_ARR_HBANDS);  // [A | B | C], (N+6) blocks each
+  const std::size_t used = (std::size_t)(num_steps() + 1) * nq_ * nq_, span = (std::size_t)(num_steps() + 6) * nq_ * nq_;
   c.hessian = PentaDiagonalMatrix<T>(num_steps() + 1, nq_);
-  c.hessian.mutable_A() = Fetch(IDTO_ARR_H_A);
-  c.hessian.mutable_B() = Fetch(IDTO_ARR_H_B);
-  c.hessian.mutable_C() = Fetch(IDTO_ARR_H_C);
+  c.hessian.mutable_A().assign(bands.begin(), bands.begin() + used);
+  c.hessian.mutable_B().assign(bands.begin() + span, bands.begin() + span + used);
+  c.hessian.mutable_C().assign(bands.begin() + 2 * span, bands.begin() + 2 * span + used);
   c.grad = c.hess = true;
 }
 
-const std::vector<VectorXd>& TO::EvalV(const TrajectoryOptimizerState<T>& s) const { CalcTrajectoryData(s); return s.cache_.v; }
-const std::vector<VectorXd>& TO::EvalA(const TrajectoryOptimizerState<T>& s) const { CalcTrajectoryData(s); return s.cache_.a; }
+const std::vector<VectorXd>& TO::EvalV(const TrajectoryOptimizerState<T>& s) const { CalcKinematics(s); return s.cache_.v; }
+const std::vector<VectorXd>& TO::EvalA(const TrajectoryOptimizerState<T>& s) const { CalcKinematics(s); return s.cache_.a; }
 const std::vector<VectorXd>& TO::EvalTau(const TrajectoryOptimizerState<T>& s) const { CalcTrajectoryData(s); return s.cache_.tau; }
-const std::vector<MatrixXd>& TO::EvalNplus(const TrajectoryOptimizerState<T>& s) const { CalcTrajectoryData(s); return s.cache_.nplus; }
+const std::vector<MatrixXd>& TO::EvalNplus(const TrajectoryOptimizerState<T>& s) const { CalcKinematics(s); return s.cache_.nplus; }
 double TO::EvalCost(const TrajectoryOptimizerState<T>& s) const { CalcTrajectoryData(s); return s.cache_.cost; }
 const VelocityPartials<double>& TO::EvalVelocityPartials(const TrajectoryOptimizerState<T>& s) const {
-  CalcDerivatives(s);
+  CalcVelocityPartials(s);
   return s.cache_.v_partials;
 }
 const InverseDynamicsPartials<double>& TO::EvalInverseDynamicsPartials(const TrajectoryOptimizerState<T>& s) const {
@@ -366,13 +393,17 @@ const VectorXd& TO::EvalLagrangeMultipliers(const TrajectoryOptimizerState<T>& s
     const int neq = num_equality_constraints(), nu = (int)unactuated_dofs_.size();
     std::vector<double> S((std::size_t)neq * neq, 0.0);
     Vec rhs((std::size_t)neq);
+    Vec jr((std::size_t)3 * nq_);
     for (int r = 0; r < neq; ++r) {
-      // row r of J is non-zero only in the three blocks around its time step
+      // row r of J is non-zero only in the three blocks around its time step: gather it once,
+      // then every column of Y contributes a short contiguous dot product
       const int t = r / nu;
-      const int c0 = std::max(0, (t - 1) * nq_), c1 = (t + 2) * nq_;
+      const int c0 = std::max(0, (t - 1) * nq_), c1 = (t + 2) * nq_, len = c1 - c0;
+      for (int kq = 0; kq < len; ++kq) jr[kq] = c.J_unscaled(r, c0 + kq);
       for (int col = 0; col <= neq; ++col) {
+        const double* ycol = Y.data() + (std::size_t)col * num_vars() + c0;
         double acc = 0;
-        for (int k = c0; k < c1; ++k) acc += c.J_unscaled(r, k) * Y(k, col);
+        for (int kq = 0; kq < len; ++kq) acc += jr[kq] * ycol[kq];
         if (col < neq) S[(std::size_t)col * neq + r] = acc;
         else rhs[r] = h[r] - acc;
       }

@@ -14,6 +14,7 @@
 #include "idto_hip.h"
 #include "kernels.h"
 #include "penta_ldl.h"
+#include "penta_apply.h"
 
 using namespace idto_dev;
 
@@ -465,7 +466,7 @@ int idto_hip_grad_hess(idto_hip_ctx* c) {
   return TimeEnd(c);
 }
 
-static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, int nrhs, double* xo) {
+static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, int nrhs, double* xo, bool one_sided = false) {
   const int n = c->N + 1, k = c->nq;
   if (k > 32) { g_err = "fast solver supports nq <= 32"; return -1; }
   // block sizes of the reference's example models are instantiated exactly, others are padded
@@ -480,7 +481,7 @@ static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, int nrhs, do
   double* dbg = c->solver_debug ? c->dbg : nullptr;
   // two-sided elimination (two workgroups meeting at block rows m, m+1) once the horizon is long
   // enough to pay for the hand-over; exchange buffer: 2 augmented blocks + [nrhs][2][K]
-  const int m_split = (c->two_sided && n >= 10) ? (n - 1) / 2 : 0;
+  const int m_split = (c->two_sided && !one_sided && n >= 10) ? (n - 1) / 2 : 0;
   const dim3 grid(m_split > 0 ? 2 : 1);
   // the two workgroups must not share a CU (each is one wavefront per SIMD, issue-bound): ask for
   // more than half of the 160 KB LDS so that the dispatcher cannot co-locate them
@@ -548,14 +549,33 @@ int idto_hip_factor_solve(idto_hip_ctx* c, const double* rhs, int nrhs, double* 
     }
     return 0;
   }
-  // fast SPD path: chunks of right-hand sides that fit one launch (each chunk re-factorises)
+  // block LDL^T: factorise once with the first right-hand side (one workgroup; the two-sided
+  // variant leaves factors of the mirrored recursion that the substitution kernel does not use) ...
   const int K = (k == 2 || k == 3 || k == 5 || k == 19 || k == 23) ? k : (k <= 8 ? 8 : k <= 16 ? 16 : k <= 24 ? 24 : 32);
-  int max_rhs = std::max(1, 15 * (64 - K) - 2 * K);
-  while (max_rhs > 1 && penta_ldl_layout(n, K, max_rhs).end * (int)sizeof(double) > 160 * 1024) max_rhs /= 2;
-  for (int j0 = 0; j0 < nrhs; j0 += max_rhs) {
-    const int cnt = std::min(max_rhs, nrhs - j0);
-    int rc = LaunchLdl(c, b + (size_t)j0 * n * k, rhs ? 1.0 : -1.0, cnt, xo + (size_t)j0 * n * k);
-    if (rc) return rc;
+  int rc = LaunchLdl(c, b, rhs ? 1.0 : -1.0, 1, xo, /*one_sided=*/nrhs > 1);
+  if (rc) return rc;
+  if (nrhs > 1) {
+    // ... then substitute the other right-hand sides in parallel: one wavefront each
+    const int waves = 4, blocks = (nrhs - 1 + waves - 1) / waves;
+    const int lds = waves * n * K * (int)sizeof(double);
+    const double* b1 = b + (size_t)n * k;
+    double* x1 = xo + (size_t)n * k;
+#define APPLY_LAUNCH(KM)                                                                                          \
+    hipLaunchKernelGGL(penta_apply_kernel<KM>, dim3(blocks), dim3(64 * waves), lds, c->stream, n, k, c->Ust, c->Hst, \
+                       c->Est, c->Dst, b1, rhs ? 1.0 : -1.0, nrhs - 1, x1)
+    switch (K) {
+      case 2: APPLY_LAUNCH(2); break;
+      case 3: APPLY_LAUNCH(3); break;
+      case 5: APPLY_LAUNCH(5); break;
+      case 8: APPLY_LAUNCH(8); break;
+      case 16: APPLY_LAUNCH(16); break;
+      case 19: APPLY_LAUNCH(19); break;
+      case 23: APPLY_LAUNCH(23); break;
+      case 24: APPLY_LAUNCH(24); break;
+      default: APPLY_LAUNCH(32); break;
+    }
+#undef APPLY_LAUNCH
+    HIP_OK(hipGetLastError());
   }
   return TimeEnd(c);
 }
@@ -631,6 +651,7 @@ long idto_hip_array_size(idto_hip_ctx* c, int what) {
     case IDTO_ARR_H_A: case IDTO_ARR_H_B: case IDTO_ARR_H_C: return (N + 1) * qq;
     case IDTO_ARR_COST: return 1;
     case IDTO_ARR_SLAB: return N * (long)c->slab_stride;
+    case IDTO_ARR_HBANDS: return 3 * (N + 6) * qq;
     case 15: return (N + 4) * 8 * 32;
     default: return -1;
   }
@@ -650,6 +671,7 @@ void* idto_hip_device_ptr(idto_hip_ctx* c, int what) {
     case IDTO_ARR_STEP: return c->step;
     case IDTO_ARR_COST: return c->cost;
     case IDTO_ARR_SLAB: return c->slab;
+    case IDTO_ARR_HBANDS: return c->HA;
     case 15: return c->dbg;
     default: return nullptr;  // tau and the three partials live strided inside the slab
   }

@@ -109,7 +109,9 @@ class TrajectoryOptimizer<double> {
   // makes the device hold `state`: level 0 q, 1 + tau/cost, 2 + dtau/dq, 3 + gradient/Hessian
   void EnsureDevice(const TrajectoryOptimizerState<T>& state, int level) const;
   std::vector<double> Fetch(int what) const;
-  void CalcTrajectoryData(const TrajectoryOptimizerState<T>& state) const;
+  void CalcTrajectoryData(const TrajectoryOptimizerState<T>& state) const;   // tau, cost
+  void CalcKinematics(const TrajectoryOptimizerState<T>& state) const;       // v, a, N+
+  void CalcVelocityPartials(const TrajectoryOptimizerState<T>& state) const;
   void CalcDerivatives(const TrajectoryOptimizerState<T>& state) const;
   void CalcGradHess(const TrajectoryOptimizerState<T>& state) const;
   const MatrixXd& EvalHinvJTg(const TrajectoryOptimizerState<T>& state) const;

@@ -57,7 +57,7 @@ class TrajectoryOptimizerState {
  private:
   friend class TrajectoryOptimizer<T>;
   struct Cache {
-    bool traj = false, deriv = false, grad = false, hess = false, scale = false, shess = false, sgrad = false,
+    bool traj = false, kin = false, vpart = false, deriv = false, grad = false, hess = false, scale = false, shess = false, sgrad = false,
          h = false, J = false, lambda = false, merit = false, mgrad = false, hinv = false, uploaded = false;
     std::vector<std::vector<T>> v, a, tau;
     std::vector<MatrixXd> nplus;

@@ -57,8 +57,11 @@ enum idto_hip_array {
   IDTO_ARR_H_C = 11,     /* diagonal (symmetric, both triangles filled) */
   IDTO_ARR_STEP = 12,    /* (N+1)*nq : solution of the last factor_solve / gn_step */
   IDTO_ARR_COST = 13,    /* 1 */
-  IDTO_ARR_SLAB = 14     /* N * slab_stride: per tau-index k [dtau_dqm | dtau_dqt | dtau_dqp | tau_k] — the
+  IDTO_ARR_SLAB = 14,    /* N * slab_stride: per tau-index k [dtau_dqm | dtau_dqt | dtau_dqp | tau_k] — the
                             buffer a multi-GPU run all-gathers (contiguous in k) */
+  IDTO_ARR_DEBUG = 15,   /* solver cycle stamps (option "solver_debug") */
+  IDTO_ARR_HBANDS = 16   /* the three Hessian bands in one copy: [A | B | C], each (N+6) blocks nq x nq
+                            (N+1 used, 5 trailing zero blocks: the solver's prefetch margin) */
 };
 
 const char* idto_hip_last_error(void);
