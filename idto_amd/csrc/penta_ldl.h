@@ -641,6 +641,104 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
   const int r_ = lane & 31, half_ = lane >> 5;
   const int rr = (r_ < K) ? r_ : 0;
   const bool live = r_ < K && half_ == 0;
+  if (nrhs == 1 && L.bl_size) {
+    // ---- single right-hand side: "push" form.  While the triangular solve of block row i yields
+    // x_i one component per step (v_readlane + FMA, ~30 cycles of dependent latency), each
+    // component is pushed at once into the pending right-hand sides of rows i-1 (through
+    // D^-1 Ht_{i-1}) and i-2 (through D^-1 Et_{i-2}): no separate mat-vec phase, no wave-uniform
+    // copy of x.  One accumulator per lane:
+    //   lanes  0..31 (row r): acc = rhs of row i (the chain), FMA with D^-1 U_i;  w2 -= Et_{i-2}[r][j] x_j
+    //   lanes 32..63 (row r): acc = rhs of row i-1,           FMA with D^-1 Ht_{i-1}
+    // (the same instruction serves both halves), operands prefetched one block row ahead.
+    if (wave == 0) {
+      auto rowsA = [&](int i, double2 (&A)[KP]) {  // lower: U_i row r ; upper: Ht_{i-1} row r
+        const int t = half_ ? i - 1 : i;
+        if (t < 0) {
+#pragma unroll
+          for (int m = 0; m < KP; ++m) A[m] = make_double2(0.0, 0.0);
+          return;
+        }
+        const double2* a = reinterpret_cast<const double2*>((half_ ? Hst : Ust) + (size_t)orig(t) * KS2 + rr * ks);
+#pragma unroll
+        for (int m = KP - 1; m >= 0; --m) A[m] = a[m];
+      };
+      auto rowsE = [&](int i, double2 (&E)[KP], double& w2init) {  // lower: Et_{i-2} row r and D^-1 rt_{i-2}
+        const int t = i - 2;
+        w2init = 0.0;
+        if (t < 0 || half_) {
+#pragma unroll
+          for (int m = 0; m < KP; ++m) E[m] = make_double2(0.0, 0.0);
+          return;
+        }
+        const double2* e = reinterpret_cast<const double2*>(Est + (size_t)orig(t) * KS2 + rr * ks);
+#pragma unroll
+        for (int m = KP - 1; m >= 0; --m) E[m] = e[m];
+        w2init = Dst[(size_t)orig(t) * K + rr] * lds[L.xall + (t + 2) * ks + rr];
+      };
+      auto dvrt = [&](int t) {
+        return (t < 0) ? 0.0 : Dst[(size_t)orig(t) * K + rr] * lds[L.xall + (t + 2) * ks + rr];
+      };
+      auto swap_halves = [&](double a) {  // value held by lane (l ^ 32)
+        const unsigned lo = (unsigned)__double2loint(a), hi = (unsigned)__double2hiint(a);
+        const auto slo = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto shi = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        return half_ ? __hiloint2double((int)shi[0], (int)slo[0]) : __hiloint2double((int)shi[1], (int)slo[1]);
+      };
+      double* xjoin = xch + 2 * (size_t)(K + ncr) * ks;  // [2][K]: x_m, x_{m+1}
+      double acc = half_ ? dvrt(nloc - 2) : dvrt(nloc - 1);
+      if (two && side) {
+        // x_{nloc} (= row m+1) and x_{nloc+1} (= row m) come from the top workgroup: their pushes
+        if (lane == 0)
+          while (__hip_atomic_load(flags + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+            __builtin_amdgcn_s_sleep(2);
+        (void)__hip_atomic_load(flags + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        const double X0 = xjoin[K + rr], X1 = xjoin[rr];  // lane r: component r of x_{nloc}, x_{nloc+1}
+        const double* h1 = Hst + (size_t)orig(nloc - 1) * KS2 + rr * ks;
+        const double* e1 = Est + (size_t)orig(nloc - 1) * KS2 + rr * ks;
+        const double* e2 = Est + (size_t)orig(nloc >= 2 ? nloc - 2 : 0) * KS2 + rr * ks;
+        double vv = 0.0, ww = 0.0;
+        for (int jj = 0; jj < K; ++jj) {
+          const double x0 = rdlane(X0, jj), x1 = rdlane(X1, jj);
+          vv = __builtin_fma(e1[jj], x1, vv);
+          vv = __builtin_fma(h1[jj], x0, vv);
+          ww = __builtin_fma(e2[jj], x0, ww);
+        }
+        acc -= half_ ? ((nloc >= 2) ? ww : 0.0) : vv;
+      }
+      double2 A0[KP], E0[KP], A1[KP], E1[KP];
+      double wi0 = 0.0, wi1 = 0.0;
+      auto solve = [&](int i, const double2 (&A)[KP], const double2 (&E)[KP], double w2) {
+#pragma unroll
+        for (int jj = K - 1; jj >= 0; --jj) {
+          const double xj = rdlane(acc, jj);  // x_i[jj]: final once the steps above it are done
+          const double ajj = (jj & 1) ? A[jj / 2].y : A[jj / 2].x;
+          const double ejj = (jj & 1) ? E[jj / 2].y : E[jj / 2].x;
+          acc = __builtin_fma(-ajj, xj, acc);  // (U strictly upper: rows >= jj keep their value)
+          w2 = __builtin_fma(-ejj, xj, w2);
+        }
+        if (live) {
+          lds[L.xall + (i + 2) * ks + r_] = acc;
+          if (two && !side && i >= m_split) xjoin[(size_t)(i - m_split) * K + r_] = acc;
+        }
+        if (two && !side && i == m_split) {  // rows m+1 and m are solved: release the other workgroup
+          __threadfence();
+          if (lane == 0) __hip_atomic_store(flags + 1, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // rotate: the lower half continues with the upper half's rhs (row i-1), the upper half
+        // takes over the lower half's w2 (row i-2)
+        acc = swap_halves(half_ ? acc : w2);
+      };
+      rowsA(nloc - 1, A0); rowsE(nloc - 1, E0, wi0);
+      for (int i = nloc - 1; i >= 0; i -= 2) {
+        rowsA(i - 1, A1); rowsE(i - 1, E1, wi1);
+        solve(i, A0, E0, wi0);
+        if (i - 1 >= 0) {
+          rowsA(i - 2, A0); rowsE(i - 2, E0, wi0);
+          solve(i - 1, A1, E1, wi1);
+        }
+      }
+    }
+  } else
   for (int j = wave; j < nrhs; j += NW) {
     double xs1[2 * KP], xs2[2 * KP];  // x_{i+1}, x_{i+2}, wave-uniform
 #pragma unroll
