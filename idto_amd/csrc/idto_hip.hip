@@ -71,6 +71,7 @@ struct idto_hip_ctx {
   bool timing_open = false;  // TimeBegin recorded an event that TimeEnd must close
   struct Timed { hipEvent_t a, b; int which; };
   std::vector<Timed> pending;
+  bool fd_full = false;                   // v / N+ in HBM belong to the resident q for every t
   int asm_stop = 0;                       // profiling aid: truncate the assembly kernel after a phase
   bool two_sided = true;                  // solver: two workgroups eliminating from both ends
   double* xch = nullptr;                  // their exchange buffer / flags
@@ -406,6 +407,7 @@ void idto_hip_destroy(idto_hip_ctx* c) {
 int idto_hip_set_problem(idto_hip_ctx* c, const idto_problem_t* p) {
   if (p->num_steps != c->N || p->time_step != c->dt) { g_err = "num_steps / time_step cannot change"; return -1; }
   HIP_OK(hipSetDevice(c->device));
+  c->fd_full = false;  // v_0 = v_init
   return UploadProblemArrays(c, p, false);
 }
 
@@ -425,12 +427,14 @@ int idto_hip_set_shard(idto_hip_ctx* c, int kb, int ke) {
 
 int idto_hip_set_q(idto_hip_ctx* c, const double* q_host) {
   HIP_OK(hipSetDevice(c->device));
+  c->fd_full = false;
   HIP_OK(hipMemcpyAsync(c->q, q_host, (size_t)(c->N + 1) * c->nq * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIP_OK(hipStreamSynchronize(c->stream));  // the host buffer may be reused by the caller
   return 0;
 }
 int idto_hip_set_q_device(idto_hip_ctx* c, const double* q_dev) {
   HIP_OK(hipSetDevice(c->device));
+  c->fd_full = false;
   HIP_OK(hipMemcpyAsync(c->q, q_dev, (size_t)(c->N + 1) * c->nq * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   return 0;
 }
@@ -450,6 +454,7 @@ int idto_hip_eval_partials(idto_hip_ctx* c) {
   if (TimeBegin(c, 0)) return -2;
   int rc = LaunchFd(c, 1, c->k_begin, c->k_end);
   if (rc) return rc;
+  c->fd_full = (c->k_begin == 0 && c->k_end == c->N);
   return TimeEnd(c);
 }
 
@@ -458,7 +463,8 @@ int idto_hip_grad_hess(idto_hip_ctx* c) {
   if (TimeBegin(c, 1)) return -2;
   if (c->weights_diagonal)
     hipLaunchKernelGGL(assemble_diag_kernel, dim3(c->N + 1, 4), dim3(256), c->asm_diag_lds, c->stream, c->M, c->P, c->q,
-                       c->slab, c->slab_stride, c->g, c->HA, c->HB, c->HC, c->asm_stop);
+                       c->slab, c->slab_stride, c->g, c->HA, c->HB, c->HC, c->asm_stop,
+                       c->fd_full ? c->v : nullptr, c->fd_full ? c->nplus : nullptr);
   else
     hipLaunchKernelGGL(assemble_kernel, dim3(c->N + 1), dim3(256), c->asm_lds, c->stream, c->M, c->P, c->q, c->slab,
                        c->slab_stride, c->g, c->HA, c->HB, c->HC);

@@ -487,7 +487,8 @@ __global__ void assemble_kernel(DevModel M, DevProblem P, const double* __restri
 __global__ void __launch_bounds__(256)
 assemble_diag_kernel(DevModel M, DevProblem P, const double* __restrict__ q, const double* __restrict__ slab,
                      int slab_stride, double* __restrict__ g, double* __restrict__ HA, double* __restrict__ HB,
-                     double* __restrict__ HC, int stop_after) {
+                     double* __restrict__ HC, int stop_after, const double* __restrict__ v_res,
+                     const double* __restrict__ nplus_res) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int i = blockIdx.x, part = blockIdx.y, N = P.N, nq = M.nq, nv = M.nv;
@@ -553,15 +554,30 @@ assemble_diag_kernel(DevModel M, DevProblem P, const double* __restrict__ q, con
     q0[c] = q[i * nq + c];
     q1[c] = (i < N) ? q[(i + 1) * nq + c] : 0.0;
   }
-  __syncthreads();
-  if (stop_after == 1) return;  // (profiling aid: phase timing by truncation)
-  nplus_block(M, q0, N0, tid, nt);
-  velocity_block(M, N0, q0, qm1, dt, v0, tid, nt);
-  if (i < N) {
-    nplus_block(M, q1, N1, tid, nt);
-    velocity_block(M, N1, q1, q0, dt, v1, tid, nt);
+  // N+(q_i), N+(q_{i+1}), v_i, v_{i+1}: the finite-difference kernel left them in HBM when it ran
+  // over the whole horizon for this q (v_res != nullptr); a rank that only holds a k-range shard
+  // of that kernel's outputs recomputes them (same expressions, same bits)
+  if (v_res) {
+    for (int idx = tid; idx < bsz; idx += nt) {
+      N0[idx] = nplus_res[(size_t)i * bsz + idx];
+      if (i < N) N1[idx] = nplus_res[(size_t)(i + 1) * bsz + idx];
+    }
+    for (int r = tid; r < nv; r += nt) {
+      v0[r] = v_res[i * nv + r];
+      if (i < N) v1[r] = v_res[(i + 1) * nv + r];
+    }
   }
   __syncthreads();
+  if (stop_after == 1) return;  // (profiling aid: phase timing by truncation)
+  if (!v_res) {
+    nplus_block(M, q0, N0, tid, nt);
+    velocity_block(M, N0, q0, qm1, dt, v0, tid, nt);
+    if (i < N) {
+      nplus_block(M, q1, N1, tid, nt);
+      velocity_block(M, N1, q1, q0, dt, v1, tid, nt);
+    }
+    __syncthreads();
+  }
   if (stop_after == 2) return;
   const double idt = 1 / dt, midt = -1 / dt;
   // weights of the V- and W1-terms depend on the row (TO.cc:1127-1161): Qv, or Qf_v at the end
