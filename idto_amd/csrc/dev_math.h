@@ -2,7 +2,10 @@
 //
 // Every expression is written with an explicit association order; together with
 // -ffp-contract=off this makes each function produce the same bits as the same
-// formula evaluated on the host.
+// formula evaluated on the host.  The products of 3-vectors and 3x3 matrices
+// (dot, cross, M v, M^T v, M M) use EXPLICIT fused multiply-adds in a fixed form, identically in
+// oracle/rigid_body.h: fma is one correctly rounded IEEE operation on both sides, and these five
+// primitives are ~60 % of the arithmetic of an inverse-dynamics evaluation.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -22,9 +25,13 @@ IDTO_DEV V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); 
 IDTO_DEV V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
 IDTO_DEV V3 operator*(V3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
 IDTO_DEV V3 operator/(V3 a, double s) { return mk(a.x / s, a.y / s, a.z / s); }
-IDTO_DEV double dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+IDTO_DEV double fma3(double a0, double b0, double a1, double b1, double a2, double b2) {
+  return __builtin_fma(a2, b2, __builtin_fma(a1, b1, a0 * b0));  // (a0 b0 (+) a1 b1) (+) a2 b2, two fused steps
+}
+IDTO_DEV double fms(double a, double b, double c, double d) { return __builtin_fma(a, b, -(c * d)); }  // a b - c d
+IDTO_DEV double dot(V3 a, V3 b) { return fma3(a.x, b.x, a.y, b.y, a.z, b.z); }
 IDTO_DEV V3 cross(V3 a, V3 b) {
-  return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+  return mk(fms(a.y, b.z, a.z, b.y), fms(a.z, b.x, a.x, b.z), fms(a.x, b.y, a.y, b.x));
 }
 IDTO_DEV V3 ldv3(const double* p) { return mk(p[0], p[1], p[2]); }
 
@@ -43,12 +50,12 @@ IDTO_DEV M3 ldm3(const double* p) {
   return R;
 }
 IDTO_DEV V3 operator*(const M3& R, V3 v) {
-  return mk((R.m[0] * v.x + R.m[1] * v.y) + R.m[2] * v.z, (R.m[3] * v.x + R.m[4] * v.y) + R.m[5] * v.z,
-            (R.m[6] * v.x + R.m[7] * v.y) + R.m[8] * v.z);
+  return mk(fma3(R.m[0], v.x, R.m[1], v.y, R.m[2], v.z), fma3(R.m[3], v.x, R.m[4], v.y, R.m[5], v.z),
+            fma3(R.m[6], v.x, R.m[7], v.y, R.m[8], v.z));
 }
 IDTO_DEV V3 tmul(const M3& R, V3 v) {  // R^T v
-  return mk((R.m[0] * v.x + R.m[3] * v.y) + R.m[6] * v.z, (R.m[1] * v.x + R.m[4] * v.y) + R.m[7] * v.z,
-            (R.m[2] * v.x + R.m[5] * v.y) + R.m[8] * v.z);
+  return mk(fma3(R.m[0], v.x, R.m[3], v.y, R.m[6], v.z), fma3(R.m[1], v.x, R.m[4], v.y, R.m[7], v.z),
+            fma3(R.m[2], v.x, R.m[5], v.y, R.m[8], v.z));
 }
 IDTO_DEV M3 operator*(const M3& A, const M3& B) {
   M3 C;
@@ -56,7 +63,7 @@ IDTO_DEV M3 operator*(const M3& A, const M3& B) {
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-      C.m[3 * r + c] = (A.m[3 * r] * B.m[c] + A.m[3 * r + 1] * B.m[3 + c]) + A.m[3 * r + 2] * B.m[6 + c];
+      C.m[3 * r + c] = fma3(A.m[3 * r], B.m[c], A.m[3 * r + 1], B.m[3 + c], A.m[3 * r + 2], B.m[6 + c]);
   return C;
 }
 IDTO_DEV V3 col(const M3& R, int c) { return mk(R.m[c], R.m[3 + c], R.m[6 + c]); }

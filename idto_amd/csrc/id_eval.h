@@ -260,10 +260,10 @@ IDTO_DEV void inertial_wrench(const DevModel& M, int b, const M3& R, V3 w, V3 al
   *f_in = (acom - g) * M.mass[b];
   const V3 wB = tmul(R, w), alB = tmul(R, al);
   const double* I = M.inertia + 6 * b;
-  const V3 Iw = mk((I[0] * wB.x + I[3] * wB.y) + I[4] * wB.z, (I[3] * wB.x + I[1] * wB.y) + I[5] * wB.z,
-                   (I[4] * wB.x + I[5] * wB.y) + I[2] * wB.z);
-  const V3 Ial = mk((I[0] * alB.x + I[3] * alB.y) + I[4] * alB.z, (I[3] * alB.x + I[1] * alB.y) + I[5] * alB.z,
-                    (I[4] * alB.x + I[5] * alB.y) + I[2] * alB.z);
+  const V3 Iw = mk(fma3(I[0], wB.x, I[3], wB.y, I[4], wB.z), fma3(I[3], wB.x, I[1], wB.y, I[5], wB.z),
+                   fma3(I[4], wB.x, I[5], wB.y, I[2], wB.z));
+  const V3 Ial = mk(fma3(I[0], alB.x, I[3], alB.y, I[4], alB.z), fma3(I[3], alB.x, I[1], alB.y, I[5], alB.z),
+                    fma3(I[4], alB.x, I[5], alB.y, I[2], alB.z));
   const V3 nB = Ial + cross(wB, Iw);
   *n_in = R * nB + cross(cW, *f_in);
 }

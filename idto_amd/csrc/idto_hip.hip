@@ -72,6 +72,7 @@ struct idto_hip_ctx {
   struct Timed { hipEvent_t a, b; int which; };
   std::vector<Timed> pending;
   bool fd_full = false;                   // v / N+ in HBM belong to the resident q for every t
+  int fd_stop = 0;                        // same for the finite-difference kernel
   int asm_stop = 0;                       // profiling aid: truncate the assembly kernel after a phase
   bool two_sided = true;                  // solver: two workgroups eliminating from both ends
   double* xch = nullptr;                  // their exchange buffer / flags
@@ -236,7 +237,7 @@ int LaunchFd(idto_hip_ctx* c, int mode, int kb, int ke) {
   const int lds = mode == 1 ? c->fd_lds : c->tau_lds;
 #define FD_LAUNCH(MC)                                                                                         \
   hipLaunchKernelGGL(fd_kernel<MC>, grid, block, lds, c->stream, c->M, c->cp, c->P, c->q, c->slab,             \
-                     c->slab_stride, c->v, c->a, c->nplus, kb, mode)
+                     c->slab_stride, c->v, c->a, c->nplus, kb, mode, c->fd_stop)
   if (c->maxc <= 2) FD_LAUNCH(2);
   else if (c->maxc <= 3) FD_LAUNCH(3);
   else if (c->maxc <= 4) FD_LAUNCH(4);
@@ -354,7 +355,7 @@ int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem, co
   int threads = ((E * K + 63) / 64) * 64;
   if (threads > 256) threads = 256;  // one wave per SIMD: the evaluation keeps its bodies in up to 512 VGPRs
   c->fd_threads = threads;
-  auto fd_lds = [&](int Ecount) { return (int)sizeof(double) * (3 * nq + 2 * (int)bsz + 3 * nv + Ecount + Ecount * nq + 3 * Ecount * nv + nv + c->M.blob_n + 2); };
+  auto fd_lds = [&](int Ecount) { return (int)sizeof(double) * (3 * nq + 2 * (int)bsz + 3 * nv + Ecount + Ecount * nq + 3 * Ecount * nv + nv + c->M.blob_n + 2 + nq / 2 + 2); };
   c->fd_lds = fd_lds(E);
   c->tau_lds = fd_lds(1);
   c->asm_lds = (int)sizeof(double) * (3 * nq + 5 * (int)bsz + 4 * nv + nq + std::max(nq, nv) + (int)bsz + 3 * (int)qq + nq);
@@ -608,6 +609,7 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "solver_debug") == 0) { c->solver_debug = value != 0; return 0; }
   if (std::strcmp(name, "two_sided") == 0) { c->two_sided = value != 0; return 0; }
   if (std::strcmp(name, "asm_stop") == 0) { c->asm_stop = value; return 0; }  // profiling aid
+  if (std::strcmp(name, "fd_stop") == 0) { c->fd_stop = value; return 0; }    // profiling aid
   g_err = std::string("unknown option ") + name;
   return -1;
 }

@@ -61,6 +61,63 @@ IDTO_DEV void nplus_block(const DevModel& M, const double* q, double* Nout, int 
   __syncthreads();
 }
 
+// N+ of TWO configurations at once (fd_kernel needs q_k and q_{k+1}): wavefront 0 works on the
+// first, wavefront 1 on the second (a single wavefront does them one after the other); within a
+// wavefront lanes 0..47 take the bodies, lanes 48..59 the 3x4 quaternion block entry by entry
+// (each entry is 9 IEEE divisions deep instead of 21 in sequence).  Same expressions as
+// nplus_block, hence the same bits.
+IDTO_DEV void nplus_pair(const DevModel& M, const double* qa, double* Na, const double* qb, double* Nb, int tid,
+                         int nthreads) {
+  const int sz = M.nv * M.nq, nv = M.nv;
+  for (int i = tid; i < sz; i += nthreads) { Na[i] = 0.0; Nb[i] = 0.0; }
+  __syncthreads();
+  const int l = tid & 63, grp = tid >> 6, ngrp = (nthreads >= 128) ? 2 : 1;
+  for (int cfg = grp; cfg < 2; cfg += ngrp) {
+    if (grp >= 2) break;
+    const double* q = cfg ? qb : qa;
+    double* Nout = cfg ? Nb : Na;
+    if (l < 48) {
+      for (int b = l; b < M.nb; b += 48) {
+        const int qs = M.qstart[b], vs = M.vstart[b], jt = M.jtype[b];
+        if (jt == IDTO_JOINT_REVOLUTE || jt == IDTO_JOINT_PRISMATIC) {
+          Nout[qs * nv + vs] = 1.0;
+        } else if (jt == IDTO_JOINT_PLANAR) {
+          for (int k = 0; k < 3; ++k) Nout[(qs + k) * nv + vs + k] = 1.0;
+        } else {
+          for (int k = 0; k < 3; ++k) Nout[(qs + 4 + k) * nv + vs + 3 + k] = 1.0;
+        }
+      }
+    } else if (l < 60) {
+      const int e = l - 48, r = e >> 2, c = e & 3;
+      for (int b = 0; b < M.nb; ++b) {
+        if (M.jtype[b] != IDTO_JOINT_FLOATING) continue;
+        const int qs = M.qstart[b], vs = M.vstart[b];
+        const double* qq = q + qs;
+        const double nrm = __builtin_sqrt(((qq[0] * qq[0] + qq[1] * qq[1]) + qq[2] * qq[2]) + qq[3] * qq[3]);
+        const double t0 = qq[0] / nrm, t1 = qq[1] / nrm, t2 = qq[2] / nrm, t3 = qq[3] / nrm;
+        const double w2 = 2.0 * t0, x2 = 2.0 * t1, y2 = 2.0 * t2, z2 = 2.0 * t3;
+        // row r of LT = L(2 q~)^T
+        const double l0 = (r == 0) ? -x2 : ((r == 1) ? -y2 : -z2);
+        const double l1 = (r == 0) ? w2 : ((r == 1) ? z2 : -y2);
+        const double l2 = (r == 0) ? -z2 : ((r == 1) ? w2 : x2);
+        const double l3 = (r == 0) ? y2 : ((r == 1) ? -x2 : w2);
+        // column c of D = (I - q~ q~^T) / |q|
+        const double tc = (c == 0) ? t0 : ((c == 1) ? t1 : ((c == 2) ? t2 : t3));
+        const double d0 = ((c == 0 ? 1.0 : 0.0) - t0 * tc) / nrm;
+        const double d1 = ((c == 1 ? 1.0 : 0.0) - t1 * tc) / nrm;
+        const double d2 = ((c == 2 ? 1.0 : 0.0) - t2 * tc) / nrm;
+        const double d3 = ((c == 3 ? 1.0 : 0.0) - t3 * tc) / nrm;
+        double acc = l0 * d0;
+        acc += l1 * d1;
+        acc += l2 * d2;
+        acc += l3 * d3;
+        Nout[(qs + c) * nv + vs + r] = acc;
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // v = N (qa - qb) / dt  (TO.cc:187-190); threads r < nv
 IDTO_DEV void velocity_block(const DevModel& M, const double* N, const double* qa, const double* qb, double dt,
                              double* vout, int tid, int nthreads) {
@@ -79,7 +136,8 @@ IDTO_DEV void velocity_block(const DevModel& M, const double* N, const double* q
 template <int MAXC>
 __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevProblem P, const double* __restrict__ q,
                           double* __restrict__ slab, int slab_stride, double* __restrict__ v_out,
-                          double* __restrict__ a_out, double* __restrict__ nplus_out, int k_begin, int mode) {
+                          double* __restrict__ a_out, double* __restrict__ nplus_out, int k_begin, int mode,
+                          int stop_after) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int k = k_begin + blockIdx.x;
@@ -107,6 +165,7 @@ __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevP
   double* etau = ea + E * nv;   // [E][nv]
   double* edump = etau + E * nv; // [nv] write-only dump row for surplus lanes
   double* mblob = edump + nv;    // [M.blob_n] the model tables
+  int* colinfo = reinterpret_cast<int*>(mblob + M.blob_n + (M.blob_n & 1));  // [nq] non-zero rows of N+ column c
 
   // stage the model into LDS and use that copy from here on
   for (int i = tid; i < M.blob_n; i += nt) mblob[i] = M.blob[i];
@@ -117,8 +176,18 @@ __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevP
   }
   __syncthreads();
   const DevModel Ml = rebase_model(M, mblob);
-  nplus_block(Ml, q0, N0, tid, nt);
-  nplus_block(Ml, q1, N1, tid, nt);
+  // N+ is sparse: column c has its non-zeros in rows [j0, j0 + cnt) (cnt = 3 for the quaternion
+  // columns, 1 otherwise); packed j0 | cnt << 16
+  for (int b = tid; b < Ml.nb; b += nt) {
+    const int qs = Ml.qstart[b], vs = Ml.vstart[b], jt = Ml.jtype[b];
+    if (jt == IDTO_JOINT_REVOLUTE || jt == IDTO_JOINT_PRISMATIC) colinfo[qs] = vs | 1 << 16;
+    else if (jt == IDTO_JOINT_PLANAR) { for (int kq = 0; kq < 3; ++kq) colinfo[qs + kq] = (vs + kq) | 1 << 16; }
+    else {
+      for (int kq = 0; kq < 4; ++kq) colinfo[qs + kq] = vs | 3 << 16;
+      for (int kq = 0; kq < 3; ++kq) colinfo[qs + 4 + kq] = (vs + 3 + kq) | 1 << 16;
+    }
+  }
+  nplus_pair(Ml, q0, N0, q1, N1, tid, nt);
   if (k > 0) velocity_block(Ml, N0, q0, qm1, dt, v0, tid, nt);
   else
     for (int r = tid; r < nv; r += nt) v0[r] = P.v_init[r];
@@ -138,6 +207,7 @@ __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevP
     if (k == 0) nplus_out[i] = N0[i];
   }
 
+  if (stop_after == 1) return;  // (profiling aid: phase timing by truncation) after N+, v, a
   // ---- evaluation inputs (TO.cc:501-521)
   const double eps = 1.4901161193847656e-08;  // sqrt(DBL_EPSILON) = 2^-26
   for (int e = tid; e < E; e += nt) {
@@ -182,6 +252,7 @@ __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevP
   }
   __syncthreads();
 
+  if (stop_after == 2) return;  // after the evaluation inputs
   // ---- the evaluations: lane = (evaluation, path)
   // Surplus groups (e >= E) re-run evaluation 0 into a dump row so that every lane
   // of a wavefront takes part in the butterfly sums inside id_eval.
@@ -196,6 +267,7 @@ __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevP
   }
   __syncthreads();
 
+  if (stop_after == 3) return;  // after the inverse-dynamics evaluations
   // ---- outputs
   double* sl = slab + (size_t)k * slab_stride;
   double* Mk = sl;
@@ -214,10 +286,12 @@ __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevP
     if (k >= 2) {
       const double sc = 1 / dt / dt;
       const double* Mcols = etau + (1 + nP + nT) * nv;  // column j = tau of mass evaluation j
+      // sum over j in the reference's order; the terms outside [j0, j0 + cnt) are exact zeros
       for (int idx = tid; idx < bsz; idx += nt) {
         const int c = idx / nv, r = idx - c * nv;
-        double acc = (sc * Mcols[r]) * N0[c * nv];
-        for (int j = 1; j < nv; ++j) acc += (sc * Mcols[j * nv + r]) * N0[c * nv + j];
+        const int j0 = colinfo[c] & 0xffff, cnt = colinfo[c] >> 16;
+        double acc = (sc * Mcols[j0 * nv + r]) * N0[c * nv + j0];
+        for (int j = j0 + 1; j < j0 + cnt; ++j) acc += (sc * Mcols[j * nv + r]) * N0[c * nv + j];
         Mk[idx] = acc;
       }
     } else {

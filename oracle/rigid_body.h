@@ -54,27 +54,32 @@ inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 inline V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
 inline V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
 inline V3 operator/(V3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
-inline double dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// (explicit fused multiply-adds in a fixed form, identically in idto_amd/csrc/dev_math.h)
+inline double fma3(double a0, double b0, double a1, double b1, double a2, double b2) {
+  return std::fma(a2, b2, std::fma(a1, b1, a0 * b0));
+}
+inline double fms(double a, double b, double c, double d) { return std::fma(a, b, -(c * d)); }  // a b - c d
+inline double dot(V3 a, V3 b) { return fma3(a.x, b.x, a.y, b.y, a.z, b.z); }
 inline V3 cross(V3 a, V3 b) {
-  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+  return {fms(a.y, b.z, a.z, b.y), fms(a.z, b.x, a.x, b.z), fms(a.x, b.y, a.y, b.x)};
 }
 struct M3 {
   double m[9];  // row-major
 };
 inline M3 Identity3() { return {{1, 0, 0, 0, 1, 0, 0, 0, 1}}; }
 inline V3 operator*(const M3& R, V3 v) {
-  return {(R.m[0] * v.x + R.m[1] * v.y) + R.m[2] * v.z, (R.m[3] * v.x + R.m[4] * v.y) + R.m[5] * v.z,
-          (R.m[6] * v.x + R.m[7] * v.y) + R.m[8] * v.z};
+  return {fma3(R.m[0], v.x, R.m[1], v.y, R.m[2], v.z), fma3(R.m[3], v.x, R.m[4], v.y, R.m[5], v.z),
+          fma3(R.m[6], v.x, R.m[7], v.y, R.m[8], v.z)};
 }
 inline V3 TMul(const M3& R, V3 v) {  // R^T v
-  return {(R.m[0] * v.x + R.m[3] * v.y) + R.m[6] * v.z, (R.m[1] * v.x + R.m[4] * v.y) + R.m[7] * v.z,
-          (R.m[2] * v.x + R.m[5] * v.y) + R.m[8] * v.z};
+  return {fma3(R.m[0], v.x, R.m[3], v.y, R.m[6], v.z), fma3(R.m[1], v.x, R.m[4], v.y, R.m[7], v.z),
+          fma3(R.m[2], v.x, R.m[5], v.y, R.m[8], v.z)};
 }
 inline M3 operator*(const M3& A, const M3& B) {
   M3 C;
   for (int r = 0; r < 3; ++r)
     for (int c = 0; c < 3; ++c)
-      C.m[3 * r + c] = (A.m[3 * r] * B.m[c] + A.m[3 * r + 1] * B.m[3 + c]) + A.m[3 * r + 2] * B.m[6 + c];
+      C.m[3 * r + c] = fma3(A.m[3 * r], B.m[c], A.m[3 * r + 1], B.m[3 + c], A.m[3 * r + 2], B.m[6 + c]);
   return C;
 }
 inline V3 Col(const M3& R, int c) { return {R.m[c], R.m[3 + c], R.m[6 + c]}; }
@@ -452,8 +457,8 @@ class Dynamics {
       const V3 wB = TMul(b.R, b.w), alB = TMul(b.R, b.al);
       const double* I = &m.inertia[6 * i];  // xx yy zz xy xz yz
       auto Imul = [&](V3 x) {
-        return V3{(I[0] * x.x + I[3] * x.y) + I[4] * x.z, (I[3] * x.x + I[1] * x.y) + I[5] * x.z,
-                  (I[4] * x.x + I[5] * x.y) + I[2] * x.z};
+        return V3{fma3(I[0], x.x, I[3], x.y, I[4], x.z), fma3(I[3], x.x, I[1], x.y, I[5], x.z),
+                  fma3(I[4], x.x, I[5], x.y, I[2], x.z)};
       };
       const V3 nB = Imul(alB) + cross(wB, Imul(wB));
       const V3 n_in = b.R * nB + cross(cW, f_in);

@@ -20,3 +20,17 @@ for name, N in (("mini_cheetah", 40), ("hopper", 50), ("allegro_hand", 60)):
         dev.sync()
         print(f"{name:14s} {label:46s} {1e6 * (time.perf_counter() - t0) / 300:7.1f} us")
     dev.close()
+
+print("fd_kernel (mini_cheetah N=40) truncated after: 1 N+/v/a, 2 evaluation inputs, 3 inverse dynamics, 0 complete")
+cfg = load_config("mini_cheetah"); model = load_model("mini_cheetah")
+prob, sp, _ = make_problem(cfg, model, num_steps=40)
+q = synthetic_trajectory(cfg, model, 40, seed=0, lower=0.01)
+dev = hip.HipPath(model, prob, sp); dev.set_q(q)
+for stop in (1, 2, 3, 0):
+    dev.set_option("fd_stop", stop)
+    for _ in range(20): dev.eval_partials()
+    dev.sync(); dev.timing_enable(True); dev.timing_reset()
+    for _ in range(200): dev.eval_partials()
+    dev.sync()
+    print(f"  fd_stop={stop}: {1e3 * dev.timing_get(0)[0]:.2f} us")
+    dev.timing_enable(False)
