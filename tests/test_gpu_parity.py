@@ -204,3 +204,49 @@ def test_update_problem_and_shard():
     assert np.array_equal(dev.get("step"), p)
     dev.close()
     dev2.close()
+
+
+@pytest.mark.parametrize("name,N", [("spinner", 1), ("spinner", 2), ("spinner", 3), ("hopper", 4), ("hopper", 9),
+                                     ("hopper", 10), ("free_body", 5), ("pendulum", 12), ("acrobot", 3)])
+def test_edge_horizons_and_padded_blocks(name, N):
+    """Shortest horizons (N = 1: a single tau), the one-sided / two-sided switch of the solver
+    (n = N + 1 = 10), and block sizes that are padded to a template size (pendulum nq = 1 and
+    free_body nq = 7 run in K = 8 blocks): same bit-exact bar as the main cases."""
+    from idto_amd.problem import ProblemDefinition, SolverParameters
+    model = load_model(name)
+    nq, nv = model.nq, model.nv
+    rng = np.random.default_rng(N)
+    if name in ("free_body", "pendulum"):
+        q0 = np.array([1.0, 0, 0, 0, 0.1, 0.2, 0.3]) if name == "free_body" else np.array([0.3])
+        prob = ProblemDefinition(num_steps=N, q_init=q0, v_init=np.zeros(nv), Qq=np.eye(nq), Qv=0.1 * np.eye(nv),
+                                 Qf_q=10 * np.eye(nq), Qf_v=np.eye(nv), R=0.5 * np.eye(nv),
+                                 q_nom=np.tile(q0, (N + 1, 1)), v_nom=np.zeros((N + 1, nv)), time_step=0.05)
+        sp = SolverParameters(verbose=False, scaling=False, equality_constraints=False)
+        q = np.tile(q0, (N + 1, 1)) + 0.05 * rng.normal(size=(N + 1, nq))
+        q[0] = q0
+    else:
+        model, prob, sp, q = setup(name, N, N, 0.01)
+    orc = Oracle(model, prob, sp)
+    dev = hip.HipPath(model, prob, sp)
+    dev.set_q(q)
+    dev.gn_step()
+    v, a, tau, cost = orc.eval_traj(q)
+    g, bands = orc.grad_hess(q)
+    _, p = orc.gn_step(q)
+    assert same(dev.get("tau"), tau) and same(dev.get("v"), v)
+    P = orc.eval_partials(q)
+    for key in ("dtau_dqp", "dtau_dqt", "dtau_dqm"):
+        assert same(dev.get(key), P[key]), key
+    assert same(dev.get("gradient"), g)
+    assert same(dev.get("H_A"), bands[0]) and same(dev.get("H_B"), bands[1]) and same(dev.get("H_C"), bands[2])
+    p_fast = dev.get("step")
+    import oracle_lib as ol
+    scale = np.abs(g).max() + 1e-300
+    res = lambda x: np.abs(ol.penta_multiply(*bands, x) + g).max() / scale
+    assert res(p_fast) <= 16 * res(p) + 1e-13, (res(p_fast), res(p))
+    dev.set_option("reference_solver", 1)
+    dev.factor_solve()
+    assert same(dev.get("step"), p)
+    dev.eval_tau()
+    assert dev.get("cost") == cost
+    dev.close()
