@@ -17,18 +17,24 @@
 // reference are at round-off level: no pivoting inside S_i (it is SPD), FMAs, reciprocals by
 // v_rcp_f64 + 2 Newton steps.  `penta_kernel` (kernels.h) stays the bit-exact restatement.
 //
-// Hardware mapping (ONE workgroup of 4 wavefronts: the recursion over i is sequential, the
-// kernel is bound by the VALU issue rate of the wavefront on the critical path, ~4 cycles
-// per instruction, so the design minimises instructions there):
+// Hardware mapping (workgroups of 4 wavefronts; the recursion over i is sequential, the kernel is
+// bound by the instruction issue rate of the wavefront on the critical path, ~5 cycles per VALU
+// instruction and 7 / 34 cycles per LDS read / write, so the design minimises instructions there):
+//   * two workgroups eliminate from both ends of the horizon and meet at block rows m, m+1
+//     ("twisted" factorisation, see the kernel); the dependent chain is n/2 block rows;
 //   * elimination: the augmented block [S_i | H_i | E_i | y] lives in the REGISTERS of one
 //     wavefront per (64 - K) right-hand-side columns, one column per lane; a pivot step
 //     broadcasts the pivot column with v_readlane (wave-uniform values sit in SGPRs) and is
 //     otherwise per-lane FMAs: no LDS traffic and no barrier in the K dependent steps;
-//   * block products: 2x2 register tiles, one job per thread, job type uniform per wavefront
-//     (no divergence), all indices precomputed outside the row loop; while wavefront 0
-//     eliminates, the others form Et^T Dn Et for the next row and write factors back to HBM;
+//   * block products X^T Dn Y on the matrix cores (v_mfma_f64_16x16x4): every operand element is
+//     read from LDS once per 16x16 tile; while wavefront 0 eliminates, the others form
+//     Et^T Dn Et for the next row (MFMA), stage and prefetch the next rows' bands and write
+//     factors back to HBM;
 //   * barriers order LDS only (s_waitcnt lgkmcnt(0); s_barrier): the register prefetch of the
-//     next row's blocks and the write-backs stay in flight across them.
+//     next row's blocks and the write-backs stay in flight across them;
+//   * back substitution in "push" form: every component of x_i is pushed into the pending
+//     right-hand sides of rows i-1, i-2 as soon as the triangular solve produces it.
+// Many right-hand sides: penta_apply.h (one wavefront per column, from the stored factors).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -153,30 +159,6 @@ __host__ __device__ inline PentaLdlLds penta_ldl_layout(int n, int K, int nrhs) 
   o += L.bl_size ? nrhs * (n + 2) * ks : 0;
   L.end = o;
   return L;
-}
-
-// 2x2 tile of P^T diag(dn) Q over m = 0..K-1; p0/p1/q0/q1 point to the tile's columns (16-byte
-// aligned, padded with a zero row when K is odd) so that every load is a ds_read_b128: a lone
-// wavefront pays ~10 cycles per DS instruction whatever its width.
-template <int K>
-__device__ __forceinline__ void tile_ptdq(const double* p0, const double* p1, const double* q0, const double* q1,
-                                          const double* dn, double& a00, double& a01, double& a10, double& a11) {
-  a00 = a01 = a10 = a11 = 0.0;
-  constexpr int KP = (K + 1) / 2;
-  const double2* P0 = reinterpret_cast<const double2*>(p0);
-  const double2* P1 = reinterpret_cast<const double2*>(p1);
-  const double2* Q0 = reinterpret_cast<const double2*>(q0);
-  const double2* Q1 = reinterpret_cast<const double2*>(q1);
-  const double2* DN = reinterpret_cast<const double2*>(dn);
-#pragma unroll
-  for (int m = 0; m < KP; ++m) {
-    const double2 d = DN[m], u0 = P0[m], u1 = P1[m], y0 = Q0[m], y1 = Q1[m];
-    const double x0a = u0.x * d.x, x1a = u1.x * d.x, x0b = u0.y * d.y, x1b = u1.y * d.y;
-    a00 = __builtin_fma(x0a, y0.x, a00); a01 = __builtin_fma(x0a, y1.x, a01);
-    a10 = __builtin_fma(x1a, y0.x, a10); a11 = __builtin_fma(x1a, y1.x, a11);
-    a00 = __builtin_fma(x0b, y0.y, a00); a01 = __builtin_fma(x0b, y1.y, a01);
-    a10 = __builtin_fma(x1b, y0.y, a10); a11 = __builtin_fma(x1b, y1.y, a11);
-  }
 }
 
 // K = compile-time block size >= k; the k x k blocks are embedded in K x K ones padded with
