@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--config", default="mini_cheetah")
     ap.add_argument("--num-steps", type=int, default=40, help="horizon N")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--batch", type=int, default=8,
+                    help="also report the aggregate rate of this many independent problems on one GPU (0/1: skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,10 +110,18 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run --nproc-per-node N")
     dist = None
+    # debugging aids for a single-GPU box (never set by the driver): all ranks on GPU 0 and a gloo
+    # process group, to exercise the multi-rank code path without RCCL
+    backend = os.environ.get("IDTO_BENCH_BACKEND", "nccl")
+    if os.environ.get("IDTO_BENCH_SAME_GPU"):
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
 
     cfg = load_config(args.config)
@@ -206,6 +216,33 @@ def main():
                        "bit_identical_to_unsharded": same,
                        "exchange": f"all_gather_into_tensor of {N * dev.slab_stride * 8} B slab over {world} ranks"}
 
+    batch_extra = None
+    if world == 1 and args.batch > 1:
+        # informational (never `value`): B independent problems resident on this ONE GPU, each context
+        # on its own stream - one problem occupies at most 164 of the 256 CUs for a third of the
+        # iteration and 2 CUs for the rest, so several iterate concurrently
+        devs = [hip.HipPath(model, prob, sp, device=local_rank) for _ in range(args.batch)]
+        for b, d in enumerate(devs):
+            d.set_q(synthetic_trajectory(cfg, model, N, seed=b, lower=0.01))
+        for _ in range(10):
+            for d in devs:
+                d.gn_step()
+        for d in devs:
+            d.sync()
+        nb = max(20, args.steps // 2)
+        t1 = time.perf_counter()
+        for _ in range(nb):
+            for d in devs:
+                d.gn_step()
+        for d in devs:
+            d.sync()
+        el = time.perf_counter() - t1
+        batch_extra = {"problems": args.batch, "value": args.batch * nb / el, "unit": "GN iters/s (aggregate)",
+                       "ms_per_round": 1e3 * el / nb,
+                       "note": "independent problems on one GPU, one HIP stream each; single host thread launching"}
+        for d in devs:
+            d.close()
+
     units = args.steps * (world if (world > 1 and not sharded) else 1)
     value = units / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
@@ -238,6 +275,8 @@ def main():
         }
         if shard_extra is not None:
             out["shard_mode"] = shard_extra
+        if batch_extra is not None:
+            out["batch_mode"] = batch_extra
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, prob, sp, q)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
