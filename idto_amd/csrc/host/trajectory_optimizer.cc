@@ -100,8 +100,9 @@ TO::TrajectoryOptimizer(const idto_model_t& model, double time_step, const Probl
                         const SolverParameters& params, int device)
     : time_step_(time_step), prob_(prob), params_(params) {
   // same run-time checks as the reference constructor / CalcInverseDynamicsPartials (TO.cc:37-74, 400-424)
-  if (params_.gradients_method != kForwardDifferences)
-    throw std::runtime_error("TrajectoryOptimizer (HIP): only gradients_method = kForwardDifferences is implemented");
+  if (params_.gradients_method != kForwardDifferences && params_.gradients_method != kCentralDifferences &&
+      params_.gradients_method != kCentralDifferences4)
+    throw std::runtime_error("TrajectoryOptimizer (HIP): gradients_method must be a finite-difference method (kAutoDiff needs Drake)");
   if (params_.exact_hessian) throw std::runtime_error("TrajectoryOptimizer (HIP): exact_hessian needs autodiff");
   for (int b = 0; b < model.nbodies; ++b) {
     const int jt = model.jtype[b];
@@ -129,6 +130,7 @@ TO::TrajectoryOptimizer(const idto_model_t& model, double time_step, const Probl
   idto_contact_params_t c = {params_.contact_stiffness, params_.dissipation_velocity, params_.stiction_velocity,
                              params_.friction_coefficient, params_.smoothing_factor};
   Check(idto_hip_create(&model, &p, &c, device, &hip_));
+  Check(idto_hip_set_option(hip_, "gradients_method", static_cast<int>(params_.gradients_method)));
 }
 
 TO::~TrajectoryOptimizer() { idto_hip_destroy(hip_); }

@@ -72,6 +72,7 @@ struct idto_hip_ctx {
   struct Timed { hipEvent_t a, b; int which; };
   std::vector<Timed> pending;
   bool fd_full = false;                   // v / N+ in HBM belong to the resident q for every t
+  int gradients_method = 0;               // 0 forward, 1 central, 2 central 4th order (solver_parameters.h:26-50)
   int fd_stop = 0;                        // same for the finite-difference kernel
   int asm_stop = 0;                       // profiling aid: truncate the assembly kernel after a phase
   bool two_sided = true;                  // solver: two workgroups eliminating from both ends
@@ -231,13 +232,30 @@ int BuildModel(idto_hip_ctx* c, const idto_model_t* m) {
 }
 
 
+int FdEvals(const idto_hip_ctx* c, int mode) {
+  return (mode == 0) ? 1 : ((mode == 1) ? 1 + 2 * c->nq + c->nv : 1 + ((mode == 2) ? 2 : 4) * 3 * c->nq);
+}
+
+// dynamic LDS of fd_kernel when it builds the inputs of `ec` evaluations per pass
+int FdLds(const idto_hip_ctx* c, int mode, int ec) {
+  const int nq = c->nq, nv = c->nv, E = FdEvals(c, mode);
+  return (int)sizeof(double) * (3 * nq + 2 * nv * nq + 3 * nv + E + E * nv + ec * (nq + 2 * nv) + nv + c->M.blob_n + 2 + nq / 2 + 2);
+}
+
 int LaunchFd(idto_hip_ctx* c, int mode, int kb, int ke) {
   if (ke <= kb) return 0;
-  dim3 grid(ke - kb), block(mode == 1 ? c->fd_threads : 64);
-  const int lds = mode == 1 ? c->fd_lds : c->tau_lds;
+  if (mode >= 1) mode = 1 + c->gradients_method;  // 1 forward, 2 central, 3 central (4th order)
+  dim3 grid(ke - kb), block(mode >= 1 ? c->fd_threads : 64);
+  // evaluations per pass: all of them if they fit in LDS, otherwise the largest multiple of
+  // the number of evaluations the block runs concurrently
+  const int E = FdEvals(c, mode), groups = (int)block.x / c->npaths;
+  int ec = E;
+  while (ec > groups && FdLds(c, mode, ec) > 160 * 1024) ec = ((ec - 1) / groups) * groups;
+  const int lds = FdLds(c, mode, ec);
+  if (lds > 160 * 1024) { g_err = "finite-difference evaluation set does not fit in LDS"; return -1; }
 #define FD_LAUNCH(MC)                                                                                         \
   hipLaunchKernelGGL(fd_kernel<MC>, grid, block, lds, c->stream, c->M, c->cp, c->P, c->q, c->slab,             \
-                     c->slab_stride, c->v, c->a, c->nplus, kb, mode, c->fd_stop)
+                     c->slab_stride, c->v, c->a, c->nplus, kb, mode, c->fd_stop, ec)
   if (c->maxc <= 2) FD_LAUNCH(2);
   else if (c->maxc <= 3) FD_LAUNCH(3);
   else if (c->maxc <= 4) FD_LAUNCH(4);
@@ -610,6 +628,11 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "two_sided") == 0) { c->two_sided = value != 0; return 0; }
   if (std::strcmp(name, "asm_stop") == 0) { c->asm_stop = value; return 0; }  // profiling aid
   if (std::strcmp(name, "fd_stop") == 0) { c->fd_stop = value; return 0; }    // profiling aid
+  if (std::strcmp(name, "gradients_method") == 0) {
+    if (value < 0 || value > 2) { g_err = "gradients_method: 0 forward, 1 central, 2 central4 (autodiff needs Drake)"; return -1; }
+    c->gradients_method = value;
+    return 0;
+  }
   g_err = std::string("unknown option ") + name;
   return -1;
 }

@@ -137,7 +137,7 @@ template <int MAXC>
 __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevProblem P, const double* __restrict__ q,
                           double* __restrict__ slab, int slab_stride, double* __restrict__ v_out,
                           double* __restrict__ a_out, double* __restrict__ nplus_out, int k_begin, int mode,
-                          int stop_after) {
+                          int stop_after, int echunk) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int k = k_begin + blockIdx.x;
@@ -145,9 +145,15 @@ __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevP
   const int bsz = nv * nq;
   const double dt = P.dt;
 
-  const int nP = (mode == 1) ? nq : 0;
-  const int nT = (mode == 1) ? nq : 0;
-  const int nM = (mode == 1) ? nv : 0;
+  // mode 0: tau only; 1: forward differences (+ nv mass-matrix columns for dtau_k/dq_{k-1});
+  // 2 / 3: central differences of 2nd / 4th order (reference TO.cc:565-885): every partial,
+  // including dtau_k/dq_{k-1}, from evaluations at q_t[i] + m*dq, m in {+1,-1} / {+1,-1,+2,-2};
+  // evaluation index e = 1 + ((g * NM + mi) * nq + i), g = 0: w.r.t. q_{k+1}, 1: q_k, 2: q_{k-1}
+  const bool central = mode >= 2;
+  const int NM = (mode == 2) ? 2 : ((mode == 3) ? 4 : 1);
+  const int nP = (mode >= 1) ? NM * nq : 0;
+  const int nT = (mode >= 1) ? NM * nq : 0;
+  const int nM = (mode == 1) ? nv : (central ? NM * nq : 0);
   const int E = 1 + nP + nT + nM;
 
   double* qm1 = lds;            // q_{k-1}
@@ -159,11 +165,14 @@ __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevP
   double* v1 = v0 + nv;         // v_{k+1}
   double* a0 = v1 + nv;         // a_k
   double* edq = a0 + nv;        // [E]
-  double* eq = edq + E;         // [E][nq]
-  double* ev = eq + E * nq;     // [E][nv]
-  double* ea = ev + E * nv;     // [E][nv]
-  double* etau = ea + E * nv;   // [E][nv]
-  double* edump = etau + E * nv; // [nv] write-only dump row for surplus lanes
+  // the evaluation inputs are built `echunk` evaluations at a time (one pass unless the
+  // central-difference evaluation set of a large model would not fit in LDS)
+  const int EC = (echunk < E) ? echunk : E;
+  double* etau = edq + E;       // [E][nv]
+  double* eq = etau + E * nv;   // [EC][nq]
+  double* ev = eq + EC * nq;    // [EC][nv]
+  double* ea = ev + EC * nv;    // [EC][nv]
+  double* edump = ea + EC * nv; // [nv] write-only dump row for surplus lanes
   double* mblob = edump + nv;    // [M.blob_n] the model tables
   int* colinfo = reinterpret_cast<int*>(mblob + M.blob_n + (M.blob_n & 1));  // [nq] non-zero rows of N+ column c
 
@@ -212,9 +221,9 @@ __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevP
   const double eps = 1.4901161193847656e-08;  // sqrt(DBL_EPSILON) = 2^-26
   for (int e = tid; e < E; e += nt) {
     double dq = 1.0;
-    if (e >= 1 && e < 1 + nP + nT) {
+    if (e >= 1 && (e < 1 + nP + nT || central)) {
       const int i = (e - 1) % nq;
-      const double qi = (e < 1 + nP) ? q1[i] : q0[i];
+      const double qi = (e < 1 + nP) ? q1[i] : ((e < 1 + nP + nT) ? q0[i] : qm1[i]);
       dq = eps * __builtin_fmax(1.0, __builtin_fabs(qi));
       const double temp = qi + dq;
       dq = temp - qi;
@@ -222,16 +231,40 @@ __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevP
     edq[e] = dq;
   }
   __syncthreads();
-  for (int idx = tid; idx < E * nq; idx += nt) {
-    const int e = idx / nq, c = idx - e * nq;
+  for (int c0 = 0; c0 < E; c0 += EC) {
+  const int ce = (E - c0 < EC) ? E - c0 : EC;  // evaluations [c0, c0 + ce) in this pass
+  for (int idx = tid; idx < ce * nq; idx += nt) {
+    const int el = idx / nq, c = idx - el * nq, e = c0 + el;
     double val = q1[c];
-    if (e >= 1 && e < 1 + nP && c == e - 1) val = q1[c] + edq[e];
+    if (e >= 1 && e < 1 + nP && c == (e - 1) % nq) {
+      if (!central) {
+        val = q1[c] + edq[e];
+      } else {  // qi + mult * dq (TO.cc:766)
+        const int mi = (e - 1) / nq;
+        const double mult = (mi == 0) ? 1.0 : ((mi == 1) ? -1.0 : ((mi == 2) ? 2.0 : -2.0));
+        val = q1[c] + mult * edq[e];
+      }
+    }
     eq[idx] = val;
   }
-  for (int idx = tid; idx < E * nv; idx += nt) {
-    const int e = idx / nv, j = idx - e * nv;
+  for (int idx = tid; idx < ce * nv; idx += nt) {
+    const int el = idx / nv, j = idx - el * nv, e = c0 + el;
     double vv = v1[j], aa = a0[j];
-    if (e >= 1 && e < 1 + nP) {
+    if (central && e >= 1) {
+      const int g = (e - 1) / (NM * nq), mi = ((e - 1) / nq) % NM, i = (e - 1) % nq;
+      const double mult = (mi == 0) ? 1.0 : ((mi == 1) ? -1.0 : ((mi == 2) ? 2.0 : -2.0));
+      const double dv = edq[e] / dt, da = dv / dt;
+      const double n1 = N1[i * nv + j], n0 = N0[i * nv + j];
+      if (g == 0) {         // tau_k(q_{k+1} + m dq): TO.cc:763-787
+        vv = v1[j] + (mult * dv) * n1;
+        aa = a0[j] + (mult * da) * n1;
+      } else if (g == 1) {  // tau_k under q_k + m dq: :788-814
+        vv = v1[j] - (mult * dv) * n1;
+        aa = a0[j] - (mult * da) * (n1 + n0);
+      } else {              // tau_k under q_{k-1} + m dq: :815-839
+        aa = a0[j] + (mult * da) * n0;
+      }
+    } else if (e >= 1 && e < 1 + nP) {
       const int i = e - 1;
       const double dv = edq[e] / dt, da = dv / dt;
       const double n1 = N1[i * nv + j];
@@ -257,15 +290,16 @@ __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevP
   // Surplus groups (e >= E) re-run evaluation 0 into a dump row so that every lane
   // of a wavefront takes part in the butterfly sums inside id_eval.
   const int groups = nt / K;
-  for (int e0 = 0; e0 < E; e0 += groups) {
-    const int e = e0 + tid / K;
+  for (int e0 = 0; e0 < ce; e0 += groups) {
+    const int el = e0 + tid / K;
     const int path = tid % K;
-    const int ee = (e < E) ? e : 0;
-    const bool full = ee < 1 + nP + nT;
-    double* tau_dst = (e < E) ? etau + ee * nv : edump;
+    const int ee = (el < ce) ? el : 0;
+    const bool full = central || c0 + ee < 1 + nP + nT;
+    double* tau_dst = (el < ce) ? etau + (c0 + ee) * nv : edump;
     id_eval<MAXC>(Ml, cp, path, full, eq + ee * nq, ev + ee * nv, ea + ee * nv, tau_dst);
   }
   __syncthreads();
+  }
 
   if (stop_after == 3) return;  // after the inverse-dynamics evaluations
   // ---- outputs
@@ -297,6 +331,24 @@ __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevP
     } else {
       const double fill = (k == 0) ? __builtin_nan("") : 0.0;
       for (int idx = tid; idx < bsz; idx += nt) Mk[idx] = fill;
+    }
+  } else if (central) {
+    // (tau(+) - tau(-)) / (2 dq), or the five-point formula, in the reference's expression order
+    for (int idx = tid; idx < 3 * bsz; idx += nt) {
+      const int g = idx / bsz, rem = idx - g * bsz, i = rem / nv, r = rem - i * nv;
+      const int e0 = 1 + (g * NM) * nq + i;  // multiplier 0 (+1); +nq per multiplier index
+      const double dq = edq[e0];
+      const double tp = etau[e0 * nv + r], tm = etau[(e0 + nq) * nv + r];
+      double d;
+      if (mode == 2) {
+        d = 0.5 * (tp - tm) / dq;
+      } else {
+        const double tpp = etau[(e0 + 2 * nq) * nv + r], tmm = etau[(e0 + 3 * nq) * nv + r];
+        d = 2.0 / 3.0 * (tp - tm) / dq - 1.0 / 12.0 * (tpp - tmm) / dq;
+      }
+      if (g == 0) Pk[rem] = d;
+      else if (g == 1) Tk[rem] = (k >= 1) ? d : 0.0;
+      else Mk[rem] = (k >= 2) ? d : ((k == 0) ? __builtin_nan("") : 0.0);
     }
   }
 }

@@ -101,6 +101,10 @@ class HipPath:
         _chk(L.idto_hip_create(C.byref(cm), C.byref(cp), C.byref(cc), int(device), C.byref(h)))
         self.h = h
         self.device = device
+        from .problem import GRADIENTS
+        gm = GRADIENTS[params.gradients_method]
+        if gm:  # 1 central, 2 central4 (SolverParameters::gradients_method); others are refused by the library
+            _chk(L.idto_hip_set_option(self.h, b"gradients_method", gm))
 
     def close(self):
         if getattr(self, "h", None):

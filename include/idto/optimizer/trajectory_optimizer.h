@@ -18,8 +18,9 @@
 // path: construction throws std::runtime_error if no HIP device is available.
 //
 // Differences from the reference, all reported through exceptions exactly where the reference
-// throws/aborts: gradients_method must be kForwardDifferences (kAutoDiff needs Drake's
-// AutoDiffXd plant, reference TO.cc:410-423 has the same kind of runtime check),
+// throws/aborts: gradients_method must be one of the finite-difference methods (forward,
+// central, central4; kAutoDiff needs Drake's AutoDiffXd plant, reference TO.cc:410-423 has
+// the same kind of runtime check),
 // exact_hessian is not supported, method kLinesearch is not supported on the device path.
 #pragma once
 

@@ -67,7 +67,7 @@ enum idto_hip_array {
 const char* idto_hip_last_error(void);
 
 /* Creates a context on HIP device `device` for the given model, problem and
- * contact parameters (copied).  `gradients_method`: 0 forward differences. */
+ * contact parameters (copied). */
 int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem,
                     const idto_contact_params_t* contact, int device, idto_hip_ctx** out);
 void idto_hip_destroy(idto_hip_ctx* ctx);
@@ -102,7 +102,9 @@ int idto_hip_gn_step(idto_hip_ctx* ctx);
  * (optimizer/trajectory_optimizer.cc:1371-1396) and CalcDoglegPoint (:2108-2202). */
 int idto_hip_solve_host(idto_hip_ctx* ctx, const double* rhs_host, int nrhs, double* x_host);
 
-/* Options: "reference_solver" = 1 selects the bit-exact restatement of the reference's
+/* Options: "gradients_method" = 0 forward differences (default), 1 / 2 central differences of
+ * 2nd / 4th order (SolverParameters::gradients_method, reference solver_parameters.h:26-50,
+ * trajectory_optimizer.cc:565-885); 3 (autodiff) is refused.  "reference_solver" = 1 selects the bit-exact restatement of the reference's
  * pivoted-LU block Thomas (slow) instead of the banded block LDL^T solver (default 0; the
  * environment variable IDTO_SOLVER_REFERENCE=1 sets it at creation); "two_sided" = 0 keeps the
  * LDL^T solver on one workgroup (default 1: two workgroups eliminate from both ends of the

@@ -40,9 +40,11 @@ def test_spinner_end_to_end_golden():
     assert st.solve_time > 0
 
 
-@pytest.mark.parametrize("name,iters", [("acrobot", 10), ("spinner", 10), ("hopper", 10), ("mini_cheetah", 5),
-                                         ("allegro_hand", 3)])
-def test_solve_tracks_the_oracle(name, iters):
+@pytest.mark.parametrize("name,iters,method", [("acrobot", 10, None), ("spinner", 10, None), ("hopper", 10, None),
+                                                ("mini_cheetah", 5, None), ("allegro_hand", 3, None),
+                                                ("spinner", 6, "central_differences"),
+                                                ("hopper", 5, "central_differences4")])
+def test_solve_tracks_the_oracle(name, iters, method):
     """Every example config (reference examples/*/*.yaml; scaling and equality constraints ON as
     in the YAMLs): the device-backed Solve follows the CPU oracle's iterates.  Tolerance: cost and
     trust-region radius sequences equal to 1e-6 relative; the reference's own Python test accepts
@@ -51,6 +53,8 @@ def test_solve_tracks_the_oracle(name, iters):
     model = load_model(name)
     prob, sp, q_guess = make_problem(cfg, model)
     sp.max_iterations, sp.verbose, sp.num_threads = iters, False, 1
+    if method:  # the airhockey example's choice (reference examples/airhockey/airhockey.yaml)
+        sp.gradients_method = method
     ref = Oracle(model, prob, sp).solve(q_guess)
     opt = TrajectoryOptimizer(model, prob, sp)
     assert opt.num_equality_constraints() == Oracle(model, prob, sp).num_eq
@@ -162,6 +166,6 @@ def test_reset_initial_conditions():  # python_bindings/test/warm_start_test.py:
 
 def test_unsupported_options_fail_loudly():
     model, prob, sp, _ = spinner_python_test_problem()
-    sp.gradients_method = "central_differences"
-    with pytest.raises(RuntimeError, match="kForwardDifferences"):
+    sp.gradients_method = "autodiff"
+    with pytest.raises(RuntimeError, match="finite-difference"):
         TrajectoryOptimizer(model, prob, sp)

@@ -250,3 +250,37 @@ def test_edge_horizons_and_padded_blocks(name, N):
     dev.eval_tau()
     assert dev.get("cost") == cost
     dev.close()
+
+
+@pytest.mark.parametrize("method", ["central_differences", "central_differences4"])
+@pytest.mark.parametrize("name,N,seed,lower", [("acrobot", 8, 0, 0.0), ("spinner", 10, 1, 0.0), ("hopper", 12, 2, 0.02),
+                                              ("mini_cheetah", 6, 3, 0.03), ("allegro_hand", 5, 4, 0.0),
+                                              ("mini_cheetah", 40, 0, 0.01)])
+def test_central_difference_partials_bit_exact(name, N, seed, lower, method):
+    """SolverParameters::gradients_method = kCentralDifferences / kCentralDifferences4
+    (reference trajectory_optimizer.cc:565-885): the device evaluates tau at q_t[i] +- dq
+    (and +- 2 dq) in the same expressions as the oracle; partials, gradient, Hessian bands
+    and the step of the reference-order solver are bit-identical."""
+    model, prob, sp, q = setup(name, N, seed, lower)
+    sp.gradients_method = method
+    orc = Oracle(model, prob, sp)
+    dev = hip.HipPath(model, prob, sp)
+    dev.set_q(q)
+    dev.eval_partials()
+    P = orc.eval_partials(q)
+    for k in ("dtau_dqp", "dtau_dqt", "dtau_dqm"):
+        got = dev.get(k)
+        assert same(got, P[k]), (k, np.nanmax(np.abs(got - P[k])))
+    _, _, tau, _ = orc.eval_traj(q)
+    assert same(dev.get("tau"), tau)
+    dev.grad_hess()
+    g, bands = orc.grad_hess(q)
+    assert same(dev.get("gradient"), g)
+    assert same(dev.get("H_A"), bands[0]) and same(dev.get("H_B"), bands[1]) and same(dev.get("H_C"), bands[2])
+    # and the methods agree with forward differences to truncation error
+    sp.gradients_method = "forward_differences"
+    dev_f = hip.HipPath(model, prob, sp)
+    dev_f.set_q(q)
+    dev_f.eval_partials()
+    a, b = dev.get("dtau_dqt"), dev_f.get("dtau_dqt")
+    assert np.abs(a - b).max() <= 2e-4 * (1.0 + np.abs(b).max())
