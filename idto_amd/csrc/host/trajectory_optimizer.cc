@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <string>
 
@@ -23,6 +24,47 @@ namespace optimizer {
 namespace {
 
 using Vec = std::vector<double>;
+
+// Optional wall-clock profile of the host loop (environment variable IDTO_OPT_PROFILE=<s>): time
+// per named phase from the (s+1)-th SolveFromWarmStart of the process on (the first solves pay
+// one-off warm-up), printed to stderr when the process exits.  tools/host_profile.py uses it.
+struct Profile {
+  static constexpr int kMax = 16;
+  const char* name[kMax] = {};
+  double sec[kMax] = {};
+  long calls[kMax] = {};
+  bool on = false;
+  int skip = std::getenv("IDTO_OPT_PROFILE") ? std::atoi(std::getenv("IDTO_OPT_PROFILE")) : -1;
+  void NewSolve() {
+    if (skip >= 0 && skip-- == 0) on = true;
+  }
+  int Slot(const char* n) {
+    for (int i = 0; i < kMax; ++i) {
+      if (name[i] == n) return i;
+      if (!name[i]) { name[i] = n; return i; }
+    }
+    return kMax - 1;
+  }
+  ~Profile() {
+    if (!on) return;
+    for (int i = 0; i < kMax && name[i]; ++i)
+      std::fprintf(stderr, "[idto_opt profile] %-28s %10.3f ms in %6ld calls\n", name[i], 1e3 * sec[i], calls[i]);
+  }
+};
+Profile g_profile;
+struct Scope {
+  int slot = -1;
+  std::chrono::steady_clock::time_point t0;
+  explicit Scope(const char* n) {
+    if (g_profile.on) { slot = g_profile.Slot(n); t0 = std::chrono::steady_clock::now(); }
+  }
+  ~Scope() {
+    if (slot >= 0) {
+      g_profile.sec[slot] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      ++g_profile.calls[slot];
+    }
+  }
+};
 
 double Dot(const Vec& a, const Vec& b) {
   double s = 0;
@@ -52,40 +94,71 @@ std::vector<MatrixXd> UnflattenBlocks(const Vec& flat, int count, int rows, int 
 
 // Solves the symmetric positive (semi-)definite n x n system S x = b in place with an LDL^T
 // factorisation with diagonal pivoting (what Eigen's ldlt() does for the reference at
-// TO.cc:1395); S is column-major and is overwritten.
+// TO.cc:1395).  S is column-major; only its lower triangle is read and it is overwritten by the
+// factors (right-looking, column-oriented: the inner loops run down contiguous columns).
 void DenseLdltSolve(std::vector<double>* S_io, int n, double* b) {
   std::vector<double>& S = *S_io;
   std::vector<int> perm((std::size_t)n);
   for (int i = 0; i < n; ++i) perm[i] = i;
-  auto at = [&](int r, int c) -> double& { return S[(std::size_t)c * n + r]; };
+  auto at = [&](int r, int c) -> double& { return S[(std::size_t)c * n + r]; };  // r >= c
+  std::vector<double> w((std::size_t)n);
   for (int j = 0; j < n; ++j) {
     int p = j;
     for (int i = j + 1; i < n; ++i)
       if (std::fabs(at(i, i)) > std::fabs(at(p, p))) p = i;
-    if (p != j) {  // symmetric row/column swap
-      for (int i = 0; i < n; ++i) std::swap(at(i, j), at(i, p));
-      for (int i = 0; i < n; ++i) std::swap(at(j, i), at(p, i));
+    if (p != j) {  // symmetric interchange j <-> p within the lower triangle
+      for (int i = 0; i < j; ++i) std::swap(at(j, i), at(p, i));
+      for (int i = j + 1; i < p; ++i) std::swap(at(i, j), at(p, i));
+      for (int i = p + 1; i < n; ++i) std::swap(at(i, j), at(i, p));
+      std::swap(at(j, j), at(p, p));
       std::swap(perm[j], perm[p]);
     }
     const double d = at(j, j);
-    if (d == 0.0) continue;  // exactly singular direction: leave it (Eigen does the same)
-    for (int i = j + 1; i < n; ++i) at(i, j) /= d;
-    for (int c = j + 1; c < n; ++c) {
-      const double f = at(c, j) * d;
-      if (f == 0.0) continue;
-      for (int r = c; r < n; ++r) at(r, c) -= at(r, j) * f;
+    if (d == 0.0) {  // exactly singular direction: drop it (Eigen does the same)
+      for (int i = j + 1; i < n; ++i) at(i, j) = 0.0;
+      continue;
     }
-    for (int c = j + 1; c < n; ++c)  // keep the full matrix symmetric for later swaps
-      for (int r = c + 1; r < n; ++r) at(c, r) = at(r, c);
+    double* cj = &at(0, j);
+    for (int i = j + 1; i < n; ++i) { w[i] = cj[i]; cj[i] /= d; }  // w = d * l_j
+    for (int c = j + 1; c < n; ++c) {
+      const double f = cj[c];
+      if (f == 0.0) continue;
+      double* cc = &at(0, c);
+      for (int r = c; r < n; ++r) cc[r] -= w[r] * f;
+    }
   }
   std::vector<double> y((std::size_t)n);
   for (int i = 0; i < n; ++i) y[i] = b[perm[i]];
-  for (int j = 0; j < n; ++j)
-    for (int i = j + 1; i < n; ++i) y[i] -= at(i, j) * y[j];
+  for (int j = 0; j < n; ++j) {
+    const double yj = y[j];
+    const double* cj = &at(0, j);
+    for (int i = j + 1; i < n; ++i) y[i] -= cj[i] * yj;
+  }
   for (int j = 0; j < n; ++j) y[j] = (at(j, j) != 0.0) ? y[j] / at(j, j) : 0.0;
-  for (int j = n - 1; j >= 0; --j)
-    for (int i = j + 1; i < n; ++i) y[j] -= at(i, j) * y[i];
+  for (int j = n - 1; j >= 0; --j) {
+    const double* cj = &at(0, j);
+    double acc0 = 0, acc1 = 0;
+    int i = j + 1;
+    for (; i + 1 < n; i += 2) { acc0 += cj[i] * y[i]; acc1 += cj[i + 1] * y[i + 1]; }
+    if (i < n) acc0 += cj[i] * y[i];
+    y[j] -= acc0 + acc1;
+  }
   for (int i = 0; i < n; ++i) b[perm[i]] = y[i];
+}
+
+// sum_k a[k] * b[k] with four independent partial sums (lets the compiler keep four FMA chains
+// in flight; plain left-to-right summation is latency-bound)
+inline double Dot4(const double* a, const double* b, int len) {
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int k = 0;
+  for (; k + 3 < len; k += 4) {
+    s0 += a[k] * b[k];
+    s1 += a[k + 1] * b[k + 1];
+    s2 += a[k + 2] * b[k + 2];
+    s3 += a[k + 3] * b[k + 3];
+  }
+  for (; k < len; ++k) s0 += a[k] * b[k];
+  return (s0 + s1) + (s2 + s3);
 }
 
 }  // namespace
@@ -190,9 +263,21 @@ Vec TO::Fetch(int what) const {
 void TO::CalcTrajectoryData(const TrajectoryOptimizerState<T>& state) const {
   auto& c = state.cache_;
   if (c.traj) return;
-  EnsureDevice(state, 1);
-  c.tau = Unflatten(Fetch(IDTO_ARR_TAU), num_steps(), nv_);
-  c.cost = Fetch(IDTO_ARR_COST)[0];
+  Scope prof_("tau + cost (device + fetch)");
+  if (resident_ != &state || !c.uploaded) {
+    // a new point: upload, evaluate and read back in one call / one synchronisation
+    const Vec q = Flatten(state.q());
+    Vec tau((std::size_t)num_steps() * nv_);
+    Check(idto_hip_trial_cost(hip_, q.data(), tau.data(), &c.cost));
+    c.tau = Unflatten(tau, num_steps(), nv_);
+    resident_ = &state;
+    c.uploaded = true;
+    device_level_ = 1;
+  } else {
+    EnsureDevice(state, 1);
+    c.tau = Unflatten(Fetch(IDTO_ARR_TAU), num_steps(), nv_);
+    c.cost = Fetch(IDTO_ARR_COST)[0];
+  }
   c.traj = true;
 }
 void TO::CalcKinematics(const TrajectoryOptimizerState<T>& state) const {
@@ -212,6 +297,7 @@ void TO::CalcDerivatives(const TrajectoryOptimizerState<T>& state) const {
   auto& c = state.cache_;
   if (c.deriv) return;
   CalcTrajectoryData(state);
+  Scope prof_("partials (device + fetch)");
   EnsureDevice(state, 2);
   const int N = num_steps();
   const Vec slab = Fetch(IDTO_ARR_SLAB);  // per k: [dtau_dqm | dtau_dqt | dtau_dqp | tau_k]
@@ -247,7 +333,8 @@ void TO::CalcVelocityPartials(const TrajectoryOptimizerState<T>& state) const {
 void TO::CalcGradHess(const TrajectoryOptimizerState<T>& state) const {
   auto& c = state.cache_;
   if (c.grad && c.hess) return;
-  CalcDerivatives(state);
+  CalcTrajectoryData(state);  // (the partials stay on the device unless somebody asks for them)
+  Scope prof_("grad + hess (device + fetch)");
   EnsureDevice(state, 3);
   c.gradient = Fetch(IDTO_ARR_GRADIENT);
   const Vec bands = Fetch(IDTO_ARR_HBANDS);  // [A | B | C], (N+6) blocks each
@@ -282,6 +369,7 @@ const PentaDiagonalMatrix<double>& TO::EvalHessian(const TrajectoryOptimizerStat
 const VectorXd& TO::EvalScaleFactors(const TrajectoryOptimizerState<T>& s) const {
   auto& c = s.cache_;
   if (!c.scale) {
+    Scope prof_("scale factors");
     Vec d;
     EvalHessian(s).ExtractDiagonal(&d);
     Vec& D = c.scale_factors;
@@ -303,6 +391,7 @@ const PentaDiagonalMatrix<double>& TO::EvalScaledHessian(const TrajectoryOptimiz
   if (!params_.scaling) return EvalHessian(s);
   auto& c = s.cache_;
   if (!c.shess) {
+    Scope prof_("scaled hessian");
     c.scaled_hessian = EvalHessian(s);
     c.scaled_hessian.ScaleByDiagonal(EvalScaleFactors(s));
     c.shess = true;
@@ -340,6 +429,7 @@ const MatrixXd& TO::EvalEqualityConstraintJacobian(const TrajectoryOptimizerStat
   auto& c = s.cache_;
   if (!c.J) {
     const auto& P = EvalInverseDynamicsPartials(s);
+    Scope prof_("constraint jacobian");
     const int nu = (int)unactuated_dofs_.size(), N = num_steps();
     c.J_unscaled = MatrixXd(nu * N, num_vars());
     for (int t = 0; t < N; ++t)
@@ -379,6 +469,7 @@ const MatrixXd& TO::EvalHinvJTg(const TrajectoryOptimizerState<T>& s) const {
     for (int i = 0; i < n; ++i) rhs(i, neq) = g[i];
     EnsureDevice(s, 3);
     c.Hinv_JT_g = MatrixXd(n, neq + 1);
+    Scope prof_("device solve H^-1[J^T|g]");
     Check(idto_hip_solve_host(hip_, rhs.data(), neq + 1, c.Hinv_JT_g.data()));
     c.hinv = true;
   }
@@ -393,27 +484,25 @@ const VectorXd& TO::EvalLagrangeMultipliers(const TrajectoryOptimizerState<T>& s
     const MatrixXd& Y = EvalHinvJTg(s);
     EvalEqualityConstraintJacobian(s);
     const int neq = num_equality_constraints(), nu = (int)unactuated_dofs_.size();
+    Scope prof_("lambda: J Y + dense LDLT");
     std::vector<double> S((std::size_t)neq * neq, 0.0);
     Vec rhs((std::size_t)neq);
     Vec jr((std::size_t)3 * nq_);
     for (int r = 0; r < neq; ++r) {
       // row r of J is non-zero only in the three blocks around its time step: gather it once,
-      // then every column of Y contributes a short contiguous dot product
+      // then every column of Y contributes a short contiguous dot product.  S = J H^-1 J^T is
+      // symmetric: only the lower triangle (col <= r) is formed, which is all the LDL^T reads.
       const int t = r / nu;
       const int c0 = std::max(0, (t - 1) * nq_), c1 = (t + 2) * nq_, len = c1 - c0;
       for (int kq = 0; kq < len; ++kq) jr[kq] = c.J_unscaled(r, c0 + kq);
-      for (int col = 0; col <= neq; ++col) {
-        const double* ycol = Y.data() + (std::size_t)col * num_vars() + c0;
-        double acc = 0;
-        for (int kq = 0; kq < len; ++kq) acc += jr[kq] * ycol[kq];
-        if (col < neq) S[(std::size_t)col * neq + r] = acc;
-        else rhs[r] = h[r] - acc;
-      }
+      for (int col = 0; col <= r; ++col)
+        S[(std::size_t)col * neq + r] = Dot4(jr.data(), Y.data() + (std::size_t)col * num_vars() + c0, len);
+      rhs[r] = h[r] - Dot4(jr.data(), Y.data() + (std::size_t)neq * num_vars() + c0, len);
     }
-    for (int cc = 0; cc < neq; ++cc)  // symmetrise (J H^-1 J^T is symmetric up to round-off)
-      for (int r = cc + 1; r < neq; ++r) S[(std::size_t)cc * neq + r] = S[(std::size_t)r * neq + cc] =
-          0.5 * (S[(std::size_t)cc * neq + r] + S[(std::size_t)r * neq + cc]);
-    DenseLdltSolve(&S, neq, rhs.data());
+    {
+      Scope prof2_("  dense LDLT");
+      DenseLdltSolve(&S, neq, rhs.data());
+    }
     c.lambda_v = rhs;
     c.lambda = true;
   }
@@ -531,6 +620,22 @@ bool TO::CalcDoglegPoint(const TrajectoryOptimizerState<T>& s, double Delta, Vec
   return true;
 }
 
+// The accepted iterate q_k + dq is the trial point CalcTrustRatio just evaluated in `scratch`
+// (same additions, same bits): its tau / cost / h and its residency on the device carry over
+// instead of being recomputed (the reference re-evaluates them through its cache, TO.cc:2550-2553).
+void TO::AdoptTrialPoint(const TrajectoryOptimizerState<T>& scratch, TrajectoryOptimizerState<T>* state) const {
+  if (!scratch.cache_.traj || scratch.q() != state->q()) return;
+  auto& c = state->cache_;
+  c.tau = scratch.cache_.tau;
+  c.cost = scratch.cache_.cost;
+  c.traj = true;
+  if (scratch.cache_.h) { c.h_viol = scratch.cache_.h_viol; c.h = true; }
+  if (resident_ == &scratch && scratch.cache_.uploaded) {
+    resident_ = state;
+    c.uploaded = true;
+  }
+}
+
 // TO.cc:1979-2035
 double TO::CalcTrustRatio(const TrajectoryOptimizerState<T>& s, const VectorXd& dq,
                           TrajectoryOptimizerState<T>* scratch) const {
@@ -595,6 +700,8 @@ SolverFlag TO::SolveFromWarmStart(WarmStart* ws, TrajectoryOptimizerSolution<T>*
   if (params_.method != kTrustRegion) throw std::runtime_error("warm start requires the trust-region method");
   const auto start_time = clock::now();
   auto iter_start = clock::now();
+  g_profile.NewSolve();
+  Scope prof_("SolveFromWarmStart total");
   TrajectoryOptimizerState<T>& state = ws->state;
   TrajectoryOptimizerState<T>& scratch = ws->scratch_state;
   Vec& dq = ws->dq;
@@ -631,6 +738,7 @@ SolverFlag TO::SolveFromWarmStart(WarmStart* ws, TrajectoryOptimizerSolution<T>*
     if (rho > eta) {  // :2550-2553
       state.AddToQ(dq);
       if (params_.normalize_quaternions) NormalizeQuaternions(&state);
+      AdoptTrialPoint(scratch, &state);
     }
     const double iter_time = std::chrono::duration<double>(clock::now() - iter_start).count();
     iter_start = clock::now();

@@ -81,6 +81,8 @@ struct idto_hip_ctx {
   size_t xch_count = 0, flag_count = 0;
   unsigned epoch = 0;
   double *stage_rhs = nullptr, *stage_x = nullptr;  // idto_hip_solve_host
+  double* pack = nullptr;                            // [tau | cost] of idto_hip_trial_cost (device)
+  double* pin = nullptr;                             // pinned host staging: q in, [tau | cost] out
   size_t stage_count = 0;
   std::vector<hipEvent_t> event_pool;  // recycled: creating events in the timed loop costs host time
   double tsum[3] = {0, 0, 0};
@@ -419,6 +421,7 @@ void idto_hip_destroy(idto_hip_ctx* c) {
   (void)TimeDrain(c);
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   for (void* p : c->allocs) (void)hipFree(p);
+  if (c->pin) (void)hipHostFree(c->pin);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -463,8 +466,34 @@ int idto_hip_eval_tau(idto_hip_ctx* c) {
   int rc = LaunchFd(c, 0, 0, c->N);
   if (rc) return rc;
   hipLaunchKernelGGL(cost_kernel, dim3(1), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
-                     c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0);
+                     c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, (double*)nullptr);
   HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int idto_hip_trial_cost(idto_hip_ctx* c, const double* q_host, double* tau_host, double* cost_host) {
+  HIP_OK(hipSetDevice(c->device));
+  if (!q_host || !cost_host) { g_err = "trial_cost: bad arguments"; return -1; }
+  const size_t nq_all = (size_t)(c->N + 1) * c->nq, ntau = (size_t)c->N * c->nv;
+  if (!c->pin) {
+    if (Alloc(c, ntau + 1, &c->pack)) return -2;
+    HIP_OK(hipHostMalloc((void**)&c->pin, (nq_all + ntau + 1) * sizeof(double), hipHostMallocDefault));
+  }
+  // one stream synchronisation for the whole trial point: q through pinned memory, N
+  // inverse-dynamics evaluations, the cost, and [tau | cost] back in one copy
+  std::memcpy(c->pin, q_host, nq_all * sizeof(double));
+  c->fd_full = false;
+  HIP_OK(hipMemcpyAsync(c->q, c->pin, nq_all * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  int rc = LaunchFd(c, 0, 0, c->N);
+  if (rc) return rc;
+  hipLaunchKernelGGL(cost_kernel, dim3(1), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
+                     c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, c->pack);
+  HIP_OK(hipGetLastError());
+  double* out = c->pin + nq_all;
+  HIP_OK(hipMemcpyAsync(out, c->pack, (ntau + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  if (tau_host) std::memcpy(tau_host, out, ntau * sizeof(double));
+  *cost_host = out[ntau];
   return 0;
 }
 

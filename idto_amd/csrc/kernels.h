@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevP
 // is accumulated serially in the reference's order.
 __global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__ q, const double* __restrict__ v,
                             const double* __restrict__ slab, int slab_stride, double* __restrict__ cost_out,
-                            int diag) {
+                            int diag, double* __restrict__ pack) {
   // e^T W e per term as the reference's Eigen expression evaluates it: tot = sum_c (sum_r e_r W[r][c]) e_c.
   // One thread per (term, column c); `diag`: the weights are diagonal, the inner sum is its one
   // non-zero product (the others are exact zeros).  Then one thread per term adds the columns in
@@ -408,7 +408,14 @@ __global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__
     cost += terms[3 * N];
     cost += terms[3 * N + 1];
     *cost_out = cost;
+    if (pack) pack[N * nv] = cost;
   }
+  // [tau_0 .. tau_{N-1} | cost] contiguous: what a trial point of the trust-region loop reads back
+  if (pack)
+    for (int idx = tid; idx < N * nv; idx += nt) {
+      const int t = idx / nv, r = idx - t * nv;
+      pack[idx] = slab[(size_t)t * slab_stride + 3 * nv * nq + r];
+    }
 }
 
 // ---------------------------------------------------------------------------

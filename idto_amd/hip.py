@@ -50,6 +50,8 @@ def lib():
         L.idto_hip_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.idto_hip_set_q.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.idto_hip_set_q_device.argtypes = [C.c_void_p, C.c_void_p]
+        L.idto_hip_trial_cost.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                          C.POINTER(C.c_double)]
         for f in ("eval_tau", "eval_partials", "grad_hess", "gn_step", "sync", "timing_reset"):
             getattr(L, "idto_hip_" + f).argtypes = [C.c_void_p]
         L.idto_hip_factor_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -70,7 +72,7 @@ def lib():
 
 EXPORTED_SYMBOLS = [
     "idto_hip_last_error", "idto_hip_create", "idto_hip_destroy", "idto_hip_set_problem", "idto_hip_set_stream",
-    "idto_hip_get_stream", "idto_hip_set_shard", "idto_hip_set_q", "idto_hip_set_q_device", "idto_hip_eval_tau",
+    "idto_hip_get_stream", "idto_hip_set_shard", "idto_hip_set_q", "idto_hip_set_q_device", "idto_hip_eval_tau", "idto_hip_trial_cost",
     "idto_hip_eval_partials", "idto_hip_grad_hess", "idto_hip_factor_solve", "idto_hip_gn_step", "idto_hip_solve_host",
     "idto_hip_set_option",
     "idto_hip_timing_enable", "idto_hip_timing_reset", "idto_hip_timing_get", "idto_hip_sync", "idto_hip_get",
@@ -140,6 +142,15 @@ class HipPath:
     # ---- path pieces (asynchronous on the context's stream)
     def eval_tau(self):
         _chk(lib().idto_hip_eval_tau(self.h))
+
+    def trial_cost(self, q):
+        """upload q, evaluate tau and the cost, return (tau (N, nv), cost) with one synchronisation"""
+        q = np.ascontiguousarray(np.asarray(q, dtype=np.float64))
+        assert q.size == (self.N + 1) * self.nq
+        tau = np.empty((self.N, self.nv))
+        cost = C.c_double()
+        _chk(lib().idto_hip_trial_cost(self.h, dptr(q), dptr(tau), C.byref(cost)))
+        return tau, cost.value
 
     def eval_partials(self):
         _chk(lib().idto_hip_eval_partials(self.h))

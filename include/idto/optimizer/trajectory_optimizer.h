@@ -117,6 +117,7 @@ class TrajectoryOptimizer<double> {
   void CalcGradHess(const TrajectoryOptimizerState<T>& state) const;
   const MatrixXd& EvalHinvJTg(const TrajectoryOptimizerState<T>& state) const;
   void NormalizeQuaternions(TrajectoryOptimizerState<T>* state) const;
+  void AdoptTrialPoint(const TrajectoryOptimizerState<T>& scratch, TrajectoryOptimizerState<T>* state) const;
   ConvergenceReason VerifyConvergenceCriteria(const TrajectoryOptimizerState<T>& state, T previous_cost,
                                               const VectorXd& dq) const;
   void Check(int rc) const;

@@ -89,6 +89,12 @@ int idto_hip_set_q(idto_hip_ctx* ctx, const double* q_host);         /* H2D copy
 int idto_hip_set_q_device(idto_hip_ctx* ctx, const double* q_device); /* D2D copy */
 
 int idto_hip_eval_tau(idto_hip_ctx* ctx);
+
+/* One trial point of the trust-region loop in one call and one synchronisation (what
+ * CalcTrustRatio, optimizer/trajectory_optimizer.cc:1979-2035, needs at q + dq): uploads q
+ * ((N+1)*nq, host), evaluates v, a, tau and the cost L(q) (:147-176), returns tau (N*nv, may be
+ * NULL) and the cost to host memory.  Equivalent to set_q + eval_tau + get(TAU) + get(COST). */
+int idto_hip_trial_cost(idto_hip_ctx* ctx, const double* q_host, double* tau_host, double* cost_host);
 int idto_hip_eval_partials(idto_hip_ctx* ctx);
 int idto_hip_grad_hess(idto_hip_ctx* ctx);
 /* Factorises the resident Hessian and solves H x = rhs for `nrhs` right-hand

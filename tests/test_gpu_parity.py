@@ -284,3 +284,21 @@ def test_central_difference_partials_bit_exact(name, N, seed, lower, method):
     dev_f.eval_partials()
     a, b = dev.get("dtau_dqt"), dev_f.get("dtau_dqt")
     assert np.abs(a - b).max() <= 2e-4 * (1.0 + np.abs(b).max())
+
+
+def test_trial_cost_equals_set_q_eval_tau():
+    """idto_hip_trial_cost (one call, one synchronisation) == set_q + eval_tau + get(tau) + get(cost),
+    bit for bit, and leaves the context ready for eval_partials on the same q"""
+    model, prob, sp, q = setup("mini_cheetah", 12, 5, 0.02)
+    orc = Oracle(model, prob, sp)
+    dev = hip.HipPath(model, prob, sp)
+    tau, cost = dev.trial_cost(q)
+    _, _, tau_ref, cost_ref = orc.eval_traj(q)
+    assert same(tau, tau_ref) and cost == cost_ref
+    dev.eval_partials()
+    P = orc.eval_partials(q)
+    assert same(dev.get("dtau_dqt"), P["dtau_dqt"])
+    q2 = q + 1e-3
+    tau2, cost2 = dev.trial_cost(q2)   # second call reuses the staging buffers
+    _, _, tau2_ref, cost2_ref = orc.eval_traj(q2)
+    assert same(tau2, tau2_ref) and cost2 == cost2_ref
