@@ -95,36 +95,79 @@ std::vector<MatrixXd> UnflattenBlocks(const Vec& flat, int count, int rows, int 
 // Solves the symmetric positive (semi-)definite n x n system S x = b in place with an LDL^T
 // factorisation with diagonal pivoting (what Eigen's ldlt() does for the reference at
 // TO.cc:1395).  S is column-major; only its lower triangle is read and it is overwritten by the
-// factors (right-looking, column-oriented: the inner loops run down contiguous columns).
+// factors.  Right-looking in panels of kPanel pivots: inside a panel only the pivot column and the
+// running diagonal are brought up to date, the rank-kPanel update of the trailing matrix is
+// applied once per panel (one pass over the matrix per panel instead of one per pivot: the
+// unblocked version is bound by cache bandwidth at n = 240).
+// (compiled for AVX2+FMA as well; the loader picks the variant the host CPU supports)
+__attribute__((target_clones("arch=haswell", "default")))
 void DenseLdltSolve(std::vector<double>* S_io, int n, double* b) {
+  constexpr int kPanel = 16;
   std::vector<double>& S = *S_io;
   std::vector<int> perm((std::size_t)n);
   for (int i = 0; i < n; ++i) perm[i] = i;
   auto at = [&](int r, int c) -> double& { return S[(std::size_t)c * n + r]; };  // r >= c
-  std::vector<double> w((std::size_t)n);
-  for (int j = 0; j < n; ++j) {
-    int p = j;
-    for (int i = j + 1; i < n; ++i)
-      if (std::fabs(at(i, i)) > std::fabs(at(p, p))) p = i;
-    if (p != j) {  // symmetric interchange j <-> p within the lower triangle
-      for (int i = 0; i < j; ++i) std::swap(at(j, i), at(p, i));
-      for (int i = j + 1; i < p; ++i) std::swap(at(i, j), at(p, i));
-      for (int i = p + 1; i < n; ++i) std::swap(at(i, j), at(i, p));
-      std::swap(at(j, j), at(p, p));
-      std::swap(perm[j], perm[p]);
+  std::vector<double> diag((std::size_t)n), W((std::size_t)n * kPanel), t((std::size_t)n);
+  for (int i = 0; i < n; ++i) diag[i] = at(i, i);
+  for (int j0 = 0; j0 < n; j0 += kPanel) {
+    const int j1 = std::min(n, j0 + kPanel);
+    for (int j = j0; j < j1; ++j) {
+      int p = j;
+      for (int i = j + 1; i < n; ++i)
+        if (std::fabs(diag[i]) > std::fabs(diag[p])) p = i;
+      if (p != j) {  // symmetric interchange j <-> p: lower triangle, panel workspace, diagonal
+        for (int i = 0; i < j; ++i) std::swap(at(j, i), at(p, i));
+        for (int i = j + 1; i < p; ++i) std::swap(at(i, j), at(p, i));
+        for (int i = p + 1; i < n; ++i) std::swap(at(i, j), at(i, p));
+        std::swap(at(j, j), at(p, p));
+        for (int q = 0; q < j - j0; ++q) std::swap(W[(std::size_t)q * n + j], W[(std::size_t)q * n + p]);
+        std::swap(diag[j], diag[p]);
+        std::swap(perm[j], perm[p]);
+      }
+      // column j of the matrix as updated by the panel's earlier pivots
+      double* __restrict tj = t.data();
+      const double* cj0 = &at(0, j);
+      for (int i = j + 1; i < n; ++i) tj[i] = cj0[i];
+      for (int q = 0; q < j - j0; ++q) {
+        const double f = at(j, j0 + q);  // L[j][pivot q]
+        if (f == 0.0) continue;
+        const double* __restrict wq = &W[(std::size_t)q * n];
+        for (int i = j + 1; i < n; ++i) tj[i] -= wq[i] * f;
+      }
+      const double d = diag[j];
+      at(j, j) = d;
+      double* __restrict cj = &at(0, j);
+      double* __restrict wj = &W[(std::size_t)(j - j0) * n];
+      double* __restrict dg = diag.data();
+      if (d == 0.0) {  // exactly singular direction: drop it (Eigen does the same)
+        for (int i = j + 1; i < n; ++i) { cj[i] = 0.0; wj[i] = 0.0; }
+        continue;
+      }
+      for (int i = j + 1; i < n; ++i) {
+        const double l = tj[i] / d;
+        wj[i] = tj[i];  // = d * l
+        cj[i] = l;
+        dg[i] -= tj[i] * l;
+      }
     }
-    const double d = at(j, j);
-    if (d == 0.0) {  // exactly singular direction: drop it (Eigen does the same)
-      for (int i = j + 1; i < n; ++i) at(i, j) = 0.0;
-      continue;
-    }
-    double* cj = &at(0, j);
-    for (int i = j + 1; i < n; ++i) { w[i] = cj[i]; cj[i] /= d; }  // w = d * l_j
-    for (int c = j + 1; c < n; ++c) {
-      const double f = cj[c];
-      if (f == 0.0) continue;
-      double* cc = &at(0, c);
-      for (int r = c; r < n; ++r) cc[r] -= w[r] * f;
+    // rank-(j1 - j0) update of the trailing lower triangle
+    const int np = j1 - j0;
+    for (int c = j1; c < n; ++c) {
+      double* __restrict cc = &at(0, c);
+      int q = 0;
+      for (; q + 3 < np; q += 4) {  // four pivots per pass over the column
+        const double f0 = at(c, j0 + q), f1 = at(c, j0 + q + 1), f2 = at(c, j0 + q + 2), f3 = at(c, j0 + q + 3);
+        const double* __restrict w0 = &W[(std::size_t)q * n];
+        const double* __restrict w1 = w0 + n;
+        const double* __restrict w2 = w1 + n;
+        const double* __restrict w3 = w2 + n;
+        for (int r = c; r < n; ++r) cc[r] -= (w0[r] * f0 + w1[r] * f1) + (w2[r] * f2 + w3[r] * f3);
+      }
+      for (; q < np; ++q) {
+        const double f = at(c, j0 + q);
+        const double* __restrict wq = &W[(std::size_t)q * n];
+        for (int r = c; r < n; ++r) cc[r] -= wq[r] * f;
+      }
     }
   }
   std::vector<double> y((std::size_t)n);
@@ -452,58 +495,61 @@ const MatrixXd& TO::EvalEqualityConstraintJacobian(const TrajectoryOptimizerStat
   return c.J_scaled;
 }
 
-// H^-1 [J^T | g] with the unscaled H and J: ONE multi-right-hand-side device solve per state.
-// Everything the iteration needs from a factorisation of H (or of the scaled H~ = D H D) is a
-// linear combination of these columns:  H~^-1 J~^T = D^-1 H^-1 J^T,  H~^-1 g~ = D^-1 H^-1 g.
-const MatrixXd& TO::EvalHinvJTg(const TrajectoryOptimizerState<T>& s) const {
+// H^-1 g_merit with the unscaled H, where g_merit = g + J^T lambda (g when there are no equality
+// constraints).  Everything the iteration needs from a factorisation of the scaled H~ = D H D
+// follows from it:  H~^-1 g~_merit = D^-1 H^-1 g_merit.
+const VectorXd& TO::EvalHinvMeritGradient(const TrajectoryOptimizerState<T>& s) const {
   auto& c = s.cache_;
+  if (params_.equality_constraints && num_equality_constraints() > 0) {
+    EvalLagrangeMultipliers(s);
+    return c.Hinv_gm;
+  }
   if (!c.hinv) {
     const Vec& g = EvalGradient(s);
-    const int neq = params_.equality_constraints ? num_equality_constraints() : 0, n = num_vars();
-    MatrixXd rhs(n, neq + 1);
-    if (neq > 0) {
-      EvalEqualityConstraintJacobian(s);
-      for (int r = 0; r < neq; ++r)
-        for (int col = 0; col < n; ++col) rhs(col, r) = c.J_unscaled(r, col);
-    }
-    for (int i = 0; i < n; ++i) rhs(i, neq) = g[i];
     EnsureDevice(s, 3);
-    c.Hinv_JT_g = MatrixXd(n, neq + 1);
-    Scope prof_("device solve H^-1[J^T|g]");
-    Check(idto_hip_solve_host(hip_, rhs.data(), neq + 1, c.Hinv_JT_g.data()));
+    c.Hinv_gm.resize(g.size());
+    Scope prof_("device solve H^-1 g");
+    Check(idto_hip_solve_host(hip_, g.data(), 1, c.Hinv_gm.data()));
     c.hinv = true;
   }
-  return c.Hinv_JT_g;
+  return c.Hinv_gm;
 }
 
-// TO.cc:1371-1396 : lambda = (J~ H~^-1 J~^T)^-1 (h - J~ H~^-1 g~) = (J H^-1 J^T)^-1 (h - J H^-1 g)
+// TO.cc:1371-1396 : lambda = (J~ H~^-1 J~^T)^-1 (h - J~ H~^-1 g~) = (J H^-1 J^T)^-1 (h - J H^-1 g).
+// The n_eq + 1 solves with H, the Schur complement S = J H^-1 J^T and J H^-1 g are formed on the
+// device from the dtau/dq blocks already there (idto_hip_constraint_schur); the host factorises
+// the small dense S; the device then combines H^-1 (g + J^T lambda) and J^T lambda
+// (idto_hip_constraint_step), which the dogleg step and the merit gradient use.
 const VectorXd& TO::EvalLagrangeMultipliers(const TrajectoryOptimizerState<T>& s) const {
   auto& c = s.cache_;
+  if (!c.lambda && num_equality_constraints() == 0) {  // fully actuated model: nothing to enforce
+    c.lambda_v.clear();
+    c.JT_lambda.assign((std::size_t)num_vars(), 0.0);
+    c.lambda = true;
+  }
   if (!c.lambda) {
     const Vec& h = EvalEqualityConstraintViolations(s);
-    const MatrixXd& Y = EvalHinvJTg(s);
-    EvalEqualityConstraintJacobian(s);
+    EvalGradient(s);
+    EnsureDevice(s, 3);
     const int neq = num_equality_constraints(), nu = (int)unactuated_dofs_.size();
-    Scope prof_("lambda: J Y + dense LDLT");
-    std::vector<double> S((std::size_t)neq * neq, 0.0);
+    std::vector<double> S((std::size_t)neq * neq);
     Vec rhs((std::size_t)neq);
-    Vec jr((std::size_t)3 * nq_);
-    for (int r = 0; r < neq; ++r) {
-      // row r of J is non-zero only in the three blocks around its time step: gather it once,
-      // then every column of Y contributes a short contiguous dot product.  S = J H^-1 J^T is
-      // symmetric: only the lower triangle (col <= r) is formed, which is all the LDL^T reads.
-      const int t = r / nu;
-      const int c0 = std::max(0, (t - 1) * nq_), c1 = (t + 2) * nq_, len = c1 - c0;
-      for (int kq = 0; kq < len; ++kq) jr[kq] = c.J_unscaled(r, c0 + kq);
-      for (int col = 0; col <= r; ++col)
-        S[(std::size_t)col * neq + r] = Dot4(jr.data(), Y.data() + (std::size_t)col * num_vars() + c0, len);
-      rhs[r] = h[r] - Dot4(jr.data(), Y.data() + (std::size_t)neq * num_vars() + c0, len);
-    }
     {
-      Scope prof2_("  dense LDLT");
+      Scope prof_("device: H^-1[g|J^T], S = J Y");
+      Check(idto_hip_constraint_schur(hip_, unactuated_dofs_.data(), nu, S.data(), rhs.data()));
+    }
+    for (int r = 0; r < neq; ++r) rhs[r] = h[r] - rhs[r];
+    {
+      Scope prof_("dense LDLT (host)");
       DenseLdltSolve(&S, neq, rhs.data());
     }
     c.lambda_v = rhs;
+    c.Hinv_gm.resize((std::size_t)num_vars());
+    c.JT_lambda.resize((std::size_t)num_vars());
+    {
+      Scope prof_("device: H^-1(g+J^T l), J^T l");
+      Check(idto_hip_constraint_step(hip_, c.lambda_v.data(), c.Hinv_gm.data(), c.JT_lambda.data()));
+    }
     c.lambda = true;
   }
   return c.lambda_v;
@@ -524,15 +570,11 @@ const VectorXd& TO::EvalMeritFunctionGradient(const TrajectoryOptimizerState<T>&
   auto& c = s.cache_;
   if (!c.mgrad) {
     const Vec& g = EvalScaledGradient(s);
-    const Vec& lam = EvalLagrangeMultipliers(s);
-    const MatrixXd& J = EvalEqualityConstraintJacobian(s);
-    const int neq = num_equality_constraints();
+    EvalLagrangeMultipliers(s);  // also leaves J^T lambda (unscaled J); J~^T lambda = D J^T lambda
+    const Vec* D = params_.scaling ? &EvalScaleFactors(s) : nullptr;
     c.merit_gradient.resize((std::size_t)num_vars());
-    for (int col = 0; col < num_vars(); ++col) {
-      double acc = 0;
-      for (int r = 0; r < neq; ++r) acc += J(r, col) * lam[r];
-      c.merit_gradient[col] = g[col] + acc;
-    }
+    for (int col = 0; col < num_vars(); ++col)
+      c.merit_gradient[col] = g[col] + (D ? (*D)[col] * c.JT_lambda[col] : c.JT_lambda[col]);
     c.mgrad = true;
   }
   return c.merit_gradient;
@@ -576,17 +618,11 @@ bool TO::CalcDoglegPoint(const TrajectoryOptimizerState<T>& s, double Delta, Vec
   H.MultiplyBy(g, &Hg);
   const double gHg = Dot(g, Hg);
   // pH = H~^-1 (-g~_merit / Delta) from the cached device solve (:2139-2149)
-  const MatrixXd& Y = EvalHinvJTg(s);
-  const int neq = params_.equality_constraints ? num_equality_constraints() : 0;
+  const Vec& y = EvalHinvMeritGradient(s);
   Vec pH((std::size_t)n);
   {
-    const Vec* lam = neq ? &EvalLagrangeMultipliers(s) : nullptr;
     const Vec* D = params_.scaling ? &EvalScaleFactors(s) : nullptr;
-    for (int i = 0; i < n; ++i) {
-      double acc = Y(i, neq);
-      for (int r = 0; r < neq; ++r) acc += Y(i, r) * (*lam)[r];
-      pH[i] = -(D ? acc / (*D)[i] : acc) / Delta;
-    }
+    for (int i = 0; i < n; ++i) pH[i] = -(D ? y[i] / (*D)[i] : y[i]) / Delta;
   }
   dqH->resize((std::size_t)n);
   for (int i = 0; i < n; ++i) (*dqH)[i] = pH[i] * Delta;  // :2152

@@ -15,6 +15,7 @@
 #include "kernels.h"
 #include "penta_ldl.h"
 #include "penta_apply.h"
+#include "constraints.h"
 
 using namespace idto_dev;
 
@@ -83,6 +84,12 @@ struct idto_hip_ctx {
   double *stage_rhs = nullptr, *stage_x = nullptr;  // idto_hip_solve_host
   double* pack = nullptr;                            // [tau | cost] of idto_hip_trial_cost (device)
   double* pin = nullptr;                             // pinned host staging: q in, [tau | cost] out
+  // equality-constraint step (constraints.h)
+  int* con_dofs = nullptr; int con_nu = 0, con_neq = 0;
+  std::vector<int> con_dofs_host;
+  double *con_S = nullptr, *con_lambda = nullptr, *con_out = nullptr;  // device: [S | J y_g], lambda, [step | J^T lambda]
+  double* con_pin = nullptr; size_t con_pin_count = 0;                 // pinned host staging for the above
+  bool con_ready = false;                                              // stage_x holds H^-1 [g | J^T] of the current H
   size_t stage_count = 0;
   std::vector<hipEvent_t> event_pool;  // recycled: creating events in the timed loop costs host time
   double tsum[3] = {0, 0, 0};
@@ -307,6 +314,14 @@ int TimeDrain(idto_hip_ctx* c) {
   return 0;
 }
 
+int EnsureStage(idto_hip_ctx* c, size_t count) {
+  if (count > c->stage_count) {  // staging buffers grow on demand and are reused
+    double *a = nullptr, *b = nullptr;
+    if (Alloc(c, count, &a) || Alloc(c, count, &b)) return -2;
+    c->stage_rhs = a; c->stage_x = b; c->stage_count = count;
+  }
+  return 0;
+}
 }  // namespace
 
 extern "C" {
@@ -422,6 +437,7 @@ void idto_hip_destroy(idto_hip_ctx* c) {
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->pin) (void)hipHostFree(c->pin);
+  if (c->con_pin) (void)hipHostFree(c->con_pin);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -430,6 +446,7 @@ int idto_hip_set_problem(idto_hip_ctx* c, const idto_problem_t* p) {
   if (p->num_steps != c->N || p->time_step != c->dt) { g_err = "num_steps / time_step cannot change"; return -1; }
   HIP_OK(hipSetDevice(c->device));
   c->fd_full = false;  // v_0 = v_init
+  c->con_ready = false;
   return UploadProblemArrays(c, p, false);
 }
 
@@ -450,6 +467,7 @@ int idto_hip_set_shard(idto_hip_ctx* c, int kb, int ke) {
 int idto_hip_set_q(idto_hip_ctx* c, const double* q_host) {
   HIP_OK(hipSetDevice(c->device));
   c->fd_full = false;
+  c->con_ready = false;
   HIP_OK(hipMemcpyAsync(c->q, q_host, (size_t)(c->N + 1) * c->nq * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIP_OK(hipStreamSynchronize(c->stream));  // the host buffer may be reused by the caller
   return 0;
@@ -457,6 +475,7 @@ int idto_hip_set_q(idto_hip_ctx* c, const double* q_host) {
 int idto_hip_set_q_device(idto_hip_ctx* c, const double* q_dev) {
   HIP_OK(hipSetDevice(c->device));
   c->fd_full = false;
+  c->con_ready = false;
   HIP_OK(hipMemcpyAsync(c->q, q_dev, (size_t)(c->N + 1) * c->nq * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   return 0;
 }
@@ -483,6 +502,7 @@ int idto_hip_trial_cost(idto_hip_ctx* c, const double* q_host, double* tau_host,
   // inverse-dynamics evaluations, the cost, and [tau | cost] back in one copy
   std::memcpy(c->pin, q_host, nq_all * sizeof(double));
   c->fd_full = false;
+  c->con_ready = false;
   HIP_OK(hipMemcpyAsync(c->q, c->pin, nq_all * sizeof(double), hipMemcpyHostToDevice, c->stream));
   int rc = LaunchFd(c, 0, 0, c->N);
   if (rc) return rc;
@@ -499,6 +519,7 @@ int idto_hip_trial_cost(idto_hip_ctx* c, const double* q_host, double* tau_host,
 
 int idto_hip_eval_partials(idto_hip_ctx* c) {
   HIP_OK(hipSetDevice(c->device));
+  c->con_ready = false;
   if (TimeBegin(c, 0)) return -2;
   int rc = LaunchFd(c, 1, c->k_begin, c->k_end);
   if (rc) return rc;
@@ -508,6 +529,7 @@ int idto_hip_eval_partials(idto_hip_ctx* c) {
 
 int idto_hip_grad_hess(idto_hip_ctx* c) {
   HIP_OK(hipSetDevice(c->device));
+  c->con_ready = false;
   if (TimeBegin(c, 1)) return -2;
   if (c->weights_diagonal)
     hipLaunchKernelGGL(assemble_diag_kernel, dim3(c->N + 1, 4), dim3(256), c->asm_diag_lds, c->stream, c->M, c->P, c->q,
@@ -603,10 +625,11 @@ int idto_hip_factor_solve(idto_hip_ctx* c, const double* rhs, int nrhs, double* 
     }
     return 0;
   }
-  // block LDL^T: factorise once with the first right-hand side (one workgroup; the two-sided
-  // variant leaves factors of the mirrored recursion that the substitution kernel does not use) ...
+  // block LDL^T: factorise once with the first right-hand side (two-sided when the horizon is
+  // long enough; the substitution kernel walks both chains of factors) ...
   const int K = (k == 2 || k == 3 || k == 5 || k == 19 || k == 23) ? k : (k <= 8 ? 8 : k <= 16 ? 16 : k <= 24 ? 24 : 32);
-  int rc = LaunchLdl(c, b, rhs ? 1.0 : -1.0, 1, xo, /*one_sided=*/nrhs > 1);
+  int rc = LaunchLdl(c, b, rhs ? 1.0 : -1.0, 1, xo);
+  const int m_split = (c->two_sided && n >= 10) ? (n - 1) / 2 : 0;  // as LaunchLdl chose
   if (rc) return rc;
   if (nrhs > 1) {
     // ... then substitute the other right-hand sides in parallel: one wavefront each
@@ -616,7 +639,7 @@ int idto_hip_factor_solve(idto_hip_ctx* c, const double* rhs, int nrhs, double* 
     double* x1 = xo + (size_t)n * k;
 #define APPLY_LAUNCH(KM)                                                                                          \
     hipLaunchKernelGGL(penta_apply_kernel<KM>, dim3(blocks), dim3(64 * waves), lds, c->stream, n, k, c->Ust, c->Hst, \
-                       c->Est, c->Dst, b1, rhs ? 1.0 : -1.0, nrhs - 1, x1)
+                       c->Est, c->Dst, b1, rhs ? 1.0 : -1.0, nrhs - 1, x1, m_split)
     switch (K) {
       case 2: APPLY_LAUNCH(2); break;
       case 3: APPLY_LAUNCH(3); break;
@@ -638,16 +661,75 @@ int idto_hip_solve_host(idto_hip_ctx* c, const double* rhs_host, int nrhs, doubl
   HIP_OK(hipSetDevice(c->device));
   if (!rhs_host || !x_host || nrhs < 1) { g_err = "solve_host: bad arguments"; return -1; }
   const size_t count = (size_t)nrhs * (c->N + 1) * c->nq;
-  if (count > c->stage_count) {  // staging buffers grow on demand and are reused
-    double *a = nullptr, *b = nullptr;
-    if (Alloc(c, count, &a) || Alloc(c, count, &b)) return -2;
-    c->stage_rhs = a; c->stage_x = b; c->stage_count = count;
-  }
+  if (EnsureStage(c, count)) return -2;
+  c->con_ready = false;  // the staging buffers are shared with the constraint step
   HIP_OK(hipMemcpyAsync(c->stage_rhs, rhs_host, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
   int rc = idto_hip_factor_solve(c, c->stage_rhs, nrhs, c->stage_x);
   if (rc) return rc;
   HIP_OK(hipMemcpyAsync(x_host, c->stage_x, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_OK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int idto_hip_constraint_schur(idto_hip_ctx* c, const int* dofs, int nu, double* S_host, double* Jy_host) {
+  HIP_OK(hipSetDevice(c->device));
+  if (!dofs || nu < 1 || nu > c->nv || !S_host || !Jy_host) { g_err = "constraint_schur: bad arguments"; return -1; }
+  for (int j = 0; j < nu; ++j)
+    if (dofs[j] < 0 || dofs[j] >= c->nv) { g_err = "constraint_schur: dof index out of range"; return -1; }
+  const int N = c->N, n = (N + 1) * c->nq, neq = nu * N;
+  if (c->con_nu != nu || !std::equal(dofs, dofs + nu, c->con_dofs_host.begin())) {
+    c->con_dofs_host.assign(dofs, dofs + nu);
+    void* p = nullptr;
+    HIP_OK(hipMalloc(&p, (size_t)nu * sizeof(int)));
+    c->allocs.push_back(p);
+    c->con_dofs = static_cast<int*>(p);
+    HIP_OK(hipMemcpy(c->con_dofs, dofs, (size_t)nu * sizeof(int), hipMemcpyHostToDevice));
+    if (Alloc(c, (size_t)neq * neq + neq, &c->con_S) || Alloc(c, (size_t)neq, &c->con_lambda) ||
+        Alloc(c, (size_t)2 * n, &c->con_out))
+      return -2;
+    const size_t need = (size_t)neq * neq + neq + 2 * (size_t)n + neq;
+    if (c->con_pin) (void)hipHostFree(c->con_pin);
+    c->con_pin = nullptr;
+    HIP_OK(hipHostMalloc((void**)&c->con_pin, need * sizeof(double), hipHostMallocDefault));
+    c->con_pin_count = need;
+    c->con_nu = nu; c->con_neq = neq;
+  }
+  c->con_ready = false;
+  if (EnsureStage(c, (size_t)(neq + 1) * n)) return -2;
+  hipLaunchKernelGGL(constraint_rhs_kernel, dim3(neq + 1), dim3(256), 0, c->stream, c->slab, c->slab_stride, c->g,
+                     c->con_dofs, nu, N, c->nq, c->nv, c->stage_rhs);
+  HIP_OK(hipGetLastError());
+  int rc = idto_hip_factor_solve(c, c->stage_rhs, neq + 1, c->stage_x);
+  if (rc) return rc;
+  hipLaunchKernelGGL(constraint_schur_kernel, dim3(neq), dim3(256), 3 * c->nq * sizeof(double), c->stream, c->slab,
+                     c->slab_stride, c->con_dofs, nu, N, c->nq, c->nv, c->stage_x, neq, c->con_S,
+                     c->con_S + (size_t)neq * neq);
+  HIP_OK(hipGetLastError());
+  const size_t count = (size_t)neq * neq + neq;
+  HIP_OK(hipMemcpyAsync(c->con_pin, c->con_S, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  std::memcpy(S_host, c->con_pin, (size_t)neq * neq * sizeof(double));
+  std::memcpy(Jy_host, c->con_pin + (size_t)neq * neq, (size_t)neq * sizeof(double));
+  c->con_ready = true;
+  return 0;
+}
+
+int idto_hip_constraint_step(idto_hip_ctx* c, const double* lambda_host, double* step_host, double* jtl_host) {
+  HIP_OK(hipSetDevice(c->device));
+  if (!c->con_ready) { g_err = "constraint_step: call idto_hip_constraint_schur for the current Hessian first"; return -1; }
+  if (!lambda_host || !step_host || !jtl_host) { g_err = "constraint_step: bad arguments"; return -1; }
+  const int N = c->N, n = (N + 1) * c->nq, neq = c->con_neq;
+  double* pl = c->con_pin + (size_t)neq * neq + neq;  // [lambda | step | J^T lambda]
+  std::memcpy(pl, lambda_host, (size_t)neq * sizeof(double));
+  HIP_OK(hipMemcpyAsync(c->con_lambda, pl, (size_t)neq * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(constraint_step_kernel, dim3((n + 63) / 64), dim3(64), neq * sizeof(double), c->stream, c->slab,
+                     c->slab_stride, c->con_dofs, c->con_nu, N, c->nq, c->nv, c->stage_x, neq, c->con_lambda, c->con_out,
+                     c->con_out + n);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpyAsync(pl + neq, c->con_out, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  std::memcpy(step_host, pl + neq, (size_t)n * sizeof(double));
+  std::memcpy(jtl_host, pl + neq + n, (size_t)n * sizeof(double));
   return 0;
 }
 

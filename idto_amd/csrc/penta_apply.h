@@ -1,5 +1,5 @@
 // penta_apply.h — solves H X = R for MANY right-hand sides with the block LDL^T factors that
-// penta_ldl_kernel (one workgroup, one-sided) left in HBM: one wavefront per right-hand side,
+// penta_ldl_kernel (one- or two-sided) left in HBM: one wavefront per right-hand side,
 // as many workgroups as needed, no synchronisation between them.  This is the path of
 // CalcLagrangeMultipliers (reference optimizer/trajectory_optimizer.cc:1371-1396: H^-1 J^T, one
 // column per equality constraint, 120-240 columns for the example models): the factorisation is
@@ -26,7 +26,7 @@ template <int K>
 __global__ void __launch_bounds__(256)
 penta_apply_kernel(int n, int k, const double* __restrict__ Ust, const double* __restrict__ Hst,
                    const double* __restrict__ Est, const double* __restrict__ Dst, const double* __restrict__ rhs,
-                   double rhs_sign, int nrhs, double* __restrict__ x) {
+                   double rhs_sign, int nrhs, double* __restrict__ x, int m_split) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.x * (blockDim.x >> 6) + wave;
@@ -35,61 +35,94 @@ penta_apply_kernel(int n, int k, const double* __restrict__ Ust, const double* _
   const size_t nk = (size_t)n * k;
   const int c = (lane < K) ? lane : K - 1;  // lanes >= K shadow lane K-1 (never stored)
   const bool live = lane < K;
-  double* rtw = lds + (size_t)wave * n * K;  // rt_i[c] of this right-hand side, all rows
+  double* rtw = lds + (size_t)wave * n * K;  // rt_i[c] of this right-hand side, all rows (original index)
+  // Two-sided factors (m_split > 0, see penta_ldl_kernel): block rows 0 .. m+1 belong to the
+  // top-down recursion (rows m, m+1 are the join), rows n-1 .. m+2 to the mirrored bottom-up one,
+  // whose local row il is original row n-1-il.  One wavefront walks both chains one after the
+  // other; the bottom chain's pending pushes enter the join rows, x_m and x_{m+1} start its
+  // back substitution.
+  const bool two = m_split > 0;
+  const int nT = two ? m_split + 2 : n, nB = two ? n - m_split - 2 : 0;
 
-  // ---- forward substitution
-  double pend1 = 0.0, pend2 = 0.0;  // pushed into rows i+1 (pend1) and i+2 (pend2)
-  for (int i = 0; i < n; ++i) {
-    const double* U = Ust + (size_t)i * KS2 + c;
-    const double* Hh = Hst + (size_t)i * KS2 + c;
-    const double* Ee = Est + (size_t)i * KS2 + c;
-    double u[K], h[K], e[K];
+  // ---- forward substitution over local rows [first, last) of one chain
+  auto forward = [&](int side, int first, int last, double& pend1, double& pend2) {
+    for (int il = first; il < last; ++il) {
+      const int i = side ? n - 1 - il : il;
+      const double* U = Ust + (size_t)i * KS2 + c;
+      const double* Hh = Hst + (size_t)i * KS2 + c;
+      const double* Ee = Est + (size_t)i * KS2 + c;
+      double u[K], h[K], e[K];
 #pragma unroll
-    for (int jj = 0; jj < K; ++jj) { u[jj] = U[jj * ks]; h[jj] = Hh[jj * ks]; e[jj] = Ee[jj * ks]; }
-    double v = ((c < k) ? rhs_sign * rhs[(size_t)j * nk + (size_t)i * k + c] : 0.0) + pend1;
-    double a1 = pend2, a2 = 0.0;
+      for (int jj = 0; jj < K; ++jj) { u[jj] = U[jj * ks]; h[jj] = Hh[jj * ks]; e[jj] = Ee[jj * ks]; }
+      double v = ((c < k) ? rhs_sign * rhs[(size_t)j * nk + (size_t)i * k + c] : 0.0) + pend1;
+      double a1 = pend2, a2 = 0.0;
 #pragma unroll
-    for (int jj = 0; jj < K; ++jj) {
-      const double t = rdlane(v, jj);       // rt_i[jj]: final once the steps before it are done
-      v = __builtin_fma(-u[jj], t, v);      // L[c][jj] = (D^-1 U)[jj][c], zero for c <= jj
-      a1 = __builtin_fma(-h[jj], t, a1);    // (Ht_i^T Dn rt_i)[c]
-      a2 = __builtin_fma(-e[jj], t, a2);    // (Et_i^T Dn rt_i)[c]
+      for (int jj = 0; jj < K; ++jj) {
+        const double t = rdlane(v, jj);       // rt_i[jj]: final once the steps before it are done
+        v = __builtin_fma(-u[jj], t, v);      // L[c][jj] = (D^-1 U)[jj][c], zero for c <= jj
+        a1 = __builtin_fma(-h[jj], t, a1);    // (Ht_i^T Dn rt_i)[c]
+        a2 = __builtin_fma(-e[jj], t, a2);    // (Et_i^T Dn rt_i)[c]
+      }
+      if (live) rtw[i * K + lane] = v;
+      pend1 = a1;  // pushed into the next row of the chain
+      pend2 = a2;  // and the one after it
     }
-    if (live) rtw[i * K + lane] = v;
-    pend1 = a1;
-    pend2 = a2;
+  };
+  double p1 = 0.0, p2 = 0.0;
+  forward(0, 0, two ? m_split : n, p1, p2);
+  if (two) {
+    double q1 = 0.0, q2 = 0.0;
+    forward(1, 0, nB, q1, q2);
+    p1 += q2;  // the bottom chain's "row nB + 1" is original row m, its "row nB" is row m+1
+    p2 += q1;
+    forward(0, m_split, nT, p1, p2);
   }
 
-  // ---- back substitution
+  // ---- back substitution over local rows first, first-1, .., 0 of one chain
   // v: pending right-hand side of the row being solved; p: what has been pushed so far into the
-  // row after it (-(D^-1 Et_{i-1}) x_{i+1}, pushed one iteration earlier)
+  // row after it (-(D^-1 Et_{i-1}) x_{i+1}, pushed one iteration earlier).  `given` leading rows
+  // are already solved (the join rows, seen from the bottom chain): they only push.
   const int r = c;
-  double v = Dst[(size_t)(n - 1) * K + r] * rtw[(n - 1) * K + r];
-  double p = 0.0;
-  for (int i = n - 1; i >= 0; --i) {
-    const double2* pu = reinterpret_cast<const double2*>(Ust + (size_t)i * KS2 + r * ks);
-    const double2* ph = reinterpret_cast<const double2*>(Hst + (size_t)(i > 0 ? i - 1 : 0) * KS2 + r * ks);
-    const double2* pe = reinterpret_cast<const double2*>(Est + (size_t)(i > 1 ? i - 2 : 0) * KS2 + r * ks);
-    double2 U2[KP], H2[KP], E2[KP];
+  double xm = 0.0, xm1 = 0.0;  // x_m, x_{m+1} (join rows)
+  auto backward = [&](int side, int first, int given) {
+    auto o = [&](int il) { const int t = side ? n - 1 - il : il; return t < 0 ? 0 : (t > n - 1 ? n - 1 : t); };
+    double v = given ? xm : Dst[(size_t)o(first) * K + r] * rtw[o(first) * K + r];
+    double p = 0.0;
+    for (int il = first; il >= 0; --il) {
+      const bool solved = il > first - given;
+      const double2* pu = reinterpret_cast<const double2*>(Ust + (size_t)o(il) * KS2 + r * ks);
+      const double2* ph = reinterpret_cast<const double2*>(Hst + (size_t)o(il > 0 ? il - 1 : 0) * KS2 + r * ks);
+      const double2* pe = reinterpret_cast<const double2*>(Est + (size_t)o(il > 1 ? il - 2 : 0) * KS2 + r * ks);
+      double2 U2[KP], H2[KP], E2[KP];
 #pragma unroll
-    for (int m = KP - 1; m >= 0; --m) { U2[m] = pu[m]; H2[m] = ph[m]; E2[m] = pe[m]; }
-    const double hs = (i > 0) ? -1.0 : 0.0, es = (i > 1) ? -1.0 : 0.0;  // rows -1, -2 do not exist
-    const double next_rt = (i > 0) ? Dst[(size_t)(i - 1) * K + r] * rtw[(i - 1) * K + r] : 0.0;
-    double pn = 0.0;
+      for (int m = KP - 1; m >= 0; --m) { U2[m] = pu[m]; H2[m] = ph[m]; E2[m] = pe[m]; }
+      // rows -1, -2 do not exist; the join rows are not coupled THROUGH THIS CHAIN to each other
+      const double hs = (il > 0 && !(given && il == first)) ? -1.0 : 0.0, es = (il > 1) ? -1.0 : 0.0;
+      const double us = solved ? 0.0 : 1.0;
+      const double next_rt = (il > 0) ? Dst[(size_t)o(il - 1) * K + r] * rtw[o(il - 1) * K + r] : 0.0;
+      double pn = 0.0;
 #pragma unroll
-    for (int jj = K - 1; jj >= 0; --jj) {
-      const double xj = rdlane(v, jj);
-      const double ujj = (jj & 1) ? U2[jj / 2].y : U2[jj / 2].x;
-      const double hjj = (jj & 1) ? H2[jj / 2].y : H2[jj / 2].x;
-      const double ejj = (jj & 1) ? E2[jj / 2].y : E2[jj / 2].x;
-      v = __builtin_fma(-ujj, xj, v);       // strictly upper: rows >= jj keep their value
-      p = __builtin_fma(hjj * hs, xj, p);   // row i-1: -(D^-1 Ht_{i-1}) x_i
-      pn = __builtin_fma(ejj * es, xj, pn); // row i-2: -(D^-1 Et_{i-2}) x_i
+      for (int jj = K - 1; jj >= 0; --jj) {
+        const double xj = rdlane(v, jj);
+        const double ujj = (jj & 1) ? U2[jj / 2].y : U2[jj / 2].x;
+        const double hjj = (jj & 1) ? H2[jj / 2].y : H2[jj / 2].x;
+        const double ejj = (jj & 1) ? E2[jj / 2].y : E2[jj / 2].x;
+        v = __builtin_fma(-(ujj * us), xj, v); // strictly upper: rows >= jj keep their value
+        p = __builtin_fma(hjj * hs, xj, p);    // row il-1: -(D^-1 Ht_{il-1}) x_il
+        pn = __builtin_fma(ejj * es, xj, pn);  // row il-2: -(D^-1 Et_{il-2}) x_il
+      }
+      if (!solved) {
+        if (live && lane < k) x[(size_t)j * nk + (size_t)o(il) * k + lane] = v;
+        if (two && !side && il == m_split + 1) xm1 = v;
+        if (two && !side && il == m_split) xm = v;
+      }
+      const bool next_given = il - 1 > first - given;  // (the second join row: what was pushed into it is not needed)
+      v = next_given ? xm1 : next_rt + p;
+      p = pn;
     }
-    if (live && lane < k) x[(size_t)j * nk + (size_t)i * k + lane] = v;
-    v = next_rt + p;
-    p = pn;
-  }
+  };
+  backward(0, nT - 1, 0);
+  if (two) backward(1, nB + 1, 2);
 }
 
 }  // namespace idto_dev

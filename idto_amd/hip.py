@@ -56,6 +56,10 @@ def lib():
             getattr(L, "idto_hip_" + f).argtypes = [C.c_void_p]
         L.idto_hip_factor_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.idto_hip_solve_host.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double)]
+        L.idto_hip_constraint_schur.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double),
+                                                C.POINTER(C.c_double)]
+        L.idto_hip_constraint_step.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                               C.POINTER(C.c_double)]
         L.idto_hip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.idto_hip_timing_enable.argtypes = [C.c_void_p, C.c_int]
         L.idto_hip_timing_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -72,7 +76,8 @@ def lib():
 
 EXPORTED_SYMBOLS = [
     "idto_hip_last_error", "idto_hip_create", "idto_hip_destroy", "idto_hip_set_problem", "idto_hip_set_stream",
-    "idto_hip_get_stream", "idto_hip_set_shard", "idto_hip_set_q", "idto_hip_set_q_device", "idto_hip_eval_tau", "idto_hip_trial_cost",
+    "idto_hip_get_stream", "idto_hip_set_shard", "idto_hip_set_q", "idto_hip_set_q_device", "idto_hip_eval_tau", "idto_hip_trial_cost", "idto_hip_constraint_schur",
+    "idto_hip_constraint_step",
     "idto_hip_eval_partials", "idto_hip_grad_hess", "idto_hip_factor_solve", "idto_hip_gn_step", "idto_hip_solve_host",
     "idto_hip_set_option",
     "idto_hip_timing_enable", "idto_hip_timing_reset", "idto_hip_timing_get", "idto_hip_sync", "idto_hip_get",
@@ -142,6 +147,23 @@ class HipPath:
     # ---- path pieces (asynchronous on the context's stream)
     def eval_tau(self):
         _chk(lib().idto_hip_eval_tau(self.h))
+
+    def constraint_schur(self, dofs):
+        """S = J H^-1 J^T (n_eq x n_eq) and J H^-1 g for the constraint tau_t[dofs] = 0 (after grad_hess)"""
+        dofs = np.ascontiguousarray(np.asarray(dofs, dtype=np.int32))
+        neq = dofs.size * self.N
+        S, Jy = np.empty((neq, neq), order="F"), np.empty(neq)
+        _chk(lib().idto_hip_constraint_schur(self.h, dofs.ctypes.data_as(C.POINTER(C.c_int)), int(dofs.size),
+                                             S.ctypes.data_as(C.POINTER(C.c_double)), dptr(Jy)))
+        return S, Jy
+
+    def constraint_step(self, lam):
+        """H^-1 (g + J^T lambda) and J^T lambda, from the factors kept by constraint_schur"""
+        lam = np.ascontiguousarray(np.asarray(lam, dtype=np.float64))
+        n = (self.N + 1) * self.nq
+        step, jtl = np.empty(n), np.empty(n)
+        _chk(lib().idto_hip_constraint_step(self.h, dptr(lam), dptr(step), dptr(jtl)))
+        return step, jtl
 
     def trial_cost(self, q):
         """upload q, evaluate tau and the cost, return (tau (N, nv), cost) with one synchronisation"""

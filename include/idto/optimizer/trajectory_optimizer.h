@@ -115,7 +115,7 @@ class TrajectoryOptimizer<double> {
   void CalcVelocityPartials(const TrajectoryOptimizerState<T>& state) const;
   void CalcDerivatives(const TrajectoryOptimizerState<T>& state) const;
   void CalcGradHess(const TrajectoryOptimizerState<T>& state) const;
-  const MatrixXd& EvalHinvJTg(const TrajectoryOptimizerState<T>& state) const;
+  const VectorXd& EvalHinvMeritGradient(const TrajectoryOptimizerState<T>& state) const;
   void NormalizeQuaternions(TrajectoryOptimizerState<T>* state) const;
   void AdoptTrialPoint(const TrajectoryOptimizerState<T>& scratch, TrajectoryOptimizerState<T>* state) const;
   ConvergenceReason VerifyConvergenceCriteria(const TrajectoryOptimizerState<T>& state, T previous_cost,

@@ -67,7 +67,8 @@ class TrajectoryOptimizerState {
     std::vector<T> gradient, scale_factors, scaled_gradient, h_viol, lambda_v, merit_gradient;
     PentaDiagonalMatrix<T> hessian, scaled_hessian;
     MatrixXd J_unscaled, J_scaled;  // num_eq x num_vars; J~ = J D when scaling is on
-    MatrixXd Hinv_JT_g;             // H^-1 [J^T | g] (unscaled H, unscaled J): num_vars x (num_eq + 1)
+    std::vector<T> Hinv_gm;         // H^-1 (g + J^T lambda) with the unscaled H and J (H^-1 g without constraints)
+    std::vector<T> JT_lambda;       // J^T lambda (unscaled J)
     T merit_v = 0;
   };
   void invalidate_cache() {

@@ -108,6 +108,19 @@ int idto_hip_gn_step(idto_hip_ctx* ctx);
  * (optimizer/trajectory_optimizer.cc:1371-1396) and CalcDoglegPoint (:2108-2202). */
 int idto_hip_solve_host(idto_hip_ctx* ctx, const double* rhs_host, int nrhs, double* x_host);
 
+/* Equality-constraint step of the trust-region iteration, kept on the device (reference
+ * CalcEqualityConstraintJacobian / CalcLagrangeMultipliers, optimizer/trajectory_optimizer.cc:
+ * 1292-1396, and the H^-1 (g + J^T lambda) of CalcDoglegPoint :2139-2149).  The constraint is
+ * h(q) = [tau_t[dof] : t < N, dof in `dofs`] (the unactuated dofs, :1267-1290); its Jacobian J
+ * consists of rows of the dtau/dq blocks already in device memory.
+ *   idto_hip_constraint_schur: after idto_hip_grad_hess, solves H Y = [g | J^T] (n_eq + 1
+ *     columns, n_eq = nu * N) and returns S = J H^-1 J^T (n_eq x n_eq, column-major) and
+ *     J H^-1 g (n_eq) to host memory; Y stays on the device.
+ *   idto_hip_constraint_step: given the multipliers lambda (n_eq, host) returns
+ *     H^-1 (g + J^T lambda) and J^T lambda (both (N+1)*nq) to host memory. */
+int idto_hip_constraint_schur(idto_hip_ctx* ctx, const int* dofs, int nu, double* S_host, double* Jy_host);
+int idto_hip_constraint_step(idto_hip_ctx* ctx, const double* lambda_host, double* step_host, double* jtl_host);
+
 /* Options: "gradients_method" = 0 forward differences (default), 1 / 2 central differences of
  * 2nd / 4th order (SolverParameters::gradients_method, reference solver_parameters.h:26-50,
  * trajectory_optimizer.cc:565-885); 3 (autodiff) is refused.  "reference_solver" = 1 selects the bit-exact restatement of the reference's
