@@ -722,11 +722,126 @@ ConvergenceReason TO::VerifyConvergenceCriteria(const TrajectoryOptimizerState<T
 SolverFlag TO::Solve(const std::vector<VectorXd>& q_guess, TrajectoryOptimizerSolution<T>* solution,
                      TrajectoryOptimizerStats<T>* stats, ConvergenceReason* reason) const {
   if (!stats->is_empty()) throw std::runtime_error("Solve: stats must be empty (TO.cc:2225)");
-  if (params_.method != kTrustRegion)
-    throw std::runtime_error("Solve (HIP): only method = kTrustRegion is implemented on the device path");
   if ((int)q_guess.size() != num_steps() + 1) throw std::runtime_error("Solve: q_guess has the wrong length");
+  if (params_.method == kLinesearch) return SolveWithLinesearch(q_guess, solution, stats);
   std::unique_ptr<WarmStart> ws = CreateWarmStart(q_guess);
   return SolveFromWarmStart(ws.get(), solution, stats, reason);
+}
+
+// TO.cc:1931-1977
+std::pair<double, int> TO::ArmijoLinesearch(const TrajectoryOptimizerState<T>& s, const VectorXd& dq,
+                                            TrajectoryOptimizerState<T>* scratch) const {
+  const double L = EvalCost(s);
+  const Vec& g = EvalGradient(s);
+  const double c = 1e-4, rho = 0.8;
+  double alpha = 1.0 / rho;
+  const double L_prime = Dot(g, dq);
+  if (!(L_prime <= 0)) throw std::runtime_error("linesearch: not a descent direction (TO.cc:1951)");
+  const double thr = 10 * std::numeric_limits<double>::epsilon() / time_step_ / time_step_;
+  if (std::fabs(L_prime) / std::fabs(L) <= thr) return {1.0, 0};
+  int i = 0;
+  double L_new;
+  Vec step(dq.size());
+  do {
+    alpha *= rho;
+    scratch->set_q(s.q());
+    for (std::size_t j = 0; j < dq.size(); ++j) step[j] = alpha * dq[j];
+    scratch->AddToQ(step);
+    if (params_.normalize_quaternions) NormalizeQuaternions(scratch);
+    L_new = EvalCost(*scratch);  // one device trial point per linesearch iteration
+    ++i;
+  } while ((L_new > L + c * alpha * L_prime) && (i < params_.max_linesearch_iterations));
+  return {alpha, i};
+}
+
+// TO.cc:1852-1929
+std::pair<double, int> TO::BacktrackingLinesearch(const TrajectoryOptimizerState<T>& s, const VectorXd& dq,
+                                                  TrajectoryOptimizerState<T>* scratch) const {
+  const double mu = params_.equality_constraints ? 1e3 : 0.0;  // l1 penalty on the constraint violations
+  auto l1 = [](const Vec& h) { double t = 0; for (double x : h) t += std::fabs(x); return t; };
+  const Vec& h = EvalEqualityConstraintViolations(s);
+  const double L = EvalCost(s) + mu * l1(h);
+  const Vec& g = EvalGradient(s);
+  const double c = 1e-4, rho = 0.8;
+  double alpha = 1.0;
+  const double L_prime = Dot(g, dq) - mu * l1(h);
+  if (!(L_prime <= 0)) throw std::runtime_error("linesearch: not a descent direction (TO.cc:1888)");
+  if (std::fabs(L_prime) / std::fabs(L) <= std::sqrt(std::numeric_limits<double>::epsilon())) return {1.0, 0};
+  Vec step(dq.size());
+  auto eval_at = [&](double al) {
+    scratch->set_q(s.q());
+    for (std::size_t j = 0; j < dq.size(); ++j) step[j] = al * dq[j];
+    scratch->AddToQ(step);
+    if (params_.normalize_quaternions) NormalizeQuaternions(scratch);
+    return EvalCost(*scratch) + mu * l1(EvalEqualityConstraintViolations(*scratch));
+  };
+  double L_old = eval_at(alpha), L_new = L_old;
+  int i = 0;
+  bool armijo_met = false;
+  while (!(armijo_met && (L_new > L_old))) {
+    L_old = L_new;
+    alpha *= rho;
+    L_new = eval_at(alpha);
+    if (L_new <= L + c * alpha * L_prime) armijo_met = true;
+    ++i;
+  }
+  return {alpha / rho, i};
+}
+
+// TO.cc:2244-2407
+SolverFlag TO::SolveWithLinesearch(const std::vector<VectorXd>& q_guess, TrajectoryOptimizerSolution<T>* solution,
+                                   TrajectoryOptimizerStats<T>* stats) const {
+  using clock = std::chrono::high_resolution_clock;
+  const auto start_time = clock::now();
+  TrajectoryOptimizerState<T> state = CreateState();
+  state.set_q(q_guess);
+  TrajectoryOptimizerState<T> scratch = CreateState();
+  Vec dq((std::size_t)num_vars()), rhs((std::size_t)num_vars()), step((std::size_t)num_vars());
+  if (params_.verbose) {
+    std::printf("-----------------------------------------------------------------------------------\n");
+    std::printf("|  iter  |   cost   |  alpha  |  LS_iters  |  time (s)  |  |g|/cost  |    |h|     |\n");
+    std::printf("-----------------------------------------------------------------------------------\n");
+  }
+  int k = 0;
+  bool linesearch_failed = false;
+  do {
+    const auto iter_start = clock::now();
+    const double cost = EvalCost(state);
+    const double h_norm = Norm(EvalEqualityConstraintViolations(state));
+    const Vec& g = EvalMeritFunctionGradient(state);
+    // dq = -H^-1 g with the unscaled Hessian (:2299-2300): one device factorisation + solve
+    EvalGradient(state);
+    EnsureDevice(state, 3);
+    for (std::size_t i = 0; i < rhs.size(); ++i) rhs[i] = -g[i];
+    Check(idto_hip_solve_host(hip_, rhs.data(), 1, dq.data()));
+    const auto [alpha, ls_iters] = (params_.linesearch_method == kArmijo) ? ArmijoLinesearch(state, dq, &scratch)
+                                                                         : BacktrackingLinesearch(state, dq, &scratch);
+    if (ls_iters >= params_.max_linesearch_iterations) {
+      linesearch_failed = true;
+      if (params_.verbose)
+        std::printf("LINESEARCH FAILED\nReached maximum linesearch iterations (%d).\n", params_.max_linesearch_iterations);
+    }
+    for (std::size_t i = 0; i < dq.size(); ++i) step[i] = alpha * dq[i];
+    const double trust_ratio = CalcTrustRatio(state, step, &scratch);
+    const double g_norm = Norm(g), dq_norm = Norm(dq), dL_dq = Dot(g, dq) / cost;  // (g dies with the cache below)
+    state.AddToQ(step);
+    if (params_.normalize_quaternions) NormalizeQuaternions(&state);
+    AdoptTrialPoint(scratch, &state);
+    const double iter_time = std::chrono::duration<double>(clock::now() - iter_start).count();
+    if (params_.verbose)
+      std::printf("| %6d | %8.3f | %7.4f | %6d     | %8.8f | %10.3e | %10.3e |\n", k, cost, alpha, ls_iters, iter_time,
+                  g_norm / cost, h_norm);
+    stats->push_data(iter_time, cost, ls_iters, alpha, std::numeric_limits<double>::quiet_NaN(), state.norm(), dq_norm,
+                     dq_norm, trust_ratio, g_norm, dL_dq, h_norm, cost);  // :2373-2385
+    ++k;
+  } while (k < params_.max_iterations && !linesearch_failed);
+  if (params_.verbose)
+    std::printf("-----------------------------------------------------------------------------------\n");
+  stats->solve_time = std::chrono::duration<double>(clock::now() - start_time).count();
+  solution->q = state.q();
+  solution->v = EvalV(state);
+  solution->tau = EvalTau(state);
+  return linesearch_failed ? SolverFlag::kLinesearchMaxIters : SolverFlag::kSuccess;
 }
 
 // TO.cc:2449-2651

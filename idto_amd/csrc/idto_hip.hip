@@ -81,6 +81,7 @@ struct idto_hip_ctx {
   unsigned* flags = nullptr;
   size_t xch_count = 0, flag_count = 0;
   unsigned epoch = 0;
+  double* Tst = nullptr;                             // column-major copies of the factor blocks (penta_apply.h)
   double *stage_rhs = nullptr, *stage_x = nullptr;  // idto_hip_solve_host
   double* pack = nullptr;                            // [tau | cost] of idto_hip_trial_cost (device)
   double* pin = nullptr;                             // pinned host staging: q in, [tau | cost] out
@@ -637,9 +638,12 @@ int idto_hip_factor_solve(idto_hip_ctx* c, const double* rhs, int nrhs, double* 
     const int lds = waves * n * K * (int)sizeof(double);
     const double* b1 = b + (size_t)n * k;
     double* x1 = xo + (size_t)n * k;
+    if (!c->Tst && Alloc(c, (size_t)3 * (c->N + 1) * 32 * 36, &c->Tst)) return -2;
 #define APPLY_LAUNCH(KM)                                                                                          \
+    hipLaunchKernelGGL(penta_factor_transpose_kernel<KM>, dim3(n, 3), dim3(256), 0, c->stream, c->Ust, c->Hst,     \
+                       c->Est, c->Tst);                                                                            \
     hipLaunchKernelGGL(penta_apply_kernel<KM>, dim3(blocks), dim3(64 * waves), lds, c->stream, n, k, c->Ust, c->Hst, \
-                       c->Est, c->Dst, b1, rhs ? 1.0 : -1.0, nrhs - 1, x1, m_split)
+                       c->Est, c->Dst, c->Tst, b1, rhs ? 1.0 : -1.0, nrhs - 1, x1, m_split)
     switch (K) {
       case 2: APPLY_LAUNCH(2); break;
       case 3: APPLY_LAUNCH(3); break;

@@ -22,11 +22,27 @@
 
 namespace idto_dev {
 
+// Column-major copies of the three factor blocks of every row (grid (n, 3)): the forward pass
+// reads COLUMNS of the row-major blocks; from the transposed copy a lane gets its column with
+// 16-byte loads, half as many load instructions on the dependent chain.
+template <int K>
+__global__ void penta_factor_transpose_kernel(const double* __restrict__ Ust, const double* __restrict__ Hst,
+                                              const double* __restrict__ Est, double* __restrict__ T) {
+  constexpr int ks = ldl_ks(K), KS2 = K * ks;
+  const int i = blockIdx.x, which = blockIdx.y, n = gridDim.x;
+  const double* src = (which == 0 ? Ust : which == 1 ? Hst : Est) + (size_t)i * KS2;
+  double* dst = T + ((size_t)which * n + i) * KS2;
+  for (int idx = threadIdx.x; idx < KS2; idx += blockDim.x) {
+    const int c = idx / ks, jj = idx - c * ks;
+    dst[idx] = (jj < K) ? src[jj * ks + c] : 0.0;
+  }
+}
+
 template <int K>
 __global__ void __launch_bounds__(256)
 penta_apply_kernel(int n, int k, const double* __restrict__ Ust, const double* __restrict__ Hst,
-                   const double* __restrict__ Est, const double* __restrict__ Dst, const double* __restrict__ rhs,
-                   double rhs_sign, int nrhs, double* __restrict__ x, int m_split) {
+                   const double* __restrict__ Est, const double* __restrict__ Dst, const double* __restrict__ Tst,
+                   const double* __restrict__ rhs, double rhs_sign, int nrhs, double* __restrict__ x, int m_split) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.x * (blockDim.x >> 6) + wave;
@@ -44,28 +60,49 @@ penta_apply_kernel(int n, int k, const double* __restrict__ Ust, const double* _
   const bool two = m_split > 0;
   const int nT = two ? m_split + 2 : n, nB = two ? n - m_split - 2 : 0;
 
-  // ---- forward substitution over local rows [first, last) of one chain
+  // ---- forward substitution over local rows [first, last) of one chain.  The factor blocks
+  // (transposed copies: 16-byte loads down the lane's column) and the right-hand side of the NEXT
+  // row are loaded while this row's chain of v_readlane / FMA runs; two register sets alternate.
+  const double* UT = Tst;
+  const double* HT = Tst + (size_t)n * KS2;
+  const double* ET = Tst + (size_t)2 * n * KS2;
+  struct Blk { double2 u[KP], h[KP], e[KP]; double b; };
+  auto fload = [&](int side, int il, Blk& d) __attribute__((always_inline)) {
+    const int i = side ? n - 1 - il : il;
+    const double2* pu = reinterpret_cast<const double2*>(UT + (size_t)i * KS2 + c * ks);
+    const double2* ph = reinterpret_cast<const double2*>(HT + (size_t)i * KS2 + c * ks);
+    const double2* pe = reinterpret_cast<const double2*>(ET + (size_t)i * KS2 + c * ks);
+#pragma unroll
+    for (int m = 0; m < KP; ++m) { d.u[m] = pu[m]; d.h[m] = ph[m]; d.e[m] = pe[m]; }
+    d.b = (c < k) ? rhs[(size_t)j * nk + (size_t)i * k + c] : 0.0;
+  };
+  auto fstep = [&](int side, int il, int last, const Blk& cur, Blk& nxt, double& pend1, double& pend2)
+      __attribute__((always_inline)) {
+    const int i = side ? n - 1 - il : il;
+    double v = rhs_sign * cur.b + pend1;
+    fload(side, il + 1 < last ? il + 1 : il, nxt);
+    double a1 = pend2, a2 = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < K; ++jj) {
+      const double t = rdlane(v, jj);       // rt_i[jj]: final once the steps before it are done
+      const double ujj = (jj & 1) ? cur.u[jj / 2].y : cur.u[jj / 2].x;
+      const double hjj = (jj & 1) ? cur.h[jj / 2].y : cur.h[jj / 2].x;
+      const double ejj = (jj & 1) ? cur.e[jj / 2].y : cur.e[jj / 2].x;
+      v = __builtin_fma(-ujj, t, v);        // L[c][jj] = (D^-1 U)[jj][c], zero for c <= jj
+      a1 = __builtin_fma(-hjj, t, a1);      // (Ht_i^T Dn rt_i)[c]
+      a2 = __builtin_fma(-ejj, t, a2);      // (Et_i^T Dn rt_i)[c]
+    }
+    if (live) rtw[i * K + lane] = v;
+    pend1 = a1;  // pushed into the next row of the chain
+    pend2 = a2;  // and the one after it
+  };
   auto forward = [&](int side, int first, int last, double& pend1, double& pend2) {
-    for (int il = first; il < last; ++il) {
-      const int i = side ? n - 1 - il : il;
-      const double* U = Ust + (size_t)i * KS2 + c;
-      const double* Hh = Hst + (size_t)i * KS2 + c;
-      const double* Ee = Est + (size_t)i * KS2 + c;
-      double u[K], h[K], e[K];
-#pragma unroll
-      for (int jj = 0; jj < K; ++jj) { u[jj] = U[jj * ks]; h[jj] = Hh[jj * ks]; e[jj] = Ee[jj * ks]; }
-      double v = ((c < k) ? rhs_sign * rhs[(size_t)j * nk + (size_t)i * k + c] : 0.0) + pend1;
-      double a1 = pend2, a2 = 0.0;
-#pragma unroll
-      for (int jj = 0; jj < K; ++jj) {
-        const double t = rdlane(v, jj);       // rt_i[jj]: final once the steps before it are done
-        v = __builtin_fma(-u[jj], t, v);      // L[c][jj] = (D^-1 U)[jj][c], zero for c <= jj
-        a1 = __builtin_fma(-h[jj], t, a1);    // (Ht_i^T Dn rt_i)[c]
-        a2 = __builtin_fma(-e[jj], t, a2);    // (Et_i^T Dn rt_i)[c]
-      }
-      if (live) rtw[i * K + lane] = v;
-      pend1 = a1;  // pushed into the next row of the chain
-      pend2 = a2;  // and the one after it
+    if (first >= last) return;
+    Blk A, B;
+    fload(side, first, A);
+    for (int il = first; il < last; il += 2) {
+      fstep(side, il, last, A, B, pend1, pend2);
+      if (il + 1 < last) fstep(side, il + 1, last, B, A, pend1, pend2);
     }
   };
   double p1 = 0.0, p2 = 0.0;
@@ -88,25 +125,29 @@ penta_apply_kernel(int n, int k, const double* __restrict__ Ust, const double* _
     auto o = [&](int il) { const int t = side ? n - 1 - il : il; return t < 0 ? 0 : (t > n - 1 ? n - 1 : t); };
     double v = given ? xm : Dst[(size_t)o(first) * K + r] * rtw[o(first) * K + r];
     double p = 0.0;
-    for (int il = first; il >= 0; --il) {
-      const bool solved = il > first - given;
+    struct Bk { double2 u[KP], h[KP], e[KP]; double d; };
+    auto bload = [&](int il, Bk& t) __attribute__((always_inline)) {
       const double2* pu = reinterpret_cast<const double2*>(Ust + (size_t)o(il) * KS2 + r * ks);
       const double2* ph = reinterpret_cast<const double2*>(Hst + (size_t)o(il > 0 ? il - 1 : 0) * KS2 + r * ks);
       const double2* pe = reinterpret_cast<const double2*>(Est + (size_t)o(il > 1 ? il - 2 : 0) * KS2 + r * ks);
-      double2 U2[KP], H2[KP], E2[KP];
 #pragma unroll
-      for (int m = KP - 1; m >= 0; --m) { U2[m] = pu[m]; H2[m] = ph[m]; E2[m] = pe[m]; }
+      for (int m = KP - 1; m >= 0; --m) { t.u[m] = pu[m]; t.h[m] = ph[m]; t.e[m] = pe[m]; }
+      t.d = Dst[(size_t)o(il > 0 ? il - 1 : 0) * K + r];
+    };
+    auto bstep = [&](int il, const Bk& cur, Bk& nxt) __attribute__((always_inline)) {
+      const bool solved = il > first - given;
+      bload(il > 0 ? il - 1 : 0, nxt);
       // rows -1, -2 do not exist; the join rows are not coupled THROUGH THIS CHAIN to each other
       const double hs = (il > 0 && !(given && il == first)) ? -1.0 : 0.0, es = (il > 1) ? -1.0 : 0.0;
       const double us = solved ? 0.0 : 1.0;
-      const double next_rt = (il > 0) ? Dst[(size_t)o(il - 1) * K + r] * rtw[o(il - 1) * K + r] : 0.0;
+      const double next_rt = (il > 0) ? cur.d * rtw[o(il - 1) * K + r] : 0.0;
       double pn = 0.0;
 #pragma unroll
       for (int jj = K - 1; jj >= 0; --jj) {
         const double xj = rdlane(v, jj);
-        const double ujj = (jj & 1) ? U2[jj / 2].y : U2[jj / 2].x;
-        const double hjj = (jj & 1) ? H2[jj / 2].y : H2[jj / 2].x;
-        const double ejj = (jj & 1) ? E2[jj / 2].y : E2[jj / 2].x;
+        const double ujj = (jj & 1) ? cur.u[jj / 2].y : cur.u[jj / 2].x;
+        const double hjj = (jj & 1) ? cur.h[jj / 2].y : cur.h[jj / 2].x;
+        const double ejj = (jj & 1) ? cur.e[jj / 2].y : cur.e[jj / 2].x;
         v = __builtin_fma(-(ujj * us), xj, v); // strictly upper: rows >= jj keep their value
         p = __builtin_fma(hjj * hs, xj, p);    // row il-1: -(D^-1 Ht_{il-1}) x_il
         pn = __builtin_fma(ejj * es, xj, pn);  // row il-2: -(D^-1 Et_{il-2}) x_il
@@ -119,6 +160,12 @@ penta_apply_kernel(int n, int k, const double* __restrict__ Ust, const double* _
       const bool next_given = il - 1 > first - given;  // (the second join row: what was pushed into it is not needed)
       v = next_given ? xm1 : next_rt + p;
       p = pn;
+    };
+    Bk A, B;
+    bload(first, A);
+    for (int il = first; il >= 0; il -= 2) {
+      bstep(il, A, B);
+      if (il >= 1) bstep(il - 1, B, A);
     }
   };
   backward(0, nT - 1, 0);

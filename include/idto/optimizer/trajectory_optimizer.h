@@ -21,11 +21,12 @@
 // throws/aborts: gradients_method must be one of the finite-difference methods (forward,
 // central, central4; kAutoDiff needs Drake's AutoDiffXd plant, reference TO.cc:410-423 has
 // the same kind of runtime check),
-// exact_hessian is not supported, method kLinesearch is not supported on the device path.
+// exact_hessian is not supported.
 #pragma once
 
 #include <memory>
 #include <stdexcept>
+#include <utility>
 #include <vector>
 
 #include "idto/optimizer/penta_diagonal_matrix.h"
@@ -117,6 +118,12 @@ class TrajectoryOptimizer<double> {
   void CalcGradHess(const TrajectoryOptimizerState<T>& state) const;
   const VectorXd& EvalHinvMeritGradient(const TrajectoryOptimizerState<T>& state) const;
   void NormalizeQuaternions(TrajectoryOptimizerState<T>* state) const;
+  std::pair<double, int> ArmijoLinesearch(const TrajectoryOptimizerState<T>& state, const VectorXd& dq,
+                                          TrajectoryOptimizerState<T>* scratch) const;
+  std::pair<double, int> BacktrackingLinesearch(const TrajectoryOptimizerState<T>& state, const VectorXd& dq,
+                                                TrajectoryOptimizerState<T>* scratch) const;
+  SolverFlag SolveWithLinesearch(const std::vector<VectorXd>& q_guess, TrajectoryOptimizerSolution<T>* solution,
+                                 TrajectoryOptimizerStats<T>* stats) const;
   void AdoptTrialPoint(const TrajectoryOptimizerState<T>& scratch, TrajectoryOptimizerState<T>* state) const;
   ConvergenceReason VerifyConvergenceCriteria(const TrajectoryOptimizerState<T>& state, T previous_cost,
                                               const VectorXd& dq) const;
