@@ -91,6 +91,29 @@ def cpu_baseline(model, prob, sp, q, budget_s=12.0):
                       f" (host has {os.cpu_count()} logical cores)"}
 
 
+def full_iteration(cfg, model, N, device, with_cpu, iters=20):
+    """Secondary number (SURVEY.md §8d): one iteration of TrajectoryOptimizer::Solve with the example
+    YAML's solver settings (scaling, equality constraints / multipliers, dogleg, trust ratio) through
+    libidto_opt.so, next to the CPU oracle's iteration on the same problem."""
+    from idto_amd.optimizer import TrajectoryOptimizer, TrajectoryOptimizerSolution, TrajectoryOptimizerStats
+    prob, sp, q_guess = make_problem(cfg, model, num_steps=N)
+    sp.max_iterations, sp.verbose, sp.num_threads = iters, False, 1
+    opt = TrajectoryOptimizer(model, prob, sp, device=device)
+    for _ in range(2):  # the second solve is the warmed-up one
+        sol, st = TrajectoryOptimizerSolution(), TrajectoryOptimizerStats()
+        opt.Solve(q_guess, sol, st)
+    out = {"ms_per_iteration": 1e3 * st.solve_time / iters, "iterations": iters,
+           "num_equality_constraints": opt.num_equality_constraints(),
+           "what": "TrajectoryOptimizer::Solve, trust region, solver settings of the example YAML"}
+    opt.close()
+    if with_cpu:
+        from oracle_lib import Oracle
+        t0 = time.perf_counter()
+        Oracle(model, prob, sp).solve(q_guess)
+        out["cpu_port_ms_per_iteration"] = 1e3 * (time.perf_counter() - t0) / iters
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,6 +123,7 @@ def main():
     ap.add_argument("--config", default="mini_cheetah")
     ap.add_argument("--num-steps", type=int, default=40, help="horizon N")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-full", action="store_true", help="skip the informational full-iteration measurement")
     ap.add_argument("--batch", type=int, default=8,
                     help="also report the aggregate rate of this many independent problems on one GPU (0/1: skip)")
     args = ap.parse_args()
@@ -280,6 +304,8 @@ def main():
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, prob, sp, q)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        if world == 1 and not args.no_full:
+            out["full_iteration"] = full_iteration(cfg, model, N, local_rank, not args.no_cpu)
         print(json.dumps(out))
     dev.close()
     if dist is not None:

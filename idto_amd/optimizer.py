@@ -148,11 +148,15 @@ class TrajectoryOptimizer:
         if rc != 0:
             raise RuntimeError(lib().idto_opt_last_error().decode())
 
+    def close(self):
+        """release the device context now (otherwise when the object is collected)"""
+        if getattr(self, "_h", None):
+            lib().idto_opt_destroy(self._h)
+            self._h = None
+
     def __del__(self):
         try:
-            if getattr(self, "_h", None):
-                lib().idto_opt_destroy(self._h)
-                self._h = None
+            self.close()
         except Exception:
             pass
 

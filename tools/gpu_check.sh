@@ -12,9 +12,9 @@ timeout 600 python bench.py --steps 200 --warmup 20 2>&1 | tail -3 | tee gpurun_
 timeout 120 python tools/solver_phases.py 2>&1 | tail -14 | tee gpurun_out/phases.log
 ROOT=$GRAFT_REPO_ROOT
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof -o $R -- python $ROOT/bench.py --steps 100 --warmup 10 --no-cpu > $ROOT/gpurun_out/prof_bench.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $ROOT/gpurun_out/pmc_fetch -o $R -- python $ROOT/bench.py --steps 50 --warmup 5 --no-cpu > $ROOT/gpurun_out/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $ROOT/gpurun_out/pmc_write -o $R -- python $ROOT/bench.py --steps 50 --warmup 5 --no-cpu > $ROOT/gpurun_out/pmc_write.log 2>&1
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof -o $R -- python $ROOT/bench.py --steps 100 --warmup 10 --no-cpu --no-full --batch 0 > $ROOT/gpurun_out/prof_bench.log 2>&1
+timeout -k 10 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $ROOT/gpurun_out/pmc_fetch -o $R -- python $ROOT/bench.py --steps 50 --warmup 5 --no-cpu --no-full --batch 0 > $ROOT/gpurun_out/pmc_fetch.log 2>&1
+timeout -k 10 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $ROOT/gpurun_out/pmc_write -o $R -- python $ROOT/bench.py --steps 50 --warmup 5 --no-cpu --no-full --batch 0 > $ROOT/gpurun_out/pmc_write.log 2>&1
 cd $ROOT
 find gpurun_out/prof gpurun_out/pmc_fetch gpurun_out/pmc_write -type f | head -30
 for f in $(find gpurun_out/prof -name "*kernel_stats*.csv" | head -1); do head -12 $f; done

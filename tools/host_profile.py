@@ -19,3 +19,4 @@ for rep in range(2):  # the profile covers the second (warmed-up) solve only
     opt.Solve(q_guess, sol, st)
     print(f"{name} N={N} n_eq={opt.num_equality_constraints()}: {1e3 * st.solve_time / iters:.3f} ms/iteration "
           f"({iters} iterations, solve {rep})", flush=True)
+opt.close()
