@@ -79,6 +79,14 @@ extern "C" {
 
 const char* idto_opt_last_error(void) { return g_err.c_str(); }
 
+int idto_opt_dense_ldlt_solve(double* S, int n, double* b) {
+  if (!S || !b || n < 1) { g_err = "dense_ldlt_solve: bad arguments"; return -1; }
+  std::vector<double> M(S, S + (std::size_t)n * n);
+  idto::optimizer::internal::DenseLdltSolve(&M, n, b);
+  std::copy(M.begin(), M.end(), S);
+  return 0;
+}
+
 int idto_opt_create(const idto_model_t* model, const idto_problem_t* p, const idto_contact_params_t* c,
                     const idto_solver_params_t* sp, int device, idto_opt** out) {
   return Guard([&] {

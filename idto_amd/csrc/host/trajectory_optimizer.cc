@@ -1,9 +1,11 @@
 // trajectory_optimizer.cc — host side of idto::optimizer::TrajectoryOptimizer<double>
 // (include/idto/optimizer/trajectory_optimizer.h) written directly on the C-ABI of
 // libidto_hip.so.  What runs where:
-//   device (include/idto_hip.h): N+, v, a, tau, cost, dtau/dq, gradient, Hessian bands,
-//                                every linear solve with H;
-//   host (this file):            the O(num_vars) bookkeeping of one trust-region iteration,
+//   device (include/idto_hip.h): N+, v, a, tau, cost, dtau/dq, gradient, Hessian bands, every
+//                                linear solve with H, the equality-constraint Schur complement
+//                                J H^-1 J^T and H^-1 (g + J^T lambda);
+//   host (this file):            the O(num_vars) bookkeeping of one trust-region / linesearch
+//                                iteration and the small dense solve for the multipliers,
 //                                following reference optimizer/trajectory_optimizer.cc
 //                                ("TO.cc") function by function (cited at each one).
 // Nothing here evaluates dynamics or factorises H: without the HIP library/device the
@@ -92,6 +94,9 @@ std::vector<MatrixXd> UnflattenBlocks(const Vec& flat, int count, int rows, int 
   return out;
 }
 
+}  // namespace
+
+namespace internal {
 // Solves the symmetric positive (semi-)definite n x n system S x = b in place with an LDL^T
 // factorisation with diagonal pivoting (what Eigen's ldlt() does for the reference at
 // TO.cc:1395).  S is column-major; only its lower triangle is read and it is overwritten by the
@@ -188,6 +193,11 @@ void DenseLdltSolve(std::vector<double>* S_io, int n, double* b) {
   }
   for (int i = 0; i < n; ++i) b[perm[i]] = y[i];
 }
+
+}  // namespace internal
+
+namespace {
+using internal::DenseLdltSolve;
 
 // sum_k a[k] * b[k] with four independent partial sums (lets the compiler keep four FMA chains
 // in flight; plain left-to-right summation is latency-bound)

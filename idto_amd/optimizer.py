@@ -31,6 +31,7 @@ def lib():
             raise hip.HipLibraryMissing(f"{LIB_PATH} not found: run ./build.sh")
         L = C.CDLL(LIB_PATH)
         L.idto_opt_last_error.restype = C.c_char_p
+        L.idto_opt_dense_ldlt_solve.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double)]
         L.idto_opt_create.argtypes = [C.POINTER(CModel), C.POINTER(CProblem), C.POINTER(CContactParams),
                                       C.POINTER(CSolverParams), C.c_int, C.POINTER(C.c_void_p)]
         L.idto_opt_destroy.argtypes = [C.c_void_p]
@@ -56,7 +57,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = [
-    "idto_opt_last_error", "idto_opt_create", "idto_opt_destroy", "idto_opt_num_steps", "idto_opt_time_step",
+    "idto_opt_last_error", "idto_opt_dense_ldlt_solve", "idto_opt_create", "idto_opt_destroy", "idto_opt_num_steps", "idto_opt_time_step",
     "idto_opt_num_equality_constraints", "idto_opt_solve", "idto_opt_ws_create", "idto_opt_ws_destroy",
     "idto_opt_ws_set_q", "idto_opt_ws_get", "idto_opt_ws_solve", "idto_opt_reset_initial_conditions",
     "idto_opt_update_nominal_trajectory", "idto_opt_eval", "idto_opt_dogleg", "idto_opt_trust_ratio",

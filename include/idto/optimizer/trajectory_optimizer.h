@@ -40,6 +40,12 @@
 namespace idto {
 namespace optimizer {
 
+namespace internal {
+// S x = b for the symmetric positive (semi-)definite Schur complement of the multipliers
+// (column-major, lower triangle read, overwritten): LDL^T with diagonal pivoting (TO.cc:1395).
+void DenseLdltSolve(std::vector<double>* S, int n, double* b);
+}  // namespace internal
+
 template <typename T>
 class TrajectoryOptimizer;
 

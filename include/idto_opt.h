@@ -21,6 +21,11 @@ typedef struct idto_opt_warm_start idto_opt_warm_start;
 
 const char* idto_opt_last_error(void);
 
+/* The small dense solve of CalcLagrangeMultipliers (optimizer/trajectory_optimizer.cc:1395,
+ * Eigen ldlt()): S x = b, S symmetric positive (semi-)definite n x n column-major (lower triangle
+ * read; overwritten by the factors), b overwritten by x.  Host only; exported for tests. */
+int idto_opt_dense_ldlt_solve(double* S, int n, double* b);
+
 /* TrajectoryOptimizer(diagram, plant, prob, params) (trajectory_optimizer.h:56-72) with the
  * plant replaced by model tables + time step. */
 int idto_opt_create(const idto_model_t* model, const idto_problem_t* problem, const idto_contact_params_t* contact,
