@@ -389,8 +389,26 @@ void TO::CalcGradHess(const TrajectoryOptimizerState<T>& state) const {
   CalcTrajectoryData(state);  // (the partials stay on the device unless somebody asks for them)
   Scope prof_("grad + hess (device + fetch)");
   EnsureDevice(state, 3);
-  c.gradient = Fetch(IDTO_ARR_GRADIENT);
-  const Vec bands = Fetch(IDTO_ARR_HBANDS);  // [A | B | C], (N+6) blocks each
+  // g and the bands are copied on a side stream while the solver - which every iteration needs
+  // next (CalcDoglegPoint :2139-2149 / CalcLagrangeMultipliers :1371-1396) - already runs
+  Check(idto_hip_prefetch(hip_, IDTO_ARR_GRADIENT));
+  Check(idto_hip_prefetch(hip_, IDTO_ARR_HBANDS));
+  if (params_.equality_constraints && num_equality_constraints() > 0) {
+    Scope prof2_("  launch constraint solve");
+    Check(idto_hip_constraint_schur_begin(hip_, unactuated_dofs_.data(), (int)unactuated_dofs_.size()));
+  } else {
+    Check(idto_hip_factor_solve(hip_, nullptr, 1, nullptr));  // IDTO_ARR_STEP = -H^-1 g
+    c.step_on_device = true;
+  }
+  {
+    Scope prof2_("  fetch g");
+    c.gradient = Fetch(IDTO_ARR_GRADIENT);
+  }
+  Vec bands;
+  {
+    Scope prof2_("  fetch H bands");
+    bands = Fetch(IDTO_ARR_HBANDS);
+  }  // [A | B | C], (N+6) blocks each
   const std::size_t used = (std::size_t)(num_steps() + 1) * nq_ * nq_, span = (std::size_t)(num_steps() + 6) * nq_ * nq_;
   c.hessian = PentaDiagonalMatrix<T>(num_steps() + 1, nq_);
   c.hessian.mutable_A().assign(bands.begin(), bands.begin() + used);
@@ -516,10 +534,16 @@ const VectorXd& TO::EvalHinvMeritGradient(const TrajectoryOptimizerState<T>& s) 
   }
   if (!c.hinv) {
     const Vec& g = EvalGradient(s);
-    EnsureDevice(s, 3);
-    c.Hinv_gm.resize(g.size());
     Scope prof_("device solve H^-1 g");
-    Check(idto_hip_solve_host(hip_, g.data(), 1, c.Hinv_gm.data()));
+    if (c.step_on_device && resident_ == &s && device_level_ == 3) {
+      // launched right behind the assembly (CalcGradHess): -H^-1 g is waiting in device memory
+      c.Hinv_gm = Fetch(IDTO_ARR_STEP);
+      for (double& x : c.Hinv_gm) x = -x;
+    } else {
+      EnsureDevice(s, 3);
+      c.Hinv_gm.resize(g.size());
+      Check(idto_hip_solve_host(hip_, g.data(), 1, c.Hinv_gm.data()));
+    }
     c.hinv = true;
   }
   return c.Hinv_gm;
@@ -542,22 +566,32 @@ const VectorXd& TO::EvalLagrangeMultipliers(const TrajectoryOptimizerState<T>& s
     EvalGradient(s);
     EnsureDevice(s, 3);
     const int neq = num_equality_constraints(), nu = (int)unactuated_dofs_.size();
-    std::vector<double> S((std::size_t)neq * neq);
-    Vec rhs((std::size_t)neq);
-    {
-      Scope prof_("device: H^-1[g|J^T], S = J Y");
-      Check(idto_hip_constraint_schur(hip_, unactuated_dofs_.data(), nu, S.data(), rhs.data()));
-    }
-    for (int r = 0; r < neq; ++r) rhs[r] = h[r] - rhs[r];
-    {
-      Scope prof_("dense LDLT (host)");
-      DenseLdltSolve(&S, neq, rhs.data());
-    }
-    c.lambda_v = rhs;
+    c.lambda_v.resize((std::size_t)neq);
     c.Hinv_gm.resize((std::size_t)num_vars());
     c.JT_lambda.resize((std::size_t)num_vars());
-    {
-      Scope prof_("device: H^-1(g+J^T l), J^T l");
+    // Where S is factorised: on the device when it is large (the 25 small launches of the blocked
+    // LDL^T cost ~0.3 ms at n_eq = 150 and 0.6 ms at 360; one host core needs 0.08 ms and 1.0 ms),
+    // otherwise - and whenever the device finds S numerically singular - on the host.
+    constexpr int kDeviceLdltFrom = 256;
+    int rc = 1;
+    Check(idto_hip_constraint_schur_begin(hip_, unactuated_dofs_.data(), nu));  // (no-op if CalcGradHess launched it)
+    if (neq >= kDeviceLdltFrom) {
+      Scope prof_("device: constraint solve");
+      rc = idto_hip_constraint_solve(hip_, h.data(), c.lambda_v.data(), c.Hinv_gm.data(), c.JT_lambda.data());
+      if (rc != 0 && rc != 1) Check(rc);
+    }
+    if (rc == 1) {
+      // pivoted LDL^T on the host, as Eigen's ldlt() of the reference (tolerates semi-definite S)
+      Scope prof_("device schur + host LDLT + device step");
+      std::vector<double> S((std::size_t)neq * neq);
+      Vec rhs((std::size_t)neq);
+      Check(idto_hip_constraint_schur(hip_, unactuated_dofs_.data(), nu, S.data(), rhs.data()));
+      for (int r = 0; r < neq; ++r) rhs[r] = h[r] - rhs[r];
+      {
+        Scope prof_("dense LDLT (host)");
+        DenseLdltSolve(&S, neq, rhs.data());
+      }
+      c.lambda_v = rhs;
       Check(idto_hip_constraint_step(hip_, c.lambda_v.data(), c.Hinv_gm.data(), c.JT_lambda.data()));
     }
     c.lambda = true;

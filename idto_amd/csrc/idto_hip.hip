@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -16,6 +17,7 @@
 #include "penta_ldl.h"
 #include "penta_apply.h"
 #include "constraints.h"
+#include "dense_ldl.h"
 
 using namespace idto_dev;
 
@@ -89,7 +91,15 @@ struct idto_hip_ctx {
   int* con_dofs = nullptr; int con_nu = 0, con_neq = 0;
   std::vector<int> con_dofs_host;
   double *con_S = nullptr, *con_lambda = nullptr, *con_out = nullptr;  // device: [S | J y_g], lambda, [step | J^T lambda]
+  double *con_W = nullptr, *con_d = nullptr, *con_h = nullptr;         // dense LDL^T: W = L D panel, pivots, [min, max | h]
+  bool con_S_factored = false;                                         // con_S holds the LDL^T factors, not S
   double* con_pin = nullptr; size_t con_pin_count = 0;                 // pinned host staging for the above
+  bool con_begun = false;                                              // constraint_schur_begin enqueued for the current H
+  // idto_hip_prefetch: copies enqueued on a side stream behind an event of the main stream
+  struct Prefetch { int what = -1; size_t off = 0, count = 0; bool pending = false; hipEvent_t ev = nullptr; };
+  Prefetch pre[4];
+  hipStream_t side = nullptr;
+  double* pre_pin = nullptr; size_t pre_cap = 0;
   bool con_ready = false;                                              // stage_x holds H^-1 [g | J^T] of the current H
   size_t stage_count = 0;
   std::vector<hipEvent_t> event_pool;  // recycled: creating events in the timed loop costs host time
@@ -439,6 +449,9 @@ void idto_hip_destroy(idto_hip_ctx* c) {
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->con_pin) (void)hipHostFree(c->con_pin);
+  if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+  for (auto& pf : c->pre) if (pf.ev) (void)hipEventDestroy(pf.ev);
+  if (c->pre_pin) (void)hipHostFree(c->pre_pin);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -447,7 +460,7 @@ int idto_hip_set_problem(idto_hip_ctx* c, const idto_problem_t* p) {
   if (p->num_steps != c->N || p->time_step != c->dt) { g_err = "num_steps / time_step cannot change"; return -1; }
   HIP_OK(hipSetDevice(c->device));
   c->fd_full = false;  // v_0 = v_init
-  c->con_ready = false;
+  c->con_ready = false; c->con_begun = false;
   return UploadProblemArrays(c, p, false);
 }
 
@@ -468,7 +481,7 @@ int idto_hip_set_shard(idto_hip_ctx* c, int kb, int ke) {
 int idto_hip_set_q(idto_hip_ctx* c, const double* q_host) {
   HIP_OK(hipSetDevice(c->device));
   c->fd_full = false;
-  c->con_ready = false;
+  c->con_ready = false; c->con_begun = false;
   HIP_OK(hipMemcpyAsync(c->q, q_host, (size_t)(c->N + 1) * c->nq * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIP_OK(hipStreamSynchronize(c->stream));  // the host buffer may be reused by the caller
   return 0;
@@ -476,7 +489,7 @@ int idto_hip_set_q(idto_hip_ctx* c, const double* q_host) {
 int idto_hip_set_q_device(idto_hip_ctx* c, const double* q_dev) {
   HIP_OK(hipSetDevice(c->device));
   c->fd_full = false;
-  c->con_ready = false;
+  c->con_ready = false; c->con_begun = false;
   HIP_OK(hipMemcpyAsync(c->q, q_dev, (size_t)(c->N + 1) * c->nq * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   return 0;
 }
@@ -503,7 +516,7 @@ int idto_hip_trial_cost(idto_hip_ctx* c, const double* q_host, double* tau_host,
   // inverse-dynamics evaluations, the cost, and [tau | cost] back in one copy
   std::memcpy(c->pin, q_host, nq_all * sizeof(double));
   c->fd_full = false;
-  c->con_ready = false;
+  c->con_ready = false; c->con_begun = false;
   HIP_OK(hipMemcpyAsync(c->q, c->pin, nq_all * sizeof(double), hipMemcpyHostToDevice, c->stream));
   int rc = LaunchFd(c, 0, 0, c->N);
   if (rc) return rc;
@@ -520,7 +533,7 @@ int idto_hip_trial_cost(idto_hip_ctx* c, const double* q_host, double* tau_host,
 
 int idto_hip_eval_partials(idto_hip_ctx* c) {
   HIP_OK(hipSetDevice(c->device));
-  c->con_ready = false;
+  c->con_ready = false; c->con_begun = false;
   if (TimeBegin(c, 0)) return -2;
   int rc = LaunchFd(c, 1, c->k_begin, c->k_end);
   if (rc) return rc;
@@ -530,7 +543,7 @@ int idto_hip_eval_partials(idto_hip_ctx* c) {
 
 int idto_hip_grad_hess(idto_hip_ctx* c) {
   HIP_OK(hipSetDevice(c->device));
-  c->con_ready = false;
+  c->con_ready = false; c->con_begun = false;
   if (TimeBegin(c, 1)) return -2;
   if (c->weights_diagonal)
     hipLaunchKernelGGL(assemble_diag_kernel, dim3(c->N + 1, 4), dim3(256), c->asm_diag_lds, c->stream, c->M, c->P, c->q,
@@ -666,7 +679,7 @@ int idto_hip_solve_host(idto_hip_ctx* c, const double* rhs_host, int nrhs, doubl
   if (!rhs_host || !x_host || nrhs < 1) { g_err = "solve_host: bad arguments"; return -1; }
   const size_t count = (size_t)nrhs * (c->N + 1) * c->nq;
   if (EnsureStage(c, count)) return -2;
-  c->con_ready = false;  // the staging buffers are shared with the constraint step
+  c->con_ready = false; c->con_begun = false;  // the staging buffers are shared with the constraint step
   HIP_OK(hipMemcpyAsync(c->stage_rhs, rhs_host, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
   int rc = idto_hip_factor_solve(c, c->stage_rhs, nrhs, c->stage_x);
   if (rc) return rc;
@@ -675,12 +688,14 @@ int idto_hip_solve_host(idto_hip_ctx* c, const double* rhs_host, int nrhs, doubl
   return 0;
 }
 
-int idto_hip_constraint_schur(idto_hip_ctx* c, const int* dofs, int nu, double* S_host, double* Jy_host) {
+int idto_hip_constraint_schur_begin(idto_hip_ctx* c, const int* dofs, int nu) {
   HIP_OK(hipSetDevice(c->device));
-  if (!dofs || nu < 1 || nu > c->nv || !S_host || !Jy_host) { g_err = "constraint_schur: bad arguments"; return -1; }
+  if (!dofs || nu < 1 || nu > c->nv) { g_err = "constraint_schur: bad arguments"; return -1; }
   for (int j = 0; j < nu; ++j)
     if (dofs[j] < 0 || dofs[j] >= c->nv) { g_err = "constraint_schur: dof index out of range"; return -1; }
   const int N = c->N, n = (N + 1) * c->nq, neq = nu * N;
+  if (c->con_begun && c->con_nu == nu && std::equal(dofs, dofs + nu, c->con_dofs_host.begin()))
+    return 0;  // already enqueued for the current Hessian
   if (c->con_nu != nu || !std::equal(dofs, dofs + nu, c->con_dofs_host.begin())) {
     c->con_dofs_host.assign(dofs, dofs + nu);
     void* p = nullptr;
@@ -688,17 +703,18 @@ int idto_hip_constraint_schur(idto_hip_ctx* c, const int* dofs, int nu, double* 
     c->allocs.push_back(p);
     c->con_dofs = static_cast<int*>(p);
     HIP_OK(hipMemcpy(c->con_dofs, dofs, (size_t)nu * sizeof(int), hipMemcpyHostToDevice));
-    if (Alloc(c, (size_t)neq * neq + neq, &c->con_S) || Alloc(c, (size_t)neq, &c->con_lambda) ||
-        Alloc(c, (size_t)2 * n, &c->con_out))
+    if (Alloc(c, (size_t)neq * neq + neq, &c->con_S) || Alloc(c, (size_t)neq + 2, &c->con_lambda) ||
+        Alloc(c, (size_t)2 * n, &c->con_out) || Alloc(c, (size_t)neq * DENSE_NB, &c->con_W) ||
+        Alloc(c, (size_t)neq, &c->con_d) || Alloc(c, (size_t)neq + 2, &c->con_h))
       return -2;
-    const size_t need = (size_t)neq * neq + neq + 2 * (size_t)n + neq;
+    const size_t need = (size_t)neq * neq + neq + 2 * (size_t)n + 2 * (size_t)neq + 4;
     if (c->con_pin) (void)hipHostFree(c->con_pin);
     c->con_pin = nullptr;
     HIP_OK(hipHostMalloc((void**)&c->con_pin, need * sizeof(double), hipHostMallocDefault));
     c->con_pin_count = need;
     c->con_nu = nu; c->con_neq = neq;
   }
-  c->con_ready = false;
+  c->con_ready = false; c->con_begun = false;
   if (EnsureStage(c, (size_t)(neq + 1) * n)) return -2;
   hipLaunchKernelGGL(constraint_rhs_kernel, dim3(neq + 1), dim3(256), 0, c->stream, c->slab, c->slab_stride, c->g,
                      c->con_dofs, nu, N, c->nq, c->nv, c->stage_rhs);
@@ -709,12 +725,78 @@ int idto_hip_constraint_schur(idto_hip_ctx* c, const int* dofs, int nu, double* 
                      c->slab_stride, c->con_dofs, nu, N, c->nq, c->nv, c->stage_x, neq, c->con_S,
                      c->con_S + (size_t)neq * neq);
   HIP_OK(hipGetLastError());
-  const size_t count = (size_t)neq * neq + neq;
-  HIP_OK(hipMemcpyAsync(c->con_pin, c->con_S, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  c->con_S_factored = false;
+  c->con_begun = true;
+  return 0;
+}
+
+int idto_hip_constraint_schur(idto_hip_ctx* c, const int* dofs, int nu, double* S_host, double* Jy_host) {
+  HIP_OK(hipSetDevice(c->device));
+  if (!S_host || !Jy_host || !dofs) { g_err = "constraint_schur: bad arguments"; return -1; }
+  const bool same = c->con_begun && nu == c->con_nu && std::equal(dofs, dofs + nu, c->con_dofs_host.begin());
+  if (!same) {
+    int rc = idto_hip_constraint_schur_begin(c, dofs, nu);
+    if (rc) return rc;
+  }
+  const int neq = c->con_neq;
+  if (c->con_S_factored) {  // the device factorisation overwrote S: form it again from Y
+    hipLaunchKernelGGL(constraint_schur_kernel, dim3(neq), dim3(256), 3 * c->nq * sizeof(double), c->stream, c->slab,
+                       c->slab_stride, c->con_dofs, c->con_nu, c->N, c->nq, c->nv, c->stage_x, neq, c->con_S,
+                       c->con_S + (size_t)neq * neq);
+    HIP_OK(hipGetLastError());
+    c->con_S_factored = false;
+  }
+  HIP_OK(hipMemcpyAsync(c->con_pin, c->con_S, ((size_t)neq * neq + neq) * sizeof(double), hipMemcpyDeviceToHost,
+                        c->stream));
   HIP_OK(hipStreamSynchronize(c->stream));
   std::memcpy(S_host, c->con_pin, (size_t)neq * neq * sizeof(double));
   std::memcpy(Jy_host, c->con_pin + (size_t)neq * neq, (size_t)neq * sizeof(double));
   c->con_ready = true;
+  return 0;
+}
+
+int idto_hip_constraint_solve(idto_hip_ctx* c, const double* h_host, double* lambda_host, double* step_host,
+                              double* jtl_host) {
+  HIP_OK(hipSetDevice(c->device));
+  if (!c->con_begun) { g_err = "constraint_solve: call idto_hip_constraint_schur_begin for the current Hessian first"; return -1; }
+  if (!h_host || !lambda_host || !step_host || !jtl_host) { g_err = "constraint_solve: bad arguments"; return -1; }
+  if (c->con_S_factored) { g_err = "constraint_solve: already called for this Hessian"; return -1; }
+  const int N = c->N, n = (N + 1) * c->nq, neq = c->con_neq;
+  // pinned layout behind [S | Jy]: [min, max | h] up, [min, max | lambda | step | J^T lambda] down
+  double* pin = c->con_pin + (size_t)neq * neq + neq;
+  pin[0] = std::numeric_limits<double>::infinity(); pin[1] = 0.0;
+  std::memcpy(pin + 2, h_host, (size_t)neq * sizeof(double));
+  HIP_OK(hipMemcpyAsync(c->con_h, pin, (size_t)(neq + 2) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  double* S = c->con_S;
+  for (int j0 = 0; j0 < neq; j0 += DENSE_NB) {
+    const int j1 = j0 + DENSE_NB;
+    const int below = neq > j1 ? neq - j1 : 0;
+    hipLaunchKernelGGL(dense_ldl_panel_kernel, dim3(1 + (below + 63) / 64), dim3(64), 0, c->stream, S, neq, j0, c->con_W,
+                       c->con_d, c->con_h);
+    if (j1 < neq) {
+      const int tiles = (neq - j1 + 31) / 32;
+      hipLaunchKernelGGL(dense_ldl_update_kernel, dim3(tiles, tiles), dim3(256), 0, c->stream, S, neq, j0, j1, c->con_W);
+    }
+  }
+  c->con_S_factored = true;
+  // lambda = S^-1 (h - J y_g)
+  hipLaunchKernelGGL(dense_ldl_solve_kernel, dim3(1), dim3(512), (neq + 512 + DENSE_NB * (DENSE_NB + 1)) * sizeof(double), c->stream, S, neq, c->con_d,
+                     S + (size_t)neq * neq, -1.0, c->con_h + 2, c->con_lambda + 2);
+  hipLaunchKernelGGL(constraint_step_kernel, dim3((n + 63) / 64), dim3(256), (neq + 256) * sizeof(double), c->stream, c->slab,
+                     c->slab_stride, c->con_dofs, c->con_nu, N, c->nq, c->nv, c->stage_x, neq, c->con_lambda + 2,
+                     c->con_out, c->con_out + n);
+  HIP_OK(hipGetLastError());
+  double* down = pin + neq + 2;
+  HIP_OK(hipMemcpyAsync(down, c->con_h, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(hipMemcpyAsync(down + 2, c->con_lambda + 2, (size_t)neq * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(hipMemcpyAsync(down + 2 + neq, c->con_out, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  c->con_ready = true;  // Y is in place for idto_hip_constraint_step (fallback path)
+  const double dmin = down[0], dmax = down[1];
+  if (!(dmin > 1e-13 * dmax) || !std::isfinite(dmax)) return 1;  // (semi-)singular S: the caller pivots on the host
+  std::memcpy(lambda_host, down + 2, (size_t)neq * sizeof(double));
+  std::memcpy(step_host, down + 2 + neq, (size_t)n * sizeof(double));
+  std::memcpy(jtl_host, down + 2 + neq + n, (size_t)n * sizeof(double));
   return 0;
 }
 
@@ -726,7 +808,7 @@ int idto_hip_constraint_step(idto_hip_ctx* c, const double* lambda_host, double*
   double* pl = c->con_pin + (size_t)neq * neq + neq;  // [lambda | step | J^T lambda]
   std::memcpy(pl, lambda_host, (size_t)neq * sizeof(double));
   HIP_OK(hipMemcpyAsync(c->con_lambda, pl, (size_t)neq * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(constraint_step_kernel, dim3((n + 63) / 64), dim3(64), neq * sizeof(double), c->stream, c->slab,
+  hipLaunchKernelGGL(constraint_step_kernel, dim3((n + 63) / 64), dim3(256), (neq + 256) * sizeof(double), c->stream, c->slab,
                      c->slab_stride, c->con_dofs, c->con_nu, N, c->nq, c->nv, c->stage_x, neq, c->con_lambda, c->con_out,
                      c->con_out + n);
   HIP_OK(hipGetLastError());
@@ -823,8 +905,46 @@ void* idto_hip_device_ptr(idto_hip_ctx* c, int what) {
   }
 }
 
+int idto_hip_prefetch(idto_hip_ctx* c, int what) {
+  HIP_OK(hipSetDevice(c->device));
+  const long count = idto_hip_array_size(c, what);
+  void* p = idto_hip_device_ptr(c, what);
+  if (count < 0 || !p) { g_err = "prefetch: array is not contiguous in device memory"; return -1; }
+  if (!c->side) HIP_OK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  // slot: the one already holding `what`, else a free one
+  idto_hip_ctx::Prefetch* slot = nullptr;
+  for (auto& pf : c->pre) if (pf.what == what) slot = &pf;
+  if (!slot) for (auto& pf : c->pre) if (pf.what < 0 && !slot) slot = &pf;
+  if (!slot) { g_err = "prefetch: at most 4 different arrays"; return -1; }
+  if (slot->what != what) {  // lay the staging area out again (rare: first use of an array)
+    HIP_OK(hipStreamSynchronize(c->side));
+    slot->what = what; slot->count = (size_t)count;
+    size_t total = 0;
+    for (auto& pf : c->pre) if (pf.what >= 0) { pf.off = total; total += pf.count; pf.pending = false; }
+    if (total > c->pre_cap) {
+      if (c->pre_pin) (void)hipHostFree(c->pre_pin);
+      c->pre_pin = nullptr;
+      HIP_OK(hipHostMalloc((void**)&c->pre_pin, total * sizeof(double), hipHostMallocDefault));
+      c->pre_cap = total;
+    }
+    if (!slot->ev) HIP_OK(hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming));
+  }
+  HIP_OK(hipEventRecord(slot->ev, c->stream));
+  HIP_OK(hipStreamWaitEvent(c->side, slot->ev, 0));
+  HIP_OK(hipMemcpyAsync(c->pre_pin + slot->off, p, slot->count * sizeof(double), hipMemcpyDeviceToHost, c->side));
+  slot->pending = true;
+  return 0;
+}
+
 int idto_hip_get(idto_hip_ctx* c, int what, double* out) {
   HIP_OK(hipSetDevice(c->device));
+  for (auto& pf : c->pre)
+    if (pf.what == what && pf.pending) {  // the copy was enqueued earlier: wait for it alone
+      HIP_OK(hipStreamSynchronize(c->side));
+      std::memcpy(out, c->pre_pin + pf.off, pf.count * sizeof(double));
+      pf.pending = false;
+      return 0;
+    }
   HIP_OK(hipStreamSynchronize(c->stream));
   const long count = idto_hip_array_size(c, what);
   if (count < 0) { g_err = "unknown array id"; return -1; }

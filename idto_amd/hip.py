@@ -58,6 +58,9 @@ def lib():
         L.idto_hip_solve_host.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double)]
         L.idto_hip_constraint_schur.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double),
                                                 C.POINTER(C.c_double)]
+        L.idto_hip_constraint_schur_begin.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
+        L.idto_hip_prefetch.argtypes = [C.c_void_p, C.c_int]
+        L.idto_hip_constraint_solve.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 4
         L.idto_hip_constraint_step.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                                C.POINTER(C.c_double)]
         L.idto_hip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
@@ -77,7 +80,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "idto_hip_last_error", "idto_hip_create", "idto_hip_destroy", "idto_hip_set_problem", "idto_hip_set_stream",
     "idto_hip_get_stream", "idto_hip_set_shard", "idto_hip_set_q", "idto_hip_set_q_device", "idto_hip_eval_tau", "idto_hip_trial_cost", "idto_hip_constraint_schur",
-    "idto_hip_constraint_step",
+    "idto_hip_constraint_schur_begin", "idto_hip_constraint_solve", "idto_hip_constraint_step", "idto_hip_prefetch",
     "idto_hip_eval_partials", "idto_hip_grad_hess", "idto_hip_factor_solve", "idto_hip_gn_step", "idto_hip_solve_host",
     "idto_hip_set_option",
     "idto_hip_timing_enable", "idto_hip_timing_reset", "idto_hip_timing_get", "idto_hip_sync", "idto_hip_get",
@@ -157,6 +160,19 @@ class HipPath:
                                              S.ctypes.data_as(C.POINTER(C.c_double)), dptr(Jy)))
         return S, Jy
 
+    def constraint_solve(self, dofs, h):
+        """multipliers entirely on the device: returns (ok, lambda, H^-1 (g + J^T lambda), J^T lambda);
+        ok False: S numerically singular, use constraint_schur + a pivoted host solve"""
+        dofs = np.ascontiguousarray(np.asarray(dofs, dtype=np.int32))
+        h = np.ascontiguousarray(np.asarray(h, dtype=np.float64))
+        n = (self.N + 1) * self.nq
+        _chk(lib().idto_hip_constraint_schur_begin(self.h, dofs.ctypes.data_as(C.POINTER(C.c_int)), int(dofs.size)))
+        lam, step, jtl = np.empty(h.size), np.empty(n), np.empty(n)
+        rc = lib().idto_hip_constraint_solve(self.h, dptr(h), dptr(lam), dptr(step), dptr(jtl))
+        if rc not in (0, 1):
+            _chk(rc)
+        return rc == 0, lam, step, jtl
+
     def constraint_step(self, lam):
         """H^-1 (g + J^T lambda) and J^T lambda, from the factors kept by constraint_schur"""
         lam = np.ascontiguousarray(np.asarray(lam, dtype=np.float64))
@@ -223,6 +239,10 @@ class HipPath:
     @property
     def slab_stride(self):
         return lib().idto_hip_slab_stride(self.h)
+
+    def prefetch(self, name):
+        """enqueue the copy of a contiguous array now; the next get(name) waits only for it"""
+        _chk(lib().idto_hip_prefetch(self.h, ARR[name]))
 
     def get(self, name):
         out = np.zeros(self.array_size(name))

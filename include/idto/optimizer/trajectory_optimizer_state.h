@@ -58,7 +58,8 @@ class TrajectoryOptimizerState {
   friend class TrajectoryOptimizer<T>;
   struct Cache {
     bool traj = false, kin = false, vpart = false, deriv = false, grad = false, hess = false, scale = false, shess = false, sgrad = false,
-         h = false, J = false, lambda = false, merit = false, mgrad = false, hinv = false, uploaded = false;
+         h = false, J = false, lambda = false, merit = false, mgrad = false, hinv = false, uploaded = false,
+         step_on_device = false;  // -H^-1 g of this state was launched with the assembly
     std::vector<std::vector<T>> v, a, tau;
     std::vector<MatrixXd> nplus;
     T cost = 0;

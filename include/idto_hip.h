@@ -119,7 +119,20 @@ int idto_hip_solve_host(idto_hip_ctx* ctx, const double* rhs_host, int nrhs, dou
  *   idto_hip_constraint_step: given the multipliers lambda (n_eq, host) returns
  *     H^-1 (g + J^T lambda) and J^T lambda (both (N+1)*nq) to host memory. */
 int idto_hip_constraint_schur(idto_hip_ctx* ctx, const int* dofs, int nu, double* S_host, double* Jy_host);
+/* Only enqueues the work of idto_hip_constraint_schur (no synchronisation; a no-op if it is
+ * already enqueued for the current Hessian); a following idto_hip_constraint_schur with the same
+ * dofs waits for it and returns the results. */
+int idto_hip_constraint_schur_begin(idto_hip_ctx* ctx, const int* dofs, int nu);
 int idto_hip_constraint_step(idto_hip_ctx* ctx, const double* lambda_host, double* step_host, double* jtl_host);
+/* The whole multiplier computation on the device, after idto_hip_constraint_schur_begin: uploads
+ * the constraint violations h (n_eq), factorises S = J H^-1 J^T there (blocked LDL^T without
+ * pivoting, csrc/dense_ldl.h), solves S lambda = h - J H^-1 g and returns lambda (n_eq),
+ * H^-1 (g + J^T lambda) and J^T lambda (both (N+1)*nq) - one synchronisation, S never leaves
+ * the device.  Returns 1 (outputs untouched) when S is numerically singular (smallest pivot
+ * <= 1e-13 x largest): the caller then uses idto_hip_constraint_schur + a pivoted factorisation
+ * on the host + idto_hip_constraint_step, as Eigen's ldlt() tolerates semi-definite S. */
+int idto_hip_constraint_solve(idto_hip_ctx* ctx, const double* h_host, double* lambda_host, double* step_host,
+                              double* jtl_host);
 
 /* Options: "gradients_method" = 0 forward differences (default), 1 / 2 central differences of
  * 2nd / 4th order (SolverParameters::gradients_method, reference solver_parameters.h:26-50,
@@ -142,6 +155,11 @@ int idto_hip_timing_reset(idto_hip_ctx* ctx);
 int idto_hip_timing_get(idto_hip_ctx* ctx, int which, double* avg_ms, int* launches);
 
 int idto_hip_sync(idto_hip_ctx* ctx);
+/* Enqueues, behind the work submitted so far, an asynchronous copy of array `what` (a
+ * contiguous one: not TAU / DTAU_*) to pinned staging memory on a side stream.  The next
+ * idto_hip_get of the same array waits for that copy only - not for kernels launched after
+ * the prefetch (how the host loop reads g and the Hessian bands while the solver runs). */
+int idto_hip_prefetch(idto_hip_ctx* ctx, int what);
 /* Synchronises and copies array `what` to host memory (sizes above). */
 int idto_hip_get(idto_hip_ctx* ctx, int what, double* host_out);
 /* Raw device pointer / element count of a resident array (for zero-copy interop). */

@@ -197,3 +197,53 @@ def test_linesearch_method_tracks_the_oracle(name, ls, eq):
     assert np.all(np.isnan(st.trust_region_radii))
     assert np.abs(sol.q - ref["q"]).max() <= 1e-5 * max(1.0, np.abs(ref["q"]).max())
     assert st.iteration_costs[-1] < st.iteration_costs[0]
+
+
+@pytest.mark.parametrize("name,N", [("spinner", 12), ("hopper", 20), ("hopper", 50), ("allegro_hand", 12),
+                                    ("mini_cheetah", 40)])
+def test_constraint_step_on_the_device(name, N):
+    """idto_hip_constraint_solve (S = J H^-1 J^T factorised on the device, blocked LDL^T) against
+    dense linear algebra on the oracle's H and J: lambda, H^-1 (g + J^T lambda), J^T lambda."""
+    import oracle_lib as ol
+    from idto_amd import hip
+    from idto_amd.problem import synthetic_trajectory
+    cfg, model = load_config(name), load_model(name)
+    prob, sp, _ = make_problem(cfg, model, num_steps=N)
+    sp.scaling, sp.equality_constraints = False, True
+    q = synthetic_trajectory(cfg, model, N, seed=3, lower=0.02)
+    orc = Oracle(model, prob, sp)
+    dofs = [j for j in range(model.nv) if not model.actuated[j]] or [0, 1]
+    g, bands = orc.grad_hess(q)
+    H = ol.penta_make_dense(*bands)
+    P = orc.eval_partials(q)
+    nq, nv, neq = model.nq, model.nv, len(dofs) * N
+    J = np.zeros((neq, (N + 1) * nq))
+    for t in range(N):
+        for i, dof in enumerate(dofs):
+            r = t * len(dofs) + i
+            J[r, (t + 1) * nq:(t + 2) * nq] = P["dtau_dqp"][t][dof]      # blocks are (nv, nq)
+            if t > 0:
+                J[r, t * nq:(t + 1) * nq] = P["dtau_dqt"][t][dof]
+            if t > 1:
+                J[r, (t - 1) * nq:t * nq] = P["dtau_dqm"][t][dof]
+    _, _, tau, _ = orc.eval_traj(q)
+    h = np.asarray(tau).reshape(N, nv)[:, dofs].ravel()
+    Y = np.linalg.solve(H, np.column_stack([g, J.T]))
+    S = J @ Y[:, 1:]
+    lam_ref = np.linalg.solve(S, h - J @ Y[:, 0])
+    step_ref = Y[:, 0] + Y[:, 1:] @ lam_ref
+    dev = hip.HipPath(model, prob, sp)
+    dev.set_q(q); dev.eval_partials(); dev.grad_hess()
+    ok, lam, step, jtl = dev.constraint_solve(dofs, h)
+    assert ok
+    # both sides solve with H (cond up to 1e10 for the hopper) and S: round-off ~ cond * eps
+    tol = max(1e-9, 50 * np.finfo(float).eps * max(np.linalg.cond(S), np.linalg.cond(H)))
+    assert np.abs(lam - lam_ref).max() <= tol * np.abs(lam_ref).max()
+    assert np.abs(jtl - J.T @ lam_ref).max() <= tol * np.abs(J.T @ lam_ref).max()
+    assert np.abs(step - step_ref).max() <= tol * np.abs(step_ref).max()
+    # the two-call path (host factorisation) gives the same multipliers
+    S_dev, Jy_dev = dev.constraint_schur(dofs)
+    assert np.abs(S_dev - S).max() <= 1e-8 * np.abs(S).max()
+    lam2 = np.linalg.solve(S_dev, h - Jy_dev)
+    assert np.abs(lam2 - lam).max() <= tol * np.abs(lam).max()
+    dev.close()
