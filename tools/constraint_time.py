@@ -21,7 +21,7 @@ for name, N in cases:
         t0 = time.perf_counter()
         for _ in range(reps): f()
         return 1e6 * (time.perf_counter() - t0) / reps
-    t_schur = timeit(lambda: dev.constraint_schur(dofs))
+    t_schur = timeit(lambda: (dev.grad_hess(), dev.constraint_schur(dofs)))  # (grad_hess: a new Hessian each time)
     S, Jy = dev.constraint_schur(dofs)
     lam = np.linalg.solve(S + 1e-9 * np.eye(neq), -Jy)
     t_step = timeit(lambda: dev.constraint_step(lam))
@@ -31,7 +31,7 @@ for name, N in cases:
     rhs = torch.randn(neq + 1, n, dtype=torch.float64, device="cuda"); x = torch.zeros_like(rhs)
     t_multi = timeit(lambda: (dev.factor_solve(rhs.data_ptr(), neq + 1, x.data_ptr()), dev.sync()))
     t_two = timeit(lambda: (dev.factor_solve(rhs.data_ptr(), 2, x.data_ptr()), dev.sync()))
-    print(f"{name:13s} N={N} n_eq={neq}: constraint_schur {t_schur:8.1f} us, constraint_step {t_step:6.1f} us, "
+    print(f"{name:13s} N={N} n_eq={neq}: grad_hess + constraint_schur {t_schur:8.1f} us, constraint_step {t_step:6.1f} us, "
           f"single-rhs factor_solve {t_one:6.1f} us, {neq + 1}-rhs factor_solve (device buffers) {t_multi:6.1f} us, "
           f"2-rhs {t_two:6.1f} us")
     dev.close()
