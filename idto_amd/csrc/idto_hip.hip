@@ -66,7 +66,7 @@ struct idto_hip_ctx {
   bool reference_solver = false;  // bit-exact pivoted-LU block Thomas (kernels.h penta_kernel)
   int asm_diag_lds = 0;
   // launch geometry
-  int fd_threads = 256, fd_lds = 0, tau_lds = 0, asm_lds = 0, penta_lds = 0, solve_lds = 0, cost_lds = 0;
+  int fd_threads = 256, fd_lds = 0, asm_lds = 0, penta_lds = 0, solve_lds = 0, cost_lds = 0;
   // timing
   bool timing = false;
   int timing_stride = 1;     // record events on every timing_stride-th launch of each kernel
@@ -401,9 +401,9 @@ int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem, co
   int threads = ((E * K + 63) / 64) * 64;
   if (threads > 256) threads = 256;  // one wave per SIMD: the evaluation keeps its bodies in up to 512 VGPRs
   c->fd_threads = threads;
-  auto fd_lds = [&](int Ecount) { return (int)sizeof(double) * (3 * nq + 2 * (int)bsz + 3 * nv + Ecount + Ecount * nq + 3 * Ecount * nv + nv + c->M.blob_n + 2 + nq / 2 + 2); };
-  c->fd_lds = fd_lds(E);
-  c->tau_lds = fd_lds(1);
+  // smallest LDS carve-up of the finite-difference kernel: the inputs of one round of concurrent
+  // evaluations per pass (LaunchFd uses more when they fit)
+  c->fd_lds = FdLds(c, 1, threads / K);
   c->asm_lds = (int)sizeof(double) * (3 * nq + 5 * (int)bsz + 4 * nv + nq + std::max(nq, nv) + (int)bsz + 3 * (int)qq + nq);
   c->asm_diag_lds = (int)sizeof(double) * (14 * ((nv + 1) & ~1) * nq + 2 * (int)bsz + 10 * nv + 6 * nq + 2);
   const int n = N + 1;
