@@ -247,3 +247,27 @@ def test_constraint_step_on_the_device(name, N):
     lam2 = np.linalg.solve(S_dev, h - Jy_dev)
     assert np.abs(lam2 - lam).max() <= tol * np.abs(lam).max()
     dev.close()
+
+
+def test_constraint_solve_reports_a_singular_schur_complement():
+    """redundant constraints (the same dof listed twice: two identical rows of J) make S = J H^-1 J^T
+    exactly singular: the device factorisation (no pivoting) must say so instead of returning
+    garbage, and the two-call path still serves the caller's pivoted solve"""
+    from idto_amd import hip
+    from idto_amd.problem import synthetic_trajectory
+    cfg, model = load_config("hopper"), load_model("hopper")
+    N = 10
+    prob, sp, _ = make_problem(cfg, model, num_steps=N)
+    q = synthetic_trajectory(cfg, model, N, seed=1, lower=0.02)
+    dev = hip.HipPath(model, prob, sp)
+    dev.set_q(q); dev.eval_partials(); dev.grad_hess()
+    dofs = [0, 1, 1]
+    ok, lam, step, jtl = dev.constraint_solve(dofs, np.zeros(len(dofs) * N))
+    assert not ok
+    S, Jy = dev.constraint_schur(dofs)   # S is formed again from Y (the factorisation overwrote it)
+    assert np.all(np.isfinite(S)) and np.abs(S - S.T).max() <= 1e-9 * np.abs(S).max()
+    assert np.allclose(S[1::3, :], S[2::3, :], rtol=1e-12, atol=0)   # duplicated rows
+    lam = np.linalg.lstsq(S, -Jy, rcond=None)[0]
+    step, jtl = dev.constraint_step(lam)
+    assert np.all(np.isfinite(step)) and np.all(np.isfinite(jtl))
+    dev.close()
