@@ -218,10 +218,12 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
   // prefetch / write back; with a single helper wavefront it does everything.
   const int nhelp = NW - gj_waves;
   const bool g_wave = wave == gj_waves;                         // forms G
-  const int io_first = (nhelp > 1) ? gj_waves + 1 : gj_waves;   // first wavefront doing the I/O
+  // (with only two helpers the one that forms G shares the I/O: a lone I/O wavefront is the
+  // bottleneck of the K = 23 / 24 instantiations, 10.6k cycles per row against 3.4k for G)
+  const int io_first = (nhelp > 2) ? gj_waves + 1 : gj_waves;   // first wavefront doing the I/O
   const int ht = tid - io_first * 64;                           // index among the I/O threads (< 0: none)
   const int hn = nt - io_first * 64;
-  constexpr int HN_MIN = GJW ? ((NT / 64 - GJW > 1) ? NT - (GJW + 1) * 64 : NT - GJW * 64) : 64;
+  constexpr int HN_MIN = GJW ? ((NT / 64 - GJW > 2) ? NT - (GJW + 1) * 64 : NT - GJW * 64) : 64;
   constexpr int PMAX = (3 * KK + HN_MIN - 1) / HN_MIN;
   // Branch-free: every I/O lane loads PMAX values per row through 32-bit offsets from HA (the
   // three bands live in one allocation); lanes/slots without a source load element 0 and the
