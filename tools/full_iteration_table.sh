@@ -18,6 +18,9 @@ cfg = load_config(name); model = load_model(name)
 prob, sp, q_guess = make_problem(cfg, model, num_steps=N)
 iters = 20 if name != "allegro_hand" else 6
 sp.max_iterations, sp.verbose = iters, False
+sp.num_threads = 1
+if name != "allegro_hand":
+    Oracle(model, prob, sp).solve(q_guess)  # warm-up (page-in, OpenMP pool)
 for nt in (1, 4):
     sp.num_threads = nt
     t0 = time.perf_counter(); Oracle(model, prob, sp).solve(q_guess)
