@@ -171,7 +171,12 @@ def main():
     exch = None
     if world > 1:
         from idto_amd.multi_gpu import SlabExchange, device_slab_view
-        exch = SlabExchange(dist, device_slab_view(dev, N), N, dev.slab_stride, rank, world)
+        try:
+            exch = SlabExchange(dist, device_slab_view(dev, N), N, dev.slab_stride, rank, world)
+        except Exception as e:  # replicas need no exchange: never let the extra measurement cost the metric
+            if sharded:
+                raise
+            print(f"[bench] rank {rank}: slab exchange unavailable ({e}); skipping the shard_mode extra", file=sys.stderr)
 
     def step_sharded():
         dev.eval_partials()
@@ -221,7 +226,13 @@ def main():
     assert np.all(np.isfinite(p)) and np.all(np.isfinite(g))
 
     shard_extra = None
-    if world > 1 and not sharded:
+    do_extra = False
+    if world > 1 and not sharded:  # every rank must agree, or the collectives below would hang
+        okt = torch.tensor([1.0 if (exch is not None and not os.environ.get("IDTO_BENCH_NO_SHARD_EXTRA")) else 0.0],
+                           device="cuda", dtype=torch.float64)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        do_extra = bool(okt.item() > 0.5)
+    if do_extra:
         # the sharded single-problem mode on the same ranks (outside the timed region of `value`)
         dev.set_q(synthetic_trajectory(cfg, model, N, seed=0, lower=0.01))
         dev.gn_step()
