@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <initializer_list>
 #include <limits>
 #include <string>
 #include <vector>
@@ -333,6 +334,13 @@ int EnsureStage(idto_hip_ctx* c, size_t count) {
   }
   return 0;
 }
+// a pending idto_hip_prefetch of an array is dropped when that array is about to be recomputed
+// (idto_hip_get then reads the new contents instead of the stale staged copy)
+void DropPrefetch(idto_hip_ctx* c, std::initializer_list<int> arrays) {
+  for (auto& pf : c->pre)
+    for (int a : arrays)
+      if (pf.what == a) pf.pending = false;
+}
 }  // namespace
 
 extern "C" {
@@ -480,6 +488,7 @@ int idto_hip_set_shard(idto_hip_ctx* c, int kb, int ke) {
 
 int idto_hip_set_q(idto_hip_ctx* c, const double* q_host) {
   HIP_OK(hipSetDevice(c->device));
+  DropPrefetch(c, {IDTO_ARR_Q});
   c->fd_full = false;
   c->con_ready = false; c->con_begun = false;
   HIP_OK(hipMemcpyAsync(c->q, q_host, (size_t)(c->N + 1) * c->nq * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -488,6 +497,7 @@ int idto_hip_set_q(idto_hip_ctx* c, const double* q_host) {
 }
 int idto_hip_set_q_device(idto_hip_ctx* c, const double* q_dev) {
   HIP_OK(hipSetDevice(c->device));
+  DropPrefetch(c, {IDTO_ARR_Q});
   c->fd_full = false;
   c->con_ready = false; c->con_begun = false;
   HIP_OK(hipMemcpyAsync(c->q, q_dev, (size_t)(c->N + 1) * c->nq * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -496,6 +506,7 @@ int idto_hip_set_q_device(idto_hip_ctx* c, const double* q_dev) {
 
 int idto_hip_eval_tau(idto_hip_ctx* c) {
   HIP_OK(hipSetDevice(c->device));
+  DropPrefetch(c, {IDTO_ARR_V, IDTO_ARR_A, IDTO_ARR_NPLUS, IDTO_ARR_SLAB, IDTO_ARR_COST});
   int rc = LaunchFd(c, 0, 0, c->N);
   if (rc) return rc;
   hipLaunchKernelGGL(cost_kernel, dim3(1), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
@@ -507,6 +518,7 @@ int idto_hip_eval_tau(idto_hip_ctx* c) {
 int idto_hip_trial_cost(idto_hip_ctx* c, const double* q_host, double* tau_host, double* cost_host) {
   HIP_OK(hipSetDevice(c->device));
   if (!q_host || !cost_host) { g_err = "trial_cost: bad arguments"; return -1; }
+  DropPrefetch(c, {IDTO_ARR_Q, IDTO_ARR_V, IDTO_ARR_A, IDTO_ARR_NPLUS, IDTO_ARR_SLAB, IDTO_ARR_COST});
   const size_t nq_all = (size_t)(c->N + 1) * c->nq, ntau = (size_t)c->N * c->nv;
   if (!c->pin) {
     if (Alloc(c, ntau + 1, &c->pack)) return -2;
@@ -533,6 +545,7 @@ int idto_hip_trial_cost(idto_hip_ctx* c, const double* q_host, double* tau_host,
 
 int idto_hip_eval_partials(idto_hip_ctx* c) {
   HIP_OK(hipSetDevice(c->device));
+  DropPrefetch(c, {IDTO_ARR_V, IDTO_ARR_A, IDTO_ARR_NPLUS, IDTO_ARR_SLAB});
   c->con_ready = false; c->con_begun = false;
   if (TimeBegin(c, 0)) return -2;
   int rc = LaunchFd(c, 1, c->k_begin, c->k_end);
@@ -543,6 +556,7 @@ int idto_hip_eval_partials(idto_hip_ctx* c) {
 
 int idto_hip_grad_hess(idto_hip_ctx* c) {
   HIP_OK(hipSetDevice(c->device));
+  DropPrefetch(c, {IDTO_ARR_GRADIENT, IDTO_ARR_H_A, IDTO_ARR_H_B, IDTO_ARR_H_C, IDTO_ARR_HBANDS});
   c->con_ready = false; c->con_begun = false;
   if (TimeBegin(c, 1)) return -2;
   if (c->weights_diagonal)
@@ -621,6 +635,7 @@ static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, int nrhs, do
 
 int idto_hip_factor_solve(idto_hip_ctx* c, const double* rhs, int nrhs, double* x) {
   HIP_OK(hipSetDevice(c->device));
+  if (!rhs) DropPrefetch(c, {IDTO_ARR_STEP});
   const int n = c->N + 1, k = c->nq;
   const double* b = rhs ? rhs : c->g;
   double* xo = rhs ? x : c->step;

@@ -158,7 +158,8 @@ int idto_hip_sync(idto_hip_ctx* ctx);
 /* Enqueues, behind the work submitted so far, an asynchronous copy of array `what` (a
  * contiguous one: not TAU / DTAU_*) to pinned staging memory on a side stream.  The next
  * idto_hip_get of the same array waits for that copy only - not for kernels launched after
- * the prefetch (how the host loop reads g and the Hessian bands while the solver runs). */
+ * the prefetch (how the host loop reads g and the Hessian bands while the solver runs).  A
+ * pending prefetch is dropped if the array is recomputed before it is read. */
 int idto_hip_prefetch(idto_hip_ctx* ctx, int what);
 /* Synchronises and copies array `what` to host memory (sizes above). */
 int idto_hip_get(idto_hip_ctx* ctx, int what, double* host_out);

@@ -307,3 +307,29 @@ def test_trial_cost_equals_set_q_eval_tau():
     tau2, cost2 = dev.trial_cost(q2)   # second call reuses the staging buffers
     _, _, tau2_ref, cost2_ref = orc.eval_traj(q2)
     assert same(tau2, tau2_ref) and cost2 == cost2_ref
+
+
+def test_prefetch_semantics():
+    """idto_hip_prefetch: get() returns the array as of the prefetch even though later kernels
+    have been launched (and are still running); a prefetch that became stale is dropped"""
+    model, prob, sp, q = setup("mini_cheetah", 20, 2, 0.02)
+    dev = hip.HipPath(model, prob, sp)
+    dev.set_q(q)
+    dev.eval_partials(); dev.grad_hess()
+    g_ref, H_ref = dev.get("gradient"), dev.get("hbands")
+    # enqueue the copies, then more work on the main stream, then read
+    dev.grad_hess()
+    dev.prefetch("gradient"); dev.prefetch("hbands")
+    dev.factor_solve()
+    assert np.array_equal(dev.get("gradient"), g_ref) and np.array_equal(dev.get("hbands"), H_ref)
+    p = dev.get("step")
+    assert np.all(np.isfinite(p))
+    # stale prefetch: the gradient is recomputed for another q before it is read
+    dev.prefetch("gradient")
+    q2 = q.copy(); q2[1:] += 1e-3
+    dev.set_q(q2); dev.eval_partials(); dev.grad_hess()
+    g2 = dev.get("gradient")
+    assert not np.array_equal(g2, g_ref)
+    dev.sync()
+    assert np.array_equal(g2, dev.get("gradient"))
+    dev.close()
