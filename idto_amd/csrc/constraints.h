@@ -57,32 +57,39 @@ __global__ void constraint_schur_kernel(const double* __restrict__ slab, int sla
   }
 }
 
-// workgroup <-> 64 consecutive variables i, 4 wavefronts splitting the sum over r:
-// out_step[i] = y_g[i] + sum_r Y_{1+r}[i] lambda[r] (partial sums of the four wavefronts added in
-// wavefront order); out_jtl[i] = sum_r J[r, i] lambda[r] (ascending r; only the rows of the three
-// time steps around i's own are non-zero)
-__global__ void __launch_bounds__(256)
+// workgroup <-> 64 consecutive variables i, STEP_WAVES wavefronts splitting the sum over r (the sum
+// is a chain of dependent loads per thread: 16 short chains instead of one of n_eq terms):
+// out_step[i] = y_g[i] + sum_r Y_{1+r}[i] lambda[r] (partial sums added in wavefront order);
+// out_jtl[i] = sum_r J[r, i] lambda[r] (ascending r; only the rows of the three time steps around
+// i's own are non-zero)
+constexpr int STEP_WAVES = 16;
+__global__ void __launch_bounds__(64 * STEP_WAVES)
 constraint_step_kernel(const double* __restrict__ slab, int slab_stride, const int* __restrict__ dofs,
                        int nu, int N, int nq, int nv, const double* __restrict__ Y, int neq,
                        const double* __restrict__ lambda, double* __restrict__ out_step,
                        double* __restrict__ out_jtl) {
-  extern __shared__ double lam[];  // [neq] + [4][64] partial sums
+  extern __shared__ double lam[];  // [neq] + [STEP_WAVES][64] partial sums
   double* part = lam + neq;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int r = threadIdx.x; r < neq; r += blockDim.x) lam[r] = lambda[r];
   __syncthreads();
   const int n = (N + 1) * nq, i = blockIdx.x * 64 + lane;
-  const int per = (neq + 3) / 4, r0 = w * per, r1 = (r0 + per < neq) ? r0 + per : neq;
+  const int per = (neq + STEP_WAVES - 1) / STEP_WAVES, r0 = w * per, r1 = (r0 + per < neq) ? r0 + per : neq;
   double acc = 0.0;
   if (i < n)
     for (int r = r0; r < r1; ++r) acc += Y[(size_t)(1 + r) * n + i] * lam[r];
   part[w * 64 + lane] = acc;
   __syncthreads();
-  if (w != 0 || i >= n) return;
-  out_step[i] = (((Y[i] + part[lane]) + part[64 + lane]) + part[128 + lane]) + part[192 + lane];
-  const int ti = i / nq;
-  double jt = 0.0;
-  for (int t = (ti >= 1 ? ti - 1 : 0); t <= ti + 1 && t < N; ++t)
-    for (int j = 0; j < nu; ++j) jt += jac_entry(slab, slab_stride, nq, nv, t, dofs[j], N, i) * lam[t * nu + j];
-  out_jtl[i] = jt;
+  if (i >= n) return;
+  if (w == 0) {
+    double tot = Y[i];
+    for (int ww = 0; ww < STEP_WAVES; ++ww) tot += part[ww * 64 + lane];
+    out_step[i] = tot;
+  } else if (w == 1) {
+    const int ti = i / nq;
+    double jt = 0.0;
+    for (int t = (ti >= 1 ? ti - 1 : 0); t <= ti + 1 && t < N; ++t)
+      for (int j = 0; j < nu; ++j) jt += jac_entry(slab, slab_stride, nq, nv, t, dofs[j], N, i) * lam[t * nu + j];
+    out_jtl[i] = jt;
+  }
 }

@@ -797,7 +797,7 @@ int idto_hip_constraint_solve(idto_hip_ctx* c, const double* h_host, double* lam
   // lambda = S^-1 (h - J y_g)
   hipLaunchKernelGGL(dense_ldl_solve_kernel, dim3(1), dim3(512), (neq + 512 + DENSE_NB * (DENSE_NB + 1)) * sizeof(double), c->stream, S, neq, c->con_d,
                      S + (size_t)neq * neq, -1.0, c->con_h + 2, c->con_lambda + 2);
-  hipLaunchKernelGGL(constraint_step_kernel, dim3((n + 63) / 64), dim3(256), (neq + 256) * sizeof(double), c->stream, c->slab,
+  hipLaunchKernelGGL(constraint_step_kernel, dim3((n + 63) / 64), dim3(64 * STEP_WAVES), (neq + 64 * STEP_WAVES) * sizeof(double), c->stream, c->slab,
                      c->slab_stride, c->con_dofs, c->con_nu, N, c->nq, c->nv, c->stage_x, neq, c->con_lambda + 2,
                      c->con_out, c->con_out + n);
   HIP_OK(hipGetLastError());
@@ -823,7 +823,7 @@ int idto_hip_constraint_step(idto_hip_ctx* c, const double* lambda_host, double*
   double* pl = c->con_pin + (size_t)neq * neq + neq;  // [lambda | step | J^T lambda]
   std::memcpy(pl, lambda_host, (size_t)neq * sizeof(double));
   HIP_OK(hipMemcpyAsync(c->con_lambda, pl, (size_t)neq * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(constraint_step_kernel, dim3((n + 63) / 64), dim3(256), (neq + 256) * sizeof(double), c->stream, c->slab,
+  hipLaunchKernelGGL(constraint_step_kernel, dim3((n + 63) / 64), dim3(64 * STEP_WAVES), (neq + 64 * STEP_WAVES) * sizeof(double), c->stream, c->slab,
                      c->slab_stride, c->con_dofs, c->con_nu, N, c->nq, c->nv, c->stage_x, neq, c->con_lambda, c->con_out,
                      c->con_out + n);
   HIP_OK(hipGetLastError());
