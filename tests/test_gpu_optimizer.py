@@ -271,3 +271,43 @@ def test_constraint_solve_reports_a_singular_schur_complement():
     step, jtl = dev.constraint_step(lam)
     assert np.all(np.isfinite(step)) and np.all(np.isfinite(jtl))
     dev.close()
+
+
+def test_equality_constraints_and_scaling_invariants():  # TO_test.cc:1637-1751, on the device path
+    """hopper without ground: the multipliers do not depend on the scaling and equal the dense
+    formula (J H^-1 J^T)^-1 (h - J H^-1 g); the merit function is the same; the scaled merit
+    gradient is D times the unscaled one; the trust ratio of the Newton step is the same and > 0.6"""
+    import oracle_lib as ol
+    from idto_amd.problem import ProblemDefinition, SolverParameters
+    model = load_model("hopper_no_ground")
+    N, dt = 5, 1e-2
+    q_init = np.array([0.0, 0.6, 0.3, -0.5, 0.2])
+    v_init = np.array([1.0, -0.2, 0.1, -0.3, 0.4])
+    prob = ProblemDefinition(num_steps=N, q_init=q_init, v_init=v_init, Qq=0.1 * np.eye(5), Qv=0.2 * np.eye(5),
+                             Qf_q=0.3 * np.eye(5), Qf_v=0.4 * np.eye(5), R=0.01 * np.eye(5),
+                             q_nom=np.tile([0.5, 0.5, 0.3, -0.4, 0.1], (N + 1, 1)),
+                             v_nom=np.tile([0.01, 0.0, 0.2, 0.1, -0.1], (N + 1, 1)), time_step=dt)
+    sp_u = SolverParameters(verbose=False, scaling=False, equality_constraints=True)
+    sp_s = SolverParameters(verbose=False, scaling=True, equality_constraints=True)
+    opt_u, opt_s = TrajectoryOptimizer(model, prob, sp_u), TrajectoryOptimizer(model, prob, sp_s)
+    q = np.array([q_init + dt * t * v_init for t in range(N + 1)])
+    e, es = opt_u.eval(q), opt_s.eval(q)
+    D = es["scale_factors"]
+    assert np.all(e["scale_factors"] == 1.0) or np.allclose(e["scaled_gradient"], e["gradient"])
+    # dense formula with the oracle's H, J (bit-identical to the device's g, H, dtau/dq)
+    orc = Oracle(model, prob, sp_u)
+    ref = orc.eval_all(q)
+    g, bands = orc.grad_hess(q)
+    Hinv = np.linalg.inv(ol.penta_make_dense(*bands))
+    J, h = ref["J"], ref["h"]
+    lam_dense = np.linalg.solve(J @ Hinv @ J.T, h - J @ Hinv @ g)
+    lscale = max(1.0, np.abs(lam_dense).max())
+    assert e["lagrange_multipliers"].size == 3 * N
+    assert np.abs(lam_dense - e["lagrange_multipliers"]).max() <= 1e-8 * lscale
+    assert np.abs(lam_dense - es["lagrange_multipliers"]).max() <= 1e-8 * lscale
+    assert abs(e["merit"] - es["merit"]) <= 1e-9 * max(1.0, abs(e["merit"]))
+    assert np.abs(D * e["merit_gradient"] - es["merit_gradient"]).max() <= 1.5e-8 * max(1.0, np.abs(es["merit_gradient"]).max())
+    dq = -Hinv @ e["merit_gradient"]
+    rho, rho_s = opt_u.trust_ratio(q, dq), opt_s.trust_ratio(q, dq)
+    assert rho > 0.6
+    assert abs(rho - rho_s) <= 1e-7
