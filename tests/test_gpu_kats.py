@@ -178,3 +178,40 @@ def test_hessian_is_gauss_newton_of_residuals():  # TO_test.cc:496-637 (HessianA
             H[2 * i - 4:2 * i - 2, 2 * i:2 * i + 2] = A[i].T
     assert np.abs(H[2:, 2:] - H_gn[2:, 2:]).max() <= 1e-5 * np.abs(H).max()
     assert np.array_equal(H[:2, :2], np.eye(2)) and not H[:2, 2:].any()     # q_0 decoupled (TO.cc:1110-1113)
+
+
+def test_contact_gradient_methods():  # TO_test.cc:183-280 (the autodiff leg replaced by central differences)
+    """spinner_sphere, dt = 1, N = 2, the reference's q: tau is the same whatever the gradient
+    method, forward / central / 4th-order central partials agree to the reference's tolerances,
+    and each equals the oracle's bit for bit"""
+    from idto_amd.problem import ProblemDefinition, SolverParameters
+    from oracle_lib import Oracle
+    model = load_model("spinner_sphere")
+    N, dt = 2, 1.0
+    q = np.array([[0.2, 1.5, 0.0], [0.4, 1.5, 0.0], [0.3, 1.4, 0.0]])
+    sq = np.sqrt(np.finfo(float).eps)
+    out = {}
+    for meth in ("forward_differences", "central_differences", "central_differences4"):
+        prob = ProblemDefinition(num_steps=N, q_init=q[0], v_init=np.zeros(3), Qq=np.eye(3), Qv=np.eye(3),
+                                 Qf_q=np.eye(3), Qf_v=np.eye(3), R=np.eye(3), q_nom=np.zeros((N + 1, 3)),
+                                 v_nom=np.zeros((N + 1, 3)), time_step=dt)
+        sp = SolverParameters(verbose=False, gradients_method=meth)
+        dev = hip.HipPath(model, prob, sp)
+        dev.set_q(q)
+        dev.eval_partials()
+        out[meth] = (dev.get("tau"), {k: dev.get(k) for k in ("dtau_dqm", "dtau_dqt", "dtau_dqp")})
+        P = Oracle(model, prob, sp).eval_partials(q)
+        for k in ("dtau_dqm", "dtau_dqt", "dtau_dqp"):
+            a, b = out[meth][1][k], np.asarray(P[k])
+            assert np.all((a == b) | (np.isnan(a) & np.isnan(b))), (meth, k)
+        dev.close()
+    tau_f, Pf = out["forward_differences"]
+    tau_c, Pc = out["central_differences"]
+    _, Pc4 = out["central_differences4"]
+    assert np.array_equal(tau_f, tau_c)
+    assert np.abs(tau_f).max() > 0.1  # the contact is active in this configuration
+    close = lambda x, y, tol: bool(np.all(np.abs(x - y) <= tol * np.maximum(1.0, np.maximum(np.abs(x), np.abs(y)))))
+    for k in ("dtau_dqm", "dtau_dqt", "dtau_dqp"):
+        for t in range(1, N):
+            assert close(Pf[k][t], Pc[k][t], 100 * sq)
+            assert close(Pc4[k][t], Pc[k][t], 100 * sq)
