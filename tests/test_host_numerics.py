@@ -50,3 +50,40 @@ def test_dense_ldlt_needs_pivoting():
     b = np.array([0.0, 1.0, 2.0])
     x = ldlt_solve(S, b)
     assert np.allclose(S @ x, b, atol=1e-14) and np.all(np.isfinite(x))
+
+
+def test_solver_parameter_defaults():
+    """python_bindings/test/solver_parameters_test.py:8-58 (the defaults of solver_parameters.h:76-166),
+    for the Python mirror and for the C++ header (compiled and printed)"""
+    import os
+    import subprocess
+    import tempfile
+    from idto_amd.problem import SolverParameters
+    sp = SolverParameters()
+    assert (sp.max_iterations, sp.max_linesearch_iterations, sp.num_threads) == (100, 50, 1)
+    assert (sp.contact_stiffness, sp.dissipation_velocity, sp.stiction_velocity) == (100.0, 0.1, 0.05)
+    assert (sp.friction_coefficient, sp.smoothing_factor) == (0.5, 0.1)
+    assert sp.scaling is True and sp.equality_constraints is True and sp.verbose is True
+    assert (sp.Delta0, sp.Delta_max) == (0.1, 1e5)
+    assert sp.method == "trust_region" and sp.linesearch_method == "armijo"
+    assert sp.gradients_method == "forward_differences" and sp.scaling_method == "double_sqrt"
+    assert not sp.check_convergence and not sp.exact_hessian and not sp.normalize_quaternions
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = r'''
+#include <cstdio>
+#include "idto/optimizer/solver_parameters.h"
+int main() {
+  idto::optimizer::SolverParameters p;
+  std::printf("%d %d %d %g %g %g %g %g %d %d %d %g %g %d %d %d %d %d\n", p.max_iterations, p.max_linesearch_iterations,
+              p.num_threads, p.contact_stiffness, p.dissipation_velocity, p.stiction_velocity, p.friction_coefficient,
+              p.smoothing_factor, (int)p.scaling, (int)p.equality_constraints, (int)p.verbose, p.Delta0, p.Delta_max,
+              (int)p.method, (int)p.linesearch_method, (int)p.gradients_method, (int)p.scaling_method,
+              (int)p.linear_solver);
+}'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.cc"), "w").write(src)
+        subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(root, "include"), os.path.join(d, "t.cc"),
+                               "-o", os.path.join(d, "t")])
+        out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
+    assert out == ["100", "50", "1", "100", "0.1", "0.05", "0.5", "0.1", "1", "1", "1", "0.1", "100000",
+                   "1", "0", "0", "2", "1"], out
