@@ -95,6 +95,7 @@ struct idto_hip_ctx {
   double *con_W = nullptr, *con_d = nullptr, *con_h = nullptr;         // dense LDL^T: W = L D panel, pivots, [min, max | h]
   bool con_S_factored = false;                                         // con_S holds the LDL^T factors, not S
   double* con_pin = nullptr; size_t con_pin_count = 0;                 // pinned host staging for the above
+  bool h_assembled = false;                                            // H comes from idto_hip_grad_hess: block row 0 is the identity
   bool con_begun = false;                                              // constraint_schur_begin enqueued for the current H
   // idto_hip_prefetch: copies enqueued on a side stream behind an event of the main stream
   struct Prefetch { int what = -1; size_t off = 0, count = 0; bool pending = false; hipEvent_t ev = nullptr; };
@@ -557,6 +558,10 @@ int idto_hip_eval_partials(idto_hip_ctx* c) {
 int idto_hip_grad_hess(idto_hip_ctx* c) {
   HIP_OK(hipSetDevice(c->device));
   DropPrefetch(c, {IDTO_ARR_GRADIENT, IDTO_ARR_H_A, IDTO_ARR_H_B, IDTO_ARR_H_C, IDTO_ARR_HBANDS});
+  if (!c->h_assembled) {  // x_0 = -g_0 = 0 is no longer written by the solver (SolverFirstRow)
+    HIP_OK(hipMemsetAsync(c->step, 0, (size_t)c->nq * sizeof(double), c->stream));
+    c->h_assembled = true;
+  }
   c->con_ready = false; c->con_begun = false;
   if (TimeBegin(c, 1)) return -2;
   if (c->weights_diagonal)
@@ -570,8 +575,18 @@ int idto_hip_grad_hess(idto_hip_ctx* c) {
   return TimeEnd(c);
 }
 
+// Rows the fast solver works on.  The assembled Gauss-Newton Hessian has C_0 = I, B_1 = A_2 = 0
+// and g_0 = 0 (q_0 is not a decision variable, TO.cc:1093-1165): block row 0 is decoupled, so the
+// factorisation starts at row 1 (one block row less on the serial chain of the top workgroup)
+// and x_0 = rhs_0.  Bands written into the context behind the API's back get the full system.
+static int SolverFirstRow(const idto_hip_ctx* c) { return (c->h_assembled && c->N >= 2) ? 1 : 0; }
+
 static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, int nrhs, double* xo, bool one_sided = false) {
-  const int n = c->N + 1, k = c->nq;
+  const int r0 = (nrhs == 1) ? SolverFirstRow(c) : 0;
+  const int n = c->N + 1 - r0, k = c->nq;
+  const size_t qq0 = (size_t)r0 * k * k;
+  b += (size_t)r0 * k;
+  xo += (size_t)r0 * k;
   if (k > 32) { g_err = "fast solver supports nq <= 32"; return -1; }
   // block sizes of the reference's example models are instantiated exactly, others are padded
   const int K = (k == 2 || k == 3 || k == 5 || k == 19 || k == 23) ? k : (k <= 8 ? 8 : k <= 16 ? 16 : k <= 24 ? 24 : 32);
@@ -605,8 +620,8 @@ static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, int nrhs, do
     }
     ++c->epoch;
   }
-#define LDL_ARGS n, k, c->HA, c->HB, c->HC, b, sign, nrhs, xo, c->Ust, c->Hst, c->Est, c->Dst, dbg, m_split, c->xch, \
-                 c->flags, c->epoch
+#define LDL_ARGS n, k, c->HA + qq0, c->HB + qq0, c->HC + qq0, b, sign, nrhs, xo, c->Ust, c->Hst, c->Est, c->Dst, dbg, \
+                 m_split, c->xch, c->flags, c->epoch
 #define LDL_LAUNCH(KM, PD, GW)                                                                                \
   do {                                                                                                        \
     if (threads == 256 && gj_waves == GW)                                                                     \
@@ -658,20 +673,24 @@ int idto_hip_factor_solve(idto_hip_ctx* c, const double* rhs, int nrhs, double* 
   // long enough; the substitution kernel walks both chains of factors) ...
   const int K = (k == 2 || k == 3 || k == 5 || k == 19 || k == 23) ? k : (k <= 8 ? 8 : k <= 16 ? 16 : k <= 24 ? 24 : 32);
   int rc = LaunchLdl(c, b, rhs ? 1.0 : -1.0, 1, xo);
-  const int m_split = (c->two_sided && n >= 10) ? (n - 1) / 2 : 0;  // as LaunchLdl chose
+  const int r0 = SolverFirstRow(c), ns = n - r0;                      // the sub-system LaunchLdl factorised
+  const int m_split = (c->two_sided && ns >= 10) ? (ns - 1) / 2 : 0;  // as LaunchLdl chose
+  if (r0 && rhs)  // x_0 = rhs_0 for every column (row 0 of H is the identity); the default rhs has g_0 = 0 = x_0
+    HIP_OK(hipMemcpy2DAsync(x, (size_t)n * k * sizeof(double), rhs, (size_t)n * k * sizeof(double), (size_t)k * sizeof(double),
+                            (size_t)nrhs, hipMemcpyDeviceToDevice, c->stream));
   if (rc) return rc;
   if (nrhs > 1) {
     // ... then substitute the other right-hand sides in parallel: one wavefront each
     const int waves = 4, blocks = (nrhs - 1 + waves - 1) / waves;
-    const int lds = waves * n * K * (int)sizeof(double);
-    const double* b1 = b + (size_t)n * k;
-    double* x1 = xo + (size_t)n * k;
+    const int lds = waves * ns * K * (int)sizeof(double);
+    const double* b1 = b + (size_t)n * k + (size_t)r0 * k;
+    double* x1 = xo + (size_t)n * k + (size_t)r0 * k;
     if (!c->Tst && Alloc(c, (size_t)3 * (c->N + 1) * 32 * 36, &c->Tst)) return -2;
 #define APPLY_LAUNCH(KM)                                                                                          \
-    hipLaunchKernelGGL(penta_factor_transpose_kernel<KM>, dim3(n, 3), dim3(256), 0, c->stream, c->Ust, c->Hst,     \
+    hipLaunchKernelGGL(penta_factor_transpose_kernel<KM>, dim3(ns, 3), dim3(256), 0, c->stream, c->Ust, c->Hst,    \
                        c->Est, c->Tst);                                                                            \
-    hipLaunchKernelGGL(penta_apply_kernel<KM>, dim3(blocks), dim3(64 * waves), lds, c->stream, n, k, c->Ust, c->Hst, \
-                       c->Est, c->Dst, c->Tst, b1, rhs ? 1.0 : -1.0, nrhs - 1, x1, m_split)
+    hipLaunchKernelGGL(penta_apply_kernel<KM>, dim3(blocks), dim3(64 * waves), lds, c->stream, ns, k, c->Ust, c->Hst, \
+                       c->Est, c->Dst, c->Tst, b1, rhs ? 1.0 : -1.0, nrhs - 1, x1, m_split, (size_t)n * k)
     switch (K) {
       case 2: APPLY_LAUNCH(2); break;
       case 3: APPLY_LAUNCH(3); break;

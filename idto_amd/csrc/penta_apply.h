@@ -42,13 +42,14 @@ template <int K>
 __global__ void __launch_bounds__(256)
 penta_apply_kernel(int n, int k, const double* __restrict__ Ust, const double* __restrict__ Hst,
                    const double* __restrict__ Est, const double* __restrict__ Dst, const double* __restrict__ Tst,
-                   const double* __restrict__ rhs, double rhs_sign, int nrhs, double* __restrict__ x, int m_split) {
+                   const double* __restrict__ rhs, double rhs_sign, int nrhs, double* __restrict__ x, int m_split,
+                   size_t cstride) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.x * (blockDim.x >> 6) + wave;
   if (j >= nrhs) return;  // no barriers below
   constexpr int ks = ldl_ks(K), KS2 = K * ks, KP = (K + 1) / 2;
-  const size_t nk = (size_t)n * k;
+  const size_t nk = cstride;  // distance between right-hand sides (>= n * k: the caller may solve a sub-system)
   const int c = (lane < K) ? lane : K - 1;  // lanes >= K shadow lane K-1 (never stored)
   const bool live = lane < K;
   double* rtw = lds + (size_t)wave * n * K;  // rt_i[c] of this right-hand side, all rows (original index)

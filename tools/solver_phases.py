@@ -19,7 +19,7 @@ for _ in range(3):
     dev.gn_step()
 dev.sync()
 dall = dev.get("debug")
-n = N + 1
+n = N  # the solver skips the decoupled block row 0 of an assembled Hessian (idto_hip.hip SolverFirstRow)
 m = (n - 1) // 2 if (two and n >= 10) else 0
 sides = [(0, m + 2), (1, n - m - 2 + 2)] if m else [(0, n)]   # (side, forward rows incl. pseudo-rows)
 names = ["stage+sync", "products+sync", "load cols", "eliminate", "store+sync -> next row"]
