@@ -432,8 +432,34 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
                                       : ((lane < k && !pseudo) ? rhs_sign * b[(size_t)orig(i) * k + lane] : 0.0);
         Wm[3 * K * ks + lane] = (bval - lds[L.yh + ((i + 1) & 1) * ks + lane]) - lds[L.ye + ((i + 1) % 3) * ks + lane];
       }
-    } else if (wave >= 2 || NW < 3) {  // one thread per (rhs, row), spread over the wavefronts >= 2
-      const int w2 = (NW < 3) ? wave : wave - 2, nw2 = (NW < 3) ? NW : NW - 2;
+    } else if (gj_waves >= 2 && NW >= 4 && nrhs == 1 && K <= 32) {
+      // two elimination wavefronts, one right-hand side: wavefront 0 (one product tile only in this
+      // phase) forms y with the two mat-vecs on its two halves - lanes 0..31 (Ht_{i-1}^T Dn rt_{i-1})[r],
+      // lanes 32..63 (Et_{i-2}^T Dn rt_{i-2})[r] - and one cross-half exchange
+      if (wave == 0) {
+        const int r = lane & 31, hf = lane >> 5, rr2 = (r < K) ? r : 0;
+        const double2* m2 = reinterpret_cast<const double2*>((hf ? Etpp : Htp) + rr2 * ks);
+        const double2* dd2 = reinterpret_cast<const double2*>(hf ? Ivpp : Ivp);
+        const double2* rv2 = reinterpret_cast<const double2*>(hf ? rtpp : rtp);
+        double acc = 0;
+#pragma unroll
+        for (int m = 0; m < (K + 1) / 2; ++m) {
+          const double2 mm = m2[m], da = dd2[m], ra = rv2[m];
+          acc = __builtin_fma(mm.x * da.x, ra.x, acc);
+          acc = __builtin_fma(mm.y * da.y, ra.y, acc);
+        }
+        const double other = __shfl_xor(acc, 32);
+        if (hf == 0 && r < K) {
+          const double bval = L.bl_size ? lds[L.bl + i * K + r]
+                                        : ((r < k && !pseudo) ? rhs_sign * b[(size_t)orig(i) * k + r] : 0.0);
+          Wm[3 * K * ks + r] = (bval - acc) - other;
+        }
+      }
+    } else if ((gj_waves >= 2 && NW >= 4) ? (wave < 2) : (wave >= 2 || NW < 3)) {
+      // one thread per (rhs, row), spread over the wavefronts >= 2 - or, with two elimination
+      // wavefronts, over those two: they have the fewest product tiles in this phase
+      const bool first2 = gj_waves >= 2 && NW >= 4;
+      const int w2 = (NW < 3 || first2) ? wave : wave - 2, nw2 = first2 ? 2 : ((NW < 3) ? NW : NW - 2);
       for (int t = w2 * 64 + lane; t < nrhs * K; t += nw2 * 64) {
         const int j = t / K, r = t - j * K;
         double a0 = 0, a1 = 0;
