@@ -8,18 +8,20 @@ factor + solve H p = -g   (reference optimizer/trajectory_optimi
 `idto_hip_gn_step` of the C-ABI.  fp64, synthetic trajectory,
 inputs resident in HBM before the timed region.
 
-Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode replicas|shard]
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode shard|replicas]
 For N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`:
-  replicas (default) every rank iterates its own problem (same model and horizon, trajectory
-           seed = rank; BASELINE config 5 style) with no data-path collective;
-           value = total iterations/s over all ranks ("weak").  After the timed region the
-           sharded mode below is ALSO measured for a few steps and reported under
-           "shard_mode" so that the RCCL exchange has a number on the same run.
-  shard    ONE problem: the (k, column) perturbation grid is split into contiguous k-ranges,
-           one per rank; one all-gather (RCCL) of the dtau/dq slab, then every rank assembles
-           and solves redundantly; value = that problem's iterations/s ("strong").
-           One MI355X already runs all N=40 fd blocks concurrently (40 of 256 CUs), so this
-           mode cannot beat one GPU at this size: DESIGN.md §7.
+  shard (default) ONE problem (BASELINE config 4): the (k, column) perturbation grid is split into
+           contiguous k-ranges, one per rank; one all-gather (RCCL) of the dtau/dq slab, then
+           every rank assembles and solves redundantly; value = that problem's iterations/s
+           ("scaling": "strong").  One MI355X already runs all N=40 fd blocks concurrently (40
+           of 256 CUs), so this mode cannot beat one GPU at this size: DESIGN.md §7.  The
+           replicas rate of the same ranks is reported as the extra "replicas_mode".
+  replicas every rank iterates its own problem (same model and horizon, trajectory seed = rank;
+           BASELINE config 5 style: `--mode replicas --config allegro_hand --num-steps 60`) with
+           no data-path collective; value = total iterations/s over all ranks ("weak").
+The timed region of `value` contains no events and no host synchronisation; per-kernel
+durations (HIP events) and the per-step latency distribution (one synchronisation per step) are
+measured in separate passes afterwards.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -68,27 +70,32 @@ def pmc_traffic(kernel):
     return e["fetch_bytes_per_launch_x2"] + e["write_bytes_per_launch_raw"], os.path.relpath(files[-1], ROOT)
 
 
-def cpu_baseline(model, prob, sp, q, budget_s=12.0):
+def cpu_baseline(model, prob, sp, q, budget_s=18.0):
     """The CPU oracle (a port of the reference algorithm, OpenMP where the reference has it)
     timed on this box's host cores on a bounded sample of the same workload."""
     from oracle_lib import Oracle
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     best = None
     notes = []
-    for nt in (1, 4):
-        if nt > (os.cpu_count() or 1):
-            continue
+    cores = os.cpu_count() or 1
+    # num_threads in {1, 4 (the reference's YAML default), all that the OpenMP loop over t can use}
+    # (BASELINE.md §3 / SURVEY §8d): the reference parallelises over the N timesteps only
+    # (TO.cc:209, :476), so "all" = min(N, cores); the best leg is the baseline
+    legs, rates = sorted({1, min(4, cores), min(prob.num_steps, cores)}), {}
+    for nt in legs:
         sp.num_threads = nt
         orc = Oracle(model, prob, sp)
         t1 = orc.time_gn_steps(q, 3)
-        iters = max(5, int(budget_s / 2 / t1))
+        iters = max(5, int(budget_s / len(legs) / t1))
         t = orc.time_gn_steps(q, iters)
         notes.append(f"{iters} iterations at num_threads={nt}: {1.0 / t:.1f} it/s")
+        rates[str(nt)] = 1.0 / t
         if best is None or 1.0 / t > best[0]:
             best = (1.0 / t, nt)
     return {"value": best[0], "unit": "GN iters/s", "cores": best[1], "kind": "port",
-            "sample": "same mini_cheetah N=40 trajectory; " + "; ".join(notes) +
-                      f" (host has {os.cpu_count()} logical cores)"}
+            "iters_per_s_by_num_threads": rates,
+            "sample": "same trajectory as the GPU run; " + "; ".join(notes) +
+                      f" (host has {cores} logical cores; the OpenMP loops run over t, so at most N threads work)"}
 
 
 def full_iteration(cfg, model, N, device, with_cpu, iters=20):
@@ -117,9 +124,9 @@ def full_iteration(cfg, model, N, device, with_cpu, iters=20):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--mode", choices=["shard", "replicas"], default="replicas")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--mode", choices=["shard", "replicas"], default="shard")
     ap.add_argument("--config", default="mini_cheetah")
     ap.add_argument("--num-steps", type=int, default=40, help="horizon N")
     ap.add_argument("--no-cpu", action="store_true")
@@ -201,62 +208,84 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    # HIP events around every 8th launch of each kernel (inside the timed region; an event pair
-    # costs ~4 us of stream time, timing every launch would inflate ms_per_step by ~15 %)
-    dev.timing_enable(8 if args.steps >= 64 else 1)
-    dev.timing_reset()
-    barrier()
+    # ---- the timed region: exactly `steps` steps, nothing else on the stream, no host sync
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    dev.timing_enable(False)
     if dist is not None:
         tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # ---- separate pass 1: per-kernel durations, HIP events around every launch (on the context's
+    # stream); never part of `value`, so `value` does not depend on --steps
+    dev.timing_enable(1)
+    dev.timing_reset()
+    for _ in range(max(20, min(100, args.steps))):
+        step()
+    barrier()
+    dev.timing_enable(False)
     kern = []
     for w in range(3):
         ms, n = dev.timing_get(w)
         kern.append((ms, n))
+    # ---- separate pass 2: latency of ONE step (launch -> results complete), synchronised per step
+    lat = []
+    for _ in range(max(50, min(200, args.steps))):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        lat.append(1e3 * (time.perf_counter() - t1))
+    lat = np.sort(np.array(lat))
+    latency = {"median": float(np.median(lat)), "p10": float(lat[int(0.1 * (len(lat) - 1))]),
+               "p90": float(lat[int(0.9 * (len(lat) - 1))]), "samples": len(lat),
+               "what": "one step with a host synchronisation before and after (ms); `value` is the "
+                       "back-to-back rate of the timed region"}
     p = dev.get("step")
     g = dev.get("gradient")
     assert np.all(np.isfinite(p)) and np.all(np.isfinite(g))
 
-    shard_extra = None
-    do_extra = False
-    if world > 1 and not sharded:  # every rank must agree, or the collectives below would hang
-        okt = torch.tensor([1.0 if (exch is not None and not os.environ.get("IDTO_BENCH_NO_SHARD_EXTRA")) else 0.0],
-                           device="cuda", dtype=torch.float64)
-        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-        do_extra = bool(okt.item() > 0.5)
-    if do_extra:
+    # ---- the other multi-rank mode on the same ranks, outside the timed region of `value`
+    # (every rank takes the same branch: collectives inside)
+    other_extra, other_key = None, None
+    if world > 1 and exch is not None:
+        other_key = "replicas_mode" if sharded else "shard_mode"
         try:
-            # the sharded single-problem mode on the same ranks (outside the timed region of `value`)
-            dev.set_q(synthetic_trajectory(cfg, model, N, seed=0, lower=0.01))
-            dev.gn_step()
-            p_ref = dev.get("step")
-            dev.set_shard(exch.lo, exch.hi)
-            ns = max(10, args.steps // 4)
+            if sharded:
+                # N independent problems, one per rank, no collective on the data path
+                dev.set_shard(0, N)
+                dev.set_q(synthetic_trajectory(cfg, model, N, seed=rank, lower=0.01))
+                fn, ns = dev.gn_step, max(10, args.steps // 4)
+            else:
+                dev.set_q(synthetic_trajectory(cfg, model, N, seed=0, lower=0.01))
+                dev.gn_step()
+                p_ref = dev.get("step")
+                dev.set_shard(exch.lo, exch.hi)
+                fn, ns = step_sharded, max(10, args.steps // 4)
             for _ in range(5):
-                step_sharded()
+                fn()
             barrier()
             t1 = time.perf_counter()
             for _ in range(ns):
-                step_sharded()
+                fn()
             barrier()
             el = time.perf_counter() - t1
             tt = torch.tensor([el], device="cuda", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            same = bool(np.array_equal(dev.get("step"), p_ref))   # sharded result == single-GPU result, bit for bit
-            shard_extra = {"value": ns / float(tt.item()), "unit": "GN iters/s (one problem)", "steps": ns,
-                           "ms_per_step": 1e3 * float(tt.item()) / ns, "scaling": "strong",
-                           "bit_identical_to_unsharded": same,
-                           "exchange": f"all_gather_into_tensor of {N * dev.slab_stride * 8} B slab over {world} ranks"}
+            if sharded:
+                other_extra = {"value": world * ns / float(tt.item()), "unit": "GN iters/s (aggregate, one problem per rank)",
+                               "steps": ns, "ms_per_step": 1e3 * float(tt.item()) / ns, "scaling": "weak"}
+            else:
+                same = bool(np.array_equal(dev.get("step"), p_ref))   # sharded == single-GPU result, bit for bit
+                other_extra = {"value": ns / float(tt.item()), "unit": "GN iters/s (one problem)", "steps": ns,
+                               "ms_per_step": 1e3 * float(tt.item()) / ns, "scaling": "strong",
+                               "bit_identical_to_unsharded": same,
+                               "exchange": f"all-gather of the {N * dev.slab_stride * 8} B slab over {world} ranks"}
         except Exception as e:  # informational only: never lose the metric over it
-            shard_extra = {"error": str(e)[:200]}
+            other_extra = {"error": str(e)[:200]}
 
     batch_extra = None
     if world == 1 and args.batch > 1:
@@ -308,13 +337,15 @@ def main():
         achieved = algb[dom] / dur_s / 1e9 if dur_s > 0 else 0.0
         traffic, traffic_src = pmc_traffic(KERNELS[dom])
         out = {
-            "metric": "Gauss-Newton iters/sec (grad+Hessian+solve), mini_cheetah N=40",
+            "metric": f"Gauss-Newton iters/sec (grad+Hessian+solve), {args.config} N={N}",
             "value": value, "unit": "GN iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong" if sharded else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config} (nq={nq}, nv={nv}, {model.npairs} contact pairs), horizon N={N}, "
                                    f"dt={prob.time_step}, forward differences, one Gauss-Newton iteration per step",
+                       "physics": "inverse dynamics / contact as defined by the in-repo oracle (oracle/rigid_body.h); "
+                                  "Drake is not available, multi-body conventions are unpinned against it (DESIGN.md §8)",
                        "parallelism": ("single GPU" if world == 1 else
                                        (f"t-range shard of the perturbation grid over {world} GPUs + RCCL all-gather "
                                         f"of the dtau/dq slabs, redundant assemble+solve" if sharded else
@@ -327,8 +358,9 @@ def main():
                          "all_kernels_avg_ms": {KERNELS[i]: kern[i][0] for i in range(3)},
                          "note": "latency/dependency-bound path (SURVEY.md §8d): HBM fraction is intrinsically small"},
         }
-        if shard_extra is not None:
-            out["shard_mode"] = shard_extra
+        if other_extra is not None:
+            out[other_key] = other_extra
+        out["step_latency_ms"] = latency
         if batch_extra is not None:
             out["batch_mode"] = batch_extra
         if not args.no_cpu and world == 1:

@@ -44,6 +44,7 @@ void FillStats(const TrajectoryOptimizerStats<double>& s, idto_stats_t* out) {
   out->solve_time = s.solve_time;
   const int n = std::min<int>(out->capacity, (int)s.iteration_times.size());
   out->count = n;
+  out->total = (int)s.iteration_times.size();
   for (int i = 0; i < n; ++i) {
     out->iteration_times[i] = s.iteration_times[i];
     out->iteration_costs[i] = s.iteration_costs[i];

@@ -218,7 +218,18 @@ inline double Dot4(const double* a, const double* b, int len) {
 
 using TO = TrajectoryOptimizer<double>;
 
+namespace {
+// H was not numerically positive definite (IDTO_HIP_FACTORIZATION_FAILED).  The reference aborts
+// here (DRAKE_DEMAND(Hlu.status() == kSuccess), TO.cc:2084 / :2091); Solve() turns it into
+// SolverFlag::kFactorizationFailed (trajectory_optimizer_solution.h:19), direct callers of the
+// Eval* methods see the exception.
+struct FactorizationFailedError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+}  // namespace
+
 void TO::Check(int rc) const {
+  if (rc == IDTO_HIP_FACTORIZATION_FAILED) throw FactorizationFailedError(std::string("idto_hip: ") + idto_hip_last_error());
   if (rc != 0) throw std::runtime_error(std::string("idto_hip: ") + idto_hip_last_error());
 }
 
@@ -578,7 +589,7 @@ const VectorXd& TO::EvalLagrangeMultipliers(const TrajectoryOptimizerState<T>& s
     if (neq >= kDeviceLdltFrom) {
       Scope prof_("device: constraint solve");
       rc = idto_hip_constraint_solve(hip_, h.data(), c.lambda_v.data(), c.Hinv_gm.data(), c.JT_lambda.data());
-      if (rc != 0 && rc != 1) Check(rc);
+      if (rc != 0 && rc != 1) Check(rc);  // (incl. IDTO_HIP_FACTORIZATION_FAILED)
     }
     if (rc == 1) {
       // pivoted LDL^T on the host, as Eigen's ldlt() of the reference (tolerates semi-definite S)
@@ -767,9 +778,14 @@ SolverFlag TO::Solve(const std::vector<VectorXd>& q_guess, TrajectoryOptimizerSo
                      TrajectoryOptimizerStats<T>* stats, ConvergenceReason* reason) const {
   if (!stats->is_empty()) throw std::runtime_error("Solve: stats must be empty (TO.cc:2225)");
   if ((int)q_guess.size() != num_steps() + 1) throw std::runtime_error("Solve: q_guess has the wrong length");
-  if (params_.method == kLinesearch) return SolveWithLinesearch(q_guess, solution, stats);
-  std::unique_ptr<WarmStart> ws = CreateWarmStart(q_guess);
-  return SolveFromWarmStart(ws.get(), solution, stats, reason);
+  try {
+    if (params_.method == kLinesearch) return SolveWithLinesearch(q_guess, solution, stats);
+    std::unique_ptr<WarmStart> ws = CreateWarmStart(q_guess);
+    return SolveFromWarmStart(ws.get(), solution, stats, reason);
+  } catch (const FactorizationFailedError& e) {
+    if (params_.verbose) std::printf("FACTORIZATION FAILED\n%s\n", e.what());
+    return SolverFlag::kFactorizationFailed;
+  }
 }
 
 // TO.cc:1931-1977
@@ -891,6 +907,16 @@ SolverFlag TO::SolveWithLinesearch(const std::vector<VectorXd>& q_guess, Traject
 // TO.cc:2449-2651
 SolverFlag TO::SolveFromWarmStart(WarmStart* ws, TrajectoryOptimizerSolution<T>* solution,
                                   TrajectoryOptimizerStats<T>* stats, ConvergenceReason* reason_out) const {
+  try {
+    return SolveFromWarmStartImpl(ws, solution, stats, reason_out);
+  } catch (const FactorizationFailedError& e) {
+    if (params_.verbose) std::printf("FACTORIZATION FAILED\n%s\n", e.what());
+    return SolverFlag::kFactorizationFailed;
+  }
+}
+
+SolverFlag TO::SolveFromWarmStartImpl(WarmStart* ws, TrajectoryOptimizerSolution<T>* solution,
+                                      TrajectoryOptimizerStats<T>* stats, ConvergenceReason* reason_out) const {
   using clock = std::chrono::high_resolution_clock;
   if (params_.method != kTrustRegion) throw std::runtime_error("warm start requires the trust-region method");
   const auto start_time = clock::now();
@@ -912,6 +938,8 @@ SolverFlag TO::SolveFromWarmStart(WarmStart* ws, TrajectoryOptimizerSolution<T>*
   }
   while (k < params_.max_iterations) {
     const bool active = CalcDoglegPoint(state, Delta, &dq, &dqH);  // :2497
+    // a step that is not finite can only come from a Hessian the factorisation could not handle
+    if (!std::isfinite(Dot(dq, dq))) throw FactorizationFailedError("idto_hip: the dogleg step is not finite");
     const Vec& g = EvalMeritFunctionGradient(state);
     const Vec& h = EvalEqualityConstraintViolations(state);
     const double cost = EvalCost(state);

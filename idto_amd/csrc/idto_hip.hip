@@ -107,6 +107,11 @@ struct idto_hip_ctx {
   std::vector<hipEvent_t> event_pool;  // recycled: creating events in the timed loop costs host time
   double tsum[3] = {0, 0, 0};
   int tcnt[3] = {0, 0, 0};
+  // factorisation status, written by the solver kernels into pinned host memory only when a pivot
+  // fails: [0] = id of the last failing factorisation, [1] = failing block rows since creation
+  unsigned* status_pin = nullptr;
+  unsigned* status_dev = nullptr;   // the same memory as the device addresses it
+  unsigned fact_id = 0;             // id of the most recent factorisation launched
 };
 
 namespace {
@@ -217,6 +222,19 @@ int BuildModel(idto_hip_ctx* c, const idto_model_t* m) {
     sb[i] = bb < 0 ? -2 : slot_of[bb];
     for (int b : {ba, bb})
       if (b >= 0 && b != m->common_body && m->body_path[b] != p) { g_err = "pair touches a body outside its path"; return -1; }
+    // box-box is implemented for ONE configuration only (id_eval.h signed_distance): A = a box on a
+    // moving body, B = a world-fixed, axis-aligned box whose top face acts as the half-space
+    // z <= top (the ground boxes of the reference's examples).  Anything else would silently get
+    // wrong witness points, so it is refused here.
+    if (m->geom_type[m->pair_a[i]] == IDTO_GEOM_BOX && m->geom_type[m->pair_b[i]] == IDTO_GEOM_BOX) {
+      const double* XB = m->geom_X + (size_t)12 * m->pair_b[i];
+      bool ident = true;
+      for (int e = 0; e < 9; ++e) ident &= (XB[e] == ((e % 4 == 0) ? 1.0 : 0.0));
+      if (ba < 0 || bb >= 0 || !ident) {
+        g_err = "box-box contact pairs must be (box on a moving body, world-fixed axis-aligned box), in this order";
+        return -1;
+      }
+    }
   }
   DevModel& M = c->M;
   M.nb = nb; M.nq = m->nq; M.nv = m->nv; M.npaths = K; M.common_body = m->common_body;
@@ -337,6 +355,17 @@ int EnsureStage(idto_hip_ctx* c, size_t count) {
 }
 // a pending idto_hip_prefetch of an array is dropped when that array is about to be recomputed
 // (idto_hip_get then reads the new contents instead of the stale staged copy)
+// after a stream synchronisation: did the most recent factorisation report a failed pivot?
+int FactorStatus(idto_hip_ctx* c) {
+  const volatile unsigned* st = c->status_pin;
+  if (c->fact_id != 0 && st[0] == c->fact_id) {
+    g_err = "factorisation failed: the Hessian is not numerically positive definite (a pivot was non-positive, "
+            "non-finite or fully cancelled)";
+    return IDTO_HIP_FACTORIZATION_FAILED;
+  }
+  return 0;
+}
+void* DevPtr(idto_hip_ctx* c, int what);
 void DropPrefetch(idto_hip_ctx* c, std::initializer_list<int> arrays) {
   for (auto& pf : c->pre)
     for (int a : arrays)
@@ -402,6 +431,13 @@ int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem, co
   bad |= Alloc(c, (size_t)(N + 1) * 32 * 36, &c->Est) != 0;
   bad |= Alloc(c, (size_t)(N + 1) * 32, &c->Dst) != 0;
   if (bad) { idto_hip_destroy(c); return -2; }
+  if (hipHostMalloc((void**)&c->status_pin, 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&c->status_dev, c->status_pin, 0) != hipSuccess) {
+    g_err = "hipHostMalloc (solver status) failed";
+    idto_hip_destroy(c);
+    return -2;
+  }
+  c->status_pin[0] = 0; c->status_pin[1] = 0;
   c->k_begin = 0; c->k_end = N;
 
   // launch geometry
@@ -420,8 +456,14 @@ int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem, co
   c->solve_lds = (int)sizeof(double) * ((n + 2) * nq + nq);
   c->cost_lds = (int)sizeof(double) * (3 * N + 2) * (1 + std::max(nq, nv));
   const int max_lds = 160 * 1024;
-  if (c->fd_lds > max_lds || c->asm_lds > max_lds || c->penta_lds > max_lds) {
-    g_err = "problem too large for the 160 KiB LDS carve-up of the v1 kernels";
+  // (cost_kernel is a single block holding one column of every cost term; penta_apply_kernel keeps
+  // the right-hand side of each of its four wavefronts: both bound the horizon as well)
+  const int Kpad = (nq == 2 || nq == 3 || nq == 5 || nq == 19 || nq == 23) ? nq : (nq <= 8 ? 8 : nq <= 16 ? 16 : nq <= 24 ? 24 : 32);
+  const int apply_lds = 4 * n * Kpad * (int)sizeof(double);
+  if (c->fd_lds > max_lds || c->asm_lds > max_lds || c->penta_lds > max_lds || c->cost_lds > max_lds ||
+      apply_lds > max_lds) {
+    g_err = "problem too large for the 160 KiB LDS carve-up of the v1 kernels (fd / assemble / solver / cost / "
+            "multi-rhs substitution)";
     idto_hip_destroy(c);
     return -1;
   }
@@ -433,6 +475,10 @@ int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem, co
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cost_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+#define APPLY_ATTR(KM) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_apply_kernel<KM>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  APPLY_ATTR(2) APPLY_ATTR(3) APPLY_ATTR(5) APPLY_ATTR(8) APPLY_ATTR(16) APPLY_ATTR(19) APPLY_ATTR(23) APPLY_ATTR(24) APPLY_ATTR(32)
+#undef APPLY_ATTR
 #define LDL_ATTR(KM, PD, GW)                                                                                          \
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_ldl_kernel<KM, 256, PD, GW>),                         \
                             hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                              \
@@ -457,6 +503,7 @@ void idto_hip_destroy(idto_hip_ctx* c) {
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->pin) (void)hipHostFree(c->pin);
+  if (c->status_pin) (void)hipHostFree(c->status_pin);
   if (c->con_pin) (void)hipHostFree(c->con_pin);
   if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
   for (auto& pf : c->pre) if (pf.ev) (void)hipEventDestroy(pf.ev);
@@ -620,8 +667,9 @@ static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, int nrhs, do
     }
     ++c->epoch;
   }
+  if (++c->fact_id == 0) c->fact_id = 1;  // (0 is the initial value of the status word)
 #define LDL_ARGS n, k, c->HA + qq0, c->HB + qq0, c->HC + qq0, b, sign, nrhs, xo, c->Ust, c->Hst, c->Est, c->Dst, dbg, \
-                 m_split, c->xch, c->flags, c->epoch
+                 m_split, c->xch, c->flags, c->epoch, c->status_dev, c->fact_id
 #define LDL_LAUNCH(KM, PD, GW)                                                                                \
   do {                                                                                                        \
     if (threads == 256 && gj_waves == GW)                                                                     \
@@ -658,8 +706,9 @@ int idto_hip_factor_solve(idto_hip_ctx* c, const double* rhs, int nrhs, double* 
   if (nrhs < 1) { g_err = "nrhs < 1"; return -1; }
   if (TimeBegin(c, 2)) return -2;
   if (c->reference_solver) {
+    if (++c->fact_id == 0) c->fact_id = 1;
     hipLaunchKernelGGL(penta_kernel, dim3(1), dim3(256), c->penta_lds, c->stream, n, k, c->HA, c->HB, c->HC, b,
-                       rhs ? 1.0 : -1.0, xo, c->Kst, c->LUst, c->pivst, c->Yst, c->Zst);
+                       rhs ? 1.0 : -1.0, xo, c->Kst, c->LUst, c->pivst, c->Yst, c->Zst, c->status_dev, c->fact_id);
     HIP_OK(hipGetLastError());
     if (TimeEnd(c)) return -2;
     if (nrhs > 1) {
@@ -719,7 +768,7 @@ int idto_hip_solve_host(idto_hip_ctx* c, const double* rhs_host, int nrhs, doubl
   if (rc) return rc;
   HIP_OK(hipMemcpyAsync(x_host, c->stage_x, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_OK(hipStreamSynchronize(c->stream));
-  return 0;
+  return FactorStatus(c);
 }
 
 int idto_hip_constraint_schur_begin(idto_hip_ctx* c, const int* dofs, int nu) {
@@ -786,7 +835,7 @@ int idto_hip_constraint_schur(idto_hip_ctx* c, const int* dofs, int nu, double* 
   std::memcpy(S_host, c->con_pin, (size_t)neq * neq * sizeof(double));
   std::memcpy(Jy_host, c->con_pin + (size_t)neq * neq, (size_t)neq * sizeof(double));
   c->con_ready = true;
-  return 0;
+  return FactorStatus(c);
 }
 
 int idto_hip_constraint_solve(idto_hip_ctx* c, const double* h_host, double* lambda_host, double* step_host,
@@ -826,6 +875,7 @@ int idto_hip_constraint_solve(idto_hip_ctx* c, const double* h_host, double* lam
   HIP_OK(hipMemcpyAsync(down + 2 + neq, c->con_out, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_OK(hipStreamSynchronize(c->stream));
   c->con_ready = true;  // Y is in place for idto_hip_constraint_step (fallback path)
+  if (int fs = FactorStatus(c)) return fs;  // H itself was not positive definite
   const double dmin = down[0], dmax = down[1];
   if (!(dmin > 1e-13 * dmax) || !std::isfinite(dmax)) return 1;  // (semi-)singular S: the caller pivots on the host
   std::memcpy(lambda_host, down + 2, (size_t)neq * sizeof(double));
@@ -850,7 +900,7 @@ int idto_hip_constraint_step(idto_hip_ctx* c, const double* lambda_host, double*
   HIP_OK(hipStreamSynchronize(c->stream));
   std::memcpy(step_host, pl + neq, (size_t)n * sizeof(double));
   std::memcpy(jtl_host, pl + neq + n, (size_t)n * sizeof(double));
-  return 0;
+  return FactorStatus(c);
 }
 
 int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
@@ -920,7 +970,9 @@ long idto_hip_array_size(idto_hip_ctx* c, int what) {
 }
 int idto_hip_slab_stride(idto_hip_ctx* c) { return c->slab_stride; }
 
-void* idto_hip_device_ptr(idto_hip_ctx* c, int what) {
+}  // extern "C"
+namespace {
+void* DevPtr(idto_hip_ctx* c, int what) {
   switch (what) {
     case IDTO_ARR_Q: return c->q;
     case IDTO_ARR_V: return c->v;
@@ -938,11 +990,22 @@ void* idto_hip_device_ptr(idto_hip_ctx* c, int what) {
     default: return nullptr;  // tau and the three partials live strided inside the slab
   }
 }
+}  // namespace
+extern "C" {
+
+void* idto_hip_device_ptr(idto_hip_ctx* c, int what) {
+  // a caller holding a pointer to the Hessian bands may overwrite them: from here on the solver
+  // treats H as a general symmetric block penta-diagonal matrix (no identity block row 0 assumed)
+  // until idto_hip_grad_hess assembles it again
+  if (what == IDTO_ARR_H_A || what == IDTO_ARR_H_B || what == IDTO_ARR_H_C || what == IDTO_ARR_HBANDS)
+    c->h_assembled = false;
+  return DevPtr(c, what);
+}
 
 int idto_hip_prefetch(idto_hip_ctx* c, int what) {
   HIP_OK(hipSetDevice(c->device));
   const long count = idto_hip_array_size(c, what);
-  void* p = idto_hip_device_ptr(c, what);
+  void* p = DevPtr(c, what);
   if (count < 0 || !p) { g_err = "prefetch: array is not contiguous in device memory"; return -1; }
   if (!c->side) HIP_OK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
   // slot: the one already holding `what`, else a free one
@@ -977,7 +1040,7 @@ int idto_hip_get(idto_hip_ctx* c, int what, double* out) {
       HIP_OK(hipStreamSynchronize(c->side));
       std::memcpy(out, c->pre_pin + pf.off, pf.count * sizeof(double));
       pf.pending = false;
-      return 0;
+      return (what == IDTO_ARR_STEP) ? FactorStatus(c) : 0;
     }
   HIP_OK(hipStreamSynchronize(c->stream));
   const long count = idto_hip_array_size(c, what);
@@ -990,8 +1053,17 @@ int idto_hip_get(idto_hip_ctx* c, int what, double* out) {
                        width * sizeof(double), c->N, hipMemcpyDeviceToHost));
     return 0;
   }
-  void* p = idto_hip_device_ptr(c, what);
+  void* p = DevPtr(c, what);
   HIP_OK(hipMemcpy(out, p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+  return (what == IDTO_ARR_STEP) ? FactorStatus(c) : 0;
+}
+
+int idto_hip_solver_status(idto_hip_ctx* c, int* failed, int* failed_rows_total) {
+  HIP_OK(hipSetDevice(c->device));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  const volatile unsigned* st = c->status_pin;
+  if (failed) *failed = (c->fact_id != 0 && st[0] == c->fact_id) ? 1 : 0;
+  if (failed_rows_total) *failed_rows_total = (int)st[1];
   return 0;
 }
 

@@ -841,7 +841,8 @@ IDTO_DEV void blk_sub_mul(const double* X, const double* L, const double* R, dou
 __global__ void penta_kernel(int n, int k, const double* __restrict__ HA, const double* __restrict__ HB,
                              const double* __restrict__ HC, const double* __restrict__ b, double rhs_sign,
                              double* __restrict__ x, double* __restrict__ Kst, double* __restrict__ LUst,
-                             int* __restrict__ pivst, double* __restrict__ Yst, double* __restrict__ Zst) {
+                             int* __restrict__ pivst, double* __restrict__ Yst, double* __restrict__ Zst,
+                             unsigned* __restrict__ status, unsigned fact_id) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int kk = k * k;
@@ -916,6 +917,12 @@ __global__ void penta_kernel(int n, int k, const double* __restrict__ HA, const 
         }
       __syncthreads();
       const double d = G[j * k + j];
+      // Eigen's PartialPivLU "always succeeds" (penta_diagonal_solver.h:108-110); a pivot that is
+      // exactly zero or not finite after pivoting (singular H) is still reported to the host
+      if (tid == 0 && !(__builtin_fabs(d) > 0.0 && __builtin_fabs(d) < __builtin_inf())) {
+        __hip_atomic_store(status, fact_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_fetch_add(status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       for (int r = j + 1 + tid; r < k; r += nt) G[j * k + r] = G[j * k + r] / d;
       __syncthreads();
       const int nr = k - j - 1, nc = ncols - j - 1;

@@ -170,7 +170,8 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
                  const double* __restrict__ HC, const double* __restrict__ b, double rhs_sign, int nrhs,
                  double* __restrict__ x, double* __restrict__ Ust, double* __restrict__ Hst,
                  double* __restrict__ Est, double* __restrict__ Dst, double* __restrict__ dbg,
-                 int m_split, double* __restrict__ xch, unsigned* __restrict__ flags, unsigned epoch) {
+                 int m_split, double* __restrict__ xch, unsigned* __restrict__ flags, unsigned epoch,
+                 unsigned* __restrict__ status, unsigned fact_id) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // ---- two-sided ("twisted") elimination, m_split > 0, grid of 2 workgroups: workgroup 0
@@ -526,8 +527,22 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
       stamp(i, 3);
       double myinv = 1.0, yacc = 0.0;
       if (!pseudo) {
+        // the diagonal entry this lane's pivot starts from (before the block's own elimination)
+        const double diag0 = (lane < K) ? Wm[lane * ks + lane] : 1.0;
         if (ypush) myinv = ldl_eliminate_wave<K, true>(xr, lane, yacc);
         else myinv = ldl_eliminate_wave<K, false>(xr, lane, yacc);
+        // factorisation status (the reference reports kFailure from Factorize and the optimizer
+        // demands success: penta_diagonal_solver.h:181-185, trajectory_optimizer.cc:2084): a pivot
+        // that is not positive, not finite, or has lost every significant digit against the diagonal
+        // entry it started from (d <= eps * S_ll) means H is not numerically positive definite.
+        // myinv = 1 / d from v_rcp + Newton: NaN for d = 0 / inf / NaN, negative for d < 0.
+        if (wave == 0) {
+          const bool bad = !(myinv > 0.0 && myinv * diag0 < 4503599627370496.0);  // 2^52 = 1 / eps
+          if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) {
+            __hip_atomic_store(status, fact_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_fetch_add(status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
       } else {
         // hand the column over (layout of W) and continue the recursion with a zero row
         if (lane < K || is_rhs) {

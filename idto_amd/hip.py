@@ -72,6 +72,7 @@ def lib():
         L.idto_hip_array_size.argtypes = [C.c_void_p, C.c_int]
         L.idto_hip_array_size.restype = C.c_long
         L.idto_hip_slab_stride.argtypes = [C.c_void_p]
+        L.idto_hip_solver_status.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.idto_hip_math_probe.argtypes = [C.c_int, C.POINTER(C.c_double), C.c_int] + [C.POINTER(C.c_double)] * 6
         _lib = L
     return _lib
@@ -85,6 +86,7 @@ EXPORTED_SYMBOLS = [
     "idto_hip_set_option",
     "idto_hip_timing_enable", "idto_hip_timing_reset", "idto_hip_timing_get", "idto_hip_sync", "idto_hip_get",
     "idto_hip_device_ptr", "idto_hip_array_size", "idto_hip_slab_stride", "idto_hip_math_probe",
+    "idto_hip_solver_status",
 ]
 
 
@@ -92,7 +94,17 @@ class HipError(RuntimeError):
     pass
 
 
+class FactorizationFailed(HipError):
+    """IDTO_HIP_FACTORIZATION_FAILED: H is not numerically positive definite (the reference's
+    PentaDiagonalFactorizationStatus::kFailure, optimizer/penta_diagonal_solver.h:181-185)"""
+
+
+FACTORIZATION_FAILED = 2
+
+
 def _chk(rc):
+    if rc == FACTORIZATION_FAILED:
+        raise FactorizationFailed(lib().idto_hip_last_error().decode())
     if rc != 0:
         raise HipError(f"idto_hip error {rc}: {lib().idto_hip_last_error().decode()}")
 
@@ -215,6 +227,12 @@ class HipPath:
 
     def sync(self):
         _chk(lib().idto_hip_sync(self.h))
+
+    def solver_status(self):
+        """(failed, failed_rows_total) of the most recent factorisation; synchronises"""
+        f, n = C.c_int(), C.c_int()
+        _chk(lib().idto_hip_solver_status(self.h, C.byref(f), C.byref(n)))
+        return bool(f.value), n.value
 
     # ---- timing (HIP events on the context's stream)
     def timing_enable(self, on=True):

@@ -77,7 +77,7 @@ class CStats(C.Structure):
                 ("dq_norms", C.POINTER(C.c_double)), ("dqH_norms", C.POINTER(C.c_double)),
                 ("trust_ratios", C.POINTER(C.c_double)), ("gradient_norms", C.POINTER(C.c_double)),
                 ("dL_dqs", C.POINTER(C.c_double)), ("h_norms", C.POINTER(C.c_double)),
-                ("merits", C.POINTER(C.c_double))]
+                ("merits", C.POINTER(C.c_double)), ("total", C.c_int)]
 
 
 def dptr(a: np.ndarray):

@@ -76,12 +76,22 @@ class TrajectoryOptimizerStats:
 
     def __init__(self, capacity=1000):
         self.c = CStats()
-        self.c.capacity = capacity
         self._arr = {}
+        self._reserve(capacity)
+
+    def _reserve(self, capacity):
+        """room for `capacity` iterations (Solve sizes it from SolverParameters::max_iterations)"""
+        assert self.c.count == 0
+        self.c.capacity = capacity
         for f in self.FIELDS:
             a = np.zeros(capacity, dtype=np.int32 if f == "linesearch_iterations" else np.float64)
             setattr(self.c, f, iptr(a) if f == "linesearch_iterations" else dptr(a))
             self._arr[f] = a
+
+    @property
+    def truncated(self):
+        """True if the solver ran more iterations than the arrays could hold"""
+        return self.c.total > self.c.count
 
     def __getattr__(self, k):
         if k in TrajectoryOptimizerStats.FIELDS:
@@ -184,6 +194,8 @@ class TrajectoryOptimizer:
         """returns the SolverFlag name; fills `solution` and `stats` (must be empty)"""
         if not stats.is_empty():
             raise RuntimeError("stats must be empty")
+        if stats.c.capacity < self._params.max_iterations:
+            stats._reserve(self._params.max_iterations)
         q, v, tau = self._outputs()
         flag, reason = C.c_int(), C.c_int()
         self._chk(lib().idto_opt_solve(self._h, dptr(_d(q_guess)), dptr(q), dptr(v), dptr(tau), C.byref(stats.c),
@@ -199,6 +211,8 @@ class TrajectoryOptimizer:
 
     def SolveFromWarmStart(self, warm_start: WarmStart, solution: TrajectoryOptimizerSolution,
                            stats: TrajectoryOptimizerStats):
+        if stats.is_empty() and stats.c.capacity < self._params.max_iterations:
+            stats._reserve(self._params.max_iterations)
         q, v, tau = self._outputs()
         flag, reason = C.c_int(), C.c_int()
         self._chk(lib().idto_opt_ws_solve(self._h, warm_start._h, dptr(q), dptr(v), dptr(tau), C.byref(stats.c),

@@ -130,6 +130,8 @@ class TrajectoryOptimizer<double> {
                                                 TrajectoryOptimizerState<T>* scratch) const;
   SolverFlag SolveWithLinesearch(const std::vector<VectorXd>& q_guess, TrajectoryOptimizerSolution<T>* solution,
                                  TrajectoryOptimizerStats<T>* stats) const;
+  SolverFlag SolveFromWarmStartImpl(WarmStart* warm_start, TrajectoryOptimizerSolution<T>* solution,
+                                    TrajectoryOptimizerStats<T>* stats, ConvergenceReason* reason) const;
   void AdoptTrialPoint(const TrajectoryOptimizerState<T>& scratch, TrajectoryOptimizerState<T>* state) const;
   ConvergenceReason VerifyConvergenceCriteria(const TrajectoryOptimizerState<T>& state, T previous_cost,
                                               const VectorXd& dq) const;

@@ -66,6 +66,15 @@ enum idto_hip_array {
 
 const char* idto_hip_last_error(void);
 
+/* Positive status of the entry points that synchronise after a factorisation of H
+ * (idto_hip_get(IDTO_ARR_STEP), idto_hip_solve_host, idto_hip_constraint_schur / _solve / _step):
+ * a pivot of the block factorisation was non-positive, non-finite or cancelled completely, i.e. H
+ * is not numerically positive definite.  The reference reports this as
+ * PentaDiagonalFactorizationStatus::kFailure (optimizer/penta_diagonal_solver.h:181-185) and the
+ * optimizer demands success (optimizer/trajectory_optimizer.cc:2084, :2091); the host-side
+ * TrajectoryOptimizer maps it to SolverFlag::kFactorizationFailed. */
+#define IDTO_HIP_FACTORIZATION_FAILED 2
+
 /* Creates a context on HIP device `device` for the given model, problem and
  * contact parameters (copied). */
 int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem,
@@ -155,6 +164,11 @@ int idto_hip_timing_reset(idto_hip_ctx* ctx);
 int idto_hip_timing_get(idto_hip_ctx* ctx, int which, double* avg_ms, int* launches);
 
 int idto_hip_sync(idto_hip_ctx* ctx);
+/* Synchronises and reports the status of the most recent factorisation launched on this context
+ * (idto_hip_factor_solve / idto_hip_gn_step / the constraint step): *failed = 1 if it met a bad
+ * pivot (see IDTO_HIP_FACTORIZATION_FAILED), else 0; *failed_rows_total (may be NULL) counts the
+ * failing block rows since the context was created. */
+int idto_hip_solver_status(idto_hip_ctx* ctx, int* failed, int* failed_rows_total);
 /* Enqueues, behind the work submitted so far, an asynchronous copy of array `what` (a
  * contiguous one: not TAU / DTAU_*) to pinned staging memory on a side stream.  The next
  * idto_hip_get of the same array waits for that copy only - not for kernels launched after

@@ -63,6 +63,12 @@ typedef struct idto_model {
   int npairs;               /* candidate signed-distance pairs (after collision filters) */
   const int* pair_a;        /* [npairs] geometry A (lower registration index) */
   const int* pair_b;        /* [npairs] geometry B */
+  /* Supported pairs: sphere-sphere, sphere-box (either order, any poses), and box-box ONLY as
+   * (A = box on a moving body, B = world-fixed box with identity rotation): B's top face is
+   * taken as the half-space z <= top (its x/y extent is not tested) and A's lowest vertex is the
+   * witness point - the body-box / foot-box vs ground-box pairs of the reference's examples
+   * (examples/mini_cheetah/mini_cheetah.cc:50-55).  idto_hip_create refuses any other box-box
+   * pair; the reference gets general closest points from Drake/FCL (TO.cc:271-279). */
 
   /* Evaluation/summation-order specification ("star" decomposition): one
    * optional common root body (computed by every path) plus npaths disjoint
@@ -131,6 +137,7 @@ typedef struct idto_stats {
   double* linesearch_alphas; double* trust_region_radii; double* q_norms; double* dq_norms;
   double* dqH_norms; double* trust_ratios; double* gradient_norms; double* dL_dqs;
   double* h_norms; double* merits;
+  int total;  /* iterations the solver ran; count = min(capacity, total): total > count means the arrays were too short */
 } idto_stats_t;
 
 #ifdef __cplusplus

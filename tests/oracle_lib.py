@@ -281,6 +281,31 @@ def penta_make_dense(A, B, C_, D, E):
     return M.T.copy()
 
 
+def refined_solution(Hd, rhs, steps=6):
+    """Extended-precision reference solution of H x = rhs (H dense, symmetric positive definite): iterative
+    refinement with the residual and the accumulated solution in 80-bit long double (numpy.longdouble;
+    x86 extended precision, eps = 1.1e-19), run twice with two different working factorisations
+    (LAPACK Cholesky and pivoted LU).  Returns (x, uncertainty): x as float64 and the relative max-norm
+    distance between the two runs - the accuracy to which x itself is known (~cond * 1e-19).
+    This is the yardstick the solver parity tests measure BOTH device solvers against: the
+    reference's algorithm (pivoted-LU block Thomas) and the production block LDL^T."""
+    import scipy.linalg as sl
+    assert np.finfo(np.longdouble).eps < 1e-18, "long double is not extended precision on this platform"
+    Hd = np.asarray(Hd, dtype=np.float64)
+    Hl, bl = Hd.astype(np.longdouble), np.asarray(rhs, dtype=np.float64).ravel().astype(np.longdouble)
+    outs = []
+    for kind in ("cho", "lu"):
+        fac = sl.cho_factor(Hd) if kind == "cho" else sl.lu_factor(Hd)
+        solve = (lambda r: sl.cho_solve(fac, r)) if kind == "cho" else (lambda r: sl.lu_solve(fac, r))
+        x = solve(np.asarray(rhs, dtype=np.float64).ravel()).astype(np.longdouble)
+        for _ in range(steps):
+            r = bl - Hl @ x
+            x = x + solve(r.astype(np.float64)).astype(np.longdouble)
+        outs.append(x)
+    nrm = float(np.abs(outs[0]).max()) + 1e-300
+    return outs[0].astype(np.float64), float(np.abs(outs[0] - outs[1]).max()) / nrm
+
+
 def penta_scale_by_diagonal(A, B, C_, D, E, s):
     n, bs = A.shape[0], A.shape[1]
     bands = [_cm(x).copy() for x in (A, B, C_, D, E)]

@@ -86,23 +86,28 @@ def test_hot_path_bit_exact(name, N, seed, lower):
     dev.factor_solve()
     assert same(dev.get("step"), p), np.abs(dev.get("step") - p).max()
     # (ii) the production solver (banded block LDL^T, no pivoting): same recursion, different
-    # elimination order => agreement to round-off.  Tolerance: the backward error
-    # |H p + g| must be as small as the pivoted LU's (x16 slack), and the forward error
-    # below 1e-9 relative to |p| scaled by the growth the LU itself shows vs. a residual
-    # correction (both are cond(H)*eps effects).
+    # elimination order => agreement to round-off.  "As accurate as the reference's algorithm" is
+    # measured, not bounded by cond(H)*eps: both solutions are compared with an extended-precision
+    # solution of the same system (oracle_lib.refined_solution: long-double iterative refinement,
+    # known to `unc` relative).  Bar: the forward error of the production solver is at most 4x the
+    # forward error of the pivoted-LU block Thomas (the reference's algorithm, bit-exact above),
+    # and its backward error |H p + g| at most 16x.
     dev.set_option("reference_solver", 0)
     dev.factor_solve()
     p_fast = dev.get("step")
     import oracle_lib as ol
+    Hd = ol.penta_make_dense(*bands)
+    p_ref, unc = ol.refined_solution(Hd, -g.ravel())
     Hp = ol.penta_multiply(*bands, p)
     Hpf = ol.penta_multiply(*bands, p_fast)
     scale = np.abs(g).max() + 1e-300
     res_lu, res_fast = np.abs(Hp + g).max() / scale, np.abs(Hpf + g).max() / scale
-    fwd = np.abs(p_fast - p).max() / np.abs(p).max()
-    cond = np.linalg.cond(ol.penta_make_dense(*bands))
-    _record(name, N, res_lu=res_lu, res_fast=res_fast, fwd=fwd, cond=cond)
+    pn = np.abs(p_ref).max()
+    err_lu, err_fast = np.abs(p.ravel() - p_ref).max() / pn, np.abs(p_fast.ravel() - p_ref).max() / pn
+    _record(name, N, res_lu=res_lu, res_fast=res_fast, err_lu=err_lu, err_fast=err_fast, ref_uncertainty=unc,
+            cond=np.linalg.cond(Hd))
     assert res_fast <= 16 * res_lu + 1e-13, (res_fast, res_lu)
-    assert fwd <= 64 * cond * np.finfo(float).eps, (fwd, cond)
+    assert err_fast <= 4 * err_lu + 16 * unc + 1e-12, (err_fast, err_lu, unc)
 
     # the fused entry point gives the same answer
     dev.set_q(q)
@@ -203,7 +208,12 @@ def test_update_problem_and_shard():
     orc = Oracle(model, prob, sp)
     g, p = orc.gn_step(q)
     assert np.array_equal(dev.get("gradient"), g)
-    assert np.abs(dev.get("step") - p).max() <= 1e-6 * np.abs(p).max()
+    import oracle_lib as ol
+    _, bands = orc.grad_hess(q)
+    p_ref, unc = ol.refined_solution(ol.penta_make_dense(*bands), -g.ravel())
+    pn = np.abs(p_ref).max()
+    err_lu, err_fast = np.abs(p.ravel() - p_ref).max() / pn, np.abs(dev.get("step").ravel() - p_ref).max() / pn
+    assert err_fast <= 4 * err_lu + 16 * unc + 1e-12, (err_fast, err_lu, unc)
     dev.set_option("reference_solver", 1)
     dev.factor_solve()
     assert np.array_equal(dev.get("step"), p)

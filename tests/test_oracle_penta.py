@@ -152,3 +152,28 @@ def test_extract_and_scale_by_diagonal():  # :321-371
     Hs = ol.penta_scale_by_diagonal(*H, s)
     assert compare(ol.penta_make_dense(*Hs), np.diag(s) @ Hd @ np.diag(s), EPS)
     assert np.array_equal(np.diag(Hd), np.concatenate([np.diag(c) for c in H[2]]))
+
+
+def test_refined_solution_against_mpmath():
+    """oracle_lib.refined_solution (the extended-precision yardstick of the GPU solver parity tests)
+    reproduces a 60-digit mpmath solve to double rounding on SPD systems up to cond ~ 1e12"""
+    import mpmath as mp
+    rng = np.random.default_rng(7)
+    size = 40
+    for cond_target in (1e4, 1e8, 1e12):
+        L = np.tril(rng.uniform(-0.3, 0.3, (size, size)), -1)
+        for i in range(size):
+            L[i, :max(0, i - 10)] = 0.0
+        L += np.eye(size)
+        L = np.logspace(0, np.log10(cond_target) / 2, size)[:, None] * L
+        H = L @ L.T
+        H = (H + H.T) / 2
+        b = rng.normal(size=size)
+        x, unc = ol.refined_solution(H, b)
+        mp.mp.dps = 60
+        xm = np.array([float(v) for v in mp.lu_solve(mp.matrix(H.tolist()), mp.matrix(b.tolist()))])
+        assert np.abs(x - xm).max() <= 4 * EPS * np.abs(xm).max()
+        assert unc < 1e-15
+        # and a plain double solve is measurably worse on the ill-conditioned one
+        if cond_target >= 1e12:
+            assert np.abs(np.linalg.solve(H, b) - xm).max() > 100 * np.abs(x - xm).max()
