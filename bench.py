@@ -136,10 +136,6 @@ def main():
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.batch > 1:
-        # the informational batch mode runs one HIP stream per problem; the runtime multiplexes streams
-        # onto 4 hardware queues unless told otherwise (read when the HIP runtime initialises)
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(32, max(4, args.batch))))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
@@ -289,42 +285,33 @@ def main():
 
     batch_extra = None
     if world == 1 and args.batch > 1:
-        # informational (never `value`): B independent problems resident on this ONE GPU, each context
-        # on its own stream - one problem occupies at most 164 of the 256 CUs for a third of the
-        # iteration and 2 CUs for the rest, so several iterate concurrently
-        devs = [hip.HipPath(model, prob, sp, device=local_rank) for _ in range(args.batch)]
-        for b, d in enumerate(devs):
-            d.set_q(synthetic_trajectory(cfg, model, N, seed=b, lower=0.01))
-        for _ in range(10):
-            for d in devs:
-                d.gn_step()
-        for d in devs:
-            d.sync()
-        nb = max(20, args.steps // 2)
-        # one host thread per problem (ctypes releases the GIL inside the C-ABI calls): a single
-        # thread launching 3 kernels x B problems per round is launch-bound, not GPU-bound
-        import threading
-        gate = threading.Barrier(args.batch + 1)
-
-        def worker(d):
-            gate.wait()
+        # informational (never `value`): B independent problems resident on this ONE GPU and advanced by
+        # ONE host thread with one launch per kernel (idto_hip_create_batch / idto_hip_gn_step_batch,
+        # grid.y = problem) - one problem leaves most of the 256 CUs idle, a batched / sampling MPC
+        # server does not
+        batch_extra = []
+        for B in sorted({args.batch, 4 * args.batch}):
+            probs = []
+            for b in range(B):
+                pb, _, _ = make_problem(cfg, model, num_steps=N)
+                probs.append(pb)
+            bd = hip.HipPath(model, probs, sp, device=local_rank)
+            bd.set_stream(stream.cuda_stream)
+            bd.set_q_batch(np.array([synthetic_trajectory(cfg, model, N, seed=b, lower=0.01) for b in range(B)]))
+            for _ in range(5):
+                bd.gn_step()
+            torch.cuda.synchronize()
+            nb = max(20, args.steps // 4)
+            t1 = time.perf_counter()
             for _ in range(nb):
-                d.gn_step()
-            d.sync()
-
-        threads = [threading.Thread(target=worker, args=(d,)) for d in devs]
-        for th in threads:
-            th.start()
-        gate.wait()
-        t1 = time.perf_counter()
-        for th in threads:
-            th.join()
-        el = time.perf_counter() - t1
-        batch_extra = {"problems": args.batch, "value": args.batch * nb / el, "unit": "GN iters/s (aggregate)",
-                       "ms_per_round": 1e3 * el / nb,
-                       "note": "independent problems on one GPU, one context + HIP stream + host thread each"}
-        for d in devs:
-            d.close()
+                bd.gn_step()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t1
+            assert bd.solver_status_batch() == [False] * B
+            batch_extra.append({"problems": B, "value": B * nb / el, "unit": "GN iters/s (aggregate)",
+                                "ms_per_round": 1e3 * el / nb,
+                                "note": "one context, one host thread, one launch per kernel for the whole batch"})
+            bd.close()
 
     units = args.steps * (world if (world > 1 and not sharded) else 1)
     value = units / elapsed

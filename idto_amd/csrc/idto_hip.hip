@@ -42,6 +42,11 @@ struct DevBuf {
 
 struct idto_hip_ctx {
   int device = 0;
+  // batch: `batch` problems of the same model / horizon, one arena each (identical layout,
+  // `pstride` bytes apart); the pointers below address problem 0
+  int batch = 1;
+  size_t pstride = 0;
+  char* arena = nullptr;
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int nb = 0, nq = 0, nv = 0, N = 0, npaths = 1, maxc = 1;
@@ -64,6 +69,7 @@ struct idto_hip_ctx {
   int slab_stride = 0;
   int k_begin = 0, k_end = 0;
   bool weights_diagonal = false;
+  std::vector<char> prob_diag;            // per problem of the batch
   bool reference_solver = false;  // bit-exact pivoted-LU block Thomas (kernels.h penta_kernel)
   int asm_diag_lds = 0;
   // launch geometry
@@ -84,6 +90,8 @@ struct idto_hip_ctx {
   unsigned* flags = nullptr;
   size_t xch_count = 0, flag_count = 0;
   unsigned epoch = 0;
+  unsigned long long* sync_cnt = nullptr;            // fused launch: [fd blocks done, assembly blocks done] (monotonic)
+  unsigned long long sync_steps = 0;                 // fused launches so far
   double* Tst = nullptr;                             // column-major copies of the factor blocks (penta_apply.h)
   double *stage_rhs = nullptr, *stage_x = nullptr;  // idto_hip_solve_host
   double* pack = nullptr;                            // [tau | cost] of idto_hip_trial_cost (device)
@@ -135,8 +143,10 @@ int Alloc(idto_hip_ctx* c, size_t count, T** dev) {
   return 0;
 }
 
-int UploadProblemArrays(idto_hip_ctx* c, const idto_problem_t* p, bool first) {
+// (problem `pb` of the batch: destination = problem 0's arrays shifted by pb * pstride)
+int UploadProblemArrays(idto_hip_ctx* c, const idto_problem_t* p, int pb = 0) {
   const int nq = c->nq, nv = c->nv, N = c->N;
+  const size_t po = (size_t)pb * c->pstride;
   const double dt = c->dt;
   auto scaled = [](const double* W, size_t n, double s1, double s2) {
     std::vector<double> out(n);
@@ -149,18 +159,12 @@ int UploadProblemArrays(idto_hip_ctx* c, const idto_problem_t* p, bool first) {
       std::vector<double>(p->Qq, p->Qq + (size_t)nq * nq), std::vector<double>(p->Qv, p->Qv + (size_t)nv * nv),
       std::vector<double>(p->R, p->R + (size_t)nv * nv), std::vector<double>(p->Qf_q, p->Qf_q + (size_t)nq * nq),
       std::vector<double>(p->Qf_v, p->Qf_v + (size_t)nv * nv)};
-  if (first) {
-    if (Upload(c, p->v_init, nv, &c->d_vinit)) return -2;
-    if (Upload(c, p->q_nom, (size_t)(N + 1) * nq, &c->d_qnom)) return -2;
-    if (Upload(c, p->v_nom, (size_t)(N + 1) * nv, &c->d_vnom)) return -2;
+  {
+    HIP_OK(hipMemcpyAsync(at_problem(c->d_vinit, po), p->v_init, nv * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(at_problem(c->d_qnom, po), p->q_nom, (size_t)(N + 1) * nq * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(at_problem(c->d_vnom, po), p->v_nom, (size_t)(N + 1) * nv * sizeof(double), hipMemcpyHostToDevice, c->stream));
     for (int i = 0; i < 10; ++i)
-      if (Upload(c, w[i].data(), w[i].size(), &c->d_w[i])) return -2;
-  } else {
-    HIP_OK(hipMemcpyAsync(c->d_vinit, p->v_init, nv * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIP_OK(hipMemcpyAsync(c->d_qnom, p->q_nom, (size_t)(N + 1) * nq * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIP_OK(hipMemcpyAsync(c->d_vnom, p->v_nom, (size_t)(N + 1) * nv * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    for (int i = 0; i < 10; ++i)
-      HIP_OK(hipMemcpyAsync(c->d_w[i], w[i].data(), w[i].size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      HIP_OK(hipMemcpyAsync(at_problem(c->d_w[i], po), w[i].data(), w[i].size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));  // host staging vectors die at scope exit
   }
   auto is_diag = [](const double* W, int n) {
@@ -169,8 +173,14 @@ int UploadProblemArrays(idto_hip_ctx* c, const idto_problem_t* p, bool first) {
         if (r != c2 && W[(size_t)c2 * n + r] != 0.0) return false;
     return true;
   };
-  c->weights_diagonal = is_diag(p->Qq, nq) && is_diag(p->Qv, nv) && is_diag(p->R, nv) && is_diag(p->Qf_q, nq) &&
-                        is_diag(p->Qf_v, nv);
+  const bool diag = is_diag(p->Qq, nq) && is_diag(p->Qv, nv) && is_diag(p->R, nv) && is_diag(p->Qf_q, nq) &&
+                    is_diag(p->Qf_v, nv);
+  // (one assembly kernel serves the whole batch: the diagonal fast path needs every problem's
+  // weights diagonal; a batch re-evaluates the flag when problem 0 is replaced)
+  if ((int)c->prob_diag.size() != c->batch) c->prob_diag.assign((size_t)c->batch, 0);
+  c->prob_diag[(size_t)pb] = diag ? 1 : 0;
+  c->weights_diagonal = true;
+  for (char d : c->prob_diag) c->weights_diagonal = c->weights_diagonal && d;
   DevProblem& P = c->P;
   P.N = N; P.dt = dt; P.v_init = c->d_vinit; P.q_nom = c->d_qnom; P.v_nom = c->d_vnom;
   P.Qq = c->d_w[0]; P.Qv = c->d_w[1]; P.R = c->d_w[2]; P.Qfq = c->d_w[3]; P.Qfv = c->d_w[4];
@@ -285,7 +295,7 @@ int FdLds(const idto_hip_ctx* c, int mode, int ec) {
 int LaunchFd(idto_hip_ctx* c, int mode, int kb, int ke) {
   if (ke <= kb) return 0;
   if (mode >= 1) mode = 1 + c->gradients_method;  // 1 forward, 2 central, 3 central (4th order)
-  dim3 grid(ke - kb), block(mode >= 1 ? c->fd_threads : 64);
+  dim3 grid(ke - kb, c->batch), block(mode >= 1 ? c->fd_threads : 64);
   // evaluations per pass: all of them if they fit in LDS, otherwise the largest multiple of
   // the number of evaluations the block runs concurrently
   const int E = FdEvals(c, mode), groups = (int)block.x / c->npaths;
@@ -295,7 +305,7 @@ int LaunchFd(idto_hip_ctx* c, int mode, int kb, int ke) {
   if (lds > 160 * 1024) { g_err = "finite-difference evaluation set does not fit in LDS"; return -1; }
 #define FD_LAUNCH(MC)                                                                                         \
   hipLaunchKernelGGL(fd_kernel<MC>, grid, block, lds, c->stream, c->M, c->cp, c->P, c->q, c->slab,             \
-                     c->slab_stride, c->v, c->a, c->nplus, kb, mode, c->fd_stop, ec)
+                     c->slab_stride, c->v, c->a, c->nplus, kb, mode, c->fd_stop, ec, c->pstride)
   if (c->maxc <= 2) FD_LAUNCH(2);
   else if (c->maxc <= 3) FD_LAUNCH(3);
   else if (c->maxc <= 4) FD_LAUNCH(4);
@@ -356,9 +366,12 @@ int EnsureStage(idto_hip_ctx* c, size_t count) {
 // a pending idto_hip_prefetch of an array is dropped when that array is about to be recomputed
 // (idto_hip_get then reads the new contents instead of the stale staged copy)
 // after a stream synchronisation: did the most recent factorisation report a failed pivot?
-int FactorStatus(idto_hip_ctx* c) {
+// (problem `pb` of the batch, or any of them for pb < 0)
+int FactorStatus(idto_hip_ctx* c, int pb = -1) {
   const volatile unsigned* st = c->status_pin;
-  if (c->fact_id != 0 && st[0] == c->fact_id) {
+  bool any = false;
+  for (int b = (pb < 0 ? 0 : pb); b < (pb < 0 ? c->batch : pb + 1); ++b) any = any || st[2 * b] == c->fact_id;
+  if (c->fact_id != 0 && any) {
     g_err = "factorisation failed: the Hessian is not numerically positive definite (a pivot was non-positive, "
             "non-finite or fully cancelled)";
     return IDTO_HIP_FACTORIZATION_FAILED;
@@ -379,15 +392,28 @@ const char* idto_hip_last_error(void) { return g_err.c_str(); }
 
 int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem, const idto_contact_params_t* contact,
                     int device, idto_hip_ctx** out) {
+  return idto_hip_create_batch(model, problem, contact, device, 1, out);
+}
+
+int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* problems, const idto_contact_params_t* contact,
+                          int device, int batch, idto_hip_ctx** out) {
   *out = nullptr;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
     g_err = "no HIP device available (the product path has no CPU fallback)";
     return -3;
   }
+  if (batch < 1 || batch > 65535) { g_err = "batch must be in [1, 65535]"; return -1; }
+  for (int b = 1; b < batch; ++b)
+    if (problems[b].num_steps != problems[0].num_steps || problems[b].time_step != problems[0].time_step) {
+      g_err = "all problems of a batch share num_steps and time_step";
+      return -1;
+    }
+  const idto_problem_t* problem = problems;
   HIP_OK(hipSetDevice(device));
   idto_hip_ctx* c = new idto_hip_ctx();
   c->device = device;
+  c->batch = batch;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_err = "hipStreamCreate failed"; delete c; return -2; }
   c->own_stream = true;
   c->nb = model->nbodies; c->nq = model->nq; c->nv = model->nv; c->N = problem->num_steps;
@@ -402,42 +428,75 @@ int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem, co
     const double eps = std::sqrt(2.220446049250313e-16);
     c->cp.threshold = -c->cp.sigma * idto::detmath::log(idto::detmath::exp(eps / (c->cp.sigma * c->cp.k)) - 1.0);
   }
-  rc = UploadProblemArrays(c, problem, true);
-  if (rc) { idto_hip_destroy(c); return rc; }
   const size_t bsz = (size_t)nv * nq, qq = (size_t)nq * nq;
   c->slab_stride = (int)(3 * bsz + nv);
-  bool bad = false;
-  bad |= Alloc(c, (size_t)(N + 1) * nq, &c->q) != 0;
-  bad |= Alloc(c, (size_t)(N + 1) * nv, &c->v) != 0;
-  bad |= Alloc(c, (size_t)N * nv, &c->a) != 0;
-  bad |= Alloc(c, (size_t)(N + 1) * bsz, &c->nplus) != 0;
-  bad |= Alloc(c, (size_t)N * c->slab_stride, &c->slab) != 0;
-  bad |= Alloc(c, (size_t)(N + 1) * nq, &c->g) != 0;
-  // two extra zero blocks: the solver prefetches rows i+1, i+2 without bounds checks
-  // (one allocation: the solver addresses all three bands from HA with 32-bit offsets)
-  bad |= Alloc(c, (size_t)3 * (N + 6) * qq, &c->HA) != 0;
+  // ---- one arena per problem (identical layout): carve offsets first, allocate batch * pstride
+  // bytes at once (zero-filled), then point the problem-0 pointers into the first arena
+  size_t top = 0;
+  auto carve = [&](size_t count, size_t elem) {
+    const size_t o = (top + 63) & ~(size_t)63;
+    top = o + std::max<size_t>(count, 1) * elem;
+    return o;
+  };
+  const size_t D = sizeof(double);
+  const size_t o_vinit = carve(nv, D), o_qnom = carve((size_t)(N + 1) * nq, D), o_vnom = carve((size_t)(N + 1) * nv, D);
+  size_t o_w[10];
+  for (int i = 0; i < 10; ++i) o_w[i] = carve((i == 0 || i == 3 || i == 5 || i == 8) ? qq : (size_t)nv * nv, D);
+  const size_t o_q = carve((size_t)(N + 1) * nq, D), o_v = carve((size_t)(N + 1) * nv, D), o_a = carve((size_t)N * nv, D);
+  const size_t o_np = carve((size_t)(N + 1) * bsz, D), o_slab = carve((size_t)N * c->slab_stride, D);
+  const size_t o_g = carve((size_t)(N + 1) * nq, D);
+  // two extra zero blocks (five are reserved): the solver prefetches rows i+1, i+2 without bounds
+  // checks (one allocation: the solver addresses all three bands from HA with 32-bit offsets)
+  const size_t o_H = carve((size_t)3 * (N + 6) * qq, D);
+  const size_t o_step = carve((size_t)(N + 1) * nq, D), o_cost = carve(1, D);
+  const size_t o_K = carve((size_t)(N + 1) * qq, D), o_LU = carve((size_t)(N + 1) * qq, D);
+  const size_t o_Y = carve((size_t)(N + 1) * qq, D), o_Z = carve((size_t)(N + 1) * qq, D);
+  const size_t o_piv = carve((size_t)(N + 1) * nq, sizeof(int));
+  const size_t o_dbg = carve((size_t)(N + 4) * 8 * 32, D);
+  const size_t o_U = carve((size_t)(N + 1) * 32 * 36, D), o_Hs = carve((size_t)(N + 1) * 32 * 36, D);
+  const size_t o_E = carve((size_t)(N + 1) * 32 * 36, D), o_Ds = carve((size_t)(N + 1) * 32, D);
+  // exchange buffer of the two-sided solver (one right-hand side): 2 augmented blocks + [2][K]
+  c->xch_count = 2 * (size_t)(3 * 32 + 1) * ldl_ks(32) + 2 * 32;
+  const size_t o_xch = carve(c->xch_count, D);
+  c->flag_count = 8;
+  const size_t o_flags = carve(c->flag_count, sizeof(unsigned)), o_sync = carve(2, sizeof(unsigned long long));
+  c->pstride = (top + 255) & ~(size_t)255;
+  {
+    void* p = nullptr;
+    if (hipMalloc(&p, c->pstride * (size_t)batch) != hipSuccess || hipMemset(p, 0, c->pstride * (size_t)batch) != hipSuccess) {
+      g_err = "hipMalloc of the problem arenas failed";
+      idto_hip_destroy(c);
+      return -2;
+    }
+    c->allocs.push_back(p);
+    c->arena = static_cast<char*>(p);
+  }
+  auto dp = [&](size_t o) { return reinterpret_cast<double*>(c->arena + o); };
+  c->d_vinit = dp(o_vinit); c->d_qnom = dp(o_qnom); c->d_vnom = dp(o_vnom);
+  for (int i = 0; i < 10; ++i) c->d_w[i] = dp(o_w[i]);
+  c->q = dp(o_q); c->v = dp(o_v); c->a = dp(o_a); c->nplus = dp(o_np); c->slab = dp(o_slab); c->g = dp(o_g);
+  c->HA = dp(o_H);
   c->HB = c->HA + (size_t)(N + 6) * qq;
   c->HC = c->HB + (size_t)(N + 6) * qq;
-  bad |= Alloc(c, (size_t)(N + 1) * nq, &c->step) != 0;
-  bad |= Alloc(c, (size_t)1, &c->cost) != 0;
-  bad |= Alloc(c, (size_t)(N + 1) * qq, &c->Kst) != 0;
-  bad |= Alloc(c, (size_t)(N + 1) * qq, &c->LUst) != 0;
-  bad |= Alloc(c, (size_t)(N + 1) * qq, &c->Yst) != 0;
-  bad |= Alloc(c, (size_t)(N + 1) * qq, &c->Zst) != 0;
-  bad |= Alloc(c, (size_t)(N + 1) * nq, &c->pivst) != 0;
-  bad |= Alloc(c, (size_t)(N + 4) * 8 * 32, &c->dbg) != 0;
-  bad |= Alloc(c, (size_t)(N + 1) * 32 * 36, &c->Ust) != 0;
-  bad |= Alloc(c, (size_t)(N + 1) * 32 * 36, &c->Hst) != 0;
-  bad |= Alloc(c, (size_t)(N + 1) * 32 * 36, &c->Est) != 0;
-  bad |= Alloc(c, (size_t)(N + 1) * 32, &c->Dst) != 0;
-  if (bad) { idto_hip_destroy(c); return -2; }
-  if (hipHostMalloc((void**)&c->status_pin, 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess ||
+  c->step = dp(o_step); c->cost = dp(o_cost);
+  c->Kst = dp(o_K); c->LUst = dp(o_LU); c->Yst = dp(o_Y); c->Zst = dp(o_Z);
+  c->pivst = reinterpret_cast<int*>(c->arena + o_piv);
+  c->dbg = dp(o_dbg);
+  c->Ust = dp(o_U); c->Hst = dp(o_Hs); c->Est = dp(o_E); c->Dst = dp(o_Ds);
+  c->xch = dp(o_xch);
+  c->flags = reinterpret_cast<unsigned*>(c->arena + o_flags);
+  c->sync_cnt = reinterpret_cast<unsigned long long*>(c->arena + o_sync);
+  for (int b = 0; b < batch; ++b) {
+    rc = UploadProblemArrays(c, problems + b, b);
+    if (rc) { idto_hip_destroy(c); return rc; }
+  }
+  if (hipHostMalloc((void**)&c->status_pin, 2 * (size_t)batch * sizeof(unsigned), hipHostMallocDefault) != hipSuccess ||
       hipHostGetDevicePointer((void**)&c->status_dev, c->status_pin, 0) != hipSuccess) {
     g_err = "hipHostMalloc (solver status) failed";
     idto_hip_destroy(c);
     return -2;
   }
-  c->status_pin[0] = 0; c->status_pin[1] = 0;
+  for (int i = 0; i < 2 * batch; ++i) c->status_pin[i] = 0;
   c->k_begin = 0; c->k_end = N;
 
   // launch geometry
@@ -512,13 +571,18 @@ void idto_hip_destroy(idto_hip_ctx* c) {
   delete c;
 }
 
-int idto_hip_set_problem(idto_hip_ctx* c, const idto_problem_t* p) {
+int idto_hip_set_problem(idto_hip_ctx* c, const idto_problem_t* p) { return idto_hip_set_problem_batch(c, 0, p); }
+
+int idto_hip_set_problem_batch(idto_hip_ctx* c, int b, const idto_problem_t* p) {
+  if (b < 0 || b >= c->batch) { g_err = "problem index outside the batch"; return -1; }
   if (p->num_steps != c->N || p->time_step != c->dt) { g_err = "num_steps / time_step cannot change"; return -1; }
   HIP_OK(hipSetDevice(c->device));
   c->fd_full = false;  // v_0 = v_init
   c->con_ready = false; c->con_begun = false;
-  return UploadProblemArrays(c, p, false);
+  return UploadProblemArrays(c, p, b);
 }
+
+int idto_hip_batch_size(idto_hip_ctx* c) { return c->batch; }
 
 int idto_hip_set_stream(idto_hip_ctx* c, void* s) {
   if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
@@ -543,6 +607,16 @@ int idto_hip_set_q(idto_hip_ctx* c, const double* q_host) {
   HIP_OK(hipStreamSynchronize(c->stream));  // the host buffer may be reused by the caller
   return 0;
 }
+int idto_hip_set_q_batch(idto_hip_ctx* c, const double* q_host) {
+  HIP_OK(hipSetDevice(c->device));
+  DropPrefetch(c, {IDTO_ARR_Q});
+  c->fd_full = false;
+  c->con_ready = false; c->con_begun = false;
+  const size_t row = (size_t)(c->N + 1) * c->nq * sizeof(double);  // one trajectory per arena
+  HIP_OK(hipMemcpy2DAsync(c->q, c->pstride, q_host, row, row, (size_t)c->batch, hipMemcpyHostToDevice, c->stream));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  return 0;
+}
 int idto_hip_set_q_device(idto_hip_ctx* c, const double* q_dev) {
   HIP_OK(hipSetDevice(c->device));
   DropPrefetch(c, {IDTO_ARR_Q});
@@ -557,14 +631,15 @@ int idto_hip_eval_tau(idto_hip_ctx* c) {
   DropPrefetch(c, {IDTO_ARR_V, IDTO_ARR_A, IDTO_ARR_NPLUS, IDTO_ARR_SLAB, IDTO_ARR_COST});
   int rc = LaunchFd(c, 0, 0, c->N);
   if (rc) return rc;
-  hipLaunchKernelGGL(cost_kernel, dim3(1), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
-                     c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, (double*)nullptr);
+  hipLaunchKernelGGL(cost_kernel, dim3(1, c->batch), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
+                     c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, (double*)nullptr, c->pstride);
   HIP_OK(hipGetLastError());
   return 0;
 }
 
 int idto_hip_trial_cost(idto_hip_ctx* c, const double* q_host, double* tau_host, double* cost_host) {
   HIP_OK(hipSetDevice(c->device));
+  if (c->batch != 1) { g_err = "trial_cost serves single-problem contexts"; return -1; }
   if (!q_host || !cost_host) { g_err = "trial_cost: bad arguments"; return -1; }
   DropPrefetch(c, {IDTO_ARR_Q, IDTO_ARR_V, IDTO_ARR_A, IDTO_ARR_NPLUS, IDTO_ARR_SLAB, IDTO_ARR_COST});
   const size_t nq_all = (size_t)(c->N + 1) * c->nq, ntau = (size_t)c->N * c->nv;
@@ -581,7 +656,7 @@ int idto_hip_trial_cost(idto_hip_ctx* c, const double* q_host, double* tau_host,
   int rc = LaunchFd(c, 0, 0, c->N);
   if (rc) return rc;
   hipLaunchKernelGGL(cost_kernel, dim3(1), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
-                     c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, c->pack);
+                     c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, c->pack, (size_t)0);
   HIP_OK(hipGetLastError());
   double* out = c->pin + nq_all;
   HIP_OK(hipMemcpyAsync(out, c->pack, (ntau + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -606,18 +681,18 @@ int idto_hip_grad_hess(idto_hip_ctx* c) {
   HIP_OK(hipSetDevice(c->device));
   DropPrefetch(c, {IDTO_ARR_GRADIENT, IDTO_ARR_H_A, IDTO_ARR_H_B, IDTO_ARR_H_C, IDTO_ARR_HBANDS});
   if (!c->h_assembled) {  // x_0 = -g_0 = 0 is no longer written by the solver (SolverFirstRow)
-    HIP_OK(hipMemsetAsync(c->step, 0, (size_t)c->nq * sizeof(double), c->stream));
+    HIP_OK(hipMemset2DAsync(c->step, c->pstride, 0, (size_t)c->nq * sizeof(double), (size_t)c->batch, c->stream));
     c->h_assembled = true;
   }
   c->con_ready = false; c->con_begun = false;
   if (TimeBegin(c, 1)) return -2;
   if (c->weights_diagonal)
-    hipLaunchKernelGGL(assemble_diag_kernel, dim3(c->N + 1, 4), dim3(256), c->asm_diag_lds, c->stream, c->M, c->P, c->q,
-                       c->slab, c->slab_stride, c->g, c->HA, c->HB, c->HC, c->asm_stop,
-                       c->fd_full ? c->v : nullptr, c->fd_full ? c->nplus : nullptr);
+    hipLaunchKernelGGL(assemble_diag_kernel, dim3(c->N + 1, 4, c->batch), dim3(256), c->asm_diag_lds, c->stream, c->M,
+                       c->P, c->q, c->slab, c->slab_stride, c->g, c->HA, c->HB, c->HC, c->asm_stop,
+                       c->fd_full ? c->v : nullptr, c->fd_full ? c->nplus : nullptr, c->pstride);
   else
-    hipLaunchKernelGGL(assemble_kernel, dim3(c->N + 1), dim3(256), c->asm_lds, c->stream, c->M, c->P, c->q, c->slab,
-                       c->slab_stride, c->g, c->HA, c->HB, c->HC);
+    hipLaunchKernelGGL(assemble_kernel, dim3(c->N + 1, c->batch), dim3(256), c->asm_lds, c->stream, c->M, c->P, c->q,
+                       c->slab, c->slab_stride, c->g, c->HA, c->HB, c->HC, c->pstride);
   HIP_OK(hipGetLastError());
   return TimeEnd(c);
 }
@@ -648,28 +723,15 @@ static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, int nrhs, do
   // two-sided elimination (two workgroups meeting at block rows m, m+1) once the horizon is long
   // enough to pay for the hand-over; exchange buffer: 2 augmented blocks + [nrhs][2][K]
   const int m_split = (c->two_sided && !one_sided && n >= 10) ? (n - 1) / 2 : 0;
-  const dim3 grid(m_split > 0 ? 2 : 1);
+  const dim3 grid(m_split > 0 ? 2 : 1, c->batch);
   // the two workgroups must not share a CU (each is one wavefront per SIMD, issue-bound): ask for
   // more than half of the 160 KB LDS so that the dispatcher cannot co-locate them
   if (m_split > 0) lds = std::max(lds, 84 * 1024);
   if (lds > 160 * 1024) { g_err = "LDS carve-up too large"; return -1; }
-  if (m_split > 0) {
-    const size_t need = 2 * (size_t)(K + ncr) * ldl_ks(K) + (size_t)nrhs * 2 * K, nflags = (size_t)nrhs + 1;
-    if (need > c->xch_count) {
-      if (Alloc(c, need, &c->xch)) return -2;
-      c->xch_count = need;
-    }
-    if (nflags > c->flag_count) {
-      if (Alloc(c, nflags, &c->flags)) return -2;
-      HIP_OK(hipMemsetAsync(c->flags, 0, nflags * sizeof(unsigned), c->stream));
-      c->flag_count = nflags;
-      c->epoch = 0;
-    }
-    ++c->epoch;
-  }
+  if (m_split > 0) ++c->epoch;  // (exchange buffer and flags live in the problem's arena)
   if (++c->fact_id == 0) c->fact_id = 1;  // (0 is the initial value of the status word)
 #define LDL_ARGS n, k, c->HA + qq0, c->HB + qq0, c->HC + qq0, b, sign, nrhs, xo, c->Ust, c->Hst, c->Est, c->Dst, dbg, \
-                 m_split, c->xch, c->flags, c->epoch, c->status_dev, c->fact_id
+                 m_split, c->xch, c->flags, c->epoch, c->status_dev, c->fact_id, c->pstride
 #define LDL_LAUNCH(KM, PD, GW)                                                                                \
   do {                                                                                                        \
     if (threads == 256 && gj_waves == GW)                                                                     \
@@ -704,11 +766,13 @@ int idto_hip_factor_solve(idto_hip_ctx* c, const double* rhs, int nrhs, double* 
   double* xo = rhs ? x : c->step;
   if (!rhs) nrhs = 1;
   if (nrhs < 1) { g_err = "nrhs < 1"; return -1; }
+  if (rhs && c->batch != 1) { g_err = "explicit right-hand sides serve single-problem contexts"; return -1; }
   if (TimeBegin(c, 2)) return -2;
   if (c->reference_solver) {
     if (++c->fact_id == 0) c->fact_id = 1;
-    hipLaunchKernelGGL(penta_kernel, dim3(1), dim3(256), c->penta_lds, c->stream, n, k, c->HA, c->HB, c->HC, b,
-                       rhs ? 1.0 : -1.0, xo, c->Kst, c->LUst, c->pivst, c->Yst, c->Zst, c->status_dev, c->fact_id);
+    hipLaunchKernelGGL(penta_kernel, dim3(1, c->batch), dim3(256), c->penta_lds, c->stream, n, k, c->HA, c->HB, c->HC, b,
+                       rhs ? 1.0 : -1.0, xo, c->Kst, c->LUst, c->pivst, c->Yst, c->Zst, c->status_dev, c->fact_id,
+                       c->pstride);
     HIP_OK(hipGetLastError());
     if (TimeEnd(c)) return -2;
     if (nrhs > 1) {
@@ -760,6 +824,7 @@ int idto_hip_factor_solve(idto_hip_ctx* c, const double* rhs, int nrhs, double* 
 int idto_hip_solve_host(idto_hip_ctx* c, const double* rhs_host, int nrhs, double* x_host) {
   HIP_OK(hipSetDevice(c->device));
   if (!rhs_host || !x_host || nrhs < 1) { g_err = "solve_host: bad arguments"; return -1; }
+  if (c->batch != 1) { g_err = "solve_host serves single-problem contexts"; return -1; }
   const size_t count = (size_t)nrhs * (c->N + 1) * c->nq;
   if (EnsureStage(c, count)) return -2;
   c->con_ready = false; c->con_begun = false;  // the staging buffers are shared with the constraint step
@@ -774,6 +839,7 @@ int idto_hip_solve_host(idto_hip_ctx* c, const double* rhs_host, int nrhs, doubl
 int idto_hip_constraint_schur_begin(idto_hip_ctx* c, const int* dofs, int nu) {
   HIP_OK(hipSetDevice(c->device));
   if (!dofs || nu < 1 || nu > c->nv) { g_err = "constraint_schur: bad arguments"; return -1; }
+  if (c->batch != 1) { g_err = "the equality-constraint step serves single-problem contexts"; return -1; }
   for (int j = 0; j < nu; ++j)
     if (dofs[j] < 0 || dofs[j] >= c->nv) { g_err = "constraint_schur: dof index out of range"; return -1; }
   const int N = c->N, n = (N + 1) * c->nq, neq = nu * N;
@@ -1042,30 +1108,51 @@ int idto_hip_get(idto_hip_ctx* c, int what, double* out) {
       pf.pending = false;
       return (what == IDTO_ARR_STEP) ? FactorStatus(c) : 0;
     }
+  return idto_hip_get_batch(c, what, 0, out);
+}
+
+int idto_hip_get_batch(idto_hip_ctx* c, int what, int pb, double* out) {
+  HIP_OK(hipSetDevice(c->device));
+  if (pb < 0 || pb >= c->batch) { g_err = "problem index outside the batch"; return -1; }
   HIP_OK(hipStreamSynchronize(c->stream));
   const long count = idto_hip_array_size(c, what);
   if (count < 0) { g_err = "unknown array id"; return -1; }
-  const size_t bsz = (size_t)c->nv * c->nq;
+  const size_t bsz = (size_t)c->nv * c->nq, po = (size_t)pb * c->pstride;
   if (what == IDTO_ARR_TAU || (what >= IDTO_ARR_DTAU_DQM && what <= IDTO_ARR_DTAU_DQP)) {
     const size_t off = what == IDTO_ARR_TAU ? 3 * bsz : (size_t)(what - IDTO_ARR_DTAU_DQM) * bsz;
     const size_t width = what == IDTO_ARR_TAU ? (size_t)c->nv : bsz;
-    HIP_OK(hipMemcpy2D(out, width * sizeof(double), c->slab + off, (size_t)c->slab_stride * sizeof(double),
+    HIP_OK(hipMemcpy2D(out, width * sizeof(double), at_problem(c->slab, po) + off, (size_t)c->slab_stride * sizeof(double),
                        width * sizeof(double), c->N, hipMemcpyDeviceToHost));
     return 0;
   }
   void* p = DevPtr(c, what);
-  HIP_OK(hipMemcpy(out, p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
-  return (what == IDTO_ARR_STEP) ? FactorStatus(c) : 0;
+  HIP_OK(hipMemcpy(out, at_problem(static_cast<char*>(p), po), (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+  return (what == IDTO_ARR_STEP) ? FactorStatus(c, pb) : 0;
 }
 
 int idto_hip_solver_status(idto_hip_ctx* c, int* failed, int* failed_rows_total) {
   HIP_OK(hipSetDevice(c->device));
   HIP_OK(hipStreamSynchronize(c->stream));
   const volatile unsigned* st = c->status_pin;
-  if (failed) *failed = (c->fact_id != 0 && st[0] == c->fact_id) ? 1 : 0;
-  if (failed_rows_total) *failed_rows_total = (int)st[1];
+  int any = 0, rows = 0;
+  for (int b = 0; b < c->batch; ++b) {
+    any |= (c->fact_id != 0 && st[2 * b] == c->fact_id) ? 1 : 0;
+    rows += (int)st[2 * b + 1];
+  }
+  if (failed) *failed = any;
+  if (failed_rows_total) *failed_rows_total = rows;
   return 0;
 }
+
+int idto_hip_solver_status_batch(idto_hip_ctx* c, int* failed) {
+  HIP_OK(hipSetDevice(c->device));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  const volatile unsigned* st = c->status_pin;
+  for (int b = 0; b < c->batch; ++b) failed[b] = (c->fact_id != 0 && st[2 * b] == c->fact_id) ? 1 : 0;
+  return 0;
+}
+
+int idto_hip_gn_step_batch(idto_hip_ctx* c) { return idto_hip_gn_step(c); }
 
 int idto_hip_math_probe(int device, const double* x, int n, double* sq, double* rc, double* sn, double* cs, double* ex,
                         double* lg) {

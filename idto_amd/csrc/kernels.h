@@ -6,6 +6,7 @@
 // -ffp-contract=off; every sum has the association order of DESIGN.md §3.2.
 #pragma once
 
+#include "batch.h"
 #include "id_eval.h"
 
 namespace idto_dev {
@@ -25,6 +26,15 @@ struct DevProblem {
   // unscaled weights for the cost (TO.cc:147-176)
   const double* Qq0; const double* Qv0; const double* R0; const double* Qfq0; const double* Qfv0;
 };
+
+__host__ __device__ __forceinline__ DevProblem at_problem(DevProblem P, size_t o) {
+  P.v_init = at_problem(P.v_init, o); P.q_nom = at_problem(P.q_nom, o); P.v_nom = at_problem(P.v_nom, o);
+  P.Qq = at_problem(P.Qq, o); P.Qv = at_problem(P.Qv, o); P.R = at_problem(P.R, o); P.Qfq = at_problem(P.Qfq, o);
+  P.Qfv = at_problem(P.Qfv, o);
+  P.Qq0 = at_problem(P.Qq0, o); P.Qv0 = at_problem(P.Qv0, o); P.R0 = at_problem(P.R0, o); P.Qfq0 = at_problem(P.Qfq0, o);
+  P.Qfv0 = at_problem(P.Qfv0, o);
+  return P;
+}
 
 // ---------------------------------------------------------------------------
 // N+(q) for one configuration into LDS (nv x nq column-major); restates
@@ -134,13 +144,12 @@ IDTO_DEV void velocity_block(const DevModel& M, const double* N, const double* q
 // mode 0: tau only (one evaluation); mode 1: forward differences (TO.cc:426-563).
 // Dynamic LDS layout (doubles): see the carve-up below.
 template <int MAXC>
-__global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevProblem P, const double* __restrict__ q,
-                          double* __restrict__ slab, int slab_stride, double* __restrict__ v_out,
-                          double* __restrict__ a_out, double* __restrict__ nplus_out, int k_begin, int mode,
-                          int stop_after, int echunk) {
+IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem& P, const double* __restrict__ q,
+                      double* __restrict__ slab, int slab_stride, double* __restrict__ v_out,
+                      double* __restrict__ a_out, double* __restrict__ nplus_out, const int k, int mode,
+                      int stop_after, int echunk) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int k = k_begin + blockIdx.x;
   const int nq = M.nq, nv = M.nv, K = M.npaths;
   const int bsz = nv * nq;
   const double dt = P.dt;
@@ -353,12 +362,28 @@ __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevP
   }
 }
 
+template <int MAXC>
+__global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevProblem P, const double* __restrict__ q,
+                          double* __restrict__ slab, int slab_stride, double* __restrict__ v_out,
+                          double* __restrict__ a_out, double* __restrict__ nplus_out, int k_begin, int mode,
+                          int stop_after, int echunk, size_t pstride) {
+  const size_t o = (size_t)blockIdx.y * pstride;  // problem of the batch
+  fd_body<MAXC>(M, cp, at_problem(P, o), at_problem(q, o), at_problem(slab, o), slab_stride, at_problem(v_out, o),
+                at_problem(a_out, o), at_problem(nplus_out, o), k_begin + (int)blockIdx.x, mode, stop_after, echunk);
+}
+
 // ---------------------------------------------------------------------------
-// Cost L(q) from resident q, v, tau (TO.cc:147-176).  One block; the final sum
+// Cost L(q) from resident q, v, tau (TO.cc:147-176).  One block per problem; the final sum
 // is accumulated serially in the reference's order.
 __global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__ q, const double* __restrict__ v,
                             const double* __restrict__ slab, int slab_stride, double* __restrict__ cost_out,
-                            int diag, double* __restrict__ pack) {
+                            int diag, double* __restrict__ pack, size_t pstride) {
+  {
+    const size_t o = (size_t)blockIdx.y * pstride;
+    P = at_problem(P, o); q = at_problem(q, o); v = at_problem(v, o); slab = at_problem(slab, o);
+    cost_out = at_problem(cost_out, o);
+    if (pack) pack = at_problem(pack, o);
+  }
   // e^T W e per term as the reference's Eigen expression evaluates it: tot = sum_c (sum_r e_r W[r][c]) e_c.
   // One thread per (term, column c); `diag`: the weights are diagonal, the inner sum is its one
   // non-zero product (the others are exact zeros).  Then one thread per term adds the columns in
@@ -460,7 +485,13 @@ IDTO_DEV void acc_vec_w_mat(const double* e, const double* W, const double* J, d
 
 __global__ void assemble_kernel(DevModel M, DevProblem P, const double* __restrict__ q,
                                 const double* __restrict__ slab, int slab_stride, double* __restrict__ g,
-                                double* __restrict__ HA, double* __restrict__ HB, double* __restrict__ HC) {
+                                double* __restrict__ HA, double* __restrict__ HB, double* __restrict__ HC,
+                                size_t pstride) {
+  {
+    const size_t o = (size_t)blockIdx.y * pstride;
+    P = at_problem(P, o); q = at_problem(q, o); slab = at_problem(slab, o); g = at_problem(g, o);
+    HA = at_problem(HA, o); HB = at_problem(HB, o); HC = at_problem(HC, o);
+  }
   extern __shared__ double lds[];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int i = blockIdx.x, N = P.N, nq = M.nq, nv = M.nv;
@@ -617,14 +648,14 @@ __global__ void assemble_kernel(DevModel M, DevProblem P, const double* __restri
 // (they are L2-resident).  The weighted operands (A(l, r) * w_l) are formed once per block in
 // LDS - the same product the inline expression yields - so that the inner loops are pure
 // 16-byte LDS reads + mul + add in the reference's term order.
-__global__ void __launch_bounds__(256)
-assemble_diag_kernel(DevModel M, DevProblem P, const double* __restrict__ q, const double* __restrict__ slab,
-                     int slab_stride, double* __restrict__ g, double* __restrict__ HA, double* __restrict__ HB,
-                     double* __restrict__ HC, int stop_after, const double* __restrict__ v_res,
-                     const double* __restrict__ nplus_res) {
+IDTO_DEV void assemble_diag_body(const DevModel& M, const DevProblem& P, const double* __restrict__ q,
+                                 const double* __restrict__ slab, int slab_stride, double* __restrict__ g,
+                                 double* __restrict__ HA, double* __restrict__ HB, double* __restrict__ HC,
+                                 int stop_after, const double* __restrict__ v_res,
+                                 const double* __restrict__ nplus_res, const int i, const int part) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int i = blockIdx.x, part = blockIdx.y, N = P.N, nq = M.nq, nv = M.nv;
+  const int N = P.N, nq = M.nq, nv = M.nv;
   const int bsz = nv * nq, qq = nq * nq;
   const int nvp = (nv + 1) & ~1;      // padded column length: 16-byte aligned columns in LDS
   const int psz = nvp * nq;
@@ -822,6 +853,18 @@ assemble_diag_kernel(DevModel M, DevProblem P, const double* __restrict__ q, con
   }
 }
 
+__global__ void __launch_bounds__(256)
+assemble_diag_kernel(DevModel M, DevProblem P, const double* __restrict__ q, const double* __restrict__ slab,
+                     int slab_stride, double* __restrict__ g, double* __restrict__ HA, double* __restrict__ HB,
+                     double* __restrict__ HC, int stop_after, const double* __restrict__ v_res,
+                     const double* __restrict__ nplus_res, size_t pstride) {
+  const size_t o = (size_t)blockIdx.z * pstride;  // problem of the batch
+  assemble_diag_body(M, at_problem(P, o), at_problem(q, o), at_problem(slab, o), slab_stride, at_problem(g, o),
+                     at_problem(HA, o), at_problem(HB, o), at_problem(HC, o), stop_after,
+                     v_res ? at_problem(v_res, o) : nullptr, nplus_res ? at_problem(nplus_res, o) : nullptr,
+                     (int)blockIdx.x, (int)blockIdx.y);
+}
+
 // ---------------------------------------------------------------------------
 // penta_kernel (v1): block-Thomas factorisation of the symmetric block
 // penta-diagonal H (lower bands A, B, C in HBM) fused with the solve of one
@@ -842,7 +885,14 @@ __global__ void penta_kernel(int n, int k, const double* __restrict__ HA, const 
                              const double* __restrict__ HC, const double* __restrict__ b, double rhs_sign,
                              double* __restrict__ x, double* __restrict__ Kst, double* __restrict__ LUst,
                              int* __restrict__ pivst, double* __restrict__ Yst, double* __restrict__ Zst,
-                             unsigned* __restrict__ status, unsigned fact_id) {
+                             unsigned* __restrict__ status, unsigned fact_id, size_t pstride) {
+  {
+    const size_t o = (size_t)blockIdx.y * pstride;
+    HA = at_problem(HA, o); HB = at_problem(HB, o); HC = at_problem(HC, o); b = at_problem(b, o); x = at_problem(x, o);
+    Kst = at_problem(Kst, o); LUst = at_problem(LUst, o); pivst = at_problem(pivst, o); Yst = at_problem(Yst, o);
+    Zst = at_problem(Zst, o);
+    status += 2 * blockIdx.y;
+  }
   extern __shared__ double lds[];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int kk = k * k;

@@ -39,6 +39,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "batch.h"
+
 namespace idto_dev {
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -165,13 +167,13 @@ __host__ __device__ inline PentaLdlLds penta_ldl_layout(int n, int K, int nrhs) 
 // the identity (padding rows/columns never mix with the real ones).
 // b, x: [nrhs][n*k]; Ust/Hst/Est: [n][K*K] factors (internal layout), Dst: [n][K].
 template <int K, int NT, bool PADDED, int GJW>
-__global__ void __launch_bounds__(NT)
-penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __restrict__ HB,
-                 const double* __restrict__ HC, const double* __restrict__ b, double rhs_sign, int nrhs,
-                 double* __restrict__ x, double* __restrict__ Ust, double* __restrict__ Hst,
-                 double* __restrict__ Est, double* __restrict__ Dst, double* __restrict__ dbg,
-                 int m_split, double* __restrict__ xch, unsigned* __restrict__ flags, unsigned epoch,
-                 unsigned* __restrict__ status, unsigned fact_id) {
+__device__ __forceinline__ void
+penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __restrict__ HB,
+               const double* __restrict__ HC, const double* __restrict__ b, double rhs_sign, int nrhs,
+               double* __restrict__ x, double* __restrict__ Ust, double* __restrict__ Hst,
+               double* __restrict__ Est, double* __restrict__ Dst, double* __restrict__ dbg,
+               int m_split, double* __restrict__ xch, unsigned* __restrict__ flags, unsigned epoch,
+               unsigned* __restrict__ status, unsigned fact_id, const int side) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // ---- two-sided ("twisted") elimination, m_split > 0, grid of 2 workgroups: workgroup 0
@@ -183,7 +185,6 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
   // and the top workgroup adds them before eliminating rows m and m+1.  Back substitution runs
   // outwards from the join in both workgroups (x_m, x_{m+1} handed to the bottom one).  The
   // dependent chain is ~n/2 block rows instead of n in both passes.
-  const int side = blockIdx.x;
   const bool two = m_split > 0;
   const int nloc = two ? (side ? n - m_split - 2 : m_split + 2) : n;  // block rows eliminated here
   const int nfwd = nloc + ((two && side) ? 2 : 0);                    // + pseudo-rows (bottom)
@@ -844,6 +845,24 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
     }
   }
   stamp(nfwd, 1);
+}
+
+// grid (sides, batch): blockIdx.x = side of the two-sided elimination, blockIdx.y = problem of the
+// batch (arenas `pstride` bytes apart, see kernels.h at_problem; b / x are per-problem arrays too)
+template <int K, int NT, bool PADDED, int GJW>
+__global__ void __launch_bounds__(NT)
+penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __restrict__ HB,
+                 const double* __restrict__ HC, const double* __restrict__ b, double rhs_sign, int nrhs,
+                 double* __restrict__ x, double* __restrict__ Ust, double* __restrict__ Hst,
+                 double* __restrict__ Est, double* __restrict__ Dst, double* __restrict__ dbg,
+                 int m_split, double* __restrict__ xch, unsigned* __restrict__ flags, unsigned epoch,
+                 unsigned* __restrict__ status, unsigned fact_id, size_t pstride) {
+  const size_t o = (size_t)blockIdx.y * pstride;
+  penta_ldl_body<K, NT, PADDED, GJW>(n, k, at_problem(HA, o), at_problem(HB, o), at_problem(HC, o), at_problem(b, o),
+                                     rhs_sign, nrhs, at_problem(x, o), at_problem(Ust, o), at_problem(Hst, o),
+                                     at_problem(Est, o), at_problem(Dst, o), dbg ? at_problem(dbg, o) : nullptr, m_split,
+                                     at_problem(xch, o), at_problem(flags, o), epoch, status + 2 * blockIdx.y, fact_id,
+                                     (int)blockIdx.x);
 }
 
 }  // namespace idto_dev

@@ -42,6 +42,14 @@ def lib():
         L.idto_hip_last_error.restype = C.c_char_p
         L.idto_hip_create.argtypes = [C.POINTER(CModel), C.POINTER(CProblem), C.POINTER(CContactParams), C.c_int,
                                       C.POINTER(C.c_void_p)]
+        L.idto_hip_create_batch.argtypes = [C.POINTER(CModel), C.POINTER(CProblem), C.POINTER(CContactParams), C.c_int,
+                                            C.c_int, C.POINTER(C.c_void_p)]
+        L.idto_hip_batch_size.argtypes = [C.c_void_p]
+        L.idto_hip_set_problem_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(CProblem)]
+        L.idto_hip_set_q_batch.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.idto_hip_gn_step_batch.argtypes = [C.c_void_p]
+        L.idto_hip_get_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.idto_hip_solver_status_batch.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.idto_hip_destroy.argtypes = [C.c_void_p]
         L.idto_hip_set_problem.argtypes = [C.c_void_p, C.POINTER(CProblem)]
         L.idto_hip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
@@ -86,7 +94,8 @@ EXPORTED_SYMBOLS = [
     "idto_hip_set_option",
     "idto_hip_timing_enable", "idto_hip_timing_reset", "idto_hip_timing_get", "idto_hip_sync", "idto_hip_get",
     "idto_hip_device_ptr", "idto_hip_array_size", "idto_hip_slab_stride", "idto_hip_math_probe",
-    "idto_hip_solver_status",
+    "idto_hip_solver_status", "idto_hip_create_batch", "idto_hip_batch_size", "idto_hip_set_problem_batch",
+    "idto_hip_set_q_batch", "idto_hip_gn_step_batch", "idto_hip_get_batch", "idto_hip_solver_status_batch",
 ]
 
 
@@ -112,15 +121,24 @@ def _chk(rc):
 class HipPath:
     """One problem resident on one MI355X: the device side of TrajectoryOptimizer."""
 
-    def __init__(self, model: Model, prob: ProblemDefinition, params: SolverParameters, device: int = 0):
+    def __init__(self, model: Model, prob, params: SolverParameters, device: int = 0):
+        """`prob`: one ProblemDefinition, or a list of them = a batch of problems of the same model and
+        horizon advanced together (idto_hip_create_batch); see HipBatch"""
         L = lib()
-        self.model, self.prob, self.params = model, prob, params
-        self.nq, self.nv, self.N = model.nq, model.nv, prob.num_steps
+        probs = list(prob) if isinstance(prob, (list, tuple)) else [prob]
+        self.batch = len(probs)
+        self.model, self.prob, self.params = model, probs[0], params
+        self.nq, self.nv, self.N = model.nq, model.nv, probs[0].num_steps
         cm, self._k1 = model.to_c()
-        cp, self._k2 = prob.to_c()
+        carr = (CProblem * self.batch)()
+        self._k2 = []
+        for b, pr in enumerate(probs):
+            cp, keep = pr.to_c()
+            carr[b] = cp
+            self._k2.append(keep)
         cc = params.contact_to_c()
         h = C.c_void_p()
-        _chk(L.idto_hip_create(C.byref(cm), C.byref(cp), C.byref(cc), int(device), C.byref(h)))
+        _chk(L.idto_hip_create_batch(C.byref(cm), carr, C.byref(cc), int(device), self.batch, C.byref(h)))
         self.h = h
         self.device = device
         from .problem import GRADIENTS
@@ -144,6 +162,21 @@ class HipPath:
         q = np.ascontiguousarray(np.asarray(q, dtype=np.float64))
         assert q.size == (self.N + 1) * self.nq
         _chk(lib().idto_hip_set_q(self.h, dptr(q)))
+
+    def set_q_batch(self, q):
+        """q: [batch, N+1, nq]"""
+        q = np.ascontiguousarray(np.asarray(q, dtype=np.float64))
+        assert q.size == self.batch * (self.N + 1) * self.nq
+        _chk(lib().idto_hip_set_q_batch(self.h, dptr(q)))
+
+    def set_problem_batch(self, b: int, prob: ProblemDefinition):
+        cp, keep = prob.to_c()
+        _chk(lib().idto_hip_set_problem_batch(self.h, int(b), C.byref(cp)))
+
+    def solver_status_batch(self):
+        out = (C.c_int * self.batch)()
+        _chk(lib().idto_hip_solver_status_batch(self.h, out))
+        return [bool(x) for x in out]
 
     def set_q_device(self, ptr: int):
         _chk(lib().idto_hip_set_q_device(self.h, C.c_void_p(ptr)))
@@ -262,9 +295,14 @@ class HipPath:
         """enqueue the copy of a contiguous array now; the next get(name) waits only for it"""
         _chk(lib().idto_hip_prefetch(self.h, ARR[name]))
 
-    def get(self, name):
+    def get(self, name, problem=None):
+        """array `name` of problem 0 (through the prefetch staging if one is pending), or of problem
+        `problem` of a batch"""
         out = np.zeros(self.array_size(name))
-        _chk(lib().idto_hip_get(self.h, ARR[name], dptr(out)))
+        if problem is None:
+            _chk(lib().idto_hip_get(self.h, ARR[name], dptr(out)))
+        else:
+            _chk(lib().idto_hip_get_batch(self.h, ARR[name], int(problem), dptr(out)))
         N, nq, nv = self.N, self.nq, self.nv
         if name == "q":
             return out.reshape(N + 1, nq)

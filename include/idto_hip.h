@@ -81,6 +81,25 @@ int idto_hip_create(const idto_model_t* model, const idto_problem_t* problem,
                     const idto_contact_params_t* contact, int device, idto_hip_ctx** out);
 void idto_hip_destroy(idto_hip_ctx* ctx);
 
+/* Batch of `batch` problems of the same model, horizon and time step (different initial
+ * conditions, weights, nominal and decision trajectories) resident on one device and advanced by
+ * ONE launch per kernel: what a controller does that runs one Gauss-Newton iteration per control
+ * tick on several warm-started problems (examples/mpc_controller.cc:43-85, BASELINE config 5), or a
+ * sampling-based planner.  Every per-problem array gets a leading batch dimension; idto_hip_set_q
+ * / idto_hip_get / idto_hip_set_problem address problem 0, the *_batch forms any problem;
+ * idto_hip_eval_tau / eval_partials / grad_hess / factor_solve(NULL) / gn_step work on all problems
+ * at once (grid.y = problem).  Entry points with explicit right-hand sides, the trial-point call
+ * and the equality-constraint step serve single-problem contexts only (the host-side
+ * TrajectoryOptimizer uses those).  idto_hip_create == idto_hip_create_batch(..., 1, ...). */
+int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* problems /* [batch] */,
+                          const idto_contact_params_t* contact, int device, int batch, idto_hip_ctx** out);
+int idto_hip_batch_size(idto_hip_ctx* ctx);
+int idto_hip_set_problem_batch(idto_hip_ctx* ctx, int problem, const idto_problem_t* p);
+int idto_hip_set_q_batch(idto_hip_ctx* ctx, const double* q_host /* [batch][(N+1)*nq] */);
+int idto_hip_gn_step_batch(idto_hip_ctx* ctx); /* = idto_hip_gn_step: every problem of the batch */
+int idto_hip_get_batch(idto_hip_ctx* ctx, int what, int problem, double* host_out);
+int idto_hip_solver_status_batch(idto_hip_ctx* ctx, int* failed /* [batch] */);
+
 /* Replaces q_init/v_init/weights/q_nom/v_nom (ResetInitialConditions /
  * UpdateNominalTrajectory, reference trajectory_optimizer.h:429-470). num_steps and
  * time_step must not change. */

@@ -1,0 +1,100 @@
+"""Batch of problems on one device (idto_hip_create_batch / idto_hip_gn_step_batch; the
+production call pattern of the reference's MPC examples is one Gauss-Newton iteration per
+control tick per warm-started problem, examples/mpc_controller.cc:43-85; BASELINE config 5 is a
+batch of 8 allegro problems): every problem of the batch must come out bit-identical (==) to the
+same problem run alone in a single-problem context - and therefore to the oracle."""
+import numpy as np
+import pytest
+
+from idto_amd import hip
+from idto_amd.model import load_model
+from idto_amd.problem import load_config, make_problem, synthetic_trajectory
+from oracle_lib import Oracle
+
+pytestmark = pytest.mark.gpu
+
+ARRAYS = ("v", "a", "tau", "nplus", "dtau_dqm", "dtau_dqt", "dtau_dqp", "gradient", "H_A", "H_B", "H_C", "step")
+
+
+def _same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
+
+
+def _problems(name, N, B):
+    cfg, model = load_config(name), load_model(name)
+    probs, qs = [], []
+    sp = None
+    for b in range(B):
+        prob, sp, _ = make_problem(cfg, model, num_steps=N)
+        sp.scaling = False
+        sp.equality_constraints = False
+        rng = np.random.default_rng(100 + b)
+        prob.q_nom = prob.q_nom + 0.01 * b                      # different nominal trajectories ...
+        prob.v_init = prob.v_init + 0.05 * rng.normal(size=model.nv)   # ... initial velocities ...
+        prob.Qq = prob.Qq * (1.0 + 0.1 * b)                     # ... and weights
+        probs.append(prob)
+        qs.append(synthetic_trajectory(cfg, model, N, seed=b, lower=0.01))
+    return model, probs, sp, np.array(qs)
+
+
+@pytest.mark.parametrize("name,N,B", [("mini_cheetah", 40, 5), ("allegro_hand", 60, 3), ("hopper", 9, 4),
+                                      ("spinner", 12, 7), ("acrobot", 8, 2)])
+@pytest.mark.parametrize("reference_solver", [0, 1])
+def test_batch_equals_single_problem_contexts(name, N, B, reference_solver):
+    model, probs, sp, qs = _problems(name, N, B)
+    batch = hip.HipPath(model, probs, sp)
+    assert batch.batch == B
+    batch.set_option("reference_solver", reference_solver)
+    batch.set_q_batch(qs)
+    batch.eval_tau()
+    costs = [batch.get("cost", b) for b in range(B)]
+    batch.gn_step()
+    assert batch.solver_status_batch() == [False] * B
+    for b in range(B):
+        one = hip.HipPath(model, probs[b], sp)
+        one.set_option("reference_solver", reference_solver)
+        one.set_q(qs[b])
+        one.eval_tau()
+        assert one.get("cost") == costs[b]
+        one.gn_step()
+        for arr in ARRAYS:
+            assert _same(batch.get(arr, b), one.get(arr)), (b, arr)
+        one.close()
+    # problem 0 through the plain accessors
+    assert _same(batch.get("step"), batch.get("step", 0))
+    # and against the oracle for the last problem (reference-order solver: bit-exact step)
+    orc = Oracle(model, probs[B - 1], sp)
+    g, p = orc.gn_step(qs[B - 1])
+    assert _same(batch.get("gradient", B - 1), g)
+    if reference_solver:
+        assert _same(batch.get("step", B - 1), p)
+    batch.close()
+
+
+def test_batch_problem_update_and_status():
+    """set_problem_batch replaces one problem's data; a semidefinite problem in the batch is reported
+    for that problem only"""
+    name, N, B = "acrobot", 12, 3
+    model, probs, sp, qs = _problems(name, N, B)
+    batch = hip.HipPath(model, probs, sp)
+    batch.set_q_batch(qs)
+    batch.gn_step()
+    before = [batch.get("step", b) for b in range(B)]
+    import copy
+    bad = copy.deepcopy(probs[1])
+    for W in (bad.Qq, bad.Qv, bad.Qf_q, bad.Qf_v):
+        W[0, :] = 0.0
+        W[:, 0] = 0.0
+    bad.R[:] = 0.0
+    batch.set_problem_batch(1, bad)
+    batch.gn_step()
+    assert batch.solver_status_batch() == [False, True, False]
+    with pytest.raises(hip.FactorizationFailed):
+        batch.get("step", 1)
+    assert _same(batch.get("step", 0), before[0]) and _same(batch.get("step", 2), before[2])
+    batch.set_problem_batch(1, probs[1])
+    batch.gn_step()
+    assert batch.solver_status_batch() == [False] * B
+    assert _same(batch.get("step", 1), before[1])
+    batch.close()

@@ -52,6 +52,7 @@ def test_semidefinite_hessian_is_reported(two_sided, reference):
     # host right-hand sides take the same exit
     with pytest.raises(hip.FactorizationFailed):
         dev.solve_host(np.ones((1, (dev.N + 1) * dev.nq)))
+    rows = dev.solver_status()[1]
     # ... and a healthy Hessian afterwards clears the status (it belongs to the last factorisation)
     cfg = load_config("acrobot")
     prob2, _, _ = make_problem(cfg, model, num_steps=dev.N)
