@@ -43,7 +43,7 @@ from idto_amd.model import load_model  # noqa: E402
 from idto_amd.problem import load_config, make_problem, synthetic_trajectory  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-KERNELS = ["fd_kernel", "assemble_diag_kernel", "penta_ldl_kernel"]
+KERNELS = ["fd_kernel", "assemble_diag_kernel", "penta_ldl_kernel", "gn_fused_kernel"]
 
 
 def algorithmic_bytes(N, nq, nv):
@@ -224,9 +224,10 @@ def main():
     barrier()
     dev.timing_enable(False)
     kern = []
-    for w in range(3):
+    for w in range(4):
         ms, n = dev.timing_get(w)
         kern.append((ms, n))
+    fused_run = kern[3][1] > 0   # the iteration ran as one persistent launch (csrc/fused.h)
     # ---- separate pass 2: latency of ONE step (launch -> results complete), synchronised per step
     lat = []
     for _ in range(max(50, min(200, args.steps))):
@@ -319,7 +320,11 @@ def main():
 
     if rank == 0:
         algb = algorithmic_bytes(N, nq, nv)
-        dom = int(np.argmax([k[0] for k in kern]))
+        # the fused launch: SURVEY.md §8d's B_alg of the whole iteration (every intermediate written
+        # once and read once): 2,605,184 B for mini_cheetah N=40
+        algb.append(8 * (2 * 3 * N * nv * nq + 2 * 3 * (N + 1) * nq * nq + 2 * 5 * (N + 1) * nq * nq
+                         + 4 * (N + 1) * nq + 2 * (N + 1) * nv + 3 * N * nv))
+        dom = 3 if fused_run else int(np.argmax([k[0] for k in kern[:3]]))
         dur_s = kern[dom][0] * 1e-3
         achieved = algb[dom] / dur_s / 1e9 if dur_s > 0 else 0.0
         traffic, traffic_src = pmc_traffic(KERNELS[dom])
@@ -342,7 +347,7 @@ def main():
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algb[dom], "avg_launch_ms": kern[dom][0],
                          "launches_timed": kern[dom][1],
-                         "all_kernels_avg_ms": {KERNELS[i]: kern[i][0] for i in range(3)},
+                         "all_kernels_avg_ms": {KERNELS[i]: kern[i][0] for i in range(4) if kern[i][1] > 0},
                          "note": "latency/dependency-bound path (SURVEY.md §8d): HBM fraction is intrinsically small"},
         }
         if other_extra is not None:

@@ -16,6 +16,7 @@
 #include "idto_hip.h"
 #include "kernels.h"
 #include "penta_ldl.h"
+#include "fused.h"
 #include "penta_apply.h"
 #include "constraints.h"
 #include "dense_ldl.h"
@@ -77,7 +78,7 @@ struct idto_hip_ctx {
   // timing
   bool timing = false;
   int timing_stride = 1;     // record events on every timing_stride-th launch of each kernel
-  unsigned timing_tick[3] = {0, 0, 0};
+  unsigned timing_tick[4] = {0, 0, 0, 0};
   bool timing_open = false;  // TimeBegin recorded an event that TimeEnd must close
   struct Timed { hipEvent_t a, b; int which; };
   std::vector<Timed> pending;
@@ -86,6 +87,8 @@ struct idto_hip_ctx {
   int fd_stop = 0;                        // same for the finite-difference kernel
   int asm_stop = 0;                       // profiling aid: truncate the assembly kernel after a phase
   bool two_sided = true;                  // solver: two workgroups eliminating from both ends
+  bool fused = true;                      // gn_step: one persistent launch (fused.h) when eligible
+  bool fused_debug = false;               // ... with per-workgroup time stamps in IDTO_ARR_DEBUG
   double* xch = nullptr;                  // their exchange buffer / flags
   unsigned* flags = nullptr;
   size_t xch_count = 0, flag_count = 0;
@@ -113,8 +116,8 @@ struct idto_hip_ctx {
   bool con_ready = false;                                              // stage_x holds H^-1 [g | J^T] of the current H
   size_t stage_count = 0;
   std::vector<hipEvent_t> event_pool;  // recycled: creating events in the timed loop costs host time
-  double tsum[3] = {0, 0, 0};
-  int tcnt[3] = {0, 0, 0};
+  double tsum[4] = {0, 0, 0, 0};
+  int tcnt[4] = {0, 0, 0, 0};
   // factorisation status, written by the solver kernels into pinned host memory only when a pivot
   // fails: [0] = id of the last failing factorisation, [1] = failing block rows since creation
   unsigned* status_pin = nullptr;
@@ -538,16 +541,18 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
 #define APPLY_ATTR(KM) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_apply_kernel<KM>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   APPLY_ATTR(2) APPLY_ATTR(3) APPLY_ATTR(5) APPLY_ATTR(8) APPLY_ATTR(16) APPLY_ATTR(19) APPLY_ATTR(23) APPLY_ATTR(24) APPLY_ATTR(32)
 #undef APPLY_ATTR
-#define LDL_ATTR(KM, PD, GW)                                                                                          \
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_ldl_kernel<KM, 256, PD, GW>),                         \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                              \
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_ldl_kernel<KM, 1024, PD, 0>),                        \
+#define LDL_ATTR(KM, PD, GW)                                                                   \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_ldl_kernel<KM, 256, PD, GW>), \
                             hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   LDL_ATTR(2, false, 1) LDL_ATTR(3, false, 1) LDL_ATTR(5, false, 1) LDL_ATTR(19, false, 1) LDL_ATTR(23, false, 2)
   LDL_ATTR(8, true, 1) LDL_ATTR(16, true, 1) LDL_ATTR(24, true, 2) LDL_ATTR(32, true, 3)
-  LDL_ATTR(2, false, 0) LDL_ATTR(3, false, 0) LDL_ATTR(5, false, 0) LDL_ATTR(19, false, 0) LDL_ATTR(23, false, 0)
-  LDL_ATTR(8, true, 0) LDL_ATTR(16, true, 0) LDL_ATTR(24, true, 0) LDL_ATTR(32, true, 0)
 #undef LDL_ATTR
+#define FUSED_ATTR(MC, KM, PD, GW)                                                                 \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_fused_kernel<MC, KM, PD, GW>),       \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  FUSED_ATTR(2, 2, false, 1) FUSED_ATTR(3, 3, false, 1) FUSED_ATTR(3, 5, false, 1) FUSED_ATTR(3, 19, false, 1)
+  FUSED_ATTR(4, 23, false, 2)
+#undef FUSED_ATTR
   if (const char* e = getenv("IDTO_SOLVER_REFERENCE")) c->reference_solver = (e[0] == '1');
   (void)hipGetLastError();
   *out = c;
@@ -703,45 +708,54 @@ int idto_hip_grad_hess(idto_hip_ctx* c) {
 // and x_0 = rhs_0.  Bands written into the context behind the API's back get the full system.
 static int SolverFirstRow(const idto_hip_ctx* c) { return (c->h_assembled && c->N >= 2) ? 1 : 0; }
 
-static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, int nrhs, double* xo, bool one_sided = false) {
-  const int r0 = (nrhs == 1) ? SolverFirstRow(c) : 0;
-  const int n = c->N + 1 - r0, k = c->nq;
-  const size_t qq0 = (size_t)r0 * k * k;
-  b += (size_t)r0 * k;
-  xo += (size_t)r0 * k;
-  if (k > 32) { g_err = "fast solver supports nq <= 32"; return -1; }
+// Geometry of one launch of the banded block LDL^T solver (one right-hand side in the kernel; more
+// go through penta_apply_kernel).
+struct LdlPlan {
+  int r0, n, k, K, gj_waves, lds, m_split;
+  size_t qq0;
+};
+static int SolverBlockSize(int k) {
   // block sizes of the reference's example models are instantiated exactly, others are padded
-  const int K = (k == 2 || k == 3 || k == 5 || k == 19 || k == 23) ? k : (k <= 8 ? 8 : k <= 16 ? 16 : k <= 24 ? 24 : 32);
-  const int per_wave = 64 - K, ncr = 2 * K + nrhs;
-  const int gj_waves = (ncr + per_wave - 1) / per_wave;
-  if (gj_waves > 15) { g_err = "too many right-hand sides for one launch"; return -1; }
-  const int threads = (gj_waves + 1 <= 4) ? 256 : 1024;
-  const PentaLdlLds L = penta_ldl_layout(n, K, nrhs);
-  int lds = L.end * (int)sizeof(double);
-  if (lds > 160 * 1024) { g_err = "right-hand sides do not fit the LDS carve-up"; return -1; }
-  double* dbg = c->solver_debug ? c->dbg : nullptr;
+  return (k == 2 || k == 3 || k == 5 || k == 19 || k == 23) ? k : (k <= 8 ? 8 : k <= 16 ? 16 : k <= 24 ? 24 : 32);
+}
+static int PlanLdl(idto_hip_ctx* c, bool one_sided, LdlPlan* p) {
+  p->r0 = SolverFirstRow(c);
+  p->n = c->N + 1 - p->r0;
+  p->k = c->nq;
+  p->qq0 = (size_t)p->r0 * p->k * p->k;
+  if (p->k > 32) { g_err = "fast solver supports nq <= 32"; return -1; }
+  p->K = SolverBlockSize(p->k);
+  const int per_wave = 64 - p->K, ncr = 2 * p->K + 1;
+  p->gj_waves = (ncr + per_wave - 1) / per_wave;
+  const PentaLdlLds L = penta_ldl_layout(p->n, p->K, 1);
+  p->lds = L.end * (int)sizeof(double);
+  if (p->lds > 160 * 1024) { g_err = "right-hand sides do not fit the LDS carve-up"; return -1; }
   // two-sided elimination (two workgroups meeting at block rows m, m+1) once the horizon is long
-  // enough to pay for the hand-over; exchange buffer: 2 augmented blocks + [nrhs][2][K]
-  const int m_split = (c->two_sided && !one_sided && n >= 10) ? (n - 1) / 2 : 0;
-  const dim3 grid(m_split > 0 ? 2 : 1, c->batch);
+  // enough to pay for the hand-over
+  p->m_split = (c->two_sided && !one_sided && p->n >= 10) ? (p->n - 1) / 2 : 0;
   // the two workgroups must not share a CU (each is one wavefront per SIMD, issue-bound): ask for
   // more than half of the 160 KB LDS so that the dispatcher cannot co-locate them
-  if (m_split > 0) lds = std::max(lds, 84 * 1024);
-  if (lds > 160 * 1024) { g_err = "LDS carve-up too large"; return -1; }
+  if (p->m_split > 0) p->lds = std::max(p->lds, 84 * 1024);
+  if (p->lds > 160 * 1024) { g_err = "LDS carve-up too large"; return -1; }
+  return 0;
+}
+
+static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, double* xo, bool one_sided = false) {
+  LdlPlan p;
+  if (int rc = PlanLdl(c, one_sided, &p)) return rc;
+  const int n = p.n, k = p.k, m_split = p.m_split, lds = p.lds, nrhs = 1;
+  const size_t qq0 = p.qq0;
+  b += (size_t)p.r0 * k;
+  xo += (size_t)p.r0 * k;
+  double* dbg = c->solver_debug ? c->dbg : nullptr;
+  const dim3 grid(m_split > 0 ? 2 : 1, c->batch);
   if (m_split > 0) ++c->epoch;  // (exchange buffer and flags live in the problem's arena)
   if (++c->fact_id == 0) c->fact_id = 1;  // (0 is the initial value of the status word)
 #define LDL_ARGS n, k, c->HA + qq0, c->HB + qq0, c->HC + qq0, b, sign, nrhs, xo, c->Ust, c->Hst, c->Est, c->Dst, dbg, \
                  m_split, c->xch, c->flags, c->epoch, c->status_dev, c->fact_id, c->pstride
-#define LDL_LAUNCH(KM, PD, GW)                                                                                \
-  do {                                                                                                        \
-    if (threads == 256 && gj_waves == GW)                                                                     \
-      hipLaunchKernelGGL((penta_ldl_kernel<KM, 256, PD, GW>), grid, dim3(256), lds, c->stream, LDL_ARGS);       \
-    else if (threads == 256)                                                                                  \
-      hipLaunchKernelGGL((penta_ldl_kernel<KM, 256, PD, 0>), grid, dim3(256), lds, c->stream, LDL_ARGS);        \
-    else                                                                                                      \
-      hipLaunchKernelGGL((penta_ldl_kernel<KM, 1024, PD, 0>), grid, dim3(1024), lds, c->stream, LDL_ARGS);      \
-  } while (0)
-  switch (K) {
+#define LDL_LAUNCH(KM, PD, GW) \
+  hipLaunchKernelGGL((penta_ldl_kernel<KM, 256, PD, GW>), grid, dim3(256), lds, c->stream, LDL_ARGS)
+  switch (p.K) {
     case 2: LDL_LAUNCH(2, false, 1); break;
     case 3: LDL_LAUNCH(3, false, 1); break;
     case 5: LDL_LAUNCH(5, false, 1); break;
@@ -756,6 +770,72 @@ static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, int nrhs, do
 #undef LDL_ARGS
   HIP_OK(hipGetLastError());
   return 0;
+}
+
+// ---- one persistent launch for the whole Gauss-Newton iteration (fused.h)
+static int FusedVariant(const idto_hip_ctx* c) {  // instantiated (MAXC, K) combinations: the reference's example models
+  const int mc = c->maxc <= 2 ? 2 : (c->maxc <= 3 ? 3 : (c->maxc <= 4 ? 4 : 8));
+  if (mc == 2 && c->nq == 2) return 1;
+  if (mc == 3 && c->nq == 3) return 2;
+  if (mc == 3 && c->nq == 5) return 3;
+  if (mc == 3 && c->nq == 19) return 4;
+  if (mc == 4 && c->nq == 23) return 5;
+  return 0;
+}
+static bool FusedEligible(const idto_hip_ctx* c) {
+  return c->fused && c->batch == 1 && c->weights_diagonal && !c->reference_solver && !c->solver_debug && c->fd_stop == 0 &&
+         c->asm_stop == 0 && c->k_begin == 0 && c->k_end == c->N && c->N >= 2 && FusedVariant(c) != 0;
+}
+static int LaunchFused(idto_hip_ctx* c) {
+  DropPrefetch(c, {IDTO_ARR_V, IDTO_ARR_A, IDTO_ARR_NPLUS, IDTO_ARR_SLAB, IDTO_ARR_GRADIENT, IDTO_ARR_H_A, IDTO_ARR_H_B,
+                   IDTO_ARR_H_C, IDTO_ARR_HBANDS, IDTO_ARR_STEP});
+  c->con_ready = false; c->con_begun = false;
+  if (!c->h_assembled) {  // x_0 = -g_0 = 0 is not written by the solver (SolverFirstRow)
+    HIP_OK(hipMemsetAsync(c->step, 0, (size_t)c->nq * sizeof(double), c->stream));
+    c->h_assembled = true;
+  }
+  LdlPlan p;
+  if (int rc = PlanLdl(c, false, &p)) return rc;
+  const int mode = 1 + c->gradients_method;
+  const int E = FdEvals(c, mode), groups = 256 / c->npaths;
+  int ec = E;
+  while (ec > groups && FdLds(c, mode, ec) > 160 * 1024) ec = ((ec - 1) / groups) * groups;
+  const int fd_lds = FdLds(c, mode, ec);
+  if (fd_lds > 160 * 1024) { g_err = "finite-difference evaluation set does not fit in LDS"; return -1; }
+  const int lds = std::max(std::max(fd_lds, c->asm_diag_lds), std::max(p.lds, 84 * 1024));
+  FusedArgs A;
+  A.M = c->M; A.cp = c->cp; A.P = c->P;
+  A.q = c->q; A.slab = c->slab; A.slab_stride = c->slab_stride; A.v = c->v; A.a = c->a; A.nplus = c->nplus;
+  A.fd_mode = mode; A.fd_echunk = ec; A.nfd = c->N;
+  A.g = c->g; A.HA = c->HA; A.HB = c->HB; A.HC = c->HC; A.nrows = c->N + 1;
+  A.n = p.n; A.k = p.k;
+  A.sHA = c->HA + p.qq0; A.sHB = c->HB + p.qq0; A.sHC = c->HC + p.qq0;
+  A.b = c->g + (size_t)p.r0 * p.k; A.rhs_sign = -1.0; A.x = c->step + (size_t)p.r0 * p.k;
+  A.Ust = c->Ust; A.Hst = c->Hst; A.Est = c->Est; A.Dst = c->Dst;
+  if (p.m_split > 0) ++c->epoch;
+  if (++c->fact_id == 0) c->fact_id = 1;
+  A.m_split = p.m_split; A.xch = c->xch; A.flags = c->flags; A.epoch = c->epoch; A.status = c->status_dev;
+  A.fact_id = c->fact_id;
+  ++c->sync_steps;
+  A.sync = c->sync_cnt;
+  A.dbg = c->fused_debug ? c->dbg : nullptr;
+  A.fd_target = c->sync_steps * (unsigned long long)A.nfd;
+  A.asm_target = c->sync_steps * (unsigned long long)(4 * A.nrows);
+  const dim3 grid(A.nfd + 4 * A.nrows + (p.m_split > 0 ? 2 : 1));
+  if (TimeBegin(c, 3)) return -2;
+#define FUSED_LAUNCH(MC, KM, PD, GW) \
+  hipLaunchKernelGGL((gn_fused_kernel<MC, KM, PD, GW>), grid, dim3(256), lds, c->stream, A)
+  switch (FusedVariant(c)) {
+    case 1: FUSED_LAUNCH(2, 2, false, 1); break;
+    case 2: FUSED_LAUNCH(3, 3, false, 1); break;
+    case 3: FUSED_LAUNCH(3, 5, false, 1); break;
+    case 4: FUSED_LAUNCH(3, 19, false, 1); break;
+    default: FUSED_LAUNCH(4, 23, false, 2); break;
+  }
+#undef FUSED_LAUNCH
+  HIP_OK(hipGetLastError());
+  c->fd_full = true;
+  return TimeEnd(c);
 }
 
 int idto_hip_factor_solve(idto_hip_ctx* c, const double* rhs, int nrhs, double* x) {
@@ -785,7 +865,7 @@ int idto_hip_factor_solve(idto_hip_ctx* c, const double* rhs, int nrhs, double* 
   // block LDL^T: factorise once with the first right-hand side (two-sided when the horizon is
   // long enough; the substitution kernel walks both chains of factors) ...
   const int K = (k == 2 || k == 3 || k == 5 || k == 19 || k == 23) ? k : (k <= 8 ? 8 : k <= 16 ? 16 : k <= 24 ? 24 : 32);
-  int rc = LaunchLdl(c, b, rhs ? 1.0 : -1.0, 1, xo);
+  int rc = LaunchLdl(c, b, rhs ? 1.0 : -1.0, xo);
   const int r0 = SolverFirstRow(c), ns = n - r0;                      // the sub-system LaunchLdl factorised
   const int m_split = (c->two_sided && ns >= 10) ? (ns - 1) / 2 : 0;  // as LaunchLdl chose
   if (r0 && rhs)  // x_0 = rhs_0 for every column (row 0 of H is the identity); the default rhs has g_0 = 0 = x_0
@@ -973,6 +1053,8 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "reference_solver") == 0) { c->reference_solver = value != 0; return 0; }
   if (std::strcmp(name, "solver_debug") == 0) { c->solver_debug = value != 0; return 0; }
   if (std::strcmp(name, "two_sided") == 0) { c->two_sided = value != 0; return 0; }
+  if (std::strcmp(name, "fused") == 0) { c->fused = value != 0; return 0; }
+  if (std::strcmp(name, "fused_debug") == 0) { c->fused_debug = value != 0; return 0; }
   if (std::strcmp(name, "asm_stop") == 0) { c->asm_stop = value; return 0; }  // profiling aid
   if (std::strcmp(name, "fd_stop") == 0) { c->fd_stop = value; return 0; }    // profiling aid
   if (std::strcmp(name, "gradients_method") == 0) {
@@ -985,6 +1067,8 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
 }
 
 int idto_hip_gn_step(idto_hip_ctx* c) {
+  HIP_OK(hipSetDevice(c->device));
+  if (FusedEligible(c)) return LaunchFused(c);
   int rc = idto_hip_eval_partials(c);
   if (rc) return rc;
   rc = idto_hip_grad_hess(c);
@@ -1000,11 +1084,11 @@ int idto_hip_timing_enable(idto_hip_ctx* c, int enable) {
 }
 int idto_hip_timing_reset(idto_hip_ctx* c) {
   if (TimeDrain(c)) return -2;
-  for (int i = 0; i < 3; ++i) { c->tsum[i] = 0; c->tcnt[i] = 0; }
+  for (int i = 0; i < 4; ++i) { c->tsum[i] = 0; c->tcnt[i] = 0; }
   return 0;
 }
 int idto_hip_timing_get(idto_hip_ctx* c, int which, double* avg_ms, int* launches) {
-  if (which < 0 || which > 2) { g_err = "bad kernel index"; return -1; }
+  if (which < 0 || which > 3) { g_err = "bad kernel index"; return -1; }
   if (TimeDrain(c)) return -2;
   *launches = c->tcnt[which];
   *avg_ms = c->tcnt[which] ? c->tsum[which] / c->tcnt[which] : 0.0;

@@ -168,12 +168,16 @@ int idto_hip_constraint_solve(idto_hip_ctx* ctx, const double* h_host, double* l
  * pivoted-LU block Thomas (slow) instead of the banded block LDL^T solver (default 0; the
  * environment variable IDTO_SOLVER_REFERENCE=1 sets it at creation); "two_sided" = 0 keeps the
  * LDL^T solver on one workgroup (default 1: two workgroups eliminate from both ends of the
- * horizon); "solver_debug" = 1 records per-phase cycle stamps (IDTO_ARR 15, tools/solver_phases.py);
+ * horizon); "fused" = 0 makes idto_hip_gn_step three launches
+ * (fd, assemble, solve) instead of one persistent launch whose workgroups take the three roles and
+ * synchronise through device-memory counters (default 1; single-problem contexts with diagonal
+ * weights and the reference's example models; csrc/fused.h); "solver_debug" = 1 records per-phase cycle stamps (IDTO_ARR 15, tools/solver_phases.py);
  * "asm_stop" truncates the assembly kernel after a phase (tools/asm_phases.py). */
 int idto_hip_set_option(idto_hip_ctx* ctx, const char* name, int value);
 
 /* Device-side timing of the last `idto_hip_gn_step`-shaped launches: average
- * milliseconds per launch of kernel `which` (0 fd, 1 assemble, 2 factor_solve)
+ * milliseconds per launch of kernel `which` (0 fd, 1 assemble, 2 factor_solve, 3 the fused
+ * single-launch iteration of idto_hip_gn_step)
  * over the launches recorded since idto_hip_timing_reset, measured with HIP
  * events on the context's stream.  enable = 1 times every launch, enable = s > 1 every
  * s-th launch (an event pair costs ~4 us of stream time: sampling keeps the timed
