@@ -141,9 +141,14 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run --nproc-per-node N")
     dist = None
-    # debugging aids for a single-GPU box (never set by the driver): all ranks on GPU 0 and a gloo
-    # process group, to exercise the multi-rank code path without RCCL
-    backend = os.environ.get("IDTO_BENCH_BACKEND", "nccl")
+    # Data path of the sharded mode: the RCCL communicator inside libidto_hip.so (ncclAllGather on
+    # the context's stream, include/idto_hip.h idto_hip_comm_*); torch.distributed is the control
+    # plane only (unique id, barrier, max over ranks) and runs on gloo.  IDTO_BENCH_EXCHANGE=torch
+    # selects the round-1 path instead (torch.distributed "nccl" all_gather_into_tensor on a
+    # zero-copy view of the slab).  IDTO_BENCH_SAME_GPU (never set by the driver) puts all ranks
+    # on GPU 0 for single-GPU debugging.
+    exchange = os.environ.get("IDTO_BENCH_EXCHANGE", "rccl")
+    backend = os.environ.get("IDTO_BENCH_BACKEND", "gloo" if exchange == "rccl" else "nccl")
     if os.environ.get("IDTO_BENCH_SAME_GPU"):
         local_rank = 0
     if world > 1:
@@ -154,6 +159,13 @@ def main():
         else:
             dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        tt = torch.tensor([x], device=("cuda" if backend == "nccl" else "cpu"), dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
 
     cfg = load_config(args.config)
     model = load_model(args.config)
@@ -173,15 +185,22 @@ def main():
 
     exch = None
     if world > 1:
-        from idto_amd.multi_gpu import SlabExchange, device_slab_view
+        from idto_amd.multi_gpu import RcclShard, SlabExchange, device_slab_view
         try:
-            exch = SlabExchange(dist, device_slab_view(dev, N), N, dev.slab_stride, rank, world)
+            if exchange == "rccl":
+                exch = RcclShard(dist, dev, rank, world)
+                dev.set_shard(0, N)   # (the shard is switched on below, per mode)
+            else:
+                exch = SlabExchange(dist, device_slab_view(dev, N), N, dev.slab_stride, rank, world)
         except Exception as e:  # replicas need no exchange: never let the extra measurement cost the metric
             if sharded:
                 raise
             print(f"[bench] rank {rank}: slab exchange unavailable ({e}); skipping the shard_mode extra", file=sys.stderr)
 
     def step_sharded():
+        if exchange == "rccl":
+            dev.gn_step_sharded()   # eval_partials (own k-range) + ncclAllGather + grad_hess + factor_solve
+            return
         dev.eval_partials()
         exch.gather()
         dev.grad_hess()
@@ -209,11 +228,7 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
 
     # ---- separate pass 1: per-kernel durations, HIP events around every launch (on the context's
     # stream); never part of `value`, so `value` does not depend on --steps
@@ -269,18 +284,16 @@ def main():
             for _ in range(ns):
                 fn()
             barrier()
-            el = time.perf_counter() - t1
-            tt = torch.tensor([el], device="cuda", dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = max_over_ranks(time.perf_counter() - t1)
             if sharded:
-                other_extra = {"value": world * ns / float(tt.item()), "unit": "GN iters/s (aggregate, one problem per rank)",
-                               "steps": ns, "ms_per_step": 1e3 * float(tt.item()) / ns, "scaling": "weak"}
+                other_extra = {"value": world * ns / el, "unit": "GN iters/s (aggregate, one problem per rank)",
+                               "steps": ns, "ms_per_step": 1e3 * el / ns, "scaling": "weak"}
             else:
                 same = bool(np.array_equal(dev.get("step"), p_ref))   # sharded == single-GPU result, bit for bit
-                other_extra = {"value": ns / float(tt.item()), "unit": "GN iters/s (one problem)", "steps": ns,
-                               "ms_per_step": 1e3 * float(tt.item()) / ns, "scaling": "strong",
+                other_extra = {"value": ns / el, "unit": "GN iters/s (one problem)", "steps": ns,
+                               "ms_per_step": 1e3 * el / ns, "scaling": "strong",
                                "bit_identical_to_unsharded": same,
-                               "exchange": f"all-gather of the {N * dev.slab_stride * 8} B slab over {world} ranks"}
+                               "exchange": f"{exchange} all-gather of the {N * dev.slab_stride * 8} B slab over {world} ranks"}
         except Exception as e:  # informational only: never lose the metric over it
             other_extra = {"error": str(e)[:200]}
 
@@ -340,7 +353,8 @@ def main():
                                   "Drake is not available, multi-body conventions are unpinned against it (DESIGN.md §8)",
                        "parallelism": ("single GPU" if world == 1 else
                                        (f"t-range shard of the perturbation grid over {world} GPUs + RCCL all-gather "
-                                        f"of the dtau/dq slabs, redundant assemble+solve" if sharded else
+                                        f"of the dtau/dq slabs ({'ncclAllGather inside libidto_hip.so' if exchange == 'rccl' else 'torch.distributed'}), "
+                                        f"redundant assemble+solve" if sharded else
                                         f"{world} independent replicas"))},
             "roofline": {"bound": "hbm", "kernel": KERNELS[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

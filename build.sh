@@ -1,5 +1,6 @@
 #!/bin/bash
-# Builds libidto_hip.so (gfx950 kernels + C-ABI).  hipcc cross-compiles without a GPU.
+# Builds libidto_hip.so (gfx950 kernels + C-ABI; links RCCL for the multi-GPU slab exchange).
+# hipcc cross-compiles without a GPU.
 # -ffp-contract=off: host/device bit-exactness of the finite-difference path.
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs, not AGPRs (saves the v_accvgpr_read moves on
 # the solver's products phase: -150 cycles per block row).
@@ -7,7 +8,7 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 -fPIC -shared \
-  -Iinclude -Iidto_amd/csrc idto_amd/csrc/idto_hip.hip -o idto_amd/libidto_hip.so "$@"
+  -Iinclude -Iidto_amd/csrc idto_amd/csrc/idto_hip.hip -o idto_amd/libidto_hip.so -L/opt/rocm/lib -lrccl "$@"
 # libidto_opt.so: the host-side TrajectoryOptimizer (C++) + its C-ABI, on top of libidto_hip.so
 g++ -O3 -std=c++17 -fPIC -shared -Wall -Iinclude idto_amd/csrc/host/trajectory_optimizer.cc \
   idto_amd/csrc/host/idto_opt_c.cc -o idto_amd/libidto_opt.so -Lidto_amd -lidto_hip -Wl,-rpath,'$ORIGIN'

@@ -90,6 +90,11 @@ int idto_opt_dense_ldlt_solve(double* S, int n, double* b) {
 
 int idto_opt_create(const idto_model_t* model, const idto_problem_t* p, const idto_contact_params_t* c,
                     const idto_solver_params_t* sp, int device, idto_opt** out) {
+  return idto_opt_create_multi(model, p, c, sp, &device, 0, out);
+}
+
+int idto_opt_create_multi(const idto_model_t* model, const idto_problem_t* p, const idto_contact_params_t* c,
+                          const idto_solver_params_t* sp, const int* devices, int ndev, idto_opt** out) {
   return Guard([&] {
     int nq = 0, nv = 0;
     for (int b = 0; b < model->nbodies; ++b) {
@@ -129,7 +134,11 @@ int idto_opt_create(const idto_model_t* model, const idto_problem_t* p, const id
     params.friction_coefficient = c->friction_coefficient;
     params.smoothing_factor = c->smoothing_factor;
     auto h = std::make_unique<idto_opt>();
-    h->to = std::make_unique<TrajectoryOptimizer<double>>(*model, p->time_step, prob, params, device);
+    if (ndev <= 0)   // (idto_opt_create: one device, no communicator)
+      h->to = std::make_unique<TrajectoryOptimizer<double>>(*model, p->time_step, prob, params, devices[0]);
+    else
+      h->to = std::make_unique<TrajectoryOptimizer<double>>(*model, p->time_step, prob, params,
+                                                            std::vector<int>(devices, devices + ndev));
     h->nq = nq; h->nv = nv; h->N = p->num_steps;
     *out = h.release();
   });

@@ -270,7 +270,32 @@ TO::TrajectoryOptimizer(const idto_model_t& model, double time_step, const Probl
   Check(idto_hip_set_option(hip_, "gradients_method", static_cast<int>(params_.gradients_method)));
 }
 
-TO::~TrajectoryOptimizer() { idto_hip_destroy(hip_); }
+TO::TrajectoryOptimizer(const idto_model_t& model, double time_step, const ProblemDefinition& prob,
+                        const SolverParameters& params, const std::vector<int>& devices)
+    : TrajectoryOptimizer(model, time_step, prob, params, devices.empty() ? 0 : devices[0]) {
+  if (devices.empty()) return;
+  const Vec qn = Flatten(prob_.q_nom), vn = Flatten(prob_.v_nom);
+  idto_problem_t p = {};
+  p.num_steps = num_steps(); p.time_step = time_step_;
+  p.q_init = prob_.q_init.data(); p.v_init = prob_.v_init.data();
+  p.Qq = prob_.Qq.data(); p.Qv = prob_.Qv.data(); p.Qf_q = prob_.Qf_q.data(); p.Qf_v = prob_.Qf_v.data();
+  p.R = prob_.R.data(); p.q_nom = qn.data(); p.v_nom = vn.data();
+  idto_contact_params_t c = {params_.contact_stiffness, params_.dissipation_velocity, params_.stiction_velocity,
+                             params_.friction_coefficient, params_.smoothing_factor};
+  shard_ctx_.push_back(hip_);
+  for (std::size_t i = 1; i < devices.size(); ++i) {
+    idto_hip_ctx* h = nullptr;
+    Check(idto_hip_create(&model, &p, &c, devices[i], &h));
+    shard_ctx_.push_back(h);
+    Check(idto_hip_set_option(h, "gradients_method", static_cast<int>(params_.gradients_method)));
+  }
+  Check(idto_hip_comm_init_all(shard_ctx_.data(), (int)shard_ctx_.size()));
+}
+
+TO::~TrajectoryOptimizer() {
+  for (std::size_t i = 1; i < shard_ctx_.size(); ++i) idto_hip_destroy(shard_ctx_[i]);
+  idto_hip_destroy(hip_);
+}
 
 void TO::UploadProblem() {
   const Vec qn = Flatten(prob_.q_nom), vn = Flatten(prob_.v_nom);
@@ -280,6 +305,7 @@ void TO::UploadProblem() {
   p.Qq = prob_.Qq.data(); p.Qv = prob_.Qv.data(); p.Qf_q = prob_.Qf_q.data(); p.Qf_v = prob_.Qf_v.data();
   p.R = prob_.R.data(); p.q_nom = qn.data(); p.v_nom = vn.data();
   Check(idto_hip_set_problem(hip_, &p));
+  for (std::size_t i = 1; i < shard_ctx_.size(); ++i) Check(idto_hip_set_problem(shard_ctx_[i], &p));
   resident_ = nullptr;  // every cached device result depends on the problem data
   device_level_ = 0;
 }
@@ -310,7 +336,17 @@ void TO::EnsureDevice(const TrajectoryOptimizerState<T>& state, int level) const
     device_level_ = 0;
   }
   if (level >= 1 && device_level_ < 1) { Check(idto_hip_eval_tau(hip_)); device_level_ = 1; }
-  if (level >= 2 && device_level_ < 2) { Check(idto_hip_eval_partials(hip_)); device_level_ = 2; }
+  if (level >= 2 && device_level_ < 2) {
+    if (shard_ctx_.empty()) {
+      Check(idto_hip_eval_partials(hip_));
+    } else {
+      // sharded over the devices: every device gets q, evaluates its k-range, one all-gather
+      const Vec q = Flatten(state.q());
+      for (std::size_t i = 1; i < shard_ctx_.size(); ++i) Check(idto_hip_set_q(shard_ctx_[i], q.data()));
+      Check(idto_hip_eval_partials_multi(const_cast<idto_hip_ctx**>(shard_ctx_.data()), (int)shard_ctx_.size()));
+    }
+    device_level_ = 2;
+  }
   if (level >= 3 && device_level_ < 3) { Check(idto_hip_grad_hess(hip_)); device_level_ = 3; }
 }
 

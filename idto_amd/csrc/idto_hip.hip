@@ -4,6 +4,7 @@
 // Nothing in here falls back to the CPU: if no HIP device is present every
 // entry point fails with a negative status.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <cmath>
 #include <cstdio>
@@ -123,7 +124,14 @@ struct idto_hip_ctx {
   unsigned* status_pin = nullptr;
   unsigned* status_dev = nullptr;   // the same memory as the device addresses it
   unsigned fact_id = 0;             // id of the most recent factorisation launched
+  // multi-GPU: this context is rank `comm_rank` of `comm_world` in an RCCL communicator;
+  // its finite-difference kernel covers the k-range [k_begin, k_end) and one in-place all-gather
+  // completes the slab (records are contiguous in k, every rank's range has `comm_per` records,
+  // the last ones padded: the slab is allocated with IDTO_SLAB_PAD spare records)
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_world = 1, comm_per = 0;
 };
+enum { IDTO_SLAB_PAD = 64 };
 
 namespace {
 
@@ -446,7 +454,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   size_t o_w[10];
   for (int i = 0; i < 10; ++i) o_w[i] = carve((i == 0 || i == 3 || i == 5 || i == 8) ? qq : (size_t)nv * nv, D);
   const size_t o_q = carve((size_t)(N + 1) * nq, D), o_v = carve((size_t)(N + 1) * nv, D), o_a = carve((size_t)N * nv, D);
-  const size_t o_np = carve((size_t)(N + 1) * bsz, D), o_slab = carve((size_t)N * c->slab_stride, D);
+  const size_t o_np = carve((size_t)(N + 1) * bsz, D), o_slab = carve((size_t)(N + IDTO_SLAB_PAD) * c->slab_stride, D);
   const size_t o_g = carve((size_t)(N + 1) * nq, D);
   // two extra zero blocks (five are reserved): the solver prefetches rows i+1, i+2 without bounds
   // checks (one allocation: the solver addresses all three bands from HA with 32-bit offsets)
@@ -563,6 +571,7 @@ void idto_hip_destroy(idto_hip_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
   (void)TimeDrain(c);
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   for (void* p : c->allocs) (void)hipFree(p);
@@ -1047,6 +1056,119 @@ int idto_hip_constraint_step(idto_hip_ctx* c, const double* lambda_host, double*
   std::memcpy(step_host, pl + neq, (size_t)n * sizeof(double));
   std::memcpy(jtl_host, pl + neq + n, (size_t)n * sizeof(double));
   return FactorStatus(c);
+}
+
+#define NCCL_OK(expr)                                                                 \
+  do {                                                                                \
+    ncclResult_t r_ = (expr);                                                         \
+    if (r_ != ncclSuccess) {                                                          \
+      g_err = std::string(#expr) + ": " + ncclGetErrorString(r_);                     \
+      return -4;                                                                      \
+    }                                                                                 \
+  } while (0)
+
+static int CommAttach(idto_hip_ctx* c, ncclComm_t comm, int rank, int world) {
+  if (c->batch != 1) { g_err = "the sharded iteration serves single-problem contexts"; return -1; }
+  if (world < 1 || world > IDTO_SLAB_PAD || rank < 0 || rank >= world) { g_err = "bad rank / world size"; return -1; }
+  c->comm = comm; c->comm_rank = rank; c->comm_world = world;
+  c->comm_per = (c->N + world - 1) / world;
+  const int lo = std::min(c->N, rank * c->comm_per);
+  return idto_hip_set_shard(c, lo, std::min(c->N, lo + c->comm_per));
+}
+
+int idto_hip_comm_unique_id(char* id_out, int bytes) {
+  if (!id_out || bytes < (int)sizeof(ncclUniqueId)) { g_err = "comm_unique_id: buffer of at least 128 bytes required"; return -1; }
+  ncclUniqueId id;
+  NCCL_OK(ncclGetUniqueId(&id));
+  std::memcpy(id_out, &id, sizeof id);
+  return 0;
+}
+
+int idto_hip_comm_init(idto_hip_ctx* c, const char* unique_id, int rank, int world) {
+  HIP_OK(hipSetDevice(c->device));
+  if (c->comm) { g_err = "comm_init: the context already belongs to a communicator"; return -1; }
+  ncclUniqueId id;
+  std::memcpy(&id, unique_id, sizeof id);
+  ncclComm_t comm = nullptr;
+  NCCL_OK(ncclCommInitRank(&comm, world, id, rank));
+  return CommAttach(c, comm, rank, world);
+}
+
+int idto_hip_comm_init_all(idto_hip_ctx** ctxs, int n) {
+  if (!ctxs || n < 1 || n > IDTO_SLAB_PAD) { g_err = "comm_init_all: bad arguments"; return -1; }
+  std::vector<int> devs(n);
+  for (int i = 0; i < n; ++i) {
+    if (ctxs[i]->comm) { g_err = "comm_init_all: a context already belongs to a communicator"; return -1; }
+    devs[i] = ctxs[i]->device;
+  }
+  std::vector<ncclComm_t> comms(n, nullptr);
+  NCCL_OK(ncclCommInitAll(comms.data(), n, devs.data()));
+  for (int i = 0; i < n; ++i)
+    if (int rc = CommAttach(ctxs[i], comms[i], i, n)) return rc;
+  return 0;
+}
+
+int idto_hip_comm_destroy(idto_hip_ctx* c) {
+  if (c->comm) {
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    NCCL_OK(ncclCommDestroy(c->comm));
+    c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
+    return idto_hip_set_shard(c, 0, c->N);
+  }
+  return 0;
+}
+
+// in place: rank r's records start at r * per * stride of the receive buffer, which is where its
+// fd_kernel wrote them
+static int AllGatherSlab(idto_hip_ctx* c) {
+  const size_t count = (size_t)c->comm_per * c->slab_stride;
+  NCCL_OK(ncclAllGather(c->slab + (size_t)c->comm_rank * count, c->slab, count, ncclDouble, c->comm, c->stream));
+  return 0;
+}
+
+int idto_hip_allgather_slab(idto_hip_ctx* c) {
+  HIP_OK(hipSetDevice(c->device));
+  if (!c->comm) { g_err = "allgather_slab: call idto_hip_comm_init first"; return -1; }
+  DropPrefetch(c, {IDTO_ARR_SLAB});
+  return AllGatherSlab(c);
+}
+
+int idto_hip_gn_step_sharded(idto_hip_ctx* c) {
+  if (!c->comm) { g_err = "gn_step_sharded: call idto_hip_comm_init first"; return -1; }
+  int rc = idto_hip_eval_partials(c);   // this rank's k-range
+  if (rc) return rc;
+  rc = idto_hip_allgather_slab(c);      // RCCL, on the context's stream
+  if (rc) return rc;
+  rc = idto_hip_grad_hess(c);           // every rank assembles and solves redundantly: identical bits, no second collective
+  if (rc) return rc;
+  return idto_hip_factor_solve(c, nullptr, 1, nullptr);
+}
+
+int idto_hip_eval_partials_multi(idto_hip_ctx** ctxs, int n) {
+  // one process driving n devices (communicator from idto_hip_comm_init_all): every device's
+  // finite-difference kernel covers its k-range, the all-gathers of all ranks go into one group
+  for (int i = 0; i < n; ++i) {
+    if (!ctxs[i]->comm) { g_err = "eval_partials_multi: call idto_hip_comm_init_all first"; return -1; }
+    if (int rc = idto_hip_eval_partials(ctxs[i])) return rc;
+  }
+  NCCL_OK(ncclGroupStart());
+  for (int i = 0; i < n; ++i) {
+    HIP_OK(hipSetDevice(ctxs[i]->device));
+    DropPrefetch(ctxs[i], {IDTO_ARR_SLAB});
+    if (int rc = AllGatherSlab(ctxs[i])) { (void)ncclGroupEnd(); return rc; }
+  }
+  NCCL_OK(ncclGroupEnd());
+  return 0;
+}
+
+int idto_hip_gn_step_multi(idto_hip_ctx** ctxs, int n) {
+  if (int rc = idto_hip_eval_partials_multi(ctxs, n)) return rc;
+  for (int i = 0; i < n; ++i) {
+    if (int rc = idto_hip_grad_hess(ctxs[i])) return rc;
+    if (int rc = idto_hip_factor_solve(ctxs[i], nullptr, 1, nullptr)) return rc;
+  }
+  return 0;
 }
 
 int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {

@@ -50,6 +50,12 @@ def lib():
         L.idto_hip_gn_step_batch.argtypes = [C.c_void_p]
         L.idto_hip_get_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.idto_hip_solver_status_batch.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.idto_hip_comm_unique_id.argtypes = [C.c_char_p, C.c_int]
+        L.idto_hip_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+        L.idto_hip_comm_init_all.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        L.idto_hip_gn_step_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        for f in ("comm_destroy", "allgather_slab", "gn_step_sharded"):
+            getattr(L, "idto_hip_" + f).argtypes = [C.c_void_p]
         L.idto_hip_destroy.argtypes = [C.c_void_p]
         L.idto_hip_set_problem.argtypes = [C.c_void_p, C.POINTER(CProblem)]
         L.idto_hip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
@@ -96,6 +102,8 @@ EXPORTED_SYMBOLS = [
     "idto_hip_device_ptr", "idto_hip_array_size", "idto_hip_slab_stride", "idto_hip_math_probe",
     "idto_hip_solver_status", "idto_hip_create_batch", "idto_hip_batch_size", "idto_hip_set_problem_batch",
     "idto_hip_set_q_batch", "idto_hip_gn_step_batch", "idto_hip_get_batch", "idto_hip_solver_status_batch",
+    "idto_hip_comm_unique_id", "idto_hip_comm_init", "idto_hip_comm_init_all", "idto_hip_comm_destroy",
+    "idto_hip_allgather_slab", "idto_hip_gn_step_sharded", "idto_hip_gn_step_multi", "idto_hip_eval_partials_multi",
 ]
 
 
@@ -188,6 +196,20 @@ class HipPath:
 
     def set_stream(self, stream_ptr: int):
         _chk(lib().idto_hip_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    # ---- multi-GPU: RCCL communicator inside the library (include/idto_hip.h)
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        """collective over the `world` ranks (ncclCommInitRank); sets this context's k-range shard"""
+        _chk(lib().idto_hip_comm_init(self.h, unique_id, int(rank), int(world)))
+
+    def comm_destroy(self):
+        _chk(lib().idto_hip_comm_destroy(self.h))
+
+    def allgather_slab(self):
+        _chk(lib().idto_hip_allgather_slab(self.h))
+
+    def gn_step_sharded(self):
+        _chk(lib().idto_hip_gn_step_sharded(self.h))
 
     def set_shard(self, k_begin: int, k_end: int):
         _chk(lib().idto_hip_set_shard(self.h, int(k_begin), int(k_end)))
@@ -319,6 +341,24 @@ class HipPath:
         if name == "cost":
             return float(out[0])
         return out
+
+
+def comm_unique_id() -> bytes:
+    """rank 0: the 128-byte id every rank passes to HipPath.comm_init"""
+    buf = C.create_string_buffer(128)
+    _chk(lib().idto_hip_comm_unique_id(buf, 128))
+    return buf.raw
+
+
+def comm_init_all(paths):
+    """one process, one HipPath per device: ncclCommInitAll"""
+    arr = (C.c_void_p * len(paths))(*[p.h for p in paths])
+    _chk(lib().idto_hip_comm_init_all(arr, len(paths)))
+
+
+def gn_step_multi(paths):
+    arr = (C.c_void_p * len(paths))(*[p.h for p in paths])
+    _chk(lib().idto_hip_gn_step_multi(arr, len(paths)))
 
 
 def math_probe(x, device=0):

@@ -66,3 +66,23 @@ def device_slab_view(dev, N: int) -> torch.Tensor:
         __cuda_array_interface__ = {"shape": (N * stride,), "typestr": "<f8",
                                     "data": (dev.device_ptr("slab"), False), "version": 2}
     return torch.as_tensor(_Ptr(), device=f"cuda:{dev.device}")
+
+
+class RcclShard:
+    """The same exchange inside libidto_hip.so (include/idto_hip.h idto_hip_comm_*): the library owns
+    an RCCL communicator, `dist` (any torch.distributed backend, gloo is enough) only carries the
+    128-byte unique id from rank 0 to the others.  After construction the HipPath's shard is its
+    rank's k-range and `dev.gn_step_sharded()` is eval_partials + ncclAllGather (in place, on the
+    context's stream) + grad_hess + factor_solve."""
+
+    def __init__(self, dist, dev, rank: int, world: int):
+        from . import hip
+        box = [hip.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        dev.comm_init(box[0], rank, world)
+        self.dev, self.rank, self.world = dev, rank, world
+        self.lo, self.hi = shard_bounds(dev.N, world, rank)
+
+    def close(self):
+        self.dev.comm_destroy()

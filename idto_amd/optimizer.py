@@ -34,6 +34,8 @@ def lib():
         L.idto_opt_dense_ldlt_solve.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double)]
         L.idto_opt_create.argtypes = [C.POINTER(CModel), C.POINTER(CProblem), C.POINTER(CContactParams),
                                       C.POINTER(CSolverParams), C.c_int, C.POINTER(C.c_void_p)]
+        L.idto_opt_create_multi.argtypes = [C.POINTER(CModel), C.POINTER(CProblem), C.POINTER(CContactParams),
+                                            C.POINTER(CSolverParams), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
         L.idto_opt_destroy.argtypes = [C.c_void_p]
         L.idto_opt_num_steps.argtypes = [C.c_void_p]
         L.idto_opt_time_step.argtypes = [C.c_void_p]
@@ -57,7 +59,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = [
-    "idto_opt_last_error", "idto_opt_dense_ldlt_solve", "idto_opt_create", "idto_opt_destroy", "idto_opt_num_steps", "idto_opt_time_step",
+    "idto_opt_last_error", "idto_opt_dense_ldlt_solve", "idto_opt_create", "idto_opt_create_multi", "idto_opt_destroy", "idto_opt_num_steps", "idto_opt_time_step",
     "idto_opt_num_equality_constraints", "idto_opt_solve", "idto_opt_ws_create", "idto_opt_ws_destroy",
     "idto_opt_ws_set_q", "idto_opt_ws_get", "idto_opt_ws_solve", "idto_opt_reset_initial_conditions",
     "idto_opt_update_nominal_trajectory", "idto_opt_eval", "idto_opt_dogleg", "idto_opt_trust_ratio",
@@ -141,7 +143,10 @@ class WarmStart:
 
 
 class TrajectoryOptimizer:
-    def __init__(self, model: Model, prob: ProblemDefinition, params: SolverParameters | None = None, device: int = 0):
+    def __init__(self, model: Model, prob: ProblemDefinition, params: SolverParameters | None = None, device: int = 0,
+                 devices=None):
+        """`devices`: list of HIP devices of this node to shard the finite-difference grid over
+        (devices[0] hosts the optimizer; one RCCL all-gather per evaluation of the partials)"""
         L = lib()
         params = params or SolverParameters()
         self.model, self._prob, self._params = model, prob, params
@@ -150,7 +155,11 @@ class TrajectoryOptimizer:
         cp, self._k2 = prob.to_c()
         cc, cs = params.contact_to_c(), params.to_c()
         h = C.c_void_p()
-        rc = L.idto_opt_create(C.byref(cm), C.byref(cp), C.byref(cc), C.byref(cs), int(device), C.byref(h))
+        if devices is None:
+            rc = L.idto_opt_create(C.byref(cm), C.byref(cp), C.byref(cc), C.byref(cs), int(device), C.byref(h))
+        else:  # sharded over several devices of the node (RCCL all-gather of the partials)
+            arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+            rc = L.idto_opt_create_multi(C.byref(cm), C.byref(cp), C.byref(cc), C.byref(cs), arr, len(devices), C.byref(h))
         if rc != 0:
             raise RuntimeError(L.idto_opt_last_error().decode())
         self._h = h

@@ -56,6 +56,14 @@ class TrajectoryOptimizer<double> {
   // `model` is copied into the device context; it need not outlive the optimizer.
   TrajectoryOptimizer(const idto_model_t& model, double time_step, const ProblemDefinition& prob,
                       const SolverParameters& params = SolverParameters{}, int device = 0);
+  // Several devices of one node (the counterpart of the reference's `num_threads`, which
+  // parallelises CalcInverseDynamicsPartialsFiniteDiff over timesteps with OpenMP,
+  // optimizer/trajectory_optimizer.cc:455-457, :476): devices[0] hosts the optimizer as above, the
+  // others hold a copy of the problem and evaluate their k-range of the finite-difference grid;
+  // one RCCL all-gather per evaluation of the partials completes dtau/dq on every device
+  // (idto_hip_comm_init_all / idto_hip_eval_partials_multi of include/idto_hip.h; no torch, no MPI).
+  TrajectoryOptimizer(const idto_model_t& model, double time_step, const ProblemDefinition& prob,
+                      const SolverParameters& params, const std::vector<int>& devices);
   ~TrajectoryOptimizer();
   TrajectoryOptimizer(const TrajectoryOptimizer&) = delete;
   TrajectoryOptimizer& operator=(const TrajectoryOptimizer&) = delete;
@@ -144,6 +152,7 @@ class TrajectoryOptimizer<double> {
   std::vector<int> unactuated_dofs_;
   std::vector<int> quaternion_starts_;
   idto_hip_ctx* hip_ = nullptr;
+  std::vector<idto_hip_ctx*> shard_ctx_;    // [hip_, contexts on the other devices] when sharded over devices
   mutable const void* resident_ = nullptr;  // state whose q is on the device
   mutable int device_level_ = 0;            // what has been evaluated for it there
 };

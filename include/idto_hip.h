@@ -113,6 +113,29 @@ void* idto_hip_get_stream(idto_hip_ctx* ctx);
  * sharding); the caller all-gathers IDTO_ARR_SLAB before grad_hess. */
 int idto_hip_set_shard(idto_hip_ctx* ctx, int k_begin, int k_end);
 
+/* Multi-GPU iteration (the reference parallelises the same loop over timesteps with
+ * OpenMP, optimizer/trajectory_optimizer.cc:455-457, :476): every GPU holds the whole problem, its
+ * finite-difference kernel covers a contiguous k-range of the (k, column) perturbation grid, ONE
+ * RCCL all-gather (in place: a rank's records already sit at their final offset of the slab)
+ * completes dtau/dq on every GPU, and every GPU assembles and solves redundantly - identical
+ * bits on all ranks, no second collective.  Two ways to form the communicator:
+ *   one process per GPU:  rank 0 calls idto_hip_comm_unique_id and ships the 128 bytes to the
+ *     other ranks by any means (MPI, a file, torch.distributed's store); every rank then calls
+ *     idto_hip_comm_init(ctx, id, rank, world) - collective, like ncclCommInitRank;
+ *   one process, several devices:  idto_hip_comm_init_all(ctxs, n) with one context per device,
+ *     then idto_hip_gn_step_multi(ctxs, n).
+ * Both set the context's shard to its rank's k-range.  idto_hip_gn_step_sharded =
+ * eval_partials (own range) + idto_hip_allgather_slab + grad_hess + factor_solve, all enqueued on
+ * the context's stream. */
+int idto_hip_comm_unique_id(char* id_out, int bytes /* >= 128 */);
+int idto_hip_comm_init(idto_hip_ctx* ctx, const char* unique_id, int rank, int world);
+int idto_hip_comm_init_all(idto_hip_ctx** ctxs, int n);
+int idto_hip_comm_destroy(idto_hip_ctx* ctx);
+int idto_hip_allgather_slab(idto_hip_ctx* ctx);
+int idto_hip_gn_step_sharded(idto_hip_ctx* ctx);
+int idto_hip_eval_partials_multi(idto_hip_ctx** ctxs, int n); /* fd shards + grouped all-gather */
+int idto_hip_gn_step_multi(idto_hip_ctx** ctxs, int n);
+
 int idto_hip_set_q(idto_hip_ctx* ctx, const double* q_host);         /* H2D copy */
 int idto_hip_set_q_device(idto_hip_ctx* ctx, const double* q_device); /* D2D copy */
 

@@ -30,6 +30,11 @@ int idto_opt_dense_ldlt_solve(double* S, int n, double* b);
  * plant replaced by model tables + time step. */
 int idto_opt_create(const idto_model_t* model, const idto_problem_t* problem, const idto_contact_params_t* contact,
                     const idto_solver_params_t* params, int device, idto_opt** out);
+/* The same optimizer sharded over `ndev` >= 1 devices of one node (devices[0] hosts it): the
+ * finite-difference grid is split into k-ranges, one RCCL all-gather per evaluation of the
+ * partials (idto_hip_comm_init_all / idto_hip_eval_partials_multi). */
+int idto_opt_create_multi(const idto_model_t* model, const idto_problem_t* problem, const idto_contact_params_t* contact,
+                          const idto_solver_params_t* params, const int* devices, int ndev, idto_opt** out);
 void idto_opt_destroy(idto_opt* opt);
 
 int idto_opt_num_steps(const idto_opt* opt);
