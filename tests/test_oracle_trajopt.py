@@ -445,3 +445,44 @@ def test_libm_and_detmath_oracles_agree():
     b = Oracle(model, prob, sp, libm=True)
     ta, tb = a.eval_traj(q)[2], b.eval_traj(q)[2]
     assert np.abs(ta - tb).max() <= 1e-12 * max(1.0, np.abs(tb).max())
+
+
+def test_unnormalised_quaternions_through_a_full_solve():
+    """SolverParameters::normalize_quaternions defaults to false (solver_parameters.h:98-99), so the
+    floating-base quaternion leaves the unit sphere during Solve.  Along such a solution: (i) the
+    generalised velocities keep the [omega_W ; v_W] layout and are what quaternion algebra gives for
+    the normalised orientations, (ii) scaling every quaternion of the trajectory by a common factor
+    changes neither v nor tau (N+ carries the 1/|q| of SURVEY.md Appendix D, the rotation matrices
+    come from normalised quaternions), (iii) N+(q) N(q) = I for N(q) = d qdot / d v."""
+    from idto_amd.problem import load_config, make_problem
+    cfg, model = load_config("mini_cheetah"), load_model("mini_cheetah")
+    prob, sp, q_guess = make_problem(cfg, model, num_steps=10)
+    sp.max_iterations, sp.verbose, sp.normalize_quaternions = 6, False, False
+    orc = Oracle(model, prob, sp)
+    q = orc.solve(q_guess)["q"]
+    norms = np.linalg.norm(q[:, :4], axis=1)
+    assert np.abs(norms - 1).max() > 1e-6, "the solve was expected to leave the unit sphere"
+    v, a, tau, _ = orc.eval_traj(q)
+    dt = prob.time_step
+    for t in range(1, 11):
+        qa, qb = q[t - 1, :4], q[t, :4]
+        # omega_W = 2 vec(qdot (x) q^-1) with qdot = (I - q~ q~^T) (q_t - q_{t-1}) / (dt |q_t|)
+        u = qb / np.linalg.norm(qb)
+        qd = (np.eye(4) - np.outer(u, u)) @ (qb - qa) / dt / np.linalg.norm(qb)
+        w = 2 * (-u[1:] * qd[0] + u[0] * qd[1:] + np.cross(u[1:], qd[1:]))
+        assert np.allclose(v[t, :3], w, rtol=0, atol=1e-12 * max(1.0, np.abs(w).max()))
+        assert np.allclose(v[t, 3:6], (q[t, 4:7] - q[t - 1, 4:7]) / dt, rtol=0, atol=1e-12)
+    qs = q.copy()
+    qs[:, :4] *= 1.37
+    v2, _, tau2, _ = orc.eval_traj(qs)
+    assert np.abs(v2 - v).max() <= 1e-11 * np.abs(v).max()
+    assert np.abs(tau2 - tau).max() <= 1e-9 * np.abs(tau).max()
+    for t in (3, 7):
+        quat = q[t, :4]
+        u = quat / np.linalg.norm(quat)
+        # qdot = N(q) v for the quaternion block: 1/2 |q| [0, w] (x) q~
+        Nq = np.zeros((4, 3))
+        for k in range(3):
+            w = np.eye(3)[k]
+            Nq[:, k] = 0.5 * np.linalg.norm(quat) * np.array([-w @ u[1:], *(u[0] * w + np.cross(w, u[1:]))])
+        assert np.allclose(orc.nplus(q[t])[:3, :4] @ Nq, np.eye(3), atol=1e-14)
