@@ -951,9 +951,128 @@ SolverFlag TO::SolveFromWarmStart(WarmStart* ws, TrajectoryOptimizerSolution<T>*
   }
 }
 
+// The trust-region loop with every O(num_vars) quantity left on the device: per
+// iteration the host launches idto_hip_gn_step (partials, g, H, -H^-1 g in one launch),
+// idto_hip_tr_prepare (scale factors, g~, H~ g~, H~ w, nine inner products) and idto_hip_tr_trial
+// (dq = D (a g~ + b w), q + dq, tau and cost there), and reads back 9 + 4 scalars.  The dogleg
+// (TO.cc:2139-2201) and the trust ratio (TO.cc:1979-2035) are functions of those inner products:
+// with pU = cU g~ and pH = -w / Delta every step is dqs = a g~ + b w, so
+//   g~.dqs = a g~.g~ + b g~.w,   dqs.H~ dqs = a^2 g~.H~g~ + 2 a b g~.H~w + b^2 w.H~w.
+// Used when no equality constraints are enforced and convergence checks are off (the configuration
+// of the mini_cheetah example); otherwise SolveFromWarmStartImpl below keeps g / H on the host.
+bool TO::DeviceLoopEligible() const {
+  if (std::getenv("IDTO_OPT_HOST_LOOP")) return false;
+  const bool constrained = params_.equality_constraints && num_equality_constraints() > 0;
+  return !constrained && !params_.check_convergence && shard_ctx_.empty();
+}
+
+SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solution,
+                             TrajectoryOptimizerStats<T>* stats) const {
+  using clock = std::chrono::high_resolution_clock;
+  const auto start_time = clock::now();
+  auto iter_start = clock::now();
+  TrajectoryOptimizerState<T>& state = ws->state;
+  double& Delta = ws->Delta;
+  const double eta = 0.0;
+  {
+    const Vec q0 = Flatten(state.q());
+    Check(idto_hip_set_q(hip_, q0.data()));
+  }
+  Check(idto_hip_set_unactuated_dofs(hip_, unactuated_dofs_.data(), (int)unactuated_dofs_.size()));
+  Check(idto_hip_eval_tau(hip_));
+  double cost = Fetch(IDTO_ARR_COST)[0];
+  const int scal = params_.scaling ? static_cast<int>(params_.scaling_method) : -1;
+  if (params_.verbose) {
+    std::printf("-------------------------------------------------------------------------------------\n");
+    std::printf("|  iter  |   cost   |    Δ    |    ρ    |  time (s)  |  |g|/cost  |    dL_dq   |    |h|     |\n");
+    std::printf("-------------------------------------------------------------------------------------\n");
+  }
+  bool have = false, last_accepted = true;
+  double S[9] = {0};
+  int k = 0;
+  while (k < params_.max_iterations) {
+    if (!have) {
+      Check(idto_hip_gn_step(hip_));
+      Check(idto_hip_tr_prepare(hip_, scal, 0, S));   // (reports a failed factorisation)
+      have = true;
+    }
+    const double gg = S[0], gHg = S[1], ww = S[2], gw = S[3], gHw = S[4], wHw = S[5], qq = S[6], hh = S[7];
+    // CalcDoglegPoint, normalised by Delta: pU = cU g~ (:2157), pH = -w / Delta (:2139-2149)
+    const double cU = -(gg / gHg) / Delta;
+    const double pUn = std::fabs(cU) * std::sqrt(gg), pHn = std::sqrt(ww) / Delta;
+    double a, b;
+    bool active;
+    if (1.0 <= pUn) {          // :2160-2168
+      a = (Delta / pUn) * cU; b = 0.0; active = true;
+    } else if (1.0 >= pHn) {   // :2171-2178
+      a = 0.0; b = -1.0; active = false;
+    } else {                   // :2180-2199
+      const double pUpU = cU * cU * gg, pHpH = ww / (Delta * Delta), pUpH = -cU * gw / Delta;
+      const double sq = SolveDoglegQuadratic(pHpH - 2 * pUpH + pUpU, 2 * (pUpH - pUpU), pUpU - 1.0);
+      a = Delta * (1.0 - sq) * cU; b = -sq; active = true;
+    }
+    if (!std::isfinite(a) || !std::isfinite(b)) throw FactorizationFailedError("idto_hip: the dogleg step is not finite");
+    double Tr[4];
+    // speculate on acceptance (the next iteration is enqueued behind the trial point) unless the last
+    // step was rejected: a rejection costs a recomputation of g and H at the old q
+    const bool speculate = last_accepted && !std::getenv("IDTO_OPT_NO_SPECULATION");
+    Check(idto_hip_tr_trial(hip_, a, b, params_.scaling ? 1 : 0, params_.normalize_quaternions ? 1 : 0, 0,
+                            speculate ? scal : -2, Tr));
+    const double dq_norm = std::sqrt(Tr[0]), gdqs = Tr[1], cost_trial = Tr[2];
+    if (!std::isfinite(Tr[0])) throw FactorizationFailedError("idto_hip: the dogleg step is not finite");
+    const double dL_dq = gdqs / cost;   // :2517-2524
+    // CalcTrustRatio (:2004-2034)
+    const double gradient_term = a * gg + b * gw;
+    const double hessian_term = 0.5 * (a * a * gHg + 2 * a * b * gHw + b * b * wHw);
+    const double predicted = -gradient_term - hessian_term, actual = cost - cost_trial;
+    const double eps = 10 * std::numeric_limits<double>::epsilon() / time_step_ / time_step_;
+    const double rho = (predicted < eps && actual < eps) ? 0.5 : actual / predicted;
+    if (!(dL_dq < std::numeric_limits<double>::epsilon()))
+      throw std::runtime_error("step is not a descent direction (TO.cc:2531)");
+    const double g_norm = std::sqrt(gg), h_norm = std::sqrt(hh), q_norm = std::sqrt(qq), dqH_norm = std::sqrt(ww);
+    last_accepted = rho > eta;
+    const double cost_k = cost;
+    if (last_accepted) {   // :2550-2553
+      Check(idto_hip_tr_accept(hip_));
+      cost = cost_trial;
+      have = false;
+    } else {
+      Check(idto_hip_tr_reject(hip_));
+      if (speculate) have = false;   // the speculative launch overwrote g, H and the Newton step of q
+    }
+    const double iter_time = std::chrono::duration<double>(clock::now() - iter_start).count();
+    iter_start = clock::now();
+    if (params_.verbose)
+      std::printf("| %6d | %8.3g | %7.2g | %7.3g | %10.5g | %10.5g | %10.4g | %10.4g |\n", k, cost_k, Delta, rho, iter_time,
+                  g_norm / cost_k, dL_dq, h_norm);
+    stats->push_data(iter_time, cost_k, 0, std::numeric_limits<double>::quiet_NaN(), Delta, q_norm, dq_norm, dqH_norm, rho,
+                     g_norm, dL_dq, h_norm, cost_k);   // :2586-2598 (merit = cost without constraints)
+    if (rho < 0.25) Delta *= 0.25;                                                   // :2614-2617
+    else if (rho > 0.75 && active) Delta = std::min(2 * Delta, params_.Delta_max);   // :2618-2622
+    ++k;
+  }
+  // the solution: q from the device; v, tau belong to it unless the last trial point was rejected
+  if (!last_accepted) Check(idto_hip_eval_tau(hip_));
+  state.set_q(Unflatten(Fetch(IDTO_ARR_Q), num_steps() + 1, nq_));
+  solution->q = state.q();
+  solution->v = Unflatten(Fetch(IDTO_ARR_V), num_steps() + 1, nv_);
+  solution->tau = Unflatten(Fetch(IDTO_ARR_TAU), num_steps(), nv_);
+  if (k > 0) {
+    ws->dq = Fetch(IDTO_ARR_TR_DQ);
+    ws->dqH = Fetch(IDTO_ARR_TR_W);
+    for (double& x : ws->dqH) x = -x;   // dqH = Delta pH = -w (:2152)
+  }
+  resident_ = nullptr;   // the device arrays were advanced without the host-side cache
+  device_level_ = 0;
+  stats->solve_time = std::chrono::duration<double>(clock::now() - start_time).count();
+  if (k == params_.max_iterations) return SolverFlag::kMaxIterationsReached;
+  return SolverFlag::kSuccess;
+}
+
 SolverFlag TO::SolveFromWarmStartImpl(WarmStart* ws, TrajectoryOptimizerSolution<T>* solution,
                                       TrajectoryOptimizerStats<T>* stats, ConvergenceReason* reason_out) const {
   using clock = std::chrono::high_resolution_clock;
+  if (params_.method == kTrustRegion && DeviceLoopEligible()) return SolveOnDevice(ws, solution, stats);
   if (params_.method != kTrustRegion) throw std::runtime_error("warm start requires the trust-region method");
   const auto start_time = clock::now();
   auto iter_start = clock::now();

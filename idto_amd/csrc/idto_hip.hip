@@ -21,6 +21,7 @@
 #include "penta_apply.h"
 #include "constraints.h"
 #include "dense_ldl.h"
+#include "trust_region.h"
 
 using namespace idto_dev;
 
@@ -130,6 +131,19 @@ struct idto_hip_ctx {
   // the last ones padded: the slab is allocated with IDTO_SLAB_PAD spare records)
   ncclComm_t comm = nullptr;
   int comm_rank = 0, comm_world = 1, comm_per = 0;
+  // device-side trust-region bookkeeping (trust_region.h): scale factors, scaled merit gradient,
+  // w = D^-1 H^-1 g_merit, the last step, the trial trajectory; [16] scalars on the device + pinned
+  double *tr_D = nullptr, *tr_gt = nullptr, *tr_w = nullptr, *tr_dq = nullptr, *q_trial = nullptr, *tr_out = nullptr;
+  double* tr_pin = nullptr;
+  int* tr_quat = nullptr; int tr_nquat = 0;
+  bool trial_resident = false;         // v / a / tau / cost in device memory belong to q_trial
+  // speculation: idto_hip_tr_trial enqueued the next iteration's gn_step + tr_prepare on the trial
+  // point before the host knew whether it accepts it (spec_scaling: the arguments it used)
+  bool spec_pending = false, spec_ready = false;
+  int spec_scaling = -2;
+  hipEvent_t spec_ev = nullptr;
+  const double* con_lambda_at = nullptr;  // where the current multipliers live (con_lambda or con_lambda + 2)
+  int* una_dofs = nullptr; int una_nu = 0; // unactuated dofs for |h| of the statistics (idto_hip_set_unactuated_dofs)
 };
 enum { IDTO_SLAB_PAD = 64 };
 
@@ -148,7 +162,12 @@ template <class T>
 int Alloc(idto_hip_ctx* c, size_t count, T** dev) {
   void* p = nullptr;
   HIP_OK(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+  // hipMemset on device memory runs on the NULL stream and does not block the host; the context's
+  // stream is non-blocking, i.e. NOT ordered after the NULL stream: without the synchronisation the
+  // zero fill can land after work the caller enqueues next on the context's stream (seen as a
+  // one-in-fifty wrong first solve on the smallest model)
   HIP_OK(hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T)));
+  HIP_OK(hipDeviceSynchronize());
   c->allocs.push_back(p);
   *dev = static_cast<T*>(p);
   return 0;
@@ -471,10 +490,14 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   const size_t o_xch = carve(c->xch_count, D);
   c->flag_count = 8;
   const size_t o_flags = carve(c->flag_count, sizeof(unsigned)), o_sync = carve(2, sizeof(unsigned long long));
+  const size_t nvars = (size_t)(N + 1) * nq;
+  const size_t o_trD = carve(nvars, D), o_trg = carve(nvars, D), o_trw = carve(nvars, D), o_trdq = carve(nvars, D),
+               o_qt = carve(nvars, D), o_trout = carve(16, D);
   c->pstride = (top + 255) & ~(size_t)255;
   {
     void* p = nullptr;
-    if (hipMalloc(&p, c->pstride * (size_t)batch) != hipSuccess || hipMemset(p, 0, c->pstride * (size_t)batch) != hipSuccess) {
+    if (hipMalloc(&p, c->pstride * (size_t)batch) != hipSuccess || hipMemset(p, 0, c->pstride * (size_t)batch) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {   // (see Alloc: the fill must not trail the uploads on the context's stream)
       g_err = "hipMalloc of the problem arenas failed";
       idto_hip_destroy(c);
       return -2;
@@ -497,6 +520,25 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   c->xch = dp(o_xch);
   c->flags = reinterpret_cast<unsigned*>(c->arena + o_flags);
   c->sync_cnt = reinterpret_cast<unsigned long long*>(c->arena + o_sync);
+  c->tr_D = dp(o_trD); c->tr_gt = dp(o_trg); c->tr_w = dp(o_trw); c->tr_dq = dp(o_trdq); c->q_trial = dp(o_qt);
+  c->tr_out = dp(o_trout);
+  {  // adaptive scaling methods start from D = 1 (TO.cc:1233-1236: scale_factors initialised to ones)
+    std::vector<double> ones(nvars, 1.0);
+    for (int b = 0; b < batch; ++b)
+      if (hipMemcpy(at_problem(c->tr_D, (size_t)b * c->pstride), ones.data(), nvars * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+        g_err = "hipMemcpy (scale factors) failed"; idto_hip_destroy(c); return -2;
+      }
+    std::vector<int> qs;
+    for (int i = 0; i < model->nbodies; ++i)
+      if (model->jtype[i] == IDTO_JOINT_FLOATING) qs.push_back(model->qstart[i]);
+    c->tr_nquat = (int)qs.size();
+    if (!qs.empty() && Upload(c, qs.data(), qs.size(), &c->tr_quat)) { idto_hip_destroy(c); return -2; }
+    if (hipHostMalloc((void**)&c->tr_pin, 16 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+      g_err = "hipHostMalloc (trust-region scalars) failed";
+      idto_hip_destroy(c);
+      return -2;
+    }
+  }
   for (int b = 0; b < batch; ++b) {
     rc = UploadProblemArrays(c, problems + b, b);
     if (rc) { idto_hip_destroy(c); return rc; }
@@ -562,6 +604,8 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   FUSED_ATTR(4, 23, false, 2)
 #undef FUSED_ATTR
   if (const char* e = getenv("IDTO_SOLVER_REFERENCE")) c->reference_solver = (e[0] == '1');
+  if (const char* e = getenv("IDTO_TWO_SIDED")) c->two_sided = (e[0] == '1');   // (debugging aids: option defaults)
+  if (const char* e = getenv("IDTO_FUSED")) c->fused = (e[0] == '1');
   (void)hipGetLastError();
   *out = c;
   return 0;
@@ -577,6 +621,8 @@ void idto_hip_destroy(idto_hip_ctx* c) {
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->status_pin) (void)hipHostFree(c->status_pin);
+  if (c->tr_pin) (void)hipHostFree(c->tr_pin);
+  if (c->spec_ev) (void)hipEventDestroy(c->spec_ev);
   if (c->con_pin) (void)hipHostFree(c->con_pin);
   if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
   for (auto& pf : c->pre) if (pf.ev) (void)hipEventDestroy(pf.ev);
@@ -614,6 +660,7 @@ int idto_hip_set_shard(idto_hip_ctx* c, int kb, int ke) {
 
 int idto_hip_set_q(idto_hip_ctx* c, const double* q_host) {
   HIP_OK(hipSetDevice(c->device));
+  c->trial_resident = false; c->spec_pending = false; c->spec_ready = false;
   DropPrefetch(c, {IDTO_ARR_Q});
   c->fd_full = false;
   c->con_ready = false; c->con_begun = false;
@@ -623,6 +670,7 @@ int idto_hip_set_q(idto_hip_ctx* c, const double* q_host) {
 }
 int idto_hip_set_q_batch(idto_hip_ctx* c, const double* q_host) {
   HIP_OK(hipSetDevice(c->device));
+  c->trial_resident = false; c->spec_pending = false; c->spec_ready = false;
   DropPrefetch(c, {IDTO_ARR_Q});
   c->fd_full = false;
   c->con_ready = false; c->con_begun = false;
@@ -633,6 +681,7 @@ int idto_hip_set_q_batch(idto_hip_ctx* c, const double* q_host) {
 }
 int idto_hip_set_q_device(idto_hip_ctx* c, const double* q_dev) {
   HIP_OK(hipSetDevice(c->device));
+  c->trial_resident = false; c->spec_pending = false; c->spec_ready = false;
   DropPrefetch(c, {IDTO_ARR_Q});
   c->fd_full = false;
   c->con_ready = false; c->con_begun = false;
@@ -642,11 +691,12 @@ int idto_hip_set_q_device(idto_hip_ctx* c, const double* q_dev) {
 
 int idto_hip_eval_tau(idto_hip_ctx* c) {
   HIP_OK(hipSetDevice(c->device));
+  c->trial_resident = false; c->spec_pending = false; c->spec_ready = false;
   DropPrefetch(c, {IDTO_ARR_V, IDTO_ARR_A, IDTO_ARR_NPLUS, IDTO_ARR_SLAB, IDTO_ARR_COST});
   int rc = LaunchFd(c, 0, 0, c->N);
   if (rc) return rc;
   hipLaunchKernelGGL(cost_kernel, dim3(1, c->batch), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
-                     c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, (double*)nullptr, c->pstride);
+                     c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, (double*)nullptr, c->pstride, (double*)nullptr);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -656,6 +706,7 @@ int idto_hip_trial_cost(idto_hip_ctx* c, const double* q_host, double* tau_host,
   if (c->batch != 1) { g_err = "trial_cost serves single-problem contexts"; return -1; }
   if (!q_host || !cost_host) { g_err = "trial_cost: bad arguments"; return -1; }
   DropPrefetch(c, {IDTO_ARR_Q, IDTO_ARR_V, IDTO_ARR_A, IDTO_ARR_NPLUS, IDTO_ARR_SLAB, IDTO_ARR_COST});
+  c->trial_resident = false; c->spec_pending = false; c->spec_ready = false;
   const size_t nq_all = (size_t)(c->N + 1) * c->nq, ntau = (size_t)c->N * c->nv;
   if (!c->pin) {
     if (Alloc(c, ntau + 1, &c->pack)) return -2;
@@ -670,7 +721,7 @@ int idto_hip_trial_cost(idto_hip_ctx* c, const double* q_host, double* tau_host,
   int rc = LaunchFd(c, 0, 0, c->N);
   if (rc) return rc;
   hipLaunchKernelGGL(cost_kernel, dim3(1), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
-                     c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, c->pack, (size_t)0);
+                     c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, c->pack, (size_t)0, (double*)nullptr);
   HIP_OK(hipGetLastError());
   double* out = c->pin + nq_all;
   HIP_OK(hipMemcpyAsync(out, c->pack, (ntau + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1017,6 +1068,7 @@ int idto_hip_constraint_solve(idto_hip_ctx* c, const double* h_host, double* lam
     }
   }
   c->con_S_factored = true;
+  c->con_lambda_at = c->con_lambda + 2;
   // lambda = S^-1 (h - J y_g)
   hipLaunchKernelGGL(dense_ldl_solve_kernel, dim3(1), dim3(512), (neq + 512 + DENSE_NB * (DENSE_NB + 1)) * sizeof(double), c->stream, S, neq, c->con_d,
                      S + (size_t)neq * neq, -1.0, c->con_h + 2, c->con_lambda + 2);
@@ -1047,6 +1099,7 @@ int idto_hip_constraint_step(idto_hip_ctx* c, const double* lambda_host, double*
   double* pl = c->con_pin + (size_t)neq * neq + neq;  // [lambda | step | J^T lambda]
   std::memcpy(pl, lambda_host, (size_t)neq * sizeof(double));
   HIP_OK(hipMemcpyAsync(c->con_lambda, pl, (size_t)neq * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  c->con_lambda_at = c->con_lambda;
   hipLaunchKernelGGL(constraint_step_kernel, dim3((n + 63) / 64), dim3(64 * STEP_WAVES), (neq + 64 * STEP_WAVES) * sizeof(double), c->stream, c->slab,
                      c->slab_stride, c->con_dofs, c->con_nu, N, c->nq, c->nv, c->stage_x, neq, c->con_lambda, c->con_out,
                      c->con_out + n);
@@ -1056,6 +1109,125 @@ int idto_hip_constraint_step(idto_hip_ctx* c, const double* lambda_host, double*
   std::memcpy(step_host, pl + neq, (size_t)n * sizeof(double));
   std::memcpy(jtl_host, pl + neq + n, (size_t)n * sizeof(double));
   return FactorStatus(c);
+}
+
+int idto_hip_set_unactuated_dofs(idto_hip_ctx* c, const int* dofs, int nu) {
+  HIP_OK(hipSetDevice(c->device));
+  if (nu < 0 || nu > c->nv || (nu > 0 && !dofs)) { g_err = "set_unactuated_dofs: bad arguments"; return -1; }
+  for (int j = 0; j < nu; ++j)
+    if (dofs[j] < 0 || dofs[j] >= c->nv) { g_err = "set_unactuated_dofs: dof index out of range"; return -1; }
+  c->una_nu = nu;
+  if (nu > 0 && Upload(c, dofs, (size_t)nu, &c->una_dofs)) return -2;
+  return 0;
+}
+
+// ---- device-side trust-region bookkeeping (trust_region.h)
+static int EnqueuePrepare(idto_hip_ctx* c, int scaling_method, int with_lambda) {
+  const int n = (c->N + 1) * c->nq;
+  const double* jtl = with_lambda ? c->con_out + n : nullptr;
+  const double* yin = with_lambda ? c->con_out : c->step;
+  const double* lam = with_lambda ? c->con_lambda_at : nullptr;
+  const int lds = (2 * n + 9 * 16) * (int)sizeof(double);
+  hipLaunchKernelGGL(tr_prepare_kernel, dim3(1), dim3(1024), lds, c->stream, c->N + 1, c->nq, c->HA, c->HB, c->HC, c->g, jtl,
+                     yin, with_lambda ? 1.0 : -1.0, c->q, scaling_method, c->tr_D, c->tr_gt, c->tr_w, c->slab,
+                     c->slab_stride, 3 * c->nv * c->nq, with_lambda ? c->con_dofs : c->una_dofs,
+                     with_lambda ? c->con_nu : c->una_nu, c->N, lam, c->tr_out);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpyAsync(c->tr_pin, c->tr_out, 9 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  return 0;
+}
+
+int idto_hip_tr_prepare(idto_hip_ctx* c, int scaling_method, int with_lambda, double* out_host) {
+  HIP_OK(hipSetDevice(c->device));
+  if (c->batch != 1) { g_err = "tr_prepare serves single-problem contexts"; return -1; }
+  if (scaling_method < -1 || scaling_method > 3) { g_err = "tr_prepare: bad scaling method"; return -1; }
+  if (with_lambda && (!c->con_ready || !c->con_lambda_at)) {
+    g_err = "tr_prepare: multipliers requested but no constraint step is resident";
+    return -1;
+  }
+  if (c->spec_ready && !with_lambda && c->spec_scaling == scaling_method) {
+    // the accepted trial point's iteration was enqueued speculatively by idto_hip_tr_trial
+    c->spec_ready = false;
+  } else {
+    c->spec_ready = false;
+    if (int rc = EnqueuePrepare(c, scaling_method, with_lambda)) return rc;
+  }
+  HIP_OK(hipStreamSynchronize(c->stream));
+  std::memcpy(out_host, c->tr_pin, 9 * sizeof(double));
+  return FactorStatus(c);
+}
+
+int idto_hip_tr_trial(idto_hip_ctx* c, double a, double b, int scaling, int normalize_quaternions, int with_lambda,
+                      int speculate_scaling_method, double* out_host) {
+  HIP_OK(hipSetDevice(c->device));
+  if (c->batch != 1) { g_err = "tr_trial serves single-problem contexts"; return -1; }
+  c->spec_pending = false; c->spec_ready = false;
+  const int n = (c->N + 1) * c->nq;
+  DropPrefetch(c, {IDTO_ARR_V, IDTO_ARR_A, IDTO_ARR_NPLUS, IDTO_ARR_SLAB, IDTO_ARR_COST});
+  hipLaunchKernelGGL(tr_trial_kernel, dim3(1), dim3(1024), 2 * 16 * sizeof(double), c->stream, n, c->nq, c->tr_D, c->tr_gt,
+                     c->tr_w, a, b, scaling, c->q, c->q_trial, c->tr_dq, c->tr_quat,
+                     normalize_quaternions ? c->tr_nquat : 0, c->tr_out + 9);
+  HIP_OK(hipGetLastError());
+  // tau and the cost at the trial point: the same kernels as idto_hip_eval_tau, reading q_trial
+  std::swap(c->q, c->q_trial);
+  int rc = LaunchFd(c, 0, 0, c->N);
+  if (!rc) {
+    hipLaunchKernelGGL(cost_kernel, dim3(1), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
+                       c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, (double*)nullptr, (size_t)0, c->tr_out + 11);
+    if (with_lambda)
+      hipLaunchKernelGGL(tr_hlambda_kernel, dim3(1), dim3(256), 16 * sizeof(double), c->stream, c->slab, c->slab_stride,
+                         3 * c->nv * c->nq, c->con_dofs, c->con_nu, c->N, c->con_lambda_at, c->tr_out + 12);
+  }
+  std::swap(c->q, c->q_trial);
+  if (rc) return rc;
+  HIP_OK(hipGetLastError());
+  c->fd_full = false;
+  c->trial_resident = true;
+  HIP_OK(hipMemcpyAsync(c->tr_pin + 9, c->tr_out + 9, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  const bool speculate = speculate_scaling_method >= -1 && !with_lambda && FusedEligible(c) &&
+                         speculate_scaling_method != 1 && speculate_scaling_method != 3;  // (adaptive scalings update D in place)
+  if (speculate) {
+    // the next iteration on the trial point, before the host has seen its cost: accepted steps (the
+    // common case) find g, H, the Newton step and the inner products ready; a rejected step costs
+    // one more idto_hip_gn_step on the old q
+    if (!c->spec_ev) HIP_OK(hipEventCreateWithFlags(&c->spec_ev, hipEventDisableTiming));
+    HIP_OK(hipEventRecord(c->spec_ev, c->stream));
+    std::swap(c->q, c->q_trial);
+    int rs = LaunchFused(c);
+    if (!rs) rs = EnqueuePrepare(c, speculate_scaling_method, 0);
+    std::swap(c->q, c->q_trial);
+    if (rs) return rs;
+    c->spec_pending = true;
+    c->spec_scaling = speculate_scaling_method;
+    HIP_OK(hipEventSynchronize(c->spec_ev));   // the trial point's scalars only
+  } else {
+    HIP_OK(hipStreamSynchronize(c->stream));
+  }
+  out_host[0] = c->tr_pin[9];    // dq . dq
+  out_host[1] = c->tr_pin[10];   // g~ . D^-1 dq
+  out_host[2] = c->tr_pin[11];   // cost at q + dq
+  out_host[3] = with_lambda ? c->tr_pin[12] : 0.0;  // h(q + dq) . lambda
+  return 0;
+}
+
+int idto_hip_tr_accept(idto_hip_ctx* c) {
+  if (!c->trial_resident) { g_err = "tr_accept: no trial point is resident"; return -1; }
+  std::swap(c->q, c->q_trial);   // v, a, tau, N+ and the cost in device memory already belong to it
+  c->trial_resident = false;
+  c->spec_ready = c->spec_pending;   // ... and so does the speculative iteration, if one was enqueued
+  c->spec_pending = false;
+  c->con_ready = false; c->con_begun = false;
+  DropPrefetch(c, {IDTO_ARR_Q});
+  return 0;
+}
+
+int idto_hip_tr_reject(idto_hip_ctx* c) {
+  // the trial point is dropped: v, a, tau (and, after a speculative launch, the partials, g, H and the
+  // Newton step) in device memory do not belong to the resident q any more
+  c->trial_resident = false; c->spec_pending = false; c->spec_ready = false;
+  c->fd_full = false;
+  c->con_ready = false; c->con_begun = false;
+  return 0;
 }
 
 #define NCCL_OK(expr)                                                                 \
@@ -1190,6 +1362,8 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
 
 int idto_hip_gn_step(idto_hip_ctx* c) {
   HIP_OK(hipSetDevice(c->device));
+  if (c->spec_ready) return 0;   // already enqueued for this q by idto_hip_tr_trial (speculation)
+  c->spec_pending = false;
   if (FusedEligible(c)) return LaunchFused(c);
   int rc = idto_hip_eval_partials(c);
   if (rc) return rc;
@@ -1237,6 +1411,7 @@ long idto_hip_array_size(idto_hip_ctx* c, int what) {
     case IDTO_ARR_SLAB: return N * (long)c->slab_stride;
     case IDTO_ARR_HBANDS: return 3 * (N + 6) * qq;
     case 15: return (N + 4) * 8 * 32;
+    case IDTO_ARR_TR_DQ: case IDTO_ARR_TR_W: case IDTO_ARR_TR_SCALE: return (N + 1) * nq;
     default: return -1;
   }
 }
@@ -1259,6 +1434,9 @@ void* DevPtr(idto_hip_ctx* c, int what) {
     case IDTO_ARR_SLAB: return c->slab;
     case IDTO_ARR_HBANDS: return c->HA;
     case 15: return c->dbg;
+    case IDTO_ARR_TR_DQ: return c->tr_dq;
+    case IDTO_ARR_TR_W: return c->tr_w;
+    case IDTO_ARR_TR_SCALE: return c->tr_D;
     default: return nullptr;  // tau and the three partials live strided inside the slab
   }
 }

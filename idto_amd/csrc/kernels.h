@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevP
 // is accumulated serially in the reference's order.
 __global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__ q, const double* __restrict__ v,
                             const double* __restrict__ slab, int slab_stride, double* __restrict__ cost_out,
-                            int diag, double* __restrict__ pack, size_t pstride) {
+                            int diag, double* __restrict__ pack, size_t pstride, double* __restrict__ cost_copy) {
   {
     const size_t o = (size_t)blockIdx.y * pstride;
     P = at_problem(P, o); q = at_problem(q, o); v = at_problem(v, o); slab = at_problem(slab, o);
@@ -433,6 +433,7 @@ __global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__
     cost += terms[3 * N];
     cost += terms[3 * N + 1];
     *cost_out = cost;
+    if (cost_copy) *cost_copy = cost;   // (single-problem contexts: next to the other trust-region scalars)
     if (pack) pack[N * nv] = cost;
   }
   // [tau_0 .. tau_{N-1} | cost] contiguous: what a trial point of the trust-region loop reads back

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libidto_hip.so")
 
 ARR = dict(q=0, v=1, a=2, tau=3, nplus=4, dtau_dqm=5, dtau_dqt=6, dtau_dqp=7, gradient=8, H_A=9, H_B=10, H_C=11,
-           step=12, cost=13, slab=14, debug=15, hbands=16)
+           step=12, cost=13, slab=14, debug=15, hbands=16, tr_dq=17, tr_w=18, tr_scale=19)
 
 _lib = None
 
@@ -56,6 +56,12 @@ def lib():
         L.idto_hip_gn_step_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int]
         for f in ("comm_destroy", "allgather_slab", "gn_step_sharded"):
             getattr(L, "idto_hip_" + f).argtypes = [C.c_void_p]
+        L.idto_hip_tr_prepare.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.idto_hip_tr_trial.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.POINTER(C.c_double)]
+        L.idto_hip_tr_accept.argtypes = [C.c_void_p]
+        L.idto_hip_tr_reject.argtypes = [C.c_void_p]
+        L.idto_hip_set_unactuated_dofs.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
         L.idto_hip_destroy.argtypes = [C.c_void_p]
         L.idto_hip_set_problem.argtypes = [C.c_void_p, C.POINTER(CProblem)]
         L.idto_hip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
@@ -102,6 +108,7 @@ EXPORTED_SYMBOLS = [
     "idto_hip_device_ptr", "idto_hip_array_size", "idto_hip_slab_stride", "idto_hip_math_probe",
     "idto_hip_solver_status", "idto_hip_create_batch", "idto_hip_batch_size", "idto_hip_set_problem_batch",
     "idto_hip_set_q_batch", "idto_hip_gn_step_batch", "idto_hip_get_batch", "idto_hip_solver_status_batch",
+    "idto_hip_tr_prepare", "idto_hip_tr_trial", "idto_hip_tr_accept", "idto_hip_tr_reject", "idto_hip_set_unactuated_dofs",
     "idto_hip_comm_unique_id", "idto_hip_comm_init", "idto_hip_comm_init_all", "idto_hip_comm_destroy",
     "idto_hip_allgather_slab", "idto_hip_gn_step_sharded", "idto_hip_gn_step_multi", "idto_hip_eval_partials_multi",
 ]
@@ -210,6 +217,29 @@ class HipPath:
 
     def gn_step_sharded(self):
         _chk(lib().idto_hip_gn_step_sharded(self.h))
+
+    # ---- trust-region bookkeeping on the device (include/idto_hip.h idto_hip_tr_*)
+    def tr_prepare(self, scaling_method: int = -1, with_lambda: bool = False):
+        out = np.zeros(9)
+        _chk(lib().idto_hip_tr_prepare(self.h, int(scaling_method), int(with_lambda), dptr(out)))
+        return out
+
+    def tr_trial(self, a: float, b: float, scaling: bool, normalize_quaternions: bool = False, with_lambda: bool = False,
+                 speculate_scaling_method: int = -2):
+        out = np.zeros(4)
+        _chk(lib().idto_hip_tr_trial(self.h, float(a), float(b), int(scaling), int(normalize_quaternions),
+                                     int(with_lambda), int(speculate_scaling_method), dptr(out)))
+        return out
+
+    def tr_reject(self):
+        _chk(lib().idto_hip_tr_reject(self.h))
+
+    def set_unactuated_dofs(self, dofs):
+        dofs = np.ascontiguousarray(np.asarray(dofs, dtype=np.int32))
+        _chk(lib().idto_hip_set_unactuated_dofs(self.h, dofs.ctypes.data_as(C.POINTER(C.c_int)), int(dofs.size)))
+
+    def tr_accept(self):
+        _chk(lib().idto_hip_tr_accept(self.h))
 
     def set_shard(self, k_begin: int, k_end: int):
         _chk(lib().idto_hip_set_shard(self.h, int(k_begin), int(k_end)))

@@ -140,6 +140,9 @@ class TrajectoryOptimizer<double> {
                                  TrajectoryOptimizerStats<T>* stats) const;
   SolverFlag SolveFromWarmStartImpl(WarmStart* warm_start, TrajectoryOptimizerSolution<T>* solution,
                                     TrajectoryOptimizerStats<T>* stats, ConvergenceReason* reason) const;
+  bool DeviceLoopEligible() const;
+  SolverFlag SolveOnDevice(WarmStart* warm_start, TrajectoryOptimizerSolution<T>* solution,
+                           TrajectoryOptimizerStats<T>* stats) const;
   void AdoptTrialPoint(const TrajectoryOptimizerState<T>& scratch, TrajectoryOptimizerState<T>* state) const;
   ConvergenceReason VerifyConvergenceCriteria(const TrajectoryOptimizerState<T>& state, T previous_cost,
                                               const VectorXd& dq) const;

@@ -60,8 +60,11 @@ enum idto_hip_array {
   IDTO_ARR_SLAB = 14,    /* N * slab_stride: per tau-index k [dtau_dqm | dtau_dqt | dtau_dqp | tau_k] — the
                             buffer a multi-GPU run all-gathers (contiguous in k) */
   IDTO_ARR_DEBUG = 15,   /* solver cycle stamps (option "solver_debug") */
-  IDTO_ARR_HBANDS = 16   /* the three Hessian bands in one copy: [A | B | C], each (N+6) blocks nq x nq
+  IDTO_ARR_HBANDS = 16,  /* the three Hessian bands in one copy: [A | B | C], each (N+6) blocks nq x nq
                             (N+1 used, 5 trailing zero blocks: the solver's prefetch margin) */
+  IDTO_ARR_TR_DQ = 17,   /* (N+1)*nq : the step dq of the last idto_hip_tr_trial */
+  IDTO_ARR_TR_W = 18,    /* (N+1)*nq : w = D^-1 H^-1 (g + J^T lambda) of the last idto_hip_tr_prepare */
+  IDTO_ARR_TR_SCALE = 19 /* (N+1)*nq : scale factors D (CalcScaleFactors) */
 };
 
 const char* idto_hip_last_error(void);
@@ -184,6 +187,37 @@ int idto_hip_constraint_step(idto_hip_ctx* ctx, const double* lambda_host, doubl
  * on the host + idto_hip_constraint_step, as Eigen's ldlt() tolerates semi-definite S. */
 int idto_hip_constraint_solve(idto_hip_ctx* ctx, const double* h_host, double* lambda_host, double* step_host,
                               double* jtl_host);
+
+/* Trust-region bookkeeping on the resident arrays: what CalcScaleFactors, the
+ * scaled gradient / Hessian products, CalcDoglegPoint and CalcTrustRatio
+ * (optimizer/trajectory_optimizer.cc:1181-1255, 2108-2202, 1979-2035) compute from g and H, without g
+ * or H leaving the device.
+ *   idto_hip_tr_prepare: after idto_hip_gn_step (or, with_lambda = 1, after the constraint step).
+ *     scaling_method -1 = no scaling, else SolverParameters::scaling_method.  With D the scale
+ *     factors, g~ = D (g + J^T lambda), H~ = D H D and w = D^-1 H^-1 (g + J^T lambda) it returns
+ *     out[9] = { g~.g~, g~.H~g~, w.w, g~.w, g~.H~w, w.H~w, q.q, h.h, h.lambda } (synchronises).
+ *     The Newton point of the dogleg is pH = -w / Delta, the Cauchy point pU = -(g~.g~ / g~.H~g~) g~ / Delta.
+ *   idto_hip_tr_trial: every dogleg step is dq = D (a g~ + b w); forms q + dq (quaternions
+ *     normalised on request), evaluates tau and the cost there and returns
+ *     out[4] = { dq.dq, g~.(a g~ + b w), L(q + dq), h(q + dq).lambda } (synchronises).
+ *     speculate_scaling_method >= -1 (else -2): right behind the trial point's evaluation the NEXT
+ *     iteration on q + dq is enqueued too - idto_hip_gn_step and idto_hip_tr_prepare with that scaling
+ *     method - while the host is still waiting for the trial point's cost: when the step is accepted
+ *     (idto_hip_tr_accept) the following idto_hip_gn_step / idto_hip_tr_prepare return what is already
+ *     there; when it is rejected (idto_hip_tr_reject) g, H and the Newton step of q have been
+ *     overwritten and must be recomputed.  (Not for the adaptive scaling methods, which update D in
+ *     place; then the call behaves as without speculation.)
+ *   idto_hip_tr_accept: q + dq becomes the resident q (its v, a, tau, cost are already resident).
+ *   idto_hip_tr_reject: q stays; v, a, tau in device memory belong to the dropped trial point. */
+/* The unactuated dofs (rows of the actuation matrix that are zero, TO.cc:63-72): h.h of
+ * idto_hip_tr_prepare is reported for them even when the constraints are not enforced (the
+ * reference logs |h| in every iteration, TO.cc:2509, :2586-2598). */
+int idto_hip_set_unactuated_dofs(idto_hip_ctx* ctx, const int* dofs, int nu);
+int idto_hip_tr_prepare(idto_hip_ctx* ctx, int scaling_method, int with_lambda, double* out_host /* [9] */);
+int idto_hip_tr_trial(idto_hip_ctx* ctx, double a, double b, int scaling, int normalize_quaternions, int with_lambda,
+                      int speculate_scaling_method, double* out_host /* [4] */);
+int idto_hip_tr_accept(idto_hip_ctx* ctx);
+int idto_hip_tr_reject(idto_hip_ctx* ctx);
 
 /* Options: "gradients_method" = 0 forward differences (default), 1 / 2 central differences of
  * 2nd / 4th order (SolverParameters::gradients_method, reference solver_parameters.h:26-50,
