@@ -133,6 +133,7 @@ struct idto_hip_ctx {
   int comm_rank = 0, comm_world = 1, comm_per = 0;
   // device-side trust-region bookkeeping (trust_region.h): scale factors, scaled merit gradient,
   // w = D^-1 H^-1 g_merit, the last step, the trial trajectory; [16] scalars on the device + pinned
+  double *tr_Dprev = nullptr, *tr_part = nullptr;   // the adaptive scalings' previous D; per-block-row partial sums
   double *tr_D = nullptr, *tr_gt = nullptr, *tr_w = nullptr, *tr_dq = nullptr, *q_trial = nullptr, *tr_out = nullptr;
   double* tr_pin = nullptr;
   int* tr_quat = nullptr; int tr_nquat = 0;
@@ -492,7 +493,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   const size_t o_flags = carve(c->flag_count, sizeof(unsigned)), o_sync = carve(2, sizeof(unsigned long long));
   const size_t nvars = (size_t)(N + 1) * nq;
   const size_t o_trD = carve(nvars, D), o_trg = carve(nvars, D), o_trw = carve(nvars, D), o_trdq = carve(nvars, D),
-               o_qt = carve(nvars, D), o_trout = carve(16, D);
+               o_qt = carve(nvars, D), o_trout = carve(16, D), o_trDp = carve(nvars, D), o_trpart = carve((size_t)9 * (N + 1), D);
   c->pstride = (top + 255) & ~(size_t)255;
   {
     void* p = nullptr;
@@ -521,11 +522,12 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   c->flags = reinterpret_cast<unsigned*>(c->arena + o_flags);
   c->sync_cnt = reinterpret_cast<unsigned long long*>(c->arena + o_sync);
   c->tr_D = dp(o_trD); c->tr_gt = dp(o_trg); c->tr_w = dp(o_trw); c->tr_dq = dp(o_trdq); c->q_trial = dp(o_qt);
-  c->tr_out = dp(o_trout);
+  c->tr_out = dp(o_trout); c->tr_Dprev = dp(o_trDp); c->tr_part = dp(o_trpart);
   {  // adaptive scaling methods start from D = 1 (TO.cc:1233-1236: scale_factors initialised to ones)
     std::vector<double> ones(nvars, 1.0);
     for (int b = 0; b < batch; ++b)
-      if (hipMemcpy(at_problem(c->tr_D, (size_t)b * c->pstride), ones.data(), nvars * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+      if (hipMemcpy(at_problem(c->tr_D, (size_t)b * c->pstride), ones.data(), nvars * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemcpy(at_problem(c->tr_Dprev, (size_t)b * c->pstride), ones.data(), nvars * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
         g_err = "hipMemcpy (scale factors) failed"; idto_hip_destroy(c); return -2;
       }
     std::vector<int> qs;
@@ -1127,11 +1129,13 @@ static int EnqueuePrepare(idto_hip_ctx* c, int scaling_method, int with_lambda) 
   const double* jtl = with_lambda ? c->con_out + n : nullptr;
   const double* yin = with_lambda ? c->con_out : c->step;
   const double* lam = with_lambda ? c->con_lambda_at : nullptr;
-  const int lds = (2 * n + 9 * 16) * (int)sizeof(double);
-  hipLaunchKernelGGL(tr_prepare_kernel, dim3(1), dim3(1024), lds, c->stream, c->N + 1, c->nq, c->HA, c->HB, c->HC, c->g, jtl,
-                     yin, with_lambda ? 1.0 : -1.0, c->q, scaling_method, c->tr_D, c->tr_gt, c->tr_w, c->slab,
-                     c->slab_stride, 3 * c->nv * c->nq, with_lambda ? c->con_dofs : c->una_dofs,
-                     with_lambda ? c->con_nu : c->una_nu, c->N, lam, c->tr_out);
+  const int lds = (23 * c->nq + 9 * 16) * (int)sizeof(double);
+  hipLaunchKernelGGL(tr_prepare_rows_kernel, dim3(c->N + 1), dim3(256), lds, c->stream, c->N + 1, c->nq, c->HA, c->HB, c->HC,
+                     c->g, jtl, yin, with_lambda ? 1.0 : -1.0, c->q, scaling_method, c->tr_Dprev, c->tr_D, c->tr_gt, c->tr_w,
+                     c->slab, c->slab_stride, 3 * c->nv * c->nq, with_lambda ? c->con_dofs : c->una_dofs,
+                     with_lambda ? c->con_nu : c->una_nu, c->N, lam, c->tr_part);
+  hipLaunchKernelGGL(tr_prepare_sum_kernel, dim3(1), dim3(256), 0, c->stream, c->N + 1, c->tr_part, c->tr_out, c->tr_D,
+                     c->tr_Dprev, n);
   HIP_OK(hipGetLastError());
   HIP_OK(hipMemcpyAsync(c->tr_pin, c->tr_out, 9 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   return 0;
