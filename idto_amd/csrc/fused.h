@@ -87,8 +87,8 @@ __global__ void __launch_bounds__(256) gn_fused_kernel(FusedArgs A) {
     fused_wait(A.sync + 1, A.asm_target, false);
     fused_stamp(A.dbg, 1);
     penta_ldl_body<K, 256, PADDED, GJW>(A.n, A.k, A.sHA, A.sHB, A.sHC, A.b, A.rhs_sign, 1, A.x, A.Ust, A.Hst, A.Est,
-                                        A.Dst, nullptr, A.m_split, A.xch, A.flags, A.epoch, A.status, A.fact_id,
-                                        bx - A.nfd - nasm);
+                                        A.Dst, nullptr, two_sided_cfg(A.n, A.m_split, bx - A.nfd - nasm), A.xch, A.flags,
+                                        A.epoch, A.status, A.fact_id);
     fused_stamp(A.dbg, 2);
   }
 }

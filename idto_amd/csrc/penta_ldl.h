@@ -163,6 +163,30 @@ __host__ __device__ inline PentaLdlLds penta_ldl_layout(int n, int K, int nrhs) 
   return L;
 }
 
+// Role of one workgroup of the factorisation.  The two-workgroup ("twisted") kernel uses two of
+// them: the top one eliminates rows 0 .. m-1 top-down and then the two join rows m, m+1 (joiner),
+// the bottom one rows n-1 .. m+2 bottom-up and runs two product-only pseudo-rows whose augmented
+// blocks are its contributions to the join rows (producer).  The nested-dissection kernel
+// (penta_nd.h) runs four such chains - two producer / joiner pairs around a separator - and needs
+// the hooks at the end.
+struct ChainCfg {
+  int two;        // 0: one workgroup eliminates the whole system
+  int mirror;     // 1: local row il is row base - il of the matrix (bands read transposed), 0: base + il
+  int producer;   // 1: pseudo-rows + publish; 0: joiner (adds the producer's contributions, eliminates the join rows)
+  int base;       // matrix row of local row 0
+  int nloc;       // block rows eliminated here (joiner: chain rows + the two join rows)
+  int m_split;    // joiner: local index of the first join row
+  int dbg_slot;   // which block of the cycle-stamp array
+  // nested dissection: a joiner chain publishes, per local row, that its factors (and rt) are in HBM
+  // (counter += 1 per I/O wavefront), and subtracts the separator's contribution from rt before its
+  // back substitution
+  unsigned long long* rowcnt;
+  unsigned long long rowcnt_unit;   // what one wavefront adds
+  double* rtpub;                    // [local row][K]
+  const double* corr;               // [local row][K]
+  unsigned* corrflag;
+};
+
 // K = compile-time block size >= k; the k x k blocks are embedded in K x K ones padded with
 // the identity (padding rows/columns never mix with the real ones).
 // b, x: [nrhs][n*k]; Ust/Hst/Est: [n][K*K] factors (internal layout), Dst: [n][K].
@@ -172,8 +196,8 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
                const double* __restrict__ HC, const double* __restrict__ b, double rhs_sign, int nrhs,
                double* __restrict__ x, double* __restrict__ Ust, double* __restrict__ Hst,
                double* __restrict__ Est, double* __restrict__ Dst, double* __restrict__ dbg,
-               int m_split, double* __restrict__ xch, unsigned* __restrict__ flags, unsigned epoch,
-               unsigned* __restrict__ status, unsigned fact_id, const int side) {
+               const ChainCfg cfg, double* __restrict__ xch, unsigned* __restrict__ flags, unsigned epoch,
+               unsigned* __restrict__ status, unsigned fact_id) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // ---- two-sided ("twisted") elimination, m_split > 0, grid of 2 workgroups: workgroup 0
@@ -185,10 +209,11 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
   // and the top workgroup adds them before eliminating rows m and m+1.  Back substitution runs
   // outwards from the join in both workgroups (x_m, x_{m+1} handed to the bottom one).  The
   // dependent chain is ~n/2 block rows instead of n in both passes.
-  const bool two = m_split > 0;
-  const int nloc = two ? (side ? n - m_split - 2 : m_split + 2) : n;  // block rows eliminated here
-  const int nfwd = nloc + ((two && side) ? 2 : 0);                    // + pseudo-rows (bottom)
-  auto orig = [&](int il) { const int o = side ? n - 1 - il : il; return o < 0 ? 0 : o; };
+  const bool two = cfg.two != 0, mirror = cfg.mirror != 0, producer = cfg.producer != 0;
+  const int m_split = cfg.m_split;
+  const int nloc = cfg.nloc;                                          // block rows eliminated here
+  const int nfwd = nloc + ((two && producer) ? 2 : 0);                // + pseudo-rows (producer)
+  auto orig = [&](int il) { const int o = mirror ? cfg.base - il : cfg.base + il; return o < 0 ? 0 : o; };
   constexpr int nt = NT, KK = K * K, ks = ldl_ks(K), NW = NT / 64;
   const int kk = k * k;
   const int ncr = 2 * K + nrhs, per_wave = 64 - K;
@@ -198,7 +223,7 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
   double* Wm = lds + L.W;
   auto stamp = [&](int i, int ph) {
     if (dbg && lane == 0)
-      dbg[((side * (NT / 64) + wave) * (n + 3) + i) * 8 + ph] = (double)__builtin_readcyclecounter();
+      dbg[((cfg.dbg_slot * (NT / 64) + wave) * (n + 3) + i) * 8 + ph] = (double)__builtin_readcyclecounter();
   };
 
   // ---- setup
@@ -248,7 +273,7 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
       if (!PADDED || (r < k && c < k)) {
         m_load |= 1ull << s;
         if (which == 1) p_off[s] = dHC + c * k + r;
-        else if (!side) p_off[s] = ((which == 0) ? dHB + kk : 2 * kk) + c * k + r;  // B_{i+1}, A_{i+2}
+        else if (!mirror) p_off[s] = ((which == 0) ? dHB + kk : 2 * kk) + c * k + r;  // B_{i+1}, A_{i+2}
         else p_off[s] = ((which == 0) ? dHB : 0) + r * k + c;                        // B_i^T, A_i^T
       } else if (which == 1 && r == c) {
         m_one |= 1ull << s;
@@ -265,7 +290,7 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
     // workgroup); pseudo-rows of the bottom workgroup have all-zero inputs
     unsigned long long kill = 0;
     if (two) {
-      if (!side) kill = (il >= m_split ? m_isA : 0ull) | (il >= m_split + 1 ? m_isB : 0ull);
+      if (!producer) kill = (il >= m_split ? m_isA : 0ull) | (il >= m_split + 1 ? m_isB : 0ull);
       else if (il >= nloc) kill = ~0ull;
     }
 #pragma unroll
@@ -488,7 +513,7 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
     lds_barrier();
     stamp(i, 2);
 
-    if (two && !side && i >= m_split) {
+    if (two && !producer && i >= m_split) {
       // ---- join: add the other workgroup's Schur-complement contributions to [S | H | . | y]
       if (i == m_split) {
         if (tid == 0)
@@ -627,6 +652,14 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
           }
         }
         for (int r = ht; r < K; r += hn) Dst[(size_t)orig(i - 1) * K + r] = Ivp[r];
+        if (cfg.rowcnt) {
+          // nested dissection: row i-1 (factors above, rt here) is complete in HBM once every I/O
+          // wavefront has released its stores
+          for (int r = ht; r < K; r += hn) cfg.rtpub[(size_t)(i - 1) * K + r] = lds[L.xall + (i - 1 + 2) * ks + r];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          if (lane == 0)
+            __hip_atomic_fetch_add(cfg.rowcnt + (i - 1), cfg.rowcnt_unit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
     stamp(i, 6);
@@ -647,15 +680,34 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
       Est[(size_t)orig(i) * K * ks + idx] = in ? El[c * ks + r] * dr : 0.0;
     }
     for (int r = tid; r < K; r += nt) Dst[(size_t)orig(i) * K + r] = Il[r];
+    if (cfg.rowcnt)
+      for (int r = tid; r < K; r += nt) cfg.rtpub[(size_t)i * K + r] = lds[L.xall + (i + 2) * ks + r];
   }
-  if (two && side) {  // publish the join contributions
+  if (two && producer) {  // publish the join contributions
     __threadfence();
     __syncthreads();
     if (tid == 0) __hip_atomic_store(flags, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();  // factors written by this block are re-read below: drain the stores
   __threadfence_block();
+  if (cfg.rowcnt && tid == 0) {  // the last row was written by every wavefront (above): one release for all
+    const int nio = (NT - io_first * 64) / 64;
+    __hip_atomic_fetch_add(cfg.rowcnt + (nloc - 1), cfg.rowcnt_unit * nio, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
   stamp(nfwd, 0);
+  if (cfg.corr) {
+    // nested dissection: this chain's rows also couple to the separator; its solution times the
+    // eliminated coupling blocks (F_il x_sep, computed by the spike workgroup) leaves rt
+    if (tid == 0)
+      while (__hip_atomic_load(cfg.corrflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
+    __syncthreads();
+    (void)__hip_atomic_load(cfg.corrflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    for (int idx = tid; idx < nloc * K; idx += nt) {
+      const int il = idx / K, r = idx - il * K;
+      lds[L.xall + (il + 2) * ks + r] -= cfg.corr[idx];
+    }
+    __syncthreads();
+  }
 
   // ---- backward pass: (D_i^-1 U_i) x_i = D_i^-1 rt_i - (D_i^-1 Ht_i) x_{i+1} - (D_i^-1 Et_i) x_{i+2}
   // One wavefront per right-hand side, no LDS staging and no barrier: lane = row r (+32 for the
@@ -712,7 +764,7 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
       };
       double* xjoin = xch + 2 * (size_t)(K + ncr) * ks;  // [2][K]: x_m, x_{m+1}
       double acc = half_ ? dvrt(nloc - 2) : dvrt(nloc - 1);
-      if (two && side) {
+      if (two && producer) {
         // x_{nloc} (= row m+1) and x_{nloc+1} (= row m) come from the top workgroup: their pushes
         if (lane == 0)
           while (__hip_atomic_load(flags + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch)
@@ -744,9 +796,9 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
         }
         if (live) {
           lds[L.xall + (i + 2) * ks + r_] = acc;
-          if (two && !side && i >= m_split) xjoin[(size_t)(i - m_split) * K + r_] = acc;
+          if (two && !producer && i >= m_split) xjoin[(size_t)(i - m_split) * K + r_] = acc;
         }
-        if (two && !side && i == m_split) {  // rows m+1 and m are solved: release the other workgroup
+        if (two && !producer && i == m_split) {  // rows m+1 and m are solved: release the other workgroup
           __threadfence();
           if (lane == 0) __hip_atomic_store(flags + 1, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -808,10 +860,10 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
         if (L.bl_size) lds[L.xall + (j * (n + 2) + i + 2) * ks + r_] = v;
         else if (r_ < k) x[(size_t)j * nk + (size_t)orig(i) * k + r_] = v;
         // the join rows' solution is what the other workgroup's back substitution starts from
-        if (two && !side && i >= m_split) xjoin[(size_t)(j * 2 + (i - m_split)) * K + r_] = v;
+        if (two && !producer && i >= m_split) xjoin[(size_t)(j * 2 + (i - m_split)) * K + r_] = v;
       }
     };
-    if (two && side) {
+    if (two && producer) {
       // x of local rows nloc (= row m+1) and nloc+1 (= row m) come from the top workgroup
       if (lane == 0)
         while (__hip_atomic_load(flags + 1 + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch)
@@ -831,7 +883,7 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
         load_row(i - 2, A0, U0, dv0, rt0);
         solve_row(i - 1, A1, U1, dv1, rt1, xs2, xs1);  // x_{i-1} -> xs1 ; then xs1 = x_{i-1}, xs2 = x_i
       }
-      if (two && !side && i == nloc - 1) {  // rows m+1 and m are solved: release the other workgroup
+      if (two && !producer && i == nloc - 1) {  // rows m+1 and m are solved: release the other workgroup
         __threadfence();
         if (lane == 0) __hip_atomic_store(flags + 1 + j, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -847,6 +899,18 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
   stamp(nfwd, 1);
 }
 
+// the two roles of the two-workgroup kernel (m_split = 0: one workgroup, the whole system)
+__host__ __device__ inline ChainCfg two_sided_cfg(int n, int m_split, int side) {
+  ChainCfg c = {};
+  c.two = m_split > 0;
+  c.mirror = side; c.producer = side;
+  c.base = side ? n - 1 : 0;
+  c.nloc = c.two ? (side ? n - m_split - 2 : m_split + 2) : n;
+  c.m_split = m_split;
+  c.dbg_slot = side;
+  return c;
+}
+
 // grid (sides, batch): blockIdx.x = side of the two-sided elimination, blockIdx.y = problem of the
 // batch (arenas `pstride` bytes apart, see kernels.h at_problem; b / x are per-problem arrays too)
 template <int K, int NT, bool PADDED, int GJW>
@@ -860,9 +924,9 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
   const size_t o = (size_t)blockIdx.y * pstride;
   penta_ldl_body<K, NT, PADDED, GJW>(n, k, at_problem(HA, o), at_problem(HB, o), at_problem(HC, o), at_problem(b, o),
                                      rhs_sign, nrhs, at_problem(x, o), at_problem(Ust, o), at_problem(Hst, o),
-                                     at_problem(Est, o), at_problem(Dst, o), dbg ? at_problem(dbg, o) : nullptr, m_split,
-                                     at_problem(xch, o), at_problem(flags, o), epoch, status + 2 * blockIdx.y, fact_id,
-                                     (int)blockIdx.x);
+                                     at_problem(Est, o), at_problem(Dst, o), dbg ? at_problem(dbg, o) : nullptr,
+                                     two_sided_cfg(n, m_split, (int)blockIdx.x), at_problem(xch, o), at_problem(flags, o),
+                                     epoch, status + 2 * blockIdx.y, fact_id);
 }
 
 }  // namespace idto_dev
