@@ -338,9 +338,12 @@ def main():
         algb.append(8 * (2 * 3 * N * nv * nq + 2 * 3 * (N + 1) * nq * nq + 2 * 5 * (N + 1) * nq * nq
                          + 4 * (N + 1) * nq + 2 * (N + 1) * nv + 3 * N * nv))
         dom = 3 if fused_run else int(np.argmax([k[0] for k in kern[:3]]))
+        names = list(KERNELS)
+        if dev.get_option("last_solver") == 2:   # nested dissection over seven workgroups (csrc/penta_nd.h)
+            names[2] = "penta_nd_kernel"
         dur_s = kern[dom][0] * 1e-3
         achieved = algb[dom] / dur_s / 1e9 if dur_s > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(KERNELS[dom])
+        traffic, traffic_src = pmc_traffic(names[dom])
         out = {
             "metric": f"Gauss-Newton iters/sec (grad+Hessian+solve), {args.config} N={N}",
             "value": value, "unit": "GN iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -356,12 +359,12 @@ def main():
                                         f"of the dtau/dq slabs ({'ncclAllGather inside libidto_hip.so' if exchange == 'rccl' else 'torch.distributed'}), "
                                         f"redundant assemble+solve" if sharded else
                                         f"{world} independent replicas"))},
-            "roofline": {"bound": "hbm", "kernel": KERNELS[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algb[dom], "avg_launch_ms": kern[dom][0],
                          "launches_timed": kern[dom][1],
-                         "all_kernels_avg_ms": {KERNELS[i]: kern[i][0] for i in range(4) if kern[i][1] > 0},
+                         "all_kernels_avg_ms": {names[i]: kern[i][0] for i in range(4) if kern[i][1] > 0},
                          "note": "latency/dependency-bound path (SURVEY.md §8d): HBM fraction is intrinsically small"},
         }
         if other_extra is not None:

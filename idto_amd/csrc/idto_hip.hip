@@ -18,6 +18,7 @@
 #include "kernels.h"
 #include "penta_ldl.h"
 #include "fused.h"
+#include "penta_nd.h"
 #include "penta_apply.h"
 #include "constraints.h"
 #include "dense_ldl.h"
@@ -90,6 +91,11 @@ struct idto_hip_ctx {
   int asm_stop = 0;                       // profiling aid: truncate the assembly kernel after a phase
   bool two_sided = true;                  // solver: two workgroups eliminating from both ends
   bool fused = true;                      // gn_step: one persistent launch (fused.h) when eligible
+  bool solver_nd = true;                  // solver: nested dissection over 7 workgroups (penta_nd.h) when eligible
+  unsigned long long* nd_rowcnt = nullptr; // its per-row release counters, buffers and launch count
+  double* nd_buf = nullptr;
+  unsigned long long nd_launches = 0;
+  int last_solver = 0;                     // 0 none yet, 1 two-workgroup LDL^T, 2 nested dissection, 3 reference LU
   bool fused_debug = false;               // ... with per-workgroup time stamps in IDTO_ARR_DEBUG
   double* xch = nullptr;                  // their exchange buffer / flags
   unsigned* flags = nullptr;
@@ -488,8 +494,9 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   const size_t o_E = carve((size_t)(N + 1) * 32 * 36, D), o_Ds = carve((size_t)(N + 1) * 32, D);
   // exchange buffer of the two-sided solver (one right-hand side): 2 augmented blocks + [2][K]
   c->xch_count = 2 * (size_t)(3 * 32 + 1) * ldl_ks(32) + 2 * 32;
-  const size_t o_xch = carve(c->xch_count, D);
-  c->flag_count = 8;
+  const size_t o_xch = carve(2 * c->xch_count, D);   // (two producer / joiner pairs in the nested-dissection kernel)
+  const size_t o_ndcnt = carve(2 * ND_MAXROWS, sizeof(unsigned long long)), o_ndbuf = carve((size_t)nd_layout(32).end, D);
+  c->flag_count = 16;
   const size_t o_flags = carve(c->flag_count, sizeof(unsigned)), o_sync = carve(2, sizeof(unsigned long long));
   const size_t nvars = (size_t)(N + 1) * nq;
   const size_t o_trD = carve(nvars, D), o_trg = carve(nvars, D), o_trw = carve(nvars, D), o_trdq = carve(nvars, D),
@@ -521,6 +528,8 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   c->xch = dp(o_xch);
   c->flags = reinterpret_cast<unsigned*>(c->arena + o_flags);
   c->sync_cnt = reinterpret_cast<unsigned long long*>(c->arena + o_sync);
+  c->nd_rowcnt = reinterpret_cast<unsigned long long*>(c->arena + o_ndcnt);
+  c->nd_buf = dp(o_ndbuf);
   c->tr_D = dp(o_trD); c->tr_gt = dp(o_trg); c->tr_w = dp(o_trw); c->tr_dq = dp(o_trdq); c->q_trial = dp(o_qt);
   c->tr_out = dp(o_trout); c->tr_Dprev = dp(o_trDp); c->tr_part = dp(o_trpart);
   {  // adaptive scaling methods start from D = 1 (TO.cc:1233-1236: scale_factors initialised to ones)
@@ -599,6 +608,9 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   LDL_ATTR(2, false, 1) LDL_ATTR(3, false, 1) LDL_ATTR(5, false, 1) LDL_ATTR(19, false, 1) LDL_ATTR(23, false, 2)
   LDL_ATTR(8, true, 1) LDL_ATTR(16, true, 1) LDL_ATTR(24, true, 2) LDL_ATTR(32, true, 3)
 #undef LDL_ATTR
+#define ND_ATTR(KM, PD) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_nd_kernel<KM, PD>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  ND_ATTR(2, false) ND_ATTR(3, false) ND_ATTR(5, false) ND_ATTR(19, false)
+#undef ND_ATTR
 #define FUSED_ATTR(MC, KM, PD, GW)                                                                 \
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_fused_kernel<MC, KM, PD, GW>),       \
                             hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -608,6 +620,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   if (const char* e = getenv("IDTO_SOLVER_REFERENCE")) c->reference_solver = (e[0] == '1');
   if (const char* e = getenv("IDTO_TWO_SIDED")) c->two_sided = (e[0] == '1');   // (debugging aids: option defaults)
   if (const char* e = getenv("IDTO_FUSED")) c->fused = (e[0] == '1');
+  if (const char* e = getenv("IDTO_SOLVER_ND")) c->solver_nd = (e[0] == '1');
   (void)hipGetLastError();
   *out = c;
   return 0;
@@ -802,15 +815,70 @@ static int PlanLdl(idto_hip_ctx* c, bool one_sided, LdlPlan* p) {
   return 0;
 }
 
-static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, double* xo, bool one_sided = false) {
+// Nested dissection (penta_nd.h): seven workgroups - two producer / joiner pairs, two spike
+// workgroups, the separator.  Its factors are not what penta_apply_kernel walks, so it serves the
+// single-right-hand-side solves only (the Gauss-Newton step).
+static bool NdEligible(const idto_hip_ctx* c, const LdlPlan& p) {
+  const bool inst = (p.K == 2 || p.K == 3 || p.K == 5 || p.K == 19) && p.K == p.k;
+  return c->solver_nd && c->two_sided && inst && p.n >= 24 && p.gj_waves == 1;
+}
+static int NdLds(const idto_hip_ctx* c, const LdlPlan& p, int nloc_max) {
+  const int ks = ldl_ks(p.K), NF = 2 * p.K, KP = 4 * ((p.K + 3) / 4);
+  const int spike = ((nloc_max + 2) * NF * ks + 3 * KP * ks + 3 * p.K * p.K + 4 * ks + NF) * (int)sizeof(double);
+  const int sep = (2 * (4 * p.K * p.K + 2 * p.K) + (2 * p.K + 1) * ks + (p.K + 1) * ks + 2 * p.K * ks + p.K * ks + 6 * ks) * (int)sizeof(double);
+  return std::max(std::max(spike, sep), p.lds);
+}
+static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double sign, double* xo) {
+  NdArgs A;
+  A.n = p.n; A.k = p.k;
+  A.HA = c->HA + p.qq0; A.HB = c->HB + p.qq0; A.HC = c->HC + p.qq0;
+  A.b = b + (size_t)p.r0 * p.k; A.rhs_sign = sign; A.x = xo + (size_t)p.r0 * p.k;
+  A.Ust = c->Ust; A.Hst = c->Hst; A.Est = c->Est; A.Dst = c->Dst;
+  // separator in the middle; in each half the joiner chain (next to the separator) gets the extra row
+  A.s = (p.n - 2) / 2;
+  const int htop = A.s, hbot = p.n - A.s - 2;
+  A.j1 = (htop - 2) / 2;                          // producer P0: rows 0 .. j1-1
+  A.j2 = p.n - (hbot - 2) / 2 - 2;                // producer P3: rows j2+2 .. n-1
+  const int nloc_max = std::max(A.s - A.j1, A.j2 - A.s);
+  if (nloc_max > ND_MAXROWS) { g_err = "horizon too long for the nested-dissection solver's row tables"; return -1; }
+  const int lds = NdLds(c, p, nloc_max);
+  if (lds > 160 * 1024) { g_err = "nested-dissection solver: LDS carve-up too large"; return -1; }
+  A.xch = c->xch; A.xch_pair = (int)c->xch_count; A.flags = c->flags;
+  A.rowcnt = c->nd_rowcnt; A.ndbuf = c->nd_buf;
+  ++c->nd_launches;
+  c->last_solver = 2;
+  {  // I/O wavefronts of a chain workgroup (penta_ldl_body: NW = 4, one elimination wavefront, three helpers)
+    const int nhelp = 4 - p.gj_waves, io_first = (nhelp > 2) ? p.gj_waves + 1 : p.gj_waves;
+    A.rowtarget = c->nd_launches * (unsigned long long)(4 - io_first);
+  }
+  ++c->epoch;
+  if (++c->fact_id == 0) c->fact_id = 1;
+  A.epoch = c->epoch; A.status = c->status_dev; A.fact_id = c->fact_id; A.pstride = c->pstride;
+  A.ts = c->solver_debug ? c->dbg : nullptr;
+  const dim3 grid(7, c->batch);
+#define ND_LAUNCH(KM, PD) hipLaunchKernelGGL((penta_nd_kernel<KM, PD>), grid, dim3(256), lds, c->stream, A)
+  switch (p.K) {
+    case 2: ND_LAUNCH(2, false); break;
+    case 3: ND_LAUNCH(3, false); break;
+    case 5: ND_LAUNCH(5, false); break;
+    default: ND_LAUNCH(19, false); break;
+  }
+#undef ND_LAUNCH
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, double* xo, bool one_sided = false, bool allow_nd = false) {
   LdlPlan p;
   if (int rc = PlanLdl(c, one_sided, &p)) return rc;
+  if (allow_nd && !one_sided && NdEligible(c, p)) return LaunchNd(c, p, b, sign, xo);
   const int n = p.n, k = p.k, m_split = p.m_split, lds = p.lds, nrhs = 1;
   const size_t qq0 = p.qq0;
   b += (size_t)p.r0 * k;
   xo += (size_t)p.r0 * k;
   double* dbg = c->solver_debug ? c->dbg : nullptr;
   const dim3 grid(m_split > 0 ? 2 : 1, c->batch);
+  c->last_solver = 1;
   if (m_split > 0) ++c->epoch;  // (exchange buffer and flags live in the problem's arena)
   if (++c->fact_id == 0) c->fact_id = 1;  // (0 is the initial value of the status word)
 #define LDL_ARGS n, k, c->HA + qq0, c->HB + qq0, c->HC + qq0, b, sign, nrhs, xo, c->Ust, c->Hst, c->Est, c->Dst, dbg, \
@@ -845,6 +913,11 @@ static int FusedVariant(const idto_hip_ctx* c) {  // instantiated (MAXC, K) comb
   return 0;
 }
 static bool FusedEligible(const idto_hip_ctx* c) {
+  {  // the nested-dissection solver is its own launch (seven workgroups): the three-launch path takes it
+    LdlPlan p;
+    idto_hip_ctx* cc = const_cast<idto_hip_ctx*>(c);
+    if (PlanLdl(cc, false, &p) == 0 && NdEligible(c, p)) return false;
+  }
   return c->fused && c->batch == 1 && c->weights_diagonal && !c->reference_solver && !c->solver_debug && c->fd_stop == 0 &&
          c->asm_stop == 0 && c->k_begin == 0 && c->k_end == c->N && c->N >= 2 && FusedVariant(c) != 0;
 }
@@ -911,6 +984,7 @@ int idto_hip_factor_solve(idto_hip_ctx* c, const double* rhs, int nrhs, double* 
   if (rhs && c->batch != 1) { g_err = "explicit right-hand sides serve single-problem contexts"; return -1; }
   if (TimeBegin(c, 2)) return -2;
   if (c->reference_solver) {
+    c->last_solver = 3;
     if (++c->fact_id == 0) c->fact_id = 1;
     hipLaunchKernelGGL(penta_kernel, dim3(1, c->batch), dim3(256), c->penta_lds, c->stream, n, k, c->HA, c->HB, c->HC, b,
                        rhs ? 1.0 : -1.0, xo, c->Kst, c->LUst, c->pivst, c->Yst, c->Zst, c->status_dev, c->fact_id,
@@ -927,7 +1001,7 @@ int idto_hip_factor_solve(idto_hip_ctx* c, const double* rhs, int nrhs, double* 
   // block LDL^T: factorise once with the first right-hand side (two-sided when the horizon is
   // long enough; the substitution kernel walks both chains of factors) ...
   const int K = (k == 2 || k == 3 || k == 5 || k == 19 || k == 23) ? k : (k <= 8 ? 8 : k <= 16 ? 16 : k <= 24 ? 24 : 32);
-  int rc = LaunchLdl(c, b, rhs ? 1.0 : -1.0, xo);
+  int rc = LaunchLdl(c, b, rhs ? 1.0 : -1.0, xo, false, /*allow_nd=*/nrhs == 1);
   const int r0 = SolverFirstRow(c), ns = n - r0;                      // the sub-system LaunchLdl factorised
   const int m_split = (c->two_sided && ns >= 10) ? (ns - 1) / 2 : 0;  // as LaunchLdl chose
   if (r0 && rhs)  // x_0 = rhs_0 for every column (row 0 of H is the identity); the default rhs has g_0 = 0 = x_0
@@ -1347,11 +1421,23 @@ int idto_hip_gn_step_multi(idto_hip_ctx** ctxs, int n) {
   return 0;
 }
 
+int idto_hip_get_option(idto_hip_ctx* c, const char* name, int* value) {
+  if (std::strcmp(name, "last_solver") == 0) { *value = c->last_solver; return 0; }
+  if (std::strcmp(name, "solver_nd") == 0) { *value = c->solver_nd; return 0; }
+  if (std::strcmp(name, "fused") == 0) { *value = c->fused; return 0; }
+  if (std::strcmp(name, "two_sided") == 0) { *value = c->two_sided; return 0; }
+  if (std::strcmp(name, "reference_solver") == 0) { *value = c->reference_solver; return 0; }
+  if (std::strcmp(name, "gradients_method") == 0) { *value = c->gradients_method; return 0; }
+  g_err = std::string("unknown option ") + name;
+  return -1;
+}
+
 int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "reference_solver") == 0) { c->reference_solver = value != 0; return 0; }
   if (std::strcmp(name, "solver_debug") == 0) { c->solver_debug = value != 0; return 0; }
   if (std::strcmp(name, "two_sided") == 0) { c->two_sided = value != 0; return 0; }
   if (std::strcmp(name, "fused") == 0) { c->fused = value != 0; return 0; }
+  if (std::strcmp(name, "solver_nd") == 0) { c->solver_nd = value != 0; return 0; }
   if (std::strcmp(name, "fused_debug") == 0) { c->fused_debug = value != 0; return 0; }
   if (std::strcmp(name, "asm_stop") == 0) { c->asm_stop = value; return 0; }  // profiling aid
   if (std::strcmp(name, "fd_stop") == 0) { c->fd_stop = value; return 0; }    // profiling aid

@@ -185,7 +185,11 @@ struct ChainCfg {
   double* rtpub;                    // [local row][K]
   const double* corr;               // [local row][K]
   unsigned* corrflag;
+  double* ts;                       // optional wall-clock stamps (100 MHz): start, join reached, forward done, backward start, end
 };
+__device__ __forceinline__ void chain_ts(const ChainCfg& cfg, int slot) {
+  if (cfg.ts && threadIdx.x == 0) cfg.ts[slot] = (double)wall_clock64();
+}
 
 // K = compile-time block size >= k; the k x k blocks are embedded in K x K ones padded with
 // the identity (padding rows/columns never mix with the real ones).
@@ -226,6 +230,7 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
       dbg[((cfg.dbg_slot * (NT / 64) + wave) * (n + 3) + i) * 8 + ph] = (double)__builtin_readcyclecounter();
   };
 
+  chain_ts(cfg, 0);
   // ---- setup
   for (int idx = tid; idx < L.bl; idx += nt) lds[idx] = 0.0;
   for (int idx = L.xall + tid; idx < L.end; idx += nt) lds[idx] = 0.0;
@@ -516,11 +521,13 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
     if (two && !producer && i >= m_split) {
       // ---- join: add the other workgroup's Schur-complement contributions to [S | H | . | y]
       if (i == m_split) {
+        chain_ts(cfg, 1);
         if (tid == 0)
           while (__hip_atomic_load(flags, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch)
             __builtin_amdgcn_s_sleep(2);
         __syncthreads();
         (void)__hip_atomic_load(flags, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);  // every wavefront acquires
+        chain_ts(cfg, 5);
       }
       const int wsz = (K + ncr) * ks;
       const double* X0 = xch;         // pseudo-row 0: contributions to row m+1 (and the (m+1, m) coupling)
@@ -695,6 +702,7 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
     __hip_atomic_fetch_add(cfg.rowcnt + (nloc - 1), cfg.rowcnt_unit * nio, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
   stamp(nfwd, 0);
+  chain_ts(cfg, 2);
   if (cfg.corr) {
     // nested dissection: this chain's rows also couple to the separator; its solution times the
     // eliminated coupling blocks (F_il x_sep, computed by the spike workgroup) leaves rt
@@ -708,6 +716,7 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
     }
     __syncthreads();
   }
+  chain_ts(cfg, 3);
 
   // ---- backward pass: (D_i^-1 U_i) x_i = D_i^-1 rt_i - (D_i^-1 Ht_i) x_{i+1} - (D_i^-1 Et_i) x_{i+2}
   // One wavefront per right-hand side, no LDS staging and no barrier: lane = row r (+32 for the
@@ -897,6 +906,7 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
     }
   }
   stamp(nfwd, 1);
+  chain_ts(cfg, 4);
 }
 
 // the two roles of the two-workgroup kernel (m_split = 0: one workgroup, the whole system)

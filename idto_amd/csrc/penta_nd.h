@@ -1,0 +1,532 @@
+// penta_nd.h — nested-dissection form of the block LDL^T factor + solve (penta_ldl.h): the
+// dependent chain of the two-workgroup kernel (n/2 block rows forward, n/2 backward) is cut again.
+//
+//   rows:  0 ........ j1-1 | j1 j1+1 | j1+2 ........ s-1 | s s+1 | s+2 ........ j2-1 | j2 j2+1 | j2+2 ........ n-1
+//          chain P0 (down)    join 1    chain J1 (up)      separator  chain J2 (down)    join 2    chain P3 (up)
+//
+// Four workgroups run the row recursion of penta_ldl_body concurrently: P0 / P3 are "producers"
+// (plain ends of the matrix, they finish with two product-only pseudo-rows = their Schur
+// contributions to the join rows), J1 / J2 are "joiners" (they start next to the separator, add the
+// producer's contributions and eliminate the two join rows) - exactly the two roles of the
+// two-workgroup kernel, twice.  What is new is the coupling of J1 / J2 to the separator rows s, s+1:
+// eliminating a chain that is coupled to rows outside of it fills the coupling blocks
+//   F_il = [ H(row il, sep row nearest) | H(row il, sep row farthest) ]            (K x 2K, nonzero for il = 0, 1)
+//   Ft_il = L_il^-1 ( F_il - (D^-1 Ht_{il-1})^T Ft_{il-1} - (D^-1 Et_{il-2})^T Ft_{il-2} )
+// which behave like 2K more right-hand sides.  They are NOT carried by the chain workgroups (their
+// row time would grow by half): a "spike" workgroup per joiner trails it by one block row, reading
+// each row's factors from HBM when the joiner's I/O wavefronts have released them (per-row counter),
+// keeps every Ft_il in LDS, accumulates  Q = sum_il Ft_il^T Dn_il Ft_il  and  qy = sum_il Ft_il^T Dn_il rt_il
+// on the matrix cores, and hands both to the separator workgroup, which eliminates
+//   [ C_s - Q..   B_{s+1}^T - Q.. ] [x_s    ]   [ r_s     - qy.. ]
+//   [ .           C_{s+1} - Q..   ] [x_{s+1}] = [ r_{s+1} - qy.. ]
+// solves it and publishes x_s, x_{s+1}.  The spike workgroups then form F_il^T-side corrections
+// Ft_il [x_sep] for all their rows at once; the joiners subtract them from rt and run the usual back
+// substitution (join rows first, handing x_join to the producers).
+// Dependent chain for n = 40, K = 19: 9 + 2 rows, one trailing spike row, the separator (2 rows) and
+// 2 + 9 rows back, instead of 20 + 2 and 22.
+#pragma once
+
+#include "penta_ldl.h"
+
+namespace idto_dev {
+
+enum { ND_MAXROWS = 32 };  // local rows of a joiner chain (incl. its two join rows)
+
+struct NdArgs {
+  int n, k;
+  const double* HA; const double* HB; const double* HC; const double* b;
+  double rhs_sign;
+  double* x;
+  double* Ust; double* Hst; double* Est; double* Dst;
+  int s, j1, j2;                 // separator rows s, s+1; join rows j1, j1+1 and j2, j2+1
+  double* xch; int xch_pair;     // two producer/joiner exchange buffers (layout of the two-workgroup kernel)
+  unsigned* flags;               // [0..1] pair P0/J1, [2..3] pair P3/J2, [4] separator solved,
+                                 // [5 + w] Q of spike workgroup w published, [7 + w] its corrections published
+  unsigned long long* rowcnt;    // [2][ND_MAXROWS]: released I/O wavefronts per local row of J1 / J2
+  unsigned long long rowtarget;  // value a row's counter reaches in this launch
+  double* ndbuf;                 // see nd_layout
+  unsigned epoch;
+  unsigned* status; unsigned fact_id;
+  size_t pstride;
+  double* ts;                    // option "solver_debug": [7 roles][64] wall-clock stamps (100 MHz)
+};
+__device__ __forceinline__ void nd_ts(const NdArgs& A, int role, int slot) {
+  if (A.ts && threadIdx.x == 0) A.ts[role * 64 + slot] = (double)wall_clock64();
+}
+
+struct NdBuf { int rtpub, corr, Q, xsep, end; };  // offsets in doubles; rtpub / corr / Q are [2][...]
+__host__ __device__ inline NdBuf nd_layout(int K) {
+  NdBuf L;
+  int o = 0;
+  L.rtpub = o; o += 2 * ND_MAXROWS * K;
+  L.corr = o; o += 2 * ND_MAXROWS * K;
+  L.Q = o; o += 2 * (4 * K * K + 2 * K);
+  L.xsep = o; o += 2 * K;
+  L.end = o;
+  return L;
+}
+
+// tile t of the lower triangle of a tile grid, row by row: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) ...
+__host__ __device__ constexpr int nd_tile_row(int t) { int tr = 0; while (t > tr) { t -= tr + 1; ++tr; } return tr; }
+__host__ __device__ constexpr int nd_tile_col(int t) { int tr = 0; while (t > tr) { t -= tr + 1; ++tr; } return t; }
+
+__device__ __forceinline__ void nd_wait(const unsigned* f, unsigned epoch) {
+  if (threadIdx.x == 0)
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
+  __syncthreads();
+  (void)__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void nd_post(unsigned* f, unsigned epoch) {
+  __syncthreads();   // every wavefront's global stores precede thread 0's release
+  if (threadIdx.x == 0) __hip_atomic_store(f, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- spike workgroup of joiner `w` (0: J1, mirrored, starts at row s-1; 1: J2, starts at row s+2)
+template <int K, bool PADDED>
+__device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
+  extern __shared__ double lds[];
+  constexpr int ks = ldl_ks(K), SK = (K + 3) / 4, TT = (K + 15) / 16, NF = 2 * K, CT = (NF + 15) / 16, KP = 4 * SK;
+  using d4 = __attribute__((ext_vector_type(4))) double;
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
+  const int k = A.k, kk = k * k, n = A.n;
+  const bool mirror = (w == 0);
+  const int base = mirror ? A.s - 1 : A.s + 2;
+  const int nloc = mirror ? A.s - A.j1 : A.j2 + 2 - (A.s + 2);   // chain rows + the two join rows
+  auto orig = [&](int il) { return mirror ? base - il : base + il; };
+  const NdBuf B = nd_layout(K);
+  const unsigned long long* rowcnt = A.rowcnt + w * ND_MAXROWS;
+  const double* rtpub = A.ndbuf + B.rtpub + (size_t)w * ND_MAXROWS * K;
+  double* corr = A.ndbuf + B.corr + (size_t)w * ND_MAXROWS * K;
+  double* Qout = A.ndbuf + B.Q + (size_t)w * (4 * K * K + 2 * K);
+  // LDS (doubles)
+  constexpr int FB = NF * ks;             // one Ft block: NF columns of K rows, stride ks
+  double* Ft = lds;                       // [nloc][FB]   (+ one zero block in front for il - 1, il - 2 < 0)
+  double* Ul = Ft + (size_t)(nloc + 2) * FB;   // [KP][ks] row-major D^-1 U_il (strict upper), zero pad rows
+  double* Hl = Ul + KP * ks;              // D^-1 Ht_{il-1}
+  double* El = Hl + KP * ks;              // D^-1 Et_{il-2}
+  double* Fi = El + KP * ks;              // [3][K*K] initial coupling blocks, column-major
+  double* dn = Fi + 3 * K * K;            // [2][ks] 1/d of rows il, il-1
+  double* rt = dn + 2 * ks;               // [2][ks]
+  double* xs = rt + 2 * ks;               // [NF] separator solution in this chain's column order
+  // rows -2, -1 (zero) precede row 0 in Ft
+  auto Ftrow = [&](int il) { return Ft + (size_t)(il + 2) * FB; };
+  for (int idx = tid; idx < (nloc + 2) * FB + 3 * KP * ks; idx += nt) lds[idx] = 0.0;
+  // initial coupling blocks (rows il = 0, 1 of the chain to the separator rows -1, -2 in its own orientation):
+  //   Fi[0] = coupling(row 0, row -1), Fi[1] = coupling(row 0, row -2), Fi[2] = coupling(row 1, row -1)
+  for (int idx = tid; idx < 3 * K * K; idx += nt) {
+    const int blk = idx / (K * K), e = idx - blk * K * K, c = e / K, r = e - c * K;
+    double val = 0.0;
+    if (r < k && c < k) {
+      if (!mirror) {   // rows base, base+1; separator rows base-1 (near), base-2 (far): B_base, A_base, A_{base+1} as stored
+        const double* src = (blk == 0) ? A.HB + (size_t)base * kk : (blk == 1) ? A.HA + (size_t)base * kk : A.HA + (size_t)(base + 1) * kk;
+        val = src[c * k + r];
+      } else {         // rows base, base-1; separator rows base+1, base+2: B_{base+1}^T, A_{base+2}^T, A_{base+1}^T
+        const double* src = (blk == 0) ? A.HB + (size_t)(base + 1) * kk : (blk == 1) ? A.HA + (size_t)(base + 2) * kk : A.HA + (size_t)(base + 1) * kk;
+        val = src[r * k + c];
+      }
+    }
+    Fi[idx] = val;
+  }
+  __syncthreads();
+
+  nd_ts(A, 4 + w, 0);
+  const int fl = lane & 15, fk = lane >> 4;
+  // Q tiles (lower triangle of the CT x CT tile grid) live in the registers of wavefronts 1..3
+  // tile list: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) -> wave 1 + (t % 3)
+  constexpr int NQT = CT * (CT + 1) / 2;
+  d4 qacc[(NQT + 2) / 3];
+#pragma unroll
+  for (int t = 0; t < (NQT + 2) / 3; ++t) qacc[t] = d4{0.0, 0.0, 0.0, 0.0};
+  double qy = 0.0;   // wave 3, lane c < NF: (Ft^T Dn rt)[c]
+
+  auto q_accumulate = [&](int il) {   // Q += Ft_il^T Dn_il Ft_il ; qy += Ft_il^T Dn_il rt_il
+    const double* F = Ftrow(il);
+    const double* dnl = dn + (il & 1) * ks;
+    const double* rtl = rt + (il & 1) * ks;
+    if (wave >= 1) {
+#pragma unroll
+      for (int t = 0; t < NQT; ++t) {   // (tile t belongs to wavefront 1 + t % 3, its accumulator is slot t / 3)
+        if (t % 3 != wave - 1) continue;
+        const int tr = nd_tile_row(t), tc = nd_tile_col(t);
+#pragma unroll
+        for (int sq = 0; sq < SK; ++sq) {
+          const double a = F[(16 * tr + fl) * ks + 4 * sq + fk];
+          const double bq = F[(16 * tc + fl) * ks + 4 * sq + fk] * dnl[4 * sq + fk];
+          qacc[t / 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, qacc[t / 3], 0, 0, 0);
+        }
+      }
+    }
+    if (wave == 3 && lane < NF) {   // (the wavefront with the fewest tiles; wavefront 0 runs the substitution)
+      double acc = 0.0;
+#pragma unroll
+      for (int r = 0; r < K; ++r) acc = __builtin_fma(F[lane * ks + r], dnl[r] * rtl[r], acc);
+      qy += acc;
+    }
+  };
+
+  // Factors of row il+1 are fetched into registers while row il is processed (the loads of a row
+  // cost ~2.5 us exposed, which alone would make this workgroup slower than the chain it follows).
+  constexpr int BLK = K * ks, PM = (3 * BLK + 255) / 256;
+  double pre[PM], pdn = 0.0, prt = 0.0;
+  auto row_ready = [&](int il) {   // uniform: every thread loads the same counter
+    return __hip_atomic_load(rowcnt + il, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= A.rowtarget;
+  };
+  auto issue = [&](int il) {       // (after an acquire on row il's counter)
+    const double* Ug = A.Ust + (size_t)orig(il) * BLK;
+    const double* Hg = A.Hst + (size_t)orig(il >= 1 ? il - 1 : 0) * BLK;
+    const double* Eg = A.Est + (size_t)orig(il >= 2 ? il - 2 : 0) * BLK;
+#pragma unroll
+    for (int sl = 0; sl < PM; ++sl) {
+      const int idx = tid + sl * 256, blk = idx / BLK, e = idx - blk * BLK;
+      double v = 0.0;
+      if (blk == 0) v = Ug[e];
+      else if (blk == 1) { if (il >= 1) v = Hg[e]; }
+      else if (blk == 2) { if (il >= 2) v = Eg[e]; }
+      pre[sl] = v;
+    }
+    if (tid < ks) {
+      pdn = (tid < K) ? A.Dst[(size_t)orig(il) * K + tid] : 0.0;
+      prt = (tid < K) ? rtpub[(size_t)il * K + tid] : 0.0;
+    }
+  };
+  auto commit = [&](int il) {      // registers -> LDS (Ul, Hl, El are KP * ks apart)
+#pragma unroll
+    for (int sl = 0; sl < PM; ++sl) {
+      const int idx = tid + sl * 256, blk = idx / BLK, e = idx - blk * BLK;
+      if (blk < 3) Ul[blk * KP * ks + e] = pre[sl];
+    }
+    if (tid < ks) { dn[(il & 1) * ks + tid] = pdn; rt[(il & 1) * ks + tid] = prt; }
+  };
+  // (per wavefront, no workgroup barrier: the wavefronts decide independently whether they could
+  // prefetch a row, so nothing here may assume that the others take the same path)
+  auto wait_row = [&](int il) {
+    while (!row_ready(il)) __builtin_amdgcn_s_sleep(1);
+    (void)__hip_atomic_load(rowcnt + il, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  wait_row(0);
+  issue(0);
+  for (int il = 0; il < nloc; ++il) {
+    nd_ts(A, 4 + w, 8 + 2 * il);
+    commit(il);
+    __syncthreads();
+    // readiness of the next row: a round trip to L2, issued now, consumed after the products
+    const unsigned long long next_cnt =
+        (il + 1 < nloc) ? __hip_atomic_load(rowcnt + il + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    if (il == 5) nd_ts(A, 4 + w, 40);
+    // ---- F_il = Finit - (D^-1 Ht_{il-1})^T Ft_{il-1} - (D^-1 Et_{il-2})^T Ft_{il-2}: TT x CT tiles
+    {
+      const double* F1 = Ftrow(il - 1);
+      const double* F2 = Ftrow(il - 2);
+      double* Fo = Ftrow(il);
+      for (int t = wave; t < TT * CT; t += nt / 64) {
+        const int tr = t / CT, tc = t - tr * CT;
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int sq = 0; sq < SK; ++sq) {
+          const int kr = 4 * sq + fk;   // summation index: row of Ht / Et and of Ft
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Hl[kr * ks + 16 * tr + fl], F1[(16 * tc + fl) * ks + kr], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(El[kr * ks + 16 * tr + fl], F2[(16 * tc + fl) * ks + kr], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int r = 16 * tr + fk + 4 * rg, c = 16 * tc + fl;
+          if (r < K && c < NF) {
+            double init = 0.0;
+            if (il == 0) init = Fi[(c < K ? 0 : 1) * K * K + (c < K ? c : c - K) * K + r];
+            else if (il == 1 && c < K) init = Fi[2 * K * K + c * K + r];
+            Fo[c * ks + r] = init - acc[rg];
+          }
+        }
+      }
+    }
+    // (the readiness check is a round trip to L2: its result is consumed only here, after the products)
+    bool prefetched = false;
+    if (il + 1 < nloc && next_cnt >= A.rowtarget) {
+      (void)__hip_atomic_load(rowcnt + il + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      issue(il + 1);
+      prefetched = true;
+    }
+    __syncthreads();
+    if (il == 5) nd_ts(A, 4 + w, 41);
+    // ---- Ft_il = L_il^-1 F_il (L^T = D^-1 U, unit): lane = column, rows in registers, the
+    // multipliers are LDS broadcasts; meanwhile the other wavefronts fold row il-1 into Q
+    if (wave == 0) {
+      if (lane < NF) {
+        double* col = Ftrow(il) + lane * ks;
+        double xr[K];
+#pragma unroll
+        for (int r = 0; r < K; ++r) xr[r] = col[r];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {   // multipliers: row j of D^-1 U, two per LDS read (ks is even)
+          const double2* u2 = reinterpret_cast<const double2*>(Ul + j * ks);
+#pragma unroll
+          for (int r2 = (j + 1) / 2; r2 < (K + 1) / 2; ++r2) {
+            const double2 m = u2[r2];
+            if (2 * r2 > j) xr[2 * r2] = __builtin_fma(-m.x, xr[j], xr[2 * r2]);
+            if (2 * r2 + 1 < K) xr[2 * r2 + 1] = __builtin_fma(-m.y, xr[j], xr[2 * r2 + 1]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < K; ++r) col[r] = xr[r];
+      }
+      if (il == 5) nd_ts(A, 4 + w, 42);
+    } else if (il >= 1) {
+      q_accumulate(il - 1);
+    }
+    __syncthreads();
+    nd_ts(A, 4 + w, 9 + 2 * il);
+    if (il + 1 < nloc && !prefetched) { wait_row(il + 1); issue(il + 1); }
+  }
+  q_accumulate(nloc - 1);
+  // ---- publish Q (dense NF x NF, both triangles) and qy
+  if (wave >= 1) {
+#pragma unroll
+    for (int t = 0; t < NQT; ++t) {
+      if (t % 3 != wave - 1) continue;
+      const int tr = nd_tile_row(t), tc = nd_tile_col(t);
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int r = 16 * tr + fk + 4 * rg, c = 16 * tc + fl;
+        if (r < NF && c < NF) { Qout[c * NF + r] = qacc[t / 3][rg]; Qout[r * NF + c] = qacc[t / 3][rg]; }
+      }
+    }
+  }
+  if (wave == 3 && lane < NF) Qout[NF * NF + lane] = qy;
+  nd_post(A.flags + 5 + w, A.epoch);
+  nd_ts(A, 4 + w, 1);
+  // ---- corrections Ft_il x_sep for every row, once the separator is solved
+  nd_wait(A.flags + 4, A.epoch);
+  nd_ts(A, 4 + w, 2);
+  {
+    const double* xsep = A.ndbuf + B.xsep;   // [x_s | x_{s+1}]
+    for (int c = tid; c < NF; c += nt) {
+      const int half = c / K, r = c - half * K;             // column block 0: nearest separator row, 1: farthest
+      const int which = mirror ? half : 1 - half;           // mirrored chain: nearest = s; other: nearest = s+1
+      xs[c] = xsep[which * K + r];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < nloc * K; idx += nt) {
+      const int il = idx / K, r = idx - il * K;
+      const double* F = Ftrow(il);
+      double acc = 0.0;
+      for (int c = 0; c < NF; ++c) acc = __builtin_fma(F[c * ks + r], xs[c], acc);
+      corr[idx] = acc;
+    }
+  }
+  nd_post(A.flags + 7 + w, A.epoch);
+  nd_ts(A, 4 + w, 3);
+}
+
+// ---- separator workgroup
+template <int K, bool PADDED>
+__device__ __forceinline__ void nd_separator(const NdArgs& A) {
+  extern __shared__ double lds[];
+  constexpr int ks = ldl_ks(K), NF = 2 * K, QS = 4 * K * K + 2 * K;
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
+  const int k = A.k, kk = k * k, s = A.s;
+  const NdBuf B = nd_layout(K);
+  double* Q = lds;                   // [2][QS]
+  double* W = Q + 2 * QS;            // [2K + 1][ks] columns [S | H | y]
+  double* S1 = W + (2 * K + 1) * ks; // [K + 1][ks] second row: [S' | y']
+  double* Us = S1 + (K + 1) * ks;    // [2][K][ks] U columns of both rows
+  double* Ht = Us + 2 * K * ks;      // [K][ks]
+  double* rtv = Ht + K * ks;         // [2][ks]
+  double* dnv = rtv + 2 * ks;        // [2][ks]
+  double* xv = dnv + 2 * ks;         // [2][ks] x_s, x_{s+1}
+  nd_ts(A, 6, 0);
+  // band blocks and right-hand sides of the separator rows first (no dependence on the chains)
+  for (int idx = tid; idx < K * K; idx += nt) {
+    const int c = idx / K, r = idx - c * K;
+    const bool in = !PADDED || (r < k && c < k);
+    W[c * ks + r] = in ? A.HC[(size_t)s * kk + c * k + r] : (r == c ? 1.0 : 0.0);
+    W[(K + c) * ks + r] = in ? A.HB[(size_t)(s + 1) * kk + r * k + c] : 0.0;   // block (s, s+1) = B_{s+1}^T
+    S1[c * ks + r] = in ? A.HC[(size_t)(s + 1) * kk + c * k + r] : (r == c ? 1.0 : 0.0);
+  }
+  for (int r = tid; r < K; r += nt) {
+    W[2 * K * ks + r] = (r < k) ? A.rhs_sign * A.b[(size_t)s * k + r] : 0.0;
+    S1[K * ks + r] = (r < k) ? A.rhs_sign * A.b[(size_t)(s + 1) * k + r] : 0.0;
+  }
+  nd_wait(A.flags + 5, A.epoch);
+  nd_wait(A.flags + 6, A.epoch);
+  nd_ts(A, 6, 1);
+  for (int idx = tid; idx < 2 * QS; idx += nt) Q[idx] = A.ndbuf[B.Q + idx];
+  __syncthreads();
+  // column blocks of the two spike workgroups: w = 0 (mirrored chain J1): nearest = s (offset 0), farthest = s+1
+  // (offset K); w = 1 (chain J2): nearest = s+1, farthest = s
+  auto qs = [&](int w, int rowsel, int colsel, int r, int c) {   // rowsel / colsel: 0 -> block of row s, 1 -> of s+1
+    const int ro = (w == 0 ? rowsel : 1 - rowsel) * K, co = (w == 0 ? colsel : 1 - colsel) * K;
+    return Q[w * QS + (co + c) * NF + ro + r];
+  };
+  auto qyv = [&](int w, int rowsel, int r) { return Q[w * QS + NF * NF + (w == 0 ? rowsel : 1 - rowsel) * K + r]; };
+  for (int idx = tid; idx < K * K; idx += nt) {
+    const int c = idx / K, r = idx - c * K;
+    W[c * ks + r] = (W[c * ks + r] - qs(0, 0, 0, r, c)) - qs(1, 0, 0, r, c);
+    W[(K + c) * ks + r] = (W[(K + c) * ks + r] - qs(0, 0, 1, r, c)) - qs(1, 0, 1, r, c);
+    S1[c * ks + r] = (S1[c * ks + r] - qs(0, 1, 1, r, c)) - qs(1, 1, 1, r, c);
+  }
+  for (int r = tid; r < K; r += nt) {
+    W[2 * K * ks + r] = (W[2 * K * ks + r] - qyv(0, 0, r)) - qyv(1, 0, r);
+    S1[K * ks + r] = (S1[K * ks + r] - qyv(0, 1, r)) - qyv(1, 1, r);
+  }
+  __syncthreads();
+  nd_ts(A, 6, 3);
+  bool bad = false;
+  // ---- row s: [S | H | y] in the registers of wavefront 0
+  if (wave == 0) {
+    const int col = (lane < 2 * K + 1) ? lane : 0;
+    double xr[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) xr[r] = W[col * ks + r];
+    const double diag0 = (lane < K) ? W[lane * ks + lane] : 1.0;
+    double yacc;
+    const double myinv = ldl_eliminate_wave<K, false>(xr, lane, yacc);
+    bad = bad || (lane < K && !(myinv > 0.0 && myinv * diag0 < 4503599627370496.0));
+    if (lane < K) {
+#pragma unroll
+      for (int r = 0; r < K; ++r) Us[lane * ks + r] = xr[r];
+      dnv[lane] = myinv;
+    } else if (lane < 2 * K) {
+#pragma unroll
+      for (int r = 0; r < K; ++r) Ht[(lane - K) * ks + r] = xr[r];
+    } else if (lane == 2 * K) {
+#pragma unroll
+      for (int r = 0; r < K; ++r) rtv[r] = xr[r];
+    }
+  }
+  __syncthreads();
+  nd_ts(A, 6, 4);
+  // ---- row s+1: S' = S_{s+1} - Ht^T Dn Ht (matrix cores, lower tiles mirrored), y' = y_{s+1} - Ht^T Dn rt
+  {
+    using d4 = __attribute__((ext_vector_type(4))) double;
+    constexpr int SK = (K + 3) / 4, TT = (K + 15) / 16, NT2 = TT * (TT + 1) / 2;
+    const int fl = lane & 15, fk = lane >> 4;
+    if (wave < NT2) {
+      const int tr = nd_tile_row(wave), tc = nd_tile_col(wave);
+      d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int sq = 0; sq < SK; ++sq) {
+        const int kr = 4 * sq + fk;
+        const double dnk = (kr < K) ? dnv[kr] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ht[(16 * tr + fl) * ks + kr], Ht[(16 * tc + fl) * ks + kr] * dnk, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int r = 16 * tr + fk + 4 * rg, c = 16 * tc + fl;
+        if (r < K && c < K && r >= c) {
+          const double val = S1[c * ks + r] - acc[rg];
+          S1[c * ks + r] = val;
+          if (r != c) S1[r * ks + c] = val;
+        }
+      }
+    } else if (wave == NT2 && lane < K) {   // (TT = 2: three tiles on wavefronts 0..2, the right-hand side on wavefront 3)
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < K; ++j) acc = __builtin_fma(Ht[lane * ks + j] * dnv[j], rtv[j], acc);
+      S1[K * ks + lane] -= acc;
+    }
+    static_assert(NT2 <= 3, "separator: S' tiles are spread over three wavefronts");
+  }
+  __syncthreads();
+  nd_ts(A, 6, 5);
+  if (wave == 0) {
+    const int col = (lane < K + 1) ? lane : 0;
+    double xr[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) xr[r] = S1[col * ks + r];
+    const double diag0 = (lane < K) ? S1[lane * ks + lane] : 1.0;
+    double yacc;
+    const double myinv = ldl_eliminate_wave<K, false>(xr, lane, yacc);
+    bad = bad || (lane < K && !(myinv > 0.0 && myinv * diag0 < 4503599627370496.0));
+    if (lane < K) {
+#pragma unroll
+      for (int r = 0; r < K; ++r) Us[(K + lane) * ks + r] = xr[r];
+      dnv[ks + lane] = myinv;
+    } else if (lane == K) {
+#pragma unroll
+      for (int r = 0; r < K; ++r) rtv[ks + r] = xr[r];
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) {
+      __hip_atomic_store(A.status, A.fact_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_fetch_add(A.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  __syncthreads();
+  nd_ts(A, 6, 6);
+  // ---- back substitution (U = D L^T: x_r = rt_r / d_r - sum_{c > r} (U[r][c] / d_r) x_c), lane = row
+  if (wave == 0) {
+    const int r = (lane < K) ? lane : 0;
+    auto back = [&](int row, double v) {   // v: right-hand side already scaled by 1/d; returns x (lane r)
+      double u[K];   // row r of D^-1 U (strict upper part), fetched before the dependent chain starts
+#pragma unroll
+      for (int j = 0; j < K; ++j) u[j] = (r < j) ? Us[(row * K + j) * ks + r] * dnv[row * ks + r] : 0.0;
+#pragma unroll
+      for (int j = K - 1; j >= 0; --j) v = __builtin_fma(-u[j], rdlane(v, j), v);
+      return v;
+    };
+    const double x1 = back(1, rtv[ks + r] * dnv[ks + r]);        // x_{s+1}
+    double acc = 0.0;
+    {
+      double hrow[K];
+#pragma unroll
+      for (int c = 0; c < K; ++c) hrow[c] = Ht[c * ks + r];
+#pragma unroll
+      for (int c = 0; c < K; ++c) acc = __builtin_fma(hrow[c], rdlane(x1, c), acc);   // (Ht x_{s+1})[r]
+    }
+    const double x0 = back(0, (rtv[r] - acc) * dnv[r]);          // x_s
+    if (lane < K) {
+      double* xsep = A.ndbuf + B.xsep;
+      xsep[lane] = x0;
+      xsep[K + lane] = x1;
+      if (lane < k) { A.x[(size_t)s * k + lane] = x0; A.x[(size_t)(s + 1) * k + lane] = x1; }
+    }
+  }
+  nd_post(A.flags + 4, A.epoch);
+  nd_ts(A, 6, 2);
+}
+
+// grid (7, batch): blockIdx.x = role, blockIdx.y = problem of the batch
+//   0: P0 producer, rows 0 .. j1-1 top-down        1: P3 producer, rows n-1 .. j2+2 bottom-up
+//   2: J1 joiner, rows s-1 .. j1+2 then j1+1, j1   3: J2 joiner, rows s+2 .. j2-1 then j2, j2+1
+//   4, 5: spike workgroups of J1, J2               6: separator
+// (workgroups are dispatched in this order: every wait is on a lower index or on the partner two
+// places up, see fused.h for the forward-progress argument)
+template <int K, bool PADDED>
+__global__ void __launch_bounds__(256) penta_nd_kernel(NdArgs A) {
+  {
+    const size_t o = (size_t)blockIdx.y * A.pstride;
+    A.HA = at_problem(A.HA, o); A.HB = at_problem(A.HB, o); A.HC = at_problem(A.HC, o); A.b = at_problem(A.b, o);
+    A.x = at_problem(A.x, o); A.Ust = at_problem(A.Ust, o); A.Hst = at_problem(A.Hst, o); A.Est = at_problem(A.Est, o);
+    A.Dst = at_problem(A.Dst, o); A.xch = at_problem(A.xch, o); A.flags = at_problem(A.flags, o);
+    A.rowcnt = at_problem(A.rowcnt, o); A.ndbuf = at_problem(A.ndbuf, o);
+    A.status += 2 * blockIdx.y;
+  }
+  const int role = blockIdx.x;
+  if (role == 6) { nd_separator<K, PADDED>(A); return; }
+  if (role >= 4) { nd_spike<K, PADDED>(A, role - 4); return; }
+  const NdBuf B = nd_layout(K);
+  ChainCfg c = {};
+  c.two = 1;
+  c.dbg_slot = role;
+  c.ts = A.ts ? A.ts + role * 64 : nullptr;
+  int pair;
+  if (role == 0) { c.mirror = 0; c.producer = 1; c.base = 0; c.nloc = A.j1; pair = 0; }
+  else if (role == 1) { c.mirror = 1; c.producer = 1; c.base = A.n - 1; c.nloc = A.n - A.j2 - 2; pair = 1; }
+  else {
+    const int w = role - 2;
+    c.mirror = (w == 0); c.producer = 0;
+    c.base = (w == 0) ? A.s - 1 : A.s + 2;
+    c.m_split = (w == 0) ? A.s - A.j1 - 2 : A.j2 - A.s - 2;
+    c.nloc = c.m_split + 2;
+    pair = w;
+    c.rowcnt = A.rowcnt + w * ND_MAXROWS; c.rowcnt_unit = 1ull;
+    c.rtpub = A.ndbuf + B.rtpub + (size_t)w * ND_MAXROWS * K;
+    c.corr = A.ndbuf + B.corr + (size_t)w * ND_MAXROWS * K;
+    c.corrflag = A.flags + 7 + w;
+  }
+  constexpr int GW = ((2 * K + 1) + (64 - K) - 1) / (64 - K);
+  penta_ldl_body<K, 256, PADDED, GW>(A.n, A.k, A.HA, A.HB, A.HC, A.b, A.rhs_sign, 1, A.x, A.Ust, A.Hst, A.Est, A.Dst,
+                                     nullptr, c, A.xch + (size_t)pair * A.xch_pair, A.flags + 2 * pair, A.epoch, A.status,
+                                     A.fact_id);
+}
+
+}  // namespace idto_dev

@@ -84,6 +84,7 @@ def lib():
         L.idto_hip_constraint_step.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                                C.POINTER(C.c_double)]
         L.idto_hip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.idto_hip_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]
         L.idto_hip_timing_enable.argtypes = [C.c_void_p, C.c_int]
         L.idto_hip_timing_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.idto_hip_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
@@ -103,7 +104,7 @@ EXPORTED_SYMBOLS = [
     "idto_hip_get_stream", "idto_hip_set_shard", "idto_hip_set_q", "idto_hip_set_q_device", "idto_hip_eval_tau", "idto_hip_trial_cost", "idto_hip_constraint_schur",
     "idto_hip_constraint_schur_begin", "idto_hip_constraint_solve", "idto_hip_constraint_step", "idto_hip_prefetch",
     "idto_hip_eval_partials", "idto_hip_grad_hess", "idto_hip_factor_solve", "idto_hip_gn_step", "idto_hip_solve_host",
-    "idto_hip_set_option",
+    "idto_hip_set_option", "idto_hip_get_option",
     "idto_hip_timing_enable", "idto_hip_timing_reset", "idto_hip_timing_get", "idto_hip_sync", "idto_hip_get",
     "idto_hip_device_ptr", "idto_hip_array_size", "idto_hip_slab_stride", "idto_hip_math_probe",
     "idto_hip_solver_status", "idto_hip_create_batch", "idto_hip_batch_size", "idto_hip_set_problem_batch",
@@ -306,6 +307,11 @@ class HipPath:
 
     def set_option(self, name: str, value: int):
         _chk(lib().idto_hip_set_option(self.h, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int()
+        _chk(lib().idto_hip_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
 
     def gn_step(self):
         _chk(lib().idto_hip_gn_step(self.h))

@@ -228,9 +228,16 @@ int idto_hip_tr_reject(idto_hip_ctx* ctx);
  * horizon); "fused" = 0 makes idto_hip_gn_step three launches
  * (fd, assemble, solve) instead of one persistent launch whose workgroups take the three roles and
  * synchronise through device-memory counters (default 1; single-problem contexts with diagonal
- * weights and the reference's example models; csrc/fused.h); "solver_debug" = 1 records per-phase cycle stamps (IDTO_ARR 15, tools/solver_phases.py);
+ * weights and the reference's example models; csrc/fused.h); "solver_nd" = 0 keeps the single-right-hand-side solve on the
+ * two-workgroup kernel instead of the nested-dissection form (csrc/penta_nd.h: four chain workgroups,
+ * two spike workgroups and a separator; default 1, used for block sizes 2 / 3 / 5 / 19 and at least 24
+ * block rows; explicit multi-right-hand-side solves always use the two-workgroup factors);
+ * "solver_debug" = 1 records per-phase cycle stamps (IDTO_ARR 15, tools/solver_phases.py);
  * "asm_stop" truncates the assembly kernel after a phase (tools/asm_phases.py). */
 int idto_hip_set_option(idto_hip_ctx* ctx, const char* name, int value);
+/* Reads an option back; additionally "last_solver": which factorisation the last solve used
+ * (1 two-workgroup block LDL^T, 2 nested dissection over seven workgroups, 3 reference-order LU). */
+int idto_hip_get_option(idto_hip_ctx* ctx, const char* name, int* value);
 
 /* Device-side timing of the last `idto_hip_gn_step`-shaped launches: average
  * milliseconds per launch of kernel `which` (0 fd, 1 assemble, 2 factor_solve, 3 the fused

@@ -29,6 +29,8 @@ def test_fused_iteration_equals_three_launches(name, N):
     sp.equality_constraints = False
     fused, plain = hip.HipPath(model, prob, sp), hip.HipPath(model, prob, sp)
     plain.set_option("fused", 0)
+    for d in (fused, plain):   # (the nested-dissection solver is a launch of its own: tests/test_gpu_nd.py)
+        d.set_option("solver_nd", 0)
     for it in range(4):
         q = synthetic_trajectory(cfg, model, N, seed=it, lower=0.01)
         for d in (fused, plain):

@@ -1,0 +1,114 @@
+"""Nested-dissection form of the block LDL^T solver (csrc/penta_nd.h: two producer / joiner chain
+pairs around a separator, two spike workgroups carrying the chains' coupling to the separator)
+against (i) the two-workgroup form of the same factorisation, (ii) the bit-exact restatement of the
+reference's pivoted-LU block Thomas (optimizer/penta_diagonal_solver.h:124-248) and (iii) an
+extended-precision solution: same accuracy bar as tests/test_gpu_parity.py, repeated launches
+bit-identical (the workgroups synchronise through device-memory flags and counters), batches,
+failure reporting, and the reference's own penta-diagonal test matrix."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from idto_amd import hip
+from idto_amd.model import load_model
+from idto_amd.problem import load_config, make_problem, synthetic_trajectory
+from oracle_lib import Oracle
+from test_gpu_penta import DeviceSolver
+from test_oracle_penta import from_lower_dense
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(name, N, seed=0):
+    cfg, model = load_config(name), load_model(name)
+    prob, sp, _ = make_problem(cfg, model, num_steps=N)
+    sp.scaling = False
+    sp.equality_constraints = False
+    return cfg, model, prob, sp, synthetic_trajectory(cfg, model, N, seed=seed, lower=0.01)
+
+
+@pytest.mark.parametrize("name,N", [("mini_cheetah", 40), ("mini_cheetah", 24), ("mini_cheetah", 31), ("hopper", 50),
+                                    ("spinner", 40), ("acrobot", 40), ("acrobot", 63)])
+def test_nested_dissection_solver(name, N):
+    cfg, model, prob, sp, q = _setup(name, N)
+    dev = hip.HipPath(model, prob, sp)
+    dev.set_q(q)
+    dev.gn_step()
+    assert dev.get_option("last_solver") == 2, "the nested-dissection kernel was expected to take this size"
+    p_nd = dev.get("step")
+    for _ in range(3):   # flags / counters are epoch-valued: repeated launches must reproduce the bits
+        dev.factor_solve()
+        assert np.array_equal(dev.get("step"), p_nd)
+    assert dev.solver_status() == (False, 0)
+    dev.set_option("solver_nd", 0)
+    dev.factor_solve()
+    assert dev.get_option("last_solver") == 1
+    p_two = dev.get("step")
+    dev.set_option("reference_solver", 1)
+    dev.factor_solve()
+    p_lu = dev.get("step")
+    orc = Oracle(model, prob, sp)
+    g, bands = orc.grad_hess(q)
+    assert np.array_equal(dev.get("gradient"), g)
+    p_ref, unc = ol.refined_solution(ol.penta_make_dense(*bands), -g.ravel())
+    pn = np.abs(p_ref).max()
+    err = lambda x: np.abs(x.ravel() - p_ref).max() / pn
+    res = lambda x: np.abs(ol.penta_multiply(*bands, x) + g).max() / (np.abs(g).max() + 1e-300)
+    assert err(p_nd) <= 4 * err(p_lu) + 16 * unc + 1e-12, (err(p_nd), err(p_two), err(p_lu))
+    assert res(p_nd) <= 16 * res(p_lu) + 1e-13, (res(p_nd), res(p_lu))
+    dev.close()
+
+
+def test_reference_penta_diagonal_case_through_nd():
+    """penta_diagonal_solver_test.cc:188-257 (SPD block penta-diagonal system, known solution) at a
+    size the nested-dissection kernel takes (bands written into the context, explicit right-hand side)"""
+    bs, n = 2, 41
+    size = n * bs
+    rng = np.random.default_rng(6)
+    Ar = rng.uniform(-1, 1, (size, size))
+    H = from_lower_dense(np.eye(size) + Ar @ Ar.T, n, bs)
+    Hd = ol.penta_make_dense(*H)
+    s = DeviceSolver(bs, n)
+    s.set_bands(H[0], H[1], H[2])
+    x_gt = np.linspace(-3, 12.4, size)
+    x = s.solve(Hd @ x_gt)
+    assert s.dev.get_option("last_solver") == 2
+    assert np.linalg.norm(x - x_gt) / np.linalg.norm(x_gt) < 50 * np.linalg.cond(Hd) * np.finfo(float).eps
+    # many right-hand sides: the two-workgroup factors serve the substitution kernel
+    X = s.solve(np.stack([Hd @ x_gt, 2 * (Hd @ x_gt)]))
+    assert s.dev.get_option("last_solver") == 1
+    assert np.linalg.norm(X[1] - 2 * x_gt) / np.linalg.norm(x_gt) < 100 * np.linalg.cond(Hd) * np.finfo(float).eps
+
+
+def test_nd_in_a_batch_and_failure_report():
+    name, N, B = "mini_cheetah", 40, 3
+    cfg, model = load_config(name), load_model(name)
+    probs, qs = [], []
+    for b in range(B):
+        prob, sp, _ = make_problem(cfg, model, num_steps=N)
+        sp.scaling = False
+        sp.equality_constraints = False
+        prob.q_nom = prob.q_nom + 0.01 * b
+        probs.append(prob)
+        qs.append(synthetic_trajectory(cfg, model, N, seed=b, lower=0.01))
+    batch = hip.HipPath(model, probs, sp)
+    batch.set_q_batch(np.array(qs))
+    batch.gn_step()
+    assert batch.get_option("last_solver") == 2
+    for b in range(B):
+        one = hip.HipPath(model, probs[b], sp)
+        one.set_q(qs[b])
+        one.gn_step()
+        assert np.array_equal(batch.get("step", b), one.get("step"))
+        one.close()
+    # a singular Hessian in one problem of the batch: reported for that problem by whichever workgroup meets it
+    import copy
+    bad = copy.deepcopy(probs[1])
+    for W in (bad.Qq, bad.Qv, bad.Qf_q, bad.Qf_v):
+        W[7, :] = 0.0
+        W[:, 7] = 0.0
+    bad.R[:] = 0.0
+    batch.set_problem_batch(1, bad)
+    batch.gn_step()
+    assert batch.solver_status_batch() == [False, True, False]
+    batch.close()

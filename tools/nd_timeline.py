@@ -1,0 +1,32 @@
+"""Timeline of the nested-dissection solver (option "solver_debug"): wall-clock stamps per role (us)."""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import numpy as np
+from idto_amd import hip
+from idto_amd.model import load_model
+from idto_amd.problem import load_config, make_problem, synthetic_trajectory
+name, N = (sys.argv[1] if len(sys.argv) > 1 else "mini_cheetah"), int(sys.argv[2]) if len(sys.argv) > 2 else 40
+cfg, model = load_config(name), load_model(name)
+prob, sp, _ = make_problem(cfg, model, num_steps=N)
+sp.scaling = False; sp.equality_constraints = False
+dev = hip.HipPath(model, prob, sp)
+dev.set_q(synthetic_trajectory(cfg, model, N, seed=0, lower=0.01))
+for _ in range(5):
+    dev.gn_step()
+dev.set_option("solver_debug", 1)
+dev.factor_solve(); dev.factor_solve()
+d = dev.get("debug")[:7 * 64].reshape(7, 64) / 100.0
+t0 = d[:4, 0].min()
+names = ["P0 producer", "P3 producer", "J1 joiner", "J2 joiner", "spike J1", "spike J2", "separator"]
+for r in range(4):
+    x = d[r] - t0
+    print(f"{names[r]:12s} start {x[0]:6.2f}  join-wait-begin {x[1]:6.2f}  join-wait-end {x[5]:6.2f}  forward done {x[2]:6.2f}  backward start {x[3]:6.2f}  end {x[4]:6.2f}")
+for r in (4, 5):
+    x = d[r] - t0
+    rows = [(x[8 + 2 * i], x[9 + 2 * i]) for i in range(16) if d[r][8 + 2 * i] > 0]
+    print(f"{names[r]:12s} start {x[0]:6.2f}  Q posted {x[1]:6.2f}  x_sep seen {x[2]:6.2f}  corr posted {x[3]:6.2f}")
+    print("   rows (ready, done):", " ".join(f"({a:5.1f},{b:5.1f})" for a, b in rows))
+    print(f"   row 5: ready {x[18]:6.2f}  loaded {x[40]:6.2f}  products {x[41]:6.2f}  substitution {x[42]:6.2f}  done {x[19]:6.2f}")
+x = d[6] - t0
+print(f"{names[6]:12s} start {x[0]:6.2f}  Q ready {x[1]:6.2f}  W built {x[3]:6.2f}  row s {x[4]:6.2f}  S' {x[5]:6.2f}  row s+1 {x[6]:6.2f}  solved+posted {x[2]:6.2f}")
