@@ -824,7 +824,7 @@ static bool NdEligible(const idto_hip_ctx* c, const LdlPlan& p) {
 }
 static int NdLds(const idto_hip_ctx* c, const LdlPlan& p, int nloc_max) {
   const int ks = ldl_ks(p.K), NF = 2 * p.K, KP = 4 * ((p.K + 3) / 4);
-  const int spike = ((nloc_max + 2) * NF * ks + 3 * KP * ks + 3 * p.K * p.K + 4 * ks + NF) * (int)sizeof(double);
+  const int spike = ((nloc_max + 3) * NF * ks + 3 * KP * ks + 3 * p.K * p.K + 4 * ks + NF + 2) * (int)sizeof(double);
   const int sep = (2 * (4 * p.K * p.K + 2 * p.K) + (2 * p.K + 1) * ks + (p.K + 1) * ks + 2 * p.K * ks + p.K * ks + 6 * ks) * (int)sizeof(double);
   return std::max(std::max(spike, sep), p.lds);
 }

@@ -108,9 +108,11 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
   double* dn = Fi + 3 * K * K;            // [2][ks] 1/d of rows il, il-1
   double* rt = dn + 2 * ks;               // [2][ks]
   double* xs = rt + 2 * ks;               // [NF] separator solution in this chain's column order
+  double* GE = xs + NF + (NF & 1);        // [FB] (D^-1 Et_{il-1})^T Ft_{il-1}: the second product of row il+1, formed a row early
   // rows -2, -1 (zero) precede row 0 in Ft
   auto Ftrow = [&](int il) { return Ft + (size_t)(il + 2) * FB; };
   for (int idx = tid; idx < (nloc + 2) * FB + 3 * KP * ks; idx += nt) lds[idx] = 0.0;
+  for (int idx = tid; idx < FB; idx += nt) GE[idx] = 0.0;
   // initial coupling blocks (rows il = 0, 1 of the chain to the separator rows -1, -2 in its own orientation):
   //   Fi[0] = coupling(row 0, row -1), Fi[1] = coupling(row 0, row -2), Fi[2] = coupling(row 1, row -1)
   for (int idx = tid; idx < 3 * K * K; idx += nt) {
@@ -174,14 +176,14 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
   auto issue = [&](int il) {       // (after an acquire on row il's counter)
     const double* Ug = A.Ust + (size_t)orig(il) * BLK;
     const double* Hg = A.Hst + (size_t)orig(il >= 1 ? il - 1 : 0) * BLK;
-    const double* Eg = A.Est + (size_t)orig(il >= 2 ? il - 2 : 0) * BLK;
+    const double* Eg = A.Est + (size_t)orig(il >= 1 ? il - 1 : 0) * BLK;   // (for row il+1's second product)
 #pragma unroll
     for (int sl = 0; sl < PM; ++sl) {
       const int idx = tid + sl * 256, blk = idx / BLK, e = idx - blk * BLK;
       double v = 0.0;
       if (blk == 0) v = Ug[e];
       else if (blk == 1) { if (il >= 1) v = Hg[e]; }
-      else if (blk == 2) { if (il >= 2) v = Eg[e]; }
+      else if (blk == 2) { if (il >= 1) v = Eg[e]; }
       pre[sl] = v;
     }
     if (tid < ks) {
@@ -213,10 +215,10 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
     const unsigned long long next_cnt =
         (il + 1 < nloc) ? __hip_atomic_load(rowcnt + il + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     if (il == 5) nd_ts(A, 4 + w, 40);
-    // ---- F_il = Finit - (D^-1 Ht_{il-1})^T Ft_{il-1} - (D^-1 Et_{il-2})^T Ft_{il-2}: TT x CT tiles
+    // ---- F_il = Finit - (D^-1 Ht_{il-1})^T Ft_{il-1} - GE, GE = (D^-1 Et_{il-2})^T Ft_{il-2} from the
+    // previous iteration's second phase: TT x CT tiles
     {
       const double* F1 = Ftrow(il - 1);
-      const double* F2 = Ftrow(il - 2);
       double* Fo = Ftrow(il);
       for (int t = wave; t < TT * CT; t += nt / 64) {
         const int tr = t / CT, tc = t - tr * CT;
@@ -225,7 +227,6 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
         for (int sq = 0; sq < SK; ++sq) {
           const int kr = 4 * sq + fk;   // summation index: row of Ht / Et and of Ft
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Hl[kr * ks + 16 * tr + fl], F1[(16 * tc + fl) * ks + kr], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(El[kr * ks + 16 * tr + fl], F2[(16 * tc + fl) * ks + kr], acc, 0, 0, 0);
         }
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
@@ -234,7 +235,7 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
             double init = 0.0;
             if (il == 0) init = Fi[(c < K ? 0 : 1) * K * K + (c < K ? c : c - K) * K + r];
             else if (il == 1 && c < K) init = Fi[2 * K * K + c * K + r];
-            Fo[c * ks + r] = init - acc[rg];
+            Fo[c * ks + r] = (init - GE[c * ks + r]) - acc[rg];
           }
         }
       }
@@ -270,8 +271,26 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
         for (int r = 0; r < K; ++r) col[r] = xr[r];
       }
       if (il == 5) nd_ts(A, 4 + w, 42);
-    } else if (il >= 1) {
-      q_accumulate(il - 1);
+    } else {
+      if (il >= 1) {
+        q_accumulate(il - 1);
+        // GE for row il+1: (D^-1 Et_{il-1})^T Ft_{il-1} (El holds Est of row il-1), tiles over wavefronts 1..3
+        const double* F1 = Ftrow(il - 1);
+        for (int t = wave - 1; t < TT * CT; t += 3) {
+          const int tr = t / CT, tc = t - tr * CT;
+          d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int sq = 0; sq < SK; ++sq) {
+            const int kr = 4 * sq + fk;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(El[kr * ks + 16 * tr + fl], F1[(16 * tc + fl) * ks + kr], acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int r = 16 * tr + fk + 4 * rg, c = 16 * tc + fl;
+            if (r < K && c < NF) GE[c * ks + r] = acc[rg];
+          }
+        }
+      }
     }
     __syncthreads();
     nd_ts(A, 4 + w, 9 + 2 * il);
@@ -349,7 +368,16 @@ __device__ __forceinline__ void nd_separator(const NdArgs& A) {
   nd_wait(A.flags + 5, A.epoch);
   nd_wait(A.flags + 6, A.epoch);
   nd_ts(A, 6, 1);
-  for (int idx = tid; idx < 2 * QS; idx += nt) Q[idx] = A.ndbuf[B.Q + idx];
+  {  // all loads in flight at once (a load -> store loop pays the L2 round trip a dozen times: 3.6 us)
+    constexpr int QL = (2 * QS + 255) / 256;
+    double tmp[QL];
+    const double* src = A.ndbuf + B.Q;
+#pragma unroll
+    for (int sl = 0; sl < QL; ++sl) tmp[sl] = (tid + sl * 256 < 2 * QS) ? src[tid + sl * 256] : 0.0;
+#pragma unroll
+    for (int sl = 0; sl < QL; ++sl)
+      if (tid + sl * 256 < 2 * QS) Q[tid + sl * 256] = tmp[sl];
+  }
   __syncthreads();
   // column blocks of the two spike workgroups: w = 0 (mirrored chain J1): nearest = s (offset 0), farthest = s+1
   // (offset K); w = 1 (chain J2): nearest = s+1, farthest = s
