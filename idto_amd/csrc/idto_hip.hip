@@ -495,7 +495,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   // exchange buffer of the two-sided solver (one right-hand side): 2 augmented blocks + [2][K]
   c->xch_count = 2 * (size_t)(3 * 32 + 1) * ldl_ks(32) + 2 * 32;
   const size_t o_xch = carve(2 * c->xch_count, D);   // (two producer / joiner pairs in the nested-dissection kernel)
-  const size_t o_ndcnt = carve(2 * ND_MAXROWS, sizeof(unsigned long long)), o_ndbuf = carve((size_t)nd_layout(32).end, D);
+  const size_t o_ndcnt = carve(4 * ND_MAXROWS, sizeof(unsigned long long)), o_ndbuf = carve((size_t)nd_layout(32).end, D);
   c->flag_count = 16;
   const size_t o_flags = carve(c->flag_count, sizeof(unsigned)), o_sync = carve(2, sizeof(unsigned long long));
   const size_t nvars = (size_t)(N + 1) * nq;
@@ -609,7 +609,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   LDL_ATTR(8, true, 1) LDL_ATTR(16, true, 1) LDL_ATTR(24, true, 2) LDL_ATTR(32, true, 3)
 #undef LDL_ATTR
 #define ND_ATTR(KM, PD) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_nd_kernel<KM, PD>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-  ND_ATTR(2, false) ND_ATTR(3, false) ND_ATTR(5, false) ND_ATTR(19, false)
+  ND_ATTR(2, false) ND_ATTR(3, false) ND_ATTR(5, false) ND_ATTR(19, false) ND_ATTR(23, false)
 #undef ND_ATTR
 #define FUSED_ATTR(MC, KM, PD, GW)                                                                 \
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_fused_kernel<MC, KM, PD, GW>),       \
@@ -819,13 +819,16 @@ static int PlanLdl(idto_hip_ctx* c, bool one_sided, LdlPlan* p) {
 // workgroups, the separator.  Its factors are not what penta_apply_kernel walks, so it serves the
 // single-right-hand-side solves only (the Gauss-Newton step).
 static bool NdEligible(const idto_hip_ctx* c, const LdlPlan& p) {
-  const bool inst = (p.K == 2 || p.K == 3 || p.K == 5 || p.K == 19) && p.K == p.k;
-  return c->solver_nd && c->two_sided && inst && p.n >= 24 && p.gj_waves == 1;
+  const bool inst = (p.K == 2 || p.K == 3 || p.K == 5 || p.K == 19 || p.K == 23) && p.K == p.k;
+  // (seven workgroups per problem, one per CU: a batch that would not fit the 256 CUs at once is
+  // better served by the two-workgroup form - same work per problem on fewer CUs)
+  return c->solver_nd && c->two_sided && inst && p.n >= 24 && 7 * c->batch <= 256;
 }
 static int NdLds(const idto_hip_ctx* c, const LdlPlan& p, int nloc_max) {
   const int ks = ldl_ks(p.K), NF = 2 * p.K, KP = 4 * ((p.K + 3) / 4);
-  const int spike = ((nloc_max + 3) * NF * ks + 3 * KP * ks + 3 * p.K * p.K + 4 * ks + NF + 2) * (int)sizeof(double);
-  const int sep = (2 * (4 * p.K * p.K + 2 * p.K) + (2 * p.K + 1) * ks + (p.K + 1) * ks + 2 * p.K * ks + p.K * ks + 6 * ks) * (int)sizeof(double);
+  (void)nloc_max;
+  const int spike = (3 * NF * ks + 3 * KP * ks + 3 * p.K * p.K + 2 * ks + 4) * (int)sizeof(double);
+  const int sep = (2 * (NF + 1) * (NF + 1) + 2 + (2 * p.K + 1) * ks + (p.K + 1) * ks + 2 * p.K * ks + p.K * ks + 6 * ks) * (int)sizeof(double);
   return std::max(std::max(spike, sep), p.lds);
 }
 static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double sign, double* xo) {
@@ -849,7 +852,8 @@ static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double s
   c->last_solver = 2;
   {  // I/O wavefronts of a chain workgroup (penta_ldl_body: NW = 4, one elimination wavefront, three helpers)
     const int nhelp = 4 - p.gj_waves, io_first = (nhelp > 2) ? p.gj_waves + 1 : p.gj_waves;
-    A.rowtarget = c->nd_launches * (unsigned long long)(4 - io_first);
+    A.rowunit = (unsigned long long)(4 - io_first);
+    A.rowtarget = c->nd_launches * A.rowunit;
   }
   ++c->epoch;
   if (++c->fact_id == 0) c->fact_id = 1;
@@ -861,6 +865,7 @@ static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double s
     case 2: ND_LAUNCH(2, false); break;
     case 3: ND_LAUNCH(3, false); break;
     case 5: ND_LAUNCH(5, false); break;
+    case 23: ND_LAUNCH(23, false); break;
     default: ND_LAUNCH(19, false); break;
   }
 #undef ND_LAUNCH

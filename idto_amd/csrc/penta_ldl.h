@@ -183,8 +183,9 @@ struct ChainCfg {
   unsigned long long* rowcnt;
   unsigned long long rowcnt_unit;   // what one wavefront adds
   double* rtpub;                    // [local row][K]
-  const double* corr;               // [local row][K]
-  unsigned* corrflag;
+  const double* fst; int fstride;   // the spike workgroup's rows [Ft_il | rt_il] (K rows, column stride ks)
+  const double* xsep;               // [x_s | x_{s+1}] once *sepflag == epoch
+  unsigned* sepflag;
   double* ts;                       // optional wall-clock stamps (100 MHz): start, join reached, forward done, backward start, end
 };
 __device__ __forceinline__ void chain_ts(const ChainCfg& cfg, int slot) {
@@ -574,6 +575,7 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
           if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) {
             __hip_atomic_store(status, fact_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_fetch_add(status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (cfg.ts) cfg.ts[20] = (double)(i + 1);   // (debug: first/last failing local row of this chain)
           }
         }
       } else {
@@ -703,16 +705,30 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
   }
   stamp(nfwd, 0);
   chain_ts(cfg, 2);
-  if (cfg.corr) {
-    // nested dissection: this chain's rows also couple to the separator; its solution times the
-    // eliminated coupling blocks (F_il x_sep, computed by the spike workgroup) leaves rt
+  if (cfg.fst) {
+    // nested dissection: this chain's rows also couple to the separator.  Once it is solved,
+    // rt_il -= Ft_il [x_near ; x_far] with the eliminated coupling blocks Ft_il the spike workgroup
+    // left in HBM (columns 0..K-1: the separator row next to this chain's first row)
     if (tid == 0)
-      while (__hip_atomic_load(cfg.corrflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
+      while (__hip_atomic_load(cfg.sepflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
     __syncthreads();
-    (void)__hip_atomic_load(cfg.corrflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_load(cfg.sepflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    double* xs = Wm;   // (the augmented block is free between the passes)
+    for (int c = tid; c < 2 * K; c += nt) {
+      const int half = c / K, r = c - half * K;
+      xs[c] = cfg.xsep[(mirror ? half : 1 - half) * K + r];   // mirrored chain: nearest = s, else nearest = s + 1
+    }
+    __syncthreads();
     for (int idx = tid; idx < nloc * K; idx += nt) {
       const int il = idx / K, r = idx - il * K;
-      lds[L.xall + (il + 2) * ks + r] -= cfg.corr[idx];
+      const double* F = cfg.fst + (size_t)il * cfg.fstride + r;
+      double f[2 * K];
+#pragma unroll
+      for (int c = 0; c < 2 * K; ++c) f[c] = F[c * ks];   // all loads in flight before the sum
+      double acc = 0.0;
+#pragma unroll
+      for (int c = 0; c < 2 * K; ++c) acc = __builtin_fma(f[c], xs[c], acc);
+      lds[L.xall + (il + 2) * ks + r] -= acc;
     }
     __syncthreads();
   }

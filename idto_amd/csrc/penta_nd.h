@@ -40,10 +40,10 @@ struct NdArgs {
   double* Ust; double* Hst; double* Est; double* Dst;
   int s, j1, j2;                 // separator rows s, s+1; join rows j1, j1+1 and j2, j2+1
   double* xch; int xch_pair;     // two producer/joiner exchange buffers (layout of the two-workgroup kernel)
-  unsigned* flags;               // [0..1] pair P0/J1, [2..3] pair P3/J2, [4] separator solved,
-                                 // [5 + w] Q of spike workgroup w published, [7 + w] its corrections published
-  unsigned long long* rowcnt;    // [2][ND_MAXROWS]: released I/O wavefronts per local row of J1 / J2
-  unsigned long long rowtarget;  // value a row's counter reaches in this launch
+  unsigned* flags;               // [0..1] pair P0/J1, [2..3] pair P3/J2, [4] separator solved
+  unsigned long long* rowcnt;    // [4][ND_MAXROWS]: released wavefronts per local row of J1, J2 (chains) and of their spike workgroups
+  unsigned long long rowtarget;  // value a joiner row's counter reaches in this launch ...
+  unsigned long long rowunit;    // ... = launches x rowunit (I/O wavefronts of a chain workgroup)
   double* ndbuf;                 // see nd_layout
   unsigned epoch;
   unsigned* status; unsigned fact_id;
@@ -54,13 +54,14 @@ __device__ __forceinline__ void nd_ts(const NdArgs& A, int role, int slot) {
   if (A.ts && threadIdx.x == 0) A.ts[role * 64 + slot] = (double)wall_clock64();
 }
 
-struct NdBuf { int rtpub, corr, Q, xsep, end; };  // offsets in doubles; rtpub / corr / Q are [2][...]
+struct NdBuf { int rtpub, fst, frow, xsep, end; };  // offsets in doubles; rtpub / fst are [2][...]
 __host__ __device__ inline NdBuf nd_layout(int K) {
   NdBuf L;
+  const int ks = ldl_ks(K), ct2 = (2 * K + 1 + 15) / 16;   // columns [Ft | rt], in tiles of 16
   int o = 0;
   L.rtpub = o; o += 2 * ND_MAXROWS * K;
-  L.corr = o; o += 2 * ND_MAXROWS * K;
-  L.Q = o; o += 2 * (4 * K * K + 2 * K);
+  L.frow = 16 * ct2 * ks;                // doubles per published row (whole 16-column tiles: the separator's MFMA loads)
+  L.fst = o; o += 2 * ND_MAXROWS * L.frow + 16 * ks;
   L.xsep = o; o += 2 * K;
   L.end = o;
   return L;
@@ -82,37 +83,40 @@ __device__ __forceinline__ void nd_post(unsigned* f, unsigned epoch) {
 }
 
 // ---- spike workgroup of joiner `w` (0: J1, mirrored, starts at row s-1; 1: J2, starts at row s+2)
+// Per row il of the joiner (its factors and rt released through the row counter):
+//   phase 1 (all wavefronts)  F_il = Finit - (D^-1 Ht_{il-1})^T Ft_{il-1} - GE          (matrix cores)
+//   phase 2  wavefront 0      Ft_il = L_il^-1 F_il                                        (lane = column)
+//            wavefronts 1..3  GE = (D^-1 Et_{il-1})^T Ft_{il-1} for row il+1, and [Ft_{il-1} | rt_{il-1}] to HBM
+//                             for the separator (Q) and the joiner (correction), released per row
+// Only the dependent pair (phase 1, substitution) is on the row's critical path: ~3.2 us, the
+// joiner needs ~3.6 us per row, so this workgroup stays one row behind it.
 template <int K, bool PADDED>
 __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
   extern __shared__ double lds[];
   constexpr int ks = ldl_ks(K), SK = (K + 3) / 4, TT = (K + 15) / 16, NF = 2 * K, CT = (NF + 15) / 16, KP = 4 * SK;
   using d4 = __attribute__((ext_vector_type(4))) double;
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
-  const int k = A.k, kk = k * k, n = A.n;
+  const int k = A.k, kk = k * k;
   const bool mirror = (w == 0);
   const int base = mirror ? A.s - 1 : A.s + 2;
   const int nloc = mirror ? A.s - A.j1 : A.j2 + 2 - (A.s + 2);   // chain rows + the two join rows
   auto orig = [&](int il) { return mirror ? base - il : base + il; };
   const NdBuf B = nd_layout(K);
   const unsigned long long* rowcnt = A.rowcnt + w * ND_MAXROWS;
+  unsigned long long* frow = A.rowcnt + (2 + w) * ND_MAXROWS;
   const double* rtpub = A.ndbuf + B.rtpub + (size_t)w * ND_MAXROWS * K;
-  double* corr = A.ndbuf + B.corr + (size_t)w * ND_MAXROWS * K;
-  double* Qout = A.ndbuf + B.Q + (size_t)w * (4 * K * K + 2 * K);
+  double* Fst = A.ndbuf + B.fst + (size_t)w * ND_MAXROWS * B.frow;
   // LDS (doubles)
-  constexpr int FB = NF * ks;             // one Ft block: NF columns of K rows, stride ks
-  double* Ft = lds;                       // [nloc][FB]   (+ one zero block in front for il - 1, il - 2 < 0)
-  double* Ul = Ft + (size_t)(nloc + 2) * FB;   // [KP][ks] row-major D^-1 U_il (strict upper), zero pad rows
+  constexpr int FB = NF * ks;             // one Ft block: NF columns of K rows, stride ks (pad rows zero)
+  double* Fr = lds;                       // [2][FB] ring: Ft_il, Ft_{il-1}
+  double* Ul = Fr + 2 * FB;               // [KP][ks] row-major D^-1 U_il (strict upper), zero pad rows
   double* Hl = Ul + KP * ks;              // D^-1 Ht_{il-1}
-  double* El = Hl + KP * ks;              // D^-1 Et_{il-2}
+  double* El = Hl + KP * ks;              // D^-1 Et_{il-1}
   double* Fi = El + KP * ks;              // [3][K*K] initial coupling blocks, column-major
-  double* dn = Fi + 3 * K * K;            // [2][ks] 1/d of rows il, il-1
-  double* rt = dn + 2 * ks;               // [2][ks]
-  double* xs = rt + 2 * ks;               // [NF] separator solution in this chain's column order
-  double* GE = xs + NF + (NF & 1);        // [FB] (D^-1 Et_{il-1})^T Ft_{il-1}: the second product of row il+1, formed a row early
-  // rows -2, -1 (zero) precede row 0 in Ft
-  auto Ftrow = [&](int il) { return Ft + (size_t)(il + 2) * FB; };
-  for (int idx = tid; idx < (nloc + 2) * FB + 3 * KP * ks; idx += nt) lds[idx] = 0.0;
-  for (int idx = tid; idx < FB; idx += nt) GE[idx] = 0.0;
+  double* rt = Fi + 3 * K * K + (K & 1);  // [2][ks] rt_il, rt_{il-1}
+  double* GE = rt + 2 * ks;               // [FB] (D^-1 Et_{il-1})^T Ft_{il-1}: the second product of row il+1, a row early
+  for (int idx = tid; idx < 2 * FB + 3 * KP * ks; idx += nt) lds[idx] = 0.0;
+  for (int idx = tid; idx < FB + 2 * ks; idx += nt) rt[idx] = 0.0;   // (rt and GE are adjacent)
   // initial coupling blocks (rows il = 0, 1 of the chain to the separator rows -1, -2 in its own orientation):
   //   Fi[0] = coupling(row 0, row -1), Fi[1] = coupling(row 0, row -2), Fi[2] = coupling(row 1, row -1)
   for (int idx = tid; idx < 3 * K * K; idx += nt) {
@@ -130,46 +134,13 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
     Fi[idx] = val;
   }
   __syncthreads();
-
   nd_ts(A, 4 + w, 0);
   const int fl = lane & 15, fk = lane >> 4;
-  // Q tiles (lower triangle of the CT x CT tile grid) live in the registers of wavefronts 1..3
-  // tile list: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) -> wave 1 + (t % 3)
-  constexpr int NQT = CT * (CT + 1) / 2;
-  d4 qacc[(NQT + 2) / 3];
-#pragma unroll
-  for (int t = 0; t < (NQT + 2) / 3; ++t) qacc[t] = d4{0.0, 0.0, 0.0, 0.0};
-  double qy = 0.0;   // wave 3, lane c < NF: (Ft^T Dn rt)[c]
-
-  auto q_accumulate = [&](int il) {   // Q += Ft_il^T Dn_il Ft_il ; qy += Ft_il^T Dn_il rt_il
-    const double* F = Ftrow(il);
-    const double* dnl = dn + (il & 1) * ks;
-    const double* rtl = rt + (il & 1) * ks;
-    if (wave >= 1) {
-#pragma unroll
-      for (int t = 0; t < NQT; ++t) {   // (tile t belongs to wavefront 1 + t % 3, its accumulator is slot t / 3)
-        if (t % 3 != wave - 1) continue;
-        const int tr = nd_tile_row(t), tc = nd_tile_col(t);
-#pragma unroll
-        for (int sq = 0; sq < SK; ++sq) {
-          const double a = F[(16 * tr + fl) * ks + 4 * sq + fk];
-          const double bq = F[(16 * tc + fl) * ks + 4 * sq + fk] * dnl[4 * sq + fk];
-          qacc[t / 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, qacc[t / 3], 0, 0, 0);
-        }
-      }
-    }
-    if (wave == 3 && lane < NF) {   // (the wavefront with the fewest tiles; wavefront 0 runs the substitution)
-      double acc = 0.0;
-#pragma unroll
-      for (int r = 0; r < K; ++r) acc = __builtin_fma(F[lane * ks + r], dnl[r] * rtl[r], acc);
-      qy += acc;
-    }
-  };
 
   // Factors of row il+1 are fetched into registers while row il is processed (the loads of a row
   // cost ~2.5 us exposed, which alone would make this workgroup slower than the chain it follows).
   constexpr int BLK = K * ks, PM = (3 * BLK + 255) / 256;
-  double pre[PM], pdn = 0.0, prt = 0.0;
+  double pre[PM], prt = 0.0;
   auto row_ready = [&](int il) {   // uniform: every thread loads the same counter
     return __hip_atomic_load(rowcnt + il, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= A.rowtarget;
   };
@@ -186,10 +157,7 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
       else if (blk == 2) { if (il >= 1) v = Eg[e]; }
       pre[sl] = v;
     }
-    if (tid < ks) {
-      pdn = (tid < K) ? A.Dst[(size_t)orig(il) * K + tid] : 0.0;
-      prt = (tid < K) ? rtpub[(size_t)il * K + tid] : 0.0;
-    }
+    if (tid < ks) prt = (tid < K) ? rtpub[(size_t)il * K + tid] : 0.0;
   };
   auto commit = [&](int il) {      // registers -> LDS (Ul, Hl, El are KP * ks apart)
 #pragma unroll
@@ -197,13 +165,19 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
       const int idx = tid + sl * 256, blk = idx / BLK, e = idx - blk * BLK;
       if (blk < 3) Ul[blk * KP * ks + e] = pre[sl];
     }
-    if (tid < ks) { dn[(il & 1) * ks + tid] = pdn; rt[(il & 1) * ks + tid] = prt; }
+    if (tid < ks) rt[(il & 1) * ks + tid] = prt;
   };
   // (per wavefront, no workgroup barrier: the wavefronts decide independently whether they could
   // prefetch a row, so nothing here may assume that the others take the same path)
   auto wait_row = [&](int il) {
     while (!row_ready(il)) __builtin_amdgcn_s_sleep(1);
     (void)__hip_atomic_load(rowcnt + il, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // [Ft_il | rt_il] -> HBM (row stride B.frow, column stride ks), by the threads [t0, t0 + tn)
+  auto publish = [&](int il, int t0, int tn) {
+    const double* F = Fr + (il & 1) * FB;
+    double* dst = Fst + (size_t)il * B.frow;
+    for (int idx = tid - t0; idx < FB + ks; idx += tn) dst[idx] = (idx < FB) ? F[idx] : rt[(il & 1) * ks + idx - FB];
   };
   wait_row(0);
   issue(0);
@@ -214,20 +188,19 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
     // readiness of the next row: a round trip to L2, issued now, consumed after the products
     const unsigned long long next_cnt =
         (il + 1 < nloc) ? __hip_atomic_load(rowcnt + il + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-    if (il == 5) nd_ts(A, 4 + w, 40);
-    // ---- F_il = Finit - (D^-1 Ht_{il-1})^T Ft_{il-1} - GE, GE = (D^-1 Et_{il-2})^T Ft_{il-2} from the
-    // previous iteration's second phase: TT x CT tiles
+    // ---- phase 1: F_il = Finit - GE - (D^-1 Ht_{il-1})^T Ft_{il-1}: TT x CT tiles
     {
-      const double* F1 = Ftrow(il - 1);
-      double* Fo = Ftrow(il);
+      const double* F1 = Fr + ((il + 1) & 1) * FB;
+      double* Fo = Fr + (il & 1) * FB;
       for (int t = wave; t < TT * CT; t += nt / 64) {
         const int tr = t / CT, tc = t - tr * CT;
         d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int sq = 0; sq < SK; ++sq) {
-          const int kr = 4 * sq + fk;   // summation index: row of Ht / Et and of Ft
+          const int kr = 4 * sq + fk;   // summation index: row of Ht and of Ft
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Hl[kr * ks + 16 * tr + fl], F1[(16 * tc + fl) * ks + kr], acc, 0, 0, 0);
         }
+        // (F1 is overwritten below only in its own slot's next use; Fo is the other ring slot)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const int r = 16 * tr + fk + 4 * rg, c = 16 * tc + fl;
@@ -240,7 +213,6 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
         }
       }
     }
-    // (the readiness check is a round trip to L2: its result is consumed only here, after the products)
     bool prefetched = false;
     if (il + 1 < nloc && next_cnt >= A.rowtarget) {
       (void)__hip_atomic_load(rowcnt + il + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
@@ -248,12 +220,11 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
       prefetched = true;
     }
     __syncthreads();
-    if (il == 5) nd_ts(A, 4 + w, 41);
-    // ---- Ft_il = L_il^-1 F_il (L^T = D^-1 U, unit): lane = column, rows in registers, the
-    // multipliers are LDS broadcasts; meanwhile the other wavefronts fold row il-1 into Q
+    // ---- phase 2
     if (wave == 0) {
+      // Ft_il = L_il^-1 F_il (L^T = D^-1 U, unit): lane = column, rows in registers, multipliers are LDS broadcasts
       if (lane < NF) {
-        double* col = Ftrow(il) + lane * ks;
+        double* col = Fr + (il & 1) * FB + lane * ks;
         double xr[K];
 #pragma unroll
         for (int r = 0; r < K; ++r) xr[r] = col[r];
@@ -270,88 +241,66 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
 #pragma unroll
         for (int r = 0; r < K; ++r) col[r] = xr[r];
       }
-      if (il == 5) nd_ts(A, 4 + w, 42);
-    } else {
-      if (il >= 1) {
-        q_accumulate(il - 1);
-        // GE for row il+1: (D^-1 Et_{il-1})^T Ft_{il-1} (El holds Est of row il-1), tiles over wavefronts 1..3
-        const double* F1 = Ftrow(il - 1);
-        for (int t = wave - 1; t < TT * CT; t += 3) {
-          const int tr = t / CT, tc = t - tr * CT;
-          d4 acc = {0.0, 0.0, 0.0, 0.0};
+    } else if (il >= 1) {
+      // GE for row il+1: (D^-1 Et_{il-1})^T Ft_{il-1} (El holds Est of row il-1), tiles over wavefronts 1..3
+      const double* F1 = Fr + ((il + 1) & 1) * FB;
+      for (int t = wave - 1; t < TT * CT; t += 3) {
+        const int tr = t / CT, tc = t - tr * CT;
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int sq = 0; sq < SK; ++sq) {
-            const int kr = 4 * sq + fk;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(El[kr * ks + 16 * tr + fl], F1[(16 * tc + fl) * ks + kr], acc, 0, 0, 0);
-          }
+        for (int sq = 0; sq < SK; ++sq) {
+          const int kr = 4 * sq + fk;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(El[kr * ks + 16 * tr + fl], F1[(16 * tc + fl) * ks + kr], acc, 0, 0, 0);
+        }
 #pragma unroll
-          for (int rg = 0; rg < 4; ++rg) {
-            const int r = 16 * tr + fk + 4 * rg, c = 16 * tc + fl;
-            if (r < K && c < NF) GE[c * ks + r] = acc[rg];
-          }
+        for (int rg = 0; rg < 4; ++rg) {
+          const int r = 16 * tr + fk + 4 * rg, c = 16 * tc + fl;
+          if (r < K && c < NF) GE[c * ks + r] = acc[rg];
         }
       }
+      // [Ft_{il-1} | rt_{il-1}] to HBM.  Its release is ONE read-modify-write after a workgroup
+      // barrier (per-wavefront fences + relaxed increments were observed to let the separator read
+      // a row too early), and it is issued a row late, here, where wavefront 3 has slack: row il-2
+      // was stored before the barrier that ended the previous iteration.
+      if (il >= 2 && tid == 192) __hip_atomic_fetch_add(frow + (il - 2), 3ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      publish(il - 1, 64, 192);
     }
     __syncthreads();
     nd_ts(A, 4 + w, 9 + 2 * il);
     if (il + 1 < nloc && !prefetched) { wait_row(il + 1); issue(il + 1); }
   }
-  q_accumulate(nloc - 1);
-  // ---- publish Q (dense NF x NF, both triangles) and qy
-  if (wave >= 1) {
-#pragma unroll
-    for (int t = 0; t < NQT; ++t) {
-      if (t % 3 != wave - 1) continue;
-      const int tr = nd_tile_row(t), tc = nd_tile_col(t);
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int r = 16 * tr + fk + 4 * rg, c = 16 * tc + fl;
-        if (r < NF && c < NF) { Qout[c * NF + r] = qacc[t / 3][rg]; Qout[r * NF + c] = qacc[t / 3][rg]; }
-      }
-    }
+  publish(nloc - 1, 0, 256);
+  __syncthreads();
+  if (tid == 0) {
+    if (nloc >= 2) __hip_atomic_fetch_add(frow + (nloc - 2), 3ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(frow + (nloc - 1), 3ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (wave == 3 && lane < NF) Qout[NF * NF + lane] = qy;
-  nd_post(A.flags + 5 + w, A.epoch);
   nd_ts(A, 4 + w, 1);
-  // ---- corrections Ft_il x_sep for every row, once the separator is solved
-  nd_wait(A.flags + 4, A.epoch);
-  nd_ts(A, 4 + w, 2);
-  {
-    const double* xsep = A.ndbuf + B.xsep;   // [x_s | x_{s+1}]
-    for (int c = tid; c < NF; c += nt) {
-      const int half = c / K, r = c - half * K;             // column block 0: nearest separator row, 1: farthest
-      const int which = mirror ? half : 1 - half;           // mirrored chain: nearest = s; other: nearest = s+1
-      xs[c] = xsep[which * K + r];
-    }
-    __syncthreads();
-    for (int idx = tid; idx < nloc * K; idx += nt) {
-      const int il = idx / K, r = idx - il * K;
-      const double* F = Ftrow(il);
-      double acc = 0.0;
-      for (int c = 0; c < NF; ++c) acc = __builtin_fma(F[c * ks + r], xs[c], acc);
-      corr[idx] = acc;
-    }
-  }
-  nd_post(A.flags + 7 + w, A.epoch);
-  nd_ts(A, 4 + w, 3);
 }
 
 // ---- separator workgroup
+// While the chains run: wavefronts 0, 1 accumulate Q of spike workgroup 0, wavefronts 2, 3 of spike
+// workgroup 1 - each wavefront on its own (no workgroup barrier, MFMA operands straight from the
+// rows the spike workgroups publish) - with [Ft | rt] as one block of 2K + 1 columns, so that
+//   Q[c][c'] = sum_il Ft_il[:, c] . Dn_il Ft_il[:, c']   and   Q[2K][c] = qy[c] = sum_il rt_il . Dn_il Ft_il[:, c].
+// Then: separator system, its two block rows eliminated in registers, back substitution, x_s and
+// x_{s+1} published.
 template <int K, bool PADDED>
 __device__ __forceinline__ void nd_separator(const NdArgs& A) {
   extern __shared__ double lds[];
-  constexpr int ks = ldl_ks(K), NF = 2 * K, QS = 4 * K * K + 2 * K;
+  constexpr int ks = ldl_ks(K), NF = 2 * K, NC = NF + 1, CT2 = (NC + 15) / 16, NQT = CT2 * (CT2 + 1) / 2, QS = NC * NC;
+  constexpr int SKq = (K + 3) / 4;
+  using d4q = __attribute__((ext_vector_type(4))) double;
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
   const int k = A.k, kk = k * k, s = A.s;
   const NdBuf B = nd_layout(K);
-  double* Q = lds;                   // [2][QS]
-  double* W = Q + 2 * QS;            // [2K + 1][ks] columns [S | H | y]
+  double* Q = lds;                   // [2][QS] dense, both triangles
+  double* W = Q + 2 * QS + (QS & 1); // [2K + 1][ks] columns [S | H | y]
   double* S1 = W + (2 * K + 1) * ks; // [K + 1][ks] second row: [S' | y']
   double* Us = S1 + (K + 1) * ks;    // [2][K][ks] U columns of both rows
   double* Ht = Us + 2 * K * ks;      // [K][ks]
   double* rtv = Ht + K * ks;         // [2][ks]
   double* dnv = rtv + 2 * ks;        // [2][ks]
-  double* xv = dnv + 2 * ks;         // [2][ks] x_s, x_{s+1}
   nd_ts(A, 6, 0);
   // band blocks and right-hand sides of the separator rows first (no dependence on the chains)
   for (int idx = tid; idx < K * K; idx += nt) {
@@ -361,31 +310,68 @@ __device__ __forceinline__ void nd_separator(const NdArgs& A) {
     W[(K + c) * ks + r] = in ? A.HB[(size_t)(s + 1) * kk + r * k + c] : 0.0;   // block (s, s+1) = B_{s+1}^T
     S1[c * ks + r] = in ? A.HC[(size_t)(s + 1) * kk + c * k + r] : (r == c ? 1.0 : 0.0);
   }
+  // (pad rows of the Ht columns are read by the MFMA k-steps of S': LDS is not cleared between
+  // kernels, and 0 * NaN from a previous kernel's bits would poison every output)
+  for (int idx = tid; idx < K * ks; idx += nt) Ht[idx] = 0.0;
   for (int r = tid; r < K; r += nt) {
     W[2 * K * ks + r] = (r < k) ? A.rhs_sign * A.b[(size_t)s * k + r] : 0.0;
     S1[K * ks + r] = (r < k) ? A.rhs_sign * A.b[(size_t)(s + 1) * k + r] : 0.0;
   }
-  nd_wait(A.flags + 5, A.epoch);
-  nd_wait(A.flags + 6, A.epoch);
-  nd_ts(A, 6, 1);
-  {  // all loads in flight at once (a load -> store loop pays the L2 round trip a dozen times: 3.6 us)
-    constexpr int QL = (2 * QS + 255) / 256;
-    double tmp[QL];
-    const double* src = A.ndbuf + B.Q;
+  {
+    const int w = wave >> 1, sub = wave & 1;            // spike workgroup followed, and which half of its tiles
+    const bool mirror = (w == 0);
+    const int base = mirror ? A.s - 1 : A.s + 2;
+    const int nloc = mirror ? A.s - A.j1 : A.j2 + 2 - (A.s + 2);
+    const unsigned long long* frow = A.rowcnt + (2 + w) * ND_MAXROWS;
+    const double* Fst = A.ndbuf + B.fst + (size_t)w * ND_MAXROWS * B.frow;
+    const unsigned long long ftarget = (A.rowtarget / A.rowunit) * 3ull;   // three wavefronts release a row
+    const int fl = lane & 15, fk = lane >> 4;
+    d4q qacc[(NQT + 1) / 2];
 #pragma unroll
-    for (int sl = 0; sl < QL; ++sl) tmp[sl] = (tid + sl * 256 < 2 * QS) ? src[tid + sl * 256] : 0.0;
+    for (int t = 0; t < (NQT + 1) / 2; ++t) qacc[t] = d4q{0.0, 0.0, 0.0, 0.0};
+    for (int il = 0; il < nloc; ++il) {
+      while (__hip_atomic_load(frow + il, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ftarget) __builtin_amdgcn_s_sleep(1);
+      (void)__hip_atomic_load(frow + il, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      const double* F = Fst + (size_t)il * B.frow;
+      const double* dg = A.Dst + (size_t)(mirror ? base - il : base + il) * K;
+      double op[CT2][SKq], dn[SKq];
 #pragma unroll
-    for (int sl = 0; sl < QL; ++sl)
-      if (tid + sl * 256 < 2 * QS) Q[tid + sl * 256] = tmp[sl];
+      for (int sq = 0; sq < SKq; ++sq) {
+        const int kr = 4 * sq + fk;
+        dn[sq] = (kr < K) ? dg[kr] : 0.0;
+#pragma unroll
+        for (int t = 0; t < CT2; ++t) op[t][sq] = F[(16 * t + fl) * ks + kr];
+      }
+#pragma unroll
+      for (int t = 0; t < NQT; ++t) {   // tile t -> wavefront t % 2 of the pair, accumulator t / 2
+        if (t % 2 != sub) continue;
+        const int tr = nd_tile_row(t), tc = nd_tile_col(t);
+#pragma unroll
+        for (int sq = 0; sq < SKq; ++sq)
+          qacc[t / 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[tr][sq], op[tc][sq] * dn[sq], qacc[t / 2], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NQT; ++t) {
+      if (t % 2 != sub) continue;
+      const int tr = nd_tile_row(t), tc = nd_tile_col(t);
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int r = 16 * tr + fk + 4 * rg, c = 16 * tc + fl;
+        // (lower triangle, mirrored: a diagonal tile holds both (r, c) and (c, r), summed in different orders)
+        if (r < NC && c < NC && r >= c) { Q[w * QS + c * NC + r] = qacc[t / 2][rg]; Q[w * QS + r * NC + c] = qacc[t / 2][rg]; }
+      }
+    }
   }
   __syncthreads();
+  nd_ts(A, 6, 1);
   // column blocks of the two spike workgroups: w = 0 (mirrored chain J1): nearest = s (offset 0), farthest = s+1
-  // (offset K); w = 1 (chain J2): nearest = s+1, farthest = s
+  // (offset K); w = 1 (chain J2): nearest = s+1, farthest = s; column 2K is rt
   auto qs = [&](int w, int rowsel, int colsel, int r, int c) {   // rowsel / colsel: 0 -> block of row s, 1 -> of s+1
     const int ro = (w == 0 ? rowsel : 1 - rowsel) * K, co = (w == 0 ? colsel : 1 - colsel) * K;
-    return Q[w * QS + (co + c) * NF + ro + r];
+    return Q[w * QS + (co + c) * NC + ro + r];
   };
-  auto qyv = [&](int w, int rowsel, int r) { return Q[w * QS + NF * NF + (w == 0 ? rowsel : 1 - rowsel) * K + r]; };
+  auto qyv = [&](int w, int rowsel, int r) { return Q[w * QS + NF * NC + (w == 0 ? rowsel : 1 - rowsel) * K + r]; };
   for (int idx = tid; idx < K * K; idx += nt) {
     const int c = idx / K, r = idx - c * K;
     W[c * ks + r] = (W[c * ks + r] - qs(0, 0, 0, r, c)) - qs(1, 0, 0, r, c);
@@ -476,6 +462,7 @@ __device__ __forceinline__ void nd_separator(const NdArgs& A) {
     if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) {
       __hip_atomic_store(A.status, A.fact_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_fetch_add(A.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (A.ts) A.ts[6 * 64 + 20] = 1.0;
     }
   }
   __syncthreads();
@@ -483,24 +470,26 @@ __device__ __forceinline__ void nd_separator(const NdArgs& A) {
   // ---- back substitution (U = D L^T: x_r = rt_r / d_r - sum_{c > r} (U[r][c] / d_r) x_c), lane = row
   if (wave == 0) {
     const int r = (lane < K) ? lane : 0;
-    auto back = [&](int row, double v) {   // v: right-hand side already scaled by 1/d; returns x (lane r)
-      double u[K];   // row r of D^-1 U (strict upper part), fetched before the dependent chain starts
+    // rows r of D^-1 U_{s+1}, D^-1 U_s (strict upper parts) and of Ht, fetched before the dependent chains start
+    double u1[K], u0[K], hrow[K];
+    const double d1 = dnv[ks + r], d0 = dnv[r];
 #pragma unroll
-      for (int j = 0; j < K; ++j) u[j] = (r < j) ? Us[(row * K + j) * ks + r] * dnv[row * ks + r] : 0.0;
-#pragma unroll
-      for (int j = K - 1; j >= 0; --j) v = __builtin_fma(-u[j], rdlane(v, j), v);
-      return v;
-    };
-    const double x1 = back(1, rtv[ks + r] * dnv[ks + r]);        // x_{s+1}
-    double acc = 0.0;
-    {
-      double hrow[K];
-#pragma unroll
-      for (int c = 0; c < K; ++c) hrow[c] = Ht[c * ks + r];
-#pragma unroll
-      for (int c = 0; c < K; ++c) acc = __builtin_fma(hrow[c], rdlane(x1, c), acc);   // (Ht x_{s+1})[r]
+    for (int j = 0; j < K; ++j) {
+      u1[j] = Us[(K + j) * ks + r];
+      u0[j] = Us[j * ks + r];
+      hrow[j] = Ht[j * ks + r];
     }
-    const double x0 = back(0, (rtv[r] - acc) * dnv[r]);          // x_s
+    double v = rtv[ks + r] * d1;
+#pragma unroll
+    for (int j = K - 1; j >= 0; --j) v = __builtin_fma(-((r < j) ? u1[j] * d1 : 0.0), rdlane(v, j), v);
+    const double x1 = v;                                         // x_{s+1}
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < K; ++c) acc = __builtin_fma(hrow[c], rdlane(x1, c), acc);   // (Ht x_{s+1})[r]
+    v = (rtv[r] - acc) * d0;
+#pragma unroll
+    for (int j = K - 1; j >= 0; --j) v = __builtin_fma(-((r < j) ? u0[j] * d0 : 0.0), rdlane(v, j), v);
+    const double x0 = v;                                         // x_s
     if (lane < K) {
       double* xsep = A.ndbuf + B.xsep;
       xsep[lane] = x0;
@@ -548,8 +537,8 @@ __global__ void __launch_bounds__(256) penta_nd_kernel(NdArgs A) {
     pair = w;
     c.rowcnt = A.rowcnt + w * ND_MAXROWS; c.rowcnt_unit = 1ull;
     c.rtpub = A.ndbuf + B.rtpub + (size_t)w * ND_MAXROWS * K;
-    c.corr = A.ndbuf + B.corr + (size_t)w * ND_MAXROWS * K;
-    c.corrflag = A.flags + 7 + w;
+    c.fst = A.ndbuf + B.fst + (size_t)w * ND_MAXROWS * B.frow; c.fstride = B.frow;
+    c.xsep = A.ndbuf + B.xsep; c.sepflag = A.flags + 4;
   }
   constexpr int GW = ((2 * K + 1) + (64 - K) - 1) / (64 - K);
   penta_ldl_body<K, 256, PADDED, GW>(A.n, A.k, A.HA, A.HB, A.HC, A.b, A.rhs_sign, 1, A.x, A.Ust, A.Hst, A.Est, A.Dst,

@@ -28,7 +28,8 @@ def _setup(name, N, seed=0):
 
 
 @pytest.mark.parametrize("name,N", [("mini_cheetah", 40), ("mini_cheetah", 24), ("mini_cheetah", 31), ("hopper", 50),
-                                    ("spinner", 40), ("acrobot", 40), ("acrobot", 63)])
+                                    ("spinner", 40), ("acrobot", 40), ("acrobot", 63), ("allegro_hand", 60),
+                                    ("allegro_hand", 27)])
 def test_nested_dissection_solver(name, N):
     cfg, model, prob, sp, q = _setup(name, N)
     dev = hip.HipPath(model, prob, sp)
@@ -112,3 +113,26 @@ def test_nd_in_a_batch_and_failure_report():
     batch.gn_step()
     assert batch.solver_status_batch() == [False, True, False]
     batch.close()
+
+
+def test_changing_inputs_every_launch():
+    """the trajectory changes every launch: a read that is not ordered after its producer would return
+    the previous launch's values (tools/nd_stress.py is the long version)"""
+    cfg, model, prob, sp, _ = _setup("mini_cheetah", 40)
+    qs = [synthetic_trajectory(cfg, model, 40, seed=s, lower=0.01) for s in range(3)]
+    dev = hip.HipPath(model, prob, sp)
+    dev.set_option("solver_nd", 0)
+    ref = []
+    for q in qs:
+        dev.set_q(q)
+        dev.gn_step()
+        ref.append(dev.get("step"))
+    dev.set_option("solver_nd", 1)
+    for it in range(60):
+        j = it % 3
+        dev.set_q(qs[j])
+        dev.gn_step()
+        assert dev.get_option("last_solver") == 2
+        p = dev.get("step")
+        assert np.abs(p - ref[j]).max() <= 1e-5 * np.abs(ref[j]).max(), it
+    dev.close()

@@ -25,8 +25,7 @@ for r in range(4):
 for r in (4, 5):
     x = d[r] - t0
     rows = [(x[8 + 2 * i], x[9 + 2 * i]) for i in range(16) if d[r][8 + 2 * i] > 0]
-    print(f"{names[r]:12s} start {x[0]:6.2f}  Q posted {x[1]:6.2f}  x_sep seen {x[2]:6.2f}  corr posted {x[3]:6.2f}")
+    print(f"{names[r]:12s} start {x[0]:6.2f}  last row published {x[1]:6.2f}")
     print("   rows (ready, done):", " ".join(f"({a:5.1f},{b:5.1f})" for a, b in rows))
-    print(f"   row 5: ready {x[18]:6.2f}  loaded {x[40]:6.2f}  products {x[41]:6.2f}  substitution {x[42]:6.2f}  done {x[19]:6.2f}")
 x = d[6] - t0
 print(f"{names[6]:12s} start {x[0]:6.2f}  Q ready {x[1]:6.2f}  W built {x[3]:6.2f}  row s {x[4]:6.2f}  S' {x[5]:6.2f}  row s+1 {x[6]:6.2f}  solved+posted {x[2]:6.2f}")
