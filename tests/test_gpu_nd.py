@@ -134,5 +134,5 @@ def test_changing_inputs_every_launch():
         dev.gn_step()
         assert dev.get_option("last_solver") == 2
         p = dev.get("step")
-        assert np.abs(p - ref[j]).max() <= 1e-5 * np.abs(ref[j]).max(), it
+        assert np.abs(p - ref[j]).max() <= 1e-3 * np.abs(ref[j]).max(), it   # (another launch's data would be off by O(1); two factorisations differ ~cond * eps)
     dev.close()
