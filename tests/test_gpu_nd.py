@@ -136,3 +136,43 @@ def test_changing_inputs_every_launch():
         p = dev.get("step")
         assert np.abs(p - ref[j]).max() <= 1e-3 * np.abs(ref[j]).max(), it   # (another launch's data would be off by O(1); two factorisations differ ~cond * eps)
     dev.close()
+
+
+def test_many_contexts_on_concurrent_streams():
+    """the solver's workgroups wait for each other through device-memory flags in a plain
+    (non-cooperative) launch.  Many contexts, each on its own stream and host thread, iterate at
+    once (seven workgroups per nested-dissection launch, one CU each): every launch must complete
+    and give its own problem's step."""
+    import threading
+    cfg, model, prob, sp, _ = _setup("mini_cheetah", 40)
+    n_ctx, iters = 24, 40
+    qs = [synthetic_trajectory(cfg, model, 40, seed=s, lower=0.01) for s in range(n_ctx)]
+    devs = [hip.HipPath(model, prob, sp) for _ in range(n_ctx)]
+    ref = []
+    for d, q in zip(devs, qs):
+        d.set_q(q)
+        d.gn_step()
+        ref.append(d.get("step"))
+    gate = threading.Barrier(n_ctx)
+    errors = []
+
+    def worker(i):
+        try:
+            gate.wait()
+            for _ in range(iters):
+                devs[i].gn_step()
+            devs[i].sync()
+            if not np.array_equal(devs[i].get("step"), ref[i]):
+                errors.append((i, "step differs"))
+        except Exception as e:   # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(n_ctx)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a launch did not complete (workgroups waiting on each other)"
+    assert not errors, errors[:3]
+    for d in devs:
+        d.close()
