@@ -184,6 +184,7 @@ struct ChainCfg {
   unsigned long long rowcnt_unit;   // what one wavefront adds
   double* rtpub;                    // [local row][K]
   const double* fst; int fstride;   // the spike workgroup's rows [Ft_il | rt_il] (K rows, column stride ks)
+  const unsigned long long* frowcnt; unsigned long long frowtarget;   // ... and their per-row release counters
   const double* xsep;               // [x_s | x_{s+1}] once *sepflag == epoch
   unsigned* sepflag;
   double* ts;                       // optional wall-clock stamps (100 MHz): start, join reached, forward done, backward start, end
@@ -708,7 +709,17 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
   if (cfg.fst) {
     // nested dissection: this chain's rows also couple to the separator.  Once it is solved,
     // rt_il -= Ft_il [x_near ; x_far] with the eliminated coupling blocks Ft_il the spike workgroup
-    // left in HBM (columns 0..K-1: the separator row next to this chain's first row)
+    // left in HBM (columns 0..K-1: the separator row next to this chain's first row).  The rows of
+    // Ft are fetched while the separator is still being eliminated (this workgroup is idle then).
+    const int pidx = (tid < nloc * K) ? tid : 0, pil = pidx / K, pr = pidx - pil * K;
+    while (__hip_atomic_load(cfg.frowcnt + pil, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cfg.frowtarget) __builtin_amdgcn_s_sleep(2);
+    (void)__hip_atomic_load(cfg.frowcnt + pil, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    double f[2 * K];
+    {
+      const double* F = cfg.fst + (size_t)pil * cfg.fstride + pr;
+#pragma unroll
+      for (int c = 0; c < 2 * K; ++c) f[c] = F[c * ks];
+    }
     if (tid == 0)
       while (__hip_atomic_load(cfg.sepflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
     __syncthreads();
@@ -719,15 +730,18 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
       xs[c] = cfg.xsep[(mirror ? half : 1 - half) * K + r];   // mirrored chain: nearest = s, else nearest = s + 1
     }
     __syncthreads();
-    for (int idx = tid; idx < nloc * K; idx += nt) {
-      const int il = idx / K, r = idx - il * K;
-      const double* F = cfg.fst + (size_t)il * cfg.fstride + r;
-      double f[2 * K];
-#pragma unroll
-      for (int c = 0; c < 2 * K; ++c) f[c] = F[c * ks];   // all loads in flight before the sum
+    if (tid < nloc * K) {
       double acc = 0.0;
 #pragma unroll
       for (int c = 0; c < 2 * K; ++c) acc = __builtin_fma(f[c], xs[c], acc);
+      lds[L.xall + (pil + 2) * ks + pr] -= acc;
+    }
+    for (int idx = tid + nt; idx < nloc * K; idx += nt) {   // (more rows than threads: the rest, unprefetched)
+      const int il = idx / K, r = idx - il * K;
+      const double* F = cfg.fst + (size_t)il * cfg.fstride + r;
+      double acc = 0.0;
+#pragma unroll
+      for (int c = 0; c < 2 * K; ++c) acc = __builtin_fma(F[c * ks], xs[c], acc);
       lds[L.xall + (il + 2) * ks + r] -= acc;
     }
     __syncthreads();

@@ -269,12 +269,11 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
     nd_ts(A, 4 + w, 9 + 2 * il);
     if (il + 1 < nloc && !prefetched) { wait_row(il + 1); issue(il + 1); }
   }
+  // (row nloc-2 was stored before the barrier that ended the loop: released while the last row is stored)
+  if (nloc >= 2 && tid == 192) __hip_atomic_fetch_add(frow + (nloc - 2), 3ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   publish(nloc - 1, 0, 256);
   __syncthreads();
-  if (tid == 0) {
-    if (nloc >= 2) __hip_atomic_fetch_add(frow + (nloc - 2), 3ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(frow + (nloc - 1), 3ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (tid == 0) __hip_atomic_fetch_add(frow + (nloc - 1), 3ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   nd_ts(A, 4 + w, 1);
 }
 
@@ -538,6 +537,7 @@ __global__ void __launch_bounds__(256) penta_nd_kernel(NdArgs A) {
     c.rowcnt = A.rowcnt + w * ND_MAXROWS; c.rowcnt_unit = 1ull;
     c.rtpub = A.ndbuf + B.rtpub + (size_t)w * ND_MAXROWS * K;
     c.fst = A.ndbuf + B.fst + (size_t)w * ND_MAXROWS * B.frow; c.fstride = B.frow;
+    c.frowcnt = A.rowcnt + (2 + w) * ND_MAXROWS; c.frowtarget = (A.rowtarget / A.rowunit) * 3ull;
     c.xsep = A.ndbuf + B.xsep; c.sepflag = A.flags + 4;
   }
   constexpr int GW = ((2 * K + 1) + (64 - K) - 1) / (64 - K);
