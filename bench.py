@@ -341,6 +341,8 @@ def main():
         names = list(KERNELS)
         if dev.get_option("last_solver") == 2:   # nested dissection over seven workgroups (csrc/penta_nd.h)
             names[2] = "penta_nd_kernel"
+        if dev.get_option("last_assembly") == 1:   # products formed by fd_kernel, combined here (kernels.h)
+            names[1] = "assemble_terms_kernel"
         dur_s = kern[dom][0] * 1e-3
         achieved = algb[dom] / dur_s / 1e9 if dur_s > 0 else 0.0
         traffic, traffic_src = pmc_traffic(names[dom])

@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256) gn_fused_kernel(FusedArgs A) {
   const int nasm = 4 * A.nrows;
   fused_stamp(A.dbg, 0);
   if (bx < A.nfd) {
-    fd_body<MAXC>(A.M, A.cp, A.P, A.q, A.slab, A.slab_stride, A.v, A.a, A.nplus, bx, A.fd_mode, 0, A.fd_echunk);
+    fd_body<MAXC>(A.M, A.cp, A.P, A.q, A.slab, A.slab_stride, A.v, A.a, A.nplus, bx, A.fd_mode, 0, A.fd_echunk, nullptr);
     fused_stamp(A.dbg, 1);
     fused_signal(A.sync);
     fused_stamp(A.dbg, 2);

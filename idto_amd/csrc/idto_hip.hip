@@ -76,6 +76,11 @@ struct idto_hip_ctx {
   std::vector<char> prob_diag;            // per problem of the batch
   bool reference_solver = false;  // bit-exact pivoted-LU block Thomas (kernels.h penta_kernel)
   int asm_diag_lds = 0;
+  int asm_terms_lds = 0;
+  double* terms = nullptr;                // per-record assembly products written by fd_kernel (asm_terms_stride)
+  bool asm_fold = true;                   // option "asm_fold": fd_kernel forms them, assemble_terms_kernel combines
+  bool terms_valid = false;               // ... and they belong to the resident slab, for every k
+  int last_assembly = 0;                  // 1 assemble_terms_kernel, 2 assemble_diag_kernel, 3 assemble_kernel
   // launch geometry
   int fd_threads = 256, fd_lds = 0, asm_lds = 0, penta_lds = 0, solve_lds = 0, cost_lds = 0;
   // timing
@@ -324,10 +329,15 @@ int FdEvals(const idto_hip_ctx* c, int mode) {
 }
 
 // dynamic LDS of fd_kernel when it builds the inputs of `ec` evaluations per pass
-int FdLds(const idto_hip_ctx* c, int mode, int ec) {
-  const int nq = c->nq, nv = c->nv, E = FdEvals(c, mode);
-  return (int)sizeof(double) * (3 * nq + 2 * nv * nq + 3 * nv + E + E * nv + ec * (nq + 2 * nv) + nv + c->M.blob_n + 2 + nq / 2 + 2);
+int FdLds(const idto_hip_ctx* c, int mode, int ec, bool with_terms = false) {
+  const int nq = c->nq, nv = c->nv, E = FdEvals(c, mode), nvp = (nv + 1) & ~1;
+  const int rec = with_terms ? 6 * nvp * nq + nvp + asm_terms_stride(nq) + 1 : 0;   // the record, its weighted copy, diag R', the products (+1: 16-byte alignment)
+  return (int)sizeof(double) * (3 * nq + 2 * nv * nq + 3 * nv + E + E * nv + ec * (nq + 2 * nv) + nv + c->M.blob_n + 2 + nq / 2 + 2 + rec);
 }
+
+// fd_kernel also forms the single-record products of the Gauss-Newton assembly (diagonal weights,
+// derivatives requested): grad_hess then only combines them
+static bool FoldTerms(const idto_hip_ctx* c, int mode) { return c->asm_fold && c->weights_diagonal && mode >= 1; }
 
 int LaunchFd(idto_hip_ctx* c, int mode, int kb, int ke) {
   if (ke <= kb) return 0;
@@ -337,12 +347,16 @@ int LaunchFd(idto_hip_ctx* c, int mode, int kb, int ke) {
   // the number of evaluations the block runs concurrently
   const int E = FdEvals(c, mode), groups = (int)block.x / c->npaths;
   int ec = E;
-  while (ec > groups && FdLds(c, mode, ec) > 160 * 1024) ec = ((ec - 1) / groups) * groups;
-  const int lds = FdLds(c, mode, ec);
+  bool fold = FoldTerms(c, mode);
+  if (fold && FdLds(c, mode, std::min(ec, groups), true) > 160 * 1024) fold = false;
+  while (ec > groups && FdLds(c, mode, ec, fold) > 160 * 1024) ec = ((ec - 1) / groups) * groups;
+  const int lds = FdLds(c, mode, ec, fold);
   if (lds > 160 * 1024) { g_err = "finite-difference evaluation set does not fit in LDS"; return -1; }
+  double* terms = fold ? c->terms : nullptr;
+  if (mode >= 1) c->terms_valid = fold && kb == 0 && ke == c->N;
 #define FD_LAUNCH(MC)                                                                                         \
   hipLaunchKernelGGL(fd_kernel<MC>, grid, block, lds, c->stream, c->M, c->cp, c->P, c->q, c->slab,             \
-                     c->slab_stride, c->v, c->a, c->nplus, kb, mode, c->fd_stop, ec, c->pstride)
+                     c->slab_stride, c->v, c->a, c->nplus, kb, mode, c->fd_stop, ec, c->pstride, terms)
   if (c->maxc <= 2) FD_LAUNCH(2);
   else if (c->maxc <= 3) FD_LAUNCH(3);
   else if (c->maxc <= 4) FD_LAUNCH(4);
@@ -501,6 +515,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   const size_t nvars = (size_t)(N + 1) * nq;
   const size_t o_trD = carve(nvars, D), o_trg = carve(nvars, D), o_trw = carve(nvars, D), o_trdq = carve(nvars, D),
                o_qt = carve(nvars, D), o_trout = carve(16, D), o_trDp = carve(nvars, D), o_trpart = carve((size_t)9 * (N + 1), D);
+  const size_t o_terms = carve((size_t)N * asm_terms_stride(nq), D);
   c->pstride = (top + 255) & ~(size_t)255;
   {
     void* p = nullptr;
@@ -532,6 +547,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   c->nd_buf = dp(o_ndbuf);
   c->tr_D = dp(o_trD); c->tr_gt = dp(o_trg); c->tr_w = dp(o_trw); c->tr_dq = dp(o_trdq); c->q_trial = dp(o_qt);
   c->tr_out = dp(o_trout); c->tr_Dprev = dp(o_trDp); c->tr_part = dp(o_trpart);
+  c->terms = dp(o_terms);
   {  // adaptive scaling methods start from D = 1 (TO.cc:1233-1236: scale_factors initialised to ones)
     std::vector<double> ones(nvars, 1.0);
     for (int b = 0; b < batch; ++b)
@@ -574,6 +590,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   c->fd_lds = FdLds(c, 1, threads / K);
   c->asm_lds = (int)sizeof(double) * (3 * nq + 5 * (int)bsz + 4 * nv + nq + std::max(nq, nv) + (int)bsz + 3 * (int)qq + nq);
   c->asm_diag_lds = (int)sizeof(double) * (14 * ((nv + 1) & ~1) * nq + 2 * (int)bsz + 10 * nv + 6 * nq + 2);
+  c->asm_terms_lds = (int)sizeof(double) * (5 * ((nv + 1) & ~1) * nq + 4 * nv + nq + 2);
   const int n = N + 1;
   c->penta_lds = (int)sizeof(double) * (10 * (int)qq + nq * (3 * nq + 1) + (n + 2) * nq + nq) + (int)sizeof(int) * nq + 16;
   c->solve_lds = (int)sizeof(double) * ((n + 2) * nq + nq);
@@ -599,6 +616,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cost_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_terms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
 #define APPLY_ATTR(KM) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_apply_kernel<KM>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   APPLY_ATTR(2) APPLY_ATTR(3) APPLY_ATTR(5) APPLY_ATTR(8) APPLY_ATTR(16) APPLY_ATTR(19) APPLY_ATTR(23) APPLY_ATTR(24) APPLY_ATTR(32)
 #undef APPLY_ATTR
@@ -621,6 +639,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   if (const char* e = getenv("IDTO_TWO_SIDED")) c->two_sided = (e[0] == '1');   // (debugging aids: option defaults)
   if (const char* e = getenv("IDTO_FUSED")) c->fused = (e[0] == '1');
   if (const char* e = getenv("IDTO_SOLVER_ND")) c->solver_nd = (e[0] == '1');
+  if (const char* e = getenv("IDTO_ASM_FOLD")) c->asm_fold = (e[0] == '1');
   (void)hipGetLastError();
   *out = c;
   return 0;
@@ -766,7 +785,12 @@ int idto_hip_grad_hess(idto_hip_ctx* c) {
   }
   c->con_ready = false; c->con_begun = false;
   if (TimeBegin(c, 1)) return -2;
-  if (c->weights_diagonal)
+  const bool combine = c->weights_diagonal && c->terms_valid && c->fd_full && c->asm_stop == 0;
+  c->last_assembly = combine ? 1 : (c->weights_diagonal ? 2 : 3);
+  if (combine)
+    hipLaunchKernelGGL(assemble_terms_kernel, dim3(c->N + 1, 4, c->batch), dim3(256), c->asm_terms_lds, c->stream, c->M, c->P,
+                       c->q, c->terms, c->v, c->nplus, c->g, c->HA, c->HB, c->HC, c->pstride);
+  else if (c->weights_diagonal)
     hipLaunchKernelGGL(assemble_diag_kernel, dim3(c->N + 1, 4, c->batch), dim3(256), c->asm_diag_lds, c->stream, c->M,
                        c->P, c->q, c->slab, c->slab_stride, c->g, c->HA, c->HB, c->HC, c->asm_stop,
                        c->fd_full ? c->v : nullptr, c->fd_full ? c->nplus : nullptr, c->pstride);
@@ -975,6 +999,7 @@ static int LaunchFused(idto_hip_ctx* c) {
 #undef FUSED_LAUNCH
   HIP_OK(hipGetLastError());
   c->fd_full = true;
+  c->terms_valid = false;   // (the fused kernel assembles from the slab itself)
   return TimeEnd(c);
 }
 
@@ -1429,6 +1454,8 @@ int idto_hip_gn_step_multi(idto_hip_ctx** ctxs, int n) {
 int idto_hip_get_option(idto_hip_ctx* c, const char* name, int* value) {
   if (std::strcmp(name, "last_solver") == 0) { *value = c->last_solver; return 0; }
   if (std::strcmp(name, "solver_nd") == 0) { *value = c->solver_nd; return 0; }
+  if (std::strcmp(name, "asm_fold") == 0) { *value = c->asm_fold; return 0; }
+  if (std::strcmp(name, "last_assembly") == 0) { *value = c->last_assembly; return 0; }
   if (std::strcmp(name, "fused") == 0) { *value = c->fused; return 0; }
   if (std::strcmp(name, "two_sided") == 0) { *value = c->two_sided; return 0; }
   if (std::strcmp(name, "reference_solver") == 0) { *value = c->reference_solver; return 0; }
@@ -1443,6 +1470,7 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "two_sided") == 0) { c->two_sided = value != 0; return 0; }
   if (std::strcmp(name, "fused") == 0) { c->fused = value != 0; return 0; }
   if (std::strcmp(name, "solver_nd") == 0) { c->solver_nd = value != 0; return 0; }
+  if (std::strcmp(name, "asm_fold") == 0) { c->asm_fold = value != 0; c->terms_valid = false; return 0; }
   if (std::strcmp(name, "fused_debug") == 0) { c->fused_debug = value != 0; return 0; }
   if (std::strcmp(name, "asm_stop") == 0) { c->asm_stop = value; return 0; }  // profiling aid
   if (std::strcmp(name, "fd_stop") == 0) { c->fd_stop = value; return 0; }    // profiling aid
@@ -1507,6 +1535,7 @@ long idto_hip_array_size(idto_hip_ctx* c, int what) {
     case IDTO_ARR_HBANDS: return 3 * (N + 6) * qq;
     case 15: return (N + 4) * 8 * 32;
     case IDTO_ARR_TR_DQ: case IDTO_ARR_TR_W: case IDTO_ARR_TR_SCALE: return (N + 1) * nq;
+    case IDTO_ARR_ASM_TERMS: return N * (long)asm_terms_stride((int)nq);
     default: return -1;
   }
 }
@@ -1532,6 +1561,7 @@ void* DevPtr(idto_hip_ctx* c, int what) {
     case IDTO_ARR_TR_DQ: return c->tr_dq;
     case IDTO_ARR_TR_W: return c->tr_w;
     case IDTO_ARR_TR_SCALE: return c->tr_D;
+    case IDTO_ARR_ASM_TERMS: return c->terms;
     default: return nullptr;  // tau and the three partials live strided inside the slab
   }
 }
@@ -1544,6 +1574,7 @@ void* idto_hip_device_ptr(idto_hip_ctx* c, int what) {
   // until idto_hip_grad_hess assembles it again
   if (what == IDTO_ARR_H_A || what == IDTO_ARR_H_B || what == IDTO_ARR_H_C || what == IDTO_ARR_HBANDS)
     c->h_assembled = false;
+  if (what == IDTO_ARR_SLAB) c->terms_valid = false;   // (records written from outside: assemble from the slab)
   return DevPtr(c, what);
 }
 

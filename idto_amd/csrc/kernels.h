@@ -138,6 +138,100 @@ IDTO_DEV void velocity_block(const DevModel& M, const double* N, const double* q
   }
 }
 
+// sum_l A[l] * B[l], l ascending, products and sums rounded separately (no FMA): THE inner product
+// of the Hessian assembly (columns of nv entries, 16-byte aligned, column stride a multiple of 2)
+IDTO_DEV double asm_dot(const double* A, const double* B, int nv) {
+  const double2* A2 = reinterpret_cast<const double2*>(A);
+  const double2* B2 = reinterpret_cast<const double2*>(B);
+  double2 a = A2[0], b = B2[0];
+  double acc = a.x * b.x;
+  if (nv > 1) acc = acc + a.y * b.y;
+  const int np = nv >> 1;
+#pragma unroll 4
+  for (int m = 1; m < np; ++m) {
+    a = A2[m]; b = B2[m];
+    acc = acc + a.x * b.x;
+    acc = acc + a.y * b.y;
+  }
+  if ((nv & 1) && nv > 1) acc = acc + A[nv - 1] * B[nv - 1];
+  return acc;
+}
+// U independent asm_dot chains in lockstep (each one the same operations in the same order as
+// asm_dot: same bits)
+template <int U>
+IDTO_DEV void asm_dot_n(const double* const (&A)[U], const double* const (&B)[U], int nv, double (&acc)[U]) {
+  const int np = nv >> 1;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const double2 a = reinterpret_cast<const double2*>(A[u])[0], b = reinterpret_cast<const double2*>(B[u])[0];
+    acc[u] = a.x * b.x;
+    if (nv > 1) acc[u] = acc[u] + a.y * b.y;
+  }
+#pragma unroll 2
+  for (int m = 1; m < np; ++m) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const double2 a = reinterpret_cast<const double2*>(A[u])[m], b = reinterpret_cast<const double2*>(B[u])[m];
+      acc[u] = acc[u] + a.x * b.x;
+      acc[u] = acc[u] + a.y * b.y;
+    }
+  }
+  if ((nv & 1) && nv > 1) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = acc[u] + A[u][nv - 1] * B[u][nv - 1];
+  }
+}
+// TB x TB asm_dot values acc[ur][uc] = asm_dot(A[ur], B[uc]) from 2 TB operand reads per step instead
+// of 2 TB^2: the products are bound by LDS bandwidth (two 16-byte reads per two multiply-adds), a
+// register tile reads each operand once for TB results.  Same operations per entry: same bits.
+template <int TB>
+IDTO_DEV void asm_dot_tile(const double* const (&A)[TB], const double* const (&B)[TB], int nv, double (&acc)[TB][TB]) {
+  const int np = nv >> 1;
+  double2 a[TB], b[TB];
+#pragma unroll
+  for (int u = 0; u < TB; ++u) {
+    a[u] = reinterpret_cast<const double2*>(A[u])[0];
+    b[u] = reinterpret_cast<const double2*>(B[u])[0];
+  }
+#pragma unroll
+  for (int ur = 0; ur < TB; ++ur)
+#pragma unroll
+    for (int uc = 0; uc < TB; ++uc) {
+      acc[ur][uc] = a[ur].x * b[uc].x;
+      if (nv > 1) acc[ur][uc] = acc[ur][uc] + a[ur].y * b[uc].y;
+    }
+  for (int m = 1; m < np; ++m) {
+#pragma unroll
+    for (int u = 0; u < TB; ++u) {
+      a[u] = reinterpret_cast<const double2*>(A[u])[m];
+      b[u] = reinterpret_cast<const double2*>(B[u])[m];
+    }
+#pragma unroll
+    for (int ur = 0; ur < TB; ++ur)
+#pragma unroll
+      for (int uc = 0; uc < TB; ++uc) {
+        acc[ur][uc] = acc[ur][uc] + a[ur].x * b[uc].x;
+        acc[ur][uc] = acc[ur][uc] + a[ur].y * b[uc].y;
+      }
+  }
+  if ((nv & 1) && nv > 1) {
+#pragma unroll
+    for (int ur = 0; ur < TB; ++ur)
+#pragma unroll
+      for (int uc = 0; uc < TB; ++uc) acc[ur][uc] = acc[ur][uc] + A[ur][nv - 1] * B[uc][nv - 1];
+  }
+}
+
+// Per tau-index k, the products of the Gauss-Newton assembly that involve record k ONLY
+// (TO.cc:1127-1153, :1064-1068, with R' = 2 dt R diagonal), formed by the finite-difference
+// workgroup that has the record in LDS (fd_body, `terms` != nullptr):
+//   CP = P_k^T R' P_k -> C_{k+1}   CT = T_k^T R' T_k -> C_k   CM = M_k^T R' M_k -> C_{k-1}   (lower triangles)
+//   BPT = P_k^T R' T_k -> B_{k+1}  BTM = T_k^T R' M_k -> B_k  APM = P_k^T R' M_k -> A_{k+1}
+//   gP = P_k^T R' tau_k -> g_{k+1} gT = T_k^T R' tau_k -> g_k gM = M_k^T R' tau_k -> g_{k-1}
+// assemble_terms_kernel adds them in the reference's order.  Each entry is the very expression
+// assemble_diag_kernel evaluates (asm_dot on the weighted column), so both paths give the same bits.
+__host__ __device__ inline int asm_terms_stride(int nq) { return 6 * nq * nq + 3 * nq + ((3 * nq) & 1); }
+
 // ---------------------------------------------------------------------------
 // fd_kernel: block <-> tau index k.  Produces slab_k = [dtau_k/dq_{k-1} |
 // dtau_k/dq_k | dtau_k/dq_{k+1} | tau_k] plus v_{k+1}, a_k, N+_{k+1}.
@@ -147,7 +241,7 @@ template <int MAXC>
 IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem& P, const double* __restrict__ q,
                       double* __restrict__ slab, int slab_stride, double* __restrict__ v_out,
                       double* __restrict__ a_out, double* __restrict__ nplus_out, const int k, int mode,
-                      int stop_after, int echunk) {
+                      int stop_after, int echunk, double* __restrict__ terms) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int nq = M.nq, nv = M.nv, K = M.npaths;
@@ -184,8 +278,17 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
   double* edump = ea + EC * nv; // [nv] write-only dump row for surplus lanes
   double* mblob = edump + nv;    // [M.blob_n] the model tables
   int* colinfo = reinterpret_cast<int*>(mblob + M.blob_n + (M.blob_n & 1));  // [nq] non-zero rows of N+ column c
+  // (terms != nullptr) the record and its weighted copy for the assembly products: 6 blocks of nq
+  // columns, column stride nvp (16-byte aligned columns), + tau_k R' and the diagonal of R'
+  const int nvp = (nv + 1) & ~1, psz = nvp * nq;
+  // (16-byte aligned: asm_dot reads double2; a misaligned ds_read_b128 costs ~250 cycles per instruction)
+  double* rec = reinterpret_cast<double*>(colinfo + nq + (nq & 1));   // [P | T | M | P R' | T R' | M R'] then diag R'
+  rec += (rec - lds) & 1;
 
   // stage the model into LDS and use that copy from here on
+  double* wr = rec + 6 * psz;      // [nv] diagonal of R' (fetched now: an HBM round trip off the tail's critical path)
+  if (terms && mode != 0)
+    for (int l = tid; l < nv; l += nt) wr[l] = P.R[l * nv + l];
   for (int i = tid; i < M.blob_n; i += nt) mblob[i] = M.blob[i];
   for (int i = tid; i < nq; i += nt) {
     qm1[i] = (k > 0) ? q[(k - 1) * nq + i] : 0.0;
@@ -321,9 +424,12 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
   if (mode == 1) {
     for (int idx = tid; idx < bsz; idx += nt) {
       const int i = idx / nv, r = idx - i * nv;
-      Pk[idx] = (etau[(1 + i) * nv + r] - etau[r]) / edq[1 + i];                      // TO.cc:531
-      Tk[idx] = (k >= 1) ? (etau[(1 + nP + i) * nv + r] - etau[r]) / edq[1 + nP + i]  // TO.cc:539
-                         : 0.0;
+      const double pv = (etau[(1 + i) * nv + r] - etau[r]) / edq[1 + i];                      // TO.cc:531
+      const double tv = (k >= 1) ? (etau[(1 + nP + i) * nv + r] - etau[r]) / edq[1 + nP + i]  // TO.cc:539
+                                 : 0.0;
+      Pk[idx] = pv;
+      Tk[idx] = tv;
+      if (terms) { rec[i * nvp + r] = pv; rec[psz + i * nvp + r] = tv; }
     }
     // dtau_k/dq_{k-1} = (1/dt^2) M(q_{k+1}) N+_k   (TO.cc:556-561)
     if (k >= 2) {
@@ -336,10 +442,14 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
         double acc = (sc * Mcols[j0 * nv + r]) * N0[c * nv + j0];
         for (int j = j0 + 1; j < j0 + cnt; ++j) acc += (sc * Mcols[j * nv + r]) * N0[c * nv + j];
         Mk[idx] = acc;
+        if (terms) rec[2 * psz + c * nvp + r] = acc;
       }
     } else {
       const double fill = (k == 0) ? __builtin_nan("") : 0.0;
-      for (int idx = tid; idx < bsz; idx += nt) Mk[idx] = fill;
+      for (int idx = tid; idx < bsz; idx += nt) {
+        Mk[idx] = fill;
+        if (terms) rec[2 * psz + (idx / nv) * nvp + idx % nv] = 0.0;   // (never used by the assembly for k < 2)
+      }
     }
   } else if (central) {
     // (tau(+) - tau(-)) / (2 dq), or the five-point formula, in the reference's expression order
@@ -355,21 +465,88 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
         const double tpp = etau[(e0 + 2 * nq) * nv + r], tmm = etau[(e0 + 3 * nq) * nv + r];
         d = 2.0 / 3.0 * (tp - tm) / dq - 1.0 / 12.0 * (tpp - tmm) / dq;
       }
-      if (g == 0) Pk[rem] = d;
-      else if (g == 1) Tk[rem] = (k >= 1) ? d : 0.0;
-      else Mk[rem] = (k >= 2) ? d : ((k == 0) ? __builtin_nan("") : 0.0);
+      const double val = (g == 0) ? d : ((g == 1) ? ((k >= 1) ? d : 0.0) : ((k >= 2) ? d : ((k == 0) ? __builtin_nan("") : 0.0)));
+      if (g == 0) Pk[rem] = val;
+      else if (g == 1) Tk[rem] = val;
+      else Mk[rem] = val;
+      if (terms) rec[g * psz + i * nvp + r] = (g == 2 && k < 2) ? 0.0 : val;
     }
   }
+  if (!terms || mode == 0 || stop_after == 4) return;
+  // ---- the assembly products of this record (see asm_terms_stride)
+  __syncthreads();
+  for (int idx = tid; idx < 3 * psz; idx += nt) {
+    const int l = idx % nvp;
+    rec[3 * psz + idx] = (l < nv) ? rec[idx] * wr[l] : 0.0;   // (A^T W)(r, l) = A(l, r) w_l, as assemble_diag_kernel forms it
+  }
+  __syncthreads();
+  if (stop_after == 5) return;
+  const int qq = nq * nq, ts = asm_terms_stride(nq);
+  double* stage = wr + nvp;   // [ts] the products in their HBM order (written out coalesced below)
+  // 3 x 3 register tiles: the lower-triangle tiles of CP, CT, CM, then all tiles of
+  // BPT = (P R')^T T, BTM = (T R')^T M, APM = (P R')^T M  (one round of 231 tiles at nq = 19)
+  constexpr int TB = 3;
+  const int nb = (nq + TB - 1) / TB, ntt = nb * (nb + 1) / 2, nbb = nb * nb, ntiles = 3 * ntt + 3 * nbb;
+  const float inb = 1.0f / (float)nb;
+  for (int tile = tid; tile < ntiles; tile += nt) {
+    if (stop_after == 6 && tile >= 3 * ntt) break;
+    int xa, sb, tr, tc, ob;
+    const bool lower = tile < 3 * ntt;
+    if (lower) {
+      const int which = (tile >= ntt) + (tile >= 2 * ntt);
+      int rem = tile - which * ntt;
+      tc = 0;
+      while (rem >= nb - tc) { rem -= nb - tc; ++tc; }
+      tr = tc + rem;
+      xa = which; sb = which; ob = which * qq;
+    } else {
+      const int it = tile - 3 * ntt, which = (it >= nbb) + (it >= 2 * nbb), e = it - which * nbb;
+      tc = (int)(((float)e + 0.5f) * inb);   // e / nb (exact: e < 2^12)
+      tr = e - tc * nb;
+      xa = (which == 1) ? 1 : 0; sb = (which == 0) ? 1 : 2; ob = (3 + which) * qq;
+    }
+    const double* A[TB];
+    const double* B[TB];
+#pragma unroll
+    for (int u = 0; u < TB; ++u) {   // (rows / columns past the edge: recompute the last one, not stored)
+      const int r = tr * TB + u, c = tc * TB + u;
+      A[u] = rec + (3 + xa) * psz + (r < nq ? r : nq - 1) * nvp;
+      B[u] = rec + sb * psz + (c < nq ? c : nq - 1) * nvp;
+    }
+    double acc[TB][TB];
+    asm_dot_tile<TB>(A, B, nv, acc);
+#pragma unroll
+    for (int ur = 0; ur < TB; ++ur)
+#pragma unroll
+      for (int uc = 0; uc < TB; ++uc) {
+        const int r = tr * TB + ur, c = tc * TB + uc;
+        if (r < nq && c < nq && (!lower || r >= c)) stage[ob + c * nq + r] = acc[ur][uc];
+      }
+  }
+  if (stop_after != 7)
+    for (int it = nt - 1 - tid; it < 3 * nq; it += nt) {   // gP, gT, gM: sum_r (tau_r w_r) J[r][j]  (threads without a tile first)
+      const int which = (it >= nq) + (it >= 2 * nq), j = it - which * nq;
+      const double* J = rec + which * psz + j * nvp;
+      double acc = (etau[0] * wr[0]) * J[0];
+      for (int r = 1; r < nv; ++r) acc += (etau[r] * wr[r]) * J[r];
+      stage[6 * qq + which * nq + j] = acc;
+    }
+  __syncthreads();
+  // (the strict upper triangles of CP, CT, CM are never read: whatever LDS held goes out with the rest)
+  double2* out2 = reinterpret_cast<double2*>(terms + (size_t)k * ts);   // ts is even, the buffer 16-byte aligned
+  const double2* st2 = reinterpret_cast<const double2*>(stage);
+  for (int idx = tid; idx < ts / 2; idx += nt) out2[idx] = st2[idx];
 }
 
 template <int MAXC>
 __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevProblem P, const double* __restrict__ q,
                           double* __restrict__ slab, int slab_stride, double* __restrict__ v_out,
                           double* __restrict__ a_out, double* __restrict__ nplus_out, int k_begin, int mode,
-                          int stop_after, int echunk, size_t pstride) {
+                          int stop_after, int echunk, size_t pstride, double* __restrict__ terms) {
   const size_t o = (size_t)blockIdx.y * pstride;  // problem of the batch
   fd_body<MAXC>(M, cp, at_problem(P, o), at_problem(q, o), at_problem(slab, o), slab_stride, at_problem(v_out, o),
-                at_problem(a_out, o), at_problem(nplus_out, o), k_begin + (int)blockIdx.x, mode, stop_after, echunk);
+                at_problem(a_out, o), at_problem(nplus_out, o), k_begin + (int)blockIdx.x, mode, stop_after, echunk,
+                terms ? at_problem(terms, o) : nullptr);
 }
 
 // ---------------------------------------------------------------------------
@@ -864,6 +1041,161 @@ assemble_diag_kernel(DevModel M, DevProblem P, const double* __restrict__ q, con
                      at_problem(HA, o), at_problem(HB, o), at_problem(HC, o), stop_after,
                      v_res ? at_problem(v_res, o) : nullptr, nplus_res ? at_problem(nplus_res, o) : nullptr,
                      (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// ---------------------------------------------------------------------------
+// assemble_terms_kernel: block row i of g and H from the per-record products the finite-difference
+// workgroups left in HBM (asm_terms_stride) plus the velocity terms (N+ / dt, formed here: they
+// are sparse and cheap).  Same sums in the same order as assemble_diag_kernel - the entries of CP,
+// CT, ... ARE its term() values - so the results are bit-identical; what is gone is the staging of
+// six dtau/dq blocks per workgroup, four workgroups per block row (3.1 MB of fetches for 0.7 MB of
+// data, and 12 us of mostly operand staging on the critical path of the iteration).
+// Grid (N + 1, 4, batch): part 0 C_i and the gradient block, 1 / 2 the column halves of B_i, 3 A_i.
+__global__ void __launch_bounds__(256)
+assemble_terms_kernel(DevModel M, DevProblem P, const double* __restrict__ q, const double* __restrict__ terms,
+                      const double* __restrict__ v_res, const double* __restrict__ nplus_res, double* __restrict__ g,
+                      double* __restrict__ HA, double* __restrict__ HB, double* __restrict__ HC, size_t pstride) {
+  {
+    const size_t o = (size_t)blockIdx.z * pstride;
+    P = at_problem(P, o); q = at_problem(q, o); terms = at_problem(terms, o); v_res = at_problem(v_res, o);
+    nplus_res = at_problem(nplus_res, o); g = at_problem(g, o);
+    HA = at_problem(HA, o); HB = at_problem(HB, o); HC = at_problem(HC, o);
+  }
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int i = blockIdx.x, part = blockIdx.y, N = P.N, nq = M.nq, nv = M.nv;
+  const int bsz = nv * nq, qq = nq * nq;
+  const int nvp = (nv + 1) & ~1, psz = nvp * nq;
+  const double dt = P.dt;
+  double* Cg = HC + (size_t)i * qq;
+  double* Bg = HB + (size_t)i * qq;
+  double* Ag = HA + (size_t)i * qq;
+  if (i == 0) {
+    if (part == 0) {
+      for (int idx = tid; idx < qq; idx += nt) {
+        Cg[idx] = (idx / nq == idx % nq) ? 1.0 : 0.0;
+        Bg[idx] = 0.0;
+        Ag[idx] = 0.0;
+      }
+      for (int j = tid; j < nq; j += nt) g[j] = 0.0;
+    }
+    return;
+  }
+  const int ts = asm_terms_stride(nq);
+  const double* Tm1 = terms + (size_t)(i - 1) * ts;            // record i-1
+  const double* T0 = terms + (size_t)(i < N ? i : 0) * ts;     // record i   (i < N)
+  const double* Tp1 = terms + (size_t)(i < N - 1 ? i + 1 : 0) * ts;
+  if (part == 3) {   // A_i (TO.cc:1150-1153): P_{i-1}^T R' M_{i-1}, nothing to add
+    for (int e = tid; e < qq; e += nt) Ag[e] = (i >= 3) ? Tm1[5 * qq + e] : 0.0;
+    return;
+  }
+  // one round of loads: everything this part needs comes straight from HBM / L2 into its LDS form
+  enum { S_V = 0, S_W, S_W1, X_V, X_W1, S_COUNT };
+  double* ops = lds;                 // S_COUNT * psz
+  double* ve = ops + S_COUNT * psz;  // (v_i - vnom_i) * weight        (gradient)
+  double* vep = ve + nv;             // (v_{i+1} - vnom_{i+1}) * weight
+  const double idt = 1 / dt, midt = -1 / dt;
+  // weights of the V- and W1-terms depend on the row (TO.cc:1127-1161): Qv, or Qf_v at the end
+  const double* wV = (i < N) ? P.Qv : P.Qfv;
+  const double* wW1 = (i < N - 1) ? P.Qv : P.Qfv;
+  for (int idx = tid; idx < bsz; idx += nt) {
+    const int c = idx / nv, l = idx - c * nv, o = c * nvp + l;
+    const double n0 = nplus_res[(size_t)i * bsz + idx];
+    const double vv = idt * n0;
+    ops[S_V * psz + o] = vv;
+    if (part == 0) {
+      const double w1 = (i < N) ? midt * nplus_res[(size_t)(i + 1) * bsz + idx] : 0.0;
+      ops[S_W1 * psz + o] = w1;
+      ops[X_W1 * psz + o] = w1 * wW1[l * nv + l];
+      ops[X_V * psz + o] = vv * wV[l * nv + l];
+    } else {
+      ops[S_W * psz + o] = midt * n0;
+      ops[X_V * psz + o] = vv * wV[l * nv + l];
+    }
+  }
+  if (part == 0) {
+    for (int r = tid; r < nv; r += nt) {
+      ve[r] = v_res[i * nv + r] - P.v_nom[i * nv + r];
+      vep[r] = (i < N) ? v_res[(i + 1) * nv + r] - P.v_nom[(i + 1) * nv + r] : 0.0;
+    }
+  }
+  __syncthreads();
+  auto term = [&](int xa, int sb, int r, int c) { return asm_dot(ops + xa * psz + r * nvp, ops + sb * psz + c * nvp, nv); };
+  if (part == 0) {
+    // C_i, lower triangle (TO.cc:1127-1137 / :1157-1161), mirrored (MakeSymmetric); then the gradient
+    const int ntri = nq * (nq + 1) / 2;
+    for (int item = tid; item < ntri + nq; item += nt) {
+      if (item < ntri) {
+        int c = 0, rem = item;
+        while (rem >= nq - c) { rem -= nq - c; ++c; }
+        const int r = c + rem, e = c * nq + r;
+        const double w0 = (i < N) ? P.Qq[e] : P.Qfq[e];
+        const double tP = Tm1[e];                                   // P_{i-1}^T R' P_{i-1}
+        const double tT = (i < N) ? T0[qq + e] : 0.0;               // T_i^T R' T_i
+        const double tM = (i < N - 1) ? Tp1[2 * qq + e] : 0.0;      // M_{i+1}^T R' M_{i+1}
+        const double* const A2[2] = {ops + X_V * psz + r * nvp, ops + X_W1 * psz + r * nvp};
+        const double* const B2[2] = {ops + S_V * psz + c * nvp, ops + S_W1 * psz + c * nvp};
+        double tv[2];   // the V- and the W1-term, two chains in lockstep (W1 operands are zeros at i == N)
+        asm_dot_n<2>(A2, B2, nv, tv);
+        double out = w0;
+        out = out + tv[0];
+        out = out + tP;
+        if (i < N) {
+          out = out + tT;
+          if (i < N - 1) out = out + tM;
+          out = out + tv[1];
+        }
+        Cg[e] = out;
+        Cg[r * nq + c] = out;
+      } else {   // gradient block (TO.cc:1046-1080)
+        const int j = item - ntri;
+        const double gP = Tm1[6 * qq + j];                              // P_{i-1}^T R' tau_{i-1}
+        const double gT = (i < N) ? T0[6 * qq + nq + j] : 0.0;          // T_i^T R' tau_i
+        const double gM = (i < N - 1) ? Tp1[6 * qq + 2 * nq + j] : 0.0; // M_{i+1}^T R' tau_{i+1}
+        const double qej = q[i * nq + j] - P.q_nom[i * nq + j];
+        const double wq = (i < N) ? P.Qq[j * nq + j] : P.Qfq[j * nq + j];
+        // sum_r (e_r w_r) J[r][j] for the V- and the W1-term, two chains in lockstep
+        const double* JV = ops + S_V * psz + j * nvp;
+        const double* JW = ops + S_W1 * psz + j * nvp;
+        const double* WV = (i < N) ? P.Qv : P.Qfv;
+        const double* WW = (i == N - 1) ? P.Qfv : P.Qv;
+        double gv = (ve[0] * WV[0]) * JV[0], gw = (vep[0] * WW[0]) * JW[0];
+        for (int r = 1; r < nv; ++r) {
+          gv += (ve[r] * WV[r * nv + r]) * JV[r];
+          gw += (vep[r] * WW[r * nv + r]) * JW[r];
+        }
+        double gj;
+        if (i < N) {
+          gj = qej * wq;
+          gj = gj + gv;
+          gj = gj + gw;
+          gj = gj + gP;
+          gj = gj + gT;
+          if (i != N - 1) gj = gj + gM;
+        } else {
+          gj = gP;
+          gj = gj + qej * wq;
+          gj = gj + gv;
+        }
+        g[(size_t)i * nq + j] = gj;
+      }
+    }
+  } else {
+    // B_i (TO.cc:1140-1147): columns [c_lo, c_hi)
+    const int half = (nq + 1) / 2, c_lo = (part == 1) ? 0 : half, c_hi = (part == 1) ? half : nq;
+    for (int e = c_lo * nq + tid; e < c_hi * nq; e += nt) {
+      const int c = e / nq, r = e - c * nq;
+      double out = 0.0;
+      if (i >= 2) {
+        const double tPT = Tm1[3 * qq + e];                        // P_{i-1}^T R' T_{i-1}
+        const double tTM = (i < N) ? T0[4 * qq + e] : 0.0;         // T_i^T R' M_i
+        out = tPT;
+        if (i < N) out = out + tTM;
+        out = out + term(X_V, S_W, r, c);
+      }
+      Bg[e] = out;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------

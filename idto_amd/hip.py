@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libidto_hip.so")
 
 ARR = dict(q=0, v=1, a=2, tau=3, nplus=4, dtau_dqm=5, dtau_dqt=6, dtau_dqp=7, gradient=8, H_A=9, H_B=10, H_C=11,
-           step=12, cost=13, slab=14, debug=15, hbands=16, tr_dq=17, tr_w=18, tr_scale=19)
+           step=12, cost=13, slab=14, debug=15, hbands=16, tr_dq=17, tr_w=18, tr_scale=19, asm_terms=20)
 
 _lib = None
 

@@ -64,7 +64,8 @@ enum idto_hip_array {
                             (N+1 used, 5 trailing zero blocks: the solver's prefetch margin) */
   IDTO_ARR_TR_DQ = 17,   /* (N+1)*nq : the step dq of the last idto_hip_tr_trial */
   IDTO_ARR_TR_W = 18,    /* (N+1)*nq : w = D^-1 H^-1 (g + J^T lambda) of the last idto_hip_tr_prepare */
-  IDTO_ARR_TR_SCALE = 19 /* (N+1)*nq : scale factors D (CalcScaleFactors) */
+  IDTO_ARR_TR_SCALE = 19, /* (N+1)*nq : scale factors D (CalcScaleFactors) */
+  IDTO_ARR_ASM_TERMS = 20 /* N*(6 nq^2 + 3 nq (+1)) : per-record assembly products (kernels.h asm_terms_stride) */
 };
 
 const char* idto_hip_last_error(void);
