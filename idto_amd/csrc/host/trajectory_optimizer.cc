@@ -990,6 +990,34 @@ SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solu
   bool have = false, last_accepted = true;
   double S[9] = {0};
   int k = 0;
+  // every iteration enqueued at once, decisions on the device, one wait (idto_hip_tr_solve); the
+  // stepwise loop below serves the adaptive scalings and IDTO_OPT_STEPWISE=1
+  const bool resident_loop = params_.max_iterations > 0 && (scal == -1 || scal == 0 || scal == 2) &&
+                             !std::getenv("IDTO_OPT_STEPWISE");
+  if (resident_loop) {
+    const int iters = params_.max_iterations;
+    std::vector<double> rows((std::size_t)iters * IDTO_TR_ROW);
+    double Delta_end = Delta;
+    Check(idto_hip_tr_solve(hip_, iters, scal, params_.scaling ? 1 : 0, params_.normalize_quaternions ? 1 : 0, Delta,
+                            params_.Delta_max, eta, rows.data(), &Delta_end));
+    const double total = std::chrono::duration<double>(clock::now() - start_time).count();
+    double timed = 0.0;
+    for (int i = 1; i < iters; ++i) timed += (rows[(std::size_t)i * IDTO_TR_ROW + 10] - rows[(std::size_t)(i - 1) * IDTO_TR_ROW + 10]) * 1e-8;
+    for (; k < iters; ++k) {
+      const double* R = rows.data() + (std::size_t)k * IDTO_TR_ROW;
+      const int flags = (int)R[14];
+      if (flags & 3) throw FactorizationFailedError("idto_hip: the dogleg step is not finite");
+      if (flags & 4) throw std::runtime_error("step is not a descent direction (TO.cc:2531)");
+      const double iter_time = (k == 0) ? std::max(0.0, total - timed) : (R[10] - R[10 - IDTO_TR_ROW]) * 1e-8;
+      if (params_.verbose)
+        std::printf("| %6d | %8.3g | %7.2g | %7.3g | %10.5g | %10.5g | %10.4g | %10.4g |\n", k, R[0], R[1], R[2], iter_time,
+                    R[6] / R[0], R[7], R[8]);
+      stats->push_data(iter_time, R[0], 0, std::numeric_limits<double>::quiet_NaN(), R[1], R[3], R[4], R[5], R[2], R[6],
+                       R[7], R[8], R[0]);   // :2586-2598 (merit = cost without constraints)
+      last_accepted = R[9] != 0.0;
+    }
+    Delta = Delta_end;
+  }
   while (k < params_.max_iterations) {
     if (!have) {
       Check(idto_hip_gn_step(hip_));

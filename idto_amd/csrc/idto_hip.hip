@@ -145,6 +145,13 @@ struct idto_hip_ctx {
   // device-side trust-region bookkeeping (trust_region.h): scale factors, scaled merit gradient,
   // w = D^-1 H^-1 g_merit, the last step, the trial trajectory; [16] scalars on the device + pinned
   double *tr_Dprev = nullptr, *tr_part = nullptr;   // the adaptive scalings' previous D; per-block-row partial sums
+  // idto_hip_tr_solve: the iteration state and the arrival counter of tr_iter_kernel (device), the
+  // per-iteration statistics rows (device, grown on demand), a pinned staging area for both
+  double* tr_state = nullptr;
+  unsigned long long* tr_cnt = nullptr;
+  unsigned long long tr_target = 0;
+  double* tr_rows = nullptr;
+  int tr_rows_cap = 0;
   double *tr_D = nullptr, *tr_gt = nullptr, *tr_w = nullptr, *tr_dq = nullptr, *q_trial = nullptr, *tr_out = nullptr;
   double* tr_pin = nullptr;
   int* tr_quat = nullptr; int tr_nquat = 0;
@@ -516,6 +523,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   const size_t o_trD = carve(nvars, D), o_trg = carve(nvars, D), o_trw = carve(nvars, D), o_trdq = carve(nvars, D),
                o_qt = carve(nvars, D), o_trout = carve(16, D), o_trDp = carve(nvars, D), o_trpart = carve((size_t)9 * (N + 1), D);
   const size_t o_terms = carve((size_t)N * asm_terms_stride(nq), D);
+  const size_t o_trstate = carve(TRS_COUNT, D), o_trcnt = carve(1, sizeof(unsigned long long));
   c->pstride = (top + 255) & ~(size_t)255;
   {
     void* p = nullptr;
@@ -548,6 +556,8 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   c->tr_D = dp(o_trD); c->tr_gt = dp(o_trg); c->tr_w = dp(o_trw); c->tr_dq = dp(o_trdq); c->q_trial = dp(o_qt);
   c->tr_out = dp(o_trout); c->tr_Dprev = dp(o_trDp); c->tr_part = dp(o_trpart);
   c->terms = dp(o_terms);
+  c->tr_state = dp(o_trstate);
+  c->tr_cnt = reinterpret_cast<unsigned long long*>(c->arena + o_trcnt);
   {  // adaptive scaling methods start from D = 1 (TO.cc:1233-1236: scale_factors initialised to ones)
     std::vector<double> ones(nvars, 1.0);
     for (int b = 0; b < batch; ++b)
@@ -730,7 +740,8 @@ int idto_hip_eval_tau(idto_hip_ctx* c) {
   int rc = LaunchFd(c, 0, 0, c->N);
   if (rc) return rc;
   hipLaunchKernelGGL(cost_kernel, dim3(1, c->batch), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
-                     c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, (double*)nullptr, c->pstride, (double*)nullptr);
+                     c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, (double*)nullptr, c->pstride, (double*)nullptr,
+                     TrDecideArgs{});
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -755,7 +766,7 @@ int idto_hip_trial_cost(idto_hip_ctx* c, const double* q_host, double* tau_host,
   int rc = LaunchFd(c, 0, 0, c->N);
   if (rc) return rc;
   hipLaunchKernelGGL(cost_kernel, dim3(1), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
-                     c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, c->pack, (size_t)0, (double*)nullptr);
+                     c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, c->pack, (size_t)0, (double*)nullptr, TrDecideArgs{});
   HIP_OK(hipGetLastError());
   double* out = c->pin + nq_all;
   HIP_OK(hipMemcpyAsync(out, c->pack, (ntau + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1228,16 +1239,30 @@ int idto_hip_set_unactuated_dofs(idto_hip_ctx* c, const int* dofs, int nu) {
 }
 
 // ---- device-side trust-region bookkeeping (trust_region.h)
+static TrRowsArgs PrepareArgs(idto_hip_ctx* c, int scaling_method, int with_lambda) {
+  const int n = (c->N + 1) * c->nq;
+  TrRowsArgs A;
+  A.nblk = c->N + 1; A.K = c->nq;
+  A.HA = c->HA; A.HB = c->HB; A.HC = c->HC; A.g = c->g;
+  A.jtl = with_lambda ? c->con_out + n : nullptr;
+  A.yin = with_lambda ? c->con_out : c->step;
+  A.ysign = with_lambda ? 1.0 : -1.0;
+  A.q = c->q; A.scaling_method = scaling_method;
+  A.Dprev = c->tr_Dprev; A.D = c->tr_D; A.gt = c->tr_gt; A.w = c->tr_w;
+  A.slab = c->slab; A.slab_stride = c->slab_stride; A.tau_off = 3 * c->nv * c->nq;
+  A.dofs = with_lambda ? c->con_dofs : c->una_dofs;
+  A.nu = with_lambda ? c->con_nu : c->una_nu;
+  A.N = c->N;
+  A.lambda = with_lambda ? c->con_lambda_at : nullptr;
+  A.partial = c->tr_part;
+  return A;
+}
+
 static int EnqueuePrepare(idto_hip_ctx* c, int scaling_method, int with_lambda) {
   const int n = (c->N + 1) * c->nq;
-  const double* jtl = with_lambda ? c->con_out + n : nullptr;
-  const double* yin = with_lambda ? c->con_out : c->step;
-  const double* lam = with_lambda ? c->con_lambda_at : nullptr;
   const int lds = (23 * c->nq + 9 * 16) * (int)sizeof(double);
-  hipLaunchKernelGGL(tr_prepare_rows_kernel, dim3(c->N + 1), dim3(256), lds, c->stream, c->N + 1, c->nq, c->HA, c->HB, c->HC,
-                     c->g, jtl, yin, with_lambda ? 1.0 : -1.0, c->q, scaling_method, c->tr_Dprev, c->tr_D, c->tr_gt, c->tr_w,
-                     c->slab, c->slab_stride, 3 * c->nv * c->nq, with_lambda ? c->con_dofs : c->una_dofs,
-                     with_lambda ? c->con_nu : c->una_nu, c->N, lam, c->tr_part);
+  hipLaunchKernelGGL(tr_prepare_rows_kernel, dim3(c->N + 1), dim3(256), lds, c->stream,
+                     PrepareArgs(c, scaling_method, with_lambda));
   hipLaunchKernelGGL(tr_prepare_sum_kernel, dim3(1), dim3(256), 0, c->stream, c->N + 1, c->tr_part, c->tr_out, c->tr_D,
                      c->tr_Dprev, n);
   HIP_OK(hipGetLastError());
@@ -1281,7 +1306,7 @@ int idto_hip_tr_trial(idto_hip_ctx* c, double a, double b, int scaling, int norm
   int rc = LaunchFd(c, 0, 0, c->N);
   if (!rc) {
     hipLaunchKernelGGL(cost_kernel, dim3(1), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
-                       c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, (double*)nullptr, (size_t)0, c->tr_out + 11);
+                       c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, (double*)nullptr, (size_t)0, c->tr_out + 11, TrDecideArgs{});
     if (with_lambda)
       hipLaunchKernelGGL(tr_hlambda_kernel, dim3(1), dim3(256), 16 * sizeof(double), c->stream, c->slab, c->slab_stride,
                          3 * c->nv * c->nq, c->con_dofs, c->con_nu, c->N, c->con_lambda_at, c->tr_out + 12);
@@ -1336,6 +1361,67 @@ int idto_hip_tr_reject(idto_hip_ctx* c) {
   c->fd_full = false;
   c->con_ready = false; c->con_begun = false;
   return 0;
+}
+
+int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int scaling, int normalize_quaternions,
+                      double Delta0, double Delta_max, double eta, double* rows_host, double* Delta_out) {
+  HIP_OK(hipSetDevice(c->device));
+  if (c->batch != 1) { g_err = "tr_solve serves single-problem contexts"; return -1; }
+  if (iterations <= 0) { g_err = "tr_solve: iterations must be positive"; return -1; }
+  if (!(scaling_method == -1 || scaling_method == 0 || scaling_method == 2)) {
+    // (the adaptive methods keep a memory of D that a rejected step must not advance: stepwise loop)
+    g_err = "tr_solve: scaling method not supported by the device-resident loop";
+    return -1;
+  }
+  if (iterations > c->tr_rows_cap) {
+    double* p = nullptr;
+    if (Alloc(c, (size_t)iterations * TRR_COUNT, &p)) return -2;   // (the previous, smaller one stays in the context's pool)
+    c->tr_rows = p;
+    c->tr_rows_cap = iterations;
+  }
+  c->spec_pending = false; c->spec_ready = false; c->trial_resident = false;
+  const int n = (c->N + 1) * c->nq, nblk = c->N + 1;
+  // state: [Delta, L(q) (resident: the caller evaluated the cost of q), ...]
+  for (int i = 0; i < TRS_COUNT; ++i) c->tr_pin[i] = 0.0;
+  c->tr_pin[TRS_DELTA] = Delta0;
+  HIP_OK(hipMemcpyAsync(c->tr_state, c->tr_pin, TRS_COUNT * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_OK(hipMemcpyAsync(c->tr_state + TRS_COST, c->cost, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  const double eps = 10 * std::numeric_limits<double>::epsilon() / c->P.dt / c->P.dt;   // TO.cc:2024
+  const int lds_iter = (int)sizeof(double) * std::max(23 * c->nq + 9 * 16, 9 * nblk + 9 + 32);
+  for (int k = 0; k < iterations; ++k) {
+    int rc = idto_hip_gn_step(c);
+    if (rc) return rc;
+    TrIterArgs T;
+    T.rows = PrepareArgs(c, scaling_method, 0);
+    T.counter = c->tr_cnt;
+    c->tr_target += (unsigned long long)nblk;
+    T.target = c->tr_target;
+    T.out = c->tr_out; T.state = c->tr_state;
+    T.n = n; T.nq = c->nq; T.scaling = scaling;
+    T.nquat = normalize_quaternions ? c->tr_nquat : 0;
+    T.quat = c->tr_quat; T.q_trial = c->q_trial; T.dq = c->tr_dq;
+    hipLaunchKernelGGL(tr_iter_kernel, dim3(nblk), dim3(256), lds_iter, c->stream, T);
+    HIP_OK(hipGetLastError());
+    // tau and the cost at the trial point, then the decision (cost_kernel's epilogue)
+    TrDecideArgs Dc;
+    Dc.state = c->tr_state; Dc.out = c->tr_out; Dc.rows = c->tr_rows; Dc.q = c->q; Dc.q_trial = c->q_trial; Dc.n = n;
+    Dc.eta = eta; Dc.Delta_max = Delta_max; Dc.eps = eps;
+    std::swap(c->q, c->q_trial);
+    rc = LaunchFd(c, 0, 0, c->N);
+    if (!rc)
+      hipLaunchKernelGGL(cost_kernel, dim3(1), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
+                         c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, (double*)nullptr, (size_t)0,
+                         (double*)nullptr, Dc);
+    std::swap(c->q, c->q_trial);
+    if (rc) return rc;
+    HIP_OK(hipGetLastError());
+    c->fd_full = false;
+  }
+  HIP_OK(hipMemcpyAsync(c->tr_pin, c->tr_state, TRS_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  HIP_OK(hipMemcpy(rows_host, c->tr_rows, (size_t)iterations * TRR_COUNT * sizeof(double), hipMemcpyDeviceToHost));
+  if (Delta_out) *Delta_out = c->tr_pin[TRS_DELTA];
+  return FactorStatus(c);
 }
 
 #define NCCL_OK(expr)                                                                 \

@@ -8,6 +8,7 @@
 
 #include "batch.h"
 #include "id_eval.h"
+#include "trust_region.h"
 
 namespace idto_dev {
 
@@ -554,7 +555,8 @@ __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevP
 // is accumulated serially in the reference's order.
 __global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__ q, const double* __restrict__ v,
                             const double* __restrict__ slab, int slab_stride, double* __restrict__ cost_out,
-                            int diag, double* __restrict__ pack, size_t pstride, double* __restrict__ cost_copy) {
+                            int diag, double* __restrict__ pack, size_t pstride, double* __restrict__ cost_copy,
+                            TrDecideArgs T) {
   {
     const size_t o = (size_t)blockIdx.y * pstride;
     P = at_problem(P, o); q = at_problem(q, o); v = at_problem(v, o); slab = at_problem(slab, o);
@@ -612,6 +614,13 @@ __global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__
     *cost_out = cost;
     if (cost_copy) *cost_copy = cost;   // (single-problem contexts: next to the other trust-region scalars)
     if (pack) pack[N * nv] = cost;
+    // (idto_hip_tr_solve) this was the trial point of a trust-region iteration: ratio, accept / reject, radius
+    if (T.state) terms[0] = tr_decide(T, cost) ? 1.0 : 0.0;
+  }
+  if (T.state) {
+    __syncthreads();
+    if (terms[0] != 0.0)
+      for (int idx = tid; idx < T.n; idx += nt) T.q[idx] = T.q_trial[idx];
   }
   // [tau_0 .. tau_{N-1} | cost] contiguous: what a trial point of the trust-region loop reads back
   if (pack)

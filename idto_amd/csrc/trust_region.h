@@ -75,15 +75,32 @@ __device__ __forceinline__ double scale_factor(int scaling_method, double hii, d
 // tr_prepare_sum_kernel refreshes afterwards), then the rows of H~ g~ and H~ w with one thread per
 // (row, band block) and a sum over the five band blocks in LDS, and writes its nine partial sums;
 // tr_prepare_sum_kernel adds the partial sums in block order (deterministic).
-__global__ void __launch_bounds__(256)
-tr_prepare_rows_kernel(int nblk, int K, const double* __restrict__ HA, const double* __restrict__ HB,
-                       const double* __restrict__ HC, const double* __restrict__ g, const double* __restrict__ jtl,
-                       const double* __restrict__ yin, double ysign, const double* __restrict__ q, int scaling_method,
-                       const double* __restrict__ Dprev, double* __restrict__ D, double* __restrict__ gt,
-                       double* __restrict__ w, const double* __restrict__ slab, int slab_stride, int tau_off,
-                       const int* __restrict__ dofs, int nu, int N, const double* __restrict__ lambda,
-                       double* __restrict__ partial) {
-  extern __shared__ double lds[];
+struct TrRowsArgs {
+  int nblk, K;
+  const double *HA, *HB, *HC, *g, *jtl, *yin;
+  double ysign;
+  const double* q;
+  int scaling_method;
+  const double* Dprev;
+  double *D, *gt, *w;
+  const double* slab;
+  int slab_stride, tau_off;
+  const int* dofs;
+  int nu, N;
+  const double* lambda;
+  double* partial;
+};
+
+__device__ __forceinline__ void tr_prepare_rows_body(const TrRowsArgs& A, double* lds) {
+  const int nblk = A.nblk, K = A.K, scaling_method = A.scaling_method, slab_stride = A.slab_stride, tau_off = A.tau_off;
+  const int nu = A.nu, N = A.N;
+  const double* __restrict__ HA = A.HA; const double* __restrict__ HB = A.HB; const double* __restrict__ HC = A.HC;
+  const double* __restrict__ g = A.g; const double* __restrict__ jtl = A.jtl; const double* __restrict__ yin = A.yin;
+  const double ysign = A.ysign;
+  const double* __restrict__ q = A.q; const double* __restrict__ Dprev = A.Dprev;
+  double* __restrict__ D = A.D; double* __restrict__ gt = A.gt; double* __restrict__ w = A.w;
+  const double* __restrict__ slab = A.slab; const int* __restrict__ dofs = A.dofs;
+  const double* __restrict__ lambda = A.lambda; double* __restrict__ partial = A.partial;
   const int i = blockIdx.x, tid = threadIdx.x, nt = blockDim.x, kk = K * K;
   double* xt = lds;            // [5 K]  D g~ of block rows i-2 .. i+2
   double* xy = xt + 5 * K;     // [5 K]  y
@@ -143,6 +160,11 @@ tr_prepare_rows_kernel(int nblk, int K, const double* __restrict__ HA, const dou
     for (int k = 0; k < 9; ++k) partial[i * 9 + k] = s[k];
 }
 
+__global__ void __launch_bounds__(256) tr_prepare_rows_kernel(TrRowsArgs A) {
+  extern __shared__ double lds[];
+  tr_prepare_rows_body(A, lds);
+}
+
 __global__ void tr_prepare_sum_kernel(int nblk, const double* __restrict__ partial, double* __restrict__ out,
                                       const double* __restrict__ D, double* __restrict__ Dprev, int n) {
   const int tid = threadIdx.x;
@@ -198,6 +220,186 @@ __global__ void tr_hlambda_kernel(const double* __restrict__ slab, int slab_stri
   }
   block_sums<1>(s, lds);
   if (threadIdx.x == 0) out[0] = s[0];
+}
+
+
+// ---------------------------------------------------------------------------
+// The trust-region iteration without the host (idto_hip_tr_solve): tr_iter_kernel = tr_prepare_rows +
+// (last workgroup to finish) tr_prepare_sum + CalcDoglegPoint + tr_trial; the bookkeeping that
+// follows the cost of the trial point - CalcTrustRatio, accept / reject, the radius update
+// (TO.cc:2004-2034, :2550-2553, :2614-2622) - is tr_decide(), called by the one workgroup of
+// cost_kernel.  The state that travels from launch to launch lives in device memory:
+enum {
+  TRS_DELTA = 0,   // trust-region radius
+  TRS_COST,        // L(q)
+  TRS_A, TRS_B,    // the step of this iteration: dq = D (a g~ + b w)
+  TRS_ACTIVE,      // the trust-region constraint is active (:2160-2199)
+  TRS_FLAGS,       // (as an integer value) TRF_*: sticky, the remaining iterations are idle
+  TRS_ITER,        // iterations decided so far
+  TRS_COUNT = 8
+};
+enum { TRF_DOGLEG = 1, TRF_NONFINITE = 2, TRF_NOT_DESCENT = 4 };
+// one row of per-iteration statistics (TrajectoryOptimizerStats::push_data, TO.cc:2586-2598)
+enum { TRR_COST = 0, TRR_DELTA, TRR_RHO, TRR_QNORM, TRR_DQNORM, TRR_DQHNORM, TRR_GNORM, TRR_DLDQ, TRR_HNORM,
+       TRR_ACCEPTED, TRR_CLOCK /* wall_clock64 ticks (100 MHz) */, TRR_A, TRR_B, TRR_COST_TRIAL, TRR_FLAGS, TRR_COUNT = 16 };
+
+struct TrIterArgs {
+  TrRowsArgs rows;
+  unsigned long long* counter;   // monotonic: workgroups of tr_iter_kernel that have published their partial sums
+  unsigned long long target;     // ... its value once every workgroup of THIS launch has
+  double* out;                   // [11] the nine inner products, then dq.dq and g~.D^-1 dq
+  double* state;                 // [TRS_COUNT]
+  int n, nq, scaling, nquat;
+  const int* quat;
+  double* q_trial;
+  double* dq;
+};
+
+// (TO.cc:2204-2242 SolveDoglegQuadratic; *ok = false where the reference throws)
+__device__ inline double tr_dogleg_quadratic(double a, double b, double c, bool* ok) {
+  if (!(a > 0)) { *ok = false; return 0.0; }
+  double s;
+  if (a < 2.220446049250313e-16) {
+    s = -c / b;
+  } else {
+    const double bt = b / a, ct = c / a;
+    const double det = bt * bt - 4 * ct;
+    if (!(det > 0)) { *ok = false; return 0.0; }
+    s = (-bt + __builtin_sqrt(det)) / 2;
+  }
+  if (!(0 < s && s < 1)) *ok = false;
+  return s;
+}
+
+__global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
+  extern __shared__ double lds[];
+  __shared__ int last;
+  __shared__ double ab[2];
+  tr_prepare_rows_body(T.rows, lds);
+  const int tid = threadIdx.x, nt = blockDim.x, nblk = T.rows.nblk, n = T.n;
+  if (tid == 0) {   // (block_sums left a barrier behind the partial sums of thread 0)
+    __atomic_thread_fence(__ATOMIC_RELEASE);   // agent scope: the partial sums, D, g~, w of this block row
+    const unsigned long long prev =
+        __hip_atomic_fetch_add(T.counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = (prev + 1 == T.target);
+  }
+  __syncthreads();
+  if (!last) return;
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  // ---- tr_prepare_sum: the partial sums in block order
+  double* part = lds;            // [9 nblk]
+  double* S = part + 9 * nblk;   // [9]
+  double* scratch = S + 9;       // [2 * 16]
+  for (int idx = tid; idx < 9 * nblk; idx += nt) part[idx] = T.rows.partial[idx];
+  for (int idx = tid; idx < n; idx += nt) const_cast<double*>(T.rows.Dprev)[idx] = T.rows.D[idx];   // the adaptive methods' memory
+  __syncthreads();
+  if (tid < 9) {
+    double acc = 0.0;
+    for (int i = 0; i < nblk; ++i) acc += part[i * 9 + tid];
+    S[tid] = acc;
+    T.out[tid] = acc;
+  }
+  __syncthreads();
+  // ---- CalcDoglegPoint normalised by Delta: pU = cU g~ (TO.cc:2157), pH = -w / Delta (:2139-2149)
+  if (tid == 0) {
+    const double gg = S[0], gHg = S[1], ww = S[2], gw = S[3];
+    const double Delta = T.state[TRS_DELTA];
+    int flags = (int)T.state[TRS_FLAGS];
+    const double cU = -(gg / gHg) / Delta;
+    const double pUn = __builtin_fabs(cU) * __builtin_sqrt(gg), pHn = __builtin_sqrt(ww) / Delta;
+    double a, b, active;
+    if (1.0 <= pUn) {          // :2160-2168
+      a = (Delta / pUn) * cU; b = 0.0; active = 1.0;
+    } else if (1.0 >= pHn) {   // :2171-2178
+      a = 0.0; b = -1.0; active = 0.0;
+    } else {                   // :2180-2199
+      const double pUpU = cU * cU * gg, pHpH = ww / (Delta * Delta), pUpH = -cU * gw / Delta;
+      bool ok = true;
+      const double sq = tr_dogleg_quadratic(pHpH - 2 * pUpH + pUpU, 2 * (pUpH - pUpU), pUpU - 1.0, &ok);
+      if (!ok) flags |= TRF_DOGLEG;
+      a = Delta * (1.0 - sq) * cU; b = -sq; active = 1.0;
+    }
+    if (!(__builtin_isfinite(a) && __builtin_isfinite(b))) flags |= TRF_NONFINITE;
+    T.state[TRS_A] = a; T.state[TRS_B] = b; T.state[TRS_ACTIVE] = active; T.state[TRS_FLAGS] = (double)flags;
+    ab[0] = a; ab[1] = b;
+  }
+  __syncthreads();
+  // ---- tr_trial: dq = D (a g~ + b w), q_trial = q + dq, [dq.dq, g~.(a g~ + b w)] with the partial sums
+  // of tr_trial_kernel's 1024 threads (thread v of it owns idx = v, v + 1024, ...): same bits
+  const double a = ab[0], b = ab[1];
+  const int lane = tid & 63;
+  for (int vt = tid; vt < 1024; vt += nt) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int idx = vt; idx < n; idx += 1024) {
+      const double dqs = a * T.rows.gt[idx] + b * T.rows.w[idx];
+      const double dq = T.scaling ? T.rows.D[idx] * dqs : dqs;
+      T.dq[idx] = dq;
+      T.q_trial[idx] = T.rows.q[idx] + dq;
+      s0 += dq * dq;
+      s1 += T.rows.gt[idx] * dqs;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { s0 += __shfl_down(s0, off); s1 += __shfl_down(s1, off); }
+    if (lane == 0) { scratch[vt >> 6] = s0; scratch[16 + (vt >> 6)] = s1; }
+  }
+  __syncthreads();
+  if (T.nquat > 0) {
+    const int nsteps = n / T.nq;
+    for (int idx = tid; idx < nsteps * T.nquat; idx += nt) {
+      const int t = idx / T.nquat, qs = T.quat[idx - t * T.nquat];
+      double* qq = T.q_trial + (size_t)t * T.nq + qs;
+      const double nrm = __builtin_sqrt(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
+      for (int k = 0; k < 4; ++k) qq[k] /= nrm;
+    }
+  }
+  if (tid == 0) {
+    double x0 = 0.0, x1 = 0.0;
+    for (int wv = 0; wv < 16; ++wv) { x0 += scratch[wv]; x1 += scratch[16 + wv]; }
+    T.out[9] = x0; T.out[10] = x1;
+  }
+}
+
+struct TrDecideArgs {
+  double* state;        // [TRS_COUNT]
+  const double* out;    // [11] from tr_iter_kernel
+  double* rows;         // [iterations][TRR_COUNT]
+  double* q;            // the iterate, overwritten by q_trial when the step is accepted
+  const double* q_trial;
+  int n;
+  double eta, Delta_max, eps;
+};
+
+// thread 0 of cost_kernel's workgroup, with the cost of the trial point; returns whether the step is accepted
+__device__ inline bool tr_decide(const TrDecideArgs& T, double cost_trial) {
+  const double* S = T.out;
+  const double gg = S[0], gHg = S[1], ww = S[2], gw = S[3], gHw = S[4], wHw = S[5], qq = S[6], hh = S[7];
+  const double a = T.state[TRS_A], b = T.state[TRS_B], Delta = T.state[TRS_DELTA], cost = T.state[TRS_COST];
+  int flags = (int)T.state[TRS_FLAGS];
+  const int k = (int)T.state[TRS_ITER];
+  const double gdqs = S[10];
+  if (!__builtin_isfinite(S[9])) flags |= TRF_NONFINITE;
+  const double dL_dq = gdqs / cost;   // :2517-2524
+  // CalcTrustRatio (:2004-2034)
+  const double gradient_term = a * gg + b * gw;
+  const double hessian_term = 0.5 * (a * a * gHg + 2 * a * b * gHw + b * b * wHw);
+  const double predicted = -gradient_term - hessian_term, actual = cost - cost_trial;
+  const double rho = (predicted < T.eps && actual < T.eps) ? 0.5 : actual / predicted;
+  if (!(dL_dq < 2.220446049250313e-16)) flags |= TRF_NOT_DESCENT;
+  const bool accept = (flags == 0) && rho > T.eta;
+  double* R = T.rows + (size_t)k * TRR_COUNT;
+  R[TRR_COST] = cost; R[TRR_DELTA] = Delta; R[TRR_RHO] = rho; R[TRR_QNORM] = __builtin_sqrt(qq);
+  R[TRR_DQNORM] = __builtin_sqrt(S[9]); R[TRR_DQHNORM] = __builtin_sqrt(ww); R[TRR_GNORM] = __builtin_sqrt(gg);
+  R[TRR_DLDQ] = dL_dq; R[TRR_HNORM] = __builtin_sqrt(hh); R[TRR_ACCEPTED] = accept ? 1.0 : 0.0;
+  R[TRR_CLOCK] = (double)wall_clock64(); R[TRR_A] = a; R[TRR_B] = b; R[TRR_COST_TRIAL] = cost_trial;
+  R[TRR_FLAGS] = (double)flags;
+  if (flags == 0) {
+    if (accept) T.state[TRS_COST] = cost_trial;   // :2550-2553
+    if (rho < 0.25) T.state[TRS_DELTA] = Delta * 0.25;                                                        // :2614-2617
+    else if (rho > 0.75 && T.state[TRS_ACTIVE] != 0.0) T.state[TRS_DELTA] = __builtin_fmin(2 * Delta, T.Delta_max);   // :2618-2622
+  }
+  T.state[TRS_FLAGS] = (double)flags;
+  T.state[TRS_ITER] = (double)(k + 1);
+  return accept;
 }
 
 }  // namespace idto_dev

@@ -220,6 +220,26 @@ int idto_hip_tr_trial(idto_hip_ctx* ctx, double a, double b, int scaling, int no
 int idto_hip_tr_accept(idto_hip_ctx* ctx);
 int idto_hip_tr_reject(idto_hip_ctx* ctx);
 
+/* The whole trust-region loop without the host (reference optimizer/trajectory_optimizer.cc:2495-2625
+ * for the case the stepwise calls above serve: no enforced constraints, no convergence checks).
+ * `iterations` iterations are enqueued back to back - per iteration idto_hip_gn_step, one launch
+ * for scale factors / inner products / dogleg point (CalcDoglegPoint :2108-2202) / trial point, the
+ * inverse dynamics and the cost there, whose kernel also forms the trust ratio (:1979-2035), accepts
+ * (q <- q + dq on the device) or rejects, and updates the radius (:2614-2622) - and the host waits
+ * once.  The iterate q must be resident with its cost evaluated (idto_hip_set_q + idto_hip_eval_tau).
+ * rows_host[iterations][IDTO_TR_ROW]: per iteration
+ *   [0] L(q_k) [1] Delta_k [2] rho [3] |q| [4] |dq| [5] |dqH| [6] |g~| [7] dL/dq [8] |h| [9] accepted
+ *   [10] device clock at the decision (100 MHz ticks) [11] a [12] b (dq = D (a g~ + b w)) [13] L(q_k + dq)
+ *   [14] flags: 1 dogleg quadratic has no root in (0,1), 2 step not finite, 4 step is not a descent
+ *   direction (where the reference throws); once a flag is set the remaining iterations are idle.
+ * scaling_method: -1 none, 0 kSqrt, 2 kDoubleSqrt (the adaptive methods: use the stepwise calls).
+ * On return q, v, a, tau, N+ in device memory are those of the final iterate when the last step was
+ * accepted; after a rejected last step v, a, tau belong to the dropped trial point.
+ * Returns IDTO_HIP_FACTORIZATION_FAILED when any iteration's factorisation failed. */
+#define IDTO_TR_ROW 16
+int idto_hip_tr_solve(idto_hip_ctx* ctx, int iterations, int scaling_method, int scaling, int normalize_quaternions,
+                      double Delta0, double Delta_max, double eta, double* rows_host, double* Delta_out);
+
 /* Options: "gradients_method" = 0 forward differences (default), 1 / 2 central differences of
  * 2nd / 4th order (SolverParameters::gradients_method, reference solver_parameters.h:26-50,
  * trajectory_optimizer.cc:565-885); 3 (autodiff) is refused.  "reference_solver" = 1 selects the bit-exact restatement of the reference's

@@ -113,3 +113,70 @@ def test_speculative_next_iteration(accept):
         assert np.array_equal(x, y)
     if not accept:
         assert np.array_equal(outs[0][4], q) and np.array_equal(outs[0][1], S0)
+
+
+def _solve(name, N, iters, stepwise, monkeypatch, scaling=True, method="double_sqrt", quat=False, q0=None):
+    from idto_amd.optimizer import TrajectoryOptimizer, TrajectoryOptimizerSolution, TrajectoryOptimizerStats
+    cfg, model = load_config(name), load_model(name)
+    prob, sp, q_guess = make_problem(cfg, model, num_steps=N)
+    sp.equality_constraints = False
+    sp.max_iterations, sp.verbose = iters, False
+    sp.scaling, sp.scaling_method = scaling, method
+    sp.normalize_quaternions = quat
+    if stepwise:
+        monkeypatch.setenv("IDTO_OPT_STEPWISE", "1")
+    else:
+        monkeypatch.delenv("IDTO_OPT_STEPWISE", raising=False)
+    opt = TrajectoryOptimizer(model, prob, sp)
+    sol, st = TrajectoryOptimizerSolution(), TrajectoryOptimizerStats()
+    flag = opt.Solve(q_guess if q0 is None else q0, sol, st)
+    return sol, st, flag
+
+
+@pytest.mark.parametrize("name,N,iters,scaling,method,quat", [
+    ("mini_cheetah", 40, 12, True, "double_sqrt", False), ("mini_cheetah", 20, 8, True, "sqrt", True),
+    ("hopper", 20, 15, False, "double_sqrt", False), ("allegro_hand", 30, 4, True, "double_sqrt", False),
+    ("acrobot", 30, 25, True, "double_sqrt", False), ("spinner", 20, 12, True, "sqrt", False)])
+def test_resident_loop_equals_stepwise_loop(name, N, iters, scaling, method, quat, monkeypatch):
+    """idto_hip_tr_solve (every iteration enqueued at once, dogleg / trust ratio / accept / radius on
+    the device) walks exactly the iterates of the loop that returns to the host twice per iteration:
+    same kernels for the O(num_vars) work, the same scalar expressions for the rest -> same bits"""
+    a_sol, a_st, a_flag = _solve(name, N, iters, False, monkeypatch, scaling, method, quat)
+    b_sol, b_st, b_flag = _solve(name, N, iters, True, monkeypatch, scaling, method, quat)
+    assert a_flag == b_flag
+    for series in ("iteration_costs", "trust_region_radii", "trust_ratios", "q_norms", "dq_norms", "dqH_norms",
+                   "gradient_norms", "dL_dqs", "h_norms", "merits"):
+        x, y = getattr(a_st, series), getattr(b_st, series)
+        assert x.size == iters and np.array_equal(x, y), (series, x, y)
+    assert np.array_equal(a_sol.q, b_sol.q) and np.array_equal(a_sol.v, b_sol.v) and np.array_equal(a_sol.tau, b_sol.tau)
+    assert (a_st.iteration_times > 0).all() and abs(a_st.iteration_times.sum() - a_st.solve_time) < 0.5 * a_st.solve_time
+    # some steps of these runs are rejected (acrobot) - the radius shrinks and the iterate stays
+    if name == "acrobot":
+        assert (a_st.trust_ratios <= 0).any()
+
+
+def test_resident_loop_rows_and_failure():
+    """the rows idto_hip_tr_solve returns; a semidefinite Hessian is reported, not iterated on"""
+    cfg, model, prob, sp, q = _setup("mini_cheetah", 24)
+    dev = hip.HipPath(model, prob, sp)
+    dev.set_unactuated_dofs(model.unactuated_dofs)
+    dev.set_q(q)
+    dev.eval_tau()
+    c0 = dev.get("cost")
+    rows, delta = dev.tr_solve(6, SCALING["double_sqrt"], True, False, 1e-1, 1e5)
+    assert rows[0, 0] == c0 and rows[0, 1] == 1e-1 and (rows[:, 14] == 0).all()
+    for k in range(1, 6):   # accepted: the next iteration starts from the trial point's cost
+        assert rows[k, 0] == (rows[k - 1, 13] if rows[k - 1, 9] else rows[k - 1, 0])
+    assert (np.diff(rows[:, 10]) > 0).all() and delta > 0
+    assert np.array_equal(dev.get("q"), q) == (not rows[:, 9].any())
+    prob.R = prob.R * 0.0
+    prob.Qq = prob.Qq * 0.0
+    prob.Qv = prob.Qv * 0.0
+    prob.Qf_q = prob.Qf_q * 0.0
+    prob.Qf_v = prob.Qf_v * 0.0
+    dev.set_problem(prob)
+    dev.set_q(q)
+    dev.eval_tau()
+    with pytest.raises(hip.FactorizationFailed):
+        dev.tr_solve(3, -1, False, False, 1e-1, 1e5)
+    dev.close()

@@ -13,7 +13,7 @@ prob, sp, _ = make_problem(cfg, model, num_steps=N)
 sp.scaling = False
 sp.equality_constraints = False
 q = synthetic_trajectory(cfg, model, N, seed=0, lower=0.01)
-for fold, stop in ((0, 0), (1, 0), (1, 4), (1, 5), (1, 6), (1, 7)):
+for fold, stop in ((0, 0), (1, 0), (1, 1), (1, 2), (1, 3), (1, 4), (1, 5), (1, 6), (1, 7)):
     dev = hip.HipPath(model, prob, sp)
     dev.set_option("asm_fold", fold)
     dev.set_option("fd_stop", stop)

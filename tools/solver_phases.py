@@ -15,6 +15,7 @@ prob, sp, _ = make_problem(cfg, model, num_steps=N)
 q = synthetic_trajectory(cfg, model, N, seed=0, lower=0.01)
 dev = hip.HipPath(model, prob, sp)
 dev.set_q(q); dev.set_option("solver_debug", 1); dev.set_option("two_sided", two)
+dev.set_option("solver_nd", 0)   # (the stamps below are those of the one- / two-workgroup kernel)
 for _ in range(3):
     dev.gn_step()
 dev.sync()
