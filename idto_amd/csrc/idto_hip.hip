@@ -787,28 +787,36 @@ int idto_hip_eval_partials(idto_hip_ctx* c) {
   return TimeEnd(c);
 }
 
-int idto_hip_grad_hess(idto_hip_ctx* c) {
-  HIP_OK(hipSetDevice(c->device));
-  DropPrefetch(c, {IDTO_ARR_GRADIENT, IDTO_ARR_H_A, IDTO_ARR_H_B, IDTO_ARR_H_C, IDTO_ARR_HBANDS});
+// g and the bands of H from the resident slab / products (gate: see assemble_terms_kernel)
+static int LaunchAssemble(idto_hip_ctx* c, const double* gate) {
   if (!c->h_assembled) {  // x_0 = -g_0 = 0 is no longer written by the solver (SolverFirstRow)
     HIP_OK(hipMemset2DAsync(c->step, c->pstride, 0, (size_t)c->nq * sizeof(double), (size_t)c->batch, c->stream));
     c->h_assembled = true;
   }
   c->con_ready = false; c->con_begun = false;
-  if (TimeBegin(c, 1)) return -2;
   const bool combine = c->weights_diagonal && c->terms_valid && c->fd_full && c->asm_stop == 0;
   c->last_assembly = combine ? 1 : (c->weights_diagonal ? 2 : 3);
-  if (combine)
+  if (combine) {
     hipLaunchKernelGGL(assemble_terms_kernel, dim3(c->N + 1, 4, c->batch), dim3(256), c->asm_terms_lds, c->stream, c->M, c->P,
-                       c->q, c->terms, c->v, c->nplus, c->g, c->HA, c->HB, c->HC, c->pstride);
-  else if (c->weights_diagonal)
+                       c->q, c->terms, c->v, c->nplus, c->g, c->HA, c->HB, c->HC, c->pstride, gate);
+  } else if (c->weights_diagonal) {
     hipLaunchKernelGGL(assemble_diag_kernel, dim3(c->N + 1, 4, c->batch), dim3(256), c->asm_diag_lds, c->stream, c->M,
                        c->P, c->q, c->slab, c->slab_stride, c->g, c->HA, c->HB, c->HC, c->asm_stop,
-                       c->fd_full ? c->v : nullptr, c->fd_full ? c->nplus : nullptr, c->pstride);
-  else
+                       c->fd_full ? c->v : nullptr, c->fd_full ? c->nplus : nullptr, c->pstride, gate);
+  } else {
+    if (gate) { g_err = "gated assembly needs diagonal cost weights"; return -1; }
     hipLaunchKernelGGL(assemble_kernel, dim3(c->N + 1, c->batch), dim3(256), c->asm_lds, c->stream, c->M, c->P, c->q,
                        c->slab, c->slab_stride, c->g, c->HA, c->HB, c->HC, c->pstride);
+  }
   HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int idto_hip_grad_hess(idto_hip_ctx* c) {
+  HIP_OK(hipSetDevice(c->device));
+  DropPrefetch(c, {IDTO_ARR_GRADIENT, IDTO_ARR_H_A, IDTO_ARR_H_B, IDTO_ARR_H_C, IDTO_ARR_HBANDS});
+  if (TimeBegin(c, 1)) return -2;
+  if (int rc = LaunchAssemble(c, nullptr)) return rc;
   return TimeEnd(c);
 }
 
@@ -1384,13 +1392,17 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
   // state: [Delta, L(q) (resident: the caller evaluated the cost of q), ...]
   for (int i = 0; i < TRS_COUNT; ++i) c->tr_pin[i] = 0.0;
   c->tr_pin[TRS_DELTA] = Delta0;
+  c->tr_pin[TRS_ACCEPTED] = 1.0;
+  c->tr_pin[TRS_SLAB_IS_Q] = 1.0;
   HIP_OK(hipMemcpyAsync(c->tr_state, c->tr_pin, TRS_COUNT * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIP_OK(hipMemcpyAsync(c->tr_state + TRS_COST, c->cost, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   const double eps = 10 * std::numeric_limits<double>::epsilon() / c->P.dt / c->P.dt;   // TO.cc:2024
   const int lds_iter = (int)sizeof(double) * std::max(23 * c->nq + 9 * 16, 9 * nblk + 9 + 32);
+  // g, H and the Newton step of the first iterate
+  int rc = idto_hip_gn_step(c);
+  if (rc) return rc;
+  const bool lookahead = c->weights_diagonal && c->asm_stop == 0 && c->fd_stop == 0;
   for (int k = 0; k < iterations; ++k) {
-    int rc = idto_hip_gn_step(c);
-    if (rc) return rc;
     TrIterArgs T;
     T.rows = PrepareArgs(c, scaling_method, 0);
     T.counter = c->tr_cnt;
@@ -1402,12 +1414,14 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
     T.quat = c->tr_quat; T.q_trial = c->q_trial; T.dq = c->tr_dq;
     hipLaunchKernelGGL(tr_iter_kernel, dim3(nblk), dim3(256), lds_iter, c->stream, T);
     HIP_OK(hipGetLastError());
-    // tau and the cost at the trial point, then the decision (cost_kernel's epilogue)
+    // tau (with its partials: the trial point is the next iterate unless rejected) and the cost at the
+    // trial point, then the decision (cost_kernel's epilogue)
     TrDecideArgs Dc;
     Dc.state = c->tr_state; Dc.out = c->tr_out; Dc.rows = c->tr_rows; Dc.q = c->q; Dc.q_trial = c->q_trial; Dc.n = n;
     Dc.eta = eta; Dc.Delta_max = Delta_max; Dc.eps = eps;
+    const bool more = k + 1 < iterations;
     std::swap(c->q, c->q_trial);
-    rc = LaunchFd(c, 0, 0, c->N);
+    rc = LaunchFd(c, (lookahead && more) ? 1 : 0, 0, c->N);
     if (!rc)
       hipLaunchKernelGGL(cost_kernel, dim3(1), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
                          c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, (double*)nullptr, (size_t)0,
@@ -1415,8 +1429,17 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
     std::swap(c->q, c->q_trial);
     if (rc) return rc;
     HIP_OK(hipGetLastError());
-    c->fd_full = false;
+    c->fd_full = lookahead && more;   // (v, N+ of the trial point = of the iterate the gated assembly runs for)
+    if (!more) break;
+    if (lookahead) {
+      rc = LaunchAssemble(c, c->tr_state + TRS_ACCEPTED);
+      if (!rc) rc = idto_hip_factor_solve(c, nullptr, 1, nullptr);   // (after a rejection: the same H, g -> the same step)
+    } else {
+      rc = idto_hip_gn_step(c);   // (dense cost weights: the partials again, at the iterate)
+    }
+    if (rc) return rc;
   }
+  c->fd_full = false;
   HIP_OK(hipMemcpyAsync(c->tr_pin, c->tr_state, TRS_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_OK(hipStreamSynchronize(c->stream));
   HIP_OK(hipMemcpy(rows_host, c->tr_rows, (size_t)iterations * TRR_COUNT * sizeof(double), hipMemcpyDeviceToHost));

@@ -1044,7 +1044,8 @@ __global__ void __launch_bounds__(256)
 assemble_diag_kernel(DevModel M, DevProblem P, const double* __restrict__ q, const double* __restrict__ slab,
                      int slab_stride, double* __restrict__ g, double* __restrict__ HA, double* __restrict__ HB,
                      double* __restrict__ HC, int stop_after, const double* __restrict__ v_res,
-                     const double* __restrict__ nplus_res, size_t pstride) {
+                     const double* __restrict__ nplus_res, size_t pstride, const double* __restrict__ gate) {
+  if (gate && *gate == 0.0) return;   // (idto_hip_tr_solve: the step was rejected, g and H of the iterate stay)
   const size_t o = (size_t)blockIdx.z * pstride;  // problem of the batch
   assemble_diag_body(M, at_problem(P, o), at_problem(q, o), at_problem(slab, o), slab_stride, at_problem(g, o),
                      at_problem(HA, o), at_problem(HB, o), at_problem(HC, o), stop_after,
@@ -1063,7 +1064,9 @@ assemble_diag_kernel(DevModel M, DevProblem P, const double* __restrict__ q, con
 __global__ void __launch_bounds__(256)
 assemble_terms_kernel(DevModel M, DevProblem P, const double* __restrict__ q, const double* __restrict__ terms,
                       const double* __restrict__ v_res, const double* __restrict__ nplus_res, double* __restrict__ g,
-                      double* __restrict__ HA, double* __restrict__ HB, double* __restrict__ HC, size_t pstride) {
+                      double* __restrict__ HA, double* __restrict__ HB, double* __restrict__ HC, size_t pstride,
+                      const double* __restrict__ gate) {
+  if (gate && *gate == 0.0) return;   // (idto_hip_tr_solve: the step was rejected, g and H of the iterate stay)
   {
     const size_t o = (size_t)blockIdx.z * pstride;
     P = at_problem(P, o); q = at_problem(q, o); terms = at_problem(terms, o); v_res = at_problem(v_res, o);

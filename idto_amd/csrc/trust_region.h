@@ -228,7 +228,10 @@ __global__ void tr_hlambda_kernel(const double* __restrict__ slab, int slab_stri
 // (last workgroup to finish) tr_prepare_sum + CalcDoglegPoint + tr_trial; the bookkeeping that
 // follows the cost of the trial point - CalcTrustRatio, accept / reject, the radius update
 // (TO.cc:2004-2034, :2550-2553, :2614-2622) - is tr_decide(), called by the one workgroup of
-// cost_kernel.  The state that travels from launch to launch lives in device memory:
+// cost_kernel.  The inverse dynamics at the trial point are evaluated together with their partials
+// (fd_kernel mode >= 1): an accepted trial point - the common case - is the next iterate and its
+// assembly follows at once; after a rejected one the gated assembly leaves g and H alone.
+// The state that travels from launch to launch lives in device memory:
 enum {
   TRS_DELTA = 0,   // trust-region radius
   TRS_COST,        // L(q)
@@ -236,7 +239,10 @@ enum {
   TRS_ACTIVE,      // the trust-region constraint is active (:2160-2199)
   TRS_FLAGS,       // (as an integer value) TRF_*: sticky, the remaining iterations are idle
   TRS_ITER,        // iterations decided so far
-  TRS_COUNT = 8
+  TRS_ACCEPTED,    // the last decision: gates the assembly of the next iteration (a rejected step keeps g, H)
+  TRS_SLAB_IS_Q,   // tau in the slab belongs to the iterate (not to a rejected trial point) ...
+  TRS_HH,          // ... else h.h of the iterate, from the iteration that last saw it
+  TRS_COUNT = 12
 };
 enum { TRF_DOGLEG = 1, TRF_NONFINITE = 2, TRF_NOT_DESCENT = 4 };
 // one row of per-iteration statistics (TrajectoryOptimizerStats::push_data, TO.cc:2586-2598)
@@ -296,6 +302,11 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
   if (tid < 9) {
     double acc = 0.0;
     for (int i = 0; i < nblk; ++i) acc += part[i * 9 + tid];
+    // (h = tau[unactuated], statistics only here) after a rejected step the slab holds the trial point's tau
+    if (tid == 7) {
+      if (T.state[TRS_SLAB_IS_Q] != 0.0) T.state[TRS_HH] = acc;
+      else acc = T.state[TRS_HH];
+    }
     S[tid] = acc;
     T.out[tid] = acc;
   }
@@ -399,6 +410,8 @@ __device__ inline bool tr_decide(const TrDecideArgs& T, double cost_trial) {
   }
   T.state[TRS_FLAGS] = (double)flags;
   T.state[TRS_ITER] = (double)(k + 1);
+  T.state[TRS_ACCEPTED] = accept ? 1.0 : 0.0;
+  T.state[TRS_SLAB_IS_Q] = accept ? 1.0 : 0.0;   // (tau, v, a, N+ and the partials in device memory are the trial point's)
   return accept;
 }
 
