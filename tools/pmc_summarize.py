@@ -50,6 +50,23 @@ def main():
     json.dump(res, open(os.path.join(dst, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
     for k, e in res.items():
         print(k, {a: round(b) for a, b in e.items() if isinstance(b, float)})
+    for f in glob.glob(os.path.join(out_root, "prof_full", "**", "*kernel_stats*.csv"), recursive=True)[:1]:
+        shutil.copy(f, os.path.join(dst, f"{rnd}_full_iteration_kernel_stats.csv"))
+    # SQ counters per kernel and launch (pmc_sq* passes)
+    lines = []
+    for d in ("pmc_sq1", "pmc_sq3"):
+        acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+        for f in glob.glob(os.path.join(out_root, d, "**", "*counter_collection*.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                k = row["Kernel_Name"].split("(")[0].split("<")[0].split("::")[-1]
+                a = acc[k][row["Counter_Name"]]
+                a[0] += float(row["Counter_Value"])
+                a[1] += 1
+        for k, cs in acc.items():
+            if "rocclr" not in k:
+                lines.append(f"{d} {k} " + str({c: round(v[0] / v[1]) for c, v in sorted(cs.items())}))
+    open(os.path.join(dst, f"{rnd}_pmc_sq_summary.txt"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
 
 
 if __name__ == "__main__":
