@@ -339,7 +339,7 @@ int FdEvals(const idto_hip_ctx* c, int mode) {
 int FdLds(const idto_hip_ctx* c, int mode, int ec, bool with_terms = false) {
   const int nq = c->nq, nv = c->nv, E = FdEvals(c, mode), nvp = (nv + 1) & ~1;
   const int rec = with_terms ? 6 * nvp * nq + nvp + asm_terms_stride(nq) + 1 : 0;   // the record, its weighted copy, diag R', the products (+1: 16-byte alignment)
-  return (int)sizeof(double) * (3 * nq + 2 * nv * nq + 3 * nv + E + E * nv + ec * (nq + 2 * nv) + nv + c->M.blob_n + 2 + nq / 2 + 2 + rec);
+  return (int)sizeof(double) * (3 * nq + 2 * nv * nq + 3 * nv + 3 * E + E * nv + ec * (nq + 2 * nv) + nv + c->M.blob_n + 2 + nq / 2 + 2 + rec);
 }
 
 // fd_kernel also forms the single-record products of the Gauss-Newton assembly (diagonal weights,

@@ -268,11 +268,13 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
   double* v0 = N1 + bsz;        // v_k
   double* v1 = v0 + nv;         // v_{k+1}
   double* a0 = v1 + nv;         // a_k
-  double* edq = a0 + nv;        // [E]
+  double* edq = a0 + nv;        // [E] perturbation of each evaluation, then [E] dq / dt and [E] dq / dt^2
   // the evaluation inputs are built `echunk` evaluations at a time (one pass unless the
   // central-difference evaluation set of a large model would not fit in LDS)
   const int EC = (echunk < E) ? echunk : E;
-  double* etau = edq + E;       // [E][nv]
+  double* edv = edq + E;
+  double* eda = edv + E;
+  double* etau = eda + E;       // [E][nv]
   double* eq = etau + E * nv;   // [EC][nq]
   double* ev = eq + EC * nq;    // [EC][nv]
   double* ea = ev + EC * nv;    // [EC][nv]
@@ -314,6 +316,22 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
   else
     for (int r = tid; r < nv; r += nt) v0[r] = P.v_init[r];
   velocity_block(Ml, N1, q1, q0, dt, v1, tid, nt);
+  // the perturbation of every evaluation (TO.cc:501-521; needs q only: formed here, a barrier earlier)
+  const double eps = 1.4901161193847656e-08;  // sqrt(DBL_EPSILON) = 2^-26
+  for (int e = tid; e < E; e += nt) {
+    double dq = 1.0;
+    if (e >= 1 && (e < 1 + nP + nT || central)) {
+      const int i = (e - 1) % nq;
+      const double qi = (e < 1 + nP) ? q1[i] : ((e < 1 + nP + nT) ? q0[i] : qm1[i]);
+      dq = eps * __builtin_fmax(1.0, __builtin_fabs(qi));
+      const double temp = qi + dq;
+      dq = temp - qi;
+    }
+    edq[e] = dq;
+    const double dv = dq / dt;   // (once per evaluation: an f64 division is ~30 dependent instructions, and the
+    edv[e] = dv;                 // input loops below would repeat both for every velocity component)
+    eda[e] = dv / dt;
+  }
   __syncthreads();
   for (int r = tid; r < nv; r += nt) a0[r] = (v1[r] - v0[r]) / dt;
   __syncthreads();
@@ -330,20 +348,7 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
   }
 
   if (stop_after == 1) return;  // (profiling aid: phase timing by truncation) after N+, v, a
-  // ---- evaluation inputs (TO.cc:501-521)
-  const double eps = 1.4901161193847656e-08;  // sqrt(DBL_EPSILON) = 2^-26
-  for (int e = tid; e < E; e += nt) {
-    double dq = 1.0;
-    if (e >= 1 && (e < 1 + nP + nT || central)) {
-      const int i = (e - 1) % nq;
-      const double qi = (e < 1 + nP) ? q1[i] : ((e < 1 + nP + nT) ? q0[i] : qm1[i]);
-      dq = eps * __builtin_fmax(1.0, __builtin_fabs(qi));
-      const double temp = qi + dq;
-      dq = temp - qi;
-    }
-    edq[e] = dq;
-  }
-  __syncthreads();
+  // ---- evaluation inputs (TO.cc:501-521): the perturbations were formed with N+ / v above
   for (int c0 = 0; c0 < E; c0 += EC) {
   const int ce = (E - c0 < EC) ? E - c0 : EC;  // evaluations [c0, c0 + ce) in this pass
   for (int idx = tid; idx < ce * nq; idx += nt) {
@@ -366,7 +371,7 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
     if (central && e >= 1) {
       const int g = (e - 1) / (NM * nq), mi = ((e - 1) / nq) % NM, i = (e - 1) % nq;
       const double mult = (mi == 0) ? 1.0 : ((mi == 1) ? -1.0 : ((mi == 2) ? 2.0 : -2.0));
-      const double dv = edq[e] / dt, da = dv / dt;
+      const double dv = edv[e], da = eda[e];
       const double n1 = N1[i * nv + j], n0 = N0[i * nv + j];
       if (g == 0) {         // tau_k(q_{k+1} + m dq): TO.cc:763-787
         vv = v1[j] + (mult * dv) * n1;
@@ -379,13 +384,13 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
       }
     } else if (e >= 1 && e < 1 + nP) {
       const int i = e - 1;
-      const double dv = edq[e] / dt, da = dv / dt;
+      const double dv = edv[e], da = eda[e];
       const double n1 = N1[i * nv + j];
       vv = v1[j] + dv * n1;
       aa = a0[j] + da * n1;
     } else if (e >= 1 + nP && e < 1 + nP + nT) {
       const int i = e - 1 - nP;
-      const double dv = edq[e] / dt, da = dv / dt;
+      const double dv = edv[e], da = eda[e];
       const double n1 = N1[i * nv + j], n0 = N0[i * nv + j];
       vv = v1[j] - dv * n1;
       aa = a0[j] - da * (n1 + n0);
