@@ -16,4 +16,26 @@ __host__ __device__ __forceinline__ T* at_problem(T* p, size_t byte_off) {
   return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<U*>(p)) + byte_off);
 }
 
+// Two sets of what fd_kernel writes (v, a, N+, the slab of partials and tau, the assembly products)
+// inside one arena, `off` bytes apart (idto_hip_tr_solve): the device-resident trust-region loop
+// evaluates the trial point into the set the iterate does NOT occupy, and accepting a step is
+// flipping one word of device state - a rejected step keeps the iterate's partials.  `which`: 0 the
+// iterate's set, 1 the other one.  state == nullptr: set A, always.
+constexpr int IDTO_TRS_CUR = 9;   // index of the current-set word in the loop's device state (trust_region.h TRS_CUR)
+struct AltSel {
+  const double* state;
+  long long off;
+  int which;
+};
+__device__ __forceinline__ long long alt_offset(const AltSel& s) {
+  if (!s.state) return 0;
+  const bool cur1 = s.state[IDTO_TRS_CUR] != 0.0;
+  return (cur1 != (s.which != 0)) ? s.off : 0;
+}
+template <class T>
+__device__ __forceinline__ T* at_set(T* p, const AltSel& s) {
+  using U = typename std::remove_const<T>::type;
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<U*>(p)) + alt_offset(s));
+}
+
 }  // namespace idto_dev

@@ -148,6 +148,10 @@ struct idto_hip_ctx {
   // idto_hip_tr_solve: the iteration state and the arrival counter of tr_iter_kernel (device), the
   // per-iteration statistics rows (device, grown on demand), a pinned staging area for both
   double* tr_state = nullptr;
+  // second set of fd_kernel's outputs (v, a, N+, slab, products), alt_off bytes behind the first, and
+  // the selectors the launches pass (batch.h AltSel): inactive (state == nullptr) outside idto_hip_tr_solve
+  long long alt_off = 0;
+  AltSel alt_r{nullptr, 0, 0}, alt_w{nullptr, 0, 1};
   unsigned long long* tr_cnt = nullptr;
   unsigned long long tr_target = 0;
   double* tr_rows = nullptr;
@@ -346,7 +350,7 @@ int FdLds(const idto_hip_ctx* c, int mode, int ec, bool with_terms = false) {
 // derivatives requested): grad_hess then only combines them
 static bool FoldTerms(const idto_hip_ctx* c, int mode) { return c->asm_fold && c->weights_diagonal && mode >= 1; }
 
-int LaunchFd(idto_hip_ctx* c, int mode, int kb, int ke) {
+int LaunchFd(idto_hip_ctx* c, int mode, int kb, int ke, AltSel alt = AltSel{nullptr, 0, 0}) {
   if (ke <= kb) return 0;
   if (mode >= 1) mode = 1 + c->gradients_method;  // 1 forward, 2 central, 3 central (4th order)
   dim3 grid(ke - kb, c->batch), block(mode >= 1 ? c->fd_threads : 64);
@@ -363,7 +367,7 @@ int LaunchFd(idto_hip_ctx* c, int mode, int kb, int ke) {
   if (mode >= 1) c->terms_valid = fold && kb == 0 && ke == c->N;
 #define FD_LAUNCH(MC)                                                                                         \
   hipLaunchKernelGGL(fd_kernel<MC>, grid, block, lds, c->stream, c->M, c->cp, c->P, c->q, c->slab,             \
-                     c->slab_stride, c->v, c->a, c->nplus, kb, mode, c->fd_stop, ec, c->pstride, terms)
+                     c->slab_stride, c->v, c->a, c->nplus, kb, mode, c->fd_stop, ec, c->pstride, terms, alt)
   if (c->maxc <= 2) FD_LAUNCH(2);
   else if (c->maxc <= 3) FD_LAUNCH(3);
   else if (c->maxc <= 4) FD_LAUNCH(4);
@@ -500,8 +504,16 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   const size_t o_vinit = carve(nv, D), o_qnom = carve((size_t)(N + 1) * nq, D), o_vnom = carve((size_t)(N + 1) * nv, D);
   size_t o_w[10];
   for (int i = 0; i < 10; ++i) o_w[i] = carve((i == 0 || i == 3 || i == 5 || i == 8) ? qq : (size_t)nv * nv, D);
-  const size_t o_q = carve((size_t)(N + 1) * nq, D), o_v = carve((size_t)(N + 1) * nv, D), o_a = carve((size_t)N * nv, D);
-  const size_t o_np = carve((size_t)(N + 1) * bsz, D), o_slab = carve((size_t)(N + IDTO_SLAB_PAD) * c->slab_stride, D);
+  const size_t o_q = carve((size_t)(N + 1) * nq, D);
+  // what fd_kernel writes, twice (batch.h AltSel): two identical carve sequences = identical relative offsets
+  size_t o_v = 0, o_a = 0, o_np = 0, o_slab = 0, o_terms = 0, o_setB = 0;
+  for (int set = 0; set < 2; ++set) {
+    const size_t v0 = carve((size_t)(N + 1) * nv, D), a0 = carve((size_t)N * nv, D), n0 = carve((size_t)(N + 1) * bsz, D);
+    const size_t s0 = carve((size_t)(N + IDTO_SLAB_PAD) * c->slab_stride, D), t0 = carve((size_t)N * asm_terms_stride(nq), D);
+    if (set == 0) { o_v = v0; o_a = a0; o_np = n0; o_slab = s0; o_terms = t0; }
+    else o_setB = v0;
+  }
+  c->alt_off = (long long)(o_setB - o_v);
   const size_t o_g = carve((size_t)(N + 1) * nq, D);
   // two extra zero blocks (five are reserved): the solver prefetches rows i+1, i+2 without bounds
   // checks (one allocation: the solver addresses all three bands from HA with 32-bit offsets)
@@ -522,7 +534,6 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   const size_t nvars = (size_t)(N + 1) * nq;
   const size_t o_trD = carve(nvars, D), o_trg = carve(nvars, D), o_trw = carve(nvars, D), o_trdq = carve(nvars, D),
                o_qt = carve(nvars, D), o_trout = carve(16, D), o_trDp = carve(nvars, D), o_trpart = carve((size_t)9 * (N + 1), D);
-  const size_t o_terms = carve((size_t)N * asm_terms_stride(nq), D);
   const size_t o_trstate = carve(TRS_COUNT, D), o_trcnt = carve(1, sizeof(unsigned long long));
   c->pstride = (top + 255) & ~(size_t)255;
   {
@@ -741,7 +752,7 @@ int idto_hip_eval_tau(idto_hip_ctx* c) {
   if (rc) return rc;
   hipLaunchKernelGGL(cost_kernel, dim3(1, c->batch), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
                      c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, (double*)nullptr, c->pstride, (double*)nullptr,
-                     TrDecideArgs{});
+                     TrDecideArgs{}, AltSel{nullptr, 0, 0});
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -766,7 +777,7 @@ int idto_hip_trial_cost(idto_hip_ctx* c, const double* q_host, double* tau_host,
   int rc = LaunchFd(c, 0, 0, c->N);
   if (rc) return rc;
   hipLaunchKernelGGL(cost_kernel, dim3(1), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
-                     c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, c->pack, (size_t)0, (double*)nullptr, TrDecideArgs{});
+                     c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, c->pack, (size_t)0, (double*)nullptr, TrDecideArgs{}, AltSel{nullptr, 0, 0});
   HIP_OK(hipGetLastError());
   double* out = c->pin + nq_all;
   HIP_OK(hipMemcpyAsync(out, c->pack, (ntau + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -798,11 +809,11 @@ static int LaunchAssemble(idto_hip_ctx* c, const double* gate) {
   c->last_assembly = combine ? 1 : (c->weights_diagonal ? 2 : 3);
   if (combine) {
     hipLaunchKernelGGL(assemble_terms_kernel, dim3(c->N + 1, 4, c->batch), dim3(256), c->asm_terms_lds, c->stream, c->M, c->P,
-                       c->q, c->terms, c->v, c->nplus, c->g, c->HA, c->HB, c->HC, c->pstride, gate);
+                       c->q, c->terms, c->v, c->nplus, c->g, c->HA, c->HB, c->HC, c->pstride, gate, c->alt_r);
   } else if (c->weights_diagonal) {
     hipLaunchKernelGGL(assemble_diag_kernel, dim3(c->N + 1, 4, c->batch), dim3(256), c->asm_diag_lds, c->stream, c->M,
                        c->P, c->q, c->slab, c->slab_stride, c->g, c->HA, c->HB, c->HC, c->asm_stop,
-                       c->fd_full ? c->v : nullptr, c->fd_full ? c->nplus : nullptr, c->pstride, gate);
+                       c->fd_full ? c->v : nullptr, c->fd_full ? c->nplus : nullptr, c->pstride, gate, c->alt_r);
   } else {
     if (gate) { g_err = "gated assembly needs diagonal cost weights"; return -1; }
     hipLaunchKernelGGL(assemble_kernel, dim3(c->N + 1, c->batch), dim3(256), c->asm_lds, c->stream, c->M, c->P, c->q,
@@ -1314,7 +1325,7 @@ int idto_hip_tr_trial(idto_hip_ctx* c, double a, double b, int scaling, int norm
   int rc = LaunchFd(c, 0, 0, c->N);
   if (!rc) {
     hipLaunchKernelGGL(cost_kernel, dim3(1), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
-                       c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, (double*)nullptr, (size_t)0, c->tr_out + 11, TrDecideArgs{});
+                       c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, (double*)nullptr, (size_t)0, c->tr_out + 11, TrDecideArgs{}, AltSel{nullptr, 0, 0});
     if (with_lambda)
       hipLaunchKernelGGL(tr_hlambda_kernel, dim3(1), dim3(256), 16 * sizeof(double), c->stream, c->slab, c->slab_stride,
                          3 * c->nv * c->nq, c->con_dofs, c->con_nu, c->N, c->con_lambda_at, c->tr_out + 12);
@@ -1393,7 +1404,6 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
   for (int i = 0; i < TRS_COUNT; ++i) c->tr_pin[i] = 0.0;
   c->tr_pin[TRS_DELTA] = Delta0;
   c->tr_pin[TRS_ACCEPTED] = 1.0;
-  c->tr_pin[TRS_SLAB_IS_Q] = 1.0;
   HIP_OK(hipMemcpyAsync(c->tr_state, c->tr_pin, TRS_COUNT * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIP_OK(hipMemcpyAsync(c->tr_state + TRS_COST, c->cost, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   const double eps = 10 * std::numeric_limits<double>::epsilon() / c->P.dt / c->P.dt;   // TO.cc:2024
@@ -1402,9 +1412,19 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
   int rc = idto_hip_gn_step(c);
   if (rc) return rc;
   const bool lookahead = c->weights_diagonal && c->asm_stop == 0 && c->fd_stop == 0;
+  // from here on the trial point's v, a, N+, tau, partials go to the set the iterate does not occupy
+  struct AltGuard {
+    idto_hip_ctx* c;
+    ~AltGuard() { c->alt_r.state = nullptr; c->alt_w.state = nullptr; }
+  } alt_guard{c};
+  if (lookahead) {
+    c->alt_r = AltSel{c->tr_state, c->alt_off, 0};
+    c->alt_w = AltSel{c->tr_state, c->alt_off, 1};
+  }
   for (int k = 0; k < iterations; ++k) {
     TrIterArgs T;
     T.rows = PrepareArgs(c, scaling_method, 0);
+    T.alt = c->alt_r;
     T.counter = c->tr_cnt;
     c->tr_target += (unsigned long long)nblk;
     T.target = c->tr_target;
@@ -1421,11 +1441,11 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
     Dc.eta = eta; Dc.Delta_max = Delta_max; Dc.eps = eps;
     const bool more = k + 1 < iterations;
     std::swap(c->q, c->q_trial);
-    rc = LaunchFd(c, (lookahead && more) ? 1 : 0, 0, c->N);
+    rc = LaunchFd(c, (lookahead && more) ? 1 : 0, 0, c->N, c->alt_w);
     if (!rc)
       hipLaunchKernelGGL(cost_kernel, dim3(1), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
                          c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, (double*)nullptr, (size_t)0,
-                         (double*)nullptr, Dc);
+                         (double*)nullptr, Dc, c->alt_w);
     std::swap(c->q, c->q_trial);
     if (rc) return rc;
     HIP_OK(hipGetLastError());
@@ -1444,6 +1464,12 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
   HIP_OK(hipStreamSynchronize(c->stream));
   HIP_OK(hipMemcpy(rows_host, c->tr_rows, (size_t)iterations * TRR_COUNT * sizeof(double), hipMemcpyDeviceToHost));
   if (Delta_out) *Delta_out = c->tr_pin[TRS_DELTA];
+  if (c->tr_pin[TRS_CUR] != 0.0) {   // the iterate's v, a, N+, slab, products ended up in the other set: it is "the" set now
+    c->v = at_problem(c->v, (size_t)c->alt_off); c->a = at_problem(c->a, (size_t)c->alt_off);
+    c->nplus = at_problem(c->nplus, (size_t)c->alt_off); c->slab = at_problem(c->slab, (size_t)c->alt_off);
+    c->terms = at_problem(c->terms, (size_t)c->alt_off);
+    c->alt_off = -c->alt_off;
+  }
   return FactorStatus(c);
 }
 

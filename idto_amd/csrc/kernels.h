@@ -548,11 +548,12 @@ template <int MAXC>
 __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevProblem P, const double* __restrict__ q,
                           double* __restrict__ slab, int slab_stride, double* __restrict__ v_out,
                           double* __restrict__ a_out, double* __restrict__ nplus_out, int k_begin, int mode,
-                          int stop_after, int echunk, size_t pstride, double* __restrict__ terms) {
-  const size_t o = (size_t)blockIdx.y * pstride;  // problem of the batch
-  fd_body<MAXC>(M, cp, at_problem(P, o), at_problem(q, o), at_problem(slab, o), slab_stride, at_problem(v_out, o),
-                at_problem(a_out, o), at_problem(nplus_out, o), k_begin + (int)blockIdx.x, mode, stop_after, echunk,
-                terms ? at_problem(terms, o) : nullptr);
+                          int stop_after, int echunk, size_t pstride, double* __restrict__ terms, AltSel alt) {
+  const size_t o = (size_t)blockIdx.y * pstride;   // problem of the batch
+  const size_t w = o + (size_t)alt_offset(alt);    // ... and the set of outputs (batch.h AltSel)
+  fd_body<MAXC>(M, cp, at_problem(P, o), at_problem(q, o), at_problem(slab, w), slab_stride, at_problem(v_out, w),
+                at_problem(a_out, w), at_problem(nplus_out, w), k_begin + (int)blockIdx.x, mode, stop_after, echunk,
+                terms ? at_problem(terms, w) : nullptr);
 }
 
 // ---------------------------------------------------------------------------
@@ -561,10 +562,10 @@ __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevP
 __global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__ q, const double* __restrict__ v,
                             const double* __restrict__ slab, int slab_stride, double* __restrict__ cost_out,
                             int diag, double* __restrict__ pack, size_t pstride, double* __restrict__ cost_copy,
-                            TrDecideArgs T) {
+                            TrDecideArgs T, AltSel alt) {
   {
-    const size_t o = (size_t)blockIdx.y * pstride;
-    P = at_problem(P, o); q = at_problem(q, o); v = at_problem(v, o); slab = at_problem(slab, o);
+    const size_t o = (size_t)blockIdx.y * pstride, w = o + (size_t)alt_offset(alt);
+    P = at_problem(P, o); q = at_problem(q, o); v = at_problem(v, w); slab = at_problem(slab, w);
     cost_out = at_problem(cost_out, o);
     if (pack) pack = at_problem(pack, o);
   }
@@ -1049,12 +1050,13 @@ __global__ void __launch_bounds__(256)
 assemble_diag_kernel(DevModel M, DevProblem P, const double* __restrict__ q, const double* __restrict__ slab,
                      int slab_stride, double* __restrict__ g, double* __restrict__ HA, double* __restrict__ HB,
                      double* __restrict__ HC, int stop_after, const double* __restrict__ v_res,
-                     const double* __restrict__ nplus_res, size_t pstride, const double* __restrict__ gate) {
+                     const double* __restrict__ nplus_res, size_t pstride, const double* __restrict__ gate, AltSel alt) {
   if (gate && *gate == 0.0) return;   // (idto_hip_tr_solve: the step was rejected, g and H of the iterate stay)
   const size_t o = (size_t)blockIdx.z * pstride;  // problem of the batch
-  assemble_diag_body(M, at_problem(P, o), at_problem(q, o), at_problem(slab, o), slab_stride, at_problem(g, o),
+  const size_t w = o + (size_t)alt_offset(alt);   // ... and the iterate's set of fd_kernel outputs
+  assemble_diag_body(M, at_problem(P, o), at_problem(q, o), at_problem(slab, w), slab_stride, at_problem(g, o),
                      at_problem(HA, o), at_problem(HB, o), at_problem(HC, o), stop_after,
-                     v_res ? at_problem(v_res, o) : nullptr, nplus_res ? at_problem(nplus_res, o) : nullptr,
+                     v_res ? at_problem(v_res, w) : nullptr, nplus_res ? at_problem(nplus_res, w) : nullptr,
                      (int)blockIdx.x, (int)blockIdx.y);
 }
 
@@ -1070,12 +1072,12 @@ __global__ void __launch_bounds__(256)
 assemble_terms_kernel(DevModel M, DevProblem P, const double* __restrict__ q, const double* __restrict__ terms,
                       const double* __restrict__ v_res, const double* __restrict__ nplus_res, double* __restrict__ g,
                       double* __restrict__ HA, double* __restrict__ HB, double* __restrict__ HC, size_t pstride,
-                      const double* __restrict__ gate) {
+                      const double* __restrict__ gate, AltSel alt) {
   if (gate && *gate == 0.0) return;   // (idto_hip_tr_solve: the step was rejected, g and H of the iterate stay)
   {
-    const size_t o = (size_t)blockIdx.z * pstride;
-    P = at_problem(P, o); q = at_problem(q, o); terms = at_problem(terms, o); v_res = at_problem(v_res, o);
-    nplus_res = at_problem(nplus_res, o); g = at_problem(g, o);
+    const size_t o = (size_t)blockIdx.z * pstride, w = o + (size_t)alt_offset(alt);
+    P = at_problem(P, o); q = at_problem(q, o); terms = at_problem(terms, w); v_res = at_problem(v_res, w);
+    nplus_res = at_problem(nplus_res, w); g = at_problem(g, o);
     HA = at_problem(HA, o); HB = at_problem(HB, o); HC = at_problem(HC, o);
   }
   extern __shared__ double lds[];

@@ -15,6 +15,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "batch.h"
+
 namespace idto_dev {
 
 // block-wide sums of NS values per thread; result valid in thread 0
@@ -240,10 +242,11 @@ enum {
   TRS_FLAGS,       // (as an integer value) TRF_*: sticky, the remaining iterations are idle
   TRS_ITER,        // iterations decided so far
   TRS_ACCEPTED,    // the last decision: gates the assembly of the next iteration (a rejected step keeps g, H)
-  TRS_SLAB_IS_Q,   // tau in the slab belongs to the iterate (not to a rejected trial point) ...
-  TRS_HH,          // ... else h.h of the iterate, from the iteration that last saw it
+  TRS_SPARE,
+  TRS_CUR,         // which of the two sets of fd_kernel outputs holds the iterate's (batch.h AltSel)
   TRS_COUNT = 12
 };
+static_assert(TRS_CUR == IDTO_TRS_CUR, "batch.h and trust_region.h disagree");
 enum { TRF_DOGLEG = 1, TRF_NONFINITE = 2, TRF_NOT_DESCENT = 4 };
 // one row of per-iteration statistics (TrajectoryOptimizerStats::push_data, TO.cc:2586-2598)
 enum { TRR_COST = 0, TRR_DELTA, TRR_RHO, TRR_QNORM, TRR_DQNORM, TRR_DQHNORM, TRR_GNORM, TRR_DLDQ, TRR_HNORM,
@@ -251,6 +254,7 @@ enum { TRR_COST = 0, TRR_DELTA, TRR_RHO, TRR_QNORM, TRR_DQNORM, TRR_DQHNORM, TRR
 
 struct TrIterArgs {
   TrRowsArgs rows;
+  AltSel alt;                    // rows.slab is set A's: h = tau[unactuated] is read from the iterate's set
   unsigned long long* counter;   // monotonic: workgroups of tr_iter_kernel that have published their partial sums
   unsigned long long target;     // ... its value once every workgroup of THIS launch has
   double* out;                   // [11] the nine inner products, then dq.dq and g~.D^-1 dq
@@ -281,6 +285,7 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
   extern __shared__ double lds[];
   __shared__ int last;
   __shared__ double ab[2];
+  T.rows.slab = at_set(T.rows.slab, T.alt);
   tr_prepare_rows_body(T.rows, lds);
   const int tid = threadIdx.x, nt = blockDim.x, nblk = T.rows.nblk, n = T.n;
   if (tid == 0) {   // (block_sums left a barrier behind the partial sums of thread 0)
@@ -302,11 +307,6 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
   if (tid < 9) {
     double acc = 0.0;
     for (int i = 0; i < nblk; ++i) acc += part[i * 9 + tid];
-    // (h = tau[unactuated], statistics only here) after a rejected step the slab holds the trial point's tau
-    if (tid == 7) {
-      if (T.state[TRS_SLAB_IS_Q] != 0.0) T.state[TRS_HH] = acc;
-      else acc = T.state[TRS_HH];
-    }
     S[tid] = acc;
     T.out[tid] = acc;
   }
@@ -411,7 +411,7 @@ __device__ inline bool tr_decide(const TrDecideArgs& T, double cost_trial) {
   T.state[TRS_FLAGS] = (double)flags;
   T.state[TRS_ITER] = (double)(k + 1);
   T.state[TRS_ACCEPTED] = accept ? 1.0 : 0.0;
-  T.state[TRS_SLAB_IS_Q] = accept ? 1.0 : 0.0;   // (tau, v, a, N+ and the partials in device memory are the trial point's)
+  if (accept) T.state[TRS_CUR] = (T.state[TRS_CUR] != 0.0) ? 0.0 : 1.0;   // the trial point's set is the iterate's now
   return accept;
 }
 
