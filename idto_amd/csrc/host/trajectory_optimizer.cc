@@ -961,9 +961,15 @@ SolverFlag TO::SolveFromWarmStart(WarmStart* ws, TrajectoryOptimizerSolution<T>*
 // Used when no equality constraints are enforced and convergence checks are off (the configuration
 // of the mini_cheetah example); otherwise SolveFromWarmStartImpl below keeps g / H on the host.
 bool TO::DeviceLoopEligible() const {
-  if (std::getenv("IDTO_OPT_HOST_LOOP")) return false;
+  if (std::getenv("IDTO_OPT_HOST_LOOP") || force_host_loop_) return false;
+  if (params_.check_convergence || !shard_ctx_.empty()) return false;
   const bool constrained = params_.equality_constraints && num_equality_constraints() > 0;
-  return !constrained && !params_.check_convergence && shard_ctx_.empty();
+  if (!constrained) return true;
+  // enforced constraints: only the resident loop (idto_hip_tr_solve) has them on the device - multipliers by a
+  // single-workgroup LDL^T of S (n_eq <= 128), the non-adaptive scalings
+  const int scal = params_.scaling ? static_cast<int>(params_.scaling_method) : -1;
+  return num_equality_constraints() <= 128 && (scal == -1 || scal == 0 || scal == 2) && params_.max_iterations > 0 &&
+         !std::getenv("IDTO_OPT_STEPWISE");
 }
 
 SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solution,
@@ -998,14 +1004,31 @@ SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solu
     const int iters = params_.max_iterations;
     std::vector<double> rows((std::size_t)iters * IDTO_TR_ROW);
     double Delta_end = Delta;
+    const bool constrained = params_.equality_constraints && num_equality_constraints() > 0;
     Check(idto_hip_tr_solve(hip_, iters, scal, params_.scaling ? 1 : 0, params_.normalize_quaternions ? 1 : 0, Delta,
-                            params_.Delta_max, eta, rows.data(), &Delta_end));
+                            params_.Delta_max, eta, constrained ? unactuated_dofs_.data() : nullptr,
+                            constrained ? (int)unactuated_dofs_.size() : 0, rows.data(), &Delta_end));
     const double total = std::chrono::duration<double>(clock::now() - start_time).count();
     double timed = 0.0;
     for (int i = 1; i < iters; ++i) timed += (rows[(std::size_t)i * IDTO_TR_ROW + 10] - rows[(std::size_t)(i - 1) * IDTO_TR_ROW + 10]) * 1e-8;
     for (; k < iters; ++k) {
       const double* R = rows.data() + (std::size_t)k * IDTO_TR_ROW;
       const int flags = (int)R[14];
+      if (flags & 8) {
+        // numerically singular S = J H^-1 J^T (redundant constraints) at this iterate: the host loop's pivoted
+        // LDL^T (Eigen's, in the reference) handles it; q on the device is still this iteration's iterate
+        state.set_q(Unflatten(Fetch(IDTO_ARR_Q), num_steps() + 1, nq_));
+        resident_ = nullptr;
+        device_level_ = 0;
+        Delta = R[1];
+        force_host_loop_ = true;
+        resume_k_ = k;
+        struct Reset { const TO* t; ~Reset() { t->force_host_loop_ = false; t->resume_k_ = 0; } } reset{this};
+        const double device_part = std::chrono::duration<double>(clock::now() - start_time).count();
+        const SolverFlag flag = SolveFromWarmStartImpl(ws, solution, stats, nullptr);
+        stats->solve_time += device_part;
+        return flag;
+      }
       if (flags & 3) throw FactorizationFailedError("idto_hip: the dogleg step is not finite");
       if (flags & 4) throw std::runtime_error("step is not a descent direction (TO.cc:2531)");
       const double iter_time = (k == 0) ? std::max(0.0, total - timed) : (R[10] - R[10 - IDTO_TR_ROW]) * 1e-8;
@@ -1013,7 +1036,7 @@ SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solu
         std::printf("| %6d | %8.3g | %7.2g | %7.3g | %10.5g | %10.5g | %10.4g | %10.4g |\n", k, R[0], R[1], R[2], iter_time,
                     R[6] / R[0], R[7], R[8]);
       stats->push_data(iter_time, R[0], 0, std::numeric_limits<double>::quiet_NaN(), R[1], R[3], R[4], R[5], R[2], R[6],
-                       R[7], R[8], R[0]);   // :2586-2598 (merit = cost without constraints)
+                       R[7], R[8], R[15]);   // :2586-2598 (merit = cost without constraints)
       last_accepted = R[9] != 0.0;
     }
     Delta = Delta_end;
@@ -1111,7 +1134,7 @@ SolverFlag TO::SolveFromWarmStartImpl(WarmStart* ws, TrajectoryOptimizerSolution
   Vec& dq = ws->dq;
   Vec& dqH = ws->dqH;
   const double eta = 0.0;  // trust ratio threshold (:2466)
-  int k = 0;
+  int k = resume_k_;       // (> 0: taking over from the device-resident loop)
   double& Delta = ws->Delta;
   double previous_cost = EvalCost(state);
   if (params_.verbose) {

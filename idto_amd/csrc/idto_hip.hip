@@ -638,6 +638,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cost_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_terms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&constraint_lambda_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
 #define APPLY_ATTR(KM) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_apply_kernel<KM>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   APPLY_ATTR(2) APPLY_ATTR(3) APPLY_ATTR(5) APPLY_ATTR(8) APPLY_ATTR(16) APPLY_ATTR(19) APPLY_ATTR(23) APPLY_ATTR(24) APPLY_ATTR(32)
 #undef APPLY_ATTR
@@ -1142,13 +1143,13 @@ int idto_hip_constraint_schur_begin(idto_hip_ctx* c, const int* dofs, int nu) {
   c->con_ready = false; c->con_begun = false;
   if (EnsureStage(c, (size_t)(neq + 1) * n)) return -2;
   hipLaunchKernelGGL(constraint_rhs_kernel, dim3(neq + 1), dim3(256), 0, c->stream, c->slab, c->slab_stride, c->g,
-                     c->con_dofs, nu, N, c->nq, c->nv, c->stage_rhs);
+                     c->con_dofs, nu, N, c->nq, c->nv, c->stage_rhs, c->alt_r);
   HIP_OK(hipGetLastError());
   int rc = idto_hip_factor_solve(c, c->stage_rhs, neq + 1, c->stage_x);
   if (rc) return rc;
   hipLaunchKernelGGL(constraint_schur_kernel, dim3(neq), dim3(256), 3 * c->nq * sizeof(double), c->stream, c->slab,
                      c->slab_stride, c->con_dofs, nu, N, c->nq, c->nv, c->stage_x, neq, c->con_S,
-                     c->con_S + (size_t)neq * neq);
+                     c->con_S + (size_t)neq * neq, c->alt_r);
   HIP_OK(hipGetLastError());
   c->con_S_factored = false;
   c->con_begun = true;
@@ -1167,7 +1168,7 @@ int idto_hip_constraint_schur(idto_hip_ctx* c, const int* dofs, int nu, double* 
   if (c->con_S_factored) {  // the device factorisation overwrote S: form it again from Y
     hipLaunchKernelGGL(constraint_schur_kernel, dim3(neq), dim3(256), 3 * c->nq * sizeof(double), c->stream, c->slab,
                        c->slab_stride, c->con_dofs, c->con_nu, c->N, c->nq, c->nv, c->stage_x, neq, c->con_S,
-                       c->con_S + (size_t)neq * neq);
+                       c->con_S + (size_t)neq * neq, c->alt_r);
     HIP_OK(hipGetLastError());
     c->con_S_factored = false;
   }
@@ -1210,7 +1211,7 @@ int idto_hip_constraint_solve(idto_hip_ctx* c, const double* h_host, double* lam
                      S + (size_t)neq * neq, -1.0, c->con_h + 2, c->con_lambda + 2);
   hipLaunchKernelGGL(constraint_step_kernel, dim3((n + 63) / 64), dim3(64 * STEP_WAVES), (neq + 64 * STEP_WAVES) * sizeof(double), c->stream, c->slab,
                      c->slab_stride, c->con_dofs, c->con_nu, N, c->nq, c->nv, c->stage_x, neq, c->con_lambda + 2,
-                     c->con_out, c->con_out + n);
+                     c->con_out, c->con_out + n, c->alt_r);
   HIP_OK(hipGetLastError());
   double* down = pin + neq + 2;
   HIP_OK(hipMemcpyAsync(down, c->con_h, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1238,7 +1239,7 @@ int idto_hip_constraint_step(idto_hip_ctx* c, const double* lambda_host, double*
   c->con_lambda_at = c->con_lambda;
   hipLaunchKernelGGL(constraint_step_kernel, dim3((n + 63) / 64), dim3(64 * STEP_WAVES), (neq + 64 * STEP_WAVES) * sizeof(double), c->stream, c->slab,
                      c->slab_stride, c->con_dofs, c->con_nu, N, c->nq, c->nv, c->stage_x, neq, c->con_lambda, c->con_out,
-                     c->con_out + n);
+                     c->con_out + n, c->alt_r);
   HIP_OK(hipGetLastError());
   HIP_OK(hipMemcpyAsync(pl + neq, c->con_out, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_OK(hipStreamSynchronize(c->stream));
@@ -1383,10 +1384,17 @@ int idto_hip_tr_reject(idto_hip_ctx* c) {
 }
 
 int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int scaling, int normalize_quaternions,
-                      double Delta0, double Delta_max, double eta, double* rows_host, double* Delta_out) {
+                      double Delta0, double Delta_max, double eta, const int* constrained_dofs, int nu,
+                      double* rows_host, double* Delta_out) {
   HIP_OK(hipSetDevice(c->device));
   if (c->batch != 1) { g_err = "tr_solve serves single-problem contexts"; return -1; }
   if (iterations <= 0) { g_err = "tr_solve: iterations must be positive"; return -1; }
+  if (nu < 0 || (nu > 0 && !constrained_dofs)) { g_err = "tr_solve: bad constraint arguments"; return -1; }
+  const int neq = nu * c->N;
+  if (nu > 0) {
+    if (neq > CON_LAMBDA_MAX) { g_err = "tr_solve: more equality constraints than the single-workgroup multiplier solve holds"; return -1; }
+    if (!c->weights_diagonal) { g_err = "tr_solve: enforced constraints need diagonal cost weights"; return -1; }
+  }
   if (!(scaling_method == -1 || scaling_method == 0 || scaling_method == 2)) {
     // (the adaptive methods keep a memory of D that a rejected step must not advance: stepwise loop)
     g_err = "tr_solve: scaling method not supported by the device-resident loop";
@@ -1408,10 +1416,17 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
   HIP_OK(hipMemcpyAsync(c->tr_state + TRS_COST, c->cost, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   const double eps = 10 * std::numeric_limits<double>::epsilon() / c->P.dt / c->P.dt;   // TO.cc:2024
   const int lds_iter = (int)sizeof(double) * std::max(23 * c->nq + 9 * 16, 9 * nblk + 9 + 32);
-  // g, H and the Newton step of the first iterate
-  int rc = idto_hip_gn_step(c);
+  // g, H and the Newton step of the first iterate (with constraints the step comes out of the multiplier chain)
+  int rc = 0;
+  if (nu > 0) {
+    rc = idto_hip_eval_partials(c);
+    if (!rc) rc = idto_hip_grad_hess(c);
+  } else {
+    rc = idto_hip_gn_step(c);
+  }
   if (rc) return rc;
   const bool lookahead = c->weights_diagonal && c->asm_stop == 0 && c->fd_stop == 0;
+  if (nu > 0 && !lookahead) { g_err = "tr_solve: enforced constraints need the two-set evaluation"; return -1; }
   // from here on the trial point's v, a, N+, tau, partials go to the set the iterate does not occupy
   struct AltGuard {
     idto_hip_ctx* c;
@@ -1422,8 +1437,26 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
     c->alt_w = AltSel{c->tr_state, c->alt_off, 1};
   }
   for (int k = 0; k < iterations; ++k) {
+    if (nu > 0) {
+      // multipliers of the iterate (TO.cc:1371-1396), all on the device: Y = H^-1 [g | J^T], S = J Y_J, J y_g
+      // (idto_hip_constraint_schur_begin), lambda = S^-1 (h - J y_g) in one workgroup, then H^-1 (g + J^T lambda)
+      // and J^T lambda (constraint_step_kernel)
+      c->con_begun = false;
+      rc = idto_hip_constraint_schur_begin(c, constrained_dofs, nu);
+      if (rc) return rc;
+      hipLaunchKernelGGL(constraint_lambda_kernel, dim3(1), dim3(CON_LAMBDA_THREADS),
+                         (size_t)con_lambda_lds_doubles(neq) * sizeof(double), c->stream,
+                         c->con_S, neq, c->slab, c->slab_stride, 3 * c->nv * c->nq, c->con_dofs, nu, c->con_lambda, c->tr_state,
+                         c->alt_r);
+      c->con_lambda_at = c->con_lambda;
+      hipLaunchKernelGGL(constraint_step_kernel, dim3((n + 63) / 64), dim3(64 * STEP_WAVES),
+                         (neq + 64 * STEP_WAVES) * sizeof(double), c->stream, c->slab, c->slab_stride, c->con_dofs, nu, c->N,
+                         c->nq, c->nv, c->stage_x, neq, c->con_lambda, c->con_out, c->con_out + n, c->alt_r);
+      HIP_OK(hipGetLastError());
+      c->con_ready = true;
+    }
     TrIterArgs T;
-    T.rows = PrepareArgs(c, scaling_method, 0);
+    T.rows = PrepareArgs(c, scaling_method, nu > 0 ? 1 : 0);
     T.alt = c->alt_r;
     T.counter = c->tr_cnt;
     c->tr_target += (unsigned long long)nblk;
@@ -1439,6 +1472,8 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
     TrDecideArgs Dc;
     Dc.state = c->tr_state; Dc.out = c->tr_out; Dc.rows = c->tr_rows; Dc.q = c->q; Dc.q_trial = c->q_trial; Dc.n = n;
     Dc.eta = eta; Dc.Delta_max = Delta_max; Dc.eps = eps;
+    Dc.lambda = nu > 0 ? c->con_lambda : nullptr; Dc.dofs = nu > 0 ? c->con_dofs : nullptr;
+    Dc.nu = nu; Dc.N = c->N; Dc.slab_stride = c->slab_stride; Dc.tau_off = 3 * c->nv * c->nq;
     const bool more = k + 1 < iterations;
     std::swap(c->q, c->q_trial);
     rc = LaunchFd(c, (lookahead && more) ? 1 : 0, 0, c->N, c->alt_w);
@@ -1453,7 +1488,7 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
     if (!more) break;
     if (lookahead) {
       rc = LaunchAssemble(c, c->tr_state + TRS_ACCEPTED);
-      if (!rc) rc = idto_hip_factor_solve(c, nullptr, 1, nullptr);   // (after a rejection: the same H, g -> the same step)
+      if (!rc && nu == 0) rc = idto_hip_factor_solve(c, nullptr, 1, nullptr);   // (after a rejection: the same H, g -> the same step)
     } else {
       rc = idto_hip_gn_step(c);   // (dense cost weights: the partials again, at the iterate)
     }
@@ -1671,6 +1706,8 @@ long idto_hip_array_size(idto_hip_ctx* c, int what) {
     case 15: return (N + 4) * 8 * 32;
     case IDTO_ARR_TR_DQ: case IDTO_ARR_TR_W: case IDTO_ARR_TR_SCALE: return (N + 1) * nq;
     case IDTO_ARR_ASM_TERMS: return N * (long)asm_terms_stride((int)nq);
+    case IDTO_ARR_CON_S: return c->con_S ? (long)c->con_neq * c->con_neq + c->con_neq : -1;
+    case IDTO_ARR_CON_LAMBDA: return (c->con_lambda_at && c->con_neq > 0) ? (long)c->con_neq : -1;
     default: return -1;
   }
 }
@@ -1697,6 +1734,8 @@ void* DevPtr(idto_hip_ctx* c, int what) {
     case IDTO_ARR_TR_W: return c->tr_w;
     case IDTO_ARR_TR_SCALE: return c->tr_D;
     case IDTO_ARR_ASM_TERMS: return c->terms;
+    case IDTO_ARR_CON_S: return c->con_S;
+    case IDTO_ARR_CON_LAMBDA: return const_cast<double*>(c->con_lambda_at);
     default: return nullptr;  // tau and the three partials live strided inside the slab
   }
 }

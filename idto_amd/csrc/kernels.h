@@ -620,8 +620,22 @@ __global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__
     *cost_out = cost;
     if (cost_copy) *cost_copy = cost;   // (single-problem contexts: next to the other trust-region scalars)
     if (pack) pack[N * nv] = cost;
-    // (idto_hip_tr_solve) this was the trial point of a trust-region iteration: ratio, accept / reject, radius
-    if (T.state) terms[0] = tr_decide(T, cost) ? 1.0 : 0.0;
+  }
+  if (T.state) {   // (idto_hip_tr_solve) this was the trial point of a trust-region iteration
+    const int neq = T.nu * T.N;
+    if (T.nu > 0) {   // h(q + dq) . lambda: products by everybody, added in index order by thread 0
+      __syncthreads();
+      for (int r = tid; r < neq; r += nt) {
+        const int t = r / T.nu, j = r - t * T.nu;
+        cols[r] = slab[(size_t)t * slab_stride + T.tau_off + T.dofs[j]] * T.lambda[r];
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {   // ratio, accept / reject, radius
+      double hl = 0.0;
+      for (int r = 0; r < neq && T.nu > 0; ++r) hl += cols[r];
+      terms[0] = tr_decide(T, *cost_out, hl) ? 1.0 : 0.0;
+    }
   }
   if (T.state) {
     __syncthreads();

@@ -247,10 +247,11 @@ enum {
   TRS_COUNT = 12
 };
 static_assert(TRS_CUR == IDTO_TRS_CUR, "batch.h and trust_region.h disagree");
-enum { TRF_DOGLEG = 1, TRF_NONFINITE = 2, TRF_NOT_DESCENT = 4 };
+enum { TRF_DOGLEG = 1, TRF_NONFINITE = 2, TRF_NOT_DESCENT = 4, TRF_SINGULAR_S = 8 /* constraints.h constraint_lambda_kernel */ };
 // one row of per-iteration statistics (TrajectoryOptimizerStats::push_data, TO.cc:2586-2598)
 enum { TRR_COST = 0, TRR_DELTA, TRR_RHO, TRR_QNORM, TRR_DQNORM, TRR_DQHNORM, TRR_GNORM, TRR_DLDQ, TRR_HNORM,
-       TRR_ACCEPTED, TRR_CLOCK /* wall_clock64 ticks (100 MHz) */, TRR_A, TRR_B, TRR_COST_TRIAL, TRR_FLAGS, TRR_COUNT = 16 };
+       TRR_ACCEPTED, TRR_CLOCK /* wall_clock64 ticks (100 MHz) */, TRR_A, TRR_B, TRR_COST_TRIAL, TRR_FLAGS,
+       TRR_MERIT /* L(q) + h(q).lambda (TO.cc:2583; = the cost without enforced constraints) */, TRR_COUNT = 16 };
 
 struct TrIterArgs {
   TrRowsArgs rows;
@@ -378,10 +379,15 @@ struct TrDecideArgs {
   const double* q_trial;
   int n;
   double eta, Delta_max, eps;
+  // enforced equality constraints (nu > 0): the merit function L + h.lambda at both points (TO.cc:1979-2003)
+  const double* lambda;   // [N nu] multipliers of the iterate
+  const int* dofs;        // [nu] unactuated degrees of freedom
+  int nu, N, slab_stride, tau_off;
 };
 
-// thread 0 of cost_kernel's workgroup, with the cost of the trial point; returns whether the step is accepted
-__device__ inline bool tr_decide(const TrDecideArgs& T, double cost_trial) {
+// thread 0 of cost_kernel's workgroup, with the cost of the trial point (and h(q + dq).lambda when
+// constraints are enforced); returns whether the step is accepted
+__device__ inline bool tr_decide(const TrDecideArgs& T, double cost_trial, double hl_trial) {
   const double* S = T.out;
   const double gg = S[0], gHg = S[1], ww = S[2], gw = S[3], gHw = S[4], wHw = S[5], qq = S[6], hh = S[7];
   const double a = T.state[TRS_A], b = T.state[TRS_B], Delta = T.state[TRS_DELTA], cost = T.state[TRS_COST];
@@ -393,7 +399,8 @@ __device__ inline bool tr_decide(const TrDecideArgs& T, double cost_trial) {
   // CalcTrustRatio (:2004-2034)
   const double gradient_term = a * gg + b * gw;
   const double hessian_term = 0.5 * (a * a * gHg + 2 * a * b * gHw + b * b * wHw);
-  const double predicted = -gradient_term - hessian_term, actual = cost - cost_trial;
+  const double merit_k = (T.nu > 0) ? cost + S[8] : cost, merit_kp = (T.nu > 0) ? cost_trial + hl_trial : cost_trial;
+  const double predicted = -gradient_term - hessian_term, actual = merit_k - merit_kp;
   const double rho = (predicted < T.eps && actual < T.eps) ? 0.5 : actual / predicted;
   if (!(dL_dq < 2.220446049250313e-16)) flags |= TRF_NOT_DESCENT;
   const bool accept = (flags == 0) && rho > T.eta;
@@ -403,6 +410,7 @@ __device__ inline bool tr_decide(const TrDecideArgs& T, double cost_trial) {
   R[TRR_DLDQ] = dL_dq; R[TRR_HNORM] = __builtin_sqrt(hh); R[TRR_ACCEPTED] = accept ? 1.0 : 0.0;
   R[TRR_CLOCK] = (double)wall_clock64(); R[TRR_A] = a; R[TRR_B] = b; R[TRR_COST_TRIAL] = cost_trial;
   R[TRR_FLAGS] = (double)flags;
+  R[TRR_MERIT] = merit_k;
   if (flags == 0) {
     if (accept) T.state[TRS_COST] = cost_trial;   // :2550-2553
     if (rho < 0.25) T.state[TRS_DELTA] = Delta * 0.25;                                                        // :2614-2617

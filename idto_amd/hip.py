@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libidto_hip.so")
 
 ARR = dict(q=0, v=1, a=2, tau=3, nplus=4, dtau_dqm=5, dtau_dqt=6, dtau_dqp=7, gradient=8, H_A=9, H_B=10, H_C=11,
-           step=12, cost=13, slab=14, debug=15, hbands=16, tr_dq=17, tr_w=18, tr_scale=19, asm_terms=20)
+           step=12, cost=13, slab=14, debug=15, hbands=16, tr_dq=17, tr_w=18, tr_scale=19, asm_terms=20, con_S=21, con_lambda=22)
 
 _lib = None
 
@@ -61,7 +61,7 @@ def lib():
                                         C.POINTER(C.c_double)]
         L.idto_hip_tr_accept.argtypes = [C.c_void_p]
         L.idto_hip_tr_solve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
-                                        C.POINTER(C.c_double), C.POINTER(C.c_double)]
+                                        C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.idto_hip_tr_reject.argtypes = [C.c_void_p]
         L.idto_hip_set_unactuated_dofs.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
         L.idto_hip_destroy.argtypes = [C.c_void_p]
@@ -238,12 +238,15 @@ class HipPath:
         _chk(lib().idto_hip_tr_reject(self.h))
 
     def tr_solve(self, iterations: int, scaling_method: int, scaling: bool, normalize_quaternions: bool, Delta0: float,
-                 Delta_max: float, eta: float = 0.0):
+                 Delta_max: float, eta: float = 0.0, constrained_dofs=()):
         """the whole trust-region loop on the device (idto_hip_tr_solve): (rows [iterations, 16], final Delta)"""
         rows = np.zeros((int(iterations), 16))
         delta = C.c_double(0.0)
+        dofs = np.ascontiguousarray(np.asarray(constrained_dofs, dtype=np.int32))
         _chk(lib().idto_hip_tr_solve(self.h, int(iterations), int(scaling_method), int(scaling), int(normalize_quaternions),
-                                     float(Delta0), float(Delta_max), float(eta), dptr(rows), C.byref(delta)))
+                                     float(Delta0), float(Delta_max), float(eta),
+                                     dofs.ctypes.data_as(C.POINTER(C.c_int)) if dofs.size else None, int(dofs.size),
+                                     dptr(rows), C.byref(delta)))
         return rows, delta.value
 
     def set_unactuated_dofs(self, dofs):

@@ -158,6 +158,10 @@ class TrajectoryOptimizer<double> {
   std::vector<idto_hip_ctx*> shard_ctx_;    // [hip_, contexts on the other devices] when sharded over devices
   mutable const void* resident_ = nullptr;  // state whose q is on the device
   mutable int device_level_ = 0;            // what has been evaluated for it there
+  // the device-resident loop met a singular constraint Schur complement at iteration resume_k_: the
+  // host loop (pivoted LDL^T) finishes the solve from that iterate
+  mutable bool force_host_loop_ = false;
+  mutable int resume_k_ = 0;
 };
 
 }  // namespace optimizer

@@ -65,6 +65,9 @@ enum idto_hip_array {
   IDTO_ARR_TR_DQ = 17,   /* (N+1)*nq : the step dq of the last idto_hip_tr_trial */
   IDTO_ARR_TR_W = 18,    /* (N+1)*nq : w = D^-1 H^-1 (g + J^T lambda) of the last idto_hip_tr_prepare */
   IDTO_ARR_TR_SCALE = 19, /* (N+1)*nq : scale factors D (CalcScaleFactors) */
+  IDTO_ARR_CON_S = 21,      /* n_eq*n_eq + n_eq : S = J H^-1 J^T (column-major) then J H^-1 g, of the last constraint step
+                               (overwritten by its factors when idto_hip_constraint_solve factorised it in place) */
+  IDTO_ARR_CON_LAMBDA = 22, /* n_eq : the multipliers of the last constraint step */
   IDTO_ARR_ASM_TERMS = 20 /* N*(6 nq^2 + 3 nq (+1)) : per-record assembly products (kernels.h asm_terms_stride) */
 };
 
@@ -232,13 +235,21 @@ int idto_hip_tr_reject(idto_hip_ctx* ctx);
  *   [10] device clock at the decision (100 MHz ticks) [11] a [12] b (dq = D (a g~ + b w)) [13] L(q_k + dq)
  *   [14] flags: 1 dogleg quadratic has no root in (0,1), 2 step not finite, 4 step is not a descent
  *   direction (where the reference throws); once a flag is set the remaining iterations are idle.
+ *   [15] the merit function L(q_k) + h(q_k).lambda_k.  Flag 8: the constraints' Schur complement is
+ *   numerically singular (redundant constraints; the host's pivoted LDL^T copes, the single-workgroup
+ *   solve does not): continue from the iterate with the stepwise calls.
+ * constrained_dofs / nu: the unactuated degrees of freedom whose tau is constrained to zero
+ * (CalcEqualityConstraintViolations, TO.cc:1257-1290), nu = 0: none enforced.  With nu > 0 every iteration
+ * also runs H^-1 [g | J^T], S = J H^-1 J^T, lambda = S^-1 (h - J H^-1 g) (TO.cc:1371-1396; nu * num_steps <=
+ * 128) and the step H^-1 (g + J^T lambda) on the device, and the ratio uses the merit function.
  * scaling_method: -1 none, 0 kSqrt, 2 kDoubleSqrt (the adaptive methods: use the stepwise calls).
  * On return q, v, a, tau, N+ in device memory are those of the final iterate when the last step was
  * accepted; after a rejected last step v, a, tau belong to the dropped trial point.
  * Returns IDTO_HIP_FACTORIZATION_FAILED when any iteration's factorisation failed. */
 #define IDTO_TR_ROW 16
 int idto_hip_tr_solve(idto_hip_ctx* ctx, int iterations, int scaling_method, int scaling, int normalize_quaternions,
-                      double Delta0, double Delta_max, double eta, double* rows_host, double* Delta_out);
+                      double Delta0, double Delta_max, double eta, const int* constrained_dofs, int nu,
+                      double* rows_host, double* Delta_out);
 
 /* Options: "gradients_method" = 0 forward differences (default), 1 / 2 central differences of
  * 2nd / 4th order (SolverParameters::gradients_method, reference solver_parameters.h:26-50,

@@ -149,7 +149,7 @@ def test_resident_loop_equals_stepwise_loop(name, N, iters, scaling, method, qua
         x, y = getattr(a_st, series), getattr(b_st, series)
         assert x.size == iters and np.array_equal(x, y), (series, x, y)
     assert np.array_equal(a_sol.q, b_sol.q) and np.array_equal(a_sol.v, b_sol.v) and np.array_equal(a_sol.tau, b_sol.tau)
-    assert (a_st.iteration_times > 0).all() and abs(a_st.iteration_times.sum() - a_st.solve_time) < 0.5 * a_st.solve_time
+    assert (a_st.iteration_times > 0).all() and a_st.iteration_times.sum() <= a_st.solve_time   # (device clock per iteration)
     # some steps of these runs are rejected (acrobot) - the radius shrinks and the iterate stays
     if name == "acrobot":
         assert (a_st.trust_ratios <= 0).any()
@@ -179,4 +179,86 @@ def test_resident_loop_rows_and_failure():
     dev.eval_tau()
     with pytest.raises(hip.FactorizationFailed):
         dev.tr_solve(3, -1, False, False, 1e-1, 1e5)
+    dev.close()
+
+
+@pytest.mark.parametrize("name,N,iters", [("hopper", 40, 12), ("acrobot", 40, 20), ("spinner", 40, 15), ("allegro_hand", 12, 4)])
+def test_resident_loop_with_equality_constraints_follows_the_host_loop(name, N, iters, monkeypatch):
+    """enforced equality constraints (the example YAMLs of acrobot, spinner, hopper, allegro): the resident loop
+    computes the multipliers on the device - H^-1 [g | J^T], S = J H^-1 J^T, a single-workgroup LDL^T of S - and
+    uses the merit function; the host loop does the same with the host's pivoted LDL^T.  Different summation
+    orders, so no bit equality, and the iteration amplifies the last-bit differences (hopper: 4e-13 after two
+    iterations, 2e-7 after twelve): the tolerances of tests/test_gpu_optimizer.py's comparison with the oracle -
+    costs and merits 1e-6 relative, radii exactly the same sequence of halvings / doublings, q to 1e-5."""
+    from idto_amd.optimizer import TrajectoryOptimizer, TrajectoryOptimizerSolution, TrajectoryOptimizerStats
+    cfg, model = load_config(name), load_model(name)
+    prob, sp, q_guess = make_problem(cfg, model, num_steps=N)
+    sp.max_iterations, sp.verbose = iters, False
+    assert sp.equality_constraints
+    out = []
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv("IDTO_OPT_HOST_LOOP", "1")
+        else:
+            monkeypatch.delenv("IDTO_OPT_HOST_LOOP", raising=False)
+        opt = TrajectoryOptimizer(model, prob, sp)
+        assert 0 < opt.num_equality_constraints() <= 128
+        sol, st = TrajectoryOptimizerSolution(), TrajectoryOptimizerStats()
+        flag = opt.Solve(q_guess, sol, st)
+        out.append((flag, sol, st))
+    (fa, sa, ta), (fb, sb, tb) = out
+    assert fa == fb
+    for series, tol in (("iteration_costs", 1e-6), ("trust_region_radii", 1e-12), ("merits", 1e-6), ("h_norms", 1e-4),
+                        ("q_norms", 1e-6)):
+        x, y = getattr(ta, series), getattr(tb, series)
+        assert x.size == iters and np.allclose(x, y, rtol=tol, atol=1e-12), (series, x, y)
+    assert np.array_equal(ta.trust_ratios > 0, tb.trust_ratios > 0)
+    assert np.abs(sa.q - sb.q).max() <= 1e-5 * max(1.0, np.abs(sb.q).max())
+
+
+def test_resident_loop_flags_a_singular_constraint_system():
+    """the same degree of freedom constrained twice: S = J H^-1 J^T is exactly singular; the single-workgroup
+    LDL^T reports it (flag 8), nothing is accepted afterwards and the iterate stays where it was"""
+    cfg, model, prob, sp, q = _setup("hopper", 20)
+    dev = hip.HipPath(model, prob, sp)
+    dev.set_q(q)
+    dev.eval_tau()
+    d = int(model.unactuated_dofs[0])
+    rows, _ = dev.tr_solve(3, SCALING["double_sqrt"], True, False, 1e-1, 1e5, constrained_dofs=[d, d])
+    assert (rows[:, 14].astype(int) & 8).all() and not rows[:, 9].any()
+    assert np.array_equal(dev.get("q"), q)
+    # and the regular set works from the same context afterwards
+    dev.set_q(q)
+    dev.eval_tau()
+    rows, _ = dev.tr_solve(3, SCALING["double_sqrt"], True, False, 1e-1, 1e5, constrained_dofs=model.unactuated_dofs)
+    assert (rows[:, 14] == 0).all() and rows[:, 9].any()
+    dev.close()
+
+
+@pytest.mark.parametrize("name,N", [("hopper", 40), ("acrobot", 40), ("spinner", 30), ("allegro_hand", 21), ("hopper", 9)])
+def test_single_workgroup_multiplier_solve(name, N):
+    """constraint_lambda_kernel: lambda = S^-1 (h - J H^-1 g) by an unpivoted LDL^T in one workgroup, against an
+    extended-precision solution of the same system (S, J H^-1 g as the device formed them).  S = J H^-1 J^T is badly
+    conditioned on these models, so the statement is the backward-stable one: the residual is at rounding level,
+    and the error against the refined solution is no worse than that of LAPACK's pivoted LU on the same S."""
+    cfg, model, prob, sp, q = _setup(name, N)
+    dev = hip.HipPath(model, prob, sp)
+    dofs = np.asarray(model.unactuated_dofs)
+    dev.set_q(q)
+    dev.eval_tau()
+    h = dev.get("tau")[:, dofs].ravel()
+    dev.tr_solve(1, SCALING["double_sqrt"], True, False, 1e-1, 1e5, constrained_dofs=dofs)
+    neq = dofs.size * N
+    raw = dev.get("con_S")
+    S, Jy = raw[:neq * neq].reshape(neq, neq).T, raw[neq * neq:]
+    lam = dev.get("con_lambda")
+    r = h - Jy
+    assert np.abs(S - S.T).max() <= 1e-9 * np.abs(S).max()
+    res = np.abs(S @ lam - r).max() / (np.abs(S).max() * np.abs(lam).max() + np.abs(r).max())
+    assert res <= 1e-12, res
+    want, unc = ol.refined_solution(0.5 * (S + S.T), r)
+    scale = np.abs(want).max()
+    err = np.abs(lam - want).max() / scale
+    err_lu = np.abs(np.linalg.solve(S, r) - want).max() / scale
+    assert err <= 4 * err_lu + 16 * unc + 1e-12, (err, err_lu, unc, np.linalg.cond(S))
     dev.close()
