@@ -29,16 +29,21 @@ __device__ __forceinline__ double jac_entry(const double* __restrict__ slab, int
 // grid: n_eq + 1 blocks; block 0 copies g, block 1 + r writes row r of J as a column
 __global__ void constraint_rhs_kernel(const double* __restrict__ slab, int slab_stride, const double* __restrict__ g,
                                       const int* __restrict__ dofs, int nu, int N, int nq, int nv,
-                                      double* __restrict__ rhs, idto_dev::AltSel alt) {
+                                      double* __restrict__ rhs, double* __restrict__ x, idto_dev::AltSel alt) {
   slab = idto_dev::at_set(slab, alt);   // (idto_hip_tr_solve: the iterate's set of partials)
   const int n = (N + 1) * nq, b = blockIdx.x;
   double* out = rhs + (size_t)b * n;
-  if (b == 0) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = g[i];
+  double* x0 = x + (size_t)b * n;       // block row 0 of the solution = of the right-hand side (C_0 = I, decoupled):
+  if (b == 0) {                         // written here, the solver starts at row 1
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { const double v = g[i]; out[i] = v; if (i < nq) x0[i] = v; }
     return;
   }
   const int r = b - 1, t = r / nu, dof = dofs[r - t * nu];
-  for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = jac_entry(slab, slab_stride, nq, nv, t, dof, N, i);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double v = jac_entry(slab, slab_stride, nq, nv, t, dof, N, i);
+    out[i] = v;
+    if (i < nq) x0[i] = v;
+  }
 }
 
 // grid: n_eq blocks (row r of J staged in LDS); thread <-> column of Y.  out_S is column-major

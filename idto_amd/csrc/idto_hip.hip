@@ -1034,7 +1034,12 @@ static int LaunchFused(idto_hip_ctx* c) {
   return TimeEnd(c);
 }
 
+static int FactorSolve(idto_hip_ctx* c, const double* rhs, int nrhs, double* x, bool x0_written);
 int idto_hip_factor_solve(idto_hip_ctx* c, const double* rhs, int nrhs, double* x) {
+  return FactorSolve(c, rhs, nrhs, x, false);
+}
+// x0_written: the caller has already put rhs_0 into x_0 of every column (block row 0 of an assembled H is the identity)
+static int FactorSolve(idto_hip_ctx* c, const double* rhs, int nrhs, double* x, bool x0_written) {
   HIP_OK(hipSetDevice(c->device));
   if (!rhs) DropPrefetch(c, {IDTO_ARR_STEP});
   const int n = c->N + 1, k = c->nq;
@@ -1065,7 +1070,7 @@ int idto_hip_factor_solve(idto_hip_ctx* c, const double* rhs, int nrhs, double* 
   int rc = LaunchLdl(c, b, rhs ? 1.0 : -1.0, xo, false, /*allow_nd=*/nrhs == 1);
   const int r0 = SolverFirstRow(c), ns = n - r0;                      // the sub-system LaunchLdl factorised
   const int m_split = (c->two_sided && ns >= 10) ? (ns - 1) / 2 : 0;  // as LaunchLdl chose
-  if (r0 && rhs)  // x_0 = rhs_0 for every column (row 0 of H is the identity); the default rhs has g_0 = 0 = x_0
+  if (r0 && rhs && !x0_written)  // x_0 = rhs_0 for every column (row 0 of H is the identity); the default rhs has g_0 = 0 = x_0
     HIP_OK(hipMemcpy2DAsync(x, (size_t)n * k * sizeof(double), rhs, (size_t)n * k * sizeof(double), (size_t)k * sizeof(double),
                             (size_t)nrhs, hipMemcpyDeviceToDevice, c->stream));
   if (rc) return rc;
@@ -1143,9 +1148,9 @@ int idto_hip_constraint_schur_begin(idto_hip_ctx* c, const int* dofs, int nu) {
   c->con_ready = false; c->con_begun = false;
   if (EnsureStage(c, (size_t)(neq + 1) * n)) return -2;
   hipLaunchKernelGGL(constraint_rhs_kernel, dim3(neq + 1), dim3(256), 0, c->stream, c->slab, c->slab_stride, c->g,
-                     c->con_dofs, nu, N, c->nq, c->nv, c->stage_rhs, c->alt_r);
+                     c->con_dofs, nu, N, c->nq, c->nv, c->stage_rhs, c->stage_x, c->alt_r);
   HIP_OK(hipGetLastError());
-  int rc = idto_hip_factor_solve(c, c->stage_rhs, neq + 1, c->stage_x);
+  int rc = FactorSolve(c, c->stage_rhs, neq + 1, c->stage_x, /*x0_written=*/true);
   if (rc) return rc;
   hipLaunchKernelGGL(constraint_schur_kernel, dim3(neq), dim3(256), 3 * c->nq * sizeof(double), c->stream, c->slab,
                      c->slab_stride, c->con_dofs, nu, N, c->nq, c->nv, c->stage_x, neq, c->con_S,
