@@ -271,3 +271,23 @@ constraint_lambda_kernel(const double* __restrict__ S_g /* [neq*neq | Jy] */, in
       state[idto_dev::TRS_FLAGS] = (double)((int)state[idto_dev::TRS_FLAGS] | idto_dev::TRF_SINGULAR_S);
   }
 }
+
+
+// Larger constraint sets in the device-resident loop go through the blocked factorisation of dense_ldl.h:
+// constraint_h_kernel forms its right-hand-side input [min pivot, max pivot | h] from the iterate's slab,
+// constraint_flag_kernel turns the pivot range it leaves behind into TRF_SINGULAR_S.
+__global__ void constraint_h_kernel(const double* __restrict__ slab, int slab_stride, int tau_off,
+                                    const int* __restrict__ dofs, int nu, int neq, double* __restrict__ stat_h,
+                                    idto_dev::AltSel alt) {
+  slab = idto_dev::at_set(slab, alt);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { stat_h[0] = __builtin_inf(); stat_h[1] = 0.0; }
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < neq; r += gridDim.x * blockDim.x) {
+    const int t = r / nu, j = r - t * nu;
+    stat_h[2 + r] = slab[(size_t)t * slab_stride + tau_off + dofs[j]];
+  }
+}
+__global__ void constraint_flag_kernel(const double* __restrict__ stat, double* __restrict__ state) {
+  const double dmin = stat[0], dmax = stat[1];
+  if (!(dmin > 1e-13 * dmax) || !__builtin_isfinite(dmax))
+    state[idto_dev::TRS_FLAGS] = (double)((int)state[idto_dev::TRS_FLAGS] | idto_dev::TRF_SINGULAR_S);
+}

@@ -965,11 +965,10 @@ bool TO::DeviceLoopEligible() const {
   if (params_.check_convergence || !shard_ctx_.empty()) return false;
   const bool constrained = params_.equality_constraints && num_equality_constraints() > 0;
   if (!constrained) return true;
-  // enforced constraints: only the resident loop (idto_hip_tr_solve) has them on the device - multipliers by a
-  // single-workgroup LDL^T of S (n_eq <= 128), the non-adaptive scalings
+  // enforced constraints: only the resident loop (idto_hip_tr_solve) has them on the device (multipliers by a
+  // single-workgroup LDL^T of S for n_eq <= 128, by the blocked one above), with the non-adaptive scalings
   const int scal = params_.scaling ? static_cast<int>(params_.scaling_method) : -1;
-  return num_equality_constraints() <= 128 && (scal == -1 || scal == 0 || scal == 2) && params_.max_iterations > 0 &&
-         !std::getenv("IDTO_OPT_STEPWISE");
+  return (scal == -1 || scal == 0 || scal == 2) && params_.max_iterations > 0 && !std::getenv("IDTO_OPT_STEPWISE");
 }
 
 SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solution,

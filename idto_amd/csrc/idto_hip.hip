@@ -1397,7 +1397,6 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
   if (nu < 0 || (nu > 0 && !constrained_dofs)) { g_err = "tr_solve: bad constraint arguments"; return -1; }
   const int neq = nu * c->N;
   if (nu > 0) {
-    if (neq > CON_LAMBDA_MAX) { g_err = "tr_solve: more equality constraints than the single-workgroup multiplier solve holds"; return -1; }
     if (!c->weights_diagonal) { g_err = "tr_solve: enforced constraints need diagonal cost weights"; return -1; }
   }
   if (!(scaling_method == -1 || scaling_method == 0 || scaling_method == 2)) {
@@ -1449,14 +1448,34 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
       c->con_begun = false;
       rc = idto_hip_constraint_schur_begin(c, constrained_dofs, nu);
       if (rc) return rc;
-      hipLaunchKernelGGL(constraint_lambda_kernel, dim3(1), dim3(CON_LAMBDA_THREADS),
-                         (size_t)con_lambda_lds_doubles(neq) * sizeof(double), c->stream,
-                         c->con_S, neq, c->slab, c->slab_stride, 3 * c->nv * c->nq, c->con_dofs, nu, c->con_lambda, c->tr_state,
-                         c->alt_r);
-      c->con_lambda_at = c->con_lambda;
+      if (neq <= CON_LAMBDA_MAX) {   // S in the LDS of one workgroup
+        hipLaunchKernelGGL(constraint_lambda_kernel, dim3(1), dim3(CON_LAMBDA_THREADS),
+                           (size_t)con_lambda_lds_doubles(neq) * sizeof(double), c->stream,
+                           c->con_S, neq, c->slab, c->slab_stride, 3 * c->nv * c->nq, c->con_dofs, nu, c->con_lambda, c->tr_state,
+                           c->alt_r);
+        c->con_lambda_at = c->con_lambda;
+      } else {                       // the blocked factorisation of dense_ldl.h, as idto_hip_constraint_solve runs it
+        hipLaunchKernelGGL(constraint_h_kernel, dim3((neq + 255) / 256), dim3(256), 0, c->stream, c->slab, c->slab_stride,
+                           3 * c->nv * c->nq, c->con_dofs, nu, neq, c->con_h, c->alt_r);
+        double* S = c->con_S;
+        for (int j0 = 0; j0 < neq; j0 += DENSE_NB) {
+          const int j1 = j0 + DENSE_NB, below = neq > j1 ? neq - j1 : 0;
+          hipLaunchKernelGGL(dense_ldl_panel_kernel, dim3(1 + (below + 63) / 64), dim3(64), 0, c->stream, S, neq, j0, c->con_W,
+                             c->con_d, c->con_h);
+          if (j1 < neq) {
+            const int tiles = (neq - j1 + 31) / 32;
+            hipLaunchKernelGGL(dense_ldl_update_kernel, dim3(tiles, tiles), dim3(256), 0, c->stream, S, neq, j0, j1, c->con_W);
+          }
+        }
+        c->con_S_factored = true;
+        hipLaunchKernelGGL(dense_ldl_solve_kernel, dim3(1), dim3(512), (neq + 512 + DENSE_NB * (DENSE_NB + 1)) * sizeof(double),
+                           c->stream, S, neq, c->con_d, S + (size_t)neq * neq, -1.0, c->con_h + 2, c->con_lambda + 2);
+        hipLaunchKernelGGL(constraint_flag_kernel, dim3(1), dim3(1), 0, c->stream, c->con_h, c->tr_state);
+        c->con_lambda_at = c->con_lambda + 2;
+      }
       hipLaunchKernelGGL(constraint_step_kernel, dim3((n + 63) / 64), dim3(64 * STEP_WAVES),
                          (neq + 64 * STEP_WAVES) * sizeof(double), c->stream, c->slab, c->slab_stride, c->con_dofs, nu, c->N,
-                         c->nq, c->nv, c->stage_x, neq, c->con_lambda, c->con_out, c->con_out + n, c->alt_r);
+                         c->nq, c->nv, c->stage_x, neq, c->con_lambda_at, c->con_out, c->con_out + n, c->alt_r);
       HIP_OK(hipGetLastError());
       c->con_ready = true;
     }
@@ -1477,7 +1496,7 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
     TrDecideArgs Dc;
     Dc.state = c->tr_state; Dc.out = c->tr_out; Dc.rows = c->tr_rows; Dc.q = c->q; Dc.q_trial = c->q_trial; Dc.n = n;
     Dc.eta = eta; Dc.Delta_max = Delta_max; Dc.eps = eps;
-    Dc.lambda = nu > 0 ? c->con_lambda : nullptr; Dc.dofs = nu > 0 ? c->con_dofs : nullptr;
+    Dc.lambda = nu > 0 ? c->con_lambda_at : nullptr; Dc.dofs = nu > 0 ? c->con_dofs : nullptr;
     Dc.nu = nu; Dc.N = c->N; Dc.slab_stride = c->slab_stride; Dc.tau_off = 3 * c->nv * c->nq;
     const bool more = k + 1 < iterations;
     std::swap(c->q, c->q_trial);

@@ -240,8 +240,9 @@ int idto_hip_tr_reject(idto_hip_ctx* ctx);
  *   solve does not): continue from the iterate with the stepwise calls.
  * constrained_dofs / nu: the unactuated degrees of freedom whose tau is constrained to zero
  * (CalcEqualityConstraintViolations, TO.cc:1257-1290), nu = 0: none enforced.  With nu > 0 every iteration
- * also runs H^-1 [g | J^T], S = J H^-1 J^T, lambda = S^-1 (h - J H^-1 g) (TO.cc:1371-1396; nu * num_steps <=
- * 128) and the step H^-1 (g + J^T lambda) on the device, and the ratio uses the merit function.
+ * also runs H^-1 [g | J^T], S = J H^-1 J^T, lambda = S^-1 (h - J H^-1 g) (TO.cc:1371-1396; one workgroup for
+ * nu * num_steps <= 128, the blocked factorisation above) and the step H^-1 (g + J^T lambda) on the device, and
+ * the ratio uses the merit function.
  * scaling_method: -1 none, 0 kSqrt, 2 kDoubleSqrt (the adaptive methods: use the stepwise calls).
  * On return q, v, a, tau, N+ in device memory are those of the final iterate when the last step was
  * accepted; after a rejected last step v, a, tau belong to the dropped trial point.

@@ -182,7 +182,8 @@ def test_resident_loop_rows_and_failure():
     dev.close()
 
 
-@pytest.mark.parametrize("name,N,iters", [("hopper", 40, 12), ("acrobot", 40, 20), ("spinner", 40, 15), ("allegro_hand", 12, 4)])
+@pytest.mark.parametrize("name,N,iters", [("hopper", 40, 12), ("acrobot", 40, 20), ("spinner", 40, 15), ("allegro_hand", 12, 4),
+                                            ("hopper", 50, 8), ("allegro_hand", 30, 3)])   # (the last two: n_eq 150 / 180 > 128, blocked LDL^T)
 def test_resident_loop_with_equality_constraints_follows_the_host_loop(name, N, iters, monkeypatch):
     """enforced equality constraints (the example YAMLs of acrobot, spinner, hopper, allegro): the resident loop
     computes the multipliers on the device - H^-1 [g | J^T], S = J H^-1 J^T, a single-workgroup LDL^T of S - and
@@ -202,7 +203,7 @@ def test_resident_loop_with_equality_constraints_follows_the_host_loop(name, N, 
         else:
             monkeypatch.delenv("IDTO_OPT_HOST_LOOP", raising=False)
         opt = TrajectoryOptimizer(model, prob, sp)
-        assert 0 < opt.num_equality_constraints() <= 128
+        assert opt.num_equality_constraints() > 0
         sol, st = TrajectoryOptimizerSolution(), TrajectoryOptimizerStats()
         flag = opt.Solve(q_guess, sol, st)
         out.append((flag, sol, st))
