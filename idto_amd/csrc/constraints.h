@@ -125,22 +125,26 @@ constexpr int CON_LAMBDA_MAX = 128;
 constexpr int CON_TILE = 4;                                    // register tile = panel width of the factorisation
 constexpr int CON_TGRID = CON_LAMBDA_MAX / CON_TILE;           // 32 x 32 tiles, the lower triangle has 528
 constexpr int CON_LAMBDA_THREADS = 576;                        // >= 528, nine wavefronts
+constexpr int CON_PS = CON_TILE + 1;                           // row stride of the published panel: odd, or the tile rows of
+                                                               // consecutive lanes (4 rows = 128 B apart) meet in 2 of the 64 banks
 __host__ __device__ constexpr int con_lambda_lds_doubles(int n) {
-  return n * (n | 1) + 2 * CON_LAMBDA_MAX * CON_TILE + CON_TILE * CON_TILE + 3 * CON_TILE + CON_LAMBDA_MAX;
+  return n * (n | 1) + 2 * CON_LAMBDA_MAX * CON_PS + CON_TILE * CON_TILE + 3 * CON_TILE + CON_LAMBDA_MAX;
 }
 __global__ void __launch_bounds__(CON_LAMBDA_THREADS)
 constraint_lambda_kernel(const double* __restrict__ S_g /* [neq*neq | Jy] */, int neq, const double* __restrict__ slab,
                          int slab_stride, int tau_off, const int* __restrict__ dofs, int nu, double* __restrict__ lambda,
-                         double* __restrict__ state, idto_dev::AltSel alt) {
+                         double* __restrict__ state, idto_dev::AltSel alt, double* __restrict__ stamps) {
   extern __shared__ double lds[];
   slab = idto_dev::at_set(slab, alt);
+  if (stamps && threadIdx.x == 0) stamps[0] = (double)clock64();
   constexpr int TB = CON_TILE;
   const int tid = threadIdx.x, n = neq, np = (n + TB - 1) / TB;
   const int ld = n | 1;                   // odd column stride of L: columns of a row spread over the banks
   double* L = lds;                        // [n][ld] column-major: unit lower L below the diagonal, D on it
-  double* Wp = L + (size_t)n * ld;        // [CON_LAMBDA_MAX][TB] the panel's columns below the diagonal tile, W = L D ...
-  double* Lp = Wp + CON_LAMBDA_MAX * TB;  // [CON_LAMBDA_MAX][TB] ... and L itself
-  double* Ld = Lp + CON_LAMBDA_MAX * TB;  // [TB][TB] unit lower factor of the diagonal tile, [TB] 1 / d, [2][TB] y of the panel
+  constexpr int PS = CON_PS;
+  double* Wp = L + (size_t)n * ld;        // [CON_LAMBDA_MAX][PS] the panel's columns below the diagonal tile, W = L D ...
+  double* Lp = Wp + CON_LAMBDA_MAX * PS;  // [CON_LAMBDA_MAX][PS] ... and L itself
+  double* Ld = Lp + CON_LAMBDA_MAX * PS;  // [TB][TB] unit lower factor of the diagonal tile, [TB] 1 / d, [2][TB] y of the panel
   double* zb = Ld + TB * TB + 3 * TB;     // (by panel parity: the next diagonal tile is factorised while phase C still reads y)
                                           // [CON_LAMBDA_MAX] D^-1 L^-1 (h - J y_g)
   __shared__ double dmin_s, dmax_s;
@@ -171,8 +175,10 @@ constraint_lambda_kernel(const double* __restrict__ S_g /* [neq*neq | Jy] */, in
   }
   if (tid == 0) { dmin_s = __builtin_inf(); dmax_s = 0.0; }
   __syncthreads();
+  if (stamps && tid == 0) stamps[1] = (double)clock64();
   // right-looking LDL^T by panels of TB columns, two barriers per panel; the forward substitution rides along
   for (int p = 0; p < np; ++p) {
+    if (stamps && tid == 0 && p < 40) stamps[8 + p] = (double)clock64();
     const int j0 = p * TB;
     if (have && ti == p && tj == p) {   // A: the diagonal tile in registers: a = l d l^T, y = l^-1 b
       double dmn = dmin_s, dmx = dmax_s;
@@ -197,14 +203,15 @@ constraint_lambda_kernel(const double* __restrict__ S_g /* [neq*neq | Jy] */, in
           a[r][c] = l;
           Ld[r * TB + c] = l;
           if (j0 + r < n) L[(size_t)(j0 + c) * ld + j0 + r] = l;
-          b[r] -= l * b[c];
+          b[r] = __builtin_fma(-l, b[c], b[r]);   // (explicit fma throughout: the library is built with -ffp-contract=off)
 #pragma unroll
-          for (int c2 = c + 1; c2 <= r; ++c2) a[r][c2] -= l * w[c2];
+          for (int c2 = c + 1; c2 <= r; ++c2) a[r][c2] = __builtin_fma(-l, w[c2], a[r][c2]);
         }
       }
       dmin_s = dmn; dmax_s = dmx;
     }
     __syncthreads();
+    if (stamps && tid == 0 && p < 40) stamps[64 + 2 * p] = (double)clock64();
     if (have && tj == p && ti > p) {    // B: the tiles below it: W = A l^-T (= L D), L = W D^-1
       double l[TB][TB], inv[TB];
 #pragma unroll
@@ -219,59 +226,61 @@ constraint_lambda_kernel(const double* __restrict__ S_g /* [neq*neq | Jy] */, in
         for (int c = 0; c < TB; ++c) {
           double w = a[r][c];
 #pragma unroll
-          for (int c2 = 0; c2 < c; ++c2) w -= a[r][c2] * l[c][c2];   // (a[r][c2] already holds W(r, c2))
+          for (int c2 = 0; c2 < c; ++c2) w = __builtin_fma(-a[r][c2], l[c][c2], w);   // (a[r][c2] already holds W(r, c2))
           a[r][c] = w;
         }
 #pragma unroll
         for (int c = 0; c < TB; ++c) {
           const double lv = a[r][c] * inv[c];
-          Wp[(i0 + r) * TB + c] = a[r][c];
-          Lp[(i0 + r) * TB + c] = lv;
+          Wp[(i0 + r) * PS + c] = a[r][c];
+          Lp[(i0 + r) * PS + c] = lv;
           if (i0 + r < n && j0 + c < n) L[(size_t)(j0 + c) * ld + i0 + r] = lv;
         }
       }
     }
     __syncthreads();
+    if (stamps && tid == 0 && p < 40) stamps[65 + 2 * p] = (double)clock64();
     if (have && tj > p) {               // C: rank-TB update of the trailing tiles (and of the right-hand side)
       double lr[TB][TB], wk[TB][TB];
 #pragma unroll
       for (int r = 0; r < TB; ++r)
 #pragma unroll
-        for (int m = 0; m < TB; ++m) { lr[r][m] = Lp[(i0 + r) * TB + m]; wk[r][m] = Wp[(k0 + r) * TB + m]; }
+        for (int m = 0; m < TB; ++m) { lr[r][m] = Lp[(i0 + r) * PS + m]; wk[r][m] = Wp[(k0 + r) * PS + m]; }
 #pragma unroll
       for (int r = 0; r < TB; ++r)
 #pragma unroll
         for (int c = 0; c < TB; ++c) {
           double acc = a[r][c];
 #pragma unroll
-          for (int m = 0; m < TB; ++m) acc -= lr[r][m] * wk[c][m];
+          for (int m = 0; m < TB; ++m) acc = __builtin_fma(-lr[r][m], wk[c][m], acc);
           a[r][c] = acc;
         }
       if (ti == tj) {
 #pragma unroll
         for (int r = 0; r < TB; ++r)
 #pragma unroll
-          for (int m = 0; m < TB; ++m) b[r] -= lr[r][m] * Ld[TB * TB + TB + (p & 1) * TB + m];
+          for (int m = 0; m < TB; ++m) b[r] = __builtin_fma(-lr[r][m], Ld[TB * TB + TB + (p & 1) * TB + m], b[r]);
       }
     }
   }
   __syncthreads();
+  if (stamps && tid == 0) stamps[2] = (double)clock64();
   // L^T x = z on one wavefront: lane owns rows lane and lane + 64
   if (tid < 64) {
     const int r0 = tid, r1 = tid + 64;
     double y0 = (r0 < n) ? zb[r0] : 0.0, y1 = (r1 < n) ? zb[r1] : 0.0;
     for (int j = n - 1; j >= 0; --j) {
       const double xj = (j < 64) ? __shfl(y0, j) : __shfl(y1, j - 64);   // final once every row below has been subtracted
-      if (r0 < j) y0 -= L[(size_t)r0 * ld + j] * xj;                     // L(j, r0)
-      if (r1 < j && r1 < n) y1 -= L[(size_t)r1 * ld + j] * xj;
+      if (r0 < j) y0 = __builtin_fma(-L[(size_t)r0 * ld + j], xj, y0);   // L(j, r0)
+      if (r1 < j && r1 < n) y1 = __builtin_fma(-L[(size_t)r1 * ld + j], xj, y1);
     }
     if (r0 < n) lambda[r0] = y0;
     if (r1 < n) lambda[r1] = y1;
     if (tid == 0 && (!(dmin_s > 1e-13 * dmax_s) || !__builtin_isfinite(dmax_s)))
       state[idto_dev::TRS_FLAGS] = (double)((int)state[idto_dev::TRS_FLAGS] | idto_dev::TRF_SINGULAR_S);
+    if (stamps && tid == 0) stamps[3] = (double)clock64();
   }
 }
-
 
 // Larger constraint sets in the device-resident loop go through the blocked factorisation of dense_ldl.h:
 // constraint_h_kernel forms its right-hand-side input [min pivot, max pivot | h] from the iterate's slab,

@@ -1452,7 +1452,7 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
         hipLaunchKernelGGL(constraint_lambda_kernel, dim3(1), dim3(CON_LAMBDA_THREADS),
                            (size_t)con_lambda_lds_doubles(neq) * sizeof(double), c->stream,
                            c->con_S, neq, c->slab, c->slab_stride, 3 * c->nv * c->nq, c->con_dofs, nu, c->con_lambda, c->tr_state,
-                           c->alt_r);
+                           c->alt_r, c->solver_debug ? c->dbg : (double*)nullptr);
         c->con_lambda_at = c->con_lambda;
       } else {                       // the blocked factorisation of dense_ldl.h, as idto_hip_constraint_solve runs it
         hipLaunchKernelGGL(constraint_h_kernel, dim3((neq + 255) / 256), dim3(256), 0, c->stream, c->slab, c->slab_stride,

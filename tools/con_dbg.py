@@ -21,3 +21,15 @@ print(name, "neq", len(model.unactuated_dofs) * N, f"{1e3*dt/iters:.4f} ms/iter"
 print("flags", rows[:, 14].astype(int))
 print("cost", rows[:6, 0], "rho", rows[:6, 2], "acc", rows[:, 9].astype(int))
 print("clock diffs us", np.diff(rows[:, 10])[:10] * 0.01)
+if os.environ.get("CON_STAMPS"):
+    dev.set_option("solver_debug", 1)
+    dev.set_option("solver_nd", 0)
+    dev.set_q(np.asarray(q_guess)); dev.eval_tau()
+    dev.tr_solve(2, SCALING[sp.scaling_method] if sp.scaling else -1, sp.scaling, False, sp.Delta0, sp.Delta_max,
+                 constrained_dofs=model.unactuated_dofs)
+    st = dev.get("debug")
+    print("lambda kernel cycles: load", st[1] - st[0], "factor", st[2] - st[1], "backward", st[3] - st[2])
+    print("per panel:", np.diff(st[8:8 + 31]).astype(int))
+    t0 = st[8:8 + 30]; t1 = st[64:64 + 60:2]; t2 = st[65:65 + 60:2]
+    print("A+barrier:", (t1 - t0)[:30].astype(int))
+    print("B+barrier:", (t2 - t1)[:30].astype(int))
