@@ -184,6 +184,7 @@ def main():
     dev.set_q(q)
 
     exch = None
+    exchange_note = None
     if world > 1:
         from idto_amd.multi_gpu import RcclShard, SlabExchange, device_slab_view
         try:
@@ -193,9 +194,25 @@ def main():
             else:
                 exch = SlabExchange(dist, device_slab_view(dev, N), N, dev.slab_stride, rank, world)
         except Exception as e:  # replicas need no exchange: never let the extra measurement cost the metric
-            if sharded:
-                raise
-            print(f"[bench] rank {rank}: slab exchange unavailable ({e}); skipping the shard_mode extra", file=sys.stderr)
+            exch = None
+            print(f"[bench] rank {rank}: slab exchange unavailable ({e})", file=sys.stderr)
+        # every rank must take the same path from here on (collectives inside): agree over the control plane
+        ok = torch.tensor([1.0 if exch is not None else 0.0], device=("cuda" if backend == "nccl" else "cpu"),
+                          dtype=torch.float64)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) < 1.0:
+            if exch is not None and exchange == "rccl":
+                try:
+                    exch.close()
+                except Exception:
+                    pass
+            exch = None
+            if sharded:   # the sharded problem cannot be measured here: report independent replicas and say so
+                sharded = False
+                exchange_note = "the slab exchange could not be set up on every rank: value is replicas, not the sharded problem"
+                q = synthetic_trajectory(cfg, model, N, seed=rank, lower=0.01)
+                dev.set_shard(0, N)
+                dev.set_q(q)
 
     def step_sharded():
         if exchange == "rccl":
@@ -369,6 +386,8 @@ def main():
                          "all_kernels_avg_ms": {names[i]: kern[i][0] for i in range(4) if kern[i][1] > 0},
                          "note": "latency/dependency-bound path (SURVEY.md §8d): HBM fraction is intrinsically small"},
         }
+        if exchange_note:
+            out["config"]["note"] = exchange_note
         if other_extra is not None:
             out[other_key] = other_extra
         out["step_latency_ms"] = latency
