@@ -1,3 +1,7 @@
+"""The device-resident trust-region loop with the example's equality constraints (idto_hip_tr_solve): time per
+iteration, flags / costs / decisions of every iteration; CON_STAMPS=1 adds the cycle stamps of the single-workgroup
+multiplier solve (constraints.h constraint_lambda_kernel; option solver_debug).
+  python tools/constrained_loop.py hopper 40 20"""
 import sys, time
 import os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
