@@ -108,27 +108,31 @@ constraint_step_kernel(const double* __restrict__ slab, int slab_stride, const i
 
 // ---------------------------------------------------------------------------
 // constraint_lambda_kernel: lambda = S^-1 (h - J y_g) (TO.cc:1371-1396) in ONE workgroup for small
-// n_eq (S in LDS: n_eq <= CON_LAMBDA_MAX), so that the device-resident trust-region loop
+// n_eq (the factor of S in LDS: n_eq <= CON_LAMBDA_MAX), so that the device-resident trust-region loop
 // (idto_hip_tr_solve) needs neither the host's factorisation nor the ~2 launches per 32 columns of
 // dense_ldl.h.  h = tau_t[dof] of the iterate comes straight from the slab.  Unpivoted LDL^T of the
-// symmetric positive definite S = J H^-1 J^T, right-looking by panels of four columns, the lower
-// triangle in 4 x 4 register tiles (one per thread, 528 of them): per panel the owner of the diagonal
-// tile factorises it in registers, the tiles below it solve for their rows of L, everybody applies the
-// rank-4 update (32 LDS reads, 64 multiply-adds) - two barriers per panel, and the forward substitution
-// of the right-hand side rides along in the diagonal tiles' owners.  (An element-by-element update of an
-// LDS-resident triangle took 254 us at n_eq = 120, one column per barrier 119 us.)  The backward
-// substitution runs on one wavefront (lane = 2 rows) without barriers.
-// A pivot that is not positive, or min / max pivot <= 1e-13 (redundant constraints: the host's
-// pivoted LDL^T copes, this does not), raises TRF_SINGULAR_S in the loop state: the remaining
-// iterations idle and the host takes over from the iterate.
+// symmetric positive definite S = J H^-1 J^T, LEFT-looking by panels of four columns and WITHOUT
+// barriers: eight wavefronts own the panels cyclically (lane = row, two rows per lane), a panel
+// collects the updates of the panels before it as their flags appear in LDS, is factorised and
+// published; a ninth wavefront follows with the right-hand side (forward substitution panel by
+// panel), then substitutes backwards in blocks of four.  The chain per panel is "update from the
+// previous panel + 4 x 4 factorisation + scaling" on one wavefront (~1.4k cycles) while the other
+// seven apply older updates.  History at n_eq = 120: element-wise updates of an LDS-resident triangle
+// 254 us; register tiles, one column per barrier 119 us; panels with two barriers 84 us (each phase
+// transition cost ~2k cycles of a lone wavefront's latency); this version: see DESIGN.md 13.
+// A pivot range min / max <= 1e-13 (redundant constraints: the host's pivoted LDL^T copes, this does
+// not) raises TRF_SINGULAR_S in the loop state: the remaining iterations idle, the host takes over.
 constexpr int CON_LAMBDA_MAX = 128;
-constexpr int CON_TILE = 4;                                    // register tile = panel width of the factorisation
-constexpr int CON_TGRID = CON_LAMBDA_MAX / CON_TILE;           // 32 x 32 tiles, the lower triangle has 528
-constexpr int CON_LAMBDA_THREADS = 576;                        // >= 528, nine wavefronts
-constexpr int CON_PS = CON_TILE + 1;                           // row stride of the published panel: odd, or the tile rows of
-                                                               // consecutive lanes (4 rows = 128 B apart) meet in 2 of the 64 banks
+constexpr int CON_TILE = 4;                                    // panel width
+constexpr int CON_FWAVES = 8;                                  // wavefronts that factorise (+ 1 for the right-hand side)
+constexpr int CON_LAMBDA_THREADS = 64 * (CON_FWAVES + 1);
+constexpr int CON_MAXOWN = (CON_LAMBDA_MAX / CON_TILE + CON_FWAVES - 1) / CON_FWAVES;   // panels per wavefront
+__host__ __device__ constexpr int con_lambda_ld(int n) { return (((n + CON_TILE - 1) / CON_TILE) * CON_TILE) | 1; }
 __host__ __device__ constexpr int con_lambda_lds_doubles(int n) {
-  return n * (n | 1) + 2 * CON_LAMBDA_MAX * CON_PS + CON_TILE * CON_TILE + 3 * CON_TILE + CON_LAMBDA_MAX;
+  return ((n + CON_TILE - 1) / CON_TILE) * CON_TILE * con_lambda_ld(n)      // L
+         + (CON_FWAVES + 1) * CON_TILE * CON_TILE                           // per-wavefront exchange of a diagonal tile / 4 values
+         + CON_LAMBDA_MAX                                                   // z
+         + CON_LAMBDA_MAX / 2;                                              // panel flags (ints)
 }
 __global__ void __launch_bounds__(CON_LAMBDA_THREADS)
 constraint_lambda_kernel(const double* __restrict__ S_g /* [neq*neq | Jy] */, int neq, const double* __restrict__ slab,
@@ -136,150 +140,211 @@ constraint_lambda_kernel(const double* __restrict__ S_g /* [neq*neq | Jy] */, in
                          double* __restrict__ state, idto_dev::AltSel alt, double* __restrict__ stamps) {
   extern __shared__ double lds[];
   slab = idto_dev::at_set(slab, alt);
-  if (stamps && threadIdx.x == 0) stamps[0] = (double)clock64();
   constexpr int TB = CON_TILE;
-  const int tid = threadIdx.x, n = neq, np = (n + TB - 1) / TB;
-  const int ld = n | 1;                   // odd column stride of L: columns of a row spread over the banks
-  double* L = lds;                        // [n][ld] column-major: unit lower L below the diagonal, D on it
-  constexpr int PS = CON_PS;
-  double* Wp = L + (size_t)n * ld;        // [CON_LAMBDA_MAX][PS] the panel's columns below the diagonal tile, W = L D ...
-  double* Lp = Wp + CON_LAMBDA_MAX * PS;  // [CON_LAMBDA_MAX][PS] ... and L itself
-  double* Ld = Lp + CON_LAMBDA_MAX * PS;  // [TB][TB] unit lower factor of the diagonal tile, [TB] 1 / d, [2][TB] y of the panel
-  double* zb = Ld + TB * TB + 3 * TB;     // (by panel parity: the next diagonal tile is factorised while phase C still reads y)
-                                          // [CON_LAMBDA_MAX] D^-1 L^-1 (h - J y_g)
-  __shared__ double dmin_s, dmax_s;
-  // thread <-> tile (ti, tj), ti >= tj, of the lower triangle, in registers for the whole factorisation;
-  // the owners of the diagonal tiles also carry their four rows of the right-hand side h - J y_g
-  int ti = 0, tj = 0;
-  {
-    int rem = tid;
-    while (tj < CON_TGRID && rem >= CON_TGRID - tj) { rem -= CON_TGRID - tj; ++tj; }
-    ti = tj + rem;
-  }
-  const int i0 = ti * TB, k0 = tj * TB;
-  const bool have = tj < CON_TGRID && ti < np;   // (tiles beyond the matrix idle)
-  double a[TB][TB], b[TB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = neq, np = (n + TB - 1) / TB, ld = con_lambda_ld(n);
+  double* L = lds;                                   // [4 np][ld] column-major: unit lower L below the diagonal, D on it
+  double* xch = L + TB * np * ld + wave * TB * TB;   // this wavefront's exchange area
+  double* zb = L + TB * np * ld + (CON_FWAVES + 1) * TB * TB;   // [CON_LAMBDA_MAX] D^-1 L^-1 (h - J y_g), then lambda
+  volatile int* flag = reinterpret_cast<volatile int*>(zb + CON_LAMBDA_MAX);   // [np] panel p is in L
+  if (stamps && tid == 0) stamps[0] = (double)clock64();
+  for (int p = tid; p < np; p += blockDim.x) flag[p] = 0;
+  __syncthreads();
+  auto wait_panel = [&](int q) {
+    while (flag[q] == 0) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
+  // the 4 x 4 block W(4p + c, 4q + m) = L D of panel q's columns at panel p's rows (wave-uniform)
+  auto wblock = [&](int p, int q, double (&wb)[TB][TB]) {
 #pragma unroll
-  for (int r = 0; r < TB; ++r) {
-    const int i = i0 + r;
+    for (int m = 0; m < TB; ++m) {
+      const double dm = L[(TB * q + m) * ld + TB * q + m];
+#pragma unroll
+      for (int c = 0; c < TB; ++c) wb[c][m] = L[(TB * q + m) * ld + TB * p + c] * dm;
+    }
+  };
+  if (wave < CON_FWAVES) {
+    // ---- factorisation: my panels are wave, wave + 8, ...; rows lane and lane + 64
+    double a[CON_MAXOWN][2][TB];
+#pragma unroll
+    for (int k = 0; k < CON_MAXOWN; ++k) {
+      const int p = wave + k * CON_FWAVES;
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        const int r = lane + 64 * sl;
+#pragma unroll
+        for (int c = 0; c < TB; ++c) {
+          const int col = TB * p + c;
+          a[k][sl][c] = (p < np && r < n && col < n && r >= TB * p) ? S_g[(size_t)col * n + r]
+                                                                   : ((r == col) ? 1.0 : 0.0);   // (identity padding)
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < CON_MAXOWN; ++k) {
+      const int p = wave + k * CON_FWAVES;
+      if (p < np) {
+        // updates from every earlier panel, as they are published
+        for (int q = 0; q < p; ++q) {
+          wait_panel(q);
+          double wb[TB][TB];
+          wblock(p, q, wb);
+#pragma unroll
+          for (int sl = 0; sl < 2; ++sl) {
+            const int r = lane + 64 * sl;
+            if (r >= TB * p && r < TB * np) {
+              double lr[TB];
+#pragma unroll
+              for (int m = 0; m < TB; ++m) lr[m] = L[(TB * q + m) * ld + r];
+#pragma unroll
+              for (int c = 0; c < TB; ++c)
+#pragma unroll
+                for (int m = 0; m < TB; ++m) a[k][sl][c] = __builtin_fma(-lr[m], wb[c][m], a[k][sl][c]);
+            }
+          }
+        }
+        // the diagonal tile: its four rows live in four lanes - through LDS to everybody, factorised by everybody
+        {
+          const int r0 = TB * p, sl0 = r0 >> 6, l0 = r0 & 63;
+          if (lane >= l0 && lane < l0 + TB) {
+#pragma unroll
+            for (int c = 0; c < TB; ++c) xch[(lane - l0) * TB + c] = (sl0 == 0) ? a[k][0][c] : a[k][1][c];
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          double t[TB][TB], inv[TB];
+#pragma unroll
+          for (int r = 0; r < TB; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) t[r][c] = xch[r * TB + c];
+#pragma unroll
+          for (int c = 0; c < TB; ++c) {
+            const double d = t[c][c];
+            double iv = __builtin_amdgcn_rcp(d);   // 1 / d: hardware estimate + 2 Newton steps
+            double e = __builtin_fma(-d, iv, 1.0);
+            iv = __builtin_fma(iv, e, iv);
+            e = __builtin_fma(-d, iv, 1.0);
+            iv = __builtin_fma(iv, e, iv);
+            inv[c] = iv;
+            double w[TB];
+#pragma unroll
+            for (int r = c + 1; r < TB; ++r) w[r] = t[r][c];   // l d
+#pragma unroll
+            for (int r = c + 1; r < TB; ++r) {
+              const double l = w[r] * iv;
+              t[r][c] = l;
+#pragma unroll
+              for (int c2 = c + 1; c2 <= r; ++c2) t[r][c2] = __builtin_fma(-l, w[c2], t[r][c2]);
+            }
+          }
+          // my rows of the panel: below the tile W = A l^-T, L = W D^-1; inside it l and d themselves
+#pragma unroll
+          for (int sl = 0; sl < 2; ++sl) {
+            const int r = lane + 64 * sl;
+            if (r >= r0 + TB && r < TB * np) {
+#pragma unroll
+              for (int c = 0; c < TB; ++c) {
+                double w = a[k][sl][c];
+#pragma unroll
+                for (int c2 = 0; c2 < c; ++c2) w = __builtin_fma(-a[k][sl][c2], t[c][c2], w);   // (a[..][c2] already holds W)
+                a[k][sl][c] = w;
+              }
+#pragma unroll
+              for (int c = 0; c < TB; ++c) L[(r0 + c) * ld + r] = a[k][sl][c] * inv[c];
+            } else if (r >= r0 && r < r0 + TB) {
+#pragma unroll
+              for (int c = 0; c < TB; ++c) {
+#pragma unroll
+                for (int rr = 0; rr < TB; ++rr)
+                  if (r - r0 == rr && c <= rr) L[(r0 + c) * ld + r] = t[rr][c];   // d on the diagonal, l below it
+              }
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) flag[p] = 1;
+        }
+      }
+    }
+    return;
+  }
+  // ---- the ninth wavefront: right-hand side.  rows lane and lane + 64 of h - J y_g
+  double b[2];
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const int r = lane + 64 * sl;
+    b[sl] = 0.0;
+    if (r < n) {
+      const int t = r / nu, j = r - t * nu;
+      b[sl] = slab[(size_t)t * slab_stride + tau_off + dofs[j]] - S_g[(size_t)n * n + r];
+    }
+  }
+  double dmn = __builtin_inf(), dmx = 0.0;
+  if (stamps && lane == 0) stamps[1] = (double)clock64();
+  for (int q = 0; q < np; ++q) {   // forward: y_q = l^-1 b_q, z_q = y_q / d_q, b -= L(:, q) y_q
+    wait_panel(q);
+    const int r0 = TB * q, sl0 = r0 >> 6, l0 = r0 & 63;
+    if (lane >= l0 && lane < l0 + TB) xch[lane - l0] = (sl0 == 0) ? b[0] : b[1];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    double y[TB];
 #pragma unroll
     for (int c = 0; c < TB; ++c) {
-      const int k = k0 + c;
-      a[r][c] = (have && i < n && k < n) ? S_g[(size_t)k * n + i] : ((i == k) ? 1.0 : 0.0);   // (identity padding)
+      y[c] = xch[c];
+#pragma unroll
+      for (int c2 = 0; c2 < c; ++c2) y[c] = __builtin_fma(-L[(r0 + c2) * ld + r0 + c], y[c2], y[c]);
     }
-    b[r] = 0.0;
-    if (have && ti == tj && i < n) {
-      const int t = i / nu, j = i - t * nu;
-      b[r] = slab[(size_t)t * slab_stride + tau_off + dofs[j]] - S_g[(size_t)n * n + i];   // h - J y_g
+#pragma unroll
+    for (int c = 0; c < TB; ++c) {
+      const double d = L[(r0 + c) * ld + r0 + c];
+      if (r0 + c < n) { dmn = __builtin_fmin(dmn, d); dmx = __builtin_fmax(dmx, d); }
+      if (lane == 0) zb[r0 + c] = y[c] / d;
     }
-  }
-  if (tid == 0) { dmin_s = __builtin_inf(); dmax_s = 0.0; }
-  __syncthreads();
-  if (stamps && tid == 0) stamps[1] = (double)clock64();
-  // right-looking LDL^T by panels of TB columns, two barriers per panel; the forward substitution rides along
-  for (int p = 0; p < np; ++p) {
-    if (stamps && tid == 0 && p < 40) stamps[8 + p] = (double)clock64();
-    const int j0 = p * TB;
-    if (have && ti == p && tj == p) {   // A: the diagonal tile in registers: a = l d l^T, y = l^-1 b
-      double dmn = dmin_s, dmx = dmax_s;
 #pragma unroll
-      for (int c = 0; c < TB; ++c) {
-        const double d = a[c][c];
-        double inv = __builtin_amdgcn_rcp(d);   // 1 / d: hardware estimate + 2 Newton steps (an IEEE division is ~4x
-        double e = __builtin_fma(-d, inv, 1.0);  // as long, and four of them are the serial part of every panel)
-        inv = __builtin_fma(inv, e, inv);
-        e = __builtin_fma(-d, inv, 1.0);
-        inv = __builtin_fma(inv, e, inv);
-        if (j0 + c < n) { dmn = __builtin_fmin(dmn, d); dmx = __builtin_fmax(dmx, d); L[(size_t)(j0 + c) * ld + j0 + c] = d; }
-        Ld[TB * TB + c] = inv;
-        Ld[TB * TB + TB + (p & 1) * TB + c] = b[c];    // y_c: every earlier column has been applied
-        zb[j0 + c] = b[c] * inv;
-        double w[TB];
+    for (int sl = 0; sl < 2; ++sl) {
+      const int r = lane + 64 * sl;
+      if (r >= r0 + TB && r < TB * np) {
 #pragma unroll
-        for (int r = c + 1; r < TB; ++r) w[r] = a[r][c];   // l d
-#pragma unroll
-        for (int r = c + 1; r < TB; ++r) {
-          const double l = w[r] * inv;
-          a[r][c] = l;
-          Ld[r * TB + c] = l;
-          if (j0 + r < n) L[(size_t)(j0 + c) * ld + j0 + r] = l;
-          b[r] = __builtin_fma(-l, b[c], b[r]);   // (explicit fma throughout: the library is built with -ffp-contract=off)
-#pragma unroll
-          for (int c2 = c + 1; c2 <= r; ++c2) a[r][c2] = __builtin_fma(-l, w[c2], a[r][c2]);
-        }
-      }
-      dmin_s = dmn; dmax_s = dmx;
-    }
-    __syncthreads();
-    if (stamps && tid == 0 && p < 40) stamps[64 + 2 * p] = (double)clock64();
-    if (have && tj == p && ti > p) {    // B: the tiles below it: W = A l^-T (= L D), L = W D^-1
-      double l[TB][TB], inv[TB];
-#pragma unroll
-      for (int c = 0; c < TB; ++c) {
-        inv[c] = Ld[TB * TB + c];
-#pragma unroll
-        for (int c2 = 0; c2 < c; ++c2) l[c][c2] = Ld[c * TB + c2];
-      }
-#pragma unroll
-      for (int r = 0; r < TB; ++r) {
-#pragma unroll
-        for (int c = 0; c < TB; ++c) {
-          double w = a[r][c];
-#pragma unroll
-          for (int c2 = 0; c2 < c; ++c2) w = __builtin_fma(-a[r][c2], l[c][c2], w);   // (a[r][c2] already holds W(r, c2))
-          a[r][c] = w;
-        }
-#pragma unroll
-        for (int c = 0; c < TB; ++c) {
-          const double lv = a[r][c] * inv[c];
-          Wp[(i0 + r) * PS + c] = a[r][c];
-          Lp[(i0 + r) * PS + c] = lv;
-          if (i0 + r < n && j0 + c < n) L[(size_t)(j0 + c) * ld + i0 + r] = lv;
-        }
-      }
-    }
-    __syncthreads();
-    if (stamps && tid == 0 && p < 40) stamps[65 + 2 * p] = (double)clock64();
-    if (have && tj > p) {               // C: rank-TB update of the trailing tiles (and of the right-hand side)
-      double lr[TB][TB], wk[TB][TB];
-#pragma unroll
-      for (int r = 0; r < TB; ++r)
-#pragma unroll
-        for (int m = 0; m < TB; ++m) { lr[r][m] = Lp[(i0 + r) * PS + m]; wk[r][m] = Wp[(k0 + r) * PS + m]; }
-#pragma unroll
-      for (int r = 0; r < TB; ++r)
-#pragma unroll
-        for (int c = 0; c < TB; ++c) {
-          double acc = a[r][c];
-#pragma unroll
-          for (int m = 0; m < TB; ++m) acc = __builtin_fma(-lr[r][m], wk[c][m], acc);
-          a[r][c] = acc;
-        }
-      if (ti == tj) {
-#pragma unroll
-        for (int r = 0; r < TB; ++r)
-#pragma unroll
-          for (int m = 0; m < TB; ++m) b[r] = __builtin_fma(-lr[r][m], Ld[TB * TB + TB + (p & 1) * TB + m], b[r]);
+        for (int m = 0; m < TB; ++m) b[sl] = __builtin_fma(-L[(r0 + m) * ld + r], y[m], b[sl]);
       }
     }
   }
-  __syncthreads();
-  if (stamps && tid == 0) stamps[2] = (double)clock64();
-  // L^T x = z on one wavefront: lane owns rows lane and lane + 64
-  if (tid < 64) {
-    const int r0 = tid, r1 = tid + 64;
-    double y0 = (r0 < n) ? zb[r0] : 0.0, y1 = (r1 < n) ? zb[r1] : 0.0;
-    for (int j = n - 1; j >= 0; --j) {
-      const double xj = (j < 64) ? __shfl(y0, j) : __shfl(y1, j - 64);   // final once every row below has been subtracted
-      if (r0 < j) y0 = __builtin_fma(-L[(size_t)r0 * ld + j], xj, y0);   // L(j, r0)
-      if (r1 < j && r1 < n) y1 = __builtin_fma(-L[(size_t)r1 * ld + j], xj, y1);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (stamps && lane == 0) stamps[2] = (double)clock64();
+  // backward: L^T x = z in blocks of four from the bottom; x replaces z
+  double x[2];
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) { const int r = lane + 64 * sl; x[sl] = (r < TB * np) ? zb[r] : 0.0; }
+  for (int q = np - 1; q >= 0; --q) {
+    const int r0 = TB * q, sl0 = r0 >> 6, l0 = r0 & 63;
+    if (lane >= l0 && lane < l0 + TB) xch[lane - l0] = (sl0 == 0) ? x[0] : x[1];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    double xs[TB];
+#pragma unroll
+    for (int c = TB - 1; c >= 0; --c) {   // unit upper l^T of the diagonal tile
+      xs[c] = xch[c];
+#pragma unroll
+      for (int c2 = c + 1; c2 < TB; ++c2) xs[c] = __builtin_fma(-L[(r0 + c) * ld + r0 + c2], xs[c2], xs[c]);
     }
-    if (r0 < n) lambda[r0] = y0;
-    if (r1 < n) lambda[r1] = y1;
-    if (tid == 0 && (!(dmin_s > 1e-13 * dmax_s) || !__builtin_isfinite(dmax_s)))
-      state[idto_dev::TRS_FLAGS] = (double)((int)state[idto_dev::TRS_FLAGS] | idto_dev::TRF_SINGULAR_S);
-    if (stamps && tid == 0) stamps[3] = (double)clock64();
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      const int r = lane + 64 * sl;
+      if (r < r0) {
+#pragma unroll
+        for (int m = 0; m < TB; ++m) x[sl] = __builtin_fma(-L[r * ld + r0 + m], xs[m], x[sl]);   // L(r0 + m, r)
+      } else if (r < r0 + TB) {
+#pragma unroll
+        for (int m = 0; m < TB; ++m)
+          if (r - r0 == m) x[sl] = xs[m];
+      }
+    }
   }
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) { const int r = lane + 64 * sl; if (r < n) lambda[r] = x[sl]; }
+  if (lane == 0 && (!(dmn > 1e-13 * dmx) || !__builtin_isfinite(dmx)))
+    state[idto_dev::TRS_FLAGS] = (double)((int)state[idto_dev::TRS_FLAGS] | idto_dev::TRF_SINGULAR_S);
+  if (stamps && lane == 0) stamps[3] = (double)clock64();
 }
 
 // Larger constraint sets in the device-resident loop go through the blocked factorisation of dense_ldl.h:

@@ -32,8 +32,4 @@ if os.environ.get("CON_STAMPS"):
     dev.tr_solve(2, SCALING[sp.scaling_method] if sp.scaling else -1, sp.scaling, False, sp.Delta0, sp.Delta_max,
                  constrained_dofs=model.unactuated_dofs)
     st = dev.get("debug")
-    print("lambda kernel cycles: load", st[1] - st[0], "factor", st[2] - st[1], "backward", st[3] - st[2])
-    print("per panel:", np.diff(st[8:8 + 31]).astype(int))
-    t0 = st[8:8 + 30]; t1 = st[64:64 + 60:2]; t2 = st[65:65 + 60:2]
-    print("A+barrier:", (t1 - t0)[:30].astype(int))
-    print("B+barrier:", (t2 - t1)[:30].astype(int))
+    print("multiplier solve, cycles: factorisation + forward substitution", st[2] - st[0], " backward substitution", st[3] - st[2])
