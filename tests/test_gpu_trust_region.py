@@ -236,7 +236,8 @@ def test_resident_loop_flags_a_singular_constraint_system():
     dev.close()
 
 
-@pytest.mark.parametrize("name,N", [("hopper", 40), ("acrobot", 40), ("spinner", 30), ("allegro_hand", 21), ("hopper", 9)])
+@pytest.mark.parametrize("name,N", [("hopper", 40), ("acrobot", 40), ("spinner", 30), ("allegro_hand", 21), ("hopper", 9),
+                                    ("acrobot", 3), ("spinner", 128), ("acrobot", 65), ("hopper", 42)])   # n_eq = 3, 128, 65, 126
 def test_single_workgroup_multiplier_solve(name, N):
     """constraint_lambda_kernel: lambda = S^-1 (h - J H^-1 g) by an unpivoted LDL^T in one workgroup, against an
     extended-precision solution of the same system (S, J H^-1 g as the device formed them).  S = J H^-1 J^T is badly
