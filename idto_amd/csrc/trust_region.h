@@ -298,6 +298,20 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
   __syncthreads();
   if (!last) return;
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  // the operands of the trial point (below) do not depend on the dogleg: fetch them now, four passes of 256
+  // threads = tr_trial_kernel's 1024, so that their L2 round trips overlap the sums and the dogleg instead of
+  // following them one pass after the other
+  constexpr int NPASS = 4;
+  double pg[NPASS], pw[NPASS], pd[NPASS], pq[NPASS];
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const int idx = tid + 256 * ps;
+    pg[ps] = pw[ps] = pd[ps] = pq[ps] = 0.0;
+    if (idx < n) {
+      pg[ps] = T.rows.gt[idx]; pw[ps] = T.rows.w[idx]; pq[ps] = T.rows.q[idx];
+      if (T.scaling) pd[ps] = T.rows.D[idx];
+    }
+  }
   // ---- tr_prepare_sum: the partial sums in block order
   double* part = lds;            // [9 nblk]
   double* S = part + 9 * nblk;   // [9]
@@ -340,9 +354,19 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
   // of tr_trial_kernel's 1024 threads (thread v of it owns idx = v, v + 1024, ...): same bits
   const double a = ab[0], b = ab[1];
   const int lane = tid & 63;
-  for (int vt = tid; vt < 1024; vt += nt) {
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {   // (blockDim.x == 256)
+    const int vt = tid + 256 * ps;
     double s0 = 0.0, s1 = 0.0;
-    for (int idx = vt; idx < n; idx += 1024) {
+    if (vt < n) {   // the prefetched first element of virtual thread vt
+      const double dqs = a * pg[ps] + b * pw[ps];
+      const double dq = T.scaling ? pd[ps] * dqs : dqs;
+      T.dq[vt] = dq;
+      T.q_trial[vt] = pq[ps] + dq;
+      s0 += dq * dq;
+      s1 += pg[ps] * dqs;
+    }
+    for (int idx = vt + 1024; idx < n; idx += 1024) {
       const double dqs = a * T.rows.gt[idx] + b * T.rows.w[idx];
       const double dq = T.scaling ? T.rows.D[idx] * dqs : dqs;
       T.dq[idx] = dq;
