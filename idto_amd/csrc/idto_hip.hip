@@ -620,7 +620,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   // (cost_kernel is a single block holding one column of every cost term; penta_apply_kernel keeps
   // the right-hand side of each of its four wavefronts: both bound the horizon as well)
   const int Kpad = (nq == 2 || nq == 3 || nq == 5 || nq == 19 || nq == 23) ? nq : (nq <= 8 ? 8 : nq <= 16 ? 16 : nq <= 24 ? 24 : 32);
-  const int apply_lds = 4 * n * Kpad * (int)sizeof(double);
+  const int apply_lds = 4 * (n * Kpad + 4 * 64 + 2) * (int)sizeof(double);
   if (c->fd_lds > max_lds || c->asm_lds > max_lds || c->penta_lds > max_lds || c->cost_lds > max_lds ||
       apply_lds > max_lds) {
     g_err = "problem too large for the 160 KiB LDS carve-up of the v1 kernels (fd / assemble / solver / cost / "
@@ -1075,9 +1075,10 @@ static int FactorSolve(idto_hip_ctx* c, const double* rhs, int nrhs, double* x, 
                             (size_t)nrhs, hipMemcpyDeviceToDevice, c->stream));
   if (rc) return rc;
   if (nrhs > 1) {
-    // ... then substitute the other right-hand sides in parallel: one wavefront each
-    const int waves = 4, blocks = (nrhs - 1 + waves - 1) / waves;
-    const int lds = waves * ns * K * (int)sizeof(double);
+    // ... then substitute the other right-hand sides in parallel: one wavefront each (two, one per chain, when the
+    // factorisation was two-sided)
+    const int waves = 4, cols = m_split > 0 ? waves / 2 : waves, blocks = (nrhs - 1 + cols - 1) / cols;
+    const int lds = waves * (ns * K + 4 * 64 + 2) * (int)sizeof(double);   // (per column: rt of every row, the chains' exchange)
     const double* b1 = b + (size_t)n * k + (size_t)r0 * k;
     double* x1 = xo + (size_t)n * k + (size_t)r0 * k;
     if (!c->Tst && Alloc(c, (size_t)3 * (c->N + 1) * 32 * 36, &c->Tst)) return -2;

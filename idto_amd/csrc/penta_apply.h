@@ -46,19 +46,31 @@ penta_apply_kernel(int n, int k, const double* __restrict__ Ust, const double* _
                    size_t cstride) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = blockIdx.x * (blockDim.x >> 6) + wave;
-  if (j >= nrhs) return;  // no barriers below
+  // Two-sided factors: TWO wavefronts per right-hand side, one per chain (the halves of the twisted
+  // factorisation are independent up to the join rows), which hand over through LDS: the bottom one its
+  // pending pushes into the join rows, the top one x_m, x_{m+1} back.  2 (n/2) + 4 block rows on the
+  // dependent chain instead of 2 n.  One-sided factors: one wavefront per right-hand side as before.
+  const bool two = m_split > 0;
+  const int wpc = two ? 2 : 1;                        // wavefronts per column
+  const int half = two ? (wave & 1) : 0, slot = wave / wpc;
+  const int j = blockIdx.x * ((blockDim.x >> 6) / wpc) + slot;
+  constexpr int XCH = 4 * 64 + 2;                     // per column: q1, q2, x_m, x_{m+1} per lane; two flags
+  double* colbase = lds + (size_t)slot * ((size_t)n * K + XCH);
+  double* rtw = colbase;                              // rt_i[c] of this right-hand side, all rows (original index)
+  double* exq = colbase + (size_t)n * K;              // [2][64] pending pushes of the bottom chain, then [2][64] x_m, x_{m+1}
+  volatile int* xflag = reinterpret_cast<volatile int*>(exq + 4 * 64);   // [0] bottom forward done, [1] join rows solved
+  if (two && half == 0 && lane < 2) xflag[lane] = 0;
+  __syncthreads();                                    // (the only barrier: flags initialised)
+  if (j >= nrhs) return;
   constexpr int ks = ldl_ks(K), KS2 = K * ks, KP = (K + 1) / 2;
   const size_t nk = cstride;  // distance between right-hand sides (>= n * k: the caller may solve a sub-system)
   const int c = (lane < K) ? lane : K - 1;  // lanes >= K shadow lane K-1 (never stored)
   const bool live = lane < K;
-  double* rtw = lds + (size_t)wave * n * K;  // rt_i[c] of this right-hand side, all rows (original index)
   // Two-sided factors (m_split > 0, see penta_ldl_kernel): block rows 0 .. m+1 belong to the
   // top-down recursion (rows m, m+1 are the join), rows n-1 .. m+2 to the mirrored bottom-up one,
   // whose local row il is original row n-1-il.  One wavefront walks both chains one after the
   // other; the bottom chain's pending pushes enter the join rows, x_m and x_{m+1} start its
   // back substitution.
-  const bool two = m_split > 0;
   const int nT = two ? m_split + 2 : n, nB = two ? n - m_split - 2 : 0;
 
   // ---- forward substitution over local rows [first, last) of one chain.  The factor blocks
@@ -106,14 +118,28 @@ penta_apply_kernel(int n, int k, const double* __restrict__ Ust, const double* _
       if (il + 1 < last) fstep(side, il + 1, last, B, A, pend1, pend2);
     }
   };
+  auto wait_flag = [&](int f) {
+    while (xflag[f] == 0) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
+  auto post_flag = [&](int f) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) xflag[f] = 1;
+  };
   double p1 = 0.0, p2 = 0.0;
-  forward(0, 0, two ? m_split : n, p1, p2);
-  if (two) {
+  if (half == 0) {
+    forward(0, 0, two ? m_split : n, p1, p2);
+    if (two) {
+      wait_flag(0);
+      p1 += exq[64 + lane];  // the bottom chain's "row nB + 1" is original row m, its "row nB" is row m+1
+      p2 += exq[lane];
+      forward(0, m_split, nT, p1, p2);
+    }
+  } else {
     double q1 = 0.0, q2 = 0.0;
     forward(1, 0, nB, q1, q2);
-    p1 += q2;  // the bottom chain's "row nB + 1" is original row m, its "row nB" is row m+1
-    p2 += q1;
-    forward(0, m_split, nT, p1, p2);
+    exq[lane] = q1; exq[64 + lane] = q2;
+    post_flag(0);
   }
 
   // ---- back substitution over local rows first, first-1, .., 0 of one chain
@@ -156,7 +182,11 @@ penta_apply_kernel(int n, int k, const double* __restrict__ Ust, const double* _
       if (!solved) {
         if (live && lane < k) x[(size_t)j * nk + (size_t)o(il) * k + lane] = v;
         if (two && !side && il == m_split + 1) xm1 = v;
-        if (two && !side && il == m_split) xm = v;
+        if (two && !side && il == m_split) {   // both join rows solved: the bottom chain's back substitution can start
+          xm = v;
+          exq[128 + lane] = xm; exq[192 + lane] = xm1;
+          post_flag(1);
+        }
       }
       const bool next_given = il - 1 > first - given;  // (the second join row: what was pushed into it is not needed)
       v = next_given ? xm1 : next_rt + p;
@@ -169,8 +199,13 @@ penta_apply_kernel(int n, int k, const double* __restrict__ Ust, const double* _
       if (il >= 1) bstep(il - 1, B, A);
     }
   };
-  backward(0, nT - 1, 0);
-  if (two) backward(1, nB + 1, 2);
+  if (half == 0) {
+    backward(0, nT - 1, 0);
+  } else {
+    wait_flag(1);
+    xm = exq[128 + lane]; xm1 = exq[192 + lane];
+    backward(1, nB + 1, 2);
+  }
 }
 
 }  // namespace idto_dev
