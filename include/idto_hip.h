@@ -297,7 +297,11 @@ int idto_hip_solver_status(idto_hip_ctx* ctx, int* failed, int* failed_rows_tota
 int idto_hip_prefetch(idto_hip_ctx* ctx, int what);
 /* Synchronises and copies array `what` to host memory (sizes above). */
 int idto_hip_get(idto_hip_ctx* ctx, int what, double* host_out);
-/* Raw device pointer / element count of a resident array (for zero-copy interop). */
+/* Raw device pointer / element count of a resident array (for zero-copy interop).  Handing out a
+ * Hessian band or the slab tells the context that the caller may write it (the solver then takes H
+ * as a general matrix, the assembly reads the slab instead of fd_kernel's products).  The pointers of
+ * IDTO_ARR_V / A / NPLUS / SLAB / ASM_TERMS are stable between calls EXCEPT across idto_hip_tr_solve,
+ * which keeps two sets of them and may leave the iterate's in the other one: ask again afterwards. */
 void* idto_hip_device_ptr(idto_hip_ctx* ctx, int what);
 long idto_hip_array_size(idto_hip_ctx* ctx, int what);
 int idto_hip_slab_stride(idto_hip_ctx* ctx);
