@@ -55,9 +55,9 @@ dense_ldl_panel_kernel(double* __restrict__ S, int n, int j0, double* __restrict
     for (int p = 0; p < NB; ++p) {
       if (p < nb) {  // (wavefront-uniform)
         const double d = rdlane(a[p], p);
-        const double l = a[p] / d;  // l_rp on lane r > p
+        const double l = a[p] * fast_rcp(d);  // l_rp on lane r > p
 #pragma unroll
-        for (int c = p + 1; c < NB; ++c) a[c] -= a[p] * rdlane(l, c);  // rows r >= c matter
+        for (int c = p + 1; c < NB; ++c) a[c] = __builtin_fma(-a[p], rdlane(l, c), a[c]);  // rows r >= c matter
         if (rr > p) a[p] = l;
       }
     }
@@ -68,8 +68,10 @@ dense_ldl_panel_kernel(double* __restrict__ S, int n, int j0, double* __restrict
     }
   }
   __syncthreads();
+  __shared__ double di[NB];
   if (tid < NB) {  // dd[r] = A[r][r] (static indexing above is not possible: read it back)
     dd[tid] = A[tid][tid];
+    di[tid] = fast_rcp(A[tid][tid]);
   }
   __syncthreads();
   if (blockIdx.x == 0) {
@@ -96,12 +98,20 @@ dense_ldl_panel_kernel(double* __restrict__ S, int n, int j0, double* __restrict
   __shared__ double xw[NB][64];
   const int r = j0 + nb + (blockIdx.x - 1) * 64 + tid;
   if (r >= n) return;  // (no barrier below)
-  for (int k = 0; k < nb; ++k) {
-    double acc = S[(size_t)(j0 + k) * n + r];
-    for (int q = 0; q < k; ++q) acc -= xw[q][tid] * A[k][q];
-    xw[k][tid] = acc;
-    S[(size_t)(j0 + k) * n + r] = acc / dd[k];  // L[r][j0 + k]
-    W[(size_t)k * n + r] = acc;                 // W = L D
+  // the row's NB entries first (the stores below alias S for the compiler: fetched one per step of the
+  // k loop they were a chain of 32 L2 round trips, 16 of the kernel's 29 us)
+  double w[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) w[k] = (k < nb) ? S[(size_t)(j0 + k) * n + r] : 0.0;
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    if (k < nb) {
+      double acc = w[k];
+      for (int q = 0; q < k; ++q) acc = __builtin_fma(-xw[q][tid], A[k][q], acc);
+      xw[k][tid] = acc;
+      S[(size_t)(j0 + k) * n + r] = acc * di[k];  // L[r][j0 + k]
+      W[(size_t)k * n + r] = acc;                 // W = L D
+    }
   }
 }
 
@@ -170,8 +180,12 @@ dense_ldl_solve_kernel(const double* __restrict__ S, int n, const double* __rest
     }
     __syncthreads();
     for (int r = j0 + nb + tid; r < n; r += nt) {
+      double lv[NB];   // (all loads in flight at once: a rolled loop was a chain of L2 round trips)
+#pragma unroll
+      for (int k = 0; k < NB; ++k) lv[k] = (k < nb) ? S[(size_t)(j0 + k) * n + r] : 0.0;
       double acc = 0.0;
-      for (int k = 0; k < nb; ++k) acc += S[(size_t)(j0 + k) * n + r] * y[j0 + k];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) acc = __builtin_fma(lv[k], y[j0 + (k < nb ? k : 0)], acc);
       y[r] -= acc;
     }
     __syncthreads();
@@ -189,8 +203,16 @@ dense_ldl_solve_kernel(const double* __restrict__ S, int n, const double* __rest
       const int lane = tid & 63, w = tid >> 6, nw = nt >> 6;
       for (int k = w; k < NB; k += nw) {
         double acc = 0.0;
-        if (k < nb)
-          for (int r = j0 + nb + lane; r < n; r += 64) acc += S[(size_t)(j0 + k) * n + r] * y[r];
+        if (k < nb) {
+          const int rb = j0 + nb + lane;
+          double sv[8];   // (eight loads in flight; the rolled loop waited for each)
+#pragma unroll
+          for (int t = 0; t < 8; ++t) sv[t] = (rb + 64 * t < n) ? S[(size_t)(j0 + k) * n + rb + 64 * t] : 0.0;
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+            if (rb + 64 * t < n) acc += sv[t] * y[rb + 64 * t];
+          for (int r = rb + 512; r < n; r += 64) acc += S[(size_t)(j0 + k) * n + r] * y[r];
+        }
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
         if (lane == 0) red[k] = acc;
       }
