@@ -61,7 +61,15 @@ __global__ void constraint_schur_kernel(const double* __restrict__ slab, int sla
   for (int c = threadIdx.x; c <= neq; c += blockDim.x) {
     const double* y = Y + (size_t)c * n + c0;
     double acc = 0.0;
-    for (int i = 0; i < len; ++i) acc += jr[i] * y[i];
+    int i = 0;
+    for (; i + 8 <= len; i += 8) {   // (eight loads in flight: a rolled loop waits for every one of them; same order of adds)
+      double y8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) y8[u] = y[i + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += jr[i + u] * y8[u];
+    }
+    for (; i < len; ++i) acc += jr[i] * y[i];
     if (c == 0) out_Jy[r] = acc;
     else out_S[(size_t)(c - 1) * neq + r] = acc;
   }
@@ -87,8 +95,17 @@ constraint_step_kernel(const double* __restrict__ slab, int slab_stride, const i
   const int n = (N + 1) * nq, i = blockIdx.x * 64 + lane;
   const int per = (neq + STEP_WAVES - 1) / STEP_WAVES, r0 = w * per, r1 = (r0 + per < neq) ? r0 + per : neq;
   double acc = 0.0;
-  if (i < n)
-    for (int r = r0; r < r1; ++r) acc += Y[(size_t)(1 + r) * n + i] * lam[r];
+  if (i < n) {
+    int r = r0;
+    for (; r + 8 <= r1; r += 8) {    // (as above)
+      double y8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) y8[u] = Y[(size_t)(1 + r + u) * n + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += y8[u] * lam[r + u];
+    }
+    for (; r < r1; ++r) acc += Y[(size_t)(1 + r) * n + i] * lam[r];
+  }
   part[w * 64 + lane] = acc;
   __syncthreads();
   if (i >= n) return;
