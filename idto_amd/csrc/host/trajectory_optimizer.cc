@@ -461,6 +461,7 @@ void TO::CalcGradHess(const TrajectoryOptimizerState<T>& state) const {
   c.hessian.mutable_A().assign(bands.begin(), bands.begin() + used);
   c.hessian.mutable_B().assign(bands.begin() + span, bands.begin() + span + used);
   c.hessian.mutable_C().assign(bands.begin() + 2 * span, bands.begin() + 2 * span + used);
+  c.hessian.MakeSymmetric();   // TO.cc:1165 (the device's C already carries both triangles; D, E are the mirrors)
   c.grad = c.hess = true;
 }
 
