@@ -928,7 +928,8 @@ static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double s
   return 0;
 }
 
-static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, double* xo, bool one_sided = false, bool allow_nd = false) {
+static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, double* xo, bool one_sided = false, bool allow_nd = false,
+                     bool factor_only = false) {
   LdlPlan p;
   if (int rc = PlanLdl(c, one_sided, &p)) return rc;
   if (allow_nd && !one_sided && NdEligible(c, p)) return LaunchNd(c, p, b, sign, xo);
@@ -942,7 +943,7 @@ static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, double* xo, 
   if (m_split > 0) ++c->epoch;  // (exchange buffer and flags live in the problem's arena)
   if (++c->fact_id == 0) c->fact_id = 1;  // (0 is the initial value of the status word)
 #define LDL_ARGS n, k, c->HA + qq0, c->HB + qq0, c->HC + qq0, b, sign, nrhs, xo, c->Ust, c->Hst, c->Est, c->Dst, dbg, \
-                 m_split, c->xch, c->flags, c->epoch, c->status_dev, c->fact_id, c->pstride
+                 m_split, c->xch, c->flags, c->epoch, c->status_dev, c->fact_id, c->pstride, factor_only ? 1 : 0
 #define LDL_LAUNCH(KM, PD, GW) \
   hipLaunchKernelGGL((penta_ldl_kernel<KM, 256, PD, GW>), grid, dim3(256), lds, c->stream, LDL_ARGS)
   switch (p.K) {
@@ -1067,7 +1068,9 @@ static int FactorSolve(idto_hip_ctx* c, const double* rhs, int nrhs, double* x, 
   // block LDL^T: factorise once with the first right-hand side (two-sided when the horizon is
   // long enough; the substitution kernel walks both chains of factors) ...
   const int K = (k == 2 || k == 3 || k == 5 || k == 19 || k == 23) ? k : (k <= 8 ? 8 : k <= 16 ? 16 : k <= 24 ? 24 : 32);
-  int rc = LaunchLdl(c, b, rhs ? 1.0 : -1.0, xo, false, /*allow_nd=*/nrhs == 1);
+  // (several right-hand sides: the factorisation stops after its forward pass, every column incl. the first is
+  // substituted by penta_apply_kernel - the chains' own back substitution would only delay the others)
+  int rc = LaunchLdl(c, b, rhs ? 1.0 : -1.0, xo, false, /*allow_nd=*/nrhs == 1, /*factor_only=*/nrhs > 1);
   const int r0 = SolverFirstRow(c), ns = n - r0;                      // the sub-system LaunchLdl factorised
   const int m_split = (c->two_sided && ns >= 10) ? (ns - 1) / 2 : 0;  // as LaunchLdl chose
   if (r0 && rhs && !x0_written)  // x_0 = rhs_0 for every column (row 0 of H is the identity); the default rhs has g_0 = 0 = x_0
@@ -1077,16 +1080,16 @@ static int FactorSolve(idto_hip_ctx* c, const double* rhs, int nrhs, double* x, 
   if (nrhs > 1) {
     // ... then substitute the other right-hand sides in parallel: one wavefront each (two, one per chain, when the
     // factorisation was two-sided)
-    const int waves = 4, cols = m_split > 0 ? waves / 2 : waves, blocks = (nrhs - 1 + cols - 1) / cols;
+    const int waves = 4, cols = m_split > 0 ? waves / 2 : waves, blocks = (nrhs + cols - 1) / cols;
     const int lds = waves * (ns * K + 4 * 64 + 2) * (int)sizeof(double);   // (per column: rt of every row, the chains' exchange)
-    const double* b1 = b + (size_t)n * k + (size_t)r0 * k;
-    double* x1 = xo + (size_t)n * k + (size_t)r0 * k;
+    const double* b1 = b + (size_t)r0 * k;
+    double* x1 = xo + (size_t)r0 * k;
     if (!c->Tst && Alloc(c, (size_t)3 * (c->N + 1) * 32 * 36, &c->Tst)) return -2;
 #define APPLY_LAUNCH(KM)                                                                                          \
     hipLaunchKernelGGL(penta_factor_transpose_kernel<KM>, dim3(ns, 3), dim3(256), 0, c->stream, c->Ust, c->Hst,    \
                        c->Est, c->Tst);                                                                            \
     hipLaunchKernelGGL(penta_apply_kernel<KM>, dim3(blocks), dim3(64 * waves), lds, c->stream, ns, k, c->Ust, c->Hst, \
-                       c->Est, c->Dst, c->Tst, b1, rhs ? 1.0 : -1.0, nrhs - 1, x1, m_split, (size_t)n * k)
+                       c->Est, c->Dst, c->Tst, b1, rhs ? 1.0 : -1.0, nrhs, x1, m_split, (size_t)n * k)
     switch (K) {
       case 2: APPLY_LAUNCH(2); break;
       case 3: APPLY_LAUNCH(3); break;

@@ -189,6 +189,8 @@ struct ChainCfg {
   const double* xsep;               // [x_s | x_{s+1}] once *sepflag == epoch
   unsigned* sepflag;
   double* ts;                       // optional wall-clock stamps (100 MHz): start, join reached, forward done, backward start, end
+  int factor_only;                  // stop once the factors are in HBM: every right-hand side (the first included) goes
+                                    // through penta_apply_kernel, the chains' own back substitution is off the path
 };
 __device__ __forceinline__ void chain_ts(const ChainCfg& cfg, int slot) {
   if (cfg.ts && threadIdx.x == 0) cfg.ts[slot] = (double)wall_clock64();
@@ -749,6 +751,7 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
   }
   chain_ts(cfg, 3);
 
+  if (cfg.factor_only) return;
   // ---- backward pass: (D_i^-1 U_i) x_i = D_i^-1 rt_i - (D_i^-1 Ht_i) x_{i+1} - (D_i^-1 Et_i) x_{i+2}
   // One wavefront per right-hand side, no LDS staging and no barrier: lane = row r (+32 for the
   // second half).  The first half holds row r of D^-1 Ht_i, the second half row r of D^-1 Et_i,
@@ -961,12 +964,14 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
                  double* __restrict__ x, double* __restrict__ Ust, double* __restrict__ Hst,
                  double* __restrict__ Est, double* __restrict__ Dst, double* __restrict__ dbg,
                  int m_split, double* __restrict__ xch, unsigned* __restrict__ flags, unsigned epoch,
-                 unsigned* __restrict__ status, unsigned fact_id, size_t pstride) {
+                 unsigned* __restrict__ status, unsigned fact_id, size_t pstride, int factor_only) {
   const size_t o = (size_t)blockIdx.y * pstride;
+  ChainCfg cfg = two_sided_cfg(n, m_split, (int)blockIdx.x);
+  cfg.factor_only = factor_only;
   penta_ldl_body<K, NT, PADDED, GJW>(n, k, at_problem(HA, o), at_problem(HB, o), at_problem(HC, o), at_problem(b, o),
                                      rhs_sign, nrhs, at_problem(x, o), at_problem(Ust, o), at_problem(Hst, o),
                                      at_problem(Est, o), at_problem(Dst, o), dbg ? at_problem(dbg, o) : nullptr,
-                                     two_sided_cfg(n, m_split, (int)blockIdx.x), at_problem(xch, o), at_problem(flags, o),
+                                     cfg, at_problem(xch, o), at_problem(flags, o),
                                      epoch, status + 2 * blockIdx.y, fact_id);
 }
 

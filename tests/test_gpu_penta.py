@@ -117,11 +117,12 @@ def test_solve_penta_diagonal(two_sided):  # :188-257
     assert np.array_equal(s.solve(b, reference=True), ol.penta_solve(*H, b))
     x = s.solve(b, two_sided=two_sided)
     assert np.linalg.norm(x - x_gt) / np.linalg.norm(x_gt) < 50 * cond * EPS
-    # many right-hand sides share one factorisation (column 0 in the factorisation kernel, the
-    # others in the substitution kernel)
+    # many right-hand sides share one factorisation: the factorisation kernel stops after its forward pass and
+    # every column (the first included) goes through the substitution kernel - same factors, a differently
+    # ordered substitution than the single-column solve above
     X = s.solve(np.stack([b, 2 * b, -b, 0.5 * b]), two_sided=two_sided)
-    assert np.array_equal(X[0], x)
-    for k, f in ((1, 2.0), (2, -1.0), (3, 0.5)):
+    assert np.linalg.norm(X[0] - x) / np.linalg.norm(x) < 50 * cond * EPS
+    for k, f in ((0, 1.0), (1, 2.0), (2, -1.0), (3, 0.5)):
         assert np.linalg.norm(X[k] - f * x_gt) / np.linalg.norm(x_gt) < 50 * cond * EPS
 
 
@@ -149,3 +150,36 @@ def test_condition_number_sweep():  # :260-319 (prints only in the reference; he
         for kw in (dict(reference=True), dict(two_sided=True), dict(two_sided=False)):
             x = s.solve(Hd @ x_gt, **kw)
             assert np.linalg.norm(x - x_gt) / np.linalg.norm(x_gt) < 100 * cond * EPS, (cond_target, kw)
+
+
+@pytest.mark.parametrize("name,N", [("hopper", 50), ("mini_cheetah", 40), ("allegro_hand", 30), ("acrobot", 40), ("spinner", 9)])
+def test_many_right_hand_sides_are_as_accurate_as_one(name, N):
+    """several right-hand sides: the factorisation kernel stops after its forward pass and every column goes through
+    penta_apply_kernel (two wavefronts per column, one per chain of the twisted factorisation).  Against the
+    extended-precision solution of the assembled Gauss-Newton system the columns must be as good as the
+    single-column solve (whose substitution runs inside the factorisation kernel) and as the pivoted LU."""
+    from idto_amd import hip
+    from idto_amd.model import load_model
+    from idto_amd.problem import load_config, make_problem, synthetic_trajectory
+    cfg, model = load_config(name), load_model(name)
+    prob, sp, _ = make_problem(cfg, model, num_steps=N)
+    sp.scaling = False
+    sp.equality_constraints = False
+    q = synthetic_trajectory(cfg, model, N, seed=0, lower=0.01)
+    dev = hip.HipPath(model, prob, sp)
+    dev.set_q(q)
+    dev.gn_step()
+    g = dev.get("gradient").ravel()
+    bands = [dev.get(k) for k in ("H_A", "H_B", "H_C")]
+    Cs, Dm, Em = ol.penta_make_symmetric(*bands)
+    Hd = ol.penta_make_dense(bands[0], bands[1], Cs, Dm, Em)
+    ref, unc = ol.refined_solution(Hd, -g)
+    scale = np.abs(ref).max()
+    err_one = np.abs(dev.get("step").ravel() - ref).max() / scale
+    err_lu = np.abs(np.linalg.solve(Hd, -g) - ref).max() / scale
+    X = dev.solve_host(np.stack([-g, 2.0 * g, -0.5 * g]))
+    for col, f in enumerate((1.0, -2.0, 0.5)):
+        err = np.abs(X[col] - f * ref).max() / scale / abs(f)
+        assert err <= 4 * max(err_one, err_lu) + 16 * unc + 1e-12, (col, err, err_one, err_lu, unc)
+    assert dev.solver_status() == (False, 0)
+    dev.close()
