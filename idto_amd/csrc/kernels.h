@@ -284,7 +284,7 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
   // (terms != nullptr) the record and its weighted copy for the assembly products: 6 blocks of nq
   // columns, column stride nvp (16-byte aligned columns), + tau_k R' and the diagonal of R'
   const int nvp = (nv + 1) & ~1, psz = nvp * nq;
-  // (16-byte aligned: asm_dot reads double2; a misaligned ds_read_b128 costs ~250 cycles per instruction)
+  // (16-byte aligned: asm_dot reads double2; 8 bytes off, the products below took twice as long)
   double* rec = reinterpret_cast<double*>(colinfo + nq + (nq & 1));   // [P | T | M | P R' | T R' | M R'] then diag R'
   rec += (rec - lds) & 1;
 

@@ -145,8 +145,8 @@ __host__ __device__ inline PentaLdlLds penta_ldl_layout(int n, int K, int nrhs) 
   L.Iv = o; o += 3 * ks;          // ring: 1/diag(U) (padded to ks)
   L.rt = o; o += 3 * L.rts;       // ring: rt_i (forward) / x_i (backward)
   L.U = o; o += 2 * L.kks;        // ring: U_i, U_{i-1} (write-back staging)
-  L.G = o; o += (K * K + 1) & ~1; // Et_{i-1}^T Dn Et_{i-1} for the next row (even size: what follows is read as double2 -
-                                  // a ds_read_b128 off a 16-byte boundary costs ~250 cycles instead of ~16)
+  L.G = o; o += (K * K + 1) & ~1; // Et_{i-1}^T Dn Et_{i-1} for the next row (even size: what follows is read as double2;
+                                  // b128 reads off a 16-byte boundary halve the LDS throughput)
   {                               // staged A_i, B_{i+1}, C_i, A_{i+2}; reused by the backward pass
     const int fwd = 4 * K * K, bwd = 3 * K * ks + ks;
     L.in = o; o += ((fwd > bwd ? fwd : bwd) + 1) & ~1;
