@@ -639,7 +639,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cost_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_terms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&constraint_lambda_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-#define APPLY_ATTR(KM) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_apply_kernel<KM>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+#define APPLY_ATTR(KM) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_apply_kernel<KM, (KM <= 8)>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   APPLY_ATTR(2) APPLY_ATTR(3) APPLY_ATTR(5) APPLY_ATTR(8) APPLY_ATTR(16) APPLY_ATTR(19) APPLY_ATTR(23) APPLY_ATTR(24) APPLY_ATTR(32)
 #undef APPLY_ATTR
 #define LDL_ATTR(KM, PD, GW)                                                                   \
@@ -1086,10 +1086,15 @@ static int FactorSolve(idto_hip_ctx* c, const double* rhs, int nrhs, double* x, 
     double* x1 = xo + (size_t)r0 * k;
     if (!c->Tst && Alloc(c, (size_t)3 * (c->N + 1) * 32 * 36, &c->Tst)) return -2;
 #define APPLY_LAUNCH(KM)                                                                                          \
-    hipLaunchKernelGGL(penta_factor_transpose_kernel<KM>, dim3(ns, 3), dim3(256), 0, c->stream, c->Ust, c->Hst,    \
-                       c->Est, c->Tst);                                                                            \
-    hipLaunchKernelGGL(penta_apply_kernel<KM>, dim3(blocks), dim3(64 * waves), lds, c->stream, ns, k, c->Ust, c->Hst, \
-                       c->Est, c->Dst, c->Tst, b1, rhs ? 1.0 : -1.0, nrhs, x1, m_split, (size_t)n * k)
+    if (KM <= 8) {   /* small blocks: the forward pass reads the row-major factors directly, no transposed copies */ \
+      hipLaunchKernelGGL((penta_apply_kernel<KM, true>), dim3(blocks), dim3(64 * waves), lds, c->stream, ns, k, c->Ust, \
+                         c->Hst, c->Est, c->Dst, c->Tst, b1, rhs ? 1.0 : -1.0, nrhs, x1, m_split, (size_t)n * k);  \
+    } else {                                                                                                        \
+      hipLaunchKernelGGL(penta_factor_transpose_kernel<KM>, dim3(ns, 3), dim3(256), 0, c->stream, c->Ust, c->Hst,  \
+                         c->Est, c->Tst);                                                                          \
+      hipLaunchKernelGGL((penta_apply_kernel<KM, false>), dim3(blocks), dim3(64 * waves), lds, c->stream, ns, k, c->Ust, \
+                         c->Hst, c->Est, c->Dst, c->Tst, b1, rhs ? 1.0 : -1.0, nrhs, x1, m_split, (size_t)n * k); \
+    }
     switch (K) {
       case 2: APPLY_LAUNCH(2); break;
       case 3: APPLY_LAUNCH(3); break;

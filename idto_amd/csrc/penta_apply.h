@@ -38,7 +38,10 @@ __global__ void penta_factor_transpose_kernel(const double* __restrict__ Ust, co
   }
 }
 
-template <int K>
+// DIRECT: the forward pass reads the columns of the row-major blocks themselves (8-byte loads, coalesced across
+// the lanes) instead of the transposed copies - for small blocks the few extra load instructions cost less than
+// the transpose launch (K <= 8: used by the acrobot / spinner / hopper models)
+template <int K, bool DIRECT>
 __global__ void __launch_bounds__(256)
 penta_apply_kernel(int n, int k, const double* __restrict__ Ust, const double* __restrict__ Hst,
                    const double* __restrict__ Est, const double* __restrict__ Dst, const double* __restrict__ Tst,
@@ -82,11 +85,24 @@ penta_apply_kernel(int n, int k, const double* __restrict__ Ust, const double* _
   struct Blk { double2 u[KP], h[KP], e[KP]; double b; };
   auto fload = [&](int side, int il, Blk& d) __attribute__((always_inline)) {
     const int i = side ? n - 1 - il : il;
-    const double2* pu = reinterpret_cast<const double2*>(UT + (size_t)i * KS2 + c * ks);
-    const double2* ph = reinterpret_cast<const double2*>(HT + (size_t)i * KS2 + c * ks);
-    const double2* pe = reinterpret_cast<const double2*>(ET + (size_t)i * KS2 + c * ks);
+    if (DIRECT) {
+      const double* pu = Ust + (size_t)i * KS2 + c;   // element [jj][c] of the row-major block: jj * ks + c
+      const double* ph = Hst + (size_t)i * KS2 + c;
+      const double* pe = Est + (size_t)i * KS2 + c;
 #pragma unroll
-    for (int m = 0; m < KP; ++m) { d.u[m] = pu[m]; d.h[m] = ph[m]; d.e[m] = pe[m]; }
+      for (int m = 0; m < KP; ++m) {
+        const bool two_ = 2 * m + 1 < K;
+        d.u[m] = make_double2(pu[(2 * m) * ks], two_ ? pu[(2 * m + 1) * ks] : 0.0);
+        d.h[m] = make_double2(ph[(2 * m) * ks], two_ ? ph[(2 * m + 1) * ks] : 0.0);
+        d.e[m] = make_double2(pe[(2 * m) * ks], two_ ? pe[(2 * m + 1) * ks] : 0.0);
+      }
+    } else {
+      const double2* pu = reinterpret_cast<const double2*>(UT + (size_t)i * KS2 + c * ks);
+      const double2* ph = reinterpret_cast<const double2*>(HT + (size_t)i * KS2 + c * ks);
+      const double2* pe = reinterpret_cast<const double2*>(ET + (size_t)i * KS2 + c * ks);
+#pragma unroll
+      for (int m = 0; m < KP; ++m) { d.u[m] = pu[m]; d.h[m] = ph[m]; d.e[m] = pe[m]; }
+    }
     d.b = (c < k) ? rhs[(size_t)j * nk + (size_t)i * k + c] : 0.0;
   };
   auto fstep = [&](int side, int il, int last, const Blk& cur, Blk& nxt, double& pend1, double& pend2)
