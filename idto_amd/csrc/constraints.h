@@ -5,7 +5,7 @@
 // The constraint h(q) = [tau_t[dof] : t < N, dof unactuated] has the Jacobian rows
 //   J[(t, dof), :] = [ dtau_t/dq_{t-1} (t > 1) | dtau_t/dq_t (t > 0) | dtau_t/dq_{t+1} ](dof, :)
 // which are rows of the slab records fd_kernel wrote, so nothing about J ever crosses PCIe:
-//   constraint_rhs_kernel    columns [g | J^T] for the multi-right-hand-side solve,
+//   (penta_apply.h RhsSource) the columns [g | J^T] of the multi-right-hand-side solve, read in place,
 //   constraint_schur_kernel  S = J Y_J (n_eq x n_eq) and J y_g from Y = H^-1 [g | J^T],
 //   constraint_step_kernel   y_g + Y_J lambda  (= H^-1 (g + J^T lambda))  and  J^T lambda.
 #pragma once
@@ -24,26 +24,6 @@ __device__ __forceinline__ double jac_entry(const double* __restrict__ slab, int
   if (which < 0 || which > 2) return 0.0;
   if ((which == 0 && t < 2) || (which == 1 && t < 1)) return 0.0;  // q_0 is not a variable of tau_t's rows (:1316-1322)
   return slab[(size_t)t * slab_stride + (size_t)which * nv * nq + i * nv + dof];
-}
-
-// grid: n_eq + 1 blocks; block 0 copies g, block 1 + r writes row r of J as a column
-__global__ void constraint_rhs_kernel(const double* __restrict__ slab, int slab_stride, const double* __restrict__ g,
-                                      const int* __restrict__ dofs, int nu, int N, int nq, int nv,
-                                      double* __restrict__ rhs, double* __restrict__ x, idto_dev::AltSel alt) {
-  slab = idto_dev::at_set(slab, alt);   // (idto_hip_tr_solve: the iterate's set of partials)
-  const int n = (N + 1) * nq, b = blockIdx.x;
-  double* out = rhs + (size_t)b * n;
-  double* x0 = x + (size_t)b * n;       // block row 0 of the solution = of the right-hand side (C_0 = I, decoupled):
-  if (b == 0) {                         // written here, the solver starts at row 1
-    for (int i = threadIdx.x; i < n; i += blockDim.x) { const double v = g[i]; out[i] = v; if (i < nq) x0[i] = v; }
-    return;
-  }
-  const int r = b - 1, t = r / nu, dof = dofs[r - t * nu];
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const double v = jac_entry(slab, slab_stride, nq, nv, t, dof, N, i);
-    out[i] = v;
-    if (i < nq) x0[i] = v;
-  }
 }
 
 // grid: n_eq blocks (row r of J staged in LDS); thread <-> column of Y.  out_S is column-major

@@ -1035,12 +1035,14 @@ static int LaunchFused(idto_hip_ctx* c) {
   return TimeEnd(c);
 }
 
-static int FactorSolve(idto_hip_ctx* c, const double* rhs, int nrhs, double* x, bool x0_written);
+static int FactorSolve(idto_hip_ctx* c, const double* rhs, int nrhs, double* x, const RhsSource* src);
 int idto_hip_factor_solve(idto_hip_ctx* c, const double* rhs, int nrhs, double* x) {
-  return FactorSolve(c, rhs, nrhs, x, false);
+  return FactorSolve(c, rhs, nrhs, x, nullptr);
 }
-// x0_written: the caller has already put rhs_0 into x_0 of every column (block row 0 of an assembled H is the identity)
-static int FactorSolve(idto_hip_ctx* c, const double* rhs, int nrhs, double* x, bool x0_written) {
+// src: the right-hand sides are [g | J^T] read in place (penta_apply.h RhsSource; nrhs > 1), `rhs` is then any valid
+// pointer to (N + 1) nq doubles for the factorisation kernel's unused first column
+static int FactorSolve(idto_hip_ctx* c, const double* rhs, int nrhs, double* x, const RhsSource* src) {
+  const bool x0_written = src != nullptr;   // (the substitution kernel zeroes x_0 itself)
   HIP_OK(hipSetDevice(c->device));
   if (!rhs) DropPrefetch(c, {IDTO_ARR_STEP});
   const int n = c->N + 1, k = c->nq;
@@ -1085,15 +1087,17 @@ static int FactorSolve(idto_hip_ctx* c, const double* rhs, int nrhs, double* x, 
     const double* b1 = b + (size_t)r0 * k;
     double* x1 = xo + (size_t)r0 * k;
     if (!c->Tst && Alloc(c, (size_t)3 * (c->N + 1) * 32 * 36, &c->Tst)) return -2;
+    RhsSource RS{};
+    if (src) { RS = *src; RS.r0 = r0; }
 #define APPLY_LAUNCH(KM)                                                                                          \
     if (KM <= 8) {   /* small blocks: the forward pass reads the row-major factors directly, no transposed copies */ \
       hipLaunchKernelGGL((penta_apply_kernel<KM, true>), dim3(blocks), dim3(64 * waves), lds, c->stream, ns, k, c->Ust, \
-                         c->Hst, c->Est, c->Dst, c->Tst, b1, rhs ? 1.0 : -1.0, nrhs, x1, m_split, (size_t)n * k);  \
+                         c->Hst, c->Est, c->Dst, c->Tst, b1, rhs ? 1.0 : -1.0, nrhs, x1, m_split, (size_t)n * k, RS);  \
     } else {                                                                                                        \
       hipLaunchKernelGGL(penta_factor_transpose_kernel<KM>, dim3(ns, 3), dim3(256), 0, c->stream, c->Ust, c->Hst,  \
                          c->Est, c->Tst);                                                                          \
       hipLaunchKernelGGL((penta_apply_kernel<KM, false>), dim3(blocks), dim3(64 * waves), lds, c->stream, ns, k, c->Ust, \
-                         c->Hst, c->Est, c->Dst, c->Tst, b1, rhs ? 1.0 : -1.0, nrhs, x1, m_split, (size_t)n * k); \
+                         c->Hst, c->Est, c->Dst, c->Tst, b1, rhs ? 1.0 : -1.0, nrhs, x1, m_split, (size_t)n * k, RS); \
     }
     switch (K) {
       case 2: APPLY_LAUNCH(2); break;
@@ -1156,10 +1160,11 @@ int idto_hip_constraint_schur_begin(idto_hip_ctx* c, const int* dofs, int nu) {
   }
   c->con_ready = false; c->con_begun = false;
   if (EnsureStage(c, (size_t)(neq + 1) * n)) return -2;
-  hipLaunchKernelGGL(constraint_rhs_kernel, dim3(neq + 1), dim3(256), 0, c->stream, c->slab, c->slab_stride, c->g,
-                     c->con_dofs, nu, N, c->nq, c->nv, c->stage_rhs, c->stage_x, c->alt_r);
-  HIP_OK(hipGetLastError());
-  int rc = FactorSolve(c, c->stage_rhs, neq + 1, c->stage_x, /*x0_written=*/true);
+  // Y = H^-1 [g | J^T]: the right-hand sides are read where they are (g; rows of the slab records), nothing is staged
+  RhsSource src{};
+  src.slab = c->slab; src.slab_stride = c->slab_stride; src.nu = nu; src.nv = c->nv; src.r0 = 0;
+  src.dofs = c->con_dofs; src.g = c->g; src.alt = c->alt_r;
+  int rc = FactorSolve(c, c->g, neq + 1, c->stage_x, &src);
   if (rc) return rc;
   hipLaunchKernelGGL(constraint_schur_kernel, dim3(neq), dim3(256), 3 * c->nq * sizeof(double), c->stream, c->slab,
                      c->slab_stride, c->con_dofs, nu, N, c->nq, c->nv, c->stage_x, neq, c->con_S,

@@ -18,9 +18,23 @@
 
 #include <hip/hip_runtime.h>
 
+#include "batch.h"
 #include "penta_ldl.h"
 
 namespace idto_dev {
+
+// Right-hand sides that are not stored: column 0 = g, column 1 + r = row r of the equality constraints' Jacobian
+// J[(t, dof), :] = [dtau_t/dq_{t-1} (t > 1) | dtau_t/dq_t (t > 0) | dtau_t/dq_{t+1}](dof, :), i.e. rows of the slab
+// records (constraints.h; reference optimizer/trajectory_optimizer.cc:1292-1334).  The substitution kernel reads
+// them where they are instead of from (n_eq + 1) staged columns (4 MB for the allegro hand at N = 60).
+// slab == nullptr: the right-hand sides are the array `rhs`.
+struct RhsSource {
+  const double* slab;
+  int slab_stride, nu, nv, r0;   // r0: block rows the solved sub-system skips at the top (their x is rhs = 0 here)
+  const int* dofs;
+  const double* g;
+  AltSel alt;
+};
 
 // Column-major copies of the three factor blocks of every row (grid (n, 3)): the forward pass
 // reads COLUMNS of the row-major blocks; from the transposed copy a lane gets its column with
@@ -46,7 +60,7 @@ __global__ void __launch_bounds__(256)
 penta_apply_kernel(int n, int k, const double* __restrict__ Ust, const double* __restrict__ Hst,
                    const double* __restrict__ Est, const double* __restrict__ Dst, const double* __restrict__ Tst,
                    const double* __restrict__ rhs, double rhs_sign, int nrhs, double* __restrict__ x, int m_split,
-                   size_t cstride) {
+                   size_t cstride, RhsSource R) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // Two-sided factors: TWO wavefronts per right-hand side, one per chain (the halves of the twisted
@@ -83,6 +97,18 @@ penta_apply_kernel(int n, int k, const double* __restrict__ Ust, const double* _
   const double* HT = Tst + (size_t)n * KS2;
   const double* ET = Tst + (size_t)2 * n * KS2;
   struct Blk { double2 u[KP], h[KP], e[KP]; double b; };
+  // component c of block row i of this column's right-hand side
+  const double* jslab = R.slab ? at_set(R.slab, R.alt) : nullptr;
+  int jt = 0, jdof = 0;
+  if (jslab && j > 0) { jt = (j - 1) / R.nu; jdof = R.dofs[(j - 1) - jt * R.nu]; }
+  auto rhs_at = [&](int i) -> double {
+    if (!jslab) return rhs[(size_t)j * nk + (size_t)i * k + c];
+    const int gi = i + R.r0;
+    if (j == 0) return R.g[(size_t)gi * k + c];
+    const int which = gi - jt + 1;   // 0: q_{t-1}, 1: q_t, 2: q_{t+1}
+    if (which < 0 || which > 2 || (which == 0 && jt < 2) || (which == 1 && jt < 1)) return 0.0;   // (q_0 is not a variable)
+    return jslab[(size_t)jt * R.slab_stride + (size_t)which * R.nv * k + c * R.nv + jdof];
+  };
   auto fload = [&](int side, int il, Blk& d) __attribute__((always_inline)) {
     const int i = side ? n - 1 - il : il;
     if (DIRECT) {
@@ -103,7 +129,7 @@ penta_apply_kernel(int n, int k, const double* __restrict__ Ust, const double* _
 #pragma unroll
       for (int m = 0; m < KP; ++m) { d.u[m] = pu[m]; d.h[m] = ph[m]; d.e[m] = pe[m]; }
     }
-    d.b = (c < k) ? rhs[(size_t)j * nk + (size_t)i * k + c] : 0.0;
+    d.b = (c < k) ? rhs_at(i) : 0.0;
   };
   auto fstep = [&](int side, int il, int last, const Blk& cur, Blk& nxt, double& pend1, double& pend2)
       __attribute__((always_inline)) {
@@ -216,6 +242,8 @@ penta_apply_kernel(int n, int k, const double* __restrict__ Ust, const double* _
     }
   };
   if (half == 0) {
+    if (jslab && lane < k)   // the block rows above the sub-system: x = rhs = 0 (g_0 = 0, J has no column of q_0)
+      for (int i0 = 0; i0 < R.r0; ++i0) x[(size_t)j * nk + (size_t)(i0 - R.r0) * k + lane] = 0.0;
     backward(0, nT - 1, 0);
   } else {
     wait_flag(1);
