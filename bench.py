@@ -70,32 +70,51 @@ def pmc_traffic(kernel):
     return e["fetch_bytes_per_launch_x2"] + e["write_bytes_per_launch_raw"], os.path.relpath(files[-1], ROOT)
 
 
-def cpu_baseline(model, prob, sp, q, budget_s=18.0):
-    """The CPU oracle (a port of the reference algorithm, OpenMP where the reference has it)
-    timed on this box's host cores on a bounded sample of the same workload."""
-    from oracle_lib import Oracle
-    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
-    best = None
-    notes = []
+def cpu_baseline(config, N, budget_s=20.0):
+    """The CPU oracle (a port of the reference algorithm, OpenMP where the reference has it: TO.cc:209,
+    :476) timed on this box's host cores on a bounded sample of the same workload.  Every leg runs in a
+    process of its own (tools/cpu_baseline.py) so that its OpenMP runtime starts with pinned threads
+    (OMP_PROC_BIND=close, OMP_PLACES=cores) that spin between the parallel regions (OMP_WAIT_POLICY=
+    active): this process already carries torch's OpenMP runtime and an environment that has been read."""
+    import subprocess
     cores = os.cpu_count() or 1
-    # num_threads in {1, 4 (the reference's YAML default), all that the OpenMP loop over t can use}
-    # (BASELINE.md §3 / SURVEY §8d): the reference parallelises over the N timesteps only
-    # (TO.cc:209, :476), so "all" = min(N, cores); the best leg is the baseline
-    legs, rates = sorted({1, min(4, cores), min(prob.num_steps, cores)}), {}
+    # num_threads in {1, 4 (the reference's YAML default), 8, 16, all that the OpenMP loops over t can
+    # use}: the reference parallelises over the N timesteps only, so "all" = min(N, cores); the best leg
+    # is the baseline
+    legs = sorted({1, min(4, cores), min(8, cores), min(16, cores), min(N, cores)})
+    env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores", OMP_WAIT_POLICY="active", OMP_DYNAMIC="false")
+    env.pop("OMP_NUM_THREADS", None)
+    rates, notes, parts1, best = {}, [], None, None
     for nt in legs:
-        sp.num_threads = nt
-        orc = Oracle(model, prob, sp)
-        t1 = orc.time_gn_steps(q, 3)
-        iters = max(5, int(budget_s / len(legs) / t1))
-        t = orc.time_gn_steps(q, iters)
-        notes.append(f"{iters} iterations at num_threads={nt}: {1.0 / t:.1f} it/s")
-        rates[str(nt)] = 1.0 / t
-        if best is None or 1.0 / t > best[0]:
-            best = (1.0 / t, nt)
-    return {"value": best[0], "unit": "GN iters/s", "cores": best[1], "kind": "port",
-            "iters_per_s_by_num_threads": rates,
-            "sample": "same trajectory as the GPU run; " + "; ".join(notes) +
-                      f" (host has {cores} logical cores; the OpenMP loops run over t, so at most N threads work)"}
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--config", config, "--num-steps", str(N),
+               "--threads", str(nt), "--budget", f"{budget_s / len(legs):.2f}"]
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120)
+            leg = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:   # a leg that cannot run is reported, never silently dropped
+            notes.append(f"num_threads={nt}: failed ({type(e).__name__})")
+            continue
+        rates[str(nt)] = leg["iters_per_s"]
+        notes.append(f"{leg['iters']} iterations at num_threads={nt}: {leg['iters_per_s']:.1f} it/s")
+        if nt == 1:
+            parts1 = leg.get("parts_s")
+        if best is None or leg["iters_per_s"] > best[0]:
+            best = (leg["iters_per_s"], nt)
+    if best is None:
+        raise RuntimeError("cpu_baseline: no leg ran: " + "; ".join(notes))
+    out = {"value": best[0], "unit": "GN iters/s", "cores": best[1], "kind": "port",
+           "iters_per_s_by_num_threads": rates,
+           "omp": "one process per leg, OMP_PROC_BIND=close OMP_PLACES=cores OMP_WAIT_POLICY=active",
+           "sample": "same trajectory as the GPU run; " + "; ".join(notes) +
+                     f" (host has {cores} logical cores; the OpenMP loops run over t, so at most N threads work)"}
+    if parts1:
+        # the reference's two parallel loops against what it runs serially: the ceiling of any thread count
+        par = parts1["tau"] + parts1["derivatives"]
+        ser = parts1["assembly"] + parts1["solve"]
+        out["serial_fraction_at_1_thread"] = ser / (par + ser)
+        out["amdahl_ceiling_iters_per_s"] = 1.0 / ser
+        out["seconds_per_iter_at_1_thread"] = parts1
+    return out
 
 
 def full_iteration(cfg, model, N, device, with_cpu, iters=20):
@@ -394,7 +413,7 @@ def main():
         if batch_extra is not None:
             out["batch_mode"] = batch_extra
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(model, prob, sp, q)
+            out["cpu_baseline"] = cpu_baseline(args.config, N)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         if world == 1 and not args.no_full:
             out["full_iteration"] = full_iteration(cfg, model, N, local_rank, not args.no_cpu)

@@ -988,6 +988,13 @@ SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solu
   Check(idto_hip_eval_tau(hip_));
   double cost = Fetch(IDTO_ARR_COST)[0];
   const int scal = params_.scaling ? static_cast<int>(params_.scaling_method) : -1;
+  // the adaptive scalings' memory of D belongs to the state (TO.cc:1241-1255 reads the cached scale
+  // factors): ones for a fresh state, the last solve's for a warm start - never the context's leftovers
+  const bool adaptive = scal == static_cast<int>(kAdaptiveSqrt) || scal == static_cast<int>(kAdaptiveDoubleSqrt);
+  if (adaptive) {
+    const Vec& Dmem = state.cache_.scale_factors;
+    Check(idto_hip_tr_set_scale_memory(hip_, (int)Dmem.size() == num_vars() ? Dmem.data() : nullptr));
+  }
   if (params_.verbose) {
     std::printf("-------------------------------------------------------------------------------------\n");
     std::printf("|  iter  |   cost   |    Δ    |    ρ    |  time (s)  |  |g|/cost  |    dL_dq   |    |h|     |\n");
@@ -1113,6 +1120,7 @@ SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solu
     ws->dqH = Fetch(IDTO_ARR_TR_W);
     for (double& x : ws->dqH) x = -x;   // dqH = Delta pH = -w (:2152)
   }
+  if (adaptive && k > 0) state.cache_.scale_factors = Fetch(IDTO_ARR_TR_SCALE);   // (kept across set_q: invalidate_cache)
   resident_ = nullptr;   // the device arrays were advanced without the host-side cache
   device_level_ = 0;
   stats->solve_time = std::chrono::duration<double>(clock::now() - start_time).count();

@@ -5,6 +5,7 @@
 // entry point fails with a negative status.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdio>
@@ -873,11 +874,25 @@ static int PlanLdl(idto_hip_ctx* c, bool one_sided, LdlPlan* p) {
 // Nested dissection (penta_nd.h): seven workgroups - two producer / joiner pairs, two spike
 // workgroups, the separator.  Its factors are not what penta_apply_kernel walks, so it serves the
 // single-right-hand-side solves only (the Gauss-Newton step).
+// separator in the middle; in each half the joiner chain (next to the separator) gets the extra row
+struct NdSplit { int s, j1, j2; };
+static NdSplit nd_split(int n) {
+  NdSplit sp;
+  sp.s = (n - 2) / 2;
+  const int htop = sp.s, hbot = n - sp.s - 2;
+  sp.j1 = (htop - 2) / 2;                          // producer P0: rows 0 .. j1-1
+  sp.j2 = n - (hbot - 2) / 2 - 2;                  // producer P3: rows j2+2 .. n-1
+  return sp;
+}
 static bool NdEligible(const idto_hip_ctx* c, const LdlPlan& p) {
   const bool inst = (p.K == 2 || p.K == 3 || p.K == 5 || p.K == 19 || p.K == 23) && p.K == p.k;
   // (seven workgroups per problem, one per CU: a batch that would not fit the 256 CUs at once is
   // better served by the two-workgroup form - same work per problem on fewer CUs)
-  return c->solver_nd && c->two_sided && inst && p.n >= 24 && 7 * c->batch <= 256;
+  if (!(c->solver_nd && c->two_sided && inst && p.n >= 24 && 7 * c->batch <= 256)) return false;
+  // the joiner chains' per-row tables hold ND_MAXROWS local rows: longer horizons (n >= 127) take the
+  // two-workgroup factorisation
+  NdSplit sp = nd_split(p.n);
+  return std::max(sp.s - sp.j1, sp.j2 - sp.s) <= ND_MAXROWS;
 }
 static int NdLds(const idto_hip_ctx* c, const LdlPlan& p, int nloc_max) {
   const int ks = ldl_ks(p.K), NF = 2 * p.K, KP = 4 * ((p.K + 3) / 4);
@@ -892,11 +907,7 @@ static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double s
   A.HA = c->HA + p.qq0; A.HB = c->HB + p.qq0; A.HC = c->HC + p.qq0;
   A.b = b + (size_t)p.r0 * p.k; A.rhs_sign = sign; A.x = xo + (size_t)p.r0 * p.k;
   A.Ust = c->Ust; A.Hst = c->Hst; A.Est = c->Est; A.Dst = c->Dst;
-  // separator in the middle; in each half the joiner chain (next to the separator) gets the extra row
-  A.s = (p.n - 2) / 2;
-  const int htop = A.s, hbot = p.n - A.s - 2;
-  A.j1 = (htop - 2) / 2;                          // producer P0: rows 0 .. j1-1
-  A.j2 = p.n - (hbot - 2) / 2 - 2;                // producer P3: rows j2+2 .. n-1
+  { const NdSplit sp = nd_split(p.n); A.s = sp.s; A.j1 = sp.j1; A.j2 = sp.j2; }
   const int nloc_max = std::max(A.s - A.j1, A.j2 - A.s);
   if (nloc_max > ND_MAXROWS) { g_err = "horizon too long for the nested-dissection solver's row tables"; return -1; }
   const int lds = NdLds(c, p, nloc_max);
@@ -1309,6 +1320,18 @@ static int EnqueuePrepare(idto_hip_ctx* c, int scaling_method, int with_lambda) 
   return 0;
 }
 
+int idto_hip_tr_set_scale_memory(idto_hip_ctx* c, const double* D_prev_host) {
+  HIP_OK(hipSetDevice(c->device));
+  if (c->batch != 1) { g_err = "tr_set_scale_memory serves single-problem contexts"; return -1; }
+  const size_t n = (size_t)(c->N + 1) * c->nq;
+  std::vector<double> ones;
+  if (!D_prev_host) { ones.assign(n, 1.0); D_prev_host = ones.data(); }
+  c->spec_ready = false;   // (a speculative tr_prepare used the previous memory)
+  HIP_OK(hipMemcpyAsync(c->tr_Dprev, D_prev_host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_OK(hipStreamSynchronize(c->stream));   // (the host buffer may be a temporary)
+  return 0;
+}
+
 int idto_hip_tr_prepare(idto_hip_ctx* c, int scaling_method, int with_lambda, double* out_host) {
   HIP_OK(hipSetDevice(c->device));
   if (c->batch != 1) { g_err = "tr_prepare serves single-problem contexts"; return -1; }
@@ -1426,6 +1449,10 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
   }
   c->spec_pending = false; c->spec_ready = false; c->trial_resident = false;
   const int n = (c->N + 1) * c->nq, nblk = c->N + 1;
+  // tr_iter_kernel finds its last workgroup by counter == target: both restart with every solve, so that a
+  // launch that failed in an earlier solve cannot leave them out of step
+  HIP_OK(hipMemsetAsync(c->tr_cnt, 0, sizeof(unsigned long long), c->stream));
+  c->tr_target = 0;
   // state: [Delta, L(q) (resident: the caller evaluated the cost of q), ...]
   for (int i = 0; i < TRS_COUNT; ++i) c->tr_pin[i] = 0.0;
   c->tr_pin[TRS_DELTA] = Delta0;
@@ -1555,6 +1582,17 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
     }                                                                                 \
   } while (0)
 
+// the RCCL that got loaded must have the major version of the headers this library was compiled with
+static int CommVersionOk() {
+  int v = 0;
+  NCCL_OK(ncclGetVersion(&v));
+  const int major_rt = v / 10000, major_ct = NCCL_VERSION_CODE / 10000;
+  if (major_rt != major_ct) {
+    g_err = "librccl version mismatch: compiled against " + std::to_string(NCCL_VERSION_CODE) + ", loaded " + std::to_string(v);
+    return -1;
+  }
+  return 0;
+}
 static int CommAttach(idto_hip_ctx* c, ncclComm_t comm, int rank, int world) {
   if (c->batch != 1) { g_err = "the sharded iteration serves single-problem contexts"; return -1; }
   if (world < 1 || world > IDTO_SLAB_PAD || rank < 0 || rank >= world) { g_err = "bad rank / world size"; return -1; }
@@ -1565,6 +1603,7 @@ static int CommAttach(idto_hip_ctx* c, ncclComm_t comm, int rank, int world) {
 }
 
 int idto_hip_comm_unique_id(char* id_out, int bytes) {
+  if (int rc = CommVersionOk()) return rc;
   if (!id_out || bytes < (int)sizeof(ncclUniqueId)) { g_err = "comm_unique_id: buffer of at least 128 bytes required"; return -1; }
   ncclUniqueId id;
   NCCL_OK(ncclGetUniqueId(&id));
@@ -1575,6 +1614,7 @@ int idto_hip_comm_unique_id(char* id_out, int bytes) {
 int idto_hip_comm_init(idto_hip_ctx* c, const char* unique_id, int rank, int world) {
   HIP_OK(hipSetDevice(c->device));
   if (c->comm) { g_err = "comm_init: the context already belongs to a communicator"; return -1; }
+  if (int rc = CommVersionOk()) return rc;
   ncclUniqueId id;
   std::memcpy(&id, unique_id, sizeof id);
   ncclComm_t comm = nullptr;
@@ -1589,6 +1629,7 @@ int idto_hip_comm_init_all(idto_hip_ctx** ctxs, int n) {
     if (ctxs[i]->comm) { g_err = "comm_init_all: a context already belongs to a communicator"; return -1; }
     devs[i] = ctxs[i]->device;
   }
+  if (int rc = CommVersionOk()) return rc;
   std::vector<ncclComm_t> comms(n, nullptr);
   NCCL_OK(ncclCommInitAll(comms.data(), n, devs.data()));
   for (int i = 0; i < n; ++i)
@@ -1659,7 +1700,24 @@ int idto_hip_gn_step_multi(idto_hip_ctx** ctxs, int n) {
   return 0;
 }
 
+// Which RCCL the process resolved: libidto_hip.so is linked against /opt/rocm/lib/librccl.so.1, but a host
+// process that imported torch first has torch's bundled copy loaded under the same soname.  Both are fine
+// as long as the major version is the one this library was compiled against: checked where a communicator is
+// created (CommVersionOk), reported here for the bench line.
+int idto_hip_rccl_info(char* path_out, int path_cap, int* version_out) {
+  int v = 0;
+  NCCL_OK(ncclGetVersion(&v));
+  if (version_out) *version_out = v;
+  if (path_out && path_cap > 0) {
+    Dl_info info;
+    const char* p = (dladdr(reinterpret_cast<void*>(&ncclAllGather), &info) && info.dli_fname) ? info.dli_fname : "?";
+    std::snprintf(path_out, (size_t)path_cap, "%s", p);
+  }
+  return 0;
+}
+
 int idto_hip_get_option(idto_hip_ctx* c, const char* name, int* value) {
+  if (std::strcmp(name, "rccl_version") == 0) { return idto_hip_rccl_info(nullptr, 0, value); }
   if (std::strcmp(name, "last_solver") == 0) { *value = c->last_solver; return 0; }
   if (std::strcmp(name, "solver_nd") == 0) { *value = c->solver_nd; return 0; }
   if (std::strcmp(name, "asm_fold") == 0) { *value = c->asm_fold; return 0; }

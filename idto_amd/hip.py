@@ -63,6 +63,7 @@ def lib():
         L.idto_hip_tr_solve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                         C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.idto_hip_tr_reject.argtypes = [C.c_void_p]
+        L.idto_hip_tr_set_scale_memory.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.idto_hip_set_unactuated_dofs.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
         L.idto_hip_destroy.argtypes = [C.c_void_p]
         L.idto_hip_set_problem.argtypes = [C.c_void_p, C.POINTER(CProblem)]
@@ -111,8 +112,8 @@ EXPORTED_SYMBOLS = [
     "idto_hip_device_ptr", "idto_hip_array_size", "idto_hip_slab_stride", "idto_hip_math_probe",
     "idto_hip_solver_status", "idto_hip_create_batch", "idto_hip_batch_size", "idto_hip_set_problem_batch",
     "idto_hip_set_q_batch", "idto_hip_gn_step_batch", "idto_hip_get_batch", "idto_hip_solver_status_batch",
-    "idto_hip_tr_prepare", "idto_hip_tr_trial", "idto_hip_tr_accept", "idto_hip_tr_reject", "idto_hip_tr_solve", "idto_hip_set_unactuated_dofs",
-    "idto_hip_comm_unique_id", "idto_hip_comm_init", "idto_hip_comm_init_all", "idto_hip_comm_destroy",
+    "idto_hip_tr_prepare", "idto_hip_tr_trial", "idto_hip_tr_accept", "idto_hip_tr_reject", "idto_hip_tr_set_scale_memory", "idto_hip_tr_solve", "idto_hip_set_unactuated_dofs",
+    "idto_hip_rccl_info", "idto_hip_comm_unique_id", "idto_hip_comm_init", "idto_hip_comm_init_all", "idto_hip_comm_destroy",
     "idto_hip_allgather_slab", "idto_hip_gn_step_sharded", "idto_hip_gn_step_multi", "idto_hip_eval_partials_multi",
 ]
 
@@ -236,6 +237,13 @@ class HipPath:
 
     def tr_reject(self):
         _chk(lib().idto_hip_tr_reject(self.h))
+
+    def tr_set_scale_memory(self, D_prev=None):
+        """the adaptive scalings' previous D (None: ones, a fresh state)"""
+        if D_prev is None:
+            _chk(lib().idto_hip_tr_set_scale_memory(self.h, None))
+        else:
+            _chk(lib().idto_hip_tr_set_scale_memory(self.h, dptr(np.ascontiguousarray(D_prev, dtype=np.float64))))
 
     def tr_solve(self, iterations: int, scaling_method: int, scaling: bool, normalize_quaternions: bool, Delta0: float,
                  Delta_max: float, eta: float = 0.0, constrained_dofs=()):
@@ -391,6 +399,14 @@ class HipPath:
         if name == "cost":
             return float(out[0])
         return out
+
+
+def rccl_info():
+    """(path of the librccl this process resolved, its version code)"""
+    buf, ver = C.create_string_buffer(1024), C.c_int(0)
+    lib().idto_hip_rccl_info.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+    _chk(lib().idto_hip_rccl_info(buf, 1024, C.byref(ver)))
+    return buf.value.decode(), int(ver.value)
 
 
 def comm_unique_id() -> bytes:

@@ -135,6 +135,10 @@ int idto_hip_set_shard(idto_hip_ctx* ctx, int k_begin, int k_end);
  * eval_partials (own range) + idto_hip_allgather_slab + grad_hess + factor_solve, all enqueued on
  * the context's stream. */
 int idto_hip_comm_unique_id(char* id_out, int bytes /* >= 128 */);
+/* The RCCL the process resolved (a host that loaded torch first carries torch's bundled librccl under the
+ * same soname): file path and ncclGetVersion() code.  Forming a communicator fails with an error naming both
+ * versions when the loaded library's major version is not the one this library was compiled against. */
+int idto_hip_rccl_info(char* path_out, int path_cap, int* version_out);
 int idto_hip_comm_init(idto_hip_ctx* ctx, const char* unique_id, int rank, int world);
 int idto_hip_comm_init_all(idto_hip_ctx** ctxs, int n);
 int idto_hip_comm_destroy(idto_hip_ctx* ctx);
@@ -222,6 +226,11 @@ int idto_hip_tr_trial(idto_hip_ctx* ctx, double a, double b, int scaling, int no
                       int speculate_scaling_method, double* out_host /* [4] */);
 int idto_hip_tr_accept(idto_hip_ctx* ctx);
 int idto_hip_tr_reject(idto_hip_ctx* ctx);
+/* The adaptive scalings (kAdaptiveSqrt / kAdaptiveDoubleSqrt, reference optimizer/trajectory_optimizer.cc:1241-1255)
+ * take the minimum of the new scale factors and the previous ones, which the reference keeps in the state's
+ * cache: ones in a fresh state (`Solve`), the last solve's in a WarmStart (`SolveFromWarmStart`).  This sets
+ * that memory: D_prev_host[(N+1)*nq], or NULL for ones.  After a solve IDTO_ARR_TR_SCALE holds the last D. */
+int idto_hip_tr_set_scale_memory(idto_hip_ctx* ctx, const double* D_prev_host);
 
 /* The whole trust-region loop without the host (reference optimizer/trajectory_optimizer.cc:2495-2625
  * for the case the stepwise calls above serve: no enforced constraints, no convergence checks).

@@ -333,6 +333,37 @@ double orc_time_gn_steps(void* hv, const double* q, int iters) {
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / iters;
 }
 
+// Where one Gauss-Newton step's time goes (bench.py's cpu_baseline only): seconds per step spent in
+// [0] tau (OpenMP loop over t, TO.cc:209), [1] derivatives (the finite-difference loop, OpenMP over t,
+// TO.cc:476, plus the serial N+ / velocity partials), [2] gradient + Hessian assembly (serial),
+// [3] factor + solve (serial).  The reference parallelises [0] and [1] only: the rest is its Amdahl floor.
+int orc_time_gn_parts(void* hv, const double* q, int iters, double* parts) {
+  return Guard([&] {
+    Optimizer& o = static_cast<Handle*>(hv)->opt;
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    for (int k = 0; k < 4; ++k) parts[k] = 0.0;
+    for (int i = 0; i < iters; ++i) {
+      State s = MakeState(o, q);
+      const auto t0 = clk::now();
+      o.EvalTau(s);
+      const auto t1 = clk::now();
+      o.EvalDerivatives(s);
+      const auto t2 = clk::now();
+      const Vec& g = o.EvalGradient(s);
+      const PentaMatrix& H = o.EvalHessian(s);
+      const auto t3 = clk::now();
+      Vec p(g.size());
+      for (size_t j = 0; j < g.size(); ++j) p[j] = -g[j];
+      PentaFactorization Hlu(H);
+      Hlu.SolveInPlace(p.data());
+      const auto t4 = clk::now();
+      parts[0] += secs(t0, t1); parts[1] += secs(t1, t2); parts[2] += secs(t2, t3); parts[3] += secs(t3, t4);
+    }
+    for (int k = 0; k < 4; ++k) parts[k] /= iters;
+  });
+}
+
 // ---- block penta-diagonal algebra (penta_diagonal_solver_test.cc) ------------
 static PentaMatrix MakePenta(int n, int bs, const double* A, const double* B, const double* C, const double* D,
                              const double* E) {

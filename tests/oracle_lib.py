@@ -244,6 +244,12 @@ class Oracle:
     def time_gn_steps(self, q, iters):
         return self.lib.orc_time_gn_steps(self.h, dptr(_d(q)), int(iters))
 
+    def time_gn_parts(self, q, iters):
+        """seconds per Gauss-Newton step in [tau, derivatives, assembly, factor + solve]"""
+        parts = np.zeros(4)
+        self._chk(self.lib.orc_time_gn_parts(self.h, dptr(_d(q)), int(iters), dptr(parts)))
+        return dict(zip(("tau", "derivatives", "assembly", "solve"), parts.tolist()))
+
 
 # ---- block penta-diagonal helpers; blocks given as [blk, row, col] ---------------
 def _cm(b):

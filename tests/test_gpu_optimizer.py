@@ -152,6 +152,33 @@ def test_warm_start_equivalence():
     assert np.array_equal(ws.get_q(), sol.q)
 
 
+@pytest.mark.parametrize("constrained", [False, True])
+def test_adaptive_scaling_memory_belongs_to_the_state(constrained):
+    """The adaptive scalings take min(previous D, new D) (TO.cc:1241-1255) and the previous D lives in the
+    state: a second Solve on the same optimizer starts from ones again (identical statistics, and the
+    oracle's), while warm starts carry it over (ten one-iteration warm starts == one ten-iteration Solve)."""
+    cfg, model = load_config("spinner"), load_model("spinner")
+    prob, sp, q_guess = make_problem(cfg, model)
+    sp.max_iterations, sp.verbose, sp.scaling, sp.scaling_method = 8, False, True, "adaptive_double_sqrt"
+    sp.equality_constraints = constrained
+    ref = Oracle(model, prob, sp).solve(q_guess)["stats"]
+    opt = TrajectoryOptimizer(model, prob, sp)
+    sol1, st1, _ = solve(opt, q_guess)
+    sol2, st2, _ = solve(opt, q_guess)
+    assert np.array_equal(st1.iteration_costs, st2.iteration_costs) and np.array_equal(sol1.q, sol2.q)
+    assert np.array_equal(st1.trust_region_radii, st2.trust_region_radii)
+    assert np.allclose(st1.iteration_costs, ref.iteration_costs, rtol=1e-6)
+    sp1 = SolverParameters(**{**sp.__dict__, "max_iterations": 1})
+    o1 = TrajectoryOptimizer(model, prob, sp1)
+    ws = o1.CreateWarmStart(q_guess)
+    costs = []
+    for _ in range(8):
+        sol, st = TrajectoryOptimizerSolution(), TrajectoryOptimizerStats()
+        o1.SolveFromWarmStart(ws, sol, st)
+        costs.append(st.iteration_costs[0])
+    assert np.allclose(costs, st1.iteration_costs, rtol=0, atol=1e-8)
+
+
 def test_reset_initial_conditions():  # python_bindings/test/warm_start_test.py:119-139
     model, prob, sp, q_guess = spinner_python_test_problem()
     sp.max_iterations = 2
