@@ -70,6 +70,25 @@ def pmc_traffic(kernel):
     return e["fetch_bytes_per_launch_x2"] + e["write_bytes_per_launch_raw"], os.path.relpath(files[-1], ROOT)
 
 
+def host_cpu_limit():
+    """CPUs this process may use: logical cores, affinity mask, CFS quota of the container (cgroup v2 cpu.max
+    or v1 cpu.cfs_quota_us / cpu.cfs_period_us; None = unlimited)."""
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    return {"logical_cores": os.cpu_count() or 1, "affinity": len(os.sched_getaffinity(0)), "cfs_quota_cpus": quota}
+
+
 def cpu_baseline(config, N, budget_s=20.0):
     """The CPU oracle (a port of the reference algorithm, OpenMP where the reference has it: TO.cc:209,
     :476) timed on this box's host cores on a bounded sample of the same workload.  Every leg runs in a
@@ -78,10 +97,14 @@ def cpu_baseline(config, N, budget_s=20.0):
     active): this process already carries torch's OpenMP runtime and an environment that has been read."""
     import subprocess
     cores = os.cpu_count() or 1
+    limit = host_cpu_limit()
+    usable = max(1, min(cores, limit["affinity"], int(limit["cfs_quota_cpus"]) if limit["cfs_quota_cpus"] else cores))
     # num_threads in {1, 4 (the reference's YAML default), 8, 16, all that the OpenMP loops over t can
     # use}: the reference parallelises over the N timesteps only, so "all" = min(N, cores); the best leg
     # is the baseline
-    legs = sorted({1, min(4, cores), min(8, cores), min(16, cores), min(N, cores)})
+    # ("cores" = what this process may actually use: its affinity mask and the container's CFS quota - spinning
+    # threads beyond the quota are throttled and run slower than one thread)
+    legs = sorted({1, min(4, usable), min(8, usable), min(16, usable), min(N, usable)})
     env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores", OMP_WAIT_POLICY="active", OMP_DYNAMIC="false")
     env.pop("OMP_NUM_THREADS", None)
     rates, notes, parts1, best = {}, [], None, None
@@ -105,8 +128,9 @@ def cpu_baseline(config, N, budget_s=20.0):
     out = {"value": best[0], "unit": "GN iters/s", "cores": best[1], "kind": "port",
            "iters_per_s_by_num_threads": rates,
            "omp": "one process per leg, OMP_PROC_BIND=close OMP_PLACES=cores OMP_WAIT_POLICY=active",
+           "host_cpu_limit": limit,
            "sample": "same trajectory as the GPU run; " + "; ".join(notes) +
-                     f" (host has {cores} logical cores; the OpenMP loops run over t, so at most N threads work)"}
+                     f" (host has {cores} logical cores, {usable} usable by this process; the OpenMP loops run over t, so at most N threads work)"}
     if parts1:
         # the reference's two parallel loops against what it runs serially: the ceiling of any thread count
         par = parts1["tau"] + parts1["derivatives"]

@@ -43,8 +43,9 @@ def main():
     sp.num_threads = args.threads
     q = synthetic_trajectory(cfg, model, args.num_steps, seed=args.seed, lower=0.01)
     orc = Oracle(model, prob, sp)
-    t1 = orc.time_gn_steps(q, 3)                      # warm-up (thread pool, caches)
-    iters = max(5, int(args.budget / t1))
+    orc.time_gn_steps(q, 2)                           # warm-up (thread pool, caches)
+    t1 = orc.time_gn_steps(q, 5)
+    iters = max(5, min(2000, int(args.budget / t1)))
     t = orc.time_gn_steps(q, iters)
     # where one step's time goes: the two OpenMP loops (tau, finite differences) against the serial
     # rest (N+, v, a, assembly, factor + solve) -- the Amdahl ceiling of the reference's parallelisation
