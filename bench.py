@@ -401,6 +401,8 @@ def main():
         names = list(KERNELS)
         if dev.get_option("last_solver") == 2:   # nested dissection over seven workgroups (csrc/penta_nd.h)
             names[2] = "penta_nd_kernel"
+        elif dev.get_option("last_solver") == 4:   # ... with pipelined chains, five workgroups (csrc/penta_pipe.h)
+            names[2] = "penta_pipe_kernel"
         if dev.get_option("last_assembly") == 1:   # products formed by fd_kernel, combined here (kernels.h)
             names[1] = "assemble_terms_kernel"
         dur_s = kern[dom][0] * 1e-3

@@ -52,18 +52,26 @@ __device__ __forceinline__ void fused_signal(unsigned long long* cnt) {
 // Polling is RELAXED (a load that reaches the agent-coherent level, no cache invalidation per
 // poll) with `nap` x 64 cycles between polls; one acquire, then the barrier publishes it to the
 // other wavefronts of the workgroup (they share the CU's vector L1, which the acquire invalidated).
-__device__ __forceinline__ void fused_wait(unsigned long long* cnt, unsigned long long target, bool many) {
+__device__ __forceinline__ void fused_wait(unsigned long long* cnt, unsigned long long target, bool many, const SpinCtl sc) {
   if (threadIdx.x == 0) {
-    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      if (many) __builtin_amdgcn_s_sleep(8);
-      else __builtin_amdgcn_s_sleep(1);
-    }
+    // (bounded: penta_ldl.h spin_wait; `many` pollers nap longer between polls)
+    spin_wait([&] {
+      if (many) __builtin_amdgcn_s_sleep(7);
+      return __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
+    }, sc);
     (void)__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
 }
 __device__ __forceinline__ void fused_stamp(double* dbg, int slot) {
   if (dbg && threadIdx.x == 0) dbg[blockIdx.x * 4 + slot] = (double)wall_clock64();
+}
+
+// (single-problem launch: the word a wait that ran out reports to sits behind the problem's two status words)
+__device__ __forceinline__ ChainCfg fused_chain_cfg(const FusedArgs& A, int side) {
+  ChainCfg c = two_sided_cfg(A.n, A.m_split, side);
+  c.spin = SpinCtl{A.status + 2, A.fact_id};
+  return c;
 }
 
 template <int MAXC, int K, bool PADDED, int GJW>
@@ -78,16 +86,16 @@ __global__ void __launch_bounds__(256) gn_fused_kernel(FusedArgs A) {
     fused_stamp(A.dbg, 2);
   } else if (bx < A.nfd + nasm) {
     const int idx = bx - A.nfd;
-    fused_wait(A.sync, A.fd_target, true);
+    fused_wait(A.sync, A.fd_target, true, SpinCtl{A.status + 2, A.fact_id});
     fused_stamp(A.dbg, 1);
     assemble_diag_body(A.M, A.P, A.q, A.slab, A.slab_stride, A.g, A.HA, A.HB, A.HC, 0, A.v, A.nplus, idx >> 2, idx & 3);
     fused_signal(A.sync + 1);
     fused_stamp(A.dbg, 2);
   } else {
-    fused_wait(A.sync + 1, A.asm_target, false);
+    fused_wait(A.sync + 1, A.asm_target, false, SpinCtl{A.status + 2, A.fact_id});
     fused_stamp(A.dbg, 1);
     penta_ldl_body<K, 256, PADDED, GJW>(A.n, A.k, A.sHA, A.sHB, A.sHC, A.b, A.rhs_sign, 1, A.x, A.Ust, A.Hst, A.Est,
-                                        A.Dst, nullptr, two_sided_cfg(A.n, A.m_split, bx - A.nfd - nasm), A.xch, A.flags,
+                                        A.Dst, nullptr, fused_chain_cfg(A, bx - A.nfd - nasm), A.xch, A.flags,
                                         A.epoch, A.status, A.fact_id);
     fused_stamp(A.dbg, 2);
   }

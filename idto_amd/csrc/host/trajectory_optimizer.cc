@@ -226,10 +226,16 @@ namespace {
 struct FactorizationFailedError : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
+// IDTO_HIP_SOLVER_TIMEOUT: a multi-workgroup solver launch did not find its partner workgroups resident (a
+// device shared with other kernels); the context has stepped down to a safer variant and the solve is repeated.
+struct SolverTimeoutError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
 }  // namespace
 
 void TO::Check(int rc) const {
   if (rc == IDTO_HIP_FACTORIZATION_FAILED) throw FactorizationFailedError(std::string("idto_hip: ") + idto_hip_last_error());
+  if (rc == IDTO_HIP_SOLVER_TIMEOUT) throw SolverTimeoutError(std::string("idto_hip: ") + idto_hip_last_error());
   if (rc != 0) throw std::runtime_error(std::string("idto_hip: ") + idto_hip_last_error());
 }
 
@@ -944,11 +950,21 @@ SolverFlag TO::SolveWithLinesearch(const std::vector<VectorXd>& q_guess, Traject
 // TO.cc:2449-2651
 SolverFlag TO::SolveFromWarmStart(WarmStart* ws, TrajectoryOptimizerSolution<T>* solution,
                                   TrajectoryOptimizerStats<T>* stats, ConvergenceReason* reason_out) const {
-  try {
-    return SolveFromWarmStartImpl(ws, solution, stats, reason_out);
-  } catch (const FactorizationFailedError& e) {
-    if (params_.verbose) std::printf("FACTORIZATION FAILED\n%s\n", e.what());
-    return SolverFlag::kFactorizationFailed;
+  for (int attempt = 0;; ++attempt) {
+    try {
+      return SolveFromWarmStartImpl(ws, solution, stats, reason_out);
+    } catch (const FactorizationFailedError& e) {
+      if (params_.verbose) std::printf("FACTORIZATION FAILED\n%s\n", e.what());
+      return SolverFlag::kFactorizationFailed;
+    } catch (const SolverTimeoutError& e) {
+      // (the warm start's state is only advanced by completed iterations: run again from it, on the variant
+      // the context has stepped down to - at most once per variant that can time out)
+      if (attempt >= 4) throw;
+      if (params_.verbose) std::printf("%s\n", e.what());
+      *stats = TrajectoryOptimizerStats<T>();
+      resident_ = nullptr;
+      device_level_ = 0;
+    }
   }
 }
 

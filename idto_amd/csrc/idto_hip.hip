@@ -20,6 +20,7 @@
 #include "penta_ldl.h"
 #include "fused.h"
 #include "penta_nd.h"
+#include "penta_pipe.h"
 #include "penta_apply.h"
 #include "constraints.h"
 #include "dense_ldl.h"
@@ -98,7 +99,13 @@ struct idto_hip_ctx {
   bool two_sided = true;                  // solver: two workgroups eliminating from both ends
   bool fused = true;                      // gn_step: one persistent launch (fused.h) when eligible
   bool solver_nd = true;                  // solver: nested dissection over 7 workgroups (penta_nd.h) when eligible
+  bool solver_pipe = true;                // ... with pipelined chains (penta_pipe.h: 5 workgroups) when the block size allows
   unsigned long long* nd_rowcnt = nullptr; // its per-row release counters, buffers and launch count
+  unsigned long long* pipe_rowcnt = nullptr;   // the same for the pipelined variant (its own launch count: the two
+  unsigned long long pipe_launches = 0;        // variants release a row with different increments)
+  int solver_timeouts = 0;                // launches whose waits between workgroups ran out (FactorStatus)
+  int last_step_kind = 0;                 // what produced IDTO_ARR_STEP last: 1 factor_solve of -g, 2 the fused launch, 0 other
+  int debug_skip_role = -1;               // test aid: a role of the nested-dissection kernels that returns at once
   double* nd_buf = nullptr;
   unsigned long long nd_launches = 0;
   int last_solver = 0;                     // 0 none yet, 1 two-workgroup LDL^T, 2 nested dissection, 3 reference LU
@@ -432,6 +439,20 @@ int EnsureStage(idto_hip_ctx* c, size_t count) {
 // (problem `pb` of the batch, or any of them for pb < 0)
 int FactorStatus(idto_hip_ctx* c, int pb = -1) {
   const volatile unsigned* st = c->status_pin;
+  if (c->fact_id != 0 && st[2 * c->batch] == c->fact_id) {
+    // A wait between the workgroups of a multi-workgroup solver ran out: its partners were not resident at the
+    // same time (other contexts' kernels on the device).  The result of that launch is garbage.  Step down to a
+    // variant with fewer co-resident workgroups for the rest of the context's life; the caller repeats the solve
+    // (idto_hip_get(STEP) and idto_hip_tr_prepare do it themselves).
+    if (c->solver_pipe && c->last_solver == 4) c->solver_pipe = false;
+    else if (c->solver_nd && (c->last_solver == 2 || c->last_solver == 4)) c->solver_nd = false;
+    else if (c->fused && c->last_solver == 5) c->fused = false;
+    else if (c->two_sided) { c->solver_nd = false; c->fused = false; c->two_sided = false; }
+    ++c->solver_timeouts;
+    g_err = "a solver launch timed out waiting for a partner workgroup (device shared with other kernels); the "
+            "context has stepped down to a variant with fewer co-resident workgroups: repeat the call";
+    return IDTO_HIP_SOLVER_TIMEOUT;
+  }
   bool any = false;
   for (int b = (pb < 0 ? 0 : pb); b < (pb < 0 ? c->batch : pb + 1); ++b) any = any || st[2 * b] == c->fact_id;
   if (c->fact_id != 0 && any) {
@@ -530,6 +551,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   c->xch_count = 2 * (size_t)(3 * 32 + 1) * ldl_ks(32) + 2 * 32;
   const size_t o_xch = carve(2 * c->xch_count, D);   // (two producer / joiner pairs in the nested-dissection kernel)
   const size_t o_ndcnt = carve(4 * ND_MAXROWS, sizeof(unsigned long long)), o_ndbuf = carve((size_t)nd_layout(32).end, D);
+  const size_t o_pipecnt = carve(4 * ND_MAXROWS, sizeof(unsigned long long));
   c->flag_count = 16;
   const size_t o_flags = carve(c->flag_count, sizeof(unsigned)), o_sync = carve(2, sizeof(unsigned long long));
   const size_t nvars = (size_t)(N + 1) * nq;
@@ -564,6 +586,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   c->flags = reinterpret_cast<unsigned*>(c->arena + o_flags);
   c->sync_cnt = reinterpret_cast<unsigned long long*>(c->arena + o_sync);
   c->nd_rowcnt = reinterpret_cast<unsigned long long*>(c->arena + o_ndcnt);
+  c->pipe_rowcnt = reinterpret_cast<unsigned long long*>(c->arena + o_pipecnt);
   c->nd_buf = dp(o_ndbuf);
   c->tr_D = dp(o_trD); c->tr_gt = dp(o_trg); c->tr_w = dp(o_trw); c->tr_dq = dp(o_trdq); c->q_trial = dp(o_qt);
   c->tr_out = dp(o_trout); c->tr_Dprev = dp(o_trDp); c->tr_part = dp(o_trpart);
@@ -592,13 +615,15 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
     rc = UploadProblemArrays(c, problems + b, b);
     if (rc) { idto_hip_destroy(c); return rc; }
   }
-  if (hipHostMalloc((void**)&c->status_pin, 2 * (size_t)batch * sizeof(unsigned), hipHostMallocDefault) != hipSuccess ||
+  // per problem [id of the last failed factorisation, count]; behind them [id of the last launch in which a
+  // wait between workgroups ran out, count] (penta_ldl.h spin_wait)
+  if (hipHostMalloc((void**)&c->status_pin, (2 * (size_t)batch + 2) * sizeof(unsigned), hipHostMallocDefault) != hipSuccess ||
       hipHostGetDevicePointer((void**)&c->status_dev, c->status_pin, 0) != hipSuccess) {
     g_err = "hipHostMalloc (solver status) failed";
     idto_hip_destroy(c);
     return -2;
   }
-  for (int i = 0; i < 2 * batch; ++i) c->status_pin[i] = 0;
+  for (int i = 0; i < 2 * batch + 2; ++i) c->status_pin[i] = 0;
   c->k_begin = 0; c->k_end = N;
 
   // launch geometry
@@ -652,6 +677,9 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
 #define ND_ATTR(KM, PD) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_nd_kernel<KM, PD>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   ND_ATTR(2, false) ND_ATTR(3, false) ND_ATTR(5, false) ND_ATTR(19, false) ND_ATTR(23, false)
 #undef ND_ATTR
+#define PIPE_ATTR(KM) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_pipe_kernel<KM>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  PIPE_ATTR(2) PIPE_ATTR(3) PIPE_ATTR(5) PIPE_ATTR(19)
+#undef PIPE_ATTR
 #define FUSED_ATTR(MC, KM, PD, GW)                                                                 \
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_fused_kernel<MC, KM, PD, GW>),       \
                             hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -662,6 +690,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   if (const char* e = getenv("IDTO_TWO_SIDED")) c->two_sided = (e[0] == '1');   // (debugging aids: option defaults)
   if (const char* e = getenv("IDTO_FUSED")) c->fused = (e[0] == '1');
   if (const char* e = getenv("IDTO_SOLVER_ND")) c->solver_nd = (e[0] == '1');
+  if (const char* e = getenv("IDTO_SOLVER_PIPE")) c->solver_pipe = (e[0] == '1');
   if (const char* e = getenv("IDTO_ASM_FOLD")) c->asm_fold = (e[0] == '1');
   (void)hipGetLastError();
   *out = c;
@@ -903,6 +932,8 @@ static int NdLds(const idto_hip_ctx* c, const LdlPlan& p, int nloc_max) {
 }
 static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double sign, double* xo) {
   NdArgs A;
+  A.debug_skip_role = c->debug_skip_role;
+  A.spin = SpinCtl{nullptr, 0};   // (set by the kernel: behind the per-problem status words)
   A.n = p.n; A.k = p.k;
   A.HA = c->HA + p.qq0; A.HB = c->HB + p.qq0; A.HC = c->HC + p.qq0;
   A.b = b + (size_t)p.r0 * p.k; A.rhs_sign = sign; A.x = xo + (size_t)p.r0 * p.k;
@@ -913,6 +944,39 @@ static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double s
   const int lds = NdLds(c, p, nloc_max);
   if (lds > 160 * 1024) { g_err = "nested-dissection solver: LDS carve-up too large"; return -1; }
   A.xch = c->xch; A.xch_pair = (int)c->xch_count; A.flags = c->flags;
+  if (c->solver_pipe && p.K <= 20) {
+    // pipelined chains (penta_pipe.h): five workgroups of eight wavefronts, the joiners carry their spike columns
+    int plds = 0;
+    switch (p.K) {
+      case 2: plds = pipe_layout<2>(p.n, true).end; break;
+      case 3: plds = pipe_layout<3>(p.n, true).end; break;
+      case 5: plds = pipe_layout<5>(p.n, true).end; break;
+      default: plds = pipe_layout<19>(p.n, true).end; break;
+    }
+    const int sep = (2 * (2 * p.K + 1) * (2 * p.K + 1) + 2 + (2 * p.K + 1) * ldl_ks(p.K) + (p.K + 1) * ldl_ks(p.K) +
+                     2 * p.K * ldl_ks(p.K) + p.K * ldl_ks(p.K) + 6 * ldl_ks(p.K)) * (int)sizeof(double);
+    plds = std::max(plds * (int)sizeof(double), sep);
+    if (plds > 160 * 1024) { g_err = "pipelined solver: LDS carve-up too large"; return -1; }
+    A.rowcnt = c->pipe_rowcnt; A.ndbuf = c->nd_buf;
+    ++c->pipe_launches;
+    c->last_solver = 4;
+    A.rowunit = 1ull; A.rowtarget = c->pipe_launches;
+    ++c->epoch;
+    if (++c->fact_id == 0) c->fact_id = 1;
+    A.epoch = c->epoch; A.status = c->status_dev; A.fact_id = c->fact_id; A.pstride = c->pstride;
+    A.ts = c->solver_debug ? c->dbg : nullptr;
+    const dim3 pgrid(5, c->batch);
+#define PIPE_LAUNCH(KM) hipLaunchKernelGGL((penta_pipe_kernel<KM>), pgrid, dim3(512), plds, c->stream, A)
+    switch (p.K) {
+      case 2: PIPE_LAUNCH(2); break;
+      case 3: PIPE_LAUNCH(3); break;
+      case 5: PIPE_LAUNCH(5); break;
+      default: PIPE_LAUNCH(19); break;
+    }
+#undef PIPE_LAUNCH
+    HIP_OK(hipGetLastError());
+    return 0;
+  }
   A.rowcnt = c->nd_rowcnt; A.ndbuf = c->nd_buf;
   ++c->nd_launches;
   c->last_solver = 2;
@@ -1029,6 +1093,8 @@ static int LaunchFused(idto_hip_ctx* c) {
   A.fd_target = c->sync_steps * (unsigned long long)A.nfd;
   A.asm_target = c->sync_steps * (unsigned long long)(4 * A.nrows);
   const dim3 grid(A.nfd + 4 * A.nrows + (p.m_split > 0 ? 2 : 1));
+  c->last_solver = 5;
+  c->last_step_kind = 2;
   if (TimeBegin(c, 3)) return -2;
 #define FUSED_LAUNCH(MC, KM, PD, GW) \
   hipLaunchKernelGGL((gn_fused_kernel<MC, KM, PD, GW>), grid, dim3(256), lds, c->stream, A)
@@ -1063,6 +1129,7 @@ static int FactorSolve(idto_hip_ctx* c, const double* rhs, int nrhs, double* x, 
   if (nrhs < 1) { g_err = "nrhs < 1"; return -1; }
   if (rhs && c->batch != 1) { g_err = "explicit right-hand sides serve single-problem contexts"; return -1; }
   if (TimeBegin(c, 2)) return -2;
+  c->last_step_kind = rhs ? 0 : 1;
   if (c->reference_solver) {
     c->last_solver = 3;
     if (++c->fact_id == 0) c->fact_id = 1;
@@ -1720,6 +1787,8 @@ int idto_hip_get_option(idto_hip_ctx* c, const char* name, int* value) {
   if (std::strcmp(name, "rccl_version") == 0) { return idto_hip_rccl_info(nullptr, 0, value); }
   if (std::strcmp(name, "last_solver") == 0) { *value = c->last_solver; return 0; }
   if (std::strcmp(name, "solver_nd") == 0) { *value = c->solver_nd; return 0; }
+  if (std::strcmp(name, "solver_pipe") == 0) { *value = c->solver_pipe; return 0; }
+  if (std::strcmp(name, "solver_timeouts") == 0) { *value = c->solver_timeouts; return 0; }
   if (std::strcmp(name, "asm_fold") == 0) { *value = c->asm_fold; return 0; }
   if (std::strcmp(name, "last_assembly") == 0) { *value = c->last_assembly; return 0; }
   if (std::strcmp(name, "fused") == 0) { *value = c->fused; return 0; }
@@ -1736,6 +1805,8 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "two_sided") == 0) { c->two_sided = value != 0; return 0; }
   if (std::strcmp(name, "fused") == 0) { c->fused = value != 0; return 0; }
   if (std::strcmp(name, "solver_nd") == 0) { c->solver_nd = value != 0; return 0; }
+  if (std::strcmp(name, "solver_pipe") == 0) { c->solver_pipe = value != 0; return 0; }
+  if (std::strcmp(name, "debug_skip_role") == 0) { c->debug_skip_role = value; return 0; }   // test aid
   if (std::strcmp(name, "asm_fold") == 0) { c->asm_fold = value != 0; c->terms_valid = false; return 0; }
   if (std::strcmp(name, "fused_debug") == 0) { c->fused_debug = value != 0; return 0; }
   if (std::strcmp(name, "asm_stop") == 0) { c->asm_stop = value; return 0; }  // profiling aid
@@ -1907,7 +1978,18 @@ int idto_hip_get_batch(idto_hip_ctx* c, int what, int pb, double* out) {
   }
   void* p = DevPtr(c, what);
   HIP_OK(hipMemcpy(out, at_problem(static_cast<char*>(p), po), (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
-  return (what == IDTO_ARR_STEP) ? FactorStatus(c, pb) : 0;
+  if (what != IDTO_ARR_STEP) return 0;
+  int fs = FactorStatus(c, pb);
+  // a launch whose waits between workgroups ran out: FactorStatus has stepped the context down, the Gauss-Newton
+  // step is computed again (at most once per variant that can time out)
+  for (int attempt = 0; fs == IDTO_HIP_SOLVER_TIMEOUT && attempt < 4 && c->last_step_kind != 0; ++attempt) {
+    const int rc = (c->last_step_kind == 2) ? idto_hip_gn_step(c) : idto_hip_factor_solve(c, nullptr, 1, nullptr);
+    if (rc) return rc;
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpy(out, at_problem(static_cast<char*>(p), po), (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+    fs = FactorStatus(c, pb);
+  }
+  return fs;
 }
 
 int idto_hip_solver_status(idto_hip_ctx* c, int* failed, int* failed_rows_total) {

@@ -69,6 +69,37 @@ __device__ __forceinline__ double fast_rcp(double d) {
   return x;
 }
 
+// ---- bounded waits between workgroups.  The multi-workgroup solvers (two-sided, nested dissection, the
+// pipelined chains, the fused Gauss-Newton launch) synchronise through flags in global memory and need their
+// partners resident at the same time - true by head-count on an otherwise idle device, not by construction
+// when other contexts' kernels occupy compute units.  Every such wait gives up after SPIN_LIMIT_TICKS of the
+// 100 MHz wall clock and reports it in host-mapped memory ([0] = id of the launch, [1] = count); the kernel
+// then runs to its end on whatever it has, and the host (FactorStatus in idto_hip.hip) repeats the solve on a
+// variant with fewer workgroups.  Nothing can hang the device.
+constexpr long long SPIN_LIMIT_TICKS = 5000000;   // 50 ms
+struct SpinCtl { unsigned* word; unsigned id; };
+template <class Ready>
+__device__ __forceinline__ bool spin_wait(Ready ready, const SpinCtl sc) {
+  unsigned n = 0;
+  long long t0 = 0;
+  while (!ready()) {
+    __builtin_amdgcn_s_sleep(1);
+    if (((++n) & 1023u) == 0) {
+      if (sc.word && __hip_atomic_load(sc.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == sc.id) return false;   // somebody gave up already
+      const long long now = (long long)wall_clock64();
+      if (t0 == 0) t0 = now;
+      else if (now - t0 > SPIN_LIMIT_TICKS) {
+        if (sc.word) {
+          __hip_atomic_store(sc.word, sc.id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_fetch_add(sc.word + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return false;
+      }
+    }
+  }
+  return true;
+}
+
 // One pivot step (J is a template parameter so that v_writelane can take the lane as an inline
 // constant).  The pivots d_J are wave-uniform (SGPR pairs); lane J keeps its own with v_writelane
 // (2 instructions per pivot, no compare/select chain) and inverts it once at the end.
@@ -191,9 +222,266 @@ struct ChainCfg {
   double* ts;                       // optional wall-clock stamps (100 MHz): start, join reached, forward done, backward start, end
   int factor_only;                  // stop once the factors are in HBM: every right-hand side (the first included) goes
                                     // through penta_apply_kernel, the chains' own back substitution is off the path
+  SpinCtl spin;                     // where a wait between workgroups that ran out reports it
 };
 __device__ __forceinline__ void chain_ts(const ChainCfg& cfg, int slot) {
   if (cfg.ts && threadIdx.x == 0) cfg.ts[slot] = (double)wall_clock64();
+}
+
+// ---- what follows the forward elimination of a chain (shared by penta_ldl_body and the pipelined forward pass of
+// penta_pipe.h): the nested-dissection correction of rt by the separator's solution, then the back substitution.
+// On entry: the chain's factors are in HBM (Ust / Hst / Est row-major with stride ks, rows scaled by 1/d; Dst = 1/d),
+// rt_il (raw) of every local row in lds[xall_off + (il + 2) * ks + r] with two leading zero rows, and a block-wide
+// barrier has ordered both; `W_off` is LDS scratch of at least 2K doubles.
+template <int K, int NT>
+__device__ __forceinline__ void
+penta_ldl_tail(int n, int k, int nrhs, double* __restrict__ x, const double* __restrict__ Ust,
+               const double* __restrict__ Hst, const double* __restrict__ Est, const double* __restrict__ Dst,
+               double* __restrict__ dbg, const ChainCfg cfg, double* __restrict__ xch, unsigned* __restrict__ flags,
+               unsigned epoch, int xall_off, int bl_size, int W_off, int nfwd) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool two = cfg.two != 0, mirror = cfg.mirror != 0, producer = cfg.producer != 0;
+  const int m_split = cfg.m_split, nloc = cfg.nloc;
+  auto orig = [&](int il) { const int o = mirror ? cfg.base - il : cfg.base + il; return o < 0 ? 0 : o; };
+  constexpr int nt = NT, ks = ldl_ks(K), NW = NT / 64;
+  const int ncr = 2 * K + nrhs;
+  const size_t nk = (size_t)n * k;
+  double* Wm = lds + W_off;
+  auto stamp = [&](int i, int ph) {
+    if (dbg && lane == 0)
+      dbg[((cfg.dbg_slot * (NT / 64) + wave) * (n + 3) + i) * 8 + ph] = (double)__builtin_readcyclecounter();
+  };
+  if (cfg.fst) {
+    // nested dissection: this chain's rows also couple to the separator.  Once it is solved,
+    // rt_il -= Ft_il [x_near ; x_far] with the eliminated coupling blocks Ft_il the spike workgroup
+    // left in HBM (columns 0..K-1: the separator row next to this chain's first row).  The rows of
+    // Ft are fetched while the separator is still being eliminated (this workgroup is idle then).
+    const int pidx = (tid < nloc * K) ? tid : 0, pil = pidx / K, pr = pidx - pil * K;
+    spin_wait([&] { return __hip_atomic_load(cfg.frowcnt + pil, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= cfg.frowtarget; }, cfg.spin);
+    (void)__hip_atomic_load(cfg.frowcnt + pil, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    double f[2 * K];
+    {
+      const double* F = cfg.fst + (size_t)pil * cfg.fstride + pr;
+#pragma unroll
+      for (int c = 0; c < 2 * K; ++c) f[c] = F[c * ks];
+    }
+    if (tid == 0)
+      spin_wait([&] { return __hip_atomic_load(cfg.sepflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch; }, cfg.spin);
+    __syncthreads();
+    (void)__hip_atomic_load(cfg.sepflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    double* xs = Wm;   // (the augmented block is free between the passes)
+    for (int c = tid; c < 2 * K; c += nt) {
+      const int half = c / K, r = c - half * K;
+      xs[c] = cfg.xsep[(mirror ? half : 1 - half) * K + r];   // mirrored chain: nearest = s, else nearest = s + 1
+    }
+    __syncthreads();
+    if (tid < nloc * K) {
+      double acc = 0.0;
+#pragma unroll
+      for (int c = 0; c < 2 * K; ++c) acc = __builtin_fma(f[c], xs[c], acc);
+      lds[xall_off + (pil + 2) * ks + pr] -= acc;
+    }
+    for (int idx = tid + nt; idx < nloc * K; idx += nt) {   // (more rows than threads: the rest, unprefetched)
+      const int il = idx / K, r = idx - il * K;
+      const double* F = cfg.fst + (size_t)il * cfg.fstride + r;
+      double acc = 0.0;
+#pragma unroll
+      for (int c = 0; c < 2 * K; ++c) acc = __builtin_fma(F[c * ks], xs[c], acc);
+      lds[xall_off + (il + 2) * ks + r] -= acc;
+    }
+    __syncthreads();
+  }
+  chain_ts(cfg, 3);
+
+  if (cfg.factor_only) return;
+  // ---- backward pass: (D_i^-1 U_i) x_i = D_i^-1 rt_i - (D_i^-1 Ht_i) x_{i+1} - (D_i^-1 Et_i) x_{i+2}
+  // One wavefront per right-hand side, no LDS staging and no barrier: lane = row r (+32 for the
+  // second half).  The first half holds row r of D^-1 Ht_i, the second half row r of D^-1 Et_i,
+  // both halves row r of the unit upper triangular D^-1 U_i (strict upper part; rows are
+  // 16-byte loads straight from HBM, prefetched one block row ahead in a second register set).
+  // x_{i+1}, x_{i+2} are wave-uniform (the back substitution produces each x_j by v_readlane).
+  constexpr int KS2 = K * ks, KP = (K + 1) / 2;
+  const int r_ = lane & 31, half_ = lane >> 5;
+  const int rr = (r_ < K) ? r_ : 0;
+  const bool live = r_ < K && half_ == 0;
+  if (nrhs == 1 && bl_size) {
+    // ---- single right-hand side: "push" form.  While the triangular solve of block row i yields
+    // x_i one component per step (v_readlane + FMA, ~30 cycles of dependent latency), each
+    // component is pushed at once into the pending right-hand sides of rows i-1 (through
+    // D^-1 Ht_{i-1}) and i-2 (through D^-1 Et_{i-2}): no separate mat-vec phase, no wave-uniform
+    // copy of x.  One accumulator per lane:
+    //   lanes  0..31 (row r): acc = rhs of row i (the chain), FMA with D^-1 U_i;  w2 -= Et_{i-2}[r][j] x_j
+    //   lanes 32..63 (row r): acc = rhs of row i-1,           FMA with D^-1 Ht_{i-1}
+    // (the same instruction serves both halves), operands prefetched one block row ahead.
+    if (wave == 0) {
+      auto rowsA = [&](int i, double2 (&A)[KP]) {  // lower: U_i row r ; upper: Ht_{i-1} row r
+        const int t = half_ ? i - 1 : i;
+        if (t < 0) {
+#pragma unroll
+          for (int m = 0; m < KP; ++m) A[m] = make_double2(0.0, 0.0);
+          return;
+        }
+        const double2* a = reinterpret_cast<const double2*>((half_ ? Hst : Ust) + (size_t)orig(t) * KS2 + rr * ks);
+#pragma unroll
+        for (int m = KP - 1; m >= 0; --m) A[m] = a[m];
+      };
+      auto rowsE = [&](int i, double2 (&E)[KP], double& w2init) {  // lower: Et_{i-2} row r and D^-1 rt_{i-2}
+        const int t = i - 2;
+        w2init = 0.0;
+        if (t < 0 || half_) {
+#pragma unroll
+          for (int m = 0; m < KP; ++m) E[m] = make_double2(0.0, 0.0);
+          return;
+        }
+        const double2* e = reinterpret_cast<const double2*>(Est + (size_t)orig(t) * KS2 + rr * ks);
+#pragma unroll
+        for (int m = KP - 1; m >= 0; --m) E[m] = e[m];
+        w2init = Dst[(size_t)orig(t) * K + rr] * lds[xall_off + (t + 2) * ks + rr];
+      };
+      auto dvrt = [&](int t) {
+        return (t < 0) ? 0.0 : Dst[(size_t)orig(t) * K + rr] * lds[xall_off + (t + 2) * ks + rr];
+      };
+      auto swap_halves = [&](double a) {  // value held by lane (l ^ 32)
+        const unsigned lo = (unsigned)__double2loint(a), hi = (unsigned)__double2hiint(a);
+        const auto slo = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto shi = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        return half_ ? __hiloint2double((int)shi[0], (int)slo[0]) : __hiloint2double((int)shi[1], (int)slo[1]);
+      };
+      double* xjoin = xch + 2 * (size_t)(K + ncr) * ks;  // [2][K]: x_m, x_{m+1}
+      double acc = half_ ? dvrt(nloc - 2) : dvrt(nloc - 1);
+      if (two && producer) {
+        // x_{nloc} (= row m+1) and x_{nloc+1} (= row m) come from the top workgroup: their pushes
+        if (lane == 0)
+          spin_wait([&] { return __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch; }, cfg.spin);
+        (void)__hip_atomic_load(flags + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        const double X0 = xjoin[K + rr], X1 = xjoin[rr];  // lane r: component r of x_{nloc}, x_{nloc+1}
+        const double* h1 = Hst + (size_t)orig(nloc - 1) * KS2 + rr * ks;
+        const double* e1 = Est + (size_t)orig(nloc - 1) * KS2 + rr * ks;
+        const double* e2 = Est + (size_t)orig(nloc >= 2 ? nloc - 2 : 0) * KS2 + rr * ks;
+        double vv = 0.0, ww = 0.0;
+        for (int jj = 0; jj < K; ++jj) {
+          const double x0 = rdlane(X0, jj), x1 = rdlane(X1, jj);
+          vv = __builtin_fma(e1[jj], x1, vv);
+          vv = __builtin_fma(h1[jj], x0, vv);
+          ww = __builtin_fma(e2[jj], x0, ww);
+        }
+        acc -= half_ ? ((nloc >= 2) ? ww : 0.0) : vv;
+      }
+      double2 A0[KP], E0[KP], A1[KP], E1[KP];
+      double wi0 = 0.0, wi1 = 0.0;
+      auto solve = [&](int i, const double2 (&A)[KP], const double2 (&E)[KP], double w2) {
+#pragma unroll
+        for (int jj = K - 1; jj >= 0; --jj) {
+          const double xj = rdlane(acc, jj);  // x_i[jj]: final once the steps above it are done
+          const double ajj = (jj & 1) ? A[jj / 2].y : A[jj / 2].x;
+          const double ejj = (jj & 1) ? E[jj / 2].y : E[jj / 2].x;
+          acc = __builtin_fma(-ajj, xj, acc);  // (U strictly upper: rows >= jj keep their value)
+          w2 = __builtin_fma(-ejj, xj, w2);
+        }
+        if (live) {
+          lds[xall_off + (i + 2) * ks + r_] = acc;
+          if (two && !producer && i >= m_split) xjoin[(size_t)(i - m_split) * K + r_] = acc;
+        }
+        if (two && !producer && i == m_split) {  // rows m+1 and m are solved: release the other workgroup
+          __threadfence();
+          if (lane == 0) __hip_atomic_store(flags + 1, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // rotate: the lower half continues with the upper half's rhs (row i-1), the upper half
+        // takes over the lower half's w2 (row i-2)
+        acc = swap_halves(half_ ? acc : w2);
+      };
+      rowsA(nloc - 1, A0); rowsE(nloc - 1, E0, wi0);
+      for (int i = nloc - 1; i >= 0; i -= 2) {
+        rowsA(i - 1, A1); rowsE(i - 1, E1, wi1);
+        solve(i, A0, E0, wi0);
+        if (i - 1 >= 0) {
+          rowsA(i - 2, A0); rowsE(i - 2, E0, wi0);
+          solve(i - 1, A1, E1, wi1);
+        }
+      }
+    }
+  } else
+  for (int j = wave; j < nrhs; j += NW) {
+    double xs1[2 * KP], xs2[2 * KP];  // x_{i+1}, x_{i+2}, wave-uniform
+#pragma unroll
+    for (int c = 0; c < 2 * KP; ++c) { xs1[c] = 0.0; xs2[c] = 0.0; }
+    double2 A0[KP], U0[KP], A1[KP], U1[KP];
+    double dv0 = 1.0, dv1 = 1.0, rt0 = 0.0, rt1 = 0.0;
+    double* xjoin = xch + 2 * (size_t)(K + ncr) * ks;  // [nrhs][2][K]: x_m, x_{m+1}
+    auto load_row = [&](int i, double2 (&A)[KP], double2 (&U)[KP], double& dv, double& rtv) {
+      if (i < 0) return;
+      const size_t io = (size_t)orig(i);
+      const double2* a = reinterpret_cast<const double2*>((half_ ? Est : Hst) + io * KS2 + rr * ks);
+      const double2* u = reinterpret_cast<const double2*>(Ust + io * KS2 + rr * ks);
+#pragma unroll
+      for (int m = 0; m < KP; ++m) { A[m] = a[m]; U[m] = u[m]; }
+      dv = Dst[io * K + rr];
+      rtv = bl_size ? lds[xall_off + (j * (n + 2) + i + 2) * ks + rr]
+                      : ((rr < k) ? x[(size_t)j * nk + io * k + rr] : 0.0);
+    };
+    // xa = x_{i+1}, xb = x_{i+2}; x_i overwrites xb (roles swap from row to row: no copies)
+    auto solve_row = [&](int i, const double2 (&A)[KP], const double2 (&U)[KP], double dv, double rtv,
+                         double (&xa)[2 * KP], double (&xb)[2 * KP]) {
+      double acca = 0.0, accb = 0.0;  // both products per lane (uniform operands), one select after
+#pragma unroll
+      for (int m = 0; m < KP; ++m) {
+        acca = __builtin_fma(A[m].x, xa[2 * m], acca);
+        acca = __builtin_fma(A[m].y, xa[2 * m + 1], acca);
+        accb = __builtin_fma(A[m].x, xb[2 * m], accb);
+        accb = __builtin_fma(A[m].y, xb[2 * m + 1], accb);
+      }
+      double acc = half_ ? accb : acca;
+      acc += __shfl_xor(acc, 32);
+      double v = __builtin_fma(rtv, dv, -acc);
+#pragma unroll
+      for (int jj = K - 1; jj >= 0; --jj) {
+        const double xj = rdlane(v, jj);
+        xb[jj] = xj;
+        const double ujj = (jj & 1) ? U[jj / 2].y : U[jj / 2].x;
+        v = __builtin_fma(-ujj, xj, v);   // U is strictly upper: lanes >= jj keep their value
+      }
+      if (live) {
+        if (bl_size) lds[xall_off + (j * (n + 2) + i + 2) * ks + r_] = v;
+        else if (r_ < k) x[(size_t)j * nk + (size_t)orig(i) * k + r_] = v;
+        // the join rows' solution is what the other workgroup's back substitution starts from
+        if (two && !producer && i >= m_split) xjoin[(size_t)(j * 2 + (i - m_split)) * K + r_] = v;
+      }
+    };
+    if (two && producer) {
+      // x of local rows nloc (= row m+1) and nloc+1 (= row m) come from the top workgroup
+      if (lane == 0)
+        spin_wait([&] { return __hip_atomic_load(flags + 1 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch; }, cfg.spin);
+      (void)__hip_atomic_load(flags + 1 + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int c = 0; c < K; ++c) {
+        xs1[c] = rdlane(xjoin[(size_t)(j * 2 + 1) * K + c], 0);  // wave-uniform: keep them in SGPRs
+        xs2[c] = rdlane(xjoin[(size_t)(j * 2 + 0) * K + c], 0);
+      }
+    }
+    load_row(nloc - 1, A0, U0, dv0, rt0);
+    for (int i = nloc - 1; i >= 0; i -= 2) {
+      load_row(i - 1, A1, U1, dv1, rt1);
+      solve_row(i, A0, U0, dv0, rt0, xs1, xs2);       // x_i -> xs2
+      if (i - 1 >= 0) {
+        load_row(i - 2, A0, U0, dv0, rt0);
+        solve_row(i - 1, A1, U1, dv1, rt1, xs2, xs1);  // x_{i-1} -> xs1 ; then xs1 = x_{i-1}, xs2 = x_i
+      }
+      if (two && !producer && i == nloc - 1) {  // rows m+1 and m are solved: release the other workgroup
+        __threadfence();
+        if (lane == 0) __hip_atomic_store(flags + 1 + j, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  __syncthreads();
+  if (bl_size) {
+    for (int idx = tid; idx < nrhs * nloc * k; idx += nt) {
+      const int j = idx / (nloc * k), rem = idx - j * (nloc * k), i = rem / k, r = rem - i * k;
+      x[(size_t)j * nk + (size_t)orig(i) * k + r] = lds[xall_off + (j * (n + 2) + i + 2) * ks + r];
+    }
+  }
+  stamp(nfwd, 1);
+  chain_ts(cfg, 4);
 }
 
 // K = compile-time block size >= k; the k x k blocks are embedded in K x K ones padded with
@@ -528,8 +816,7 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
       if (i == m_split) {
         chain_ts(cfg, 1);
         if (tid == 0)
-          while (__hip_atomic_load(flags, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch)
-            __builtin_amdgcn_s_sleep(2);
+          spin_wait([&] { return __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch; }, cfg.spin);
         __syncthreads();
         (void)__hip_atomic_load(flags, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);  // every wavefront acquires
         chain_ts(cfg, 5);
@@ -709,238 +996,7 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
   }
   stamp(nfwd, 0);
   chain_ts(cfg, 2);
-  if (cfg.fst) {
-    // nested dissection: this chain's rows also couple to the separator.  Once it is solved,
-    // rt_il -= Ft_il [x_near ; x_far] with the eliminated coupling blocks Ft_il the spike workgroup
-    // left in HBM (columns 0..K-1: the separator row next to this chain's first row).  The rows of
-    // Ft are fetched while the separator is still being eliminated (this workgroup is idle then).
-    const int pidx = (tid < nloc * K) ? tid : 0, pil = pidx / K, pr = pidx - pil * K;
-    while (__hip_atomic_load(cfg.frowcnt + pil, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cfg.frowtarget) __builtin_amdgcn_s_sleep(2);
-    (void)__hip_atomic_load(cfg.frowcnt + pil, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-    double f[2 * K];
-    {
-      const double* F = cfg.fst + (size_t)pil * cfg.fstride + pr;
-#pragma unroll
-      for (int c = 0; c < 2 * K; ++c) f[c] = F[c * ks];
-    }
-    if (tid == 0)
-      while (__hip_atomic_load(cfg.sepflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
-    __syncthreads();
-    (void)__hip_atomic_load(cfg.sepflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-    double* xs = Wm;   // (the augmented block is free between the passes)
-    for (int c = tid; c < 2 * K; c += nt) {
-      const int half = c / K, r = c - half * K;
-      xs[c] = cfg.xsep[(mirror ? half : 1 - half) * K + r];   // mirrored chain: nearest = s, else nearest = s + 1
-    }
-    __syncthreads();
-    if (tid < nloc * K) {
-      double acc = 0.0;
-#pragma unroll
-      for (int c = 0; c < 2 * K; ++c) acc = __builtin_fma(f[c], xs[c], acc);
-      lds[L.xall + (pil + 2) * ks + pr] -= acc;
-    }
-    for (int idx = tid + nt; idx < nloc * K; idx += nt) {   // (more rows than threads: the rest, unprefetched)
-      const int il = idx / K, r = idx - il * K;
-      const double* F = cfg.fst + (size_t)il * cfg.fstride + r;
-      double acc = 0.0;
-#pragma unroll
-      for (int c = 0; c < 2 * K; ++c) acc = __builtin_fma(F[c * ks], xs[c], acc);
-      lds[L.xall + (il + 2) * ks + r] -= acc;
-    }
-    __syncthreads();
-  }
-  chain_ts(cfg, 3);
-
-  if (cfg.factor_only) return;
-  // ---- backward pass: (D_i^-1 U_i) x_i = D_i^-1 rt_i - (D_i^-1 Ht_i) x_{i+1} - (D_i^-1 Et_i) x_{i+2}
-  // One wavefront per right-hand side, no LDS staging and no barrier: lane = row r (+32 for the
-  // second half).  The first half holds row r of D^-1 Ht_i, the second half row r of D^-1 Et_i,
-  // both halves row r of the unit upper triangular D^-1 U_i (strict upper part; rows are
-  // 16-byte loads straight from HBM, prefetched one block row ahead in a second register set).
-  // x_{i+1}, x_{i+2} are wave-uniform (the back substitution produces each x_j by v_readlane).
-  constexpr int KS2 = K * ks, KP = (K + 1) / 2;
-  const int r_ = lane & 31, half_ = lane >> 5;
-  const int rr = (r_ < K) ? r_ : 0;
-  const bool live = r_ < K && half_ == 0;
-  if (nrhs == 1 && L.bl_size) {
-    // ---- single right-hand side: "push" form.  While the triangular solve of block row i yields
-    // x_i one component per step (v_readlane + FMA, ~30 cycles of dependent latency), each
-    // component is pushed at once into the pending right-hand sides of rows i-1 (through
-    // D^-1 Ht_{i-1}) and i-2 (through D^-1 Et_{i-2}): no separate mat-vec phase, no wave-uniform
-    // copy of x.  One accumulator per lane:
-    //   lanes  0..31 (row r): acc = rhs of row i (the chain), FMA with D^-1 U_i;  w2 -= Et_{i-2}[r][j] x_j
-    //   lanes 32..63 (row r): acc = rhs of row i-1,           FMA with D^-1 Ht_{i-1}
-    // (the same instruction serves both halves), operands prefetched one block row ahead.
-    if (wave == 0) {
-      auto rowsA = [&](int i, double2 (&A)[KP]) {  // lower: U_i row r ; upper: Ht_{i-1} row r
-        const int t = half_ ? i - 1 : i;
-        if (t < 0) {
-#pragma unroll
-          for (int m = 0; m < KP; ++m) A[m] = make_double2(0.0, 0.0);
-          return;
-        }
-        const double2* a = reinterpret_cast<const double2*>((half_ ? Hst : Ust) + (size_t)orig(t) * KS2 + rr * ks);
-#pragma unroll
-        for (int m = KP - 1; m >= 0; --m) A[m] = a[m];
-      };
-      auto rowsE = [&](int i, double2 (&E)[KP], double& w2init) {  // lower: Et_{i-2} row r and D^-1 rt_{i-2}
-        const int t = i - 2;
-        w2init = 0.0;
-        if (t < 0 || half_) {
-#pragma unroll
-          for (int m = 0; m < KP; ++m) E[m] = make_double2(0.0, 0.0);
-          return;
-        }
-        const double2* e = reinterpret_cast<const double2*>(Est + (size_t)orig(t) * KS2 + rr * ks);
-#pragma unroll
-        for (int m = KP - 1; m >= 0; --m) E[m] = e[m];
-        w2init = Dst[(size_t)orig(t) * K + rr] * lds[L.xall + (t + 2) * ks + rr];
-      };
-      auto dvrt = [&](int t) {
-        return (t < 0) ? 0.0 : Dst[(size_t)orig(t) * K + rr] * lds[L.xall + (t + 2) * ks + rr];
-      };
-      auto swap_halves = [&](double a) {  // value held by lane (l ^ 32)
-        const unsigned lo = (unsigned)__double2loint(a), hi = (unsigned)__double2hiint(a);
-        const auto slo = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-        const auto shi = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-        return half_ ? __hiloint2double((int)shi[0], (int)slo[0]) : __hiloint2double((int)shi[1], (int)slo[1]);
-      };
-      double* xjoin = xch + 2 * (size_t)(K + ncr) * ks;  // [2][K]: x_m, x_{m+1}
-      double acc = half_ ? dvrt(nloc - 2) : dvrt(nloc - 1);
-      if (two && producer) {
-        // x_{nloc} (= row m+1) and x_{nloc+1} (= row m) come from the top workgroup: their pushes
-        if (lane == 0)
-          while (__hip_atomic_load(flags + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch)
-            __builtin_amdgcn_s_sleep(2);
-        (void)__hip_atomic_load(flags + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-        const double X0 = xjoin[K + rr], X1 = xjoin[rr];  // lane r: component r of x_{nloc}, x_{nloc+1}
-        const double* h1 = Hst + (size_t)orig(nloc - 1) * KS2 + rr * ks;
-        const double* e1 = Est + (size_t)orig(nloc - 1) * KS2 + rr * ks;
-        const double* e2 = Est + (size_t)orig(nloc >= 2 ? nloc - 2 : 0) * KS2 + rr * ks;
-        double vv = 0.0, ww = 0.0;
-        for (int jj = 0; jj < K; ++jj) {
-          const double x0 = rdlane(X0, jj), x1 = rdlane(X1, jj);
-          vv = __builtin_fma(e1[jj], x1, vv);
-          vv = __builtin_fma(h1[jj], x0, vv);
-          ww = __builtin_fma(e2[jj], x0, ww);
-        }
-        acc -= half_ ? ((nloc >= 2) ? ww : 0.0) : vv;
-      }
-      double2 A0[KP], E0[KP], A1[KP], E1[KP];
-      double wi0 = 0.0, wi1 = 0.0;
-      auto solve = [&](int i, const double2 (&A)[KP], const double2 (&E)[KP], double w2) {
-#pragma unroll
-        for (int jj = K - 1; jj >= 0; --jj) {
-          const double xj = rdlane(acc, jj);  // x_i[jj]: final once the steps above it are done
-          const double ajj = (jj & 1) ? A[jj / 2].y : A[jj / 2].x;
-          const double ejj = (jj & 1) ? E[jj / 2].y : E[jj / 2].x;
-          acc = __builtin_fma(-ajj, xj, acc);  // (U strictly upper: rows >= jj keep their value)
-          w2 = __builtin_fma(-ejj, xj, w2);
-        }
-        if (live) {
-          lds[L.xall + (i + 2) * ks + r_] = acc;
-          if (two && !producer && i >= m_split) xjoin[(size_t)(i - m_split) * K + r_] = acc;
-        }
-        if (two && !producer && i == m_split) {  // rows m+1 and m are solved: release the other workgroup
-          __threadfence();
-          if (lane == 0) __hip_atomic_store(flags + 1, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // rotate: the lower half continues with the upper half's rhs (row i-1), the upper half
-        // takes over the lower half's w2 (row i-2)
-        acc = swap_halves(half_ ? acc : w2);
-      };
-      rowsA(nloc - 1, A0); rowsE(nloc - 1, E0, wi0);
-      for (int i = nloc - 1; i >= 0; i -= 2) {
-        rowsA(i - 1, A1); rowsE(i - 1, E1, wi1);
-        solve(i, A0, E0, wi0);
-        if (i - 1 >= 0) {
-          rowsA(i - 2, A0); rowsE(i - 2, E0, wi0);
-          solve(i - 1, A1, E1, wi1);
-        }
-      }
-    }
-  } else
-  for (int j = wave; j < nrhs; j += NW) {
-    double xs1[2 * KP], xs2[2 * KP];  // x_{i+1}, x_{i+2}, wave-uniform
-#pragma unroll
-    for (int c = 0; c < 2 * KP; ++c) { xs1[c] = 0.0; xs2[c] = 0.0; }
-    double2 A0[KP], U0[KP], A1[KP], U1[KP];
-    double dv0 = 1.0, dv1 = 1.0, rt0 = 0.0, rt1 = 0.0;
-    double* xjoin = xch + 2 * (size_t)(K + ncr) * ks;  // [nrhs][2][K]: x_m, x_{m+1}
-    auto load_row = [&](int i, double2 (&A)[KP], double2 (&U)[KP], double& dv, double& rtv) {
-      if (i < 0) return;
-      const size_t io = (size_t)orig(i);
-      const double2* a = reinterpret_cast<const double2*>((half_ ? Est : Hst) + io * KS2 + rr * ks);
-      const double2* u = reinterpret_cast<const double2*>(Ust + io * KS2 + rr * ks);
-#pragma unroll
-      for (int m = 0; m < KP; ++m) { A[m] = a[m]; U[m] = u[m]; }
-      dv = Dst[io * K + rr];
-      rtv = L.bl_size ? lds[L.xall + (j * (n + 2) + i + 2) * ks + rr]
-                      : ((rr < k) ? x[(size_t)j * nk + io * k + rr] : 0.0);
-    };
-    // xa = x_{i+1}, xb = x_{i+2}; x_i overwrites xb (roles swap from row to row: no copies)
-    auto solve_row = [&](int i, const double2 (&A)[KP], const double2 (&U)[KP], double dv, double rtv,
-                         double (&xa)[2 * KP], double (&xb)[2 * KP]) {
-      double acca = 0.0, accb = 0.0;  // both products per lane (uniform operands), one select after
-#pragma unroll
-      for (int m = 0; m < KP; ++m) {
-        acca = __builtin_fma(A[m].x, xa[2 * m], acca);
-        acca = __builtin_fma(A[m].y, xa[2 * m + 1], acca);
-        accb = __builtin_fma(A[m].x, xb[2 * m], accb);
-        accb = __builtin_fma(A[m].y, xb[2 * m + 1], accb);
-      }
-      double acc = half_ ? accb : acca;
-      acc += __shfl_xor(acc, 32);
-      double v = __builtin_fma(rtv, dv, -acc);
-#pragma unroll
-      for (int jj = K - 1; jj >= 0; --jj) {
-        const double xj = rdlane(v, jj);
-        xb[jj] = xj;
-        const double ujj = (jj & 1) ? U[jj / 2].y : U[jj / 2].x;
-        v = __builtin_fma(-ujj, xj, v);   // U is strictly upper: lanes >= jj keep their value
-      }
-      if (live) {
-        if (L.bl_size) lds[L.xall + (j * (n + 2) + i + 2) * ks + r_] = v;
-        else if (r_ < k) x[(size_t)j * nk + (size_t)orig(i) * k + r_] = v;
-        // the join rows' solution is what the other workgroup's back substitution starts from
-        if (two && !producer && i >= m_split) xjoin[(size_t)(j * 2 + (i - m_split)) * K + r_] = v;
-      }
-    };
-    if (two && producer) {
-      // x of local rows nloc (= row m+1) and nloc+1 (= row m) come from the top workgroup
-      if (lane == 0)
-        while (__hip_atomic_load(flags + 1 + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch)
-          __builtin_amdgcn_s_sleep(2);
-      (void)__hip_atomic_load(flags + 1 + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-      for (int c = 0; c < K; ++c) {
-        xs1[c] = rdlane(xjoin[(size_t)(j * 2 + 1) * K + c], 0);  // wave-uniform: keep them in SGPRs
-        xs2[c] = rdlane(xjoin[(size_t)(j * 2 + 0) * K + c], 0);
-      }
-    }
-    load_row(nloc - 1, A0, U0, dv0, rt0);
-    for (int i = nloc - 1; i >= 0; i -= 2) {
-      load_row(i - 1, A1, U1, dv1, rt1);
-      solve_row(i, A0, U0, dv0, rt0, xs1, xs2);       // x_i -> xs2
-      if (i - 1 >= 0) {
-        load_row(i - 2, A0, U0, dv0, rt0);
-        solve_row(i - 1, A1, U1, dv1, rt1, xs2, xs1);  // x_{i-1} -> xs1 ; then xs1 = x_{i-1}, xs2 = x_i
-      }
-      if (two && !producer && i == nloc - 1) {  // rows m+1 and m are solved: release the other workgroup
-        __threadfence();
-        if (lane == 0) __hip_atomic_store(flags + 1 + j, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  }
-  __syncthreads();
-  if (L.bl_size) {
-    for (int idx = tid; idx < nrhs * nloc * k; idx += nt) {
-      const int j = idx / (nloc * k), rem = idx - j * (nloc * k), i = rem / k, r = rem - i * k;
-      x[(size_t)j * nk + (size_t)orig(i) * k + r] = lds[L.xall + (j * (n + 2) + i + 2) * ks + r];
-    }
-  }
-  stamp(nfwd, 1);
-  chain_ts(cfg, 4);
+  penta_ldl_tail<K, NT>(n, k, nrhs, x, Ust, Hst, Est, Dst, dbg, cfg, xch, flags, epoch, L.xall, L.bl_size, L.W, nfwd);
 }
 
 // the two roles of the two-workgroup kernel (m_split = 0: one workgroup, the whole system)
@@ -968,6 +1024,7 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
   const size_t o = (size_t)blockIdx.y * pstride;
   ChainCfg cfg = two_sided_cfg(n, m_split, (int)blockIdx.x);
   cfg.factor_only = factor_only;
+  cfg.spin = SpinCtl{status + 2 * gridDim.y, fact_id};   // (behind the per-problem status words)
   penta_ldl_body<K, NT, PADDED, GJW>(n, k, at_problem(HA, o), at_problem(HB, o), at_problem(HC, o), at_problem(b, o),
                                      rhs_sign, nrhs, at_problem(x, o), at_problem(Ust, o), at_problem(Hst, o),
                                      at_problem(Est, o), at_problem(Dst, o), dbg ? at_problem(dbg, o) : nullptr,

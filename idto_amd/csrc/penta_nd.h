@@ -49,6 +49,8 @@ struct NdArgs {
   unsigned* status; unsigned fact_id;
   size_t pstride;
   double* ts;                    // option "solver_debug": [7 roles][64] wall-clock stamps (100 MHz)
+  SpinCtl spin;                  // where a wait between workgroups that ran out reports it (penta_ldl.h spin_wait)
+  int debug_skip_role;           // test aid: this role returns at once (its partners' waits must run out), -1: none
 };
 __device__ __forceinline__ void nd_ts(const NdArgs& A, int role, int slot) {
   if (A.ts && threadIdx.x == 0) A.ts[role * 64 + slot] = (double)wall_clock64();
@@ -71,9 +73,9 @@ __host__ __device__ inline NdBuf nd_layout(int K) {
 __host__ __device__ constexpr int nd_tile_row(int t) { int tr = 0; while (t > tr) { t -= tr + 1; ++tr; } return tr; }
 __host__ __device__ constexpr int nd_tile_col(int t) { int tr = 0; while (t > tr) { t -= tr + 1; ++tr; } return t; }
 
-__device__ __forceinline__ void nd_wait(const unsigned* f, unsigned epoch) {
+__device__ __forceinline__ void nd_wait(const unsigned* f, unsigned epoch, const SpinCtl sc) {
   if (threadIdx.x == 0)
-    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
+    spin_wait([&] { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch; }, sc);
   __syncthreads();
   (void)__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -170,7 +172,7 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
   // (per wavefront, no workgroup barrier: the wavefronts decide independently whether they could
   // prefetch a row, so nothing here may assume that the others take the same path)
   auto wait_row = [&](int il) {
-    while (!row_ready(il)) __builtin_amdgcn_s_sleep(1);
+    spin_wait([&] { return row_ready(il); }, A.spin);
     (void)__hip_atomic_load(rowcnt + il, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
   };
   // [Ft_il | rt_il] -> HBM (row stride B.frow, column stride ks), by the threads [t0, t0 + tn)
@@ -290,7 +292,8 @@ __device__ __forceinline__ void nd_separator(const NdArgs& A) {
   constexpr int ks = ldl_ks(K), NF = 2 * K, NC = NF + 1, CT2 = (NC + 15) / 16, NQT = CT2 * (CT2 + 1) / 2, QS = NC * NC;
   constexpr int SKq = (K + 3) / 4;
   using d4q = __attribute__((ext_vector_type(4))) double;
-  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
+  if (threadIdx.x >= 256) return;    // (penta_pipe_kernel launches 512-thread workgroups: four wavefronts work here)
+  const int tid = threadIdx.x, nt = 256, lane = tid & 63, wave = tid >> 6;
   const int k = A.k, kk = k * k, s = A.s;
   const NdBuf B = nd_layout(K);
   double* Q = lds;                   // [2][QS] dense, both triangles
@@ -329,7 +332,7 @@ __device__ __forceinline__ void nd_separator(const NdArgs& A) {
 #pragma unroll
     for (int t = 0; t < (NQT + 1) / 2; ++t) qacc[t] = d4q{0.0, 0.0, 0.0, 0.0};
     for (int il = 0; il < nloc; ++il) {
-      while (__hip_atomic_load(frow + il, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ftarget) __builtin_amdgcn_s_sleep(1);
+      spin_wait([&] { return __hip_atomic_load(frow + il, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ftarget; }, A.spin);
       (void)__hip_atomic_load(frow + il, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
       const double* F = Fst + (size_t)il * B.frow;
       const double* dg = A.Dst + (size_t)(mirror ? base - il : base + il) * K;
@@ -514,9 +517,11 @@ __global__ void __launch_bounds__(256) penta_nd_kernel(NdArgs A) {
     A.x = at_problem(A.x, o); A.Ust = at_problem(A.Ust, o); A.Hst = at_problem(A.Hst, o); A.Est = at_problem(A.Est, o);
     A.Dst = at_problem(A.Dst, o); A.xch = at_problem(A.xch, o); A.flags = at_problem(A.flags, o);
     A.rowcnt = at_problem(A.rowcnt, o); A.ndbuf = at_problem(A.ndbuf, o);
+    A.spin = SpinCtl{A.status + 2 * gridDim.y, A.fact_id};
     A.status += 2 * blockIdx.y;
   }
   const int role = blockIdx.x;
+  if (role == A.debug_skip_role) return;
   if (role == 6) { nd_separator<K, PADDED>(A); return; }
   if (role >= 4) { nd_spike<K, PADDED>(A, role - 4); return; }
   const NdBuf B = nd_layout(K);
@@ -524,6 +529,7 @@ __global__ void __launch_bounds__(256) penta_nd_kernel(NdArgs A) {
   c.two = 1;
   c.dbg_slot = role;
   c.ts = A.ts ? A.ts + role * 64 : nullptr;
+  c.spin = A.spin;
   int pair;
   if (role == 0) { c.mirror = 0; c.producer = 1; c.base = 0; c.nloc = A.j1; pair = 0; }
   else if (role == 1) { c.mirror = 1; c.producer = 1; c.base = A.n - 1; c.nloc = A.n - A.j2 - 2; pair = 1; }

@@ -1,0 +1,745 @@
+// penta_pipe.h — the forward elimination of a chain of the block LDL^T factorisation (penta_ldl.h) as a
+// pipeline of wavefronts that follow each other through LDS, without a products phase.
+//
+// penta_ldl_body eliminates block row i in the registers of one wavefront, then ALL wavefronts form the next
+// row's Schur complement S_{i+1} = C - Et_{i-1}^T Dn Et_{i-1} - Ht_i^T Dn Ht_i on the matrix cores from LDS,
+// and the eliminating wavefront loads it back: per block row 2.1k cycles of products + 0.4k of loads + 1.6k of
+// stores and barriers next to the 4.1k cycles of the K dependent pivots (profiles/r02_solver_phases.txt).
+// Here the update by Ht_i is applied pivot by pivot WHILE row i is eliminated (right-looking):
+//
+//   wave A (row i)      pivot j: scaled pivot row t_j = [D^-1 U | D^-1 Ht | D^-1 Et | D^-1 rt]_j and d_j -> LDS
+//   wave B (row i+1)    holds W_{i+1} = [S | H | E | y] in the same one-column-per-lane register layout and
+//                       applies  W_{i+1}[r][c] -= Ht_i[j][r] / d_j * [Ht_i | Et_i | . | rt_i][j][c]  as soon as
+//                       row j appears (19 multipliers as LDS broadcasts, one FMA per row)
+//   when A has published its last pivot, B holds the complete W_{i+1} and starts eliminating at once; A
+//   reloads with the inputs of row i+2 and becomes the follower.
+//
+// The update by Et_i (two rows ahead, a whole row time of slack) stays a dense block product on the matrix
+// cores: helper wavefronts form  G = Et_i^T Dn [Et_i | rt_i | Ft_i]  from the published rows, the follower
+// subtracts it half-way through its row.  The same helpers stage the band blocks (HBM -> LDS, column layout)
+// and write the factors out for the back substitution - the published rows ARE the row-major, 1/d-scaled
+// factors penta_ldl_tail and penta_apply_kernel read.  The chain's critical path per block row is the K pivots
+// of wave A plus one LDS hand-over.
+//
+// Nested dissection (penta_nd.h): the 2K "spike" columns F that couple a joiner chain to the separator are
+// carried by a second pair of wavefronts (A', B') in lock-step with the chain - they were a workgroup of their
+// own trailing the joiner by a row and a half (9 us at the end of the forward pass).
+//
+// Reference recursion: optimizer/penta_diagonal_solver.h:124-197 (Factorize), :199-248 (SolveInPlace).
+#pragma once
+
+#include "penta_nd.h"
+
+namespace idto_dev {
+
+// positions (in doubles) inside one published row; every part starts at an even position so that pairs are
+// 16-byte aligned for ds_read_b128
+template <int K>
+struct PipeGeo {
+  static constexpr int KE = K + (K & 1);
+  static constexpr int KR = 4 * ((K + 3) / 4);        // rows of a ring slot (pad rows stay zero: MFMA k-steps)
+  static constexpr int oS = 0, oH = KE, oE = 2 * KE, oy = 3 * KE, oF = 3 * KE + 2;
+  static constexpr int od = oF + 2 * K;               // the main wavefront's "row published" word (NaN until then)
+  static constexpr int og = od + 1;                   // the spike wavefront's
+  static constexpr int oi = og + 1;                   // 1 / d_j
+  static constexpr int odump = oi + 1;                // 8 positions written by lanes that hold no column
+  static constexpr int oz = odump + 8;                // a position that stays zero
+  // the parts the follower multiplies with, once more UNscaled: W_{i+1}[r][c] -= (Ht[j][r] / d_j) * Ht[j][c] with the
+  // second factor as it sits in the eliminating wavefront's registers (recomputing it as scaled * d costs two more
+  // roundings per term: measurably less accurate at cond(H) ~ 1e12)
+  static constexpr int oRH = oz + 1 + ((oz + 1) & 1), oRE = oRH + KE, oRy = oRE + KE;
+  static constexpr int used = oRy + 1;
+  static constexpr int RS = ((used + 15) / 32) * 32 + 16;   // = 16 mod 32: the four k-rows of an MFMA operand read hit different banks
+  static constexpr int SLOT = KR * RS;
+  static constexpr int GS = ldl_ks(K);                // column stride of the staged inputs and of G
+  static constexpr int NCX = 3 * K + 1;               // columns [S | H | E | y] of the main wavefront
+  static constexpr int NGC = KE + 2 + 2 * K;          // columns of G: [S-part (K, padded to KE) | y | . | F (2K)]
+  static_assert(3 * K <= 61, "main wavefront: 3K + 1 columns and the lane that publishes d");
+  static_assert(RS >= used && RS % 32 == 16, "row stride");
+};
+
+struct PipeLds {   // offsets in doubles
+  int ring, stage, gbuf, xall, W, flags, end;
+};
+template <int K>
+__host__ __device__ inline PipeLds pipe_layout(int n, bool spike) {
+  using G = PipeGeo<K>;
+  PipeLds L;
+  int o = 0;
+  L.ring = o; o += 3 * G::SLOT;
+  L.stage = o; o += 2 * (G::NCX + (spike ? 2 * K : 0)) * G::GS + 2;   // (+ a dump double)
+  L.gbuf = o; o += 2 * G::NGC * G::GS;
+  L.xall = o; o += (n + 2) * G::GS;
+  L.W = o; o += 2 * G::KE + 2;
+  L.flags = o; o += 32;            // 64 ints
+  L.end = o;
+  return L;
+}
+
+// flag words (ints, values = local row + 1)
+enum {
+  PF_SLOTGEN = 0,    // [3] main wavefront owns ring slot s for row il
+  PF_SLOTGEN2 = 3,   // [3] spike wavefront likewise
+  PF_ROWDONE = 6,    // [3] all pivots of row il published (main)
+  PF_ROWDONE2 = 9,   // [3] (spike)
+  PF_STAGED = 12,    // [2] inputs of row il are in stage buffer il & 1
+  PF_INITD = 14,     // [2] main wavefront has loaded them
+  PF_INITD2 = 16,    // [2] spike wavefront has
+  PF_GDONE = 18,     // [2][2] G of row il is in gbuf[il & 1] (two helper wavefronts)
+  PF_COPIED = 22,    // [3] factors of the row in ring slot s are written out
+  PF_COPIED2 = 25,   // [3] spike columns likewise
+  PF_ABORT = 28,     // a bounded wait ran out: everybody stops waiting
+  PF_JOINCNT = 29,   // producer: wavefronts that have written their join contribution
+  PF_COUNT = 30
+};
+
+constexpr int PIPE_SPIN_CAP = 1 << 17;   // polls (~150 cycles each with the sleep: ~10 ms) before a wait gives up
+
+// flags and published words are polled: volatile accesses in the LDS address space (a volatile access through a
+// generic pointer becomes a flat load with system-scope cache bits)
+typedef __attribute__((address_space(3))) volatile int pipe_lds_int;
+typedef __attribute__((address_space(3))) volatile double pipe_lds_dbl;
+
+struct PipeCtl {
+  pipe_lds_int* f;       // LDS flags
+  unsigned* status;      // host-mapped factorisation status
+  unsigned fact_id;
+};
+// A bounded wait that ran out (a partner workgroup is not resident, or a bug) sets PF_ABORT: every other wait of
+// the workgroup then gives up early, and the end of pipe_forward reports a failed factorisation.  (No function
+// call here: a call site inside the chain wavefronts' row loop makes every live register cross it.)
+// every poll is wave-uniform by construction (readfirstlane): scalar branches, no exec-mask loops
+__device__ __forceinline__ bool pipe_giveup(const PipeCtl& c, int n) {
+  if ((n & 255) != 0) return false;
+  if (__builtin_amdgcn_readfirstlane(c.f[PF_ABORT]) != 0) return true;
+  if (n >= PIPE_SPIN_CAP) { c.f[PF_ABORT] = 1; return true; }
+  return false;
+}
+// waits until flag >= target; bounded, see PIPE_SPIN_CAP
+__device__ __forceinline__ void pipe_wait(const PipeCtl& c, int flag, int target) {
+  int n = 0;
+  while (__builtin_amdgcn_readfirstlane(c.f[flag]) < target) {
+    __builtin_amdgcn_s_sleep(1);
+    if (pipe_giveup(c, ++n)) break;
+  }
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+// one lane posts flag = value after the wavefront's earlier LDS writes (LDS executes a wavefront's operations
+// in order; the fence only keeps the compiler from reordering)
+__device__ __forceinline__ void pipe_post(const PipeCtl& c, int flag, int value) {
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  if ((threadIdx.x & 63) == 0) c.f[flag] = value;
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+// a bounded wait on a word in global memory (another workgroup's flag, penta_ldl.h spin_wait); false: it gave up
+__device__ __forceinline__ bool pipe_wait_global(const PipeCtl& c, const unsigned* f, unsigned epoch, const SpinCtl sc) {
+  const bool ok = spin_wait([&] {
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == epoch;
+  }, sc);
+  if (!ok) c.f[PF_ABORT] = 1;
+  (void)__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+  return ok;
+}
+
+__device__ __forceinline__ bool pipe_isnan(double v) { return v != v; }
+// keeps a per-lane offset opaque to loop-invariant code motion: the chain wavefronts' row loop is one huge
+// unrolled body, and every address the compiler hoists out of it (the join rows' exchange buffer alone: 57
+// 64-bit pointers) is a register that lives through the pivots
+__device__ __forceinline__ int pipe_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
+// 1 / d: hardware estimate (~2^-23 relative) and ONE cubic step, x (1 + e + e^2) with e = 1 - d x: error e^3 ~ 2^-69,
+// three dependent FMAs instead of the four of two Newton steps (the reciprocal chain is on the critical path of
+// every pivot)
+__device__ __forceinline__ double pipe_rcp(double d) {
+#ifdef PIPE_RCP_TWO_NEWTON
+  return fast_rcp(d);
+#endif
+  const double x = __builtin_amdgcn_rcp(d);
+  const double e = __builtin_fma(-d, x, 1.0);
+  const double p = __builtin_fma(e, e, e);
+  return __builtin_fma(x, p, x);
+}
+
+// v with lane LANE replaced by the wave-uniform 64-bit pattern (hi, lo): two v_writelane_b32
+template <int LANE>
+__device__ __forceinline__ double pipe_setlane(double v, int uhi, int ulo) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  wrlane<LANE>(lo, ulo);
+  wrlane<LANE>(hi, uhi);
+  return __hiloint2double(hi, lo);
+}
+
+// ---- wave A, main columns: pivot J of the row held in xr (lane = column of [S | H | E | y]); `rowp` / `rawp` =
+// this lane's positions in row 0 of the ring slot, `slot0` = the slot's base.
+// penta_ldl_body's pivot step broadcasts the K - J - 1 multipliers with two v_readlane_b32 each and is bound
+// by the issue rate of one wavefront (~70 instructions for a middle pivot).  Here the scaled pivot row is
+// written to LDS anyway (the followers and the factors need it), and its entries D^-1 U[J][r] ARE the
+// multipliers: the wavefront reads them back as LDS broadcasts, two per instruction, and updates
+// xr[r] -= (U[J][r] / d_J) * xr[J].  Only the next row goes the fast way (v_readlane), so that the next pivot
+// and its reciprocal do not wait for the LDS round trip; the rest of the update runs in its shadow.
+// (Multipliers from the upper triangle throughout: L = (D^-1 U)^T exactly, as the back substitution assumes.)
+// (One more step of software pipelining: the multipliers read back at pivot J are used at pivot J+1 - `mu_p`,
+// `xj_p` are pivot J-1's - so that no instruction of the dependent chain pivot -> reciprocal -> next pivot ever
+// waits for an LDS read issued in the same step.  Row J+1 gets pivot J-1's term first, then pivot J's by
+// v_readlane, and is complete for the next reciprocal; rows J+2.. get pivot J-1's terms in the chain's shadow.)
+template <int K, int J>
+__device__ __forceinline__ void pipe_pivot(double (&xr)[K], double inv, const double (&mu_p)[K], const double xj_p,
+                                           double* __restrict__ rowp, double* __restrict__ rawp,
+                                           const double* __restrict__ slot0, const bool is63) {
+  using G = PipeGeo<K>;
+  // Two LDS writes per pivot, in this order and at once: the unscaled parts, then the scaled row whose lane 62 is
+  // the "published" word the followers poll.  The fences are compiler barriers (the hardware executes a
+  // wavefront's LDS operations in order): without them the compiler pairs the writes of two consecutive pivots
+  // into one ds_write2_b64 - a row would go out a pivot late, and the word could overtake the unscaled parts.
+  const double xj = xr[J];
+  rawp[J * G::RS] = xj;   // (columns of H, E, y: the unscaled pivot row; other lanes: a dump position)
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  double t = xj * inv;
+  {
+    // lanes 62 / 63 carry no column: 63 publishes 1 / d_J (the factors' Dn, the pivot test), 62 the "published"
+    // word - any non-NaN pattern (a NaN reads as "not yet" to the followers), here the high half of a small float
+    t = is63 ? inv : t;
+    int lo = __double2loint(t), hi = __double2hiint(t);
+    wrlane<62>(hi, 0x3f800000);
+    t = __hiloint2double(hi, lo);
+  }
+  rowp[J * G::RS] = t;
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  double inv_next = 1.0;
+  double mu[K];
+  if constexpr (J + 2 < K) {   // the multipliers of rows J+2 .. K-1, back from the row just written
+    const double2* p2 = reinterpret_cast<const double2*>(slot0 + J * G::RS);
+#pragma unroll
+    for (int m = (J + 2) / 2; m < (K + 1) / 2; ++m) {
+      const double2 v = p2[m];
+      if (2 * m >= J + 2) mu[2 * m] = v.x;
+      if (2 * m + 1 < K) mu[2 * m + 1] = v.y;
+    }
+  }
+  if constexpr (J + 1 < K) {
+    if constexpr (J >= 1) xr[J + 1] = __builtin_fma(-mu_p[J + 1], xj_p, xr[J + 1]);
+    const double m1 = rdlane(t, J + 1);
+    xr[J + 1] = __builtin_fma(-m1, xj, xr[J + 1]);
+    inv_next = pipe_rcp(rdlane(xr[J + 1], J + 1));
+  }
+  if constexpr (J >= 1) {
+#pragma unroll
+    for (int r = J + 2; r < K; ++r) xr[r] = __builtin_fma(-mu_p[r], xj_p, xr[r]);
+  }
+  if constexpr (J + 1 < K) pipe_pivot<K, J + 1>(xr, inv_next, mu, xj, rowp, rawp, slot0, is63);
+}
+
+// K uniform multipliers [pos0, pos0 + K) of a published row (pos0 even): LDS broadcast reads, two per instruction
+template <int K>
+__device__ __forceinline__ void pipe_read_mult(const double* __restrict__ row, int pos0, double (&mu)[K]) {
+  const double2* p2 = reinterpret_cast<const double2*>(row + pos0);
+#pragma unroll
+  for (int m = 0; m < K / 2; ++m) { const double2 v = p2[m]; mu[2 * m] = v.x; mu[2 * m + 1] = v.y; }
+  if (K & 1) mu[K - 1] = row[pos0 + K - 1];
+}
+
+// waits until row J of a ring slot carries a pivot (main) / the spike wavefront's word, i.e. until the word is no
+// quiet NaN (the publisher never writes one: pipe_pivot).  Polls the high half only - one 8-byte LDS write
+// lands both halves at once; bounded
+__device__ __forceinline__ void pipe_wait_row(const PipeCtl& c, const double* word) {
+  pipe_lds_int* hi = (pipe_lds_int*)word + 1;
+  int n = 0;
+  while ((__builtin_amdgcn_readfirstlane(*hi) & 0x7ff80000) == 0x7ff80000) {
+    __builtin_amdgcn_s_sleep(1);
+    if (pipe_giveup(c, ++n)) break;
+  }
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+
+struct PipeArgs {
+  int n, k;
+  const double* HA; const double* HB; const double* HC; const double* b;
+  double rhs_sign;
+  double* x;
+  double* Ust; double* Hst; double* Est; double* Dst;
+  double* xch; unsigned* flags; unsigned epoch;
+  unsigned* status; unsigned fact_id;
+  // nested dissection (spike chains): [Ft | rt] rows for the separator and their release counters
+  double* fst; int fstride; unsigned long long* frowcnt;
+  double* ts;
+};
+
+// ---- a chain wavefront: set sigma (of three) handles the rows il = sigma, sigma + 3, ...; `spk` (compile time): this
+// wavefront carries the 2K spike columns, else the columns [S | H | E | y]
+template <int K, bool SPK, bool spk>
+__device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCfg& cfg, const PipeLds& L, const PipeCtl& ctl,
+                                                const int sigma) {
+  extern __shared__ double lds[];
+  using G = PipeGeo<K>;
+  constexpr int ks = ldl_ks(K), RS = G::RS, GS = G::GS, NCS = G::NCX + (SPK ? 2 * K : 0);
+  const int lane = threadIdx.x & 63;
+  const bool producer = cfg.producer != 0;
+  const int nloc = cfg.nloc, m_split = cfg.m_split;
+  const int nrows = nloc + (producer ? 2 : 0);
+  double* ring = lds + L.ring;
+  double* stg = lds + L.stage;
+  double* gbuf = lds + L.gbuf;
+  const double qnan = __builtin_nan("");
+  // =====================================================================================================
+  // Three sets: while one eliminates row i and the second follows it with row i+1, the third - which eliminated
+  // row i-1 - loads the inputs of row i+2 and is ready the moment row i+1 starts publishing (with two sets the
+  // follower started ~0.7 us behind the wavefront it follows and, running at the same pace, stayed there).
+    // this lane's column: position in a published row, column in the staging buffer / G, source position of
+  // the follower's update (what pivot row j of the row before contributes to this column)
+  int pos, scol, gcol, src, rawpos = G::odump + (lane & 7);
+  bool has_col = true;
+  if (!spk) {
+    if (lane < K) { pos = G::oS + lane; scol = lane; gcol = lane; src = G::oRH + lane; }
+    else if (lane < 2 * K) { pos = G::oH + lane - K; scol = lane; gcol = -1; src = G::oRE + lane - K; rawpos = G::oRH + lane - K; }
+    else if (lane < 3 * K) { pos = G::oE + lane - 2 * K; scol = lane; gcol = -1; src = -1; rawpos = G::oRE + lane - 2 * K; }
+    else if (lane == 3 * K) { pos = G::oy; scol = lane; gcol = G::KE; src = G::oRy; rawpos = G::oRy; }
+    else { pos = (lane == 62) ? G::od : (lane == 63) ? G::oi : G::odump + (lane & 7); scol = -1; gcol = -1; src = -1; has_col = false; }
+  } else {
+    if (lane < 2 * K) { pos = G::oF + lane; scol = G::NCX + lane; gcol = G::KE + 2 + lane; src = pos; }
+    else { pos = (lane == 63) ? G::og : G::odump + (lane & 7); scol = -1; gcol = -1; src = -1; has_col = false; }
+  }
+  const int srcp = src >= 0 ? src : G::oz;
+  const int f_slotgen = spk ? PF_SLOTGEN2 : PF_SLOTGEN, f_rowdone = spk ? PF_ROWDONE2 : PF_ROWDONE;
+  const int f_initd = spk ? PF_INITD2 : PF_INITD;
+  double xr[K];
+  for (int il = sigma; il < nrows; il += 3) {
+    const bool pseudo = il >= nloc;
+    const int slot = il % 3, pslot = (il + 2) % 3;   // ring slots of this row and of the row before
+    // option "solver_debug": phases of the fifth row of the chain (slots 8 .. 15 of the role's stamps)
+    auto pstamp = [&](int k) { if (!spk && cfg.ts && il == 4 && lane == 0) cfg.ts[8 + k] = (double)wall_clock64(); };
+    pstamp(0);
+    // ---- the row's inputs
+    pipe_wait(ctl, PF_STAGED + (il & 1), il + 1);
+    if (has_col) {
+      const double2* s2 = reinterpret_cast<const double2*>(stg + (il & 1) * NCS * GS + scol * GS);
+#pragma unroll
+      for (int r2 = 0; r2 < K / 2; ++r2) { const double2 v = s2[r2]; xr[2 * r2] = v.x; xr[2 * r2 + 1] = v.y; }
+      if (K & 1) xr[K - 1] = stg[(il & 1) * NCS * GS + scol * GS + K - 1];
+    } else {
+#pragma unroll
+      for (int r = 0; r < K; ++r) xr[r] = 0.0;
+    }
+    // the diagonal entry of the band block this lane's pivot starts from (pivot test below)
+    const double diag0 = (!spk && lane < K) ? stg[(il & 1) * NCS * GS + lane * GS + lane] : 1.0;
+    pipe_post(ctl, f_initd + (il & 1), il + 1);
+    pstamp(1);
+    auto reuse_check = [&]() {
+      // this row will be published into the ring slot of row il - 3: that row must have been consumed (checked
+      // half-way through the row before - it has long been, and the check is off the critical path)
+      if (il >= 3 && !pseudo) {
+        pipe_wait(ctl, PF_COPIED + slot, il - 2);
+        if (SPK) pipe_wait(ctl, PF_COPIED2 + slot, il - 2);
+        pipe_wait(ctl, PF_GDONE + ((il - 3) & 1), il - 2);
+      }
+    };
+    // ---- follower: the updates by the row before, pivot by pivot as wave A publishes them
+    const bool follow = il >= 1 && !(il - 1 >= nloc);   // (a pseudo-row publishes nothing)
+    if (follow) {
+      pipe_wait(ctl, PF_SLOTGEN + pslot, il);
+      if (spk) pipe_wait(ctl, PF_SLOTGEN2 + pslot, il);
+    }
+    const double* prow = ring + pslot * G::SLOT;
+    bool subg_done = il < 2;
+    auto subg = [&]() {   // the update by Et of two rows before: G from the matrix cores
+      pipe_wait(ctl, PF_GDONE + (il & 1), il - 1);
+      reuse_check();
+      if (gcol >= 0) {
+        const double2* g2 = reinterpret_cast<const double2*>(gbuf + (il & 1) * G::NGC * GS + gcol * GS);
+#pragma unroll
+        for (int r2 = 0; r2 < K / 2; ++r2) { const double2 v = g2[r2]; xr[2 * r2] -= v.x; xr[2 * r2 + 1] -= v.y; }
+        if (K & 1) xr[K - 1] -= gbuf[(il & 1) * G::NGC * GS + gcol * GS + K - 1];
+      }
+      subg_done = true;
+    };
+    if (follow) {
+      // The K rank-one terms are summed on their own and subtracted once, (C - G) - sum as penta_ldl_body's
+      // products phase does (subtracting them one by one from the band block rounds K times at the magnitude of C).
+      // Software pipeline: the multipliers of pivot J + 1 are in flight while pivot J's terms are formed, and ONE
+      // poll tells how many rows wave A has published (lane l watches row l's word), so a follower that is behind
+      // does not poll at all.
+      double acc[K], mu[2][K], vv[2];
+#pragma unroll
+      for (int r = 0; r < K; ++r) acc[r] = 0.0;
+      pipe_lds_int* watch = (pipe_lds_int*)(prow + (lane < K ? lane * RS + G::od : (spk && lane >= 32 && lane < 32 + K) ? (lane - 32) * RS + G::og : G::oz)) + 1;
+      int avail = 0;
+      auto need = [&](int J) {   // returns once row J is published (bounded)
+        int n = 0;
+        while (J >= avail) {
+          const unsigned long long pub = __builtin_amdgcn_ballot_w64((*watch & 0x7ff80000) != 0x7ff80000);
+          const int a0 = __builtin_ctzll(~pub | (1ull << K)), a1 = __builtin_ctzll(~(pub >> 32) | (1ull << K));
+          avail = spk ? (a0 < a1 ? a0 : a1) : a0;
+          if (J < avail) break;
+          __builtin_amdgcn_s_sleep(1);
+          if (pipe_giveup(ctl, ++n)) { avail = K; break; }
+        }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+      };
+      auto load = [&](int J, double (&m)[K], double& v) {
+        pipe_read_mult<K>(prow + J * RS, G::oH, m);
+        v = prow[J * RS + srcp];   // (unscaled: oRH / oRE / oRy; spike rows are published unscaled)
+      };
+      pstamp(2);
+      need(0);
+      load(0, mu[0], vv[0]);
+      pstamp(3);
+#pragma unroll
+      for (int J = 0; J < K; ++J) {
+        if (J + 1 < K) { need(J + 1); load(J + 1, mu[(J + 1) & 1], vv[(J + 1) & 1]); }
+        if (J == (K + 1) / 2) pstamp(4);
+        if (J == K - 1) pstamp(5);
+        if (J == (K + 1) / 2 && !subg_done) subg();
+#pragma unroll
+        for (int r = 0; r < K; ++r) acc[r] = __builtin_fma(mu[J & 1][r], vv[J & 1], acc[r]);
+      }
+      if (!subg_done) subg();
+#pragma unroll
+      for (int r = 0; r < K; ++r) xr[r] -= acc[r];
+      pstamp(6);
+    }
+    if (!subg_done) subg();
+    // ---- join rows of a joiner: the producer's Schur-complement contributions
+    if (!producer && !spk && cfg.two && il >= m_split) {
+      if (il == m_split) chain_ts(cfg, 1);
+      if (pipe_wait_global(ctl, A.flags, A.epoch, cfg.spin)) {
+        constexpr int wsz = (K + 2 * K + 1) * ks;
+        const double* X0 = A.xch;          // contributions to the join row next to the producer (+ the coupling of the two)
+        const double* X1 = A.xch + wsz;    // contributions to the other join row
+        const double* Xs = (il == m_split) ? X1 : X0;
+        const int lo = pipe_opaque(lane * ks), ho = pipe_opaque(K * ks + lane - K);
+        if (lane < K) {
+#pragma unroll
+          for (int r = 0; r < K; ++r) xr[r] += Xs[lo + r];
+        } else if (lane == 3 * K) {
+#pragma unroll
+          for (int r = 0; r < K; ++r) xr[r] += Xs[lo + r];
+        } else if (lane < 2 * K && il == m_split) {   // H(r, c) += H'(c, r)
+#pragma unroll
+          for (int r = 0; r < K; ++r) xr[r] += X0[ho + r * ks];
+        }
+      }
+      if (il == m_split) chain_ts(cfg, 5);
+    }
+    if (pseudo) {
+      // ---- producer: hand the column over (layout of penta_ldl_body's exchange buffer)
+      if (has_col) {
+        const int wo = pipe_opaque((il - nloc) * (K + 2 * K + 1) * ks + lane * ks);   // column `lane` of [S | H | E | y]
+#pragma unroll
+        for (int r = 0; r < K; ++r) A.xch[wo + r] = xr[r];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) {
+        const int old = __hip_atomic_fetch_add(reinterpret_cast<int*>(lds + L.flags) + PF_JOINCNT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (old == 1) __hip_atomic_store(A.flags, A.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      continue;
+    }
+    // ---- wave A: eliminate, publishing every pivot row
+    double* rowp = ring + slot * G::SLOT + pos;
+    if (!spk && cfg.ts && lane == 0 && il < 20) cfg.ts[24 + 2 * il] = (double)wall_clock64();   // option "solver_debug": elimination of row il starts ...
+    if (lane < K) ring[slot * G::SLOT + lane * RS + (spk ? G::og : G::od)] = qnan;
+    pipe_post(ctl, f_slotgen + slot, il + 1);
+    if (!spk) {
+      {
+        double mu0[K];
+#pragma unroll
+        for (int r = 0; r < K; ++r) mu0[r] = 0.0;
+        pipe_pivot<K, 0>(xr, pipe_rcp(rdlane(xr[0], 0)), mu0, 0.0, rowp, ring + slot * G::SLOT + rawpos, ring + slot * G::SLOT, lane == 63);
+      }
+      pipe_post(ctl, f_rowdone + slot, il + 1);
+      if (cfg.ts && lane == 0 && il < 20) cfg.ts[25 + 2 * il] = (double)wall_clock64();   // ... and ends
+      // factorisation status (the reference reports kFailure from Factorize: penta_diagonal_solver.h:181-185,
+      // trajectory_optimizer.cc:2084): every pivot positive, finite, and not cancelled to nothing against the
+      // diagonal entry of H it started from (d <= eps H_ll: H is not numerically positive definite)
+      const double il_ = (lane < K) ? ring[slot * G::SLOT + lane * RS + G::oi] : 1.0;   // 1 / d: NaN for d = 0 / inf / NaN
+      const bool bad = lane < K && !(il_ > 0.0 && il_ * diag0 < 4503599627370496.0);
+      if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) {
+        __hip_atomic_store(A.status, A.fact_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_fetch_add(A.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (cfg.ts) cfg.ts[20] = (double)(il + 1);
+      }
+    } else {
+      // spike columns: Ft = L^-1 F with the multipliers D^-1 U the main wavefront publishes; rows go out raw
+      const double* arow = ring + slot * G::SLOT;
+      pipe_wait(ctl, PF_SLOTGEN + slot, il + 1);
+      pipe_lds_int* watch = (pipe_lds_int*)(arow + (lane < K ? lane * RS + G::od : G::oz)) + 1;
+      int avail = 0;
+#pragma unroll
+      for (int J = 0; J < K; ++J) {
+        for (int n = 0; J >= avail;) {   // one poll covers every row the main wavefront has published
+          avail = __builtin_ctzll(~__builtin_amdgcn_ballot_w64((*watch & 0x7ff80000) != 0x7ff80000) | (1ull << K));
+          if (J < avail) break;
+          __builtin_amdgcn_s_sleep(1);
+          if (pipe_giveup(ctl, ++n)) { avail = K; break; }
+        }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        rowp[J * RS] = pipe_setlane<63>(xr[J], 0x3ff00000, 0);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        if (J + 1 < K) {
+          // multipliers T_J[c], c = J+1 .. K-1 (pairs from the even position below J+1)
+          const double2* p2 = reinterpret_cast<const double2*>(arow + J * RS);
+#pragma unroll
+          for (int m = (J + 1) / 2; m < (K + 1) / 2; ++m) {
+            const double2 v = p2[m];
+            if (2 * m > J) xr[2 * m] = __builtin_fma(-v.x, xr[J], xr[2 * m]);
+            if (2 * m + 1 < K) xr[2 * m + 1] = __builtin_fma(-v.y, xr[J], xr[2 * m + 1]);
+          }
+        }
+      }
+      pipe_post(ctl, f_rowdone + slot, il + 1);
+    }
+  }
+}
+
+// The forward pass of one chain.  512 threads (no spike columns: waves 0-2 eliminate in turn, 3 = I/O, 4 = G, the rest idle) or
+// (SPK: waves 0-2 main columns, 3-5 spike columns, 6 = I/O, 7 = G and the spike rows out).
+// On exit (after a block-wide barrier): factors in HBM, rt of every row in lds[L.xall ...], as penta_ldl_tail expects.
+template <int K, bool SPK>
+__device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& cfg, const PipeLds& L) {
+  extern __shared__ double lds[];
+  using G = PipeGeo<K>;
+  constexpr int ks = ldl_ks(K), KK = K * K, RS = G::RS, GS = G::GS, NCS = G::NCX + (SPK ? 2 * K : 0);
+  // (the wavefront index is uniform: tell the compiler, or the chain wavefronts' row loop - which starts at
+  // wave & 1 - becomes a divergent loop with every counter in a vector register)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool mirror = cfg.mirror != 0, producer = cfg.producer != 0;
+  const int nloc = cfg.nloc, m_split = cfg.m_split;
+  const int nrows = nloc + (producer ? 2 : 0);   // + the producer's two pseudo-rows (its contributions to the join rows)
+  const int k = A.k, kk = k * k;
+  auto orig = [&](int il) { const int o = mirror ? cfg.base - il : cfg.base + il; return o < 0 ? 0 : o; };
+  double* ring = lds + L.ring;
+  double* stg = lds + L.stage;
+  double* gbuf = lds + L.gbuf;
+  PipeCtl ctl{(pipe_lds_int*)(lds + L.flags), A.status, A.fact_id};
+  const double qnan = __builtin_nan("");
+
+  // ---- setup: zero everything (pad rows / columns of the ring must be exact zeros), flags
+  for (int idx = tid; idx < L.end; idx += blockDim.x) lds[idx] = 0.0;
+  __syncthreads();
+  chain_ts(cfg, 0);
+
+  constexpr int W_SPK0 = 3, W_IO = SPK ? 6 : 3, W_G = SPK ? 7 : 4;
+
+  if (wave < 3) {
+    pipe_chain_wave<K, SPK, false>(A, cfg, L, ctl, wave);
+  } else if (SPK && wave < W_SPK0 + 3) {
+    pipe_chain_wave<K, SPK, true>(A, cfg, L, ctl, wave - W_SPK0);
+  } else if (wave == W_IO) {
+    // =====================================================================================================
+    // I/O wavefront: stages the band blocks of row t + 2 (column layout), writes the factors of row t out
+    constexpr int PM = (NCS * K + 63) / 64;
+    const int dHB = (int)(A.HB - A.HA), dHC = (int)(A.HC - A.HA);
+    // per-lane slots (fixed over the rows): source offset relative to the row's A block (or to its right-hand
+    // side), destination in the staging buffer, which part the element belongs to
+    int s_off[PM], s_dst[PM];
+    unsigned long long mH = 0, mE = 0, mY = 0, mAny = 0;
+    static_assert(PM <= 64, "slot masks are 64-bit");
+#pragma unroll
+    for (int s = 0; s < PM; ++s) {
+      const int e = lane + 64 * s;
+      const bool valid = e < NCS * K;
+      const int c = valid ? e / K : 0, r = valid ? e - c * K : 0;
+      s_dst[s] = valid ? c * GS + r : 2 * NCS * GS;   // (one dump double behind the two staging buffers)
+      s_off[s] = 0;
+      if (!valid) continue;
+      if (c < K) { s_off[s] = dHC + c * k + r; mAny |= 1ull << s; }
+      else if (c < 2 * K) { const int cc = c - K; s_off[s] = mirror ? dHB + cc * k + r : dHB + kk + r * k + cc; mH |= 1ull << s; mAny |= 1ull << s; }
+      else if (c < 3 * K) { const int cc = c - 2 * K; s_off[s] = mirror ? cc * k + r : 2 * kk + r * k + cc; mE |= 1ull << s; mAny |= 1ull << s; }
+      else if (c == 3 * K) { s_off[s] = r; mY |= 1ull << s; mAny |= 1ull << s; }
+    }
+    auto stage_row = [&](int il) {
+      const bool pseudo = il >= nloc;
+      const int o = orig(il);
+      const double* base = A.HA + (size_t)o * kk;
+      const double* bp = A.b + (size_t)o * k;
+      double* dst = stg + (il & 1) * NCS * GS;
+      // join rows of a joiner have no coupling beyond the join, a producer's pseudo-rows have all-zero inputs
+      unsigned long long kill = ~mAny;
+      if (pseudo) kill = ~0ull;
+      else if (!producer && cfg.two) kill |= (il >= m_split ? mE : 0ull) | (il >= m_split + 1 ? mH : 0ull);
+      double val[PM];
+#pragma unroll
+      for (int s = 0; s < PM; ++s) {
+        const double* p = (mY >> s & 1) ? bp : base;
+        val[s] = p[s_off[s]];
+      }
+#pragma unroll
+      for (int s = 0; s < PM; ++s) {
+        double v = (mY >> s & 1) ? A.rhs_sign * val[s] : val[s];
+        v = (kill >> s & 1) ? 0.0 : v;
+        if (s_dst[s] < 2 * NCS * GS) dst[s_dst[s]] = v;
+      }
+      if (SPK && il < 2) {
+        // coupling of this chain's first two rows to the separator rows (nearest first), see penta_nd.h:
+        //   row 0: [coupling(row 0, nearest) | coupling(row 0, farthest)],  row 1: [coupling(row 1, nearest) | 0]
+        for (int e = lane; e < 2 * KK; e += 64) {
+          const int f = e / K, r = e - f * K, ff = f < K ? f : f - K;
+          double v = 0.0;
+          if (il == 0) {
+            if (!mirror) v = (f < K) ? base[dHB + ff * k + r] : base[ff * k + r];
+            else v = (f < K) ? base[dHB + kk + r * k + ff] : base[2 * kk + r * k + ff];
+          } else if (f < K) {
+            v = mirror ? base[2 * kk + r * k + ff] : base[ff * k + r];
+          }
+          dst[(G::NCX + f) * GS + r] = v;
+        }
+      }
+    };
+    auto copy_row = [&](int il) {
+      const int slot = il % 3, o = orig(il);
+      const double* row0 = ring + slot * G::SLOT;
+      for (int idx = lane; idx < K * ks; idx += 64) {
+        const int r = idx / ks, c = idx - r * ks;
+        const double* row = row0 + r * RS;
+        const bool in = c < K;
+        A.Ust[(size_t)o * K * ks + idx] = (in && r < c) ? row[G::oS + c] : 0.0;
+        A.Hst[(size_t)o * K * ks + idx] = in ? row[G::oH + c] : 0.0;
+        A.Est[(size_t)o * K * ks + idx] = in ? row[G::oE + c] : 0.0;
+      }
+      if (lane < K) {
+        if (!SPK) A.Dst[(size_t)o * K + lane] = row0[lane * RS + G::oi];
+        lds[L.xall + (il + 2) * ks + lane] = row0[lane * RS + G::oRy];   // rt (unscaled) for the back substitution
+      }
+    };
+    stage_row(0);
+    pipe_post(ctl, PF_STAGED + 0, 1);
+    if (nrows > 1) { stage_row(1); pipe_post(ctl, PF_STAGED + 1, 2); }
+    for (int t = 0; t < nrows; ++t) {
+      if (t + 2 < nrows) {
+        pipe_wait(ctl, PF_INITD + (t & 1), t + 1);
+        if (SPK) pipe_wait(ctl, PF_INITD2 + (t & 1), t + 1);
+        stage_row(t + 2);
+        pipe_post(ctl, PF_STAGED + (t & 1), t + 3);
+      }
+      if (t < nloc) {
+        pipe_wait(ctl, PF_ROWDONE + t % 3, t + 1);
+        copy_row(t);
+        pipe_post(ctl, PF_COPIED + t % 3, t + 1);
+      }
+    }
+  } else if (wave == W_G) {
+    // =====================================================================================================
+    // G = Et_t^T Dn [Et_t | rt_t | Ft_t] on the matrix cores: A operand the scaled rows D^-1 Et, B operand the
+    // unscaled [Et | rt] (oRE ...) and spike rows (oF ...)
+    using d4 = __attribute__((ext_vector_type(4))) double;
+    constexpr int SK = (K + 3) / 4, TT = (K + 15) / 16;
+    constexpr int NCG = SPK ? G::NGC : G::KE + 1;        // columns of G that exist
+    constexpr int CT = (NCG + 15) / 16;
+    const int fl = lane & 15, fk = lane >> 4;
+    for (int t = 0; t < nloc; ++t) {
+      const int slot = t % 3;
+      pipe_wait(ctl, PF_ROWDONE + slot, t + 1);
+      if (SPK) pipe_wait(ctl, PF_ROWDONE2 + slot, t + 1);
+      const double* row0 = ring + slot * G::SLOT;
+      if (t + 2 < nrows) {   // (else nobody is two rows ahead)
+        double* gout = gbuf + (t & 1) * G::NGC * GS;
+        double a[TT][SK];
+#pragma unroll
+        for (int sq = 0; sq < SK; ++sq) {
+          const double* row = row0 + (4 * sq + fk) * RS;   // (pad rows: zeros)
+#pragma unroll
+          for (int tr = 0; tr < TT; ++tr) a[tr][sq] = row[G::oE + 16 * tr + fl];
+        }
+        for (int tc = 0; tc < CT; ++tc) {
+          const int ci = 16 * tc + fl;                                                // column of G
+          const int bpos = ci < G::KE + 2 ? G::oRE + ci : G::oF + ci - (G::KE + 2);   // where its operand sits in a row
+          double bq[SK];
+#pragma unroll
+          for (int sq = 0; sq < SK; ++sq) bq[sq] = row0[(4 * sq + fk) * RS + bpos];
+#pragma unroll
+          for (int tr = 0; tr < TT; ++tr) {
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int sq = 0; sq < SK; ++sq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tr][sq], bq[sq], acc, 0, 0, 0);
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              const int r = 16 * tr + fk + 4 * rg;
+              if (r < K && ci < NCG) gout[ci * GS + r] = acc[rg];
+            }
+          }
+        }
+        pipe_post(ctl, PF_GDONE + (t & 1), t + 1);
+      }
+      if (SPK) {
+        // [Ft | rt] of the row to HBM for the separator's Q (and this chain's own correction), 1 / d with them
+        const int o = orig(t);
+        double* dst = A.fst + (size_t)t * A.fstride;
+        for (int idx = lane; idx < (2 * K + 1) * K; idx += 64) {
+          const int c = idx / K, r = idx - c * K;
+          const double* row = row0 + r * RS;
+          dst[c * ks + r] = (c < 2 * K) ? row[G::oF + c] : row[G::oRy];
+        }
+        if (lane < K) A.Dst[(size_t)o * K + lane] = row0[lane * RS + G::oi];
+        pipe_post(ctl, PF_COPIED2 + slot, t + 1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(A.frowcnt + t, 3ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0 && ctl.f[PF_ABORT] != 0 && cfg.spin.word) {   // a wait gave up: tell the host (it repeats the solve)
+    __hip_atomic_store(cfg.spin.word, cfg.spin.id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_fetch_add(cfg.spin.word + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  chain_ts(cfg, 2);
+}
+
+// grid (5, batch), 512 threads: blockIdx.x = role, blockIdx.y = problem of the batch
+//   0: P0 producer, rows 0 .. j1-1 top-down        1: P3 producer, rows n-1 .. j2+2 bottom-up
+//   2: J1 joiner, rows s-1 .. j1+2 then j1+1, j1   3: J2 joiner, rows s+2 .. j2-1 then j2, j2+1   (with their spike columns)
+//   4: the separator (penta_nd.h nd_separator)
+// Every wait is bounded (PIPE_SPIN_CAP): a workgroup that is not resident with its partners ends with the
+// factorisation status set instead of hanging the device.
+template <int K>
+__global__ void __launch_bounds__(512) penta_pipe_kernel(NdArgs A) {
+  {
+    const size_t o = (size_t)blockIdx.y * A.pstride;
+    A.HA = at_problem(A.HA, o); A.HB = at_problem(A.HB, o); A.HC = at_problem(A.HC, o); A.b = at_problem(A.b, o);
+    A.x = at_problem(A.x, o); A.Ust = at_problem(A.Ust, o); A.Hst = at_problem(A.Hst, o); A.Est = at_problem(A.Est, o);
+    A.Dst = at_problem(A.Dst, o); A.xch = at_problem(A.xch, o); A.flags = at_problem(A.flags, o);
+    A.rowcnt = at_problem(A.rowcnt, o); A.ndbuf = at_problem(A.ndbuf, o);
+    A.spin = SpinCtl{A.status + 2 * gridDim.y, A.fact_id};
+    A.status += 2 * blockIdx.y;
+  }
+  const int role = blockIdx.x;
+  if (role == A.debug_skip_role) return;
+  if (role == 4) { nd_separator<K, false>(A); return; }
+  const NdBuf B = nd_layout(K);
+  ChainCfg c = {};
+  c.two = 1;
+  c.dbg_slot = role;
+  c.ts = A.ts ? A.ts + role * 64 : nullptr;
+  c.spin = A.spin;
+  int pair;
+  if (role == 0) { c.mirror = 0; c.producer = 1; c.base = 0; c.nloc = A.j1; pair = 0; }
+  else if (role == 1) { c.mirror = 1; c.producer = 1; c.base = A.n - 1; c.nloc = A.n - A.j2 - 2; pair = 1; }
+  else {
+    const int w = role - 2;
+    c.mirror = (w == 0); c.producer = 0;
+    c.base = (w == 0) ? A.s - 1 : A.s + 2;
+    c.m_split = (w == 0) ? A.s - A.j1 - 2 : A.j2 - A.s - 2;
+    c.nloc = c.m_split + 2;
+    pair = w;
+    c.fst = A.ndbuf + B.fst + (size_t)w * ND_MAXROWS * B.frow; c.fstride = B.frow;
+    c.frowcnt = A.rowcnt + (2 + w) * ND_MAXROWS; c.frowtarget = (A.rowtarget / A.rowunit) * 3ull;
+    c.xsep = A.ndbuf + B.xsep; c.sepflag = A.flags + 4;
+  }
+  PipeArgs P;
+  P.n = A.n; P.k = A.k; P.HA = A.HA; P.HB = A.HB; P.HC = A.HC; P.b = A.b; P.rhs_sign = A.rhs_sign; P.x = A.x;
+  P.Ust = A.Ust; P.Hst = A.Hst; P.Est = A.Est; P.Dst = A.Dst;
+  P.xch = A.xch + (size_t)pair * A.xch_pair; P.flags = A.flags + 2 * pair; P.epoch = A.epoch;
+  P.status = A.status; P.fact_id = A.fact_id;
+  P.fst = const_cast<double*>(c.fst); P.fstride = c.fstride;
+  P.frowcnt = role >= 2 ? A.rowcnt + (2 + role - 2) * ND_MAXROWS : nullptr;
+  P.ts = c.ts;
+  const bool spike = role >= 2;
+  const PipeLds L = pipe_layout<K>(A.n, spike);
+  if (spike) pipe_forward<K, true>(P, c, L);
+  else pipe_forward<K, false>(P, c, L);
+  if (threadIdx.x >= 256) return;
+  penta_ldl_tail<K, 256>(A.n, A.k, 1, A.x, A.Ust, A.Hst, A.Est, A.Dst, nullptr, c, P.xch, P.flags, A.epoch, L.xall, 1,
+                         L.W, c.nloc + (c.producer ? 2 : 0));
+}
+
+}  // namespace idto_dev

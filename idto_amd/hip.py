@@ -127,12 +127,20 @@ class FactorizationFailed(HipError):
     PentaDiagonalFactorizationStatus::kFailure, optimizer/penta_diagonal_solver.h:181-185)"""
 
 
+class SolverTimeout(HipError):
+    """IDTO_HIP_SOLVER_TIMEOUT: a multi-workgroup solver launch did not find its partner workgroups resident; the
+    context has stepped down to a variant with fewer co-resident workgroups - repeat the call"""
+
+
 FACTORIZATION_FAILED = 2
+SOLVER_TIMEOUT = 3
 
 
 def _chk(rc):
     if rc == FACTORIZATION_FAILED:
         raise FactorizationFailed(lib().idto_hip_last_error().decode())
+    if rc == SOLVER_TIMEOUT:
+        raise SolverTimeout(lib().idto_hip_last_error().decode())
     if rc != 0:
         raise HipError(f"idto_hip error {rc}: {lib().idto_hip_last_error().decode()}")
 

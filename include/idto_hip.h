@@ -81,6 +81,14 @@ const char* idto_hip_last_error(void);
  * optimizer demands success (optimizer/trajectory_optimizer.cc:2084, :2091); the host-side
  * TrajectoryOptimizer maps it to SolverFlag::kFactorizationFailed. */
 #define IDTO_HIP_FACTORIZATION_FAILED 2
+/* The solver variants that spread one factorisation over several workgroups (two-sided, nested dissection,
+ * pipelined chains, the fused Gauss-Newton launch) need those workgroups resident at the same time.  On a
+ * device shared with other kernels that is not guaranteed: every wait between workgroups is bounded (50 ms),
+ * a launch whose wait ran out ends normally with this status at the next synchronisation, and the context
+ * steps down to a variant with fewer co-resident workgroups (ultimately one, which cannot wait for anybody).
+ * idto_hip_get(IDTO_ARR_STEP) repeats the solve itself; from the other entry points the caller repeats the
+ * call.  idto_hip_get_option("solver_timeouts") counts the occurrences. */
+#define IDTO_HIP_SOLVER_TIMEOUT 3
 
 /* Creates a context on HIP device `device` for the given model, problem and
  * contact parameters (copied). */

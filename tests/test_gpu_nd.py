@@ -1,6 +1,7 @@
-"""Nested-dissection form of the block LDL^T solver (csrc/penta_nd.h: two producer / joiner chain
-pairs around a separator, two spike workgroups carrying the chains' coupling to the separator)
-against (i) the two-workgroup form of the same factorisation, (ii) the bit-exact restatement of the
+"""Nested-dissection form of the block LDL^T solver - csrc/penta_pipe.h (production for block sizes up to 20:
+pipelined chains, five workgroups, the joiners carry their coupling to the separator; `last_solver` 4) and
+csrc/penta_nd.h (two producer / joiner chain pairs around a separator, two spike workgroups carrying the
+chains' coupling to the separator; `last_solver` 2) - against (i) the two-workgroup form of the same factorisation, (ii) the bit-exact restatement of the
 reference's pivoted-LU block Thomas (optimizer/penta_diagonal_solver.h:124-248) and (iii) an
 extended-precision solution: same accuracy bar as tests/test_gpu_parity.py, repeated launches
 bit-identical (the workgroups synchronise through device-memory flags and counters), batches,
@@ -30,12 +31,15 @@ def _setup(name, N, seed=0):
 @pytest.mark.parametrize("name,N", [("mini_cheetah", 40), ("mini_cheetah", 24), ("mini_cheetah", 31), ("hopper", 50),
                                     ("spinner", 40), ("acrobot", 40), ("acrobot", 63), ("allegro_hand", 60),
                                     ("allegro_hand", 27)])
-def test_nested_dissection_solver(name, N):
+@pytest.mark.parametrize("pipe", [1, 0])
+def test_nested_dissection_solver(name, N, pipe):
     cfg, model, prob, sp, q = _setup(name, N)
     dev = hip.HipPath(model, prob, sp)
+    dev.set_option("solver_pipe", pipe)
     dev.set_q(q)
     dev.gn_step()
-    assert dev.get_option("last_solver") == 2, "the nested-dissection kernel was expected to take this size"
+    want = 4 if (pipe and model.nq <= 20) else 2
+    assert dev.get_option("last_solver") == want, "the nested-dissection kernel was expected to take this size"
     p_nd = dev.get("step")
     for _ in range(3):   # flags / counters are epoch-valued: repeated launches must reproduce the bits
         dev.factor_solve()
@@ -73,7 +77,7 @@ def test_reference_penta_diagonal_case_through_nd():
     s.set_bands(H[0], H[1], H[2])
     x_gt = np.linspace(-3, 12.4, size)
     x = s.solve(Hd @ x_gt)
-    assert s.dev.get_option("last_solver") == 2
+    assert s.dev.get_option("last_solver") == 4
     assert np.linalg.norm(x - x_gt) / np.linalg.norm(x_gt) < 50 * np.linalg.cond(Hd) * np.finfo(float).eps
     # many right-hand sides: the two-workgroup factors serve the substitution kernel
     X = s.solve(np.stack([Hd @ x_gt, 2 * (Hd @ x_gt)]))
@@ -81,7 +85,8 @@ def test_reference_penta_diagonal_case_through_nd():
     assert np.linalg.norm(X[1] - 2 * x_gt) / np.linalg.norm(x_gt) < 100 * np.linalg.cond(Hd) * np.finfo(float).eps
 
 
-def test_nd_in_a_batch_and_failure_report():
+@pytest.mark.parametrize("pipe", [1, 0])
+def test_nd_in_a_batch_and_failure_report(pipe):
     name, N, B = "mini_cheetah", 40, 3
     cfg, model = load_config(name), load_model(name)
     probs, qs = [], []
@@ -93,11 +98,13 @@ def test_nd_in_a_batch_and_failure_report():
         probs.append(prob)
         qs.append(synthetic_trajectory(cfg, model, N, seed=b, lower=0.01))
     batch = hip.HipPath(model, probs, sp)
+    batch.set_option("solver_pipe", pipe)
     batch.set_q_batch(np.array(qs))
     batch.gn_step()
-    assert batch.get_option("last_solver") == 2
+    assert batch.get_option("last_solver") == (4 if pipe else 2)
     for b in range(B):
         one = hip.HipPath(model, probs[b], sp)
+        one.set_option("solver_pipe", pipe)
         one.set_q(qs[b])
         one.gn_step()
         assert np.array_equal(batch.get("step", b), one.get("step"))
@@ -115,7 +122,8 @@ def test_nd_in_a_batch_and_failure_report():
     batch.close()
 
 
-def test_changing_inputs_every_launch():
+@pytest.mark.parametrize("pipe", [1, 0])
+def test_changing_inputs_every_launch(pipe):
     """the trajectory changes every launch: a read that is not ordered after its producer would return
     the previous launch's values (tools/nd_stress.py is the long version)"""
     cfg, model, prob, sp, _ = _setup("mini_cheetah", 40)
@@ -128,11 +136,12 @@ def test_changing_inputs_every_launch():
         dev.gn_step()
         ref.append(dev.get("step"))
     dev.set_option("solver_nd", 1)
+    dev.set_option("solver_pipe", pipe)
     for it in range(60):
         j = it % 3
         dev.set_q(qs[j])
         dev.gn_step()
-        assert dev.get_option("last_solver") == 2
+        assert dev.get_option("last_solver") == (4 if pipe else 2)
         p = dev.get("step")
         assert np.abs(p - ref[j]).max() <= 1e-3 * np.abs(ref[j]).max(), it   # (another launch's data would be off by O(1); two factorisations differ ~cond * eps)
     dev.close()

@@ -18,6 +18,23 @@ dev.set_option("solver_debug", 1)
 dev.factor_solve(); dev.factor_solve()
 d = dev.get("debug")[:7 * 64].reshape(7, 64) / 100.0
 t0 = d[:4, 0].min()
+if dev.get_option("last_solver") == 4:   # pipelined chains (csrc/penta_pipe.h): five workgroups, no spike workgroups
+    names = ["P0 producer", "P3 producer", "J1 joiner", "J2 joiner"]
+    for r in range(4):
+        x = d[r] - t0
+        rows = [(x[24 + 2 * i], x[25 + 2 * i]) for i in range(20) if d[r][24 + 2 * i] > 0]
+        gaps = np.diff([a for a, _ in rows])
+        print(f"{names[r]:12s} start {x[0]:6.2f}  join-wait-begin {x[1]:6.2f}  join-wait-end {x[5]:6.2f}  forward done {x[2]:6.2f}  "
+              f"backward start {x[3]:6.2f}  end {x[4]:6.2f}")
+        print("   elimination of row il (start, end):", " ".join(f"({a:5.2f},{b:5.2f})" for a, b in rows))
+        if len(gaps):
+            print(f"   median: row to row {np.median(gaps):.2f} us, the K pivots {np.median([b - a for a, b in rows]):.2f} us")
+        ph = x[8:15]
+        print("   row 4 as follower: inputs wanted %.2f, loaded %.2f, follow from %.2f, first row of the row before read %.2f, "
+              "half of its rows applied %.2f, last row read %.2f, ready to eliminate %.2f" % tuple(ph))
+    x = d[6] - t0
+    print(f"separator    start {x[0]:6.2f}  Q ready {x[1]:6.2f}  W built {x[3]:6.2f}  row s {x[4]:6.2f}  S' {x[5]:6.2f}  row s+1 {x[6]:6.2f}  solved+posted {x[2]:6.2f}")
+    sys.exit(0)
 names = ["P0 producer", "P3 producer", "J1 joiner", "J2 joiner", "spike J1", "spike J2", "separator"]
 for r in range(4):
     x = d[r] - t0
