@@ -59,7 +59,7 @@ struct PipeGeo {
 };
 
 struct PipeLds {   // offsets in doubles
-  int ring, stage, gbuf, xall, W, flags, end;
+  int ring, stage, gbuf, xhi, xall, W, flags, end;
 };
 template <int K>
 __host__ __device__ inline PipeLds pipe_layout(int n, bool spike) {
@@ -69,7 +69,12 @@ __host__ __device__ inline PipeLds pipe_layout(int n, bool spike) {
   L.ring = o; o += 3 * G::SLOT;
   L.stage = o; o += 2 * (G::NCX + (spike ? 2 * K : 0)) * G::GS + 2;   // (+ a dump double)
   L.gbuf = o; o += 2 * G::NGC * G::GS;
-  L.xall = o; o += (n + 2) * G::GS;
+  {   // the second follower's rows of the next block row, [column][row] (+ a dump column)
+    constexpr int NHI = K >= 3 ? K - ((((K + 1) / 2) + 1) & ~1) : 0;
+    L.xhi = o; o += (G::NCX + (spike ? 2 * K : 0) + 1) * (NHI + (NHI & 1)) + 2;
+  }
+  (void)n;
+  L.xall = o; o += (ND_MAXROWS + 2) * G::GS;   // rt of the chain's local rows (two leading zero rows)
   L.W = o; o += 2 * G::KE + 2;
   L.flags = o; o += 32;            // 64 ints
   L.end = o;
@@ -90,7 +95,9 @@ enum {
   PF_COPIED2 = 25,   // [3] spike columns likewise
   PF_ABORT = 28,     // a bounded wait ran out: everybody stops waiting
   PF_JOINCNT = 29,   // producer: wavefronts that have written their join contribution
-  PF_COUNT = 30
+  PF_HIDONE = 30,    // the second follower's (high) rows of row il are in the hand-over buffer (main columns)
+  PF_HIDONE2 = 31,   // (spike columns)
+  PF_COUNT = 32
 };
 
 constexpr int PIPE_SPIN_CAP = 1 << 17;   // polls (~150 cycles each with the sleep: ~10 ms) before a wait gives up
@@ -182,11 +189,14 @@ __device__ __forceinline__ double pipe_setlane(double v, int uhi, int ulo) {
 // `xj_p` are pivot J-1's - so that no instruction of the dependent chain pivot -> reciprocal -> next pivot ever
 // waits for an LDS read issued in the same step.  Row J+1 gets pivot J-1's term first, then pivot J's by
 // v_readlane, and is complete for the next reciprocal; rows J+2.. get pivot J-1's terms in the chain's shadow.)
-template <int K, int J>
+// `hook` runs once, at pivot JH, off the dependent chain: the eliminating wavefront takes in the high rows the
+// second follower accumulated (pipe_chain_wave).
+template <int K, int J, int JH, class Hook>
 __device__ __forceinline__ void pipe_pivot(double (&xr)[K], double inv, const double (&mu_p)[K], const double xj_p,
                                            double* __restrict__ rowp, double* __restrict__ rawp,
-                                           const double* __restrict__ slot0, const bool is63) {
+                                           const double* __restrict__ slot0, const bool is63, Hook hook, double* dbg = nullptr) {
   using G = PipeGeo<K>;
+  if ((J == 4 || J == 9 || J == 14 || J == K - 1) && dbg) dbg[J == K - 1 ? 3 : J / 5] = (double)wall_clock64();   // (option "solver_debug")
   // Two LDS writes per pivot, in this order and at once: the unscaled parts, then the scaled row whose lane 62 is
   // the "published" word the followers poll.  The fences are compiler barriers (the hardware executes a
   // wavefront's LDS operations in order): without them the compiler pairs the writes of two consecutive pivots
@@ -222,11 +232,12 @@ __device__ __forceinline__ void pipe_pivot(double (&xr)[K], double inv, const do
     xr[J + 1] = __builtin_fma(-m1, xj, xr[J + 1]);
     inv_next = pipe_rcp(rdlane(xr[J + 1], J + 1));
   }
+  if constexpr (J == JH) hook();
   if constexpr (J >= 1) {
 #pragma unroll
     for (int r = J + 2; r < K; ++r) xr[r] = __builtin_fma(-mu_p[r], xj_p, xr[r]);
   }
-  if constexpr (J + 1 < K) pipe_pivot<K, J + 1>(xr, inv_next, mu, xj, rowp, rawp, slot0, is63);
+  if constexpr (J + 1 < K) pipe_pivot<K, J + 1, JH>(xr, inv_next, mu, xj, rowp, rawp, slot0, is63, hook, dbg);
 }
 
 // K uniform multipliers [pos0, pos0 + K) of a published row (pos0 even): LDS broadcast reads, two per instruction
@@ -264,14 +275,89 @@ struct PipeArgs {
   double* ts;
 };
 
-// ---- a chain wavefront: set sigma (of three) handles the rows il = sigma, sigma + 3, ...; `spk` (compile time): this
-// wavefront carries the 2K spike columns, else the columns [S | H | E | y]
+// ---- a chain wavefront.  Three of them take turns: while one ELIMINATES row i (publishing every pivot row), the
+// other two FOLLOW it with the Schur update of row i+1, W_{i+1} -= Ht_i^T Dn [Ht_i | Et_i | rt_i], one half of
+// W's K rows each: the wavefront that eliminates row i+1 next takes rows 0 .. RLO-1, the one that has just
+// eliminated row i-1 takes rows RLO .. K-1 and hands them over through LDS.  (A follower's pivot step is K
+// double-precision FMAs per lane at 8 cycles each plus the multiplier reads - slower than the eliminating
+// wavefront's step; with one follower per row the chain ran at the follower's pace, 0.8 us behind every row.)
+// The high rows are subtracted a few pivots into the elimination (subtractions commute): the hand-over is off the
+// critical path.  `spk` (compile time): this wavefront carries the 2K spike columns, else [S | H | E | y].
+template <int K>
+struct PipeRows {
+  static constexpr int RLO = K >= 3 ? (((K + 1) / 2 + 1) & ~1) : K;   // even: the high rows' multipliers start 16-byte aligned
+  static constexpr int NHI = K - RLO;
+  static constexpr int JH = RLO >= 6 ? 4 : (RLO >= 2 ? RLO - 2 : 0);   // pivot at which the eliminating wavefront takes the high rows in
+  static constexpr int XS = NHI + (NHI & 1);                          // stride of a column in the hand-over buffer
+};
+
+// the follower's loop over the pivot rows of the row before (ring slot at `prow`): acc[r - R0] += mu_r * v for the rows
+// [R0, R0 + NR).  Software pipeline: the multipliers of pivot J + 1 are in flight while pivot J's terms are formed,
+// and ONE poll tells how many rows have been published (lane l watches row l's word), so a follower that is behind
+// does not poll at all.  `mid` runs once half-way.
+// how many leading rows of a ring slot are published (main words, and the spike words when `spk`): ONE LDS read -
+// lane l watches row l's main word, lane 32 + l its spike word
+template <int K, bool spk>
+struct PipeWatch {
+  pipe_lds_int* w;
+  int avail = 0;
+  __device__ __forceinline__ PipeWatch(const double* slot0) {
+    using G = PipeGeo<K>;
+    const int lane = threadIdx.x & 63;
+    w = (pipe_lds_int*)(slot0 + (lane < K ? lane * G::RS + G::od : (spk && lane >= 32 && lane < 32 + K) ? (lane - 32) * G::RS + G::og : G::oz)) + 1;
+  }
+  // returns once row J is published (bounded)
+  __device__ __forceinline__ void need(const PipeCtl& ctl, int J) {
+    int n = 0;
+    while (J >= avail) {
+      const unsigned long long pub = __builtin_amdgcn_ballot_w64((*w & 0x7ff80000) != 0x7ff80000);
+      const int a0 = __builtin_ctzll(~pub | (1ull << K)), a1 = __builtin_ctzll(~(pub >> 32) | (1ull << K));
+      avail = spk ? (a0 < a1 ? a0 : a1) : a0;
+      if (J < avail) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (pipe_giveup(ctl, ++n)) { avail = K; break; }
+    }
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  }
+};
+
+template <int K, int R0, int NR, bool spk, class Mid>
+__device__ __forceinline__ void pipe_follow(const PipeCtl& ctl, const double* __restrict__ prow, const int srcp, double (&acc)[NR > 0 ? NR : 1], Mid mid,
+                                            double* dbg = nullptr) {
+  using G = PipeGeo<K>;
+  constexpr int RS = G::RS;
+  static_assert((R0 & 1) == 0, "multiplier pairs");
+  const int lane = threadIdx.x & 63;
+  double mu[2][NR > 0 ? NR + 1 : 1], vv[2];
+  (void)lane;
+  PipeWatch<K, spk> watch(prow);
+  auto need = [&](int J) { watch.need(ctl, J); };
+  auto load = [&](int J, double (&m)[NR > 0 ? NR + 1 : 1], double& v) {
+    const double2* p2 = reinterpret_cast<const double2*>(prow + J * RS + G::oH + R0);
+#pragma unroll
+    for (int q = 0; q < (NR + 1) / 2; ++q) { const double2 t2 = p2[q]; m[2 * q] = t2.x; m[2 * q + 1] = t2.y; }
+    v = prow[J * RS + srcp];   // (unscaled: oRH / oRE / oRy; spike rows are published unscaled)
+  };
+  need(0);
+  load(0, mu[0], vv[0]);
+#pragma unroll
+  for (int J = 0; J < K; ++J) {
+    if (J + 1 < K) { need(J + 1); load(J + 1, mu[(J + 1) & 1], vv[(J + 1) & 1]); }
+    if (J == (K + 1) / 2) mid();
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = __builtin_fma(mu[J & 1][r], vv[J & 1], acc[r]);
+    if ((J == 4 || J == 9 || J == 14 || J == K - 1) && dbg) dbg[J == K - 1 ? 3 : J / 5] = (double)wall_clock64();   // (option "solver_debug")
+  }
+}
+
 template <int K, bool SPK, bool spk>
 __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCfg& cfg, const PipeLds& L, const PipeCtl& ctl,
                                                 const int sigma) {
   extern __shared__ double lds[];
   using G = PipeGeo<K>;
+  using R = PipeRows<K>;
   constexpr int ks = ldl_ks(K), RS = G::RS, GS = G::GS, NCS = G::NCX + (SPK ? 2 * K : 0);
+  constexpr int RLO = R::RLO, NHI = R::NHI;
   const int lane = threadIdx.x & 63;
   const bool producer = cfg.producer != 0;
   const int nloc = cfg.nloc, m_split = cfg.m_split;
@@ -279,13 +365,10 @@ __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCf
   double* ring = lds + L.ring;
   double* stg = lds + L.stage;
   double* gbuf = lds + L.gbuf;
+  double* xhi = lds + L.xhi;
   const double qnan = __builtin_nan("");
-  // =====================================================================================================
-  // Three sets: while one eliminates row i and the second follows it with row i+1, the third - which eliminated
-  // row i-1 - loads the inputs of row i+2 and is ready the moment row i+1 starts publishing (with two sets the
-  // follower started ~0.7 us behind the wavefront it follows and, running at the same pace, stayed there).
-    // this lane's column: position in a published row, column in the staging buffer / G, source position of
-  // the follower's update (what pivot row j of the row before contributes to this column)
+  // this lane's column: position in a published row, column in the staging buffer / G / the hand-over buffer,
+  // source position of the follower's update (what pivot row j of the row before contributes to this column)
   int pos, scol, gcol, src, rawpos = G::odump + (lane & 7);
   bool has_col = true;
   if (!spk) {
@@ -299,16 +382,19 @@ __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCf
     else { pos = (lane == 63) ? G::og : G::odump + (lane & 7); scol = -1; gcol = -1; src = -1; has_col = false; }
   }
   const int srcp = src >= 0 ? src : G::oz;
+  const int xcol = has_col ? scol : NCS;   // (lanes without a column: a dump column of the hand-over buffer)
   const int f_slotgen = spk ? PF_SLOTGEN2 : PF_SLOTGEN, f_rowdone = spk ? PF_ROWDONE2 : PF_ROWDONE;
-  const int f_initd = spk ? PF_INITD2 : PF_INITD;
+  const int f_initd = spk ? PF_INITD2 : PF_INITD, f_hidone = spk ? PF_HIDONE2 : PF_HIDONE;
   double xr[K];
-  for (int il = sigma; il < nrows; il += 3) {
-    const bool pseudo = il >= nloc;
-    const int slot = il % 3, pslot = (il + 2) % 3;   // ring slots of this row and of the row before
-    // option "solver_debug": phases of the fifth row of the chain (slots 8 .. 15 of the role's stamps)
-    auto pstamp = [&](int k) { if (!spk && cfg.ts && il == 4 && lane == 0) cfg.ts[8 + k] = (double)wall_clock64(); };
-    pstamp(0);
-    // ---- the row's inputs
+  double diag0 = 1.0;
+  auto publishes = [&](int il) { return il >= 0 && il < nloc; };   // (a producer's pseudo-rows publish nothing)
+  // the inputs of row il -> xr (staged by the I/O wavefront)
+  auto init_row = [&](int il) {
+    if (spk && il >= 2) {   // (only a chain's first two rows couple to the separator directly: the rest is fill-in)
+#pragma unroll
+      for (int r = 0; r < K; ++r) xr[r] = 0.0;
+      return;
+    }
     pipe_wait(ctl, PF_STAGED + (il & 1), il + 1);
     if (has_col) {
       const double2* s2 = reinterpret_cast<const double2*>(stg + (il & 1) * NCS * GS + scol * GS);
@@ -319,108 +405,135 @@ __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCf
 #pragma unroll
       for (int r = 0; r < K; ++r) xr[r] = 0.0;
     }
-    // the diagonal entry of the band block this lane's pivot starts from (pivot test below)
-    const double diag0 = (!spk && lane < K) ? stg[(il & 1) * NCS * GS + lane * GS + lane] : 1.0;
-    pipe_post(ctl, f_initd + (il & 1), il + 1);
-    pstamp(1);
-    auto reuse_check = [&]() {
-      // this row will be published into the ring slot of row il - 3: that row must have been consumed (checked
-      // half-way through the row before - it has long been, and the check is off the critical path)
-      if (il >= 3 && !pseudo) {
-        pipe_wait(ctl, PF_COPIED + slot, il - 2);
-        if (SPK) pipe_wait(ctl, PF_COPIED2 + slot, il - 2);
-        pipe_wait(ctl, PF_GDONE + ((il - 3) & 1), il - 2);
+    // the diagonal entry of the band block this lane's pivot starts from (pivot test after the elimination)
+    diag0 = (!spk && lane < K) ? stg[(il & 1) * NCS * GS + lane * GS + lane] : 1.0;
+    if (!spk) pipe_post(ctl, f_initd + (il & 1), il + 1);
+  };
+  // x[r] -= G[r] for r < nr (rows of this lane's column of G = Et^T Dn [Et | rt | Ft] of row il - 2, gbuf[il & 1])
+  auto sub_g = [&](int il, double (&x)[K], int nr) {
+    const double2* g2 = reinterpret_cast<const double2*>(gbuf + (il & 1) * G::NGC * GS + gcol * GS);
+#pragma unroll
+    for (int r2 = 0; r2 < (K + 1) / 2; ++r2) {
+      if (2 * r2 < nr) {
+        const double2 v = g2[r2];
+        x[2 * r2] -= v.x;
+        if (2 * r2 + 1 < nr && 2 * r2 + 1 < K) x[2 * r2 + 1] -= v.y;
       }
+    }
+  };
+  // follows row il - 1 with the HIGH rows of row il (which another wavefront will eliminate) and hands them over;
+  // `mid`: what this wavefront does for itself half-way (loading its own next row's inputs)
+  auto follow_high = [&](int il, auto mid) {
+    if (NHI == 0 || il >= nrows || !publishes(il - 1)) { mid(); return; }
+    const int pslot = (il + 2) % 3;
+    pipe_wait(ctl, PF_SLOTGEN + pslot, il);
+    if (spk) pipe_wait(ctl, PF_SLOTGEN2 + pslot, il);
+    double acc[NHI > 0 ? NHI : 1];
+#pragma unroll
+    for (int r = 0; r < NHI; ++r) acc[r] = 0.0;
+    pipe_follow<K, RLO, NHI, spk>(ctl, ring + pslot * G::SLOT, srcp, acc, [&] {
+      mid();
+      if (il >= 2 && gcol >= 0) {   // this half's share of G (added: the hand-over is subtracted)
+        pipe_wait(ctl, PF_GDONE + (il & 1), il - 1);
+        const double2* g2 = reinterpret_cast<const double2*>(gbuf + (il & 1) * G::NGC * GS + gcol * GS + RLO);
+#pragma unroll
+        for (int q = 0; q < (NHI + 1) / 2; ++q) {
+          const double2 v = g2[q];
+          acc[2 * q] += v.x;
+          if (2 * q + 1 < NHI) acc[2 * q + 1] += v.y;
+        }
+      }
+    });
+    // (the buffer's previous contents - row il - 1's high rows - were taken in by the wavefront that has just
+    // finished eliminating row il - 1)
+    double* dst = xhi + xcol * R::XS;
+#pragma unroll
+    for (int r = 0; r < NHI; ++r) dst[r] = acc[r];
+    pipe_post(ctl, f_hidone, il + 1);
+  };
+
+  if (sigma == 2) follow_high(1, [] {});   // (row 1's high rows: nobody has eliminated a row before row 0 yet)
+  if (sigma < nrows) init_row(sigma);
+  for (int il = sigma; il < nrows; il += 3) {
+    const bool pseudo = il >= nloc;
+    const int slot = il % 3, pslot = (il + 2) % 3;   // ring slots of this row and of the row before
+    // option "solver_debug": phases of the fifth row of the chain (slots 8 .. 15 of the role's stamps)
+    auto pstamp = [&](int k) { if (!spk && cfg.ts && il == 4 && lane == 0) cfg.ts[8 + k] = (double)wall_clock64(); };
+    pstamp(0);
+    const bool follow = publishes(il - 1);
+    const bool take_high = NHI > 0 && follow;   // the other follower's rows (with their share of G) arrive through the hand-over buffer
+    bool subg_done = il < 2;
+    auto subg = [&]() {   // the update by Et of two rows before: G from the matrix cores (the rows the other follower does not cover)
+      pipe_wait(ctl, PF_GDONE + (il & 1), il - 1);
+      if (gcol >= 0) sub_g(il, xr, take_high ? RLO : K);
+      subg_done = true;
     };
-    // ---- follower: the updates by the row before, pivot by pivot as wave A publishes them
-    const bool follow = il >= 1 && !(il - 1 >= nloc);   // (a pseudo-row publishes nothing)
+    // ---- join rows of a joiner: the producer's Schur-complement contributions to this row, fetched NOW - the
+    // producer chain (no spike columns) has long finished when the joiner arrives here, and the loads (19 per lane,
+    // a cold round trip to another workgroup's stores) then overlap the row this wavefront is about to follow.  One
+    // branch-free pass: every lane has a source (or a zero factor).
+    const bool joins = !producer && !spk && cfg.two && il >= m_split;
+    double xjoin[K];
+    if (joins) {
+      if (il == m_split) chain_ts(cfg, 1);
+      const bool ok = pipe_wait_global(ctl, A.flags, A.epoch, cfg.spin);
+      constexpr int wsz = (K + 2 * K + 1) * ks;
+      // X0: contributions to the join row next to the producer (+ the coupling of the two), X1: to the other
+      const int first = (il == m_split);
+      int off = 0, stride = 0;
+      double on = 0.0;
+      if (lane < K || lane == 3 * K) { off = (first ? wsz : 0) + lane * ks; stride = 1; on = 1.0; }       // S, y
+      else if (lane < 2 * K && first) { off = K * ks + (lane - K); stride = ks; on = 1.0; }                 // H(r, c) += H'(c, r)
+      off = pipe_opaque(off);
+      if (!ok) on = 0.0;
+#pragma unroll
+      for (int r = 0; r < K; ++r) xjoin[r] = A.xch[off + r * stride] * on;
+      if (il == m_split) chain_ts(cfg, 5);
+    }
+    if (il >= 3 && !pseudo) {
+      // this row will be published into the ring slot of row il - 3: that row must have been consumed.  It has
+      // long been, and here - before the row to follow has started - the check costs nothing.
+      pipe_wait(ctl, PF_COPIED + slot, il - 2);
+      pipe_wait(ctl, PF_GDONE + ((il - 3) & 1), il - 2);
+    }
+    // ---- follower of row il - 1: the LOW rows of this wavefront's own row
     if (follow) {
       pipe_wait(ctl, PF_SLOTGEN + pslot, il);
       if (spk) pipe_wait(ctl, PF_SLOTGEN2 + pslot, il);
-    }
-    const double* prow = ring + pslot * G::SLOT;
-    bool subg_done = il < 2;
-    auto subg = [&]() {   // the update by Et of two rows before: G from the matrix cores
-      pipe_wait(ctl, PF_GDONE + (il & 1), il - 1);
-      reuse_check();
-      if (gcol >= 0) {
-        const double2* g2 = reinterpret_cast<const double2*>(gbuf + (il & 1) * G::NGC * GS + gcol * GS);
-#pragma unroll
-        for (int r2 = 0; r2 < K / 2; ++r2) { const double2 v = g2[r2]; xr[2 * r2] -= v.x; xr[2 * r2 + 1] -= v.y; }
-        if (K & 1) xr[K - 1] -= gbuf[(il & 1) * G::NGC * GS + gcol * GS + K - 1];
-      }
-      subg_done = true;
-    };
-    if (follow) {
-      // The K rank-one terms are summed on their own and subtracted once, (C - G) - sum as penta_ldl_body's
-      // products phase does (subtracting them one by one from the band block rounds K times at the magnitude of C).
-      // Software pipeline: the multipliers of pivot J + 1 are in flight while pivot J's terms are formed, and ONE
-      // poll tells how many rows wave A has published (lane l watches row l's word), so a follower that is behind
-      // does not poll at all.
-      double acc[K], mu[2][K], vv[2];
-#pragma unroll
-      for (int r = 0; r < K; ++r) acc[r] = 0.0;
-      pipe_lds_int* watch = (pipe_lds_int*)(prow + (lane < K ? lane * RS + G::od : (spk && lane >= 32 && lane < 32 + K) ? (lane - 32) * RS + G::og : G::oz)) + 1;
-      int avail = 0;
-      auto need = [&](int J) {   // returns once row J is published (bounded)
-        int n = 0;
-        while (J >= avail) {
-          const unsigned long long pub = __builtin_amdgcn_ballot_w64((*watch & 0x7ff80000) != 0x7ff80000);
-          const int a0 = __builtin_ctzll(~pub | (1ull << K)), a1 = __builtin_ctzll(~(pub >> 32) | (1ull << K));
-          avail = spk ? (a0 < a1 ? a0 : a1) : a0;
-          if (J < avail) break;
-          __builtin_amdgcn_s_sleep(1);
-          if (pipe_giveup(ctl, ++n)) { avail = K; break; }
-        }
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);
-      };
-      auto load = [&](int J, double (&m)[K], double& v) {
-        pipe_read_mult<K>(prow + J * RS, G::oH, m);
-        v = prow[J * RS + srcp];   // (unscaled: oRH / oRE / oRy; spike rows are published unscaled)
-      };
       pstamp(2);
-      need(0);
-      load(0, mu[0], vv[0]);
-      pstamp(3);
+      double acc[RLO];
 #pragma unroll
-      for (int J = 0; J < K; ++J) {
-        if (J + 1 < K) { need(J + 1); load(J + 1, mu[(J + 1) & 1], vv[(J + 1) & 1]); }
-        if (J == (K + 1) / 2) pstamp(4);
-        if (J == K - 1) pstamp(5);
-        if (J == (K + 1) / 2 && !subg_done) subg();
-#pragma unroll
-        for (int r = 0; r < K; ++r) acc[r] = __builtin_fma(mu[J & 1][r], vv[J & 1], acc[r]);
-      }
+      for (int r = 0; r < RLO; ++r) acc[r] = 0.0;
+      pipe_follow<K, 0, RLO, spk>(ctl, ring + pslot * G::SLOT, srcp, acc, [&] { pstamp(4); subg(); },
+                                  (!spk && cfg.ts && il == 4 && lane == 0) ? cfg.ts + 20 : nullptr);
+      pstamp(5);
       if (!subg_done) subg();
+      // (C - G) - sum: the K rank-one terms are summed on their own and subtracted once, as penta_ldl_body's
+      // products phase does (subtracting them one by one rounds K times at the magnitude of C)
 #pragma unroll
-      for (int r = 0; r < K; ++r) xr[r] -= acc[r];
+      for (int r = 0; r < RLO; ++r) xr[r] -= acc[r];
       pstamp(6);
     }
     if (!subg_done) subg();
-    // ---- join rows of a joiner: the producer's Schur-complement contributions
-    if (!producer && !spk && cfg.two && il >= m_split) {
-      if (il == m_split) chain_ts(cfg, 1);
-      if (pipe_wait_global(ctl, A.flags, A.epoch, cfg.spin)) {
-        constexpr int wsz = (K + 2 * K + 1) * ks;
-        const double* X0 = A.xch;          // contributions to the join row next to the producer (+ the coupling of the two)
-        const double* X1 = A.xch + wsz;    // contributions to the other join row
-        const double* Xs = (il == m_split) ? X1 : X0;
-        const int lo = pipe_opaque(lane * ks), ho = pipe_opaque(K * ks + lane - K);
-        if (lane < K) {
+    auto high_rows = [&]() {
+      if (!take_high) return;
+      pipe_wait(ctl, f_hidone, il + 1);
+      const double2* x2 = reinterpret_cast<const double2*>(xhi + xcol * R::XS);
 #pragma unroll
-          for (int r = 0; r < K; ++r) xr[r] += Xs[lo + r];
-        } else if (lane == 3 * K) {
-#pragma unroll
-          for (int r = 0; r < K; ++r) xr[r] += Xs[lo + r];
-        } else if (lane < 2 * K && il == m_split) {   // H(r, c) += H'(c, r)
-#pragma unroll
-          for (int r = 0; r < K; ++r) xr[r] += X0[ho + r * ks];
-        }
+      for (int q = 0; q < (NHI + 1) / 2; ++q) {
+        const double2 v = x2[q];
+        xr[RLO + 2 * q] -= v.x;
+        if (2 * q + 1 < NHI) xr[RLO + 2 * q + 1] -= v.y;
       }
-      if (il == m_split) chain_ts(cfg, 5);
+    };
+    // ---- join rows of a joiner: the producer's Schur-complement contributions (fetched at the top of the iteration)
+    if (joins) {
+#pragma unroll
+      for (int r = 0; r < K; ++r) xr[r] += xjoin[r];
     }
     if (pseudo) {
       // ---- producer: hand the column over (layout of penta_ldl_body's exchange buffer)
+      high_rows();
       if (has_col) {
         const int wo = pipe_opaque((il - nloc) * (K + 2 * K + 1) * ks + lane * ks);   // column `lane` of [S | H | E | y]
 #pragma unroll
@@ -432,62 +545,76 @@ __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCf
         const int old = __hip_atomic_fetch_add(reinterpret_cast<int*>(lds + L.flags) + PF_JOINCNT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (old == 1) __hip_atomic_store(A.flags, A.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
-      continue;
-    }
-    // ---- wave A: eliminate, publishing every pivot row
-    double* rowp = ring + slot * G::SLOT + pos;
-    if (!spk && cfg.ts && lane == 0 && il < 20) cfg.ts[24 + 2 * il] = (double)wall_clock64();   // option "solver_debug": elimination of row il starts ...
-    if (lane < K) ring[slot * G::SLOT + lane * RS + (spk ? G::og : G::od)] = qnan;
-    pipe_post(ctl, f_slotgen + slot, il + 1);
-    if (!spk) {
-      {
-        double mu0[K];
-#pragma unroll
-        for (int r = 0; r < K; ++r) mu0[r] = 0.0;
-        pipe_pivot<K, 0>(xr, pipe_rcp(rdlane(xr[0], 0)), mu0, 0.0, rowp, ring + slot * G::SLOT + rawpos, ring + slot * G::SLOT, lane == 63);
-      }
-      pipe_post(ctl, f_rowdone + slot, il + 1);
-      if (cfg.ts && lane == 0 && il < 20) cfg.ts[25 + 2 * il] = (double)wall_clock64();   // ... and ends
-      // factorisation status (the reference reports kFailure from Factorize: penta_diagonal_solver.h:181-185,
-      // trajectory_optimizer.cc:2084): every pivot positive, finite, and not cancelled to nothing against the
-      // diagonal entry of H it started from (d <= eps H_ll: H is not numerically positive definite)
-      const double il_ = (lane < K) ? ring[slot * G::SLOT + lane * RS + G::oi] : 1.0;   // 1 / d: NaN for d = 0 / inf / NaN
-      const bool bad = lane < K && !(il_ > 0.0 && il_ * diag0 < 4503599627370496.0);
-      if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) {
-        __hip_atomic_store(A.status, A.fact_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_fetch_add(A.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (cfg.ts) cfg.ts[20] = (double)(il + 1);
-      }
     } else {
-      // spike columns: Ft = L^-1 F with the multipliers D^-1 U the main wavefront publishes; rows go out raw
-      const double* arow = ring + slot * G::SLOT;
-      pipe_wait(ctl, PF_SLOTGEN + slot, il + 1);
-      pipe_lds_int* watch = (pipe_lds_int*)(arow + (lane < K ? lane * RS + G::od : G::oz)) + 1;
-      int avail = 0;
+      // ---- eliminate, publishing every pivot row
+      double* rowp = ring + slot * G::SLOT + pos;
+      if (!spk && cfg.ts && lane == 0 && il < 20) cfg.ts[24 + 2 * il] = (double)wall_clock64();   // option "solver_debug": elimination of row il starts ...
+      if (lane < K) ring[slot * G::SLOT + lane * RS + (spk ? G::og : G::od)] = qnan;
+      pipe_post(ctl, f_slotgen + slot, il + 1);
+      if (!spk) {
+        {
+          double mu0[K];
 #pragma unroll
-      for (int J = 0; J < K; ++J) {
-        for (int n = 0; J >= avail;) {   // one poll covers every row the main wavefront has published
-          avail = __builtin_ctzll(~__builtin_amdgcn_ballot_w64((*watch & 0x7ff80000) != 0x7ff80000) | (1ull << K));
-          if (J < avail) break;
-          __builtin_amdgcn_s_sleep(1);
-          if (pipe_giveup(ctl, ++n)) { avail = K; break; }
+          for (int r = 0; r < K; ++r) mu0[r] = 0.0;
+          pipe_pivot<K, 0, R::JH>(xr, pipe_rcp(rdlane(xr[0], 0)), mu0, 0.0, rowp, ring + slot * G::SLOT + rawpos, ring + slot * G::SLOT,
+                                  lane == 63, high_rows, (cfg.ts && il == 3 && lane == 0) ? cfg.ts + 16 : nullptr);
         }
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        rowp[J * RS] = pipe_setlane<63>(xr[J], 0x3ff00000, 0);
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        if (J + 1 < K) {
-          // multipliers T_J[c], c = J+1 .. K-1 (pairs from the even position below J+1)
-          const double2* p2 = reinterpret_cast<const double2*>(arow + J * RS);
+        pipe_post(ctl, f_rowdone + slot, il + 1);
+        if (cfg.ts && lane == 0 && il < 20) cfg.ts[25 + 2 * il] = (double)wall_clock64();   // ... and ends
+        // factorisation status (the reference reports kFailure from Factorize: penta_diagonal_solver.h:181-185,
+        // trajectory_optimizer.cc:2084): every pivot positive, finite, and not cancelled to nothing against the
+        // diagonal entry of H it started from (d <= eps H_ll: H is not numerically positive definite)
+        const double il_ = (lane < K) ? ring[slot * G::SLOT + lane * RS + G::oi] : 1.0;   // 1 / d: NaN for d = 0 / inf / NaN
+        const bool bad = lane < K && !(il_ > 0.0 && il_ * diag0 < 4503599627370496.0);
+        if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) {
+          __hip_atomic_store(A.status, A.fact_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_fetch_add(A.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (cfg.ts) cfg.ts[7] = (double)(il + 1);
+        }
+      } else {
+        // spike columns: Ft = L^-1 F with the multipliers D^-1 U the main wavefront publishes; rows go out unscaled
+        const double* arow = ring + slot * G::SLOT;
+        double* fout = A.fst + (size_t)il * A.fstride + pipe_opaque(lane * ks);
+        pipe_wait(ctl, PF_SLOTGEN + slot, il + 1);
+        pipe_lds_int* watch = (pipe_lds_int*)(arow + (lane < K ? lane * RS + G::od : G::oz)) + 1;
+        int avail = 0;
 #pragma unroll
-          for (int m = (J + 1) / 2; m < (K + 1) / 2; ++m) {
-            const double2 v = p2[m];
-            if (2 * m > J) xr[2 * m] = __builtin_fma(-v.x, xr[J], xr[2 * m]);
-            if (2 * m + 1 < K) xr[2 * m + 1] = __builtin_fma(-v.y, xr[J], xr[2 * m + 1]);
+        for (int J = 0; J < K; ++J) {
+          if (J == R::JH) high_rows();
+          for (int n = 0; J >= avail;) {   // one poll covers every row the main wavefront has published
+            avail = __builtin_ctzll(~__builtin_amdgcn_ballot_w64((*watch & 0x7ff80000) != 0x7ff80000) | (1ull << K));
+            if (J < avail) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (pipe_giveup(ctl, ++n)) { avail = K; break; }
+          }
+          __atomic_signal_fence(__ATOMIC_SEQ_CST);
+          rowp[J * RS] = pipe_setlane<63>(xr[J], 0x3ff00000, 0);
+          __atomic_signal_fence(__ATOMIC_SEQ_CST);
+          if (lane < 2 * K) fout[J] = xr[J];   // (and to HBM for the separator's Q / this chain's own correction: column `lane`, row J)
+          if (J + 1 < K) {
+            // multipliers T_J[c], c = J+1 .. K-1 (pairs from the even position below J+1)
+            const double2* p2 = reinterpret_cast<const double2*>(arow + J * RS);
+#pragma unroll
+            for (int m = (J + 1) / 2; m < (K + 1) / 2; ++m) {
+              const double2 v = p2[m];
+              if (2 * m > J) xr[2 * m] = __builtin_fma(-v.x, xr[J], xr[2 * m]);
+              if (2 * m + 1 < K) xr[2 * m + 1] = __builtin_fma(-v.y, xr[J], xr[2 * m + 1]);
+            }
           }
         }
+        pipe_post(ctl, f_rowdone + slot, il + 1);
+        // the row's spike block is in HBM: one of the three releases the separator waits for (the I/O wavefront
+        // adds two with 1 / d and rt)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(A.frowcnt + il, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
-      pipe_post(ctl, f_rowdone + slot, il + 1);
     }
+    // ---- follower of row il + 1: the HIGH rows of row il + 2 for the wavefront that eliminates it; half-way,
+    // this wavefront's own next row's inputs
+    bool inited = false;
+    follow_high(il + 2, [&] { if (il + 3 < nrows) init_row(il + 3); inited = true; });
+    if (!inited && il + 3 < nrows) init_row(il + 3);
   }
 }
 
@@ -527,7 +654,7 @@ __device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& 
   } else if (wave == W_IO) {
     // =====================================================================================================
     // I/O wavefront: stages the band blocks of row t + 2 (column layout), writes the factors of row t out
-    constexpr int PM = (NCS * K + 63) / 64;
+    constexpr int PM = (G::NCX * K + 63) / 64;   // (the spike columns' inputs: only rows 0 and 1, below)
     const int dHB = (int)(A.HB - A.HA), dHC = (int)(A.HC - A.HA);
     // per-lane slots (fixed over the rows): source offset relative to the row's A block (or to its right-hand
     // side), destination in the staging buffer, which part the element belongs to
@@ -537,7 +664,7 @@ __device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& 
 #pragma unroll
     for (int s = 0; s < PM; ++s) {
       const int e = lane + 64 * s;
-      const bool valid = e < NCS * K;
+      const bool valid = e < G::NCX * K;
       const int c = valid ? e / K : 0, r = valid ? e - c * K : 0;
       s_dst[s] = valid ? c * GS + r : 2 * NCS * GS;   // (one dump double behind the two staging buffers)
       s_off[s] = 0;
@@ -597,8 +724,15 @@ __device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& 
         A.Est[(size_t)o * K * ks + idx] = in ? row[G::oE + c] : 0.0;
       }
       if (lane < K) {
-        if (!SPK) A.Dst[(size_t)o * K + lane] = row0[lane * RS + G::oi];
-        lds[L.xall + (il + 2) * ks + lane] = row0[lane * RS + G::oRy];   // rt (unscaled) for the back substitution
+        const double rt = row0[lane * RS + G::oRy];
+        A.Dst[(size_t)o * K + lane] = row0[lane * RS + G::oi];
+        lds[L.xall + (il + 2) * ks + lane] = rt;   // rt (unscaled) for the back substitution
+        if (SPK) A.fst[(size_t)il * A.fstride + 2 * K * ks + lane] = rt;   // ... and as column 2K of the spike block
+      }
+      if (SPK) {   // two of the three releases of the row (the spike wavefront adds the third)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(A.frowcnt + il, 2ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
     };
     stage_row(0);
@@ -607,7 +741,6 @@ __device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& 
     for (int t = 0; t < nrows; ++t) {
       if (t + 2 < nrows) {
         pipe_wait(ctl, PF_INITD + (t & 1), t + 1);
-        if (SPK) pipe_wait(ctl, PF_INITD2 + (t & 1), t + 1);
         stage_row(t + 2);
         pipe_post(ctl, PF_STAGED + (t & 1), t + 3);
       }
@@ -628,52 +761,47 @@ __device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& 
     const int fl = lane & 15, fk = lane >> 4;
     for (int t = 0; t < nloc; ++t) {
       const int slot = t % 3;
-      pipe_wait(ctl, PF_ROWDONE + slot, t + 1);
-      if (SPK) pipe_wait(ctl, PF_ROWDONE2 + slot, t + 1);
       const double* row0 = ring + slot * G::SLOT;
       if (t + 2 < nrows) {   // (else nobody is two rows ahead)
-        double* gout = gbuf + (t & 1) * G::NGC * GS;
-        double a[TT][SK];
+        // The products run WHILE the row is being eliminated: k-step sq (pivot rows 4 sq .. 4 sq + 3) as soon as
+        // those rows are published, so that G is complete a k-step after the row's last pivot and the followers
+        // of the row after next can take it in early.
+        pipe_wait(ctl, PF_SLOTGEN + slot, t + 1);
+        if (SPK) pipe_wait(ctl, PF_SLOTGEN2 + slot, t + 1);
+        PipeWatch<K, SPK> watch(row0);
+        d4 acc[CT][TT];
+#pragma unroll
+        for (int tc = 0; tc < CT; ++tc)
+#pragma unroll
+          for (int tr = 0; tr < TT; ++tr) acc[tc][tr] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int sq = 0; sq < SK; ++sq) {
+          watch.need(ctl, (4 * sq + 3 < K ? 4 * sq + 3 : K - 1));
           const double* row = row0 + (4 * sq + fk) * RS;   // (pad rows: zeros)
+          double a[TT], bq[CT];
 #pragma unroll
-          for (int tr = 0; tr < TT; ++tr) a[tr][sq] = row[G::oE + 16 * tr + fl];
+          for (int tr = 0; tr < TT; ++tr) a[tr] = row[G::oE + 16 * tr + fl];
+#pragma unroll
+          for (int tc = 0; tc < CT; ++tc) {
+            const int ci = 16 * tc + fl;                                                // column of G
+            bq[tc] = row[ci < G::KE + 2 ? G::oRE + ci : G::oF + ci - (G::KE + 2)];       // where its operand sits in a row
+          }
+#pragma unroll
+          for (int tc = 0; tc < CT; ++tc)
+#pragma unroll
+            for (int tr = 0; tr < TT; ++tr) acc[tc][tr] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tr], bq[tc], acc[tc][tr], 0, 0, 0);
         }
-        for (int tc = 0; tc < CT; ++tc) {
-          const int ci = 16 * tc + fl;                                                // column of G
-          const int bpos = ci < G::KE + 2 ? G::oRE + ci : G::oF + ci - (G::KE + 2);   // where its operand sits in a row
-          double bq[SK];
+        double* gout = gbuf + (t & 1) * G::NGC * GS;
 #pragma unroll
-          for (int sq = 0; sq < SK; ++sq) bq[sq] = row0[(4 * sq + fk) * RS + bpos];
+        for (int tc = 0; tc < CT; ++tc)
 #pragma unroll
-          for (int tr = 0; tr < TT; ++tr) {
-            d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int sq = 0; sq < SK; ++sq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tr][sq], bq[sq], acc, 0, 0, 0);
+          for (int tr = 0; tr < TT; ++tr)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-              const int r = 16 * tr + fk + 4 * rg;
-              if (r < K && ci < NCG) gout[ci * GS + r] = acc[rg];
+              const int r = 16 * tr + fk + 4 * rg, ci = 16 * tc + fl;
+              if (r < K && ci < NCG) gout[ci * GS + r] = acc[tc][tr][rg];
             }
-          }
-        }
         pipe_post(ctl, PF_GDONE + (t & 1), t + 1);
-      }
-      if (SPK) {
-        // [Ft | rt] of the row to HBM for the separator's Q (and this chain's own correction), 1 / d with them
-        const int o = orig(t);
-        double* dst = A.fst + (size_t)t * A.fstride;
-        for (int idx = lane; idx < (2 * K + 1) * K; idx += 64) {
-          const int c = idx / K, r = idx - c * K;
-          const double* row = row0 + r * RS;
-          dst[c * ks + r] = (c < 2 * K) ? row[G::oF + c] : row[G::oRy];
-        }
-        if (lane < K) A.Dst[(size_t)o * K + lane] = row0[lane * RS + G::oi];
-        pipe_post(ctl, PF_COPIED2 + slot, t + 1);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(A.frowcnt + t, 3ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }

@@ -29,6 +29,8 @@ if dev.get_option("last_solver") == 4:   # pipelined chains (csrc/penta_pipe.h):
         print("   elimination of row il (start, end):", " ".join(f"({a:5.2f},{b:5.2f})" for a, b in rows))
         if len(gaps):
             print(f"   median: row to row {np.median(gaps):.2f} us, the K pivots {np.median([b - a for a, b in rows]):.2f} us")
+        print("   pivots 4, 9, 14, last: row 3 published at %.2f %.2f %.2f %.2f, row 4's follower had applied them at %.2f %.2f %.2f %.2f"
+              % (tuple(x[16:20]) + tuple(x[20:24])))
         ph = x[8:15]
         print("   row 4 as follower: inputs wanted %.2f, loaded %.2f, follow from %.2f, first row of the row before read %.2f, "
               "half of its rows applied %.2f, last row read %.2f, ready to eliminate %.2f" % tuple(ph))
