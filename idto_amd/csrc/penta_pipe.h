@@ -196,12 +196,22 @@ __device__ __forceinline__ void pipe_pivot(double (&xr)[K], double inv, const do
                                            double* __restrict__ rowp, double* __restrict__ rawp,
                                            const double* __restrict__ slot0, const bool is63, Hook hook, double* dbg = nullptr) {
   using G = PipeGeo<K>;
-  if ((J == 4 || J == 9 || J == 14 || J == K - 1) && dbg) dbg[J == K - 1 ? 3 : J / 5] = (double)wall_clock64();   // (option "solver_debug")
+  (void)dbg;
   // Two LDS writes per pivot, in this order and at once: the unscaled parts, then the scaled row whose lane 62 is
   // the "published" word the followers poll.  The fences are compiler barriers (the hardware executes a
   // wavefront's LDS operations in order): without them the compiler pairs the writes of two consecutive pivots
   // into one ds_write2_b64 - a row would go out a pivot late, and the word could overtake the unscaled parts.
   const double xj = xr[J];
+  // The dependent chain of the factorisation is  1/d_J -> d_{J+1} -> 1/d_{J+1}.  d_{J+1} = S[J+1][J+1] - U[J][J+1]^2 / d_J
+  // sits in lane J+1 and needs nothing but that lane's own registers and 1/d_J: it is formed HERE, before the
+  // scaled row, its publication and the broadcast of the next multiplier - all of which then run beside the chain
+  // instead of inside it (the same value reaches xr[J+1] the usual way below; the two differ by a rounding).
+  double inv_next = 1.0;
+  if constexpr (J + 1 < K) {
+    if constexpr (J >= 1) xr[J + 1] = __builtin_fma(-mu_p[J + 1], xj_p, xr[J + 1]);   // pivot J-1's term (its multiplier was read a step ago)
+    const double dn = __builtin_fma(-(xj * xj), inv, xr[J + 1]);
+    inv_next = pipe_rcp(rdlane(dn, J + 1));
+  }
   rawp[J * G::RS] = xj;   // (columns of H, E, y: the unscaled pivot row; other lanes: a dump position)
   __atomic_signal_fence(__ATOMIC_SEQ_CST);
   double t = xj * inv;
@@ -215,7 +225,6 @@ __device__ __forceinline__ void pipe_pivot(double (&xr)[K], double inv, const do
   }
   rowp[J * G::RS] = t;
   __atomic_signal_fence(__ATOMIC_SEQ_CST);
-  double inv_next = 1.0;
   double mu[K];
   if constexpr (J + 2 < K) {   // the multipliers of rows J+2 .. K-1, back from the row just written
     const double2* p2 = reinterpret_cast<const double2*>(slot0 + J * G::RS);
@@ -227,16 +236,17 @@ __device__ __forceinline__ void pipe_pivot(double (&xr)[K], double inv, const do
     }
   }
   if constexpr (J + 1 < K) {
-    if constexpr (J >= 1) xr[J + 1] = __builtin_fma(-mu_p[J + 1], xj_p, xr[J + 1]);
     const double m1 = rdlane(t, J + 1);
     xr[J + 1] = __builtin_fma(-m1, xj, xr[J + 1]);
-    inv_next = pipe_rcp(rdlane(xr[J + 1], J + 1));
   }
   if constexpr (J == JH) hook();
   if constexpr (J >= 1) {
 #pragma unroll
     for (int r = J + 2; r < K; ++r) xr[r] = __builtin_fma(-mu_p[r], xj_p, xr[r]);
   }
+  // (keep the steps apart: left to itself the scheduler defers a row's updates until the row becomes the pivot
+  // row - a chain of dependent FMAs into one accumulator right where the next pivot waits for it)
+  __builtin_amdgcn_sched_barrier(0);
   if constexpr (J + 1 < K) pipe_pivot<K, J + 1, JH>(xr, inv_next, mu, xj, rowp, rawp, slot0, is63, hook, dbg);
 }
 
@@ -301,7 +311,8 @@ template <int K, bool spk>
 struct PipeWatch {
   pipe_lds_int* w;
   int avail = 0;
-  __device__ __forceinline__ PipeWatch(const double* slot0) {
+  bool spk_wg;   // the workgroup carries spike columns (all eight wavefronts busy)
+  __device__ __forceinline__ PipeWatch(const double* slot0, bool spk_wg_) : spk_wg(spk_wg_) {
     using G = PipeGeo<K>;
     const int lane = threadIdx.x & 63;
     w = (pipe_lds_int*)(slot0 + (lane < K ? lane * G::RS + G::od : (spk && lane >= 32 && lane < 32 + K) ? (lane - 32) * G::RS + G::og : G::oz)) + 1;
@@ -314,14 +325,17 @@ struct PipeWatch {
       const int a0 = __builtin_ctzll(~pub | (1ull << K)), a1 = __builtin_ctzll(~(pub >> 32) | (1ull << K));
       avail = spk ? (a0 < a1 ? a0 : a1) : a0;
       if (J < avail) break;
-      __builtin_amdgcn_s_sleep(1);
+      // (a poll is an LDS round trip and the row it waits for ~100 ns away: no nap where the wavefront has its SIMD to
+      // itself; in the joiner workgroups two wavefronts share a SIMD, and a spinning follower takes issue slots from
+      // the eliminating wavefront next to it - measured: rows 3.3 -> 4.0 us)
+      if (spk_wg) __builtin_amdgcn_s_sleep(1);
       if (pipe_giveup(ctl, ++n)) { avail = K; break; }
     }
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
   }
 };
 
-template <int K, int R0, int NR, bool spk, class Mid>
+template <int K, int R0, int NR, bool spk, bool SPKWG, class Mid>
 __device__ __forceinline__ void pipe_follow(const PipeCtl& ctl, const double* __restrict__ prow, const int srcp, double (&acc)[NR > 0 ? NR : 1], Mid mid,
                                             double* dbg = nullptr) {
   using G = PipeGeo<K>;
@@ -330,7 +344,7 @@ __device__ __forceinline__ void pipe_follow(const PipeCtl& ctl, const double* __
   const int lane = threadIdx.x & 63;
   double mu[2][NR > 0 ? NR + 1 : 1], vv[2];
   (void)lane;
-  PipeWatch<K, spk> watch(prow);
+  PipeWatch<K, spk> watch(prow, SPKWG);
   auto need = [&](int J) { watch.need(ctl, J); };
   auto load = [&](int J, double (&m)[NR > 0 ? NR + 1 : 1], double& v) {
     const double2* p2 = reinterpret_cast<const double2*>(prow + J * RS + G::oH + R0);
@@ -390,9 +404,24 @@ __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCf
   auto publishes = [&](int il) { return il >= 0 && il < nloc; };   // (a producer's pseudo-rows publish nothing)
   // the inputs of row il -> xr (staged by the I/O wavefront)
   auto init_row = [&](int il) {
-    if (spk && il >= 2) {   // (only a chain's first two rows couple to the separator directly: the rest is fill-in)
+    if (spk) {
+      // coupling of this chain's first two rows to the separator rows (nearest first), see penta_nd.h:
+      //   row 0: [coupling(row 0, nearest) | coupling(row 0, farthest)],  row 1: [coupling(row 1, nearest) | 0];
+      // every other row's spike block is fill-in and starts from zero.  Straight from the band arrays.
+      const int k = A.k, kk = k * k, dHB = (int)(A.HB - A.HA);
+      const bool mir = cfg.mirror != 0;
+      const int f = lane, ff = f < K ? f : f - K;
+      const bool on = lane < 2 * K && (il == 0 || (il == 1 && f < K));
+      int off = 0, stride = 0;
+      if (on) {
+        if (il == 0) { off = mir ? (f < K ? dHB + kk : 2 * kk) + ff : (f < K ? dHB : 0) + ff * k; }
+        else { off = mir ? 2 * kk + ff : ff * k; }
+        stride = mir ? k : 1;
+      }
+      const int o = mir ? cfg.base - il : cfg.base + il;
+      const double* base = A.HA + (size_t)(o < 0 ? 0 : o) * kk + pipe_opaque(off);
 #pragma unroll
-      for (int r = 0; r < K; ++r) xr[r] = 0.0;
+      for (int r = 0; r < K; ++r) xr[r] = (il < 2 && on) ? base[r * stride] : 0.0;
       return;
     }
     pipe_wait(ctl, PF_STAGED + (il & 1), il + 1);
@@ -431,7 +460,7 @@ __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCf
     double acc[NHI > 0 ? NHI : 1];
 #pragma unroll
     for (int r = 0; r < NHI; ++r) acc[r] = 0.0;
-    pipe_follow<K, RLO, NHI, spk>(ctl, ring + pslot * G::SLOT, srcp, acc, [&] {
+    pipe_follow<K, RLO, NHI, spk, SPK>(ctl, ring + pslot * G::SLOT, srcp, acc, [&] {
       mid();
       if (il >= 2 && gcol >= 0) {   // this half's share of G (added: the hand-over is subtracted)
         pipe_wait(ctl, PF_GDONE + (il & 1), il - 1);
@@ -504,7 +533,7 @@ __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCf
       double acc[RLO];
 #pragma unroll
       for (int r = 0; r < RLO; ++r) acc[r] = 0.0;
-      pipe_follow<K, 0, RLO, spk>(ctl, ring + pslot * G::SLOT, srcp, acc, [&] { pstamp(4); subg(); },
+      pipe_follow<K, 0, RLO, spk, SPK>(ctl, ring + pslot * G::SLOT, srcp, acc, [&] { pstamp(4); if (!subg_done) subg(); },
                                   (!spk && cfg.ts && il == 4 && lane == 0) ? cfg.ts + 20 : nullptr);
       pstamp(5);
       if (!subg_done) subg();
@@ -640,12 +669,20 @@ __device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& 
   PipeCtl ctl{(pipe_lds_int*)(lds + L.flags), A.status, A.fact_id};
   const double qnan = __builtin_nan("");
 
-  // ---- setup: zero everything (pad rows / columns of the ring must be exact zeros), flags
-  for (int idx = tid; idx < L.end; idx += blockDim.x) lds[idx] = 0.0;
+  // ---- setup: what must be exact zeros - the flags, the pad rows of the ring slots (the matrix cores' k-steps read
+  // them) and the position `oz` of every row, the rt rows - nothing else (LDS is 150 KB here; everything else is
+  // written before it is read)
+  for (int idx = tid; idx < 32; idx += blockDim.x) lds[L.flags + idx] = 0.0;
+  for (int idx = tid; idx < 3 * (G::KR - K) * RS; idx += blockDim.x) {
+    const int sl = idx / ((G::KR - K) * RS), e = idx - sl * (G::KR - K) * RS;
+    ring[sl * G::SLOT + K * RS + e] = 0.0;
+  }
+  for (int idx = tid; idx < 3 * K; idx += blockDim.x) ring[(idx / K) * G::SLOT + (idx % K) * RS + G::oz] = 0.0;
+  for (int idx = tid; idx < (ND_MAXROWS + 2) * GS; idx += blockDim.x) lds[L.xall + idx] = 0.0;
   __syncthreads();
   chain_ts(cfg, 0);
 
-  constexpr int W_SPK0 = 3, W_IO = SPK ? 6 : 3, W_G = SPK ? 7 : 4;
+  constexpr int W_SPK0 = 3, W_IO = SPK ? 6 : 3, W_G = 7;   // (G on the SIMD it shares with the I/O or a spike wavefront, not with a main one)
 
   if (wave < 3) {
     pipe_chain_wave<K, SPK, false>(A, cfg, L, ctl, wave);
@@ -695,21 +732,6 @@ __device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& 
         double v = (mY >> s & 1) ? A.rhs_sign * val[s] : val[s];
         v = (kill >> s & 1) ? 0.0 : v;
         if (s_dst[s] < 2 * NCS * GS) dst[s_dst[s]] = v;
-      }
-      if (SPK && il < 2) {
-        // coupling of this chain's first two rows to the separator rows (nearest first), see penta_nd.h:
-        //   row 0: [coupling(row 0, nearest) | coupling(row 0, farthest)],  row 1: [coupling(row 1, nearest) | 0]
-        for (int e = lane; e < 2 * KK; e += 64) {
-          const int f = e / K, r = e - f * K, ff = f < K ? f : f - K;
-          double v = 0.0;
-          if (il == 0) {
-            if (!mirror) v = (f < K) ? base[dHB + ff * k + r] : base[ff * k + r];
-            else v = (f < K) ? base[dHB + kk + r * k + ff] : base[2 * kk + r * k + ff];
-          } else if (f < K) {
-            v = mirror ? base[2 * kk + r * k + ff] : base[ff * k + r];
-          }
-          dst[(G::NCX + f) * GS + r] = v;
-        }
       }
     };
     auto copy_row = [&](int il) {
@@ -768,7 +790,7 @@ __device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& 
         // of the row after next can take it in early.
         pipe_wait(ctl, PF_SLOTGEN + slot, t + 1);
         if (SPK) pipe_wait(ctl, PF_SLOTGEN2 + slot, t + 1);
-        PipeWatch<K, SPK> watch(row0);
+        PipeWatch<K, SPK> watch(row0, true);
         d4 acc[CT][TT];
 #pragma unroll
         for (int tc = 0; tc < CT; ++tc)
