@@ -835,6 +835,185 @@ __device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& 
   chain_ts(cfg, 2);
 }
 
+// ---- back substitution of a chain in recursion form.
+// penta_ldl_tail solves  U_i x_i = Dn rt_i - (Dn Ht_i) x_{i+1} - (Dn Et_i) x_{i+2}  row after row: K dependent
+// (v_readlane, FMA) steps per block row on one wavefront, 0.8 us per row, all of it on the critical path after the
+// separator has answered.  But a chain's workgroup is IDLE between the end of its forward pass and that answer
+// (10 us for the joiners, 25 us for the producers).  In that time all its wavefronts form, for every row at once,
+//   [Y_i | Z_i | c_i | W_i] = U_i^-1 [Dn Ht_i | Dn Et_i | Dn rt_i | Dn Ft_i]
+// (K back substitutions with one column per lane, the reference's Y_i, Z_i: optimizer/penta_diagonal_solver.h:160-178),
+// so that what remains afterwards is  c_i -= W_i x_sep  (all rows in parallel) and
+//   x_i = c_i - Y_i x_{i+1} - Z_i x_{i+2},
+// two dense K x K mat-vecs per row with x passed through LDS: ~0.12 us per row.
+// LDS (everything the forward pass used is free): per local row [Y | Z] row-major (stride 2 KE), W likewise, c.
+template <int K, bool SPK>
+struct PipeBack {
+  static constexpr int KE = K + (K & 1), YS = 2 * KE > ldl_ks(K) ? 2 * KE : ldl_ks(K);   // (a row-major block also stages D^-1 U, stride ks)
+  static constexpr int oYZ = 0, oW = K * YS, oC = oW + (SPK ? K * YS : 0), BS = oC + KE;
+};
+
+template <int K, bool SPK>
+__device__ __forceinline__ bool pipe_backward_fits(const PipeLds& L, int nloc) { return nloc * PipeBack<K, SPK>::BS + 4 * PipeBack<K, SPK>::KE + 2 <= L.xall; }
+
+template <int K, bool SPK>
+__device__ __forceinline__ void pipe_backward(const PipeArgs& A, const ChainCfg& cfg, const PipeLds& L) {
+  extern __shared__ double lds[];
+  using B = PipeBack<K, SPK>;
+  constexpr int ks = ldl_ks(K), KE = B::KE, YS = B::YS, KS2 = K * ks;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
+  const bool mirror = cfg.mirror != 0, producer = cfg.producer != 0;
+  const int nloc = cfg.nloc, m_split = cfg.m_split, k = A.k;
+  auto orig = [&](int il) { const int o = mirror ? cfg.base - il : cfg.base + il; return o < 0 ? 0 : o; };
+  double* xb = lds + nloc * B::BS;   // [4][KE]: x of the last rows, for the broadcast reads
+  // ---- phase 1 (no dependence on other workgroups): the recursion matrices of every row, rows over wavefronts.
+  // Two passes ([Y | Z | c], then W): one pass with both solves keeps 2 x 171 multipliers alive in the compiler's eyes.
+  // (Branch-free: every lane loads from somewhere and stores somewhere - a dump double behind the x ring for the lanes
+  // without a column - or the register allocator loses the row vector to scratch in the exec-mask maze.)
+  double* dump = xb + 4 * KE;
+  auto solve = [&](const double* Us, double (&xr)[K]) __attribute__((always_inline)) {   // xr <- U^-1 xr, U = I + strictly upper (rows of Us), bottom row first
+    constexpr int NP = (K + 1) / 2;
+    double2 ub[2][NP];   // the multipliers of a row are read while the row below is applied
+    auto loadu = [&](int r, double2 (&u)[NP]) __attribute__((always_inline)) {
+      const double2* u2 = reinterpret_cast<const double2*>(Us + r * ks);
+#pragma unroll
+      for (int m = (r + 1) / 2; m < NP; ++m) u[m] = u2[m];
+    };
+    if (K >= 2) loadu(K - 2, ub[0]);
+#pragma unroll
+    for (int q = 0; q < K - 1; ++q) {
+      const int r = K - 2 - q;
+      if (r >= 1) loadu(r - 1, ub[(q + 1) & 1]);
+      asm volatile("" ::: "memory");   // (keeps the reads where they are: left alone the compiler reads all K (K - 1) / 2 multipliers first, 360 registers)
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+      for (int m = (r + 1) / 2; m < NP; ++m) {
+        const double2 u = ub[q & 1][m];
+        if (2 * m > r) a0 = __builtin_fma(u.x, xr[2 * m], a0);
+        if (2 * m + 1 < K) a1 = __builtin_fma(u.y, xr[2 * m + 1], a1);
+      }
+      xr[r] -= a0 + a1;
+    }
+  };
+  for (int pass = 0; pass < (SPK ? 2 : 1); ++pass) {
+    for (int il = wave; il < nloc; il += nwaves) {
+      const int o = orig(il);
+      double* slot = lds + il * B::BS;
+      double* Us = slot + (SPK ? B::oW : B::oYZ);   // D^-1 U staged here (row-major, stride ks); overwritten by the results
+      constexpr int NU = (KS2 + 63) / 64;
+      double uv[NU];   // (all global loads of the task are issued before anything waits for one)
+#pragma unroll
+      for (int t = 0; t < NU; ++t) uv[t] = A.Ust[(size_t)o * KS2 + (lane + 64 * t < KS2 ? lane + 64 * t : 0)];
+      const double dinv = (lane < K) ? A.Dst[(size_t)o * K + lane] : 0.0;   // lane r: 1 / d_r
+      double xr[K];
+      double* dst = dump;
+      int dstride = 0;
+      if (pass == 0) {   // columns [Dn Ht | Dn Et | Dn rt]; the two pad entries of a row of [Y | Z] (odd K) are cleared on the way
+        const double* src = (lane < K) ? A.Hst + (size_t)o * KS2 + lane : A.Est + (size_t)o * KS2 + (lane < 2 * K ? lane - K : 0);
+        const double mg = lane < 2 * K ? 1.0 : 0.0, mc = lane == 2 * K ? 1.0 : 0.0;
+#pragma unroll
+        for (int r = 0; r < K; ++r) xr[r] = src[r * ks] * mg + (rdlane(dinv, r) * lds[L.xall + (il + 2) * ks + r]) * mc;
+        if (lane < 2 * K) { dst = slot + B::oYZ + (lane < K ? lane : KE + lane - K); dstride = YS; }
+        else if (lane == 2 * K) { dst = slot + B::oC; dstride = 1; }
+        else if ((K & 1) && lane <= 2 * K + 2) { dst = slot + B::oYZ + (lane == 2 * K + 1 ? K : KE + K); dstride = YS; }   // (xr = 0 there)
+      } else {           // columns Dn Ft (the coupling to the separator)
+        const double* fsrc = A.fst + (size_t)il * A.fstride + (size_t)(lane < 2 * K ? lane : 0) * ks;
+        const double mf = lane < 2 * K ? 1.0 : 0.0;
+#pragma unroll
+        for (int r = 0; r < K; ++r) xr[r] = (rdlane(dinv, r) * fsrc[r]) * mf;
+        if (lane < 2 * K) { dst = slot + B::oW + (lane < K ? lane : KE + lane - K); dstride = YS; }
+        else if ((K & 1) && lane <= 2 * K + 1) { dst = slot + B::oW + (lane == 2 * K ? K : KE + K); dstride = YS; }
+      }
+#pragma unroll
+      for (int t = 0; t < NU; ++t) if (lane + 64 * t < KS2) Us[lane + 64 * t] = uv[t];
+      __atomic_signal_fence(__ATOMIC_SEQ_CST);
+      solve(Us, xr);
+      __atomic_signal_fence(__ATOMIC_SEQ_CST);   // (the staged U may sit where the results go)
+#pragma unroll
+      for (int r = 0; r < K; ++r) dst[r * dstride] = xr[r];
+    }
+  }
+  __syncthreads();
+  chain_ts(cfg, 3);
+  if (cfg.ts && tid == 0) cfg.ts[6] = (double)wall_clock64();
+  // ---- phase 2 (spike chains): once the separator is solved, c_i -= W_i [x_near ; x_far]
+  if (SPK && cfg.fst) {
+    double* xs = lds + L.W;
+    // (the 2K threads that fetch x_sep poll the flag themselves and read their entry with an agent-scope load - no
+    // cache invalidation, one barrier less than thread 0 polling for everybody)
+    if (tid < 2 * KE) {
+      spin_wait([&] { return __hip_atomic_load(cfg.sepflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.epoch; }, cfg.spin);
+      const int half = tid / KE, r = tid - half * KE;
+      xs[tid] = (r < K) ? __hip_atomic_load(cfg.xsep + (mirror ? half : 1 - half) * K + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;   // mirrored chain: nearest = s, else nearest = s + 1
+    }
+    __syncthreads();
+    for (int il = wave; il < nloc; il += nwaves) {
+      if (lane < K) {
+        const double2* w2 = reinterpret_cast<const double2*>(lds + il * B::BS + B::oW + lane * YS);
+        const double2* x2 = reinterpret_cast<const double2*>(xs);
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int m = 0; m < KE; ++m) { const double2 w = w2[m], x = x2[m]; a0 = __builtin_fma(w.x, x.x, a0); a1 = __builtin_fma(w.y, x.y, a1); }
+        lds[il * B::BS + B::oC + lane] -= a0 + a1;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- phase 3: the recursion on one wavefront.  Lanes 0..31: row r of Y_il (times x_{il+1}), lanes 32..63: row r of
+  // Z_il (times x_{il+2}); the halves meet in one exchange.  The matrix rows are in registers a row ahead (two sets,
+  // the loop is unrolled by two); on the dependent chain of a row: x_{il+1} back from LDS (ten broadcast reads), K
+  // FMAs in two accumulators, the exchange, x_il to LDS.
+  if (wave != 0) return;
+  if (cfg.ts && tid == 0) cfg.ts[21] = (double)wall_clock64();
+  const int hf = lane >> 5, r_ = lane & 31, rr = r_ < K ? r_ : 0;
+  static_assert(K <= 32, "one row per lane of a half-wavefront");
+  for (int c = lane; c < 4 * KE; c += 64) xb[c] = 0.0;
+  if (cfg.two && producer) {
+    // x of local rows nloc (next to this chain) and nloc + 1 come from the joiner (its two join rows)
+    if (lane == 0) spin_wait([&] { return __hip_atomic_load(A.flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.epoch; }, cfg.spin);
+    (void)__hip_atomic_load(A.flags + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    const double* xjoin = A.xch + 2 * (size_t)(K + 2 * K + 1) * ks;
+    if (lane < K) { xb[(nloc & 3) * KE + lane] = xjoin[K + lane]; xb[((nloc + 1) & 3) * KE + lane] = xjoin[lane]; }
+  }
+  double* xjoin = A.xch + 2 * (size_t)(K + 2 * K + 1) * ks;
+  double M0[KE], M1[KE], c0 = 0.0, c1 = 0.0;
+  auto fetch = [&](int il, double (&M)[KE], double& c) __attribute__((always_inline)) {
+    const double2* y2 = reinterpret_cast<const double2*>(lds + il * B::BS + B::oYZ + rr * YS + hf * KE);
+#pragma unroll
+    for (int m = 0; m < KE / 2; ++m) { const double2 a = y2[m]; M[2 * m] = a.x; M[2 * m + 1] = a.y; }
+    c = lds[il * B::BS + B::oC + rr];
+  };
+  auto row = [&](int il, const double (&M)[KE], const double c, double (&Mn)[KE], double& cn) __attribute__((always_inline)) {
+    const double2* xv = reinterpret_cast<const double2*>(xb + ((il + 1 + hf) & 3) * KE);
+    double x[KE];
+#pragma unroll
+    for (int m = 0; m < KE / 2; ++m) { const double2 a = xv[m]; x[2 * m] = a.x; x[2 * m + 1] = a.y; }
+    if (il >= 1) fetch(il - 1, Mn, cn);
+    // (pad entries of the rows were cleared when they were written, the pad entries of x are zero)
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int m = 0; m < KE / 2; ++m) { a0 = __builtin_fma(M[2 * m], x[2 * m], a0); a1 = __builtin_fma(M[2 * m + 1], x[2 * m + 1], a1); }
+    const double part = a0 + a1;
+    const double v = c - (part + __shfl_xor(part, 32));
+    if (lane < K) {
+      xb[(il & 3) * KE + lane] = v;
+      if (lane < k) A.x[(size_t)orig(il) * k + lane] = v;
+      if (cfg.two && !producer && il >= m_split) xjoin[(size_t)(il - m_split) * K + lane] = v;
+    }
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    if (cfg.two && !producer && il == m_split) {   // the join rows are solved: release the producer
+      __threadfence();
+      if (lane == 0) __hip_atomic_store(A.flags + 1, A.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  if (nloc > 0) fetch(nloc - 1, M0, c0);
+  if (cfg.ts && tid == 0) cfg.ts[22] = (double)wall_clock64();
+  for (int il = nloc - 1; il >= 0; il -= 2) {
+    row(il, M0, c0, M1, c1);
+    if (il >= 1) row(il - 1, M1, c1, M0, c0);
+  }
+  chain_ts(cfg, 4);
+}
+
 // grid (5, batch), 512 threads: blockIdx.x = role, blockIdx.y = problem of the batch
 //   0: P0 producer, rows 0 .. j1-1 top-down        1: P3 producer, rows n-1 .. j2+2 bottom-up
 //   2: J1 joiner, rows s-1 .. j1+2 then j1+1, j1   3: J2 joiner, rows s+2 .. j2-1 then j2, j2+1   (with their spike columns)
@@ -887,6 +1066,13 @@ __global__ void __launch_bounds__(512) penta_pipe_kernel(NdArgs A) {
   const PipeLds L = pipe_layout<K>(A.n, spike);
   if (spike) pipe_forward<K, true>(P, c, L);
   else pipe_forward<K, false>(P, c, L);
+  // back substitution: in recursion form when every row's matrices fit the LDS (horizons up to ~45 block rows at
+  // K = 19), else row by row from the factors as the two-workgroup kernel does
+  if (spike ? pipe_backward_fits<K, true>(L, c.nloc) : pipe_backward_fits<K, false>(L, c.nloc)) {
+    if (spike) pipe_backward<K, true>(P, c, L);
+    else pipe_backward<K, false>(P, c, L);
+    return;
+  }
   if (threadIdx.x >= 256) return;
   penta_ldl_tail<K, 256>(A.n, A.k, 1, A.x, A.Ust, A.Hst, A.Est, A.Dst, nullptr, c, P.xch, P.flags, A.epoch, L.xall, 1,
                          L.W, c.nloc + (c.producer ? 2 : 0));

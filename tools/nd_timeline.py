@@ -31,6 +31,7 @@ if dev.get_option("last_solver") == 4:   # pipelined chains (csrc/penta_pipe.h):
             print(f"   median: row to row {np.median(gaps):.2f} us, the K pivots {np.median([b - a for a, b in rows]):.2f} us")
         print("   pivots 4, 9, 14, last: row 3 published at %.2f %.2f %.2f %.2f, row 4's follower had applied them at %.2f %.2f %.2f %.2f"
               % (tuple(x[16:20]) + tuple(x[20:24])))
+        print("   back substitution: recursion matrices ready %.2f, corrected by the separator's solution %.2f, recursion from %.2f to %.2f" % (x[3], x[21], x[22], x[4]))
         ph = x[8:15]
         print("   row 4 as follower: inputs wanted %.2f, loaded %.2f, follow from %.2f, first row of the row before read %.2f, "
               "half of its rows applied %.2f, last row read %.2f, ready to eliminate %.2f" % tuple(ph))
