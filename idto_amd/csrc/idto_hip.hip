@@ -106,6 +106,7 @@ struct idto_hip_ctx {
   int solver_timeouts = 0;                // launches whose waits between workgroups ran out (FactorStatus)
   int last_step_kind = 0;                 // what produced IDTO_ARR_STEP last: 1 factor_solve of -g, 2 the fused launch, 0 other
   int debug_skip_role = -1;               // test aid: a role of the nested-dissection kernels that returns at once
+  int debug_pipe_tail = 0;                // measurement aid: pipelined solver with the row-by-row back substitution
   double* nd_buf = nullptr;
   unsigned long long nd_launches = 0;
   int last_solver = 0;                     // 0 none yet, 1 two-workgroup LDL^T, 2 nested dissection, 3 reference LU
@@ -905,12 +906,20 @@ static int PlanLdl(idto_hip_ctx* c, bool one_sided, LdlPlan* p) {
 // single-right-hand-side solves only (the Gauss-Newton step).
 // separator in the middle; in each half the joiner chain (next to the separator) gets the extra row
 struct NdSplit { int s, j1, j2; };
-static NdSplit nd_split(int n) {
+// Pipelined chains (penta_pipe.h): a joiner's block row costs ~1.35x a producer's (its spike wavefronts share the
+// SIMDs) and its two join rows come after the producer's hand-over, so the producers take ~57% of the rows that are
+// not join rows: both sides then reach the join together (measured at K = 19: 2.56 / 3.45 us per row).
+static NdSplit nd_split(int n, bool pipe) {
   NdSplit sp;
   sp.s = (n - 2) / 2;
   const int htop = sp.s, hbot = n - sp.s - 2;
-  sp.j1 = (htop - 2) / 2;                          // producer P0: rows 0 .. j1-1
-  sp.j2 = n - (hbot - 2) / 2 - 2;                  // producer P3: rows j2+2 .. n-1
+  auto producer_rows = [&](int half) {
+    if (!pipe) return (half - 2) / 2;
+    int np = (int)(0.575 * (half - 2) + 0.6);
+    return std::max(1, std::min(np, half - 3));
+  };
+  sp.j1 = producer_rows(htop);                     // producer P0: rows 0 .. j1-1
+  sp.j2 = n - producer_rows(hbot) - 2;             // producer P3: rows j2+2 .. n-1
   return sp;
 }
 static bool NdEligible(const idto_hip_ctx* c, const LdlPlan& p) {
@@ -920,8 +929,8 @@ static bool NdEligible(const idto_hip_ctx* c, const LdlPlan& p) {
   if (!(c->solver_nd && c->two_sided && inst && p.n >= 24 && 7 * c->batch <= 256)) return false;
   // the joiner chains' per-row tables hold ND_MAXROWS local rows: longer horizons (n >= 127) take the
   // two-workgroup factorisation
-  NdSplit sp = nd_split(p.n);
-  return std::max(sp.s - sp.j1, sp.j2 - sp.s) <= ND_MAXROWS;
+  NdSplit sp = nd_split(p.n, c->solver_pipe && p.K <= 20);
+  return std::max(std::max(sp.s - sp.j1, sp.j2 - sp.s), std::max(sp.j1, p.n - sp.j2 - 2)) <= ND_MAXROWS;
 }
 static int NdLds(const idto_hip_ctx* c, const LdlPlan& p, int nloc_max) {
   const int ks = ldl_ks(p.K), NF = 2 * p.K, KP = 4 * ((p.K + 3) / 4);
@@ -933,13 +942,14 @@ static int NdLds(const idto_hip_ctx* c, const LdlPlan& p, int nloc_max) {
 static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double sign, double* xo) {
   NdArgs A;
   A.debug_skip_role = c->debug_skip_role;
+  A.debug_pipe_tail = c->debug_pipe_tail;
   A.spin = SpinCtl{nullptr, 0};   // (set by the kernel: behind the per-problem status words)
   A.n = p.n; A.k = p.k;
   A.HA = c->HA + p.qq0; A.HB = c->HB + p.qq0; A.HC = c->HC + p.qq0;
   A.b = b + (size_t)p.r0 * p.k; A.rhs_sign = sign; A.x = xo + (size_t)p.r0 * p.k;
   A.Ust = c->Ust; A.Hst = c->Hst; A.Est = c->Est; A.Dst = c->Dst;
-  { const NdSplit sp = nd_split(p.n); A.s = sp.s; A.j1 = sp.j1; A.j2 = sp.j2; }
-  const int nloc_max = std::max(A.s - A.j1, A.j2 - A.s);
+  { const NdSplit sp = nd_split(p.n, c->solver_pipe && p.K <= 20); A.s = sp.s; A.j1 = sp.j1; A.j2 = sp.j2; }
+  const int nloc_max = std::max(std::max(A.s - A.j1, A.j2 - A.s), std::max(A.j1, A.n - A.j2 - 2));
   if (nloc_max > ND_MAXROWS) { g_err = "horizon too long for the nested-dissection solver's row tables"; return -1; }
   const int lds = NdLds(c, p, nloc_max);
   if (lds > 160 * 1024) { g_err = "nested-dissection solver: LDS carve-up too large"; return -1; }
@@ -1807,6 +1817,7 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "solver_nd") == 0) { c->solver_nd = value != 0; return 0; }
   if (std::strcmp(name, "solver_pipe") == 0) { c->solver_pipe = value != 0; return 0; }
   if (std::strcmp(name, "debug_skip_role") == 0) { c->debug_skip_role = value; return 0; }   // test aid
+  if (std::strcmp(name, "debug_pipe_tail") == 0) { c->debug_pipe_tail = value; return 0; }   // measurement aid
   if (std::strcmp(name, "asm_fold") == 0) { c->asm_fold = value != 0; c->terms_valid = false; return 0; }
   if (std::strcmp(name, "fused_debug") == 0) { c->fused_debug = value != 0; return 0; }
   if (std::strcmp(name, "asm_stop") == 0) { c->asm_stop = value; return 0; }  // profiling aid

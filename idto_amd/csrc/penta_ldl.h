@@ -219,6 +219,7 @@ struct ChainCfg {
   const unsigned long long* frowcnt; unsigned long long frowtarget;   // ... and their per-row release counters
   const double* xsep;               // [x_s | x_{s+1}] once *sepflag == epoch
   unsigned* sepflag;
+  const double* xsep_ll;            // the same with the epoch in every word (penta_nd.h ll_store)
   double* ts;                       // optional wall-clock stamps (100 MHz): start, join reached, forward done, backward start, end
   int factor_only;                  // stop once the factors are in HBM: every right-hand side (the first included) goes
                                     // through penta_apply_kernel, the chains' own back substitution is off the path

@@ -51,12 +51,13 @@ struct NdArgs {
   double* ts;                    // option "solver_debug": [7 roles][64] wall-clock stamps (100 MHz)
   SpinCtl spin;                  // where a wait between workgroups that ran out reports it (penta_ldl.h spin_wait)
   int debug_skip_role;           // test aid: this role returns at once (its partners' waits must run out), -1: none
+  int debug_pipe_tail;           // measurement aid: penta_pipe_kernel takes the row-by-row back substitution
 };
 __device__ __forceinline__ void nd_ts(const NdArgs& A, int role, int slot) {
   if (A.ts && threadIdx.x == 0) A.ts[role * 64 + slot] = (double)wall_clock64();
 }
 
-struct NdBuf { int rtpub, fst, frow, xsep, end; };  // offsets in doubles; rtpub / fst are [2][...]
+struct NdBuf { int rtpub, fst, frow, xsep, ll, end; };  // offsets in doubles; rtpub / fst are [2][...]
 __host__ __device__ inline NdBuf nd_layout(int K) {
   NdBuf L;
   const int ks = ldl_ks(K), ct2 = (2 * K + 1 + 15) / 16;   // columns [Ft | rt], in tiles of 16
@@ -65,6 +66,8 @@ __host__ __device__ inline NdBuf nd_layout(int K) {
   L.frow = 16 * ct2 * ks;                // doubles per published row (whole 16-column tiles: the separator's MFMA loads)
   L.fst = o; o += 2 * ND_MAXROWS * L.frow + 16 * ks;
   L.xsep = o; o += 2 * K;
+  o += o & 1;
+  L.ll = o; o += 3 * 4 * K;              // flagged copies (ll_store): x_sep, and the two join rows of each producer / joiner pair
   L.end = o;
   return L;
 }
@@ -79,6 +82,29 @@ __device__ __forceinline__ void nd_wait(const unsigned* f, unsigned epoch, const
   __syncthreads();
   (void)__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
 }
+// A double handed to another workgroup in ONE memory round trip: each 32-bit half travels in an 8-byte word with the
+// launch's epoch next to it (8-byte stores are single transactions), so the reader polls the data itself - no flag to
+// wait for first, no cache invalidation before the data may be read.  (The usual flag + acquire + load costs three.)
+__device__ __forceinline__ void ll_store(double* slot2, double v, unsigned epoch) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v), e = (unsigned long long)epoch << 32;
+  // (agent-scope stores: a plain store may sit dirty in this XCD's L2, where the reader's XCD does not look)
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(slot2);
+  __hip_atomic_store(q, (b & 0xffffffffull) | e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 1, (b >> 32) | e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool ll_try(const double* slot2, unsigned epoch, double& v) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(slot2);
+  const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v = __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
+  return (unsigned)(a >> 32) == epoch && (unsigned)(b >> 32) == epoch;
+}
+__device__ __forceinline__ double ll_load(const double* slot2, unsigned epoch, const SpinCtl& sc) {
+  double v = 0.0;
+  spin_wait([&] { return ll_try(slot2, epoch, v); }, sc);
+  return v;
+}
+
 __device__ __forceinline__ void nd_post(unsigned* f, unsigned epoch) {
   __syncthreads();   // every wavefront's global stores precede thread 0's release
   if (threadIdx.x == 0) __hip_atomic_store(f, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -496,6 +522,9 @@ __device__ __forceinline__ void nd_separator(const NdArgs& A) {
       double* xsep = A.ndbuf + B.xsep;
       xsep[lane] = x0;
       xsep[K + lane] = x1;
+      double* xll = A.ndbuf + B.ll;
+      ll_store(xll + 2 * lane, x0, A.epoch);
+      ll_store(xll + 2 * (K + lane), x1, A.epoch);
       if (lane < k) { A.x[(size_t)s * k + lane] = x0; A.x[(size_t)(s + 1) * k + lane] = x1; }
     }
   }

@@ -282,6 +282,7 @@ struct PipeArgs {
   unsigned* status; unsigned fact_id;
   // nested dissection (spike chains): [Ft | rt] rows for the separator and their release counters
   double* fst; int fstride; unsigned long long* frowcnt;
+  double* xjoin_ll;   // the pair's two join rows of x, joiner -> producer, epoch in every word (penta_nd.h ll_store)
   double* ts;
 };
 
@@ -852,6 +853,14 @@ struct PipeBack {
   static constexpr int oYZ = 0, oW = K * YS, oC = oW + (SPK ? K * YS : 0), BS = oC + KE;
 };
 
+// v[lane] + v[lane ^ 32] in every lane: one v_permlane32_swap per 32-bit half (a ds_bpermute round trip costs ~100 cycles)
+__device__ __forceinline__ double pipe_half_sum(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+
 template <int K, bool SPK>
 __device__ __forceinline__ bool pipe_backward_fits(const PipeLds& L, int nloc) { return nloc * PipeBack<K, SPK>::BS + 4 * PipeBack<K, SPK>::KE + 2 <= L.xall; }
 
@@ -938,12 +947,10 @@ __device__ __forceinline__ void pipe_backward(const PipeArgs& A, const ChainCfg&
   // ---- phase 2 (spike chains): once the separator is solved, c_i -= W_i [x_near ; x_far]
   if (SPK && cfg.fst) {
     double* xs = lds + L.W;
-    // (the 2K threads that fetch x_sep poll the flag themselves and read their entry with an agent-scope load - no
-    // cache invalidation, one barrier less than thread 0 polling for everybody)
+    // (the 2K threads that fetch x_sep poll their own entry, which carries the epoch: penta_nd.h ll_store)
     if (tid < 2 * KE) {
-      spin_wait([&] { return __hip_atomic_load(cfg.sepflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.epoch; }, cfg.spin);
       const int half = tid / KE, r = tid - half * KE;
-      xs[tid] = (r < K) ? __hip_atomic_load(cfg.xsep + (mirror ? half : 1 - half) * K + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;   // mirrored chain: nearest = s, else nearest = s + 1
+      xs[tid] = (r < K) ? ll_load(cfg.xsep_ll + 2 * ((mirror ? half : 1 - half) * K + r), A.epoch, cfg.spin) : 0.0;   // mirrored chain: nearest = s, else nearest = s + 1
     }
     __syncthreads();
     for (int il = wave; il < nloc; il += nwaves) {
@@ -969,12 +976,11 @@ __device__ __forceinline__ void pipe_backward(const PipeArgs& A, const ChainCfg&
   for (int c = lane; c < 4 * KE; c += 64) xb[c] = 0.0;
   if (cfg.two && producer) {
     // x of local rows nloc (next to this chain) and nloc + 1 come from the joiner (its two join rows)
-    if (lane == 0) spin_wait([&] { return __hip_atomic_load(A.flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.epoch; }, cfg.spin);
-    (void)__hip_atomic_load(A.flags + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-    const double* xjoin = A.xch + 2 * (size_t)(K + 2 * K + 1) * ks;
-    if (lane < K) { xb[(nloc & 3) * KE + lane] = xjoin[K + lane]; xb[((nloc + 1) & 3) * KE + lane] = xjoin[lane]; }
+    if (lane < K) {
+      xb[(nloc & 3) * KE + lane] = ll_load(A.xjoin_ll + 2 * (K + lane), A.epoch, cfg.spin);
+      xb[((nloc + 1) & 3) * KE + lane] = ll_load(A.xjoin_ll + 2 * lane, A.epoch, cfg.spin);
+    }
   }
-  double* xjoin = A.xch + 2 * (size_t)(K + 2 * K + 1) * ks;
   double M0[KE], M1[KE], c0 = 0.0, c1 = 0.0;
   auto fetch = [&](int il, double (&M)[KE], double& c) __attribute__((always_inline)) {
     const double2* y2 = reinterpret_cast<const double2*>(lds + il * B::BS + B::oYZ + rr * YS + hf * KE);
@@ -993,17 +999,13 @@ __device__ __forceinline__ void pipe_backward(const PipeArgs& A, const ChainCfg&
 #pragma unroll
     for (int m = 0; m < KE / 2; ++m) { a0 = __builtin_fma(M[2 * m], x[2 * m], a0); a1 = __builtin_fma(M[2 * m + 1], x[2 * m + 1], a1); }
     const double part = a0 + a1;
-    const double v = c - (part + __shfl_xor(part, 32));
+    const double v = c - pipe_half_sum(part);
     if (lane < K) {
       xb[(il & 3) * KE + lane] = v;
       if (lane < k) A.x[(size_t)orig(il) * k + lane] = v;
-      if (cfg.two && !producer && il >= m_split) xjoin[(size_t)(il - m_split) * K + lane] = v;
+      if (cfg.two && !producer && il >= m_split) ll_store(A.xjoin_ll + 2 * ((il - m_split) * K + lane), v, A.epoch);   // a join row: the producer polls it
     }
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    if (cfg.two && !producer && il == m_split) {   // the join rows are solved: release the producer
-      __threadfence();
-      if (lane == 0) __hip_atomic_store(A.flags + 1, A.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
   };
   if (nloc > 0) fetch(nloc - 1, M0, c0);
   if (cfg.ts && tid == 0) cfg.ts[22] = (double)wall_clock64();
@@ -1053,6 +1055,7 @@ __global__ void __launch_bounds__(512) penta_pipe_kernel(NdArgs A) {
     c.fst = A.ndbuf + B.fst + (size_t)w * ND_MAXROWS * B.frow; c.fstride = B.frow;
     c.frowcnt = A.rowcnt + (2 + w) * ND_MAXROWS; c.frowtarget = (A.rowtarget / A.rowunit) * 3ull;
     c.xsep = A.ndbuf + B.xsep; c.sepflag = A.flags + 4;
+    c.xsep_ll = A.ndbuf + B.ll;
   }
   PipeArgs P;
   P.n = A.n; P.k = A.k; P.HA = A.HA; P.HB = A.HB; P.HC = A.HC; P.b = A.b; P.rhs_sign = A.rhs_sign; P.x = A.x;
@@ -1062,13 +1065,20 @@ __global__ void __launch_bounds__(512) penta_pipe_kernel(NdArgs A) {
   P.fst = const_cast<double*>(c.fst); P.fstride = c.fstride;
   P.frowcnt = role >= 2 ? A.rowcnt + (2 + role - 2) * ND_MAXROWS : nullptr;
   P.ts = c.ts;
+  P.xjoin_ll = A.ndbuf + B.ll + (1 + pair) * 4 * K;
   const bool spike = role >= 2;
   const PipeLds L = pipe_layout<K>(A.n, spike);
   if (spike) pipe_forward<K, true>(P, c, L);
   else pipe_forward<K, false>(P, c, L);
   // back substitution: in recursion form when every row's matrices fit the LDS (horizons up to ~45 block rows at
   // K = 19), else row by row from the factors as the two-workgroup kernel does
-  if (spike ? pipe_backward_fits<K, true>(L, c.nloc) : pipe_backward_fits<K, false>(L, c.nloc)) {
+  // (all four chains take the same form: the join rows change hands in the form's own protocol)
+  // Recursion form only where the triangular solves are long (K = 19): multiplying by precomputed U^-1 blocks costs
+  // a factor ~cond(U) of backward error (measured 1e-14 componentwise against 1e-16; the forward error is unchanged),
+  // which small blocks need not pay - their row-by-row chain is K steps anyway.
+  const bool recursion = K > 8 && !A.debug_pipe_tail && pipe_backward_fits<K, true>(pipe_layout<K>(A.n, true), max(A.s - A.j1, A.j2 - A.s)) &&
+                         pipe_backward_fits<K, false>(pipe_layout<K>(A.n, false), max(A.j1, A.n - A.j2 - 2));
+  if (recursion) {
     if (spike) pipe_backward<K, true>(P, c, L);
     else pipe_backward<K, false>(P, c, L);
     return;

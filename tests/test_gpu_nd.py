@@ -58,9 +58,15 @@ def test_nested_dissection_solver(name, N, pipe):
     p_ref, unc = ol.refined_solution(ol.penta_make_dense(*bands), -g.ravel())
     pn = np.abs(p_ref).max()
     err = lambda x: np.abs(x.ravel() - p_ref).max() / pn
-    res = lambda x: np.abs(ol.penta_multiply(*bands, x) + g).max() / (np.abs(g).max() + 1e-300)
+    # componentwise backward error |H x + g| / (|H| |x| + |g|).  The pipelined solver's back substitution multiplies
+    # by precomputed U^-1 blocks (penta_pipe.h pipe_backward): ~1e-14 where the row-by-row substitution has ~1e-16 and
+    # the reference's pivoted-LU block Thomas ~1e-14 .. 1e-12 (tools/nd_accuracy.py); the forward error is what the
+    # Gauss-Newton step sees and is bounded against LU's above.
+    ab = [np.abs(b) for b in bands]
+    bwd = lambda x: (np.abs(ol.penta_multiply(*bands, x) + g.ravel()) /
+                     (ol.penta_multiply(*ab, np.abs(x)) + np.abs(g.ravel()) + 1e-300)).max()
     assert err(p_nd) <= 4 * err(p_lu) + 16 * unc + 1e-12, (err(p_nd), err(p_two), err(p_lu))
-    assert res(p_nd) <= 16 * res(p_lu) + 1e-13, (res(p_nd), res(p_lu))
+    assert bwd(p_nd) <= 16 * bwd(p_lu) + 2e-13, (bwd(p_nd), bwd(p_lu))
     dev.close()
 
 

@@ -29,7 +29,7 @@ for N in Ns:
         dev = hip.HipPath(model, prob, sp)
         dev.set_q(q)
         out = {}
-        for label, opts in (("pipe", {"solver_pipe": 1}), ("nd", {"solver_pipe": 0}), ("two", {"solver_nd": 0}),
+        for label, opts in (("pipe", {"solver_pipe": 1}), ("ptail", {"debug_pipe_tail": 1}), ("nd", {"solver_pipe": 0, "debug_pipe_tail": 0}), ("two", {"solver_nd": 0}),
                             ("lu", {"reference_solver": 1})):
             for k, v in opts.items():
                 dev.set_option(k, v)
@@ -40,5 +40,11 @@ for N in Ns:
         p_ref, unc = ol.refined_solution(ol.penta_make_dense(*bands), -g.ravel())
         pn = np.abs(p_ref).max()
         err = {k: np.abs(v.ravel() - p_ref).max() / pn for k, v in out.items()}
+        gn = np.abs(g).max() + 1e-300
+        res = {k: np.abs(ol.penta_multiply(*bands, v) + g).max() / gn for k, v in out.items()}
+        ab = [np.abs(b) for b in bands]
+        bwd = {k: (np.abs(ol.penta_multiply(*bands, v) + g.ravel()) / (ol.penta_multiply(*ab, np.abs(v)) + np.abs(g.ravel()) + 1e-300)).max() for k, v in out.items()}
+        print(f"{name} N={N} seed={seed}: residual/|g| lu {res['lu']:.1e} pipe {res['pipe']:.1e} ptail {res['ptail']:.1e} nd {res['nd']:.1e} two {res['two']:.1e}")
+        print(f"{name} N={N} seed={seed}: componentwise backward error lu {bwd['lu']:.1e} pipe {bwd['pipe']:.1e} ptail {bwd['ptail']:.1e} nd {bwd['nd']:.1e} two {bwd['two']:.1e}")
         print(f"{name} N={N} seed={seed}: lu {err['lu']:.2e}  pipe/lu {err['pipe'] / err['lu']:.2f}  nd/lu {err['nd'] / err['lu']:.2f}  "
               f"two/lu {err['two'] / err['lu']:.2f}  (unc {unc:.1e})", flush=True)
