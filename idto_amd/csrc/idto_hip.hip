@@ -101,6 +101,9 @@ struct idto_hip_ctx {
   bool solver_nd = true;                  // solver: nested dissection over 7 workgroups (penta_nd.h) when eligible
   bool solver_pipe = true;                // ... with pipelined chains (penta_pipe.h: 5 workgroups) when the block size allows
   unsigned long long* nd_rowcnt = nullptr; // its per-row release counters, buffers and launch count
+  unsigned* asm_ready = nullptr;               // penta_pipe.h PipeAsm: [N + 1][4] epoch words of the assembly inside the solver's launch
+  bool asm_in_solver = true;                  // option "asm_in_solver": idto_hip_gn_step assembles g and H inside the pipelined solver's launch
+  bool fuse_asm_next = false;                 // (set by idto_hip_gn_step for the FactorSolve that follows)
   unsigned long long* pipe_rowcnt = nullptr;   // the same for the pipelined variant (its own launch count: the two
   unsigned long long pipe_launches = 0;        // variants release a row with different increments)
   int solver_timeouts = 0;                // launches whose waits between workgroups ran out (FactorStatus)
@@ -553,6 +556,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   const size_t o_xch = carve(2 * c->xch_count, D);   // (two producer / joiner pairs in the nested-dissection kernel)
   const size_t o_ndcnt = carve(4 * ND_MAXROWS, sizeof(unsigned long long)), o_ndbuf = carve((size_t)nd_layout(32).end, D);
   const size_t o_pipecnt = carve(4 * ND_MAXROWS, sizeof(unsigned long long));
+  const size_t o_asmready = carve(4 * (size_t)(N + 1), sizeof(unsigned));
   c->flag_count = 16;
   const size_t o_flags = carve(c->flag_count, sizeof(unsigned)), o_sync = carve(2, sizeof(unsigned long long));
   const size_t nvars = (size_t)(N + 1) * nq;
@@ -588,6 +592,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   c->sync_cnt = reinterpret_cast<unsigned long long*>(c->arena + o_sync);
   c->nd_rowcnt = reinterpret_cast<unsigned long long*>(c->arena + o_ndcnt);
   c->pipe_rowcnt = reinterpret_cast<unsigned long long*>(c->arena + o_pipecnt);
+  c->asm_ready = reinterpret_cast<unsigned*>(c->arena + o_asmready);
   c->nd_buf = dp(o_ndbuf);
   c->tr_D = dp(o_trD); c->tr_gt = dp(o_trg); c->tr_w = dp(o_trw); c->tr_dq = dp(o_trdq); c->q_trial = dp(o_qt);
   c->tr_out = dp(o_trout); c->tr_Dprev = dp(o_trDp); c->tr_part = dp(o_trpart);
@@ -943,6 +948,7 @@ static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double s
   NdArgs A;
   A.debug_skip_role = c->debug_skip_role;
   A.debug_pipe_tail = c->debug_pipe_tail;
+  A.asm_ready = nullptr; A.asm_first = 0;
   A.spin = SpinCtl{nullptr, 0};   // (set by the kernel: behind the per-problem status words)
   A.n = p.n; A.k = p.k;
   A.HA = c->HA + p.qq0; A.HB = c->HB + p.qq0; A.HC = c->HC + p.qq0;
@@ -975,8 +981,20 @@ static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double s
     if (++c->fact_id == 0) c->fact_id = 1;
     A.epoch = c->epoch; A.status = c->status_dev; A.fact_id = c->fact_id; A.pstride = c->pstride;
     A.ts = c->solver_debug ? c->dbg : nullptr;
-    const dim3 pgrid(5, c->batch);
-#define PIPE_LAUNCH(KM) hipLaunchKernelGGL((penta_pipe_kernel<KM>), pgrid, dim3(512), plds, c->stream, A)
+    // (idto_hip_gn_step: g and the bands are assembled by 4 (N + 1) more workgroups of this launch, penta_pipe.h PipeAsm)
+    PipeAsm F{};
+    F.on = c->fuse_asm_next ? 1 : 0;
+    c->fuse_asm_next = false;
+    if (F.on) {
+      F.nq = c->nq; F.nv = c->nv; F.rows = c->N + 1; F.first = p.r0;
+      F.P = c->P; F.q = c->q; F.terms = c->terms; F.v_res = c->v; F.nplus = c->nplus;
+      F.g = c->g; F.HA = c->HA; F.HB = c->HB; F.HC = c->HC; F.alt = c->alt_r; F.ready = c->asm_ready;
+      plds = std::max(plds, c->asm_terms_lds);
+      c->last_assembly = 4;
+    }
+    A.asm_ready = nullptr; A.asm_first = 0;
+    const dim3 pgrid(5 + (F.on ? 4 * (c->N + 1) : 0), c->batch);
+#define PIPE_LAUNCH(KM) hipLaunchKernelGGL((penta_pipe_kernel<KM>), pgrid, dim3(512), plds, c->stream, A, F)
     switch (p.K) {
       case 2: PIPE_LAUNCH(2); break;
       case 3: PIPE_LAUNCH(3); break;
@@ -1798,6 +1816,7 @@ int idto_hip_get_option(idto_hip_ctx* c, const char* name, int* value) {
   if (std::strcmp(name, "last_solver") == 0) { *value = c->last_solver; return 0; }
   if (std::strcmp(name, "solver_nd") == 0) { *value = c->solver_nd; return 0; }
   if (std::strcmp(name, "solver_pipe") == 0) { *value = c->solver_pipe; return 0; }
+  if (std::strcmp(name, "asm_in_solver") == 0) { *value = c->asm_in_solver; return 0; }
   if (std::strcmp(name, "solver_timeouts") == 0) { *value = c->solver_timeouts; return 0; }
   if (std::strcmp(name, "asm_fold") == 0) { *value = c->asm_fold; return 0; }
   if (std::strcmp(name, "last_assembly") == 0) { *value = c->last_assembly; return 0; }
@@ -1816,6 +1835,7 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "fused") == 0) { c->fused = value != 0; return 0; }
   if (std::strcmp(name, "solver_nd") == 0) { c->solver_nd = value != 0; return 0; }
   if (std::strcmp(name, "solver_pipe") == 0) { c->solver_pipe = value != 0; return 0; }
+  if (std::strcmp(name, "asm_in_solver") == 0) { c->asm_in_solver = value != 0; return 0; }
   if (std::strcmp(name, "debug_skip_role") == 0) { c->debug_skip_role = value; return 0; }   // test aid
   if (std::strcmp(name, "debug_pipe_tail") == 0) { c->debug_pipe_tail = value; return 0; }   // measurement aid
   if (std::strcmp(name, "asm_fold") == 0) { c->asm_fold = value != 0; c->terms_valid = false; return 0; }
@@ -1831,6 +1851,19 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   return -1;
 }
 
+// Does idto_hip_gn_step's solve take the pipelined kernel with the assembly inside (the conditions of LaunchAssemble's
+// products path and of LaunchNd's pipelined branch, evaluated as they will be once the bands count as assembled)?
+static bool AsmInSolver(idto_hip_ctx* c) {
+  if (!(c->asm_in_solver && c->solver_pipe && !c->reference_solver)) return false;
+  if (!(c->weights_diagonal && c->terms_valid && c->fd_full && c->asm_stop == 0)) return false;
+  const bool was = c->h_assembled;
+  c->h_assembled = true;   // (the plan's first row depends on it)
+  LdlPlan p;
+  const bool ok = PlanLdl(c, false, &p) == 0 && p.K <= 20 && NdEligible(c, p) && 5 * c->batch <= 64;
+  c->h_assembled = was;
+  return ok;
+}
+
 int idto_hip_gn_step(idto_hip_ctx* c) {
   HIP_OK(hipSetDevice(c->device));
   if (c->spec_ready) return 0;   // already enqueued for this q by idto_hip_tr_trial (speculation)
@@ -1838,6 +1871,22 @@ int idto_hip_gn_step(idto_hip_ctx* c) {
   if (FusedEligible(c)) return LaunchFused(c);
   int rc = idto_hip_eval_partials(c);
   if (rc) return rc;
+  if (AsmInSolver(c)) {
+    // two launches: the pipelined solver's grid carries the assembly (LaunchNd).  LaunchAssemble's bookkeeping:
+    DropPrefetch(c, {IDTO_ARR_GRADIENT, IDTO_ARR_H_A, IDTO_ARR_H_B, IDTO_ARR_H_C, IDTO_ARR_HBANDS});
+    if (!c->h_assembled) {
+      HIP_OK(hipMemset2DAsync(c->step, c->pstride, 0, (size_t)c->nq * sizeof(double), (size_t)c->batch, c->stream));
+      c->h_assembled = true;
+    }
+    c->con_ready = false; c->con_begun = false;
+    c->fuse_asm_next = true;
+    rc = idto_hip_factor_solve(c, nullptr, 1, nullptr);
+    if (c->fuse_asm_next) {   // (nobody took it: the solve went another way than AsmInSolver foresaw)
+      c->fuse_asm_next = false;
+      if (!rc) { g_err = "gn_step: the solver that was to assemble g and H did not run"; rc = -1; }
+    }
+    return rc;
+  }
   rc = idto_hip_grad_hess(c);
   if (rc) return rc;
   return idto_hip_factor_solve(c, nullptr, 1, nullptr);

@@ -1090,21 +1090,23 @@ assemble_diag_kernel(DevModel M, DevProblem P, const double* __restrict__ q, con
 // six dtau/dq blocks per workgroup, four workgroups per block row (3.1 MB of fetches for 0.7 MB of
 // data, and 12 us of mostly operand staging on the critical path of the iteration).
 // Grid (N + 1, 4, batch): part 0 C_i and the gradient block, 1 / 2 the column halves of B_i, 3 A_i.
-__global__ void __launch_bounds__(256)
-assemble_terms_kernel(DevModel M, DevProblem P, const double* __restrict__ q, const double* __restrict__ terms,
-                      const double* __restrict__ v_res, const double* __restrict__ nplus_res, double* __restrict__ g,
-                      double* __restrict__ HA, double* __restrict__ HB, double* __restrict__ HC, size_t pstride,
-                      const double* __restrict__ gate, AltSel alt) {
-  if (gate && *gate == 0.0) return;   // (idto_hip_tr_solve: the step was rejected, g and H of the iterate stay)
-  {
-    const size_t o = (size_t)blockIdx.z * pstride, w = o + (size_t)alt_offset(alt);
-    P = at_problem(P, o); q = at_problem(q, o); terms = at_problem(terms, w); v_res = at_problem(v_res, w);
-    nplus_res = at_problem(nplus_res, w); g = at_problem(g, o);
-    HA = at_problem(HA, o); HB = at_problem(HB, o); HC = at_problem(HC, o);
-  }
-  extern __shared__ double lds[];
+// (WT: results leave with agent-scope write-through stores - the form in which another workgroup of the SAME launch
+// may consume them, see penta_pipe.h; bits are the same either way)
+template <bool WT>
+IDTO_DEV void asm_put(double* p, double v) {
+  if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
+// block row i, part `part` (all threads of the workgroup; `lds`: asm_terms_lds bytes)
+template <bool WT>
+__device__ __forceinline__ void assemble_terms_row(int nq, int nv, const DevProblem& P, const double* __restrict__ q,
+                                                   const double* __restrict__ terms, const double* __restrict__ v_res,
+                                                   const double* __restrict__ nplus_res, double* __restrict__ g,
+                                                   double* __restrict__ HA, double* __restrict__ HB, double* __restrict__ HC,
+                                                   int i, int part, double* lds) {
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int i = blockIdx.x, part = blockIdx.y, N = P.N, nq = M.nq, nv = M.nv;
+  const int N = P.N;
   const int bsz = nv * nq, qq = nq * nq;
   const int nvp = (nv + 1) & ~1, psz = nvp * nq;
   const double dt = P.dt;
@@ -1114,11 +1116,11 @@ assemble_terms_kernel(DevModel M, DevProblem P, const double* __restrict__ q, co
   if (i == 0) {
     if (part == 0) {
       for (int idx = tid; idx < qq; idx += nt) {
-        Cg[idx] = (idx / nq == idx % nq) ? 1.0 : 0.0;
-        Bg[idx] = 0.0;
-        Ag[idx] = 0.0;
+        asm_put<WT>(Cg + idx, (idx / nq == idx % nq) ? 1.0 : 0.0);
+        asm_put<WT>(Bg + idx, 0.0);
+        asm_put<WT>(Ag + idx, 0.0);
       }
-      for (int j = tid; j < nq; j += nt) g[j] = 0.0;
+      for (int j = tid; j < nq; j += nt) asm_put<WT>(g + j, 0.0);
     }
     return;
   }
@@ -1127,8 +1129,37 @@ assemble_terms_kernel(DevModel M, DevProblem P, const double* __restrict__ q, co
   const double* T0 = terms + (size_t)(i < N ? i : 0) * ts;     // record i   (i < N)
   const double* Tp1 = terms + (size_t)(i < N - 1 ? i + 1 : 0) * ts;
   if (part == 3) {   // A_i (TO.cc:1150-1153): P_{i-1}^T R' M_{i-1}, nothing to add
-    for (int e = tid; e < qq; e += nt) Ag[e] = (i >= 3) ? Tm1[5 * qq + e] : 0.0;
+    for (int e = tid; e < qq; e += nt) asm_put<WT>(Ag + e, (i >= 3) ? Tm1[5 * qq + e] : 0.0);
     return;
+  }
+  // The product terms of the thread's FIRST item (its only one when the workgroup has a thread per item) are requested
+  // here, before the staging below waits for ITS loads: two memory latencies in a row become one.  (Values and the
+  // order of the sums are what they were.)
+  const int ntri = nq * (nq + 1) / 2;
+  double pre0 = 0.0, pre1 = 0.0, pre2 = 0.0, pre3 = 0.0, pre4 = 0.0;
+  if (part == 0) {
+    if (tid < ntri) {
+      int c = 0, rem = tid;
+      while (rem >= nq - c) { rem -= nq - c; ++c; }
+      const int e = c * nq + c + rem;
+      pre0 = Tm1[e];
+      pre1 = (i < N) ? T0[qq + e] : 0.0;
+      pre2 = (i < N - 1) ? Tp1[2 * qq + e] : 0.0;
+      pre3 = (i < N) ? P.Qq[e] : P.Qfq[e];
+    } else if (tid < ntri + nq) {
+      const int j = tid - ntri;
+      pre0 = Tm1[6 * qq + j];
+      pre1 = (i < N) ? T0[6 * qq + nq + j] : 0.0;
+      pre2 = (i < N - 1) ? Tp1[6 * qq + 2 * nq + j] : 0.0;
+      pre3 = q[i * nq + j];
+      pre4 = P.q_nom[i * nq + j];
+    }
+  } else {
+    const int half0 = (nq + 1) / 2, e0 = ((part == 1) ? 0 : half0) * nq + tid;
+    if (i >= 2 && e0 < ((part == 1) ? half0 : nq) * nq) {
+      pre0 = Tm1[3 * qq + e0];
+      pre1 = (i < N) ? T0[4 * qq + e0] : 0.0;
+    }
   }
   // one round of loads: everything this part needs comes straight from HBM / L2 into its LDS form
   enum { S_V = 0, S_W, S_W1, X_V, X_W1, S_COUNT };
@@ -1164,16 +1195,16 @@ assemble_terms_kernel(DevModel M, DevProblem P, const double* __restrict__ q, co
   auto term = [&](int xa, int sb, int r, int c) { return asm_dot(ops + xa * psz + r * nvp, ops + sb * psz + c * nvp, nv); };
   if (part == 0) {
     // C_i, lower triangle (TO.cc:1127-1137 / :1157-1161), mirrored (MakeSymmetric); then the gradient
-    const int ntri = nq * (nq + 1) / 2;
     for (int item = tid; item < ntri + nq; item += nt) {
+      const bool first = item == tid;
       if (item < ntri) {
         int c = 0, rem = item;
         while (rem >= nq - c) { rem -= nq - c; ++c; }
         const int r = c + rem, e = c * nq + r;
-        const double w0 = (i < N) ? P.Qq[e] : P.Qfq[e];
-        const double tP = Tm1[e];                                   // P_{i-1}^T R' P_{i-1}
-        const double tT = (i < N) ? T0[qq + e] : 0.0;               // T_i^T R' T_i
-        const double tM = (i < N - 1) ? Tp1[2 * qq + e] : 0.0;      // M_{i+1}^T R' M_{i+1}
+        const double w0 = first ? pre3 : ((i < N) ? P.Qq[e] : P.Qfq[e]);
+        const double tP = first ? pre0 : Tm1[e];                                   // P_{i-1}^T R' P_{i-1}
+        const double tT = first ? pre1 : ((i < N) ? T0[qq + e] : 0.0);             // T_i^T R' T_i
+        const double tM = first ? pre2 : ((i < N - 1) ? Tp1[2 * qq + e] : 0.0);    // M_{i+1}^T R' M_{i+1}
         const double* const A2[2] = {ops + X_V * psz + r * nvp, ops + X_W1 * psz + r * nvp};
         const double* const B2[2] = {ops + S_V * psz + c * nvp, ops + S_W1 * psz + c * nvp};
         double tv[2];   // the V- and the W1-term, two chains in lockstep (W1 operands are zeros at i == N)
@@ -1186,14 +1217,14 @@ assemble_terms_kernel(DevModel M, DevProblem P, const double* __restrict__ q, co
           if (i < N - 1) out = out + tM;
           out = out + tv[1];
         }
-        Cg[e] = out;
-        Cg[r * nq + c] = out;
+        asm_put<WT>(Cg + e, out);
+        asm_put<WT>(Cg + r * nq + c, out);
       } else {   // gradient block (TO.cc:1046-1080)
         const int j = item - ntri;
-        const double gP = Tm1[6 * qq + j];                              // P_{i-1}^T R' tau_{i-1}
-        const double gT = (i < N) ? T0[6 * qq + nq + j] : 0.0;          // T_i^T R' tau_i
-        const double gM = (i < N - 1) ? Tp1[6 * qq + 2 * nq + j] : 0.0; // M_{i+1}^T R' tau_{i+1}
-        const double qej = q[i * nq + j] - P.q_nom[i * nq + j];
+        const double gP = first ? pre0 : Tm1[6 * qq + j];                              // P_{i-1}^T R' tau_{i-1}
+        const double gT = first ? pre1 : ((i < N) ? T0[6 * qq + nq + j] : 0.0);        // T_i^T R' tau_i
+        const double gM = first ? pre2 : ((i < N - 1) ? Tp1[6 * qq + 2 * nq + j] : 0.0);   // M_{i+1}^T R' tau_{i+1}
+        const double qej = first ? pre3 - pre4 : q[i * nq + j] - P.q_nom[i * nq + j];
         const double wq = (i < N) ? P.Qq[j * nq + j] : P.Qfq[j * nq + j];
         // sum_r (e_r w_r) J[r][j] for the V- and the W1-term, two chains in lockstep
         const double* JV = ops + S_V * psz + j * nvp;
@@ -1218,7 +1249,7 @@ assemble_terms_kernel(DevModel M, DevProblem P, const double* __restrict__ q, co
           gj = gj + qej * wq;
           gj = gj + gv;
         }
-        g[(size_t)i * nq + j] = gj;
+        asm_put<WT>(g + (size_t)i * nq + j, gj);
       }
     }
   } else {
@@ -1228,15 +1259,32 @@ assemble_terms_kernel(DevModel M, DevProblem P, const double* __restrict__ q, co
       const int c = e / nq, r = e - c * nq;
       double out = 0.0;
       if (i >= 2) {
-        const double tPT = Tm1[3 * qq + e];                        // P_{i-1}^T R' T_{i-1}
-        const double tTM = (i < N) ? T0[4 * qq + e] : 0.0;         // T_i^T R' M_i
+        const bool first = e == c_lo * nq + tid;
+        const double tPT = first ? pre0 : Tm1[3 * qq + e];                        // P_{i-1}^T R' T_{i-1}
+        const double tTM = first ? pre1 : ((i < N) ? T0[4 * qq + e] : 0.0);       // T_i^T R' M_i
         out = tPT;
         if (i < N) out = out + tTM;
         out = out + term(X_V, S_W, r, c);
       }
-      Bg[e] = out;
+      asm_put<WT>(Bg + e, out);
     }
   }
+}
+
+__global__ void __launch_bounds__(256)
+assemble_terms_kernel(DevModel M, DevProblem P, const double* __restrict__ q, const double* __restrict__ terms,
+                      const double* __restrict__ v_res, const double* __restrict__ nplus_res, double* __restrict__ g,
+                      double* __restrict__ HA, double* __restrict__ HB, double* __restrict__ HC, size_t pstride,
+                      const double* __restrict__ gate, AltSel alt) {
+  if (gate && *gate == 0.0) return;   // (idto_hip_tr_solve: the step was rejected, g and H of the iterate stay)
+  {
+    const size_t o = (size_t)blockIdx.z * pstride, w = o + (size_t)alt_offset(alt);
+    P = at_problem(P, o); q = at_problem(q, o); terms = at_problem(terms, w); v_res = at_problem(v_res, w);
+    nplus_res = at_problem(nplus_res, w); g = at_problem(g, o);
+    HA = at_problem(HA, o); HB = at_problem(HB, o); HC = at_problem(HC, o);
+  }
+  extern __shared__ double lds[];
+  assemble_terms_row<false>(M.nq, M.nv, P, q, terms, v_res, nplus_res, g, HA, HB, HC, (int)blockIdx.x, (int)blockIdx.y, lds);
 }
 
 // ---------------------------------------------------------------------------

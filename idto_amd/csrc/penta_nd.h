@@ -51,6 +51,8 @@ struct NdArgs {
   double* ts;                    // option "solver_debug": [7 roles][64] wall-clock stamps (100 MHz)
   SpinCtl spin;                  // where a wait between workgroups that ran out reports it (penta_ldl.h spin_wait)
   int debug_skip_role;           // test aid: this role returns at once (its partners' waits must run out), -1: none
+  const unsigned* asm_ready;     // penta_pipe.h PipeAsm: the launch assembles g and the bands itself ([rows][4] epoch words), else nullptr
+  int asm_first;
   int debug_pipe_tail;           // measurement aid: penta_pipe_kernel takes the row-by-row back substitution
 };
 __device__ __forceinline__ void nd_ts(const NdArgs& A, int role, int slot) {
@@ -330,20 +332,25 @@ __device__ __forceinline__ void nd_separator(const NdArgs& A) {
   double* rtv = Ht + K * ks;         // [2][ks]
   double* dnv = rtv + 2 * ks;        // [2][ks]
   nd_ts(A, 6, 0);
+  // (rows s, s + 1 assembled by this very launch: wait for their eight words, then read past the L2)
+  if (A.asm_ready && tid < 8)
+    spin_wait([&] { return __hip_atomic_load(A.asm_ready + 4 * (s + A.asm_first) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.epoch; }, A.spin);
+  if (A.asm_ready) __syncthreads();
+  auto band = [&](const double* p) { return A.asm_ready ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };
   // band blocks and right-hand sides of the separator rows first (no dependence on the chains)
   for (int idx = tid; idx < K * K; idx += nt) {
     const int c = idx / K, r = idx - c * K;
     const bool in = !PADDED || (r < k && c < k);
-    W[c * ks + r] = in ? A.HC[(size_t)s * kk + c * k + r] : (r == c ? 1.0 : 0.0);
-    W[(K + c) * ks + r] = in ? A.HB[(size_t)(s + 1) * kk + r * k + c] : 0.0;   // block (s, s+1) = B_{s+1}^T
-    S1[c * ks + r] = in ? A.HC[(size_t)(s + 1) * kk + c * k + r] : (r == c ? 1.0 : 0.0);
+    W[c * ks + r] = in ? band(A.HC + (size_t)s * kk + c * k + r) : (r == c ? 1.0 : 0.0);
+    W[(K + c) * ks + r] = in ? band(A.HB + (size_t)(s + 1) * kk + r * k + c) : 0.0;   // block (s, s+1) = B_{s+1}^T
+    S1[c * ks + r] = in ? band(A.HC + (size_t)(s + 1) * kk + c * k + r) : (r == c ? 1.0 : 0.0);
   }
   // (pad rows of the Ht columns are read by the MFMA k-steps of S': LDS is not cleared between
   // kernels, and 0 * NaN from a previous kernel's bits would poison every output)
   for (int idx = tid; idx < K * ks; idx += nt) Ht[idx] = 0.0;
   for (int r = tid; r < K; r += nt) {
-    W[2 * K * ks + r] = (r < k) ? A.rhs_sign * A.b[(size_t)s * k + r] : 0.0;
-    S1[K * ks + r] = (r < k) ? A.rhs_sign * A.b[(size_t)(s + 1) * k + r] : 0.0;
+    W[2 * K * ks + r] = (r < k) ? A.rhs_sign * band(A.b + (size_t)s * k + r) : 0.0;
+    S1[K * ks + r] = (r < k) ? A.rhs_sign * band(A.b + (size_t)(s + 1) * k + r) : 0.0;
   }
   {
     const int w = wave >> 1, sub = wave & 1;            // spike workgroup followed, and which half of its tiles

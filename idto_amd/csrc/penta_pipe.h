@@ -28,6 +28,7 @@
 // Reference recursion: optimizer/penta_diagonal_solver.h:124-197 (Factorize), :199-248 (SolveInPlace).
 #pragma once
 
+#include "kernels.h"
 #include "penta_nd.h"
 
 namespace idto_dev {
@@ -283,8 +284,68 @@ struct PipeArgs {
   // nested dissection (spike chains): [Ft | rt] rows for the separator and their release counters
   double* fst; int fstride; unsigned long long* frowcnt;
   double* xjoin_ll;   // the pair's two join rows of x, joiner -> producer, epoch in every word (penta_nd.h ll_store)
+  // g and the bands assembled by other workgroups of this launch (PipeAsm): [rows][4] words that hold the epoch once
+  // part p of block row i is in memory; solver row o is assembly row o + asm_first.  nullptr: they were there before.
+  const unsigned* asm_ready; int asm_first, asm_rows;
   double* ts;
 };
+
+// ---- g and the band blocks formed INSIDE the solver's launch (idto_hip_gn_step): workgroups 5 .. 5 + 4 (N + 1) - 1
+// of the grid run assemble_terms_kernel's rows (kernels.h assemble_terms_row: same expressions, same bits), store with
+// write-through and publish one word per (block row, part); the chains' loads of a row wait for the words of the
+// rows it touches and bypass the L2 (another XCD's L2 held the lines first).  What this buys is the launch boundary
+// between assembly and solver (~8 us a step); the assembly workgroups are gone long before the chains need
+// their compute units' neighbours.
+struct PipeAsm {
+  int on;                   // 0: the bands are in HBM already
+  int nq, nv, rows, first;  // rows = N + 1 block rows; solver row 0 is block row `first`
+  DevProblem P;
+  const double* q; const double* terms; const double* v_res; const double* nplus;
+  double* g; double* HA; double* HB; double* HC;
+  AltSel alt;
+  unsigned* ready;
+};
+
+__device__ __forceinline__ void pipe_assemble(const NdArgs& A, PipeAsm F) {
+  extern __shared__ double lds[];
+  const int a = (int)blockIdx.x - 5, i = a >> 2, part = a & 3;
+  if (i >= F.rows) return;
+  if (A.ts && threadIdx.x == 0)   // debug stamps of role 5: [0] latest end, [1] latest start of an assembly workgroup (positive doubles order like integers)
+    atomicMax(reinterpret_cast<unsigned long long*>(A.ts + 5 * 64 + 1), (unsigned long long)__double_as_longlong((double)wall_clock64()));
+  if (A.ts && a == 4 && threadIdx.x == 0) A.ts[5 * 64 + 8] = (double)wall_clock64();
+  const size_t o = (size_t)blockIdx.y * A.pstride, w = o + (size_t)alt_offset(F.alt);
+  const DevProblem P = at_problem(F.P, o);
+  assemble_terms_row<true>(F.nq, F.nv, P, at_problem(F.q, o), at_problem(F.terms, w), at_problem(F.v_res, w),
+                           at_problem(F.nplus, w), at_problem(F.g, o), at_problem(F.HA, o), at_problem(F.HB, o),
+                           at_problem(F.HC, o), i, part, lds);
+  if (A.ts && a == 4 && threadIdx.x == 0) A.ts[5 * 64 + 9] = (double)wall_clock64();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every write-through store acknowledged ...
+  __syncthreads();
+  if (A.ts && a == 4 && threadIdx.x == 0) A.ts[5 * 64 + 10] = (double)wall_clock64();
+  if (threadIdx.x == 0)                              // ... before the word that says so
+    __hip_atomic_store(at_problem(F.ready, o) + 4 * i + part, A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (A.ts && threadIdx.x == 0)
+    atomicMax(reinterpret_cast<unsigned long long*>(A.ts + 5 * 64), (unsigned long long)__double_as_longlong((double)wall_clock64()));
+}
+
+// one wavefront waits for solver rows o_lo .. o_hi (clamped to the system) to be assembled: a lane per word
+__device__ __forceinline__ void pipe_rows_ready(const PipeArgs& A, const PipeCtl& c, int o_lo, int o_hi, const SpinCtl sc) {
+  if (!A.asm_ready) return;
+  const int lane = threadIdx.x & 63;
+  o_lo = o_lo < 0 ? 0 : o_lo;
+  o_hi = o_hi > A.n - 1 ? A.n - 1 : o_hi;
+  const int nw = 4 * (o_hi - o_lo + 1);
+  const unsigned* w = A.asm_ready + 4 * (o_lo + A.asm_first) + (lane < nw ? lane : 0);
+  const bool ok = spin_wait([&] {
+    const bool mine = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.epoch;
+    return __builtin_amdgcn_ballot_w64(mine) == __builtin_amdgcn_ballot_w64(true);
+  }, sc);
+  if (!ok) c.f[PF_ABORT] = 1;
+}
+// a band entry: through the L2 when it was assembled by this launch
+__device__ __forceinline__ double pipe_band(const PipeArgs& A, const double* p) {
+  return A.asm_ready ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
 
 // ---- a chain wavefront.  Three of them take turns: while one ELIMINATES row i (publishing every pivot row), the
 // other two FOLLOW it with the Schur update of row i+1, W_{i+1} -= Ht_i^T Dn [Ht_i | Et_i | rt_i], one half of
@@ -421,8 +482,9 @@ __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCf
       }
       const int o = mir ? cfg.base - il : cfg.base + il;
       const double* base = A.HA + (size_t)(o < 0 ? 0 : o) * kk + pipe_opaque(off);
+      if (il < 2) pipe_rows_ready(A, ctl, o, mir ? o : o + 2, cfg.spin);
 #pragma unroll
-      for (int r = 0; r < K; ++r) xr[r] = (il < 2 && on) ? base[r * stride] : 0.0;
+      for (int r = 0; r < K; ++r) xr[r] = (il < 2 && on) ? pipe_band(A, base + r * stride) : 0.0;
       return;
     }
     pipe_wait(ctl, PF_STAGED + (il & 1), il + 1);
@@ -722,11 +784,21 @@ __device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& 
       unsigned long long kill = ~mAny;
       if (pseudo) kill = ~0ull;
       else if (!producer && cfg.two) kill |= (il >= m_split ? mE : 0ull) | (il >= m_split + 1 ? mH : 0ull);
+      if (!pseudo) pipe_rows_ready(A, ctl, o, mirror ? o : o + 2, cfg.spin);
+      if (il == 0 && A.ts && lane == 0) A.ts[7] = (double)wall_clock64();   // (debug: the first row's inputs are assembled)
       double val[PM];
+      if (A.asm_ready) {
 #pragma unroll
-      for (int s = 0; s < PM; ++s) {
-        const double* p = (mY >> s & 1) ? bp : base;
-        val[s] = p[s_off[s]];
+        for (int s = 0; s < PM; ++s) {
+          const double* p = (mY >> s & 1) ? bp : base;
+          val[s] = __hip_atomic_load(p + s_off[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < PM; ++s) {
+          const double* p = (mY >> s & 1) ? bp : base;
+          val[s] = p[s_off[s]];
+        }
       }
 #pragma unroll
       for (int s = 0; s < PM; ++s) {
@@ -1023,7 +1095,8 @@ __device__ __forceinline__ void pipe_backward(const PipeArgs& A, const ChainCfg&
 // Every wait is bounded (PIPE_SPIN_CAP): a workgroup that is not resident with its partners ends with the
 // factorisation status set instead of hanging the device.
 template <int K>
-__global__ void __launch_bounds__(512) penta_pipe_kernel(NdArgs A) {
+__global__ void __launch_bounds__(512) penta_pipe_kernel(NdArgs A, PipeAsm F) {
+  if (blockIdx.x >= 5) { pipe_assemble(A, F); return; }
   {
     const size_t o = (size_t)blockIdx.y * A.pstride;
     A.HA = at_problem(A.HA, o); A.HB = at_problem(A.HB, o); A.HC = at_problem(A.HC, o); A.b = at_problem(A.b, o);
@@ -1035,7 +1108,12 @@ __global__ void __launch_bounds__(512) penta_pipe_kernel(NdArgs A) {
   }
   const int role = blockIdx.x;
   if (role == A.debug_skip_role) return;
-  if (role == 4) { nd_separator<K, false>(A); return; }
+  if (role == 4) {
+    A.asm_ready = F.on ? at_problem(F.ready, (size_t)blockIdx.y * A.pstride) : nullptr;
+    A.asm_first = F.first;
+    nd_separator<K, false>(A);
+    return;
+  }
   const NdBuf B = nd_layout(K);
   ChainCfg c = {};
   c.two = 1;
@@ -1066,6 +1144,8 @@ __global__ void __launch_bounds__(512) penta_pipe_kernel(NdArgs A) {
   P.frowcnt = role >= 2 ? A.rowcnt + (2 + role - 2) * ND_MAXROWS : nullptr;
   P.ts = c.ts;
   P.xjoin_ll = A.ndbuf + B.ll + (1 + pair) * 4 * K;
+  P.asm_ready = F.on ? at_problem(F.ready, (size_t)blockIdx.y * A.pstride) : nullptr;
+  P.asm_first = F.first; P.asm_rows = F.rows;
   const bool spike = role >= 2;
   const PipeLds L = pipe_layout<K>(A.n, spike);
   if (spike) pipe_forward<K, true>(P, c, L);

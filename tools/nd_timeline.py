@@ -15,9 +15,18 @@ dev.set_q(synthetic_trajectory(cfg, model, N, seed=0, lower=0.01))
 for _ in range(5):
     dev.gn_step()
 dev.set_option("solver_debug", 1)
-dev.factor_solve(); dev.factor_solve()
+fused = os.environ.get("IDTO_TIMELINE_GN_STEP", "0") == "1"   # the whole Gauss-Newton step: the solver's launch assembles g and H too
+if fused:
+    dbg = dev.device_ptr("debug") if hasattr(dev, "device_ptr") else None
+    dev.gn_step(); dev.gn_step()
+else:
+    dev.factor_solve(); dev.factor_solve()
 d = dev.get("debug")[:7 * 64].reshape(7, 64) / 100.0
 t0 = d[:4, 0].min()
+if fused and dev.get_option("last_assembly") == 4:
+    print("  block row 1 part 0: start %.2f, results computed and stores issued %.2f, stores acknowledged %.2f" % tuple(d[5][8:11] - t0))
+    print("  chains saw their first row's inputs assembled at", " ".join("%.2f" % (d[r][7] - t0) for r in range(4)))
+    print(f"assembly workgroups inside the launch: the last one started at {d[5][1] - t0:.2f}, the last one had published its block at {d[5][0] - t0:.2f} (maxima over ALL debug launches)")
 if dev.get_option("last_solver") == 4:   # pipelined chains (csrc/penta_pipe.h): five workgroups, no spike workgroups
     names = ["P0 producer", "P3 producer", "J1 joiner", "J2 joiner"]
     for r in range(4):
