@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--no-full", action="store_true", help="skip the informational full-iteration measurement")
     ap.add_argument("--batch", type=int, default=16,
                     help="also report the aggregate rate of this many independent problems on one GPU (0/1: skip)")
+    ap.add_argument("--set", action="append", default=[], metavar="OPTION=INT",
+                    help="a context option of the C-ABI (idto_hip_set_option), e.g. asm_in_solver=0: profiling aid")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -224,6 +226,9 @@ def main():
     dev = hip.HipPath(model, prob, sp, device=local_rank)
     stream = torch.cuda.current_stream()
     dev.set_stream(stream.cuda_stream)
+    for kv in args.set:
+        name, _, val = kv.partition("=")
+        dev.set_option(name, int(val))
     dev.set_q(q)
 
     exch = None

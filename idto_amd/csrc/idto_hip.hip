@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <initializer_list>
 #include <limits>
@@ -920,7 +921,8 @@ static NdSplit nd_split(int n, bool pipe) {
   const int htop = sp.s, hbot = n - sp.s - 2;
   auto producer_rows = [&](int half) {
     if (!pipe) return (half - 2) / 2;
-    int np = (int)(0.575 * (half - 2) + 0.6);
+    static const double share = [] { const char* e = std::getenv("IDTO_PIPE_SPLIT"); return e ? std::atof(e) : 0.52; }();   // (measurement aid)
+    int np = (int)(share * (half - 2) + 0.6);
     return std::max(1, std::min(np, half - 3));
   };
   sp.j1 = producer_rows(htop);                     // producer P0: rows 0 .. j1-1

@@ -59,7 +59,7 @@ __device__ __forceinline__ void nd_ts(const NdArgs& A, int role, int slot) {
   if (A.ts && threadIdx.x == 0) A.ts[role * 64 + slot] = (double)wall_clock64();
 }
 
-struct NdBuf { int rtpub, fst, frow, xsep, ll, end; };  // offsets in doubles; rtpub / fst are [2][...]
+struct NdBuf { int rtpub, fst, frow, xsep, ll, joinll, joinll_pair, end; };  // offsets in doubles; rtpub / fst are [2][...]
 __host__ __device__ inline NdBuf nd_layout(int K) {
   NdBuf L;
   const int ks = ldl_ks(K), ct2 = (2 * K + 1 + 15) / 16;   // columns [Ft | rt], in tiles of 16
@@ -70,6 +70,8 @@ __host__ __device__ inline NdBuf nd_layout(int K) {
   L.xsep = o; o += 2 * K;
   o += o & 1;
   L.ll = o; o += 3 * 4 * K;              // flagged copies (ll_store): x_sep, and the two join rows of each producer / joiner pair
+  L.joinll = o; L.joinll_pair = 2 * 2 * K * 64;            // [pseudo row][r][column: 64 lanes] of 16-byte slots   // penta_pipe.h: a producer's Schur-complement contributions to the join rows, flagged
+  o += 2 * L.joinll_pair;
   L.end = o;
   return L;
 }

@@ -60,7 +60,7 @@ struct PipeGeo {
 };
 
 struct PipeLds {   // offsets in doubles
-  int ring, stage, gbuf, xhi, xall, W, flags, end;
+  int ring, stage, gbuf, xhi, jbuf, xall, W, flags, end;
 };
 template <int K>
 __host__ __device__ inline PipeLds pipe_layout(int n, bool spike) {
@@ -75,6 +75,7 @@ __host__ __device__ inline PipeLds pipe_layout(int n, bool spike) {
     L.xhi = o; o += (G::NCX + (spike ? 2 * K : 0) + 1) * (NHI + (NHI & 1)) + 2;
   }
   (void)n;
+  L.jbuf = o; o += spike ? (3 * K + 2) * G::KE : 0;   // a joiner: the producer's contributions to its two join rows, columns [S | H | y], [S | y]
   L.xall = o; o += (ND_MAXROWS + 2) * G::GS;   // rt of the chain's local rows (two leading zero rows)
   L.W = o; o += 2 * G::KE + 2;
   L.flags = o; o += 32;            // 64 ints
@@ -95,7 +96,7 @@ enum {
   PF_COPIED = 22,    // [3] factors of the row in ring slot s are written out
   PF_COPIED2 = 25,   // [3] spike columns likewise
   PF_ABORT = 28,     // a bounded wait ran out: everybody stops waiting
-  PF_JOINCNT = 29,   // producer: wavefronts that have written their join contribution
+  PF_JOINED = 29,    // joiner: the producer's contributions to the two join rows are in the stage buffers
   PF_HIDONE = 30,    // the second follower's (high) rows of row il are in the hand-over buffer (main columns)
   PF_HIDONE2 = 31,   // (spike columns)
   PF_COUNT = 32
@@ -284,6 +285,7 @@ struct PipeArgs {
   // nested dissection (spike chains): [Ft | rt] rows for the separator and their release counters
   double* fst; int fstride; unsigned long long* frowcnt;
   double* xjoin_ll;   // the pair's two join rows of x, joiner -> producer, epoch in every word (penta_nd.h ll_store)
+  double* join_ll;    // the producer's contributions to the join rows, [2][(3K + 1) ks] values in the same form
   // g and the bands assembled by other workgroups of this launch (PipeAsm): [rows][4] words that hold the epoch once
   // part p of block row i is in memory; solver row o is assembly row o + asm_first.  nullptr: they were there before.
   const unsigned* asm_ready; int asm_first, asm_rows;
@@ -482,7 +484,7 @@ __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCf
       }
       const int o = mir ? cfg.base - il : cfg.base + il;
       const double* base = A.HA + (size_t)(o < 0 ? 0 : o) * kk + pipe_opaque(off);
-      if (il < 2) pipe_rows_ready(A, ctl, o, mir ? o : o + 2, cfg.spin);
+      if (il < 2) pipe_rows_ready(A, ctl, o, o + 2, cfg.spin);   // (the coupling blocks sit in rows o + 1, o + 2 of the band arrays for both directions)
 #pragma unroll
       for (int r = 0; r < K; ++r) xr[r] = (il < 2 && on) ? pipe_band(A, base + r * stride) : 0.0;
       return;
@@ -560,28 +562,8 @@ __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCf
       if (gcol >= 0) sub_g(il, xr, take_high ? RLO : K);
       subg_done = true;
     };
-    // ---- join rows of a joiner: the producer's Schur-complement contributions to this row, fetched NOW - the
-    // producer chain (no spike columns) has long finished when the joiner arrives here, and the loads (19 per lane,
-    // a cold round trip to another workgroup's stores) then overlap the row this wavefront is about to follow.  One
-    // branch-free pass: every lane has a source (or a zero factor).
-    const bool joins = !producer && !spk && cfg.two && il >= m_split;
-    double xjoin[K];
-    if (joins) {
-      if (il == m_split) chain_ts(cfg, 1);
-      const bool ok = pipe_wait_global(ctl, A.flags, A.epoch, cfg.spin);
-      constexpr int wsz = (K + 2 * K + 1) * ks;
-      // X0: contributions to the join row next to the producer (+ the coupling of the two), X1: to the other
-      const int first = (il == m_split);
-      int off = 0, stride = 0;
-      double on = 0.0;
-      if (lane < K || lane == 3 * K) { off = (first ? wsz : 0) + lane * ks; stride = 1; on = 1.0; }       // S, y
-      else if (lane < 2 * K && first) { off = K * ks + (lane - K); stride = ks; on = 1.0; }                 // H(r, c) += H'(c, r)
-      off = pipe_opaque(off);
-      if (!ok) on = 0.0;
-#pragma unroll
-      for (int r = 0; r < K; ++r) xjoin[r] = A.xch[off + r * stride] * on;
-      if (il == m_split) chain_ts(cfg, 5);
-    }
+    // (join rows of a joiner: the producer's Schur-complement contributions were added to the row's inputs by the I/O
+    // wavefront when it staged them - no chain wavefront ever waits on another workgroup's memory)
     if (il >= 3 && !pseudo) {
       // this row will be published into the ring slot of row il - 3: that row must have been consumed.  It has
       // long been, and here - before the row to follow has started - the check costs nothing.
@@ -618,24 +600,26 @@ __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCf
         if (2 * q + 1 < NHI) xr[RLO + 2 * q + 1] -= v.y;
       }
     };
-    // ---- join rows of a joiner: the producer's Schur-complement contributions (fetched at the top of the iteration)
-    if (joins) {
+    if (!producer && !spk && cfg.two && il >= m_split) {
+      // ---- join rows of a joiner: + the producer's contributions (fetch_join, the I/O wavefront)
+      pipe_wait(ctl, PF_JOINED, 1);
+      const bool first = il == m_split;
+      // stage column -> column of the buffer: S, H (first join row only), y
+      const int jc = scol < K ? scol : (scol < 2 * K && first) ? scol : scol == 3 * K ? (first ? 2 * K : K) : -1;
+      if (has_col && jc >= 0) {
+        const double2* s2 = reinterpret_cast<const double2*>(lds + L.jbuf + (first ? 0 : (2 * K + 1) * G::KE) + jc * G::KE);
 #pragma unroll
-      for (int r = 0; r < K; ++r) xr[r] += xjoin[r];
+        for (int r2 = 0; r2 < K / 2; ++r2) { const double2 v = s2[r2]; xr[2 * r2] += v.x; xr[2 * r2 + 1] += v.y; }
+        if (K & 1) xr[K - 1] += lds[L.jbuf + (first ? 0 : (2 * K + 1) * G::KE) + jc * G::KE + K - 1];
+      }
     }
     if (pseudo) {
       // ---- producer: hand the column over (layout of penta_ldl_body's exchange buffer)
       high_rows();
-      if (has_col) {
-        const int wo = pipe_opaque((il - nloc) * (K + 2 * K + 1) * ks + lane * ks);   // column `lane` of [S | H | E | y]
+      if (has_col) {   // (write-through, the epoch in every word: no fence, no flag - penta_nd.h ll_store)
+        const int wo = pipe_opaque((il - nloc) * K * 64 + lane);   // column `lane` of [S | H | E | y]
 #pragma unroll
-        for (int r = 0; r < K; ++r) A.xch[wo + r] = xr[r];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) {
-        const int old = __hip_atomic_fetch_add(reinterpret_cast<int*>(lds + L.flags) + PF_JOINCNT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (old == 1) __hip_atomic_store(A.flags, A.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        for (int r = 0; r < K; ++r) ll_store(A.join_ll + 2 * (wo + r * 64), xr[r], A.epoch);
       }
     } else {
       // ---- eliminate, publishing every pivot row
@@ -807,6 +791,42 @@ __device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& 
         if (s_dst[s] < 2 * NCS * GS) dst[s_dst[s]] = v;
       }
     };
+    // The producer's Schur-complement contributions to the joiner's two join rows (its two pseudo-rows; penta_nd.h
+    // ll_store: every value carries the epoch, the lanes poll the data itself, all 36 loads of a lane in flight at
+    // once) -> LDS, columns [S | H | y] for the join row next to the producer (X0 = pseudo-row 1, and the coupling of
+    // the two join rows, H(r, c) += H'(c, r)), [S | y] for the other (X1 = pseudo-row 0).  Source slots: [pseudo
+    // row][r][column: 64].  The chain wavefronts pick the values up from LDS after they have followed the row before:
+    // none of them ever waits on another workgroup's memory.  One attempt; false: not all there yet.
+    auto fetch_join = [&]() {
+      constexpr int NV1 = (2 * K + 1) * K, NV2 = (K + 1) * K, PM1 = (NV1 + 63) / 64, PM2 = (NV2 + 63) / 64;
+      const unsigned long long* q = reinterpret_cast<const unsigned long long*>(A.join_ll);
+      double add[PM1 + PM2];
+      bool good = true;
+#pragma unroll
+      for (int s = 0; s < PM1 + PM2; ++s) {
+        const bool one = s < PM1;
+        const int v = lane + 64 * (one ? s : s - PM1), c = v / K, r = v - c * K;
+        const bool in = v < (one ? NV1 : NV2);
+        int src = 0;
+        if (one) src = c < K ? K * 64 + r * 64 + c : c < 2 * K ? (c - K) * 64 + K + r : K * 64 + r * 64 + 3 * K;
+        else src = c < K ? r * 64 + c : r * 64 + 3 * K;
+        src = in ? src : 0;
+        const unsigned long long a = __hip_atomic_load(q + 2 * src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long b = __hip_atomic_load(q + 2 * src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        add[s] = __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
+        good = good && (!in || ((unsigned)(a >> 32) == A.epoch && (unsigned)(b >> 32) == A.epoch));
+      }
+      if (__builtin_amdgcn_ballot_w64(good) != __builtin_amdgcn_ballot_w64(true)) return false;
+      double* jb = lds + L.jbuf;
+#pragma unroll
+      for (int s = 0; s < PM1 + PM2; ++s) {
+        const bool one = s < PM1;
+        const int v = lane + 64 * (one ? s : s - PM1), c = v / K, r = v - c * K;
+        if (v < (one ? NV1 : NV2)) jb[(one ? 0 : (2 * K + 1) * G::KE) + c * G::KE + r] = add[s];
+      }
+      return true;
+    };
+    bool join_done = producer || !cfg.two;
     auto copy_row = [&](int il) {
       const int slot = il % 3, o = orig(il);
       const double* row0 = ring + slot * G::SLOT;
@@ -833,16 +853,31 @@ __device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& 
     stage_row(0);
     pipe_post(ctl, PF_STAGED + 0, 1);
     if (nrows > 1) { stage_row(1); pipe_post(ctl, PF_STAGED + 1, 2); }
+    int copied = 0;   // rows whose factors are written out
     for (int t = 0; t < nrows; ++t) {
       if (t + 2 < nrows) {
         pipe_wait(ctl, PF_INITD + (t & 1), t + 1);
         stage_row(t + 2);
         pipe_post(ctl, PF_STAGED + (t & 1), t + 3);
       }
-      if (t < nloc) {
-        pipe_wait(ctl, PF_ROWDONE + t % 3, t + 1);
-        copy_row(t);
-        pipe_post(ctl, PF_COPIED + t % 3, t + 1);
+      // the producer's contributions (fetch_join): a look when the row before the last is staged, the wait proper
+      // when the last one is.  From the first look on the factors of finished rows wait their turn (the ring slot of
+      // row t is not needed again before row t + 3): the chains want the join data the moment the row before the
+      // join has been followed, and copy_row's release fence alone is ~1 us.
+      if (!join_done && t + 2 >= m_split) {
+        if (cfg.ts && lane == 0 && t + 1 >= m_split) cfg.ts[1] = (double)wall_clock64();
+        if (t + 1 >= m_split) { if (!spin_wait(fetch_join, cfg.spin)) ctl.f[PF_ABORT] = 1; join_done = true; }
+        else join_done = fetch_join();
+        if (join_done) {
+          pipe_post(ctl, PF_JOINED, 1);
+          if (cfg.ts && lane == 0) cfg.ts[5] = (double)wall_clock64();
+        }
+      }
+      if (!join_done && t + 2 >= m_split) continue;
+      for (; copied <= t && copied < nloc; ++copied) {
+        pipe_wait(ctl, PF_ROWDONE + copied % 3, copied + 1);
+        copy_row(copied);
+        pipe_post(ctl, PF_COPIED + copied % 3, copied + 1);
       }
     }
   } else if (wave == W_G) {
@@ -1144,6 +1179,7 @@ __global__ void __launch_bounds__(512) penta_pipe_kernel(NdArgs A, PipeAsm F) {
   P.frowcnt = role >= 2 ? A.rowcnt + (2 + role - 2) * ND_MAXROWS : nullptr;
   P.ts = c.ts;
   P.xjoin_ll = A.ndbuf + B.ll + (1 + pair) * 4 * K;
+  P.join_ll = A.ndbuf + B.joinll + (size_t)pair * B.joinll_pair;
   P.asm_ready = F.on ? at_problem(F.ready, (size_t)blockIdx.y * A.pstride) : nullptr;
   P.asm_first = F.first; P.asm_rows = F.rows;
   const bool spike = role >= 2;

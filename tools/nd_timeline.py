@@ -35,6 +35,8 @@ if dev.get_option("last_solver") == 4:   # pipelined chains (csrc/penta_pipe.h):
         gaps = np.diff([a for a, _ in rows])
         print(f"{names[r]:12s} start {x[0]:6.2f}  join-wait-begin {x[1]:6.2f}  join-wait-end {x[5]:6.2f}  forward done {x[2]:6.2f}  "
               f"backward start {x[3]:6.2f}  end {x[4]:6.2f}")
+        if r >= 2:
+            print(f"   first join row: staging began {x[1]:.2f}, the producer's contributions were in {x[5]:.2f}")
         print("   elimination of row il (start, end):", " ".join(f"({a:5.2f},{b:5.2f})" for a, b in rows))
         if len(gaps):
             print(f"   median: row to row {np.median(gaps):.2f} us, the K pivots {np.median([b - a for a, b in rows]):.2f} us")
