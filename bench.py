@@ -362,6 +362,59 @@ def main():
         except Exception as e:  # informational only: never lose the metric over it
             other_extra = {"error": str(e)[:200]}
 
+    # ---- the sharded result against the same problem on one device (every rank: same bits expected everywhere)
+    bit_identical = None
+    if world > 1 and sharded and exch is not None:
+        try:
+            dev.set_shard(exch.lo, exch.hi)
+            dev.set_q(q)
+            step_sharded()
+            p_sh = dev.get("step")
+            dev.set_shard(0, N)
+            dev.set_q(q)
+            dev.gn_step()
+            same = 1.0 if np.array_equal(dev.get("step"), p_sh) else 0.0
+            tt = torch.tensor([same], device=("cuda" if backend == "nccl" else "cpu"), dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+            bit_identical = bool(tt.item() == 1.0)
+        except Exception as e:  # informational only
+            bit_identical = f"not checked: {str(e)[:160]}"
+
+    # ---- BASELINE config 5 on the same ranks (informational, outside the timed region of `value`): allegro_hand
+    # + sphere, 60 steps, one warm-started problem per GPU, no collective on the data path
+    config5 = None
+    if world > 1:
+        try:
+            c5, m5 = load_config("allegro_hand"), load_model("allegro_hand")
+            N5 = 60
+            p5, s5, _ = make_problem(c5, m5, num_steps=N5)
+            s5.scaling = False
+            s5.equality_constraints = False
+            d5 = hip.HipPath(m5, p5, s5, device=local_rank)
+            d5.set_stream(stream.cuda_stream)
+            q5 = synthetic_trajectory(c5, m5, N5, seed=rank, lower=0.01)
+            d5.set_q(q5)
+            d5.gn_step()
+            q5 = q5 + 0.5 * d5.get("step").reshape(q5.shape)   # warm start: the guess after one damped Gauss-Newton step
+            d5.set_q(q5)
+            for _ in range(5):
+                d5.gn_step()
+            barrier()
+            n5 = max(10, args.steps // 4)
+            t1 = time.perf_counter()
+            for _ in range(n5):
+                d5.gn_step()
+            barrier()
+            el = max_over_ranks(time.perf_counter() - t1)
+            ok5 = bool(np.all(np.isfinite(d5.get("step")))) and d5.solver_status() == (False, 0)
+            config5 = {"workload": f"allegro_hand + sphere (nq={m5.nq}, nv={m5.nv}, {m5.npairs} contact pairs), horizon N={N5}, "
+                                   f"one warm-started problem per GPU ({world} problems), no data-path collective",
+                       "value": world * n5 / el, "unit": "GN iters/s (aggregate)", "steps": n5, "ms_per_step": 1e3 * el / n5,
+                       "scaling": "weak", "finite_and_factorised_on_rank0": ok5}
+            d5.close()
+        except Exception as e:  # informational only: never lose the metric over it
+            config5 = {"error": str(e)[:200]}
+
     batch_extra = None
     if world == 1 and args.batch > 1:
         # informational (never `value`): B independent problems resident on this ONE GPU and advanced by
@@ -440,6 +493,15 @@ def main():
             out["config"]["note"] = exchange_note
         if other_extra is not None:
             out[other_key] = other_extra
+        if bit_identical is not None:
+            out["bit_identical_to_unsharded"] = bit_identical
+        if config5 is not None:
+            out["config5_workload"] = config5
+        try:   # which RCCL this process resolved (libidto_hip.so checks the major version where a communicator is created)
+            rp, rv = hip.rccl_info()
+            out["rccl"] = {"path": rp, "version_code": rv}
+        except Exception as e:
+            out["rccl"] = {"error": str(e)[:120]}
         out["step_latency_ms"] = latency
         if batch_extra is not None:
             out["batch_mode"] = batch_extra

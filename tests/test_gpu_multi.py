@@ -131,3 +131,38 @@ def test_cpp_optimizer_over_a_device_list():
         opt.close()
     assert outs[0][0] == outs[1][0]
     assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="needs two visible devices (runs by itself on a multi-GPU node)")
+@pytest.mark.parametrize("name,N,ndev", [("mini_cheetah", 9, 2), ("mini_cheetah", 40, 2), ("allegro_hand", 13, 2),
+                                         ("mini_cheetah", 41, 4), ("mini_cheetah", 40, 8)])
+def test_devices_of_one_process_share_the_horizon(name, N, ndev):
+    """One process, one context per device, idto_hip_comm_init_all + idto_hip_gn_step_multi: every device evaluates
+    its k-range (ragged: 9 = 5 + 4, 41 over 4, 13 over 2), the grouped RCCL all-gather completes every slab in place,
+    every device assembles and solves - slab and step of EVERY device equal the unsharded run bit for bit
+    (trajectory_optimizer.cc:455-457: the reference's parallel loop over time steps, here over devices)."""
+    if _device_count() < ndev:
+        pytest.skip(f"{ndev} devices wanted, {_device_count()} visible")
+    model, prob, sp, q = _setup(name, N)
+    ref = hip.HipPath(model, prob, sp, device=0)
+    ref.set_q(q)
+    ref.gn_step()
+    want_slab, want_step = ref.get("slab"), ref.get("step")
+    ref.close()
+    devs = [hip.HipPath(model, prob, sp, device=d) for d in range(ndev)]
+    for d in devs:
+        d.set_q(q)
+    hip.comm_init_all(devs)
+    for _ in range(3):
+        hip.gn_step_multi(devs)
+    for r, d in enumerate(devs):
+        assert _same(d.get("slab"), want_slab), f"slab of device {r}"
+        assert _same(d.get("step"), want_step), f"step of device {r}"
+    for d in devs:
+        d.comm_destroy()
+        d.close()
