@@ -979,17 +979,28 @@ SolverFlag TO::SolveFromWarmStart(WarmStart* ws, TrajectoryOptimizerSolution<T>*
 // of the mini_cheetah example); otherwise SolveFromWarmStartImpl below keeps g / H on the host.
 bool TO::DeviceLoopEligible() const {
   if (std::getenv("IDTO_OPT_HOST_LOOP") || force_host_loop_) return false;
-  if (params_.check_convergence || !shard_ctx_.empty()) return false;
+  if (!shard_ctx_.empty()) return false;
   const bool constrained = params_.equality_constraints && num_equality_constraints() > 0;
-  if (!constrained) return true;
-  // enforced constraints: only the resident loop (idto_hip_tr_solve) has them on the device (multipliers by a
-  // single-workgroup LDL^T of S for n_eq <= 128, by the blocked one above), with the non-adaptive scalings
+  if (!constrained && !params_.check_convergence) return true;
+  // enforced constraints and the convergence criteria: only the resident loop (idto_hip_tr_solve) has them on the
+  // device (multipliers by a single-workgroup LDL^T of S for n_eq <= 128, by the blocked one above; the criteria
+  // by the iteration kernel that follows an accepted step)
+  return ResidentLoopEligible();
+}
+
+// every iteration enqueued at once, decisions on the device, one wait (idto_hip_tr_solve)
+bool TO::ResidentLoopEligible() const {
+  if (params_.max_iterations <= 0 || std::getenv("IDTO_OPT_STEPWISE")) return false;
   const int scal = params_.scaling ? static_cast<int>(params_.scaling_method) : -1;
-  return (scal == -1 || scal == 0 || scal == 2) && params_.max_iterations > 0 && !std::getenv("IDTO_OPT_STEPWISE");
+  const bool adaptive = scal == static_cast<int>(kAdaptiveSqrt) || scal == static_cast<int>(kAdaptiveDoubleSqrt);
+  if (!adaptive) return true;
+  int weights_diagonal = 0;   // (the adaptive scalings ride on the gated assembly, which serves diagonal cost weights)
+  Check(idto_hip_get_option(hip_, "weights_diagonal", &weights_diagonal));
+  return weights_diagonal != 0;
 }
 
 SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solution,
-                             TrajectoryOptimizerStats<T>* stats) const {
+                             TrajectoryOptimizerStats<T>* stats, ConvergenceReason* reason_out) const {
   using clock = std::chrono::high_resolution_clock;
   const auto start_time = clock::now();
   auto iter_start = clock::now();
@@ -1020,10 +1031,18 @@ SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solu
   double S[9] = {0};
   int k = 0;
   // every iteration enqueued at once, decisions on the device, one wait (idto_hip_tr_solve); the
-  // stepwise loop below serves the adaptive scalings and IDTO_OPT_STEPWISE=1
-  const bool resident_loop = params_.max_iterations > 0 && (scal == -1 || scal == 0 || scal == 2) &&
-                             !std::getenv("IDTO_OPT_STEPWISE");
+  // stepwise loop below serves IDTO_OPT_STEPWISE=1 (and the adaptive scalings with dense cost weights)
+  const bool resident_loop = ResidentLoopEligible();
+  bool converged = false;
   if (resident_loop) {
+    if (params_.check_convergence) {   // VerifyConvergenceCriteria (TO.cc:2654-2689) inside the device loop
+      const auto& t = params_.convergence_tolerances;
+      const double tol[6] = {t.rel_cost_reduction, t.abs_cost_reduction, t.rel_gradient_along_dq, t.abs_gradient_along_dq,
+                             t.rel_state_change, t.abs_state_change};
+      Check(idto_hip_tr_set_convergence(hip_, tol));
+    } else {
+      Check(idto_hip_tr_set_convergence(hip_, nullptr));
+    }
     const int iters = params_.max_iterations;
     std::vector<double> rows((std::size_t)iters * IDTO_TR_ROW);
     double Delta_end = Delta;
@@ -1052,6 +1071,8 @@ SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solu
         stats->solve_time += device_part;
         return flag;
       }
+      if (flags & 32)   // (in the iteration it happened in, not only when it is the last one: idto_hip_tr_solve rows [14])
+        throw FactorizationFailedError("idto_hip: factorisation failed in iteration " + std::to_string(k));
       if (flags & 3) throw FactorizationFailedError("idto_hip: the dogleg step is not finite");
       if (flags & 4) throw std::runtime_error("step is not a descent direction (TO.cc:2531)");
       const double iter_time = (k == 0) ? std::max(0.0, total - timed) : (R[10] - R[10 - IDTO_TR_ROW]) * 1e-8;
@@ -1061,10 +1082,20 @@ SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solu
       stats->push_data(iter_time, R[0], 0, std::numeric_limits<double>::quiet_NaN(), R[1], R[3], R[4], R[5], R[2], R[6],
                        R[7], R[8], R[15]);   // :2586-2598 (merit = cost without constraints)
       last_accepted = R[9] != 0.0;
+      if (params_.check_convergence && last_accepted) {   // :2600-2612
+        const ConvergenceReason reason = static_cast<ConvergenceReason>((int)R[16]);
+        stats->convergence_reason = reason;
+        if (reason_out) *reason_out = reason;
+        if (reason != kNoConvergenceCriteriaSatisfied) {   // (the reference leaves the loop before the radius update)
+          converged = true;
+          Delta = R[1];
+          break;
+        }
+      }
     }
-    Delta = Delta_end;
+    if (!converged) Delta = Delta_end;
   }
-  while (k < params_.max_iterations) {
+  while (k < params_.max_iterations && !converged) {
     if (!have) {
       Check(idto_hip_gn_step(hip_));
       Check(idto_hip_tr_prepare(hip_, scal, 0, S));   // (reports a failed factorisation)
@@ -1147,7 +1178,7 @@ SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solu
 SolverFlag TO::SolveFromWarmStartImpl(WarmStart* ws, TrajectoryOptimizerSolution<T>* solution,
                                       TrajectoryOptimizerStats<T>* stats, ConvergenceReason* reason_out) const {
   using clock = std::chrono::high_resolution_clock;
-  if (params_.method == kTrustRegion && DeviceLoopEligible()) return SolveOnDevice(ws, solution, stats);
+  if (params_.method == kTrustRegion && DeviceLoopEligible()) return SolveOnDevice(ws, solution, stats, reason_out);
   if (params_.method != kTrustRegion) throw std::runtime_error("warm start requires the trust-region method");
   const auto start_time = clock::now();
   auto iter_start = clock::now();

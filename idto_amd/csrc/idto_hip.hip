@@ -103,6 +103,8 @@ struct idto_hip_ctx {
   bool solver_pipe = true;                // ... with pipelined chains (penta_pipe.h: 5 workgroups) when the block size allows
   unsigned long long* nd_rowcnt = nullptr; // its per-row release counters, buffers and launch count
   unsigned* asm_ready = nullptr;               // penta_pipe.h PipeAsm: [N + 1][4] epoch words of the assembly inside the solver's launch
+  bool tr_conv_on = false;                 // idto_hip_tr_set_convergence
+  double tr_conv_tol[6] = {0, 0, 0, 0, 0, 0};
   bool asm_in_solver = true;                  // option "asm_in_solver": idto_hip_gn_step assembles g and H inside the pipelined solver's launch
   bool fuse_asm_next = false;                 // (set by idto_hip_gn_step for the FactorSolve that follows)
   unsigned long long* pipe_rowcnt = nullptr;   // the same for the pipelined variant (its own launch count: the two
@@ -1429,6 +1431,12 @@ int idto_hip_tr_set_scale_memory(idto_hip_ctx* c, const double* D_prev_host) {
   return 0;
 }
 
+int idto_hip_tr_set_convergence(idto_hip_ctx* c, const double* tolerances) {
+  c->tr_conv_on = tolerances != nullptr;
+  for (int i = 0; i < 6; ++i) c->tr_conv_tol[i] = tolerances ? tolerances[i] : 0.0;
+  return 0;
+}
+
 int idto_hip_tr_prepare(idto_hip_ctx* c, int scaling_method, int with_lambda, double* out_host) {
   HIP_OK(hipSetDevice(c->device));
   if (c->batch != 1) { g_err = "tr_prepare serves single-problem contexts"; return -1; }
@@ -1533,11 +1541,11 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
   if (nu > 0) {
     if (!c->weights_diagonal) { g_err = "tr_solve: enforced constraints need diagonal cost weights"; return -1; }
   }
-  if (!(scaling_method == -1 || scaling_method == 0 || scaling_method == 2)) {
-    // (the adaptive methods keep a memory of D that a rejected step must not advance: stepwise loop)
-    g_err = "tr_solve: scaling method not supported by the device-resident loop";
-    return -1;
-  }
+  // (the adaptive methods, D = min(D_prev, f(diag H)): tr_iter_kernel keeps D_prev.  A rejected step leaves g and H
+  // where they are - the gated assembly - so the next iteration forms min(D, f(diag H)) = D again: the memory does
+  // not advance, as in the reference, whose cached scale factors belong to the state that did not change.)
+  if (scaling_method < -1 || scaling_method > 3) { g_err = "tr_solve: bad scaling method"; return -1; }
+  const bool adaptive = scaling_method == 1 || scaling_method == 3;
   if (iterations > c->tr_rows_cap) {
     double* p = nullptr;
     if (Alloc(c, (size_t)iterations * TRR_COUNT, &p)) return -2;   // (the previous, smaller one stays in the context's pool)
@@ -1568,6 +1576,7 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
   }
   if (rc) return rc;
   const bool lookahead = c->weights_diagonal && c->asm_stop == 0 && c->fd_stop == 0;
+  if (adaptive && !lookahead) { g_err = "tr_solve: the adaptive scalings need the gated assembly (diagonal cost weights)"; return -1; }
   if (nu > 0 && !lookahead) { g_err = "tr_solve: enforced constraints need the two-set evaluation"; return -1; }
   // from here on the trial point's v, a, N+, tau, partials go to the set the iterate does not occupy
   struct AltGuard {
@@ -1578,7 +1587,16 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
     c->alt_r = AltSel{c->tr_state, c->alt_off, 0};
     c->alt_w = AltSel{c->tr_state, c->alt_off, 1};
   }
-  for (int k = 0; k < iterations; ++k) {
+  TrConvergence conv{};
+  conv.on = c->tr_conv_on ? 1 : 0;
+  conv.rel_cost = c->tr_conv_tol[0]; conv.abs_cost = c->tr_conv_tol[1]; conv.rel_grad = c->tr_conv_tol[2];
+  conv.abs_grad = c->tr_conv_tol[3]; conv.rel_state = c->tr_conv_tol[4]; conv.abs_state = c->tr_conv_tol[5];
+  conv.rows = c->tr_rows;
+  // (with convergence checks the last iteration, too, is followed by g at its iterate: one more pass of the loop
+  // body up to tr_iter_kernel, which then only evaluates the criteria)
+  const int passes = iterations + (conv.on ? 1 : 0);
+  for (int k = 0; k < passes; ++k) {
+    conv.check_only = (k == iterations) ? 1 : 0;
     if (nu > 0) {
       // multipliers of the iterate (TO.cc:1371-1396), all on the device: Y = H^-1 [g | J^T], S = J Y_J, J y_g
       // (idto_hip_constraint_schur_begin), lambda = S^-1 (h - J y_g) in one workgroup, then H^-1 (g + J^T lambda)
@@ -1627,8 +1645,11 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
     T.n = n; T.nq = c->nq; T.scaling = scaling;
     T.nquat = normalize_quaternions ? c->tr_nquat : 0;
     T.quat = c->tr_quat; T.q_trial = c->q_trial; T.dq = c->tr_dq;
+    T.conv = conv;
+    T.fact_status = c->status_dev; T.fact_id = c->fact_id;   // (the most recent factorisation: this iteration's step)
     hipLaunchKernelGGL(tr_iter_kernel, dim3(nblk), dim3(256), lds_iter, c->stream, T);
     HIP_OK(hipGetLastError());
+    if (k == iterations) break;   // (the check-only pass)
     // tau (with its partials: the trial point is the next iterate unless rejected) and the cost at the
     // trial point, then the decision (cost_kernel's epilogue)
     TrDecideArgs Dc;
@@ -1636,7 +1657,7 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
     Dc.eta = eta; Dc.Delta_max = Delta_max; Dc.eps = eps;
     Dc.lambda = nu > 0 ? c->con_lambda_at : nullptr; Dc.dofs = nu > 0 ? c->con_dofs : nullptr;
     Dc.nu = nu; Dc.N = c->N; Dc.slab_stride = c->slab_stride; Dc.tau_off = 3 * c->nv * c->nq;
-    const bool more = k + 1 < iterations;
+    const bool more = k + 1 < passes;
     std::swap(c->q, c->q_trial);
     rc = LaunchFd(c, (lookahead && more) ? 1 : 0, 0, c->N, c->alt_w);
     if (!rc)
@@ -1816,6 +1837,7 @@ int idto_hip_rccl_info(char* path_out, int path_cap, int* version_out) {
 int idto_hip_get_option(idto_hip_ctx* c, const char* name, int* value) {
   if (std::strcmp(name, "rccl_version") == 0) { return idto_hip_rccl_info(nullptr, 0, value); }
   if (std::strcmp(name, "last_solver") == 0) { *value = c->last_solver; return 0; }
+  if (std::strcmp(name, "weights_diagonal") == 0) { *value = c->weights_diagonal ? 1 : 0; return 0; }
   if (std::strcmp(name, "solver_nd") == 0) { *value = c->solver_nd; return 0; }
   if (std::strcmp(name, "solver_pipe") == 0) { *value = c->solver_pipe; return 0; }
   if (std::strcmp(name, "asm_in_solver") == 0) { *value = c->asm_in_solver; return 0; }

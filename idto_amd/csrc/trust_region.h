@@ -242,16 +242,33 @@ enum {
   TRS_FLAGS,       // (as an integer value) TRF_*: sticky, the remaining iterations are idle
   TRS_ITER,        // iterations decided so far
   TRS_ACCEPTED,    // the last decision: gates the assembly of the next iteration (a rejected step keeps g, H)
-  TRS_SPARE,
+  TRS_PREVCOST,    // convergence check: L of the iterate the last accepted step started from (VerifyConvergenceCriteria's previous_cost)
   TRS_CUR,         // which of the two sets of fd_kernel outputs holds the iterate's (batch.h AltSel)
+  TRS_CHECK,       // an accepted step's convergence criteria are to be evaluated by the next tr_iter_kernel (it needs g there)
+  TRS_DQN,         // |dq| of that step
   TRS_COUNT = 12
 };
 static_assert(TRS_CUR == IDTO_TRS_CUR, "batch.h and trust_region.h disagree");
-enum { TRF_DOGLEG = 1, TRF_NONFINITE = 2, TRF_NOT_DESCENT = 4, TRF_SINGULAR_S = 8 /* constraints.h constraint_lambda_kernel */ };
+enum { TRF_DOGLEG = 1, TRF_NONFINITE = 2, TRF_NOT_DESCENT = 4, TRF_SINGULAR_S = 8 /* constraints.h constraint_lambda_kernel */,
+       TRF_CONVERGED = 16 /* a convergence criterion held after an accepted step (TO.cc:2654-2689): not an error */,
+       TRF_FACTORIZATION = 32 /* the factorisation behind this iteration's step met a bad pivot (penta_diagonal_solver.h:181-185) */ };
 // one row of per-iteration statistics (TrajectoryOptimizerStats::push_data, TO.cc:2586-2598)
 enum { TRR_COST = 0, TRR_DELTA, TRR_RHO, TRR_QNORM, TRR_DQNORM, TRR_DQHNORM, TRR_GNORM, TRR_DLDQ, TRR_HNORM,
        TRR_ACCEPTED, TRR_CLOCK /* wall_clock64 ticks (100 MHz) */, TRR_A, TRR_B, TRR_COST_TRIAL, TRR_FLAGS,
-       TRR_MERIT /* L(q) + h(q).lambda (TO.cc:2583; = the cost without enforced constraints) */, TRR_COUNT = 16 };
+       TRR_MERIT /* L(q) + h(q).lambda (TO.cc:2583; = the cost without enforced constraints) */,
+       TRR_REASON /* ConvergenceReason bitmask of the accepted step (trajectory_optimizer_solution.h:17-23), 0: none / not checked */,
+       TRR_COUNT = 17 };
+
+// VerifyConvergenceCriteria (TO.cc:2654-2689) inside the resident loop.  The criteria of the step accepted in
+// iteration k need the gradient AT the new iterate: they are evaluated by the tr_iter_kernel of iteration k + 1
+// (or by one more, check-only, launch after the last iteration) from
+//   |L_prev - L| < abs_cost + rel_cost L,   |g.dq| < abs_grad + rel_grad L,   |dq| < abs_state + rel_state |q|
+// and written into row k; a satisfied criterion sets the sticky TRF_CONVERGED: the remaining iterations idle.
+struct TrConvergence {
+  int on, check_only;
+  double rel_cost, abs_cost, rel_grad, abs_grad, rel_state, abs_state;
+  double* rows;   // [iterations][TRR_COUNT]
+};
 
 struct TrIterArgs {
   TrRowsArgs rows;
@@ -264,6 +281,9 @@ struct TrIterArgs {
   const int* quat;
   double* q_trial;
   double* dq;
+  TrConvergence conv;
+  const unsigned* fact_status;   // the solver's status word (host-mapped) and the id of the factorisation this iteration's step
+  unsigned fact_id;              // came from: a failure in the MIDDLE of the resident loop is flagged in its own iteration
 };
 
 // (TO.cc:2204-2242 SolveDoglegQuadratic; *ok = false where the reference throws)
@@ -298,6 +318,8 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
   __syncthreads();
   if (!last) return;
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  // (requested now, used by thread 0 at the dogleg: the round trip to host-mapped memory overlaps the sums)
+  const unsigned fact_word = (tid == 0 && T.fact_status) ? __hip_atomic_load(T.fact_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
   // the operands of the trial point (below) do not depend on the dogleg: fetch them now, four passes of 256
   // threads = tr_trial_kernel's 1024, so that their L2 round trips overlap the sums and the dogleg instead of
   // following them one pass after the other
@@ -326,11 +348,43 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
     T.out[tid] = acc;
   }
   __syncthreads();
+  // ---- the convergence criteria of the step the previous iteration accepted (TrConvergence): g.dq with the merit
+  // function's gradient at THIS iterate and the dq that led here (still in T.dq: the trial point below overwrites it)
+  if (T.conv.on) {
+    double sgd = 0.0;
+    for (int idx = tid; idx < n; idx += nt) {
+      const double gm = T.rows.jtl ? T.rows.g[idx] + T.rows.jtl[idx] : T.rows.g[idx];
+      sgd += gm * T.dq[idx];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sgd += __shfl_down(sgd, off);
+    if ((tid & 63) == 0) scratch[tid >> 6] = sgd;
+    __syncthreads();
+    if (tid == 0) {
+      int flags = (int)T.state[TRS_FLAGS];
+      if (T.state[TRS_CHECK] != 0.0 && (flags & ~TRF_CONVERGED) == 0) {
+        double gdq = 0.0;
+        for (int wv = 0; wv < nt / 64; ++wv) gdq += scratch[wv];
+        const double cost = T.state[TRS_COST], prev = T.state[TRS_PREVCOST];
+        int reason = 0;
+        if (__builtin_fabs(prev - cost) < T.conv.abs_cost + T.conv.rel_cost * cost) reason |= 1;
+        if (__builtin_fabs(gdq) < T.conv.abs_grad + T.conv.rel_grad * cost) reason |= 2;
+        if (T.state[TRS_DQN] < T.conv.abs_state + T.conv.rel_state * __builtin_sqrt(S[6])) reason |= 4;
+        const int k_prev = (int)T.state[TRS_ITER] - 1;
+        if (k_prev >= 0) T.conv.rows[(size_t)k_prev * TRR_COUNT + TRR_REASON] = (double)reason;
+        if (reason) T.state[TRS_FLAGS] = (double)(flags | TRF_CONVERGED);
+      }
+      T.state[TRS_CHECK] = 0.0;
+    }
+    __syncthreads();
+    if (T.conv.check_only) return;
+  }
   // ---- CalcDoglegPoint normalised by Delta: pU = cU g~ (TO.cc:2157), pH = -w / Delta (:2139-2149)
   if (tid == 0) {
     const double gg = S[0], gHg = S[1], ww = S[2], gw = S[3];
     const double Delta = T.state[TRS_DELTA];
     int flags = (int)T.state[TRS_FLAGS];
+    if (T.fact_status && fact_word == T.fact_id) flags |= TRF_FACTORIZATION;
     const double cU = -(gg / gHg) / Delta;
     const double pUn = __builtin_fabs(cU) * __builtin_sqrt(gg), pHn = __builtin_sqrt(ww) / Delta;
     double a, b, active;
@@ -435,7 +489,11 @@ __device__ inline bool tr_decide(const TrDecideArgs& T, double cost_trial, doubl
   R[TRR_CLOCK] = (double)wall_clock64(); R[TRR_A] = a; R[TRR_B] = b; R[TRR_COST_TRIAL] = cost_trial;
   R[TRR_FLAGS] = (double)flags;
   R[TRR_MERIT] = merit_k;
+  R[TRR_REASON] = 0.0;
   if (flags == 0) {
+    if (accept) {   // (the convergence criteria of this step: TrConvergence)
+      T.state[TRS_PREVCOST] = cost; T.state[TRS_CHECK] = 1.0; T.state[TRS_DQN] = __builtin_sqrt(S[9]);
+    }
     if (accept) T.state[TRS_COST] = cost_trial;   // :2550-2553
     if (rho < 0.25) T.state[TRS_DELTA] = Delta * 0.25;                                                        // :2614-2617
     else if (rho > 0.75 && T.state[TRS_ACTIVE] != 0.0) T.state[TRS_DELTA] = __builtin_fmin(2 * Delta, T.Delta_max);   // :2618-2622

@@ -64,6 +64,7 @@ def lib():
                                         C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.idto_hip_tr_reject.argtypes = [C.c_void_p]
         L.idto_hip_tr_set_scale_memory.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.idto_hip_tr_set_convergence.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.idto_hip_set_unactuated_dofs.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
         L.idto_hip_destroy.argtypes = [C.c_void_p]
         L.idto_hip_set_problem.argtypes = [C.c_void_p, C.POINTER(CProblem)]
@@ -112,7 +113,7 @@ EXPORTED_SYMBOLS = [
     "idto_hip_device_ptr", "idto_hip_array_size", "idto_hip_slab_stride", "idto_hip_math_probe",
     "idto_hip_solver_status", "idto_hip_create_batch", "idto_hip_batch_size", "idto_hip_set_problem_batch",
     "idto_hip_set_q_batch", "idto_hip_gn_step_batch", "idto_hip_get_batch", "idto_hip_solver_status_batch",
-    "idto_hip_tr_prepare", "idto_hip_tr_trial", "idto_hip_tr_accept", "idto_hip_tr_reject", "idto_hip_tr_set_scale_memory", "idto_hip_tr_solve", "idto_hip_set_unactuated_dofs",
+    "idto_hip_tr_prepare", "idto_hip_tr_trial", "idto_hip_tr_accept", "idto_hip_tr_reject", "idto_hip_tr_set_scale_memory", "idto_hip_tr_set_convergence", "idto_hip_tr_solve", "idto_hip_set_unactuated_dofs",
     "idto_hip_rccl_info", "idto_hip_comm_unique_id", "idto_hip_comm_init", "idto_hip_comm_init_all", "idto_hip_comm_destroy",
     "idto_hip_allgather_slab", "idto_hip_gn_step_sharded", "idto_hip_gn_step_multi", "idto_hip_eval_partials_multi",
 ]
@@ -255,15 +256,25 @@ class HipPath:
 
     def tr_solve(self, iterations: int, scaling_method: int, scaling: bool, normalize_quaternions: bool, Delta0: float,
                  Delta_max: float, eta: float = 0.0, constrained_dofs=()):
-        """the whole trust-region loop on the device (idto_hip_tr_solve): (rows [iterations, 16], final Delta)"""
-        rows = np.zeros((int(iterations), 16))
+        """the whole trust-region loop on the device (idto_hip_tr_solve): (rows [iterations, 17], final Delta)"""
+        rows = np.zeros((int(iterations), 17))
         delta = C.c_double(0.0)
         dofs = np.ascontiguousarray(np.asarray(constrained_dofs, dtype=np.int32))
+        self.last_tr_rows = rows   # (filled even when the call reports a failed factorisation)
         _chk(lib().idto_hip_tr_solve(self.h, int(iterations), int(scaling_method), int(scaling), int(normalize_quaternions),
                                      float(Delta0), float(Delta_max), float(eta),
                                      dofs.ctypes.data_as(C.POINTER(C.c_int)) if dofs.size else None, int(dofs.size),
                                      dptr(rows), C.byref(delta)))
         return rows, delta.value
+
+    def tr_set_convergence(self, tolerances=None):
+        """[rel_cost, abs_cost, rel_gradient_along_dq, abs_gradient_along_dq, rel_state, abs_state] or None (no checks)"""
+        if tolerances is None:
+            _chk(lib().idto_hip_tr_set_convergence(self.h, None))
+        else:
+            t = np.ascontiguousarray(np.asarray(tolerances, dtype=np.float64))
+            assert t.size == 6
+            _chk(lib().idto_hip_tr_set_convergence(self.h, dptr(t)))
 
     def set_unactuated_dofs(self, dofs):
         dofs = np.ascontiguousarray(np.asarray(dofs, dtype=np.int32))

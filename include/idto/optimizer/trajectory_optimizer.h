@@ -141,8 +141,9 @@ class TrajectoryOptimizer<double> {
   SolverFlag SolveFromWarmStartImpl(WarmStart* warm_start, TrajectoryOptimizerSolution<T>* solution,
                                     TrajectoryOptimizerStats<T>* stats, ConvergenceReason* reason) const;
   bool DeviceLoopEligible() const;
+  bool ResidentLoopEligible() const;
   SolverFlag SolveOnDevice(WarmStart* warm_start, TrajectoryOptimizerSolution<T>* solution,
-                           TrajectoryOptimizerStats<T>* stats) const;
+                           TrajectoryOptimizerStats<T>* stats, ConvergenceReason* reason) const;
   void AdoptTrialPoint(const TrajectoryOptimizerState<T>& scratch, TrajectoryOptimizerState<T>* state) const;
   ConvergenceReason VerifyConvergenceCriteria(const TrajectoryOptimizerState<T>& state, T previous_cost,
                                               const VectorXd& dq) const;

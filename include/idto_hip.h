@@ -251,8 +251,9 @@ int idto_hip_tr_set_scale_memory(idto_hip_ctx* ctx, const double* D_prev_host);
  *   [0] L(q_k) [1] Delta_k [2] rho [3] |q| [4] |dq| [5] |dqH| [6] |g~| [7] dL/dq [8] |h| [9] accepted
  *   [10] device clock at the decision (100 MHz ticks) [11] a [12] b (dq = D (a g~ + b w)) [13] L(q_k + dq)
  *   [14] flags: 1 dogleg quadratic has no root in (0,1), 2 step not finite, 4 step is not a descent
- *   direction (where the reference throws); once a flag is set the remaining iterations are idle.
- *   [15] the merit function L(q_k) + h(q_k).lambda_k.  Flag 8: the constraints' Schur complement is
+ *   direction (where the reference throws), 16 a convergence criterion held (idto_hip_tr_set_convergence), 32 the
+ *   factorisation behind this iteration's step met a bad pivot; once a flag is set the remaining iterations are idle.
+ *   [15] the merit function L(q_k) + h(q_k).lambda_k.  [16] see idto_hip_tr_set_convergence.  Flag 8: the constraints' Schur complement is
  *   numerically singular (redundant constraints; the host's pivoted LDL^T copes, the single-workgroup
  *   solve does not): continue from the iterate with the stepwise calls.
  * constrained_dofs / nu: the unactuated degrees of freedom whose tau is constrained to zero
@@ -260,11 +261,20 @@ int idto_hip_tr_set_scale_memory(idto_hip_ctx* ctx, const double* D_prev_host);
  * also runs H^-1 [g | J^T], S = J H^-1 J^T, lambda = S^-1 (h - J H^-1 g) (TO.cc:1371-1396; one workgroup for
  * nu * num_steps <= 128, the blocked factorisation above) and the step H^-1 (g + J^T lambda) on the device, and
  * the ratio uses the merit function.
- * scaling_method: -1 none, 0 kSqrt, 2 kDoubleSqrt (the adaptive methods: use the stepwise calls).
+ * scaling_method: -1 none, else ScalingMethod (solver_parameters.h:52-62): 0 kSqrt, 1 kAdaptiveSqrt, 2 kDoubleSqrt,
+ * 3 kAdaptiveDoubleSqrt; the adaptive methods' memory of D is idto_hip_tr_set_scale_memory's (a rejected step does
+ * not advance it: g and H stay, min(D, f(diag H)) = D).
  * On return q, v, a, tau, N+ in device memory are those of the final iterate when the last step was
  * accepted; after a rejected last step v, a, tau belong to the dropped trial point.
  * Returns IDTO_HIP_FACTORIZATION_FAILED when any iteration's factorisation failed. */
-#define IDTO_TR_ROW 16
+#define IDTO_TR_ROW 17
+/* VerifyConvergenceCriteria (reference trajectory_optimizer.cc:2654-2689) inside idto_hip_tr_solve.
+ * tolerances: {rel_cost_reduction, abs_cost_reduction, rel_gradient_along_dq, abs_gradient_along_dq, rel_state_change,
+ * abs_state_change} (solver_parameters.h:17-31), or NULL: no checks (the default).  With tolerances set, row k of
+ * idto_hip_tr_solve carries in [16] the ConvergenceReason bitmask of the step accepted in iteration k (1 cost reduction,
+ * 2 gradient along dq, 4 state change; 0: none, or the step was rejected); the first row with a non-zero mask is the
+ * last iteration that ran - the ones behind it are idle, flag 16 - and q on the device is its iterate. */
+int idto_hip_tr_set_convergence(idto_hip_ctx* ctx, const double* tolerances);
 int idto_hip_tr_solve(idto_hip_ctx* ctx, int iterations, int scaling_method, int scaling, int normalize_quaternions,
                       double Delta0, double Delta_max, double eta, const int* constrained_dofs, int nu,
                       double* rows_host, double* Delta_out);

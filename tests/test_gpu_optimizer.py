@@ -341,3 +341,50 @@ def test_equality_constraints_and_scaling_invariants():  # TO_test.cc:1637-1751,
     rho, rho_s = opt_u.trust_ratio(q, dq), opt_s.trust_ratio(q, dq)
     assert rho > 0.6
     assert abs(rho - rho_s) <= 1e-7
+
+
+@pytest.mark.parametrize("name,tols,constrained", [
+    ("spinner", dict(rel_cost_reduction=1e-4), False),          # stops on the cost criterion
+    ("spinner", dict(rel_state_change=2e-3), False),            # ... on the state criterion
+    ("acrobot", dict(rel_gradient_along_dq=1e-3), False),      # ... on the gradient criterion (after rejected steps)
+    ("hopper", dict(rel_cost_reduction=3e-3), True),            # with enforced equality constraints (merit gradient)
+    ("mini_cheetah", dict(rel_cost_reduction=0.019), False),    # third iteration
+    ("spinner", dict(), False),                                 # zero tolerances are never satisfied: runs to max_iterations
+])
+def test_convergence_criteria_inside_the_device_loop(name, tols, constrained, monkeypatch):
+    """check_convergence = true with the device-resident loop (VerifyConvergenceCriteria, TO.cc:2654-2689, evaluated by
+    the iteration kernel that follows an accepted step): the solve stops at the iteration the CPU oracle stops at, with
+    the oracle's flag and reason bitmask, and the host loop (IDTO_OPT_HOST_LOOP=1) agrees"""
+    cfg, model = load_config(name), load_model(name)
+    prob, sp, q_guess = make_problem(cfg, model)
+    sp.max_iterations, sp.verbose, sp.num_threads = 40 if name != "mini_cheetah" else 12, False, 1
+    sp.equality_constraints = constrained
+    sp.check_convergence = True
+    for k in ("rel_cost_reduction", "abs_cost_reduction", "rel_gradient_along_dq", "abs_gradient_along_dq",
+              "rel_state_change", "abs_state_change"):
+        setattr(sp, k, tols.get(k, 0.0))
+    ref = Oracle(model, prob, sp).solve(q_guess)
+    n_ref = ref["stats"].iteration_costs.size
+    out = {}
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv("IDTO_OPT_HOST_LOOP", "1")
+        else:
+            monkeypatch.delenv("IDTO_OPT_HOST_LOOP", raising=False)
+        opt = TrajectoryOptimizer(model, prob, sp)
+        sol, st, flag = solve(opt, q_guess)
+        out[host] = (sol, st, flag, opt.last_convergence_reason)
+        opt.close()
+    flags = {0: "kSuccess", 3: "kMaxIterationsReached"}
+    for host in (False, True):
+        sol, st, flag, reason = out[host]
+        assert st.iteration_costs.size == n_ref, (host, st.iteration_costs.size, n_ref)
+        assert flag == flags.get(ref["flag"], flag) and reason == ref["reason"], (host, flag, reason, ref["flag"], ref["reason"])
+        assert np.allclose(st.iteration_costs, ref["stats"].iteration_costs, rtol=1e-6)
+        assert np.abs(sol.q - ref["q"]).max() <= 1e-5 * max(1.0, np.abs(ref["q"]).max())
+    if tols:
+        assert n_ref < sp.max_iterations and out[False][3] != 0
+    else:
+        assert n_ref == sp.max_iterations and out[False][2] == "kMaxIterationsReached"
+    assert np.array_equal(out[False][1].trust_region_radii, out[True][1].trust_region_radii) or \
+        np.allclose(out[False][1].trust_region_radii, out[True][1].trust_region_radii, rtol=1e-12)

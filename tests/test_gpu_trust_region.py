@@ -136,7 +136,10 @@ def _solve(name, N, iters, stepwise, monkeypatch, scaling=True, method="double_s
 @pytest.mark.parametrize("name,N,iters,scaling,method,quat", [
     ("mini_cheetah", 40, 12, True, "double_sqrt", False), ("mini_cheetah", 20, 8, True, "sqrt", True),
     ("hopper", 20, 15, False, "double_sqrt", False), ("allegro_hand", 30, 4, True, "double_sqrt", False),
-    ("acrobot", 30, 25, True, "double_sqrt", False), ("spinner", 20, 12, True, "sqrt", False)])
+    ("acrobot", 30, 25, True, "double_sqrt", False), ("spinner", 20, 12, True, "sqrt", False),
+    # the adaptive scalings (D = min(D_prev, .), TO.cc:1241-1255): the acrobot run rejects steps, D_prev must not move then
+    ("acrobot", 30, 25, True, "adaptive_double_sqrt", False), ("mini_cheetah", 40, 10, True, "adaptive_sqrt", False),
+    ("hopper", 20, 15, True, "adaptive_double_sqrt", False)])
 def test_resident_loop_equals_stepwise_loop(name, N, iters, scaling, method, quat, monkeypatch):
     """idto_hip_tr_solve (every iteration enqueued at once, dogleg / trust ratio / accept / radius on
     the device) walks exactly the iterates of the loop that returns to the host twice per iteration:
@@ -179,6 +182,8 @@ def test_resident_loop_rows_and_failure():
     dev.eval_tau()
     with pytest.raises(hip.FactorizationFailed):
         dev.tr_solve(3, -1, False, False, 1e-1, 1e5)
+    # ... in the rows of the iterations it happened in (flag 32), none of which accepted a step
+    assert (dev.last_tr_rows[:, 14].astype(int) & 32).all() and not dev.last_tr_rows[:, 9].any()
     dev.close()
 
 
