@@ -50,6 +50,8 @@ def main():
     json.dump(res, open(os.path.join(dst, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
     for k, e in res.items():
         print(k, {a: round(b) for a, b in e.items() if isinstance(b, float)})
+    for f in glob.glob(os.path.join(out_root, "prof_3launch", "**", "*kernel_stats*.csv"), recursive=True)[:1]:
+        shutil.copy(f, os.path.join(dst, f"{rnd}_kernel_stats_assembly_in_its_own_launch.csv"))
     for f in glob.glob(os.path.join(out_root, "prof_full", "**", "*kernel_stats*.csv"), recursive=True)[:1]:
         shutil.copy(f, os.path.join(dst, f"{rnd}_full_iteration_kernel_stats.csv"))
     # SQ counters per kernel and launch (pmc_sq* passes)
