@@ -445,6 +445,51 @@ def main():
                                 "note": "one context, one host thread, one launch per kernel for the whole batch"})
             bd.close()
 
+    # informational (never `value`): BASELINE config 5 on ONE GPU - 8 warm-started allegro_hand N=60 problems advanced
+    # through whole trust-region iterations (scaling, dogleg, trial point, ratio, accept / reject on the device) by
+    # idto_hip_tr_solve_batch: one launch set per iteration for all of them, one host thread, one wait
+    batch_tr = None
+    if world == 1 and args.batch > 1 and not args.no_full:
+        try:
+            c5, m5 = load_config("allegro_hand"), load_model("allegro_hand")
+            N5, B5, it5 = 60, 8, 10
+            probs5, qs5 = [], []
+            for b in range(B5):
+                p5, s5, _ = make_problem(c5, m5, num_steps=N5)
+                probs5.append(p5)
+                qs5.append(synthetic_trajectory(c5, m5, N5, seed=b, lower=0.01))
+            s5.scaling, s5.equality_constraints = True, False
+            d5 = hip.HipPath(m5, probs5, s5, device=local_rank)
+            d5.set_stream(stream.cuda_stream)
+            times = []
+            for rep in range(3):
+                d5.set_q_batch(np.array(qs5))
+                d5.eval_tau()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                rows5, _ = d5.tr_solve_batch(it5, 2, True, False, 1e-1, 1e5)
+                times.append(time.perf_counter() - t1)
+            d5.close()
+            d1 = hip.HipPath(m5, probs5[0], s5, device=local_rank)
+            d1.set_stream(stream.cuda_stream)
+            t_single = []
+            for rep in range(3):
+                d1.set_q(qs5[0])
+                d1.eval_tau()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                d1.tr_solve(it5, 2, True, False, 1e-1, 1e5)
+                t_single.append(time.perf_counter() - t1)
+            d1.close()
+            batch_tr = {"workload": f"allegro_hand + sphere N={N5}, {B5} problems in one batch context, {it5} trust-region "
+                                    "iterations each (double_sqrt scaling, no enforced constraints)",
+                        "ms_per_iteration_of_the_batch": 1e3 * min(times) / it5,
+                        "value": B5 * it5 / min(times), "unit": "trust-region iterations/s (aggregate)",
+                        "ms_per_iteration_one_problem_alone": 1e3 * min(t_single) / it5,
+                        "accepted_steps": int(rows5[:, :, 9].sum()), "flags_clean": bool((rows5[:, :, 14] == 0).all())}
+        except Exception as e:  # informational only
+            batch_tr = {"error": str(e)[:200]}
+
     units = args.steps * (world if (world > 1 and not sharded) else 1)
     value = units / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
@@ -505,6 +550,8 @@ def main():
         out["step_latency_ms"] = latency
         if batch_extra is not None:
             out["batch_mode"] = batch_extra
+        if batch_tr is not None:
+            out["batch_trust_region"] = batch_tr
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.config, N)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

@@ -27,9 +27,11 @@ struct AltSel {
   long long off;
   int which;
 };
-__device__ __forceinline__ long long alt_offset(const AltSel& s) {
+// (`o`: the problem's arena offset in bytes - every problem of a batch has its own loop state, hence its own current set)
+__device__ __forceinline__ long long alt_offset(const AltSel& s, size_t o = 0) {
   if (!s.state) return 0;
-  const bool cur1 = s.state[IDTO_TRS_CUR] != 0.0;
+  const double* st = reinterpret_cast<const double*>(reinterpret_cast<const char*>(s.state) + o);
+  const bool cur1 = st[IDTO_TRS_CUR] != 0.0;
   return (cur1 != (s.which != 0)) ? s.off : 0;
 }
 template <class T>

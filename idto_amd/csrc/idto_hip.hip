@@ -1530,11 +1530,13 @@ int idto_hip_tr_reject(idto_hip_ctx* c) {
   return 0;
 }
 
-int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int scaling, int normalize_quaternions,
-                      double Delta0, double Delta_max, double eta, const int* constrained_dofs, int nu,
-                      double* rows_host, double* Delta_out) {
+// Delta0s / Delta_out: one radius per problem of the context; rows_host: [batch][iterations][TRR_COUNT]
+static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scaling, int normalize_quaternions,
+                   const double* Delta0s, double Delta_max, double eta, const int* constrained_dofs, int nu,
+                   double* rows_host, double* Delta_out) {
   HIP_OK(hipSetDevice(c->device));
-  if (c->batch != 1) { g_err = "tr_solve serves single-problem contexts"; return -1; }
+  const int B = c->batch;
+  if (B != 1 && nu > 0) { g_err = "tr_solve: enforced constraints serve single-problem contexts"; return -1; }
   if (iterations <= 0) { g_err = "tr_solve: iterations must be positive"; return -1; }
   if (nu < 0 || (nu > 0 && !constrained_dofs)) { g_err = "tr_solve: bad constraint arguments"; return -1; }
   const int neq = nu * c->N;
@@ -1548,22 +1550,27 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
   const bool adaptive = scaling_method == 1 || scaling_method == 3;
   if (iterations > c->tr_rows_cap) {
     double* p = nullptr;
-    if (Alloc(c, (size_t)iterations * TRR_COUNT, &p)) return -2;   // (the previous, smaller one stays in the context's pool)
+    if (Alloc(c, (size_t)B * iterations * TRR_COUNT, &p)) return -2;   // (the previous, smaller one stays in the context's pool)
     c->tr_rows = p;
     c->tr_rows_cap = iterations;
   }
+  const size_t rows_stride = (size_t)iterations * TRR_COUNT;
   c->spec_pending = false; c->spec_ready = false; c->trial_resident = false;
   const int n = (c->N + 1) * c->nq, nblk = c->N + 1;
   // tr_iter_kernel finds its last workgroup by counter == target: both restart with every solve, so that a
   // launch that failed in an earlier solve cannot leave them out of step
-  HIP_OK(hipMemsetAsync(c->tr_cnt, 0, sizeof(unsigned long long), c->stream));
+  HIP_OK(hipMemset2DAsync(c->tr_cnt, c->pstride, 0, sizeof(unsigned long long), (size_t)B, c->stream));
   c->tr_target = 0;
-  // state: [Delta, L(q) (resident: the caller evaluated the cost of q), ...]
-  for (int i = 0; i < TRS_COUNT; ++i) c->tr_pin[i] = 0.0;
-  c->tr_pin[TRS_DELTA] = Delta0;
-  c->tr_pin[TRS_ACCEPTED] = 1.0;
-  HIP_OK(hipMemcpyAsync(c->tr_state, c->tr_pin, TRS_COUNT * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIP_OK(hipMemcpyAsync(c->tr_state + TRS_COST, c->cost, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  // state of every problem: [Delta, L(q) (resident: the caller evaluated the cost of q), ...]
+  {
+    std::vector<double> st((size_t)B * TRS_COUNT, 0.0);
+    for (int b = 0; b < B; ++b) { st[(size_t)b * TRS_COUNT + TRS_DELTA] = Delta0s[b]; st[(size_t)b * TRS_COUNT + TRS_ACCEPTED] = 1.0; }
+    HIP_OK(hipMemcpy2DAsync(c->tr_state, c->pstride, st.data(), TRS_COUNT * sizeof(double), TRS_COUNT * sizeof(double), (size_t)B,
+                            hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));   // (the host buffer is a temporary)
+  }
+  HIP_OK(hipMemcpy2DAsync(c->tr_state + TRS_COST, c->pstride, c->cost, c->pstride, sizeof(double), (size_t)B,
+                          hipMemcpyDeviceToDevice, c->stream));
   const double eps = 10 * std::numeric_limits<double>::epsilon() / c->P.dt / c->P.dt;   // TO.cc:2024
   const int lds_iter = (int)sizeof(double) * std::max(23 * c->nq + 9 * 16, 9 * nblk + 9 + 32);
   // g, H and the Newton step of the first iterate (with constraints the step comes out of the multiplier chain)
@@ -1576,6 +1583,7 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
   }
   if (rc) return rc;
   const bool lookahead = c->weights_diagonal && c->asm_stop == 0 && c->fd_stop == 0;
+  if (B != 1 && !lookahead) { g_err = "tr_solve on a batch context needs the two-set evaluation (diagonal cost weights)"; return -1; }
   if (adaptive && !lookahead) { g_err = "tr_solve: the adaptive scalings need the gated assembly (diagonal cost weights)"; return -1; }
   if (nu > 0 && !lookahead) { g_err = "tr_solve: enforced constraints need the two-set evaluation"; return -1; }
   // from here on the trial point's v, a, N+, tau, partials go to the set the iterate does not occupy
@@ -1647,13 +1655,15 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
     T.quat = c->tr_quat; T.q_trial = c->q_trial; T.dq = c->tr_dq;
     T.conv = conv;
     T.fact_status = c->status_dev; T.fact_id = c->fact_id;   // (the most recent factorisation: this iteration's step)
-    hipLaunchKernelGGL(tr_iter_kernel, dim3(nblk), dim3(256), lds_iter, c->stream, T);
+    T.pstride = c->pstride; T.rows_stride = rows_stride;
+    hipLaunchKernelGGL(tr_iter_kernel, dim3(nblk, B), dim3(256), lds_iter, c->stream, T);
     HIP_OK(hipGetLastError());
     if (k == iterations) break;   // (the check-only pass)
     // tau (with its partials: the trial point is the next iterate unless rejected) and the cost at the
     // trial point, then the decision (cost_kernel's epilogue)
     TrDecideArgs Dc;
     Dc.state = c->tr_state; Dc.out = c->tr_out; Dc.rows = c->tr_rows; Dc.q = c->q; Dc.q_trial = c->q_trial; Dc.n = n;
+    Dc.rows_stride = rows_stride;
     Dc.eta = eta; Dc.Delta_max = Delta_max; Dc.eps = eps;
     Dc.lambda = nu > 0 ? c->con_lambda_at : nullptr; Dc.dofs = nu > 0 ? c->con_dofs : nullptr;
     Dc.nu = nu; Dc.N = c->N; Dc.slab_stride = c->slab_stride; Dc.tau_off = 3 * c->nv * c->nq;
@@ -1661,8 +1671,8 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
     std::swap(c->q, c->q_trial);
     rc = LaunchFd(c, (lookahead && more) ? 1 : 0, 0, c->N, c->alt_w);
     if (!rc)
-      hipLaunchKernelGGL(cost_kernel, dim3(1), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
-                         c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, (double*)nullptr, (size_t)0,
+      hipLaunchKernelGGL(cost_kernel, dim3(1, B), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
+                         c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, (double*)nullptr, c->pstride,
                          (double*)nullptr, Dc, c->alt_w);
     std::swap(c->q, c->q_trial);
     if (rc) return rc;
@@ -1678,6 +1688,23 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
     if (rc) return rc;
   }
   c->fd_full = false;
+  if (B != 1) {
+    // every problem has its own current set: the ones whose iterate ended up in the other set get it copied over
+    // (a single-problem context swaps its pointers instead, below)
+    if (c->alt_off <= 0) { g_err = "tr_solve: batch contexts keep their primary output set"; return -1; }
+    hipLaunchKernelGGL(tr_fold_sets_kernel, dim3(64, B), dim3(256), 0, c->stream, c->v, (size_t)c->alt_off / sizeof(double),
+                       c->tr_state, c->pstride);
+    HIP_OK(hipGetLastError());
+    std::vector<double> st((size_t)B * TRS_COUNT);
+    HIP_OK(hipMemcpy2DAsync(st.data(), TRS_COUNT * sizeof(double), c->tr_state, c->pstride, TRS_COUNT * sizeof(double), (size_t)B,
+                            hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpy(rows_host, c->tr_rows, (size_t)B * rows_stride * sizeof(double), hipMemcpyDeviceToHost));
+    if (Delta_out) for (int b = 0; b < B; ++b) Delta_out[b] = st[(size_t)b * TRS_COUNT + TRS_DELTA];
+    for (int b = 0; b < B; ++b)
+      if (int fs = FactorStatus(c, b)) return fs;
+    return 0;
+  }
   HIP_OK(hipMemcpyAsync(c->tr_pin, c->tr_state, TRS_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_OK(hipStreamSynchronize(c->stream));
   HIP_OK(hipMemcpy(rows_host, c->tr_rows, (size_t)iterations * TRR_COUNT * sizeof(double), hipMemcpyDeviceToHost));
@@ -1689,6 +1716,21 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
     c->alt_off = -c->alt_off;
   }
   return FactorStatus(c);
+}
+
+int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int scaling, int normalize_quaternions,
+                      double Delta0, double Delta_max, double eta, const int* constrained_dofs, int nu,
+                      double* rows_host, double* Delta_out) {
+  if (c->batch != 1) { g_err = "tr_solve serves single-problem contexts (batches: idto_hip_tr_solve_batch)"; return -1; }
+  return TrSolve(c, iterations, scaling_method, scaling, normalize_quaternions, &Delta0, Delta_max, eta, constrained_dofs, nu,
+                 rows_host, Delta_out);
+}
+
+int idto_hip_tr_solve_batch(idto_hip_ctx* c, int iterations, int scaling_method, int scaling, int normalize_quaternions,
+                            const double* Delta0, double Delta_max, double eta, double* rows_host, double* Delta_out) {
+  if (!Delta0 || !rows_host) { g_err = "tr_solve_batch: Delta0[batch] and rows_host[batch][iterations][IDTO_TR_ROW] are required"; return -1; }
+  return TrSolve(c, iterations, scaling_method, scaling, normalize_quaternions, Delta0, Delta_max, eta, nullptr, 0, rows_host,
+                 Delta_out);
 }
 
 #define NCCL_OK(expr)                                                                 \

@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevP
                           double* __restrict__ a_out, double* __restrict__ nplus_out, int k_begin, int mode,
                           int stop_after, int echunk, size_t pstride, double* __restrict__ terms, AltSel alt) {
   const size_t o = (size_t)blockIdx.y * pstride;   // problem of the batch
-  const size_t w = o + (size_t)alt_offset(alt);    // ... and the set of outputs (batch.h AltSel)
+  const size_t w = o + (size_t)alt_offset(alt, o);    // ... and the set of outputs (batch.h AltSel)
   fd_body<MAXC>(M, cp, at_problem(P, o), at_problem(q, o), at_problem(slab, w), slab_stride, at_problem(v_out, w),
                 at_problem(a_out, w), at_problem(nplus_out, w), k_begin + (int)blockIdx.x, mode, stop_after, echunk,
                 terms ? at_problem(terms, w) : nullptr);
@@ -564,10 +564,15 @@ __global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__
                             int diag, double* __restrict__ pack, size_t pstride, double* __restrict__ cost_copy,
                             TrDecideArgs T, AltSel alt) {
   {
-    const size_t o = (size_t)blockIdx.y * pstride, w = o + (size_t)alt_offset(alt);
+    const size_t o = (size_t)blockIdx.y * pstride, w = o + (size_t)alt_offset(alt, o);
     P = at_problem(P, o); q = at_problem(q, o); v = at_problem(v, w); slab = at_problem(slab, w);
     cost_out = at_problem(cost_out, o);
     if (pack) pack = at_problem(pack, o);
+    if (T.state) {   // (the trust-region decision of THIS problem: trust_region.h tr_decide)
+      T.state = at_problem(T.state, o); T.out = at_problem(T.out, o); T.q = at_problem(T.q, o);
+      T.q_trial = at_problem(T.q_trial, o); T.rows += (size_t)blockIdx.y * T.rows_stride;
+      if (T.lambda) T.lambda = at_problem(T.lambda, o);
+    }
   }
   // e^T W e per term as the reference's Eigen expression evaluates it: tot = sum_c (sum_r e_r W[r][c]) e_c.
   // One thread per (term, column c); `diag`: the weights are diagonal, the inner sum is its one
@@ -1073,9 +1078,9 @@ assemble_diag_kernel(DevModel M, DevProblem P, const double* __restrict__ q, con
                      int slab_stride, double* __restrict__ g, double* __restrict__ HA, double* __restrict__ HB,
                      double* __restrict__ HC, int stop_after, const double* __restrict__ v_res,
                      const double* __restrict__ nplus_res, size_t pstride, const double* __restrict__ gate, AltSel alt) {
-  if (gate && *gate == 0.0) return;   // (idto_hip_tr_solve: the step was rejected, g and H of the iterate stay)
+  if (gate && *at_problem(gate, (size_t)blockIdx.z * pstride) == 0.0) return;   // (idto_hip_tr_solve: this problem's step was rejected, its g and H stay)
   const size_t o = (size_t)blockIdx.z * pstride;  // problem of the batch
-  const size_t w = o + (size_t)alt_offset(alt);   // ... and the iterate's set of fd_kernel outputs
+  const size_t w = o + (size_t)alt_offset(alt, o);   // ... and the iterate's set of fd_kernel outputs
   assemble_diag_body(M, at_problem(P, o), at_problem(q, o), at_problem(slab, w), slab_stride, at_problem(g, o),
                      at_problem(HA, o), at_problem(HB, o), at_problem(HC, o), stop_after,
                      v_res ? at_problem(v_res, w) : nullptr, nplus_res ? at_problem(nplus_res, w) : nullptr,
@@ -1276,9 +1281,9 @@ assemble_terms_kernel(DevModel M, DevProblem P, const double* __restrict__ q, co
                       const double* __restrict__ v_res, const double* __restrict__ nplus_res, double* __restrict__ g,
                       double* __restrict__ HA, double* __restrict__ HB, double* __restrict__ HC, size_t pstride,
                       const double* __restrict__ gate, AltSel alt) {
-  if (gate && *gate == 0.0) return;   // (idto_hip_tr_solve: the step was rejected, g and H of the iterate stay)
+  if (gate && *at_problem(gate, (size_t)blockIdx.z * pstride) == 0.0) return;   // (idto_hip_tr_solve: this problem's step was rejected, its g and H stay)
   {
-    const size_t o = (size_t)blockIdx.z * pstride, w = o + (size_t)alt_offset(alt);
+    const size_t o = (size_t)blockIdx.z * pstride, w = o + (size_t)alt_offset(alt, o);
     P = at_problem(P, o); q = at_problem(q, o); terms = at_problem(terms, w); v_res = at_problem(v_res, w);
     nplus_res = at_problem(nplus_res, w); g = at_problem(g, o);
     HA = at_problem(HA, o); HB = at_problem(HB, o); HC = at_problem(HC, o);

@@ -315,7 +315,7 @@ __device__ __forceinline__ void pipe_assemble(const NdArgs& A, PipeAsm F) {
   if (A.ts && threadIdx.x == 0)   // debug stamps of role 5: [0] latest end, [1] latest start of an assembly workgroup (positive doubles order like integers)
     atomicMax(reinterpret_cast<unsigned long long*>(A.ts + 5 * 64 + 1), (unsigned long long)__double_as_longlong((double)wall_clock64()));
   if (A.ts && a == 4 && threadIdx.x == 0) A.ts[5 * 64 + 8] = (double)wall_clock64();
-  const size_t o = (size_t)blockIdx.y * A.pstride, w = o + (size_t)alt_offset(F.alt);
+  const size_t o = (size_t)blockIdx.y * A.pstride, w = o + (size_t)alt_offset(F.alt, o);
   const DevProblem P = at_problem(F.P, o);
   assemble_terms_row<true>(F.nq, F.nv, P, at_problem(F.q, o), at_problem(F.terms, w), at_problem(F.v_res, w),
                            at_problem(F.nplus, w), at_problem(F.g, o), at_problem(F.HA, o), at_problem(F.HB, o),

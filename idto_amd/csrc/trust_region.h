@@ -284,6 +284,7 @@ struct TrIterArgs {
   TrConvergence conv;
   const unsigned* fact_status;   // the solver's status word (host-mapped) and the id of the factorisation this iteration's step
   unsigned fact_id;              // came from: a failure in the MIDDLE of the resident loop is flagged in its own iteration
+  size_t pstride, rows_stride;   // batch contexts: grid.y = problem (arena stride in bytes; doubles between the problems' rows)
 };
 
 // (TO.cc:2204-2242 SolveDoglegQuadratic; *ok = false where the reference throws)
@@ -306,7 +307,20 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
   extern __shared__ double lds[];
   __shared__ int last;
   __shared__ double ab[2];
-  T.rows.slab = at_set(T.rows.slab, T.alt);
+  {   // problem of the batch: every array of the loop lives in the problem's arena
+    const size_t o = (size_t)blockIdx.y * T.pstride;
+    TrRowsArgs& A = T.rows;
+    A.HA = at_problem(A.HA, o); A.HB = at_problem(A.HB, o); A.HC = at_problem(A.HC, o); A.g = at_problem(A.g, o);
+    if (A.jtl) A.jtl = at_problem(A.jtl, o);
+    A.yin = at_problem(A.yin, o); A.q = at_problem(A.q, o); A.Dprev = at_problem(A.Dprev, o); A.D = at_problem(A.D, o);
+    A.gt = at_problem(A.gt, o); A.w = at_problem(A.w, o); A.partial = at_problem(A.partial, o);
+    if (A.lambda) A.lambda = at_problem(A.lambda, o);
+    A.slab = at_problem(A.slab, o + (size_t)alt_offset(T.alt, o));   // (h = tau[unactuated] is read from the iterate's set)
+    T.counter = at_problem(T.counter, o); T.out = at_problem(T.out, o); T.state = at_problem(T.state, o);
+    T.q_trial = at_problem(T.q_trial, o); T.dq = at_problem(T.dq, o);
+    T.conv.rows += (size_t)blockIdx.y * T.rows_stride;
+    if (T.fact_status) T.fact_status += 2 * blockIdx.y;
+  }
   tr_prepare_rows_body(T.rows, lds);
   const int tid = threadIdx.x, nt = blockDim.x, nblk = T.rows.nblk, n = T.n;
   if (tid == 0) {   // (block_sums left a barrier behind the partial sums of thread 0)
@@ -453,6 +467,7 @@ struct TrDecideArgs {
   double* state;        // [TRS_COUNT]
   const double* out;    // [11] from tr_iter_kernel
   double* rows;         // [iterations][TRR_COUNT]
+  size_t rows_stride;   // doubles between the rows of consecutive problems of a batch
   double* q;            // the iterate, overwritten by q_trial when the step is accepted
   const double* q_trial;
   int n;
@@ -503,6 +518,16 @@ __device__ inline bool tr_decide(const TrDecideArgs& T, double cost_trial, doubl
   T.state[TRS_ACCEPTED] = accept ? 1.0 : 0.0;
   if (accept) T.state[TRS_CUR] = (T.state[TRS_CUR] != 0.0) ? 0.0 : 1.0;   // the trial point's set is the iterate's now
   return accept;
+}
+
+// batch contexts after idto_hip_tr_solve_batch: a problem whose iterate's v, a, N+, slab and products ended up in the
+// second set of fd_kernel outputs (batch.h AltSel) gets them copied into the first (grid (x, problem))
+__global__ void tr_fold_sets_kernel(double* set_a, size_t count, const double* state, size_t pstride) {
+  const size_t o = (size_t)blockIdx.y * pstride;
+  if (at_problem(state, o)[TRS_CUR] == 0.0) return;
+  double* a = at_problem(set_a, o);
+  const double* b = a + count;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) a[i] = b[i];
 }
 
 }  // namespace idto_dev

@@ -62,6 +62,8 @@ def lib():
         L.idto_hip_tr_accept.argtypes = [C.c_void_p]
         L.idto_hip_tr_solve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                         C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.idto_hip_tr_solve_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_double,
+                                              C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.idto_hip_tr_reject.argtypes = [C.c_void_p]
         L.idto_hip_tr_set_scale_memory.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.idto_hip_tr_set_convergence.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
@@ -113,7 +115,7 @@ EXPORTED_SYMBOLS = [
     "idto_hip_device_ptr", "idto_hip_array_size", "idto_hip_slab_stride", "idto_hip_math_probe",
     "idto_hip_solver_status", "idto_hip_create_batch", "idto_hip_batch_size", "idto_hip_set_problem_batch",
     "idto_hip_set_q_batch", "idto_hip_gn_step_batch", "idto_hip_get_batch", "idto_hip_solver_status_batch",
-    "idto_hip_tr_prepare", "idto_hip_tr_trial", "idto_hip_tr_accept", "idto_hip_tr_reject", "idto_hip_tr_set_scale_memory", "idto_hip_tr_set_convergence", "idto_hip_tr_solve", "idto_hip_set_unactuated_dofs",
+    "idto_hip_tr_prepare", "idto_hip_tr_trial", "idto_hip_tr_accept", "idto_hip_tr_reject", "idto_hip_tr_set_scale_memory", "idto_hip_tr_set_convergence", "idto_hip_tr_solve", "idto_hip_tr_solve_batch", "idto_hip_set_unactuated_dofs",
     "idto_hip_rccl_info", "idto_hip_comm_unique_id", "idto_hip_comm_init", "idto_hip_comm_init_all", "idto_hip_comm_destroy",
     "idto_hip_allgather_slab", "idto_hip_gn_step_sharded", "idto_hip_gn_step_multi", "idto_hip_eval_partials_multi",
 ]
@@ -266,6 +268,18 @@ class HipPath:
                                      dofs.ctypes.data_as(C.POINTER(C.c_int)) if dofs.size else None, int(dofs.size),
                                      dptr(rows), C.byref(delta)))
         return rows, delta.value
+
+    def tr_solve_batch(self, iterations: int, scaling_method: int, scaling: bool, normalize_quaternions: bool, Delta0,
+                       Delta_max: float, eta: float = 0.0):
+        """idto_hip_tr_solve_batch: (rows [batch, iterations, 17], final Delta [batch])"""
+        B = self.batch
+        rows = np.zeros((B, int(iterations), 17))
+        d0 = np.ascontiguousarray(np.broadcast_to(np.asarray(Delta0, dtype=np.float64), (B,)))
+        delta = np.zeros(B)
+        self.last_tr_rows = rows
+        _chk(lib().idto_hip_tr_solve_batch(self.h, int(iterations), int(scaling_method), int(scaling), int(normalize_quaternions),
+                                           dptr(d0), float(Delta_max), float(eta), dptr(rows), dptr(delta)))
+        return rows, delta
 
     def tr_set_convergence(self, tolerances=None):
         """[rel_cost, abs_cost, rel_gradient_along_dq, abs_gradient_along_dq, rel_state, abs_state] or None (no checks)"""

@@ -279,6 +279,16 @@ int idto_hip_tr_solve(idto_hip_ctx* ctx, int iterations, int scaling_method, int
                       double Delta0, double Delta_max, double eta, const int* constrained_dofs, int nu,
                       double* rows_host, double* Delta_out);
 
+/* The same loop for every problem of a batch context at once (idto_hip_create_batch): one launch set per iteration
+ * with grid.y = problem, one host thread, one wait - the call pattern of an MPC server that advances several
+ * warm-started problems per tick (reference examples/mpc_controller.cc:43-85, BASELINE config 5).  Every problem keeps
+ * its own radius, accepts or rejects on its own, and idles on its own flags; no equality constraints (nu = 0).
+ * Delta0[batch], Delta_out[batch] (may be NULL); rows_host[batch][iterations][IDTO_TR_ROW]: problem b's rows are
+ * what idto_hip_tr_solve returns for the same problem in a context of its own, bit for bit.  Every problem's q must
+ * be resident with its cost evaluated (idto_hip_set_q_batch + idto_hip_eval_tau). */
+int idto_hip_tr_solve_batch(idto_hip_ctx* ctx, int iterations, int scaling_method, int scaling, int normalize_quaternions,
+                            const double* Delta0, double Delta_max, double eta, double* rows_host, double* Delta_out);
+
 /* Options: "gradients_method" = 0 forward differences (default), 1 / 2 central differences of
  * 2nd / 4th order (SolverParameters::gradients_method, reference solver_parameters.h:26-50,
  * trajectory_optimizer.cc:565-885); 3 (autodiff) is refused.  "reference_solver" = 1 selects the bit-exact restatement of the reference's

@@ -98,3 +98,47 @@ def test_batch_problem_update_and_status():
     assert batch.solver_status_batch() == [False] * B
     assert _same(batch.get("step", 1), before[1])
     batch.close()
+
+
+@pytest.mark.parametrize("name,N,B,iters,method", [("mini_cheetah", 40, 5, 8, "double_sqrt"), ("allegro_hand", 60, 8, 4, "double_sqrt"),
+                                                   ("acrobot", 30, 6, 20, "sqrt"), ("hopper", 20, 3, 10, "adaptive_double_sqrt"),
+                                                   ("spinner", 20, 4, 10, None)])
+def test_trust_region_loop_of_a_batch_equals_the_single_problem_loops(name, N, B, iters, method):
+    """idto_hip_tr_solve_batch: B problems (different nominal trajectories, weights, initial guesses, radii) advance
+    through the whole trust-region loop in ONE launch set per iteration from one host thread; each accepts / rejects on
+    its own.  Rows, final radius and final iterate of every problem == those of idto_hip_tr_solve on the same problem
+    in a context of its own (BASELINE config 5 / examples/mpc_controller.cc:43-85: several warm-started problems per tick)."""
+    from idto_amd.problem import SCALING
+    model, probs, sp, qs = _problems(name, N, B)
+    sm = SCALING[method] if method else -1
+    d0 = np.array([1e-1 * (1 + 0.5 * b) for b in range(B)])
+    want = []
+    for b in range(B):
+        dev = hip.HipPath(model, probs[b], sp)
+        dev.set_q(qs[b])
+        dev.eval_tau()
+        rows, delta = dev.tr_solve(iters, sm, method is not None, False, d0[b], 1e5)
+        want.append((rows, delta, dev.get("q"), dev.get("v"), dev.get("tau")))
+        dev.close()
+    bd = hip.HipPath(model, probs, sp)
+    bd.set_q_batch(qs)
+    bd.eval_tau()
+    rows, delta = bd.tr_solve_batch(iters, sm, method is not None, False, d0, 1e5)
+    accepted = 0
+    for b in range(B):
+        r0, d, q, v, tau = want[b]
+        cols = [c for c in range(17) if c != 10]   # (column 10 is the device clock)
+        assert np.array_equal(rows[b][:, cols], r0[:, cols]), (b, rows[b][:, :3], r0[:, :3])
+        assert delta[b] == d
+        assert _same(bd.get("q", problem=b), q) and _same(bd.get("v", problem=b), v) and _same(bd.get("tau", problem=b), tau)
+        accepted += int(r0[:, 9].sum())
+    assert accepted > 0
+    # the context is usable afterwards: a Gauss-Newton step of the batch from the final iterates == the single contexts'
+    bd.gn_step()
+    for b in range(B):
+        dev = hip.HipPath(model, probs[b], sp)
+        dev.set_q(want[b][2])
+        dev.gn_step()
+        assert _same(bd.get("step", problem=b), dev.get("step")), b
+        dev.close()
+    bd.close()
