@@ -191,3 +191,29 @@ def test_many_contexts_on_concurrent_streams():
     assert not errors, errors[:3]
     for d in devs:
         d.close()
+
+
+@pytest.mark.parametrize("name,N,want", [("hopper", 150, 1), ("acrobot", 200, 1), ("mini_cheetah", 100, 4), ("hopper", 100, 4),
+                                         ("mini_cheetah", 70, 4), ("spinner", 126, 4), ("spinner", 140, 1)])
+def test_long_horizons(name, N, want):
+    """The chains' per-row tables hold ND_MAXROWS = 32 local rows: longer horizons must fall back to the two-workgroup
+    factorisation (last_solver 1) instead of failing, and the pipelined kernel's longest chains (its back
+    substitution then no longer fits the LDS in recursion form at K = 19 and goes row by row) must stay accurate."""
+    cfg, model, prob, sp, q = _setup(name, N)
+    dev = hip.HipPath(model, prob, sp)
+    dev.set_option("fused", 0)   # (the small models' single-launch iteration has its own tests: this one is about the chains)
+    dev.set_q(q)
+    dev.gn_step()
+    assert dev.get_option("last_solver") == want
+    p_fast = dev.get("step")
+    assert dev.solver_status() == (False, 0)
+    dev.set_option("reference_solver", 1)
+    dev.factor_solve()
+    p_lu = dev.get("step")
+    orc = Oracle(model, prob, sp)
+    g, bands = orc.grad_hess(q)
+    p_ref, unc = ol.refined_solution(ol.penta_make_dense(*bands), -g.ravel())
+    pn = np.abs(p_ref).max()
+    err = lambda x: np.abs(x.ravel() - p_ref).max() / pn
+    assert err(p_fast) <= 4 * err(p_lu) + 16 * unc + 1e-12, (err(p_fast), err(p_lu), unc)
+    dev.close()
