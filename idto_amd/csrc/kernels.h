@@ -77,11 +77,14 @@ IDTO_DEV void nplus_block(const DevModel& M, const double* q, double* Nout, int 
 // wavefront lanes 0..47 take the bodies, lanes 48..59 the 3x4 quaternion block entry by entry
 // (each entry is 9 IEEE divisions deep instead of 21 in sequence).  Same expressions as
 // nplus_block, hence the same bits.
+// `zeroed`: the caller cleared both blocks behind a barrier of its own (fd_body: together with its first loads)
 IDTO_DEV void nplus_pair(const DevModel& M, const double* qa, double* Na, const double* qb, double* Nb, int tid,
-                         int nthreads) {
+                         int nthreads, bool zeroed = false) {
   const int sz = M.nv * M.nq, nv = M.nv;
-  for (int i = tid; i < sz; i += nthreads) { Na[i] = 0.0; Nb[i] = 0.0; }
-  __syncthreads();
+  if (!zeroed) {
+    for (int i = tid; i < sz; i += nthreads) { Na[i] = 0.0; Nb[i] = 0.0; }
+    __syncthreads();
+  }
   const int l = tid & 63, grp = tid >> 6, ngrp = (nthreads >= 128) ? 2 : 1;
   for (int cfg = grp; cfg < 2; cfg += ngrp) {
     if (grp >= 2) break;
@@ -130,13 +133,14 @@ IDTO_DEV void nplus_pair(const DevModel& M, const double* qa, double* Na, const 
 }
 
 // v = N (qa - qb) / dt  (TO.cc:187-190); threads r < nv
+IDTO_DEV double velocity_row(const DevModel& M, const double* N, const double* qa, const double* qb, double dt, int r) {
+  double acc = N[r] * (qa[0] - qb[0]);
+  for (int c = 1; c < M.nq; ++c) acc += N[c * M.nv + r] * (qa[c] - qb[c]);
+  return acc / dt;
+}
 IDTO_DEV void velocity_block(const DevModel& M, const double* N, const double* qa, const double* qb, double dt,
                              double* vout, int tid, int nthreads) {
-  for (int r = tid; r < M.nv; r += nthreads) {
-    double acc = N[r] * (qa[0] - qb[0]);
-    for (int c = 1; c < M.nq; ++c) acc += N[c * M.nv + r] * (qa[c] - qb[c]);
-    vout[r] = acc / dt;
-  }
+  for (int r = tid; r < M.nv; r += nthreads) vout[r] = velocity_row(M, N, qa, qb, dt, r);
 }
 
 // sum_l A[l] * B[l], l ascending, products and sums rounded separately (no FMA): THE inner product
@@ -298,6 +302,7 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
     q0[i] = q[k * nq + i];
     q1[i] = q[(k + 1) * nq + i];
   }
+  for (int i = tid; i < bsz; i += nt) { N0[i] = 0.0; N1[i] = 0.0; }   // (nplus_pair fills the non-zeros behind this barrier)
   __syncthreads();
   const DevModel Ml = rebase_model(M, mblob);
   // N+ is sparse: column c has its non-zeros in rows [j0, j0 + cnt) (cnt = 3 for the quaternion
@@ -311,11 +316,16 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
       for (int kq = 0; kq < 3; ++kq) colinfo[qs + 4 + kq] = (vs + 3 + kq) | 1 << 16;
     }
   }
-  nplus_pair(Ml, q0, N0, q1, N1, tid, nt);
-  if (k > 0) velocity_block(Ml, N0, q0, qm1, dt, v0, tid, nt);
-  else
-    for (int r = tid; r < nv; r += nt) v0[r] = P.v_init[r];
-  velocity_block(Ml, N1, q1, q0, dt, v1, tid, nt);
+  nplus_pair(Ml, q0, N0, q1, N1, tid, nt, true);
+  // v_k, v_{k+1} and a_k = (v_{k+1} - v_k) / dt of row r by ONE thread: no barrier between velocities and acceleration
+  // (the expressions, hence the bits, are velocity_block's and the reference's, TO.cc:187-201)
+  for (int r = tid; r < nv; r += nt) {
+    const double vr0 = (k > 0) ? velocity_row(Ml, N0, q0, qm1, dt, r) : P.v_init[r];
+    const double vr1 = velocity_row(Ml, N1, q1, q0, dt, r);
+    v0[r] = vr0;
+    v1[r] = vr1;
+    a0[r] = (vr1 - vr0) / dt;
+  }
   // the perturbation of every evaluation (TO.cc:501-521; needs q only: formed here, a barrier earlier)
   const double eps = 1.4901161193847656e-08;  // sqrt(DBL_EPSILON) = 2^-26
   for (int e = tid; e < E; e += nt) {
@@ -332,8 +342,6 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
     edv[e] = dv;                 // input loops below would repeat both for every velocity component)
     eda[e] = dv / dt;
   }
-  __syncthreads();
-  for (int r = tid; r < nv; r += nt) a0[r] = (v1[r] - v0[r]) / dt;
   __syncthreads();
 
   // trajectory outputs
@@ -435,7 +443,11 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
                                  : 0.0;
       Pk[idx] = pv;
       Tk[idx] = tv;
-      if (terms) { rec[i * nvp + r] = pv; rec[psz + i * nvp + r] = tv; }
+      if (terms) {   // ... and (A^T W)(r, l) = A(l, r) w_l, as assemble_diag_kernel forms it, by the thread that holds A(l, r)
+        rec[i * nvp + r] = pv; rec[psz + i * nvp + r] = tv;
+        rec[3 * psz + i * nvp + r] = pv * wr[r]; rec[4 * psz + i * nvp + r] = tv * wr[r];
+        if (r == nv - 1 && nvp > nv) { rec[3 * psz + i * nvp + nv] = 0.0; rec[4 * psz + i * nvp + nv] = 0.0; }
+      }
     }
     // dtau_k/dq_{k-1} = (1/dt^2) M(q_{k+1}) N+_k   (TO.cc:556-561)
     if (k >= 2) {
@@ -448,13 +460,22 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
         double acc = (sc * Mcols[j0 * nv + r]) * N0[c * nv + j0];
         for (int j = j0 + 1; j < j0 + cnt; ++j) acc += (sc * Mcols[j * nv + r]) * N0[c * nv + j];
         Mk[idx] = acc;
-        if (terms) rec[2 * psz + c * nvp + r] = acc;
+        if (terms) {
+          rec[2 * psz + c * nvp + r] = acc;
+          rec[5 * psz + c * nvp + r] = acc * wr[r];
+          if (r == nv - 1 && nvp > nv) rec[5 * psz + c * nvp + nv] = 0.0;
+        }
       }
     } else {
       const double fill = (k == 0) ? __builtin_nan("") : 0.0;
       for (int idx = tid; idx < bsz; idx += nt) {
         Mk[idx] = fill;
-        if (terms) rec[2 * psz + (idx / nv) * nvp + idx % nv] = 0.0;   // (never used by the assembly for k < 2)
+        if (terms) {   // (never used by the assembly for k < 2)
+          const int c = idx / nv, r = idx % nv;
+          rec[2 * psz + c * nvp + r] = 0.0;
+          rec[5 * psz + c * nvp + r] = 0.0 * wr[r];
+          if (r == nv - 1 && nvp > nv) rec[5 * psz + c * nvp + nv] = 0.0;
+        }
       }
     }
   } else if (central) {
@@ -475,16 +496,16 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
       if (g == 0) Pk[rem] = val;
       else if (g == 1) Tk[rem] = val;
       else Mk[rem] = val;
-      if (terms) rec[g * psz + i * nvp + r] = (g == 2 && k < 2) ? 0.0 : val;
+      if (terms) {
+        const double rv = (g == 2 && k < 2) ? 0.0 : val;
+        rec[g * psz + i * nvp + r] = rv;
+        rec[(3 + g) * psz + i * nvp + r] = rv * wr[r];
+        if (r == nv - 1 && nvp > nv) rec[(3 + g) * psz + i * nvp + nv] = 0.0;
+      }
     }
   }
   if (!terms || mode == 0 || stop_after == 4) return;
-  // ---- the assembly products of this record (see asm_terms_stride)
-  __syncthreads();
-  for (int idx = tid; idx < 3 * psz; idx += nt) {
-    const int l = idx % nvp;
-    rec[3 * psz + idx] = (l < nv) ? rec[idx] * wr[l] : 0.0;   // (A^T W)(r, l) = A(l, r) w_l, as assemble_diag_kernel forms it
-  }
+  // ---- the assembly products of this record (see asm_terms_stride); the weighted copy was formed with the record
   __syncthreads();
   if (stop_after == 5) return;
   const int qq = nq * nq, ts = asm_terms_stride(nq);
