@@ -952,7 +952,7 @@ static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double s
   NdArgs A;
   A.debug_skip_role = c->debug_skip_role;
   A.debug_pipe_tail = c->debug_pipe_tail;
-  A.asm_ready = nullptr; A.asm_first = 0;
+  A.asm_ready = nullptr; A.asm_first = 0; A.wt_rows = 0;
   A.spin = SpinCtl{nullptr, 0};   // (set by the kernel: behind the per-problem status words)
   A.n = p.n; A.k = p.k;
   A.HA = c->HA + p.qq0; A.HB = c->HB + p.qq0; A.HC = c->HC + p.qq0;

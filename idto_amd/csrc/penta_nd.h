@@ -53,6 +53,7 @@ struct NdArgs {
   int debug_skip_role;           // test aid: this role returns at once (its partners' waits must run out), -1: none
   const unsigned* asm_ready;     // penta_pipe.h PipeAsm: the launch assembles g and the bands itself ([rows][4] epoch words), else nullptr
   int asm_first;
+  int wt_rows;                   // penta_pipe_kernel: the chains publish a row's spike block, 1 / d and rt with write-through stores (read past the L2, no acquire)
   int debug_pipe_tail;           // measurement aid: penta_pipe_kernel takes the row-by-row back substitution
 };
 __device__ __forceinline__ void nd_ts(const NdArgs& A, int role, int slot) {
@@ -368,16 +369,26 @@ __device__ __forceinline__ void nd_separator(const NdArgs& A) {
     for (int t = 0; t < (NQT + 1) / 2; ++t) qacc[t] = d4q{0.0, 0.0, 0.0, 0.0};
     for (int il = 0; il < nloc; ++il) {
       spin_wait([&] { return __hip_atomic_load(frow + il, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ftarget; }, A.spin);
-      (void)__hip_atomic_load(frow + il, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      if (!A.wt_rows) (void)__hip_atomic_load(frow + il, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
       const double* F = Fst + (size_t)il * B.frow;
       const double* dg = A.Dst + (size_t)(mirror ? base - il : base + il) * K;
       double op[CT2][SKq], dn[SKq];
+      if (A.wt_rows) {
 #pragma unroll
-      for (int sq = 0; sq < SKq; ++sq) {
-        const int kr = 4 * sq + fk;
-        dn[sq] = (kr < K) ? dg[kr] : 0.0;
+        for (int sq = 0; sq < SKq; ++sq) {
+          const int kr = 4 * sq + fk;
+          dn[sq] = (kr < K) ? __hip_atomic_load(dg + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
 #pragma unroll
-        for (int t = 0; t < CT2; ++t) op[t][sq] = F[(16 * t + fl) * ks + kr];
+          for (int t = 0; t < CT2; ++t) op[t][sq] = __hip_atomic_load(F + (16 * t + fl) * ks + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      } else {
+#pragma unroll
+        for (int sq = 0; sq < SKq; ++sq) {
+          const int kr = 4 * sq + fk;
+          dn[sq] = (kr < K) ? dg[kr] : 0.0;
+#pragma unroll
+          for (int t = 0; t < CT2; ++t) op[t][sq] = F[(16 * t + fl) * ks + kr];
+        }
       }
 #pragma unroll
       for (int t = 0; t < NQT; ++t) {   // tile t -> wavefront t % 2 of the pair, accumulator t / 2

@@ -666,7 +666,9 @@ __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCf
           __atomic_signal_fence(__ATOMIC_SEQ_CST);
           rowp[J * RS] = pipe_setlane<63>(xr[J], 0x3ff00000, 0);
           __atomic_signal_fence(__ATOMIC_SEQ_CST);
-          if (lane < 2 * K) fout[J] = xr[J];   // (and to HBM for the separator's Q / this chain's own correction: column `lane`, row J)
+          // (and to HBM for the separator's Q / this chain's own correction: column `lane`, row J; write-through - the
+          // separator sits on another XCD - so that the row's release below is a drained store queue, not a fence)
+          if (lane < 2 * K) __hip_atomic_store(fout + J, xr[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (J + 1 < K) {
             // multipliers T_J[c], c = J+1 .. K-1 (pairs from the even position below J+1)
             const double2* p2 = reinterpret_cast<const double2*>(arow + J * RS);
@@ -681,9 +683,8 @@ __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCf
         pipe_post(ctl, f_rowdone + slot, il + 1);
         // the row's spike block is in HBM: one of the three releases the separator waits for (the I/O wavefront
         // adds two with 1 / d and rt)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(A.frowcnt + il, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_fetch_add(A.frowcnt + il, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     // ---- follower of row il + 1: the HIGH rows of row il + 2 for the wavefront that eliminates it; half-way,
@@ -840,14 +841,15 @@ __device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& 
       }
       if (lane < K) {
         const double rt = row0[lane * RS + G::oRy];
-        A.Dst[(size_t)o * K + lane] = row0[lane * RS + G::oi];
+        // (1 / d and rt are what the separator reads of this row besides the spike block: write-through)
+        if (SPK) __hip_atomic_store(A.Dst + (size_t)o * K + lane, row0[lane * RS + G::oi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else A.Dst[(size_t)o * K + lane] = row0[lane * RS + G::oi];
         lds[L.xall + (il + 2) * ks + lane] = rt;   // rt (unscaled) for the back substitution
-        if (SPK) A.fst[(size_t)il * A.fstride + 2 * K * ks + lane] = rt;   // ... and as column 2K of the spike block
+        if (SPK) __hip_atomic_store(A.fst + (size_t)il * A.fstride + 2 * K * ks + lane, rt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... and as column 2K of the spike block
       }
-      if (SPK) {   // two of the three releases of the row (the spike wavefront adds the third)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (SPK) {   // two of the three releases of the row (the spike wavefront adds the third): a drained store queue
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(A.frowcnt + il, 2ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_fetch_add(A.frowcnt + il, 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     };
     stage_row(0);
@@ -1146,6 +1148,7 @@ __global__ void __launch_bounds__(512) penta_pipe_kernel(NdArgs A, PipeAsm F) {
   if (role == 4) {
     A.asm_ready = F.on ? at_problem(F.ready, (size_t)blockIdx.y * A.pstride) : nullptr;
     A.asm_first = F.first;
+    A.wt_rows = 1;
     nd_separator<K, false>(A);
     return;
   }
