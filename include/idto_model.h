@@ -75,7 +75,12 @@ typedef struct idto_model {
    * chains hanging off the world or off the common body.  It fixes the
    * association order of the floating-point sums over children / contact
    * pairs so that a serial CPU evaluation and the
-   * lane-parallel HIP evaluation produce identical bits. */
+   * lane-parallel HIP evaluation produce identical bits.
+   * HARD LIMIT: this is the only topology the device evaluates - a tree whose branching happens
+   * at the world and at ONE body (no closed loops, no second branching body further down a
+   * chain), chains of at most IDTO_MAX_CHAIN bodies.  It covers the reference's five example
+   * models; the reference itself takes any MultibodyPlant (TO.cc:271-279).  idto_hip_create
+   * rejects a model whose tables do not describe such a tree. */
   int npaths;               /* power of two, <= IDTO_MAX_PATHS */
   int common_body;          /* body index or -1 */
   const int* body_path;     /* [nbodies] path of each body, -1 for the common body */
