@@ -6,12 +6,10 @@
 //
 // Right-looking blocked LDL^T without pivoting, panels of NB = 32 columns, S column-major with
 // only the lower triangle referenced:
-//   dense_ldl_panel_kernel   (1 workgroup)  factorises the NB x NB diagonal block in LDS, solves
-//                                           the panel rows below it (one thread per row), writes
-//                                           L into S and W = L D into a workspace, tracks the
-//                                           smallest / largest pivot;
-//   dense_ldl_update_kernel  (many)         S[r][c] -= sum_k W[r][k] L[c][k] on 32 x 32 tiles of
-//                                           the trailing lower triangle;
+//   dense_ldl_step_kernel    (one launch per panel, a workgroup per 32 x 32 tile of the trailing lower triangle)
+//                            factorises the NB x NB diagonal block (every workgroup for itself), solves the panel
+//                            rows of its row and column block, subtracts W_R L_C^T from its tile on the matrix
+//                            cores; L goes to a matrix of its own, the pivots and their extremes to dvec / stat;
 //   dense_ldl_solve_kernel   (1 workgroup)  L y = r, D z = y, L^T x = z, blocked the same way.
 // No pivoting: S is positive definite whenever the constraint Jacobian has full row rank.  The
 // pivot extremes are returned; the caller falls back to the host's pivoted LDL^T (which, like
@@ -25,29 +23,46 @@ namespace idto_dev {
 
 constexpr int DENSE_NB = 32;
 
-// stat[0] = min pivot so far, stat[1] = max pivot so far (initialised by the caller: +inf, 0).
-// grid: 1 + ceil(rows below the block / 64) workgroups of one wavefront.  Every workgroup
-// factorises the NB x NB diagonal block for itself in LDS (cheap, and it saves a launch);
-// workgroup 0 writes the block's factor, the pivots and the statistics, workgroup b > 0 solves
-// the 64 panel rows j0 + NB + 64 (b - 1) .. with one thread per row.
-__global__ void __launch_bounds__(64)
-dense_ldl_panel_kernel(double* __restrict__ S, int n, int j0, double* __restrict__ W, double* __restrict__ dvec,
-                       double* __restrict__ stat) {
-  constexpr int NB = DENSE_NB;
-  __shared__ double A[NB][NB + 1];  // diagonal block, then its unit-lower factor
-  __shared__ double dd[NB];
-  const int tid = threadIdx.x, nt = 64;
-  const int nb = (n - j0 < NB) ? n - j0 : NB;
-  for (int idx = tid; idx < NB * NB; idx += nt) {
+// ---- one panel step in ONE launch.  stat[0] = min pivot so far, stat[1] = max pivot so far (initialised by the
+// caller: +inf, 0).  (Rounds 1-2 ran a panel kernel - diagonal block + row solves, 21 us - and an update kernel -
+// 6 us - per panel: two launches, W = L D through HBM.)
+// grid (tiles, tiles) over the 32 x 32 tiles of the trailing block [j1, n) x [j1, n), tiles with tr >= tc work;
+// (1, 1) for the last panel.  Every workgroup factorises the NB x NB diagonal block for itself (wavefront 0,
+// registers + v_readlane), solves the panel rows of ITS row block and ITS column
+// block against it (wavefronts 0 and 1, one thread per row: W = L D for the rows, L for the columns) and subtracts
+// W_R L_C^T from its tile with v_mfma_f64_16x16x4 (four wavefronts, one 16 x 16 quadrant each, 8 k-steps).  The
+// panel of S is only READ here - L goes to a matrix of its own (`Lm`, same shape; the tiles of the first tile column
+// write their rows, tile (0, 0) the diagonal block, d and the pivot statistics) - so no workgroup can see a panel
+// another one has already overwritten.
+__global__ void __launch_bounds__(256)
+dense_ldl_step_kernel(double* __restrict__ S, double* __restrict__ Lm, int n, int j0, double* __restrict__ dvec,
+                      double* __restrict__ stat) {
+  constexpr int NB = DENSE_NB, T = 32;
+  const int tr = blockIdx.x, tc = blockIdx.y;
+  if (tr < tc) return;
+  __shared__ double A[NB][NB + 1];     // diagonal block, then its unit-lower factor
+  __shared__ double dd[NB], di[NB];
+  __shared__ double xw[2][NB][T + 1];  // [0]: W[r0 + i][k] = x_k d_k of the row block, [1]: of the column block
+  __shared__ double Lt[NB][T + 1];     // L[c0 + j][k]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = (n - j0 < NB) ? n - j0 : NB, j1 = j0 + nb;
+  const int r0 = j1 + tr * T, c0 = j1 + tc * T;
+  for (int idx = tid; idx < NB * NB; idx += 256) {
     const int r = idx % NB, c = idx / NB;
     A[r][c] = (r < nb && c < nb && r >= c) ? S[(size_t)(j0 + c) * n + j0 + r] : 0.0;
   }
+  // the panel rows of both blocks, fetched while the diagonal block is factorised (wavefronts 1, 2)
+  double w[NB];
+  const int which = wave - 1;                                   // 0: row block, 1: column block
+  const int prow = (which == 0 ? r0 : c0) + (lane & 31);
+  const bool solver = (wave == 1 || (wave == 2 && tr != tc)) && lane < 32 && r0 < n;
+  if (solver) {
+#pragma unroll
+    for (int k = 0; k < NB; ++k) w[k] = (k < nb && prow < n) ? S[(size_t)(j0 + k) * n + prow] : 0.0;
+  }
   __syncthreads();
-  // unpivoted LDL^T of the block in registers: lane r keeps row r; the pivot and the scaled pivot
-  // column travel through v_readlane with constant lane numbers (fully unrolled: 496 updates).
-  // LDS read-modify-write loops would be latency-bound (~250 cycles per element).
-  {
-    const int rr = tid & 31;
+  if (wave == 0) {
+    const int rr = lane & 31;
     double a[NB];
 #pragma unroll
     for (int c = 0; c < NB; ++c) a[c] = A[rr][c];
@@ -61,20 +76,19 @@ dense_ldl_panel_kernel(double* __restrict__ S, int n, int j0, double* __restrict
         if (rr > p) a[p] = l;
       }
     }
-    __syncthreads();
-    if (tid < NB) {
+    if (lane < NB) {
 #pragma unroll
       for (int c = 0; c < NB; ++c) A[rr][c] = a[c];
     }
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    if (lane < NB) {
+      const double d = A[lane][lane];
+      dd[lane] = d;
+      di[lane] = fast_rcp(d);
+    }
   }
   __syncthreads();
-  __shared__ double di[NB];
-  if (tid < NB) {  // dd[r] = A[r][r] (static indexing above is not possible: read it back)
-    dd[tid] = A[tid][tid];
-    di[tid] = fast_rcp(A[tid][tid]);
-  }
-  __syncthreads();
-  if (blockIdx.x == 0) {
+  if (tr == 0 && tc == 0) {   // the diagonal block's factor, its pivots, the statistics
     if (tid == 0) {
       double mn = stat[0], mx = stat[1];
       for (int p = 0; p < nb; ++p) {
@@ -84,61 +98,45 @@ dense_ldl_panel_kernel(double* __restrict__ S, int n, int j0, double* __restrict
       }
       stat[0] = mn; stat[1] = mx;
     }
-    for (int p = tid; p < nb; p += nt) dvec[j0 + p] = dd[p];
-    // the block's factor (unit diagonal implied; the diagonal keeps d)
-    for (int idx = tid; idx < nb * nb; idx += nt) {
+    for (int p = tid; p < nb; p += 256) dvec[j0 + p] = dd[p];
+    for (int idx = tid; idx < nb * nb; idx += 256) {
       const int r = idx % nb, c = idx / nb;
-      if (r > c) S[(size_t)(j0 + c) * n + j0 + r] = A[r][c];
-      else if (r == c) S[(size_t)(j0 + c) * n + j0 + r] = dd[c];
+      if (r > c) Lm[(size_t)(j0 + c) * n + j0 + r] = A[r][c];
+      else if (r == c) Lm[(size_t)(j0 + c) * n + j0 + r] = dd[c];
     }
-    return;
   }
+  if (r0 >= n) return;   // (the last panel: nothing below it)
   // a panel row below the block: w = S[r, J] = x (L_JJ D)^T  =>  x_k d_k = w_k - sum_{q<k} (x_q d_q) L_JJ[k][q]
-  // (x_q d_q kept in LDS, one column of 64 threads per q: rolled loops, no register pressure)
-  __shared__ double xw[NB][64];
-  const int r = j0 + nb + (blockIdx.x - 1) * 64 + tid;
-  if (r >= n) return;  // (no barrier below)
-  // the row's NB entries first (the stores below alias S for the compiler: fetched one per step of the
-  // k loop they were a chain of 32 L2 round trips, 16 of the kernel's 29 us)
-  double w[NB];
+  if (solver) {
+    const int i = lane & 31;
 #pragma unroll
-  for (int k = 0; k < NB; ++k) w[k] = (k < nb) ? S[(size_t)(j0 + k) * n + r] : 0.0;
-#pragma unroll
-  for (int k = 0; k < NB; ++k) {
-    if (k < nb) {
-      double acc = w[k];
-      for (int q = 0; q < k; ++q) acc = __builtin_fma(-xw[q][tid], A[k][q], acc);
-      xw[k][tid] = acc;
-      S[(size_t)(j0 + k) * n + r] = acc * di[k];  // L[r][j0 + k]
-      W[(size_t)k * n + r] = acc;                 // W = L D
+    for (int k = 0; k < NB; ++k) {
+      double acc = 0.0;
+      if (k < nb) {
+        acc = w[k];
+        for (int q = 0; q < k; ++q) acc = __builtin_fma(-xw[which][q][i], A[k][q], acc);
+      }
+      xw[which][k][i] = acc;
+      const double l = acc * di[k < nb ? k : 0];
+      if (which == 1 || tr == tc) Lt[k][i] = (k < nb) ? l : 0.0;
+      if (which == 0 && tc == 0 && k < nb && prow < n) Lm[(size_t)(j0 + k) * n + prow] = l;   // L[r][j0 + k]
     }
-  }
-}
-
-// grid: (tiles, tiles) over the trailing block rows/cols [j1, n); only tiles with tr >= tc work
-__global__ void __launch_bounds__(256)
-dense_ldl_update_kernel(double* __restrict__ S, int n, int j0, int j1, const double* __restrict__ W) {
-  constexpr int NB = DENSE_NB, T = 32;
-  const int tr = blockIdx.x, tc = blockIdx.y;
-  if (tr < tc) return;
-  __shared__ double Wt[NB][T + 1];  // W[r0 + i][k]
-  __shared__ double Lt[NB][T + 1];  // L[c0 + j][k]
-  const int r0 = j1 + tr * T, c0 = j1 + tc * T, tid = threadIdx.x;
-  const int nb = j1 - j0;
-  for (int idx = tid; idx < NB * T; idx += 256) {
-    const int i = idx % T, k = idx / T;
-    Wt[k][i] = (k < nb && r0 + i < n) ? W[(size_t)k * n + r0 + i] : 0.0;
-    Lt[k][i] = (k < nb && c0 + i < n) ? S[(size_t)(j0 + k) * n + c0 + i] : 0.0;
   }
   __syncthreads();
-  const int i = tid % T;
-  for (int j = tid / T; j < T; j += 256 / T) {
-    const int r = r0 + i, c = c0 + j;
-    if (r < n && c < n && r >= c) {
-      double acc = 0.0;
+  // tile -= W_R L_C^T on the matrix cores: wavefront q takes the 16 x 16 quadrant (q >> 1, q & 1)
+  {
+    using d4 = __attribute__((ext_vector_type(4))) double;
+    const int qr = wave >> 1, qc = wave & 1, fl = lane & 15, fk = lane >> 4;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int k = 0; k < NB; ++k) acc += Wt[k][i] * Lt[k][j];
-      S[(size_t)c * n + r] -= acc;
+    for (int sq = 0; sq < NB / 4; ++sq) {
+      const int kr = 4 * sq + fk;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xw[0][kr][16 * qr + fl], Lt[kr][16 * qc + fl], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int r = r0 + 16 * qr + fk + 4 * rg, c = c0 + 16 * qc + fl;
+      if (r < n && c < n && r >= c) S[(size_t)c * n + r] -= acc[rg];
     }
   }
 }

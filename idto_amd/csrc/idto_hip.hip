@@ -131,7 +131,8 @@ struct idto_hip_ctx {
   int* con_dofs = nullptr; int con_nu = 0, con_neq = 0;
   std::vector<int> con_dofs_host;
   double *con_S = nullptr, *con_lambda = nullptr, *con_out = nullptr;  // device: [S | J y_g], lambda, [step | J^T lambda]
-  double *con_W = nullptr, *con_d = nullptr, *con_h = nullptr;         // dense LDL^T: W = L D panel, pivots, [min, max | h]
+  double *con_d = nullptr, *con_h = nullptr;                            // dense LDL^T: pivots, [min, max | h]
+  double* con_L = nullptr;                                             // ... and the factor L (dense_ldl_step_kernel only reads S's panels)
   bool con_S_factored = false;                                         // con_S holds the LDL^T factors, not S
   double* con_pin = nullptr; size_t con_pin_count = 0;                 // pinned host staging for the above
   bool h_assembled = false;                                            // H comes from idto_hip_grad_hess: block row 0 is the identity
@@ -1258,8 +1259,8 @@ int idto_hip_constraint_schur_begin(idto_hip_ctx* c, const int* dofs, int nu) {
     c->con_dofs = static_cast<int*>(p);
     HIP_OK(hipMemcpy(c->con_dofs, dofs, (size_t)nu * sizeof(int), hipMemcpyHostToDevice));
     if (Alloc(c, (size_t)neq * neq + neq, &c->con_S) || Alloc(c, (size_t)neq + 2, &c->con_lambda) ||
-        Alloc(c, (size_t)2 * n, &c->con_out) || Alloc(c, (size_t)neq * DENSE_NB, &c->con_W) ||
-        Alloc(c, (size_t)neq, &c->con_d) || Alloc(c, (size_t)neq + 2, &c->con_h))
+        Alloc(c, (size_t)2 * n, &c->con_out) ||
+        Alloc(c, (size_t)neq, &c->con_d) || Alloc(c, (size_t)neq + 2, &c->con_h) || Alloc(c, (size_t)neq * neq, &c->con_L))
       return -2;
     const size_t need = (size_t)neq * neq + neq + 2 * (size_t)n + 2 * (size_t)neq + 4;
     if (c->con_pin) (void)hipHostFree(c->con_pin);
@@ -1310,6 +1311,15 @@ int idto_hip_constraint_schur(idto_hip_ctx* c, const int* dofs, int nu, double* 
   return FactorStatus(c);
 }
 
+// S = L D L^T without pivoting, one launch per panel of 32 columns (dense_ldl.h dense_ldl_step_kernel); L -> con_L
+static void LaunchDenseLdl(idto_hip_ctx* c, double* S, int neq) {
+  for (int j0 = 0; j0 < neq; j0 += DENSE_NB) {
+    const int j1 = j0 + DENSE_NB, below = neq > j1 ? neq - j1 : 0;
+    const int tiles = below > 0 ? (below + 31) / 32 : 1;
+    hipLaunchKernelGGL(dense_ldl_step_kernel, dim3(tiles, tiles), dim3(256), 0, c->stream, S, c->con_L, neq, j0, c->con_d, c->con_h);
+  }
+}
+
 int idto_hip_constraint_solve(idto_hip_ctx* c, const double* h_host, double* lambda_host, double* step_host,
                               double* jtl_host) {
   HIP_OK(hipSetDevice(c->device));
@@ -1323,20 +1333,11 @@ int idto_hip_constraint_solve(idto_hip_ctx* c, const double* h_host, double* lam
   std::memcpy(pin + 2, h_host, (size_t)neq * sizeof(double));
   HIP_OK(hipMemcpyAsync(c->con_h, pin, (size_t)(neq + 2) * sizeof(double), hipMemcpyHostToDevice, c->stream));
   double* S = c->con_S;
-  for (int j0 = 0; j0 < neq; j0 += DENSE_NB) {
-    const int j1 = j0 + DENSE_NB;
-    const int below = neq > j1 ? neq - j1 : 0;
-    hipLaunchKernelGGL(dense_ldl_panel_kernel, dim3(1 + (below + 63) / 64), dim3(64), 0, c->stream, S, neq, j0, c->con_W,
-                       c->con_d, c->con_h);
-    if (j1 < neq) {
-      const int tiles = (neq - j1 + 31) / 32;
-      hipLaunchKernelGGL(dense_ldl_update_kernel, dim3(tiles, tiles), dim3(256), 0, c->stream, S, neq, j0, j1, c->con_W);
-    }
-  }
+  LaunchDenseLdl(c, S, neq);
   c->con_S_factored = true;
   c->con_lambda_at = c->con_lambda + 2;
   // lambda = S^-1 (h - J y_g)
-  hipLaunchKernelGGL(dense_ldl_solve_kernel, dim3(1), dim3(512), (neq + 512 + DENSE_NB * (DENSE_NB + 1)) * sizeof(double), c->stream, S, neq, c->con_d,
+  hipLaunchKernelGGL(dense_ldl_solve_kernel, dim3(1), dim3(512), (neq + 512 + DENSE_NB * (DENSE_NB + 1)) * sizeof(double), c->stream, c->con_L, neq, c->con_d,
                      S + (size_t)neq * neq, -1.0, c->con_h + 2, c->con_lambda + 2);
   hipLaunchKernelGGL(constraint_step_kernel, dim3((n + 63) / 64), dim3(64 * STEP_WAVES), (neq + 64 * STEP_WAVES) * sizeof(double), c->stream, c->slab,
                      c->slab_stride, c->con_dofs, c->con_nu, N, c->nq, c->nv, c->stage_x, neq, c->con_lambda + 2,
@@ -1622,18 +1623,10 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
         hipLaunchKernelGGL(constraint_h_kernel, dim3((neq + 255) / 256), dim3(256), 0, c->stream, c->slab, c->slab_stride,
                            3 * c->nv * c->nq, c->con_dofs, nu, neq, c->con_h, c->alt_r);
         double* S = c->con_S;
-        for (int j0 = 0; j0 < neq; j0 += DENSE_NB) {
-          const int j1 = j0 + DENSE_NB, below = neq > j1 ? neq - j1 : 0;
-          hipLaunchKernelGGL(dense_ldl_panel_kernel, dim3(1 + (below + 63) / 64), dim3(64), 0, c->stream, S, neq, j0, c->con_W,
-                             c->con_d, c->con_h);
-          if (j1 < neq) {
-            const int tiles = (neq - j1 + 31) / 32;
-            hipLaunchKernelGGL(dense_ldl_update_kernel, dim3(tiles, tiles), dim3(256), 0, c->stream, S, neq, j0, j1, c->con_W);
-          }
-        }
+        LaunchDenseLdl(c, S, neq);
         c->con_S_factored = true;
         hipLaunchKernelGGL(dense_ldl_solve_kernel, dim3(1), dim3(512), (neq + 512 + DENSE_NB * (DENSE_NB + 1)) * sizeof(double),
-                           c->stream, S, neq, c->con_d, S + (size_t)neq * neq, -1.0, c->con_h + 2, c->con_lambda + 2);
+                           c->stream, c->con_L, neq, c->con_d, S + (size_t)neq * neq, -1.0, c->con_h + 2, c->con_lambda + 2);
         hipLaunchKernelGGL(constraint_flag_kernel, dim3(1), dim3(1), 0, c->stream, c->con_h, c->tr_state);
         c->con_lambda_at = c->con_lambda + 2;
       }
