@@ -36,7 +36,8 @@ constexpr int DENSE_NB = 32;
 // another one has already overwritten.
 __global__ void __launch_bounds__(256)
 dense_ldl_step_kernel(double* __restrict__ S, double* __restrict__ Lm, int n, int j0, double* __restrict__ dvec,
-                      double* __restrict__ stat) {
+                      double* __restrict__ stat, const double* __restrict__ b, double b_sign, const double* __restrict__ b2,
+                      double* __restrict__ rv) {
   constexpr int NB = DENSE_NB, T = 32;
   const int tr = blockIdx.x, tc = blockIdx.y;
   if (tr < tc) return;
@@ -44,6 +45,7 @@ dense_ldl_step_kernel(double* __restrict__ S, double* __restrict__ Lm, int n, in
   __shared__ double dd[NB], di[NB];
   __shared__ double xw[2][NB][T + 1];  // [0]: W[r0 + i][k] = x_k d_k of the row block, [1]: of the column block
   __shared__ double Lt[NB][T + 1];     // L[c0 + j][k]
+  __shared__ double ys[NB];            // forward substitution of the right-hand side: y of this panel
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nb = (n - j0 < NB) ? n - j0 : NB, j1 = j0 + nb;
   const int r0 = j1 + tr * T, c0 = j1 + tc * T;
@@ -59,6 +61,15 @@ dense_ldl_step_kernel(double* __restrict__ S, double* __restrict__ Lm, int n, in
   if (solver) {
 #pragma unroll
     for (int k = 0; k < NB; ++k) w[k] = (k < nb && prow < n) ? S[(size_t)(j0 + k) * n + prow] : 0.0;
+  }
+  // the right-hand side rides along (L y = r panel by panel: the solve kernel then only substitutes backwards):
+  // rv holds r with the panels before this one eliminated; the first step forms r = b2 + b_sign b itself
+  const bool rhs = rv != nullptr && tc == 0 && wave == 3 && lane < 32;
+  double rj = 0.0, rr_blk = 0.0;
+  if (rhs) {
+    const int gj = j0 + lane, gr = r0 + lane;
+    if (lane < nb) rj = (j0 == 0) ? (b2 ? b2[gj] : 0.0) + b_sign * b[gj] : rv[gj];
+    if (gr < n) rr_blk = (j0 == 0) ? (b2 ? b2[gr] : 0.0) + b_sign * b[gr] : rv[gr];
   }
   __syncthreads();
   if (wave == 0) {
@@ -105,6 +116,19 @@ dense_ldl_step_kernel(double* __restrict__ S, double* __restrict__ Lm, int n, in
       else if (r == c) Lm[(size_t)(j0 + c) * n + j0 + r] = dd[c];
     }
   }
+  if (rv != nullptr && tc == 0 && wave == 3) {   // y_J = L_JJ^-1 r_J: lane r keeps r_r and row r of the unit-lower factor
+    const int r = lane & 31;
+    double lr[NB];
+#pragma unroll
+    for (int p = 0; p < NB; ++p) lr[p] = A[r][p];
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+      const double yp = rdlane(rj, p);  // final: rows < p have been eliminated
+      if (r > p) rj -= lr[p] * yp;
+    }
+    if (lane < NB) ys[lane] = (lane < nb) ? rj : 0.0;
+    if (tr == 0 && lane < nb) rv[j0 + lane] = rj;   // (the panel's y replaces its r)
+  }
   if (r0 >= n) return;   // (the last panel: nothing below it)
   // a panel row below the block: w = S[r, J] = x (L_JJ D)^T  =>  x_k d_k = w_k - sum_{q<k} (x_q d_q) L_JJ[k][q]
   if (solver) {
@@ -123,6 +147,12 @@ dense_ldl_step_kernel(double* __restrict__ S, double* __restrict__ Lm, int n, in
     }
   }
   __syncthreads();
+  if (rhs && r0 + lane < n) {   // r_R -= L_R,J y_J  (L = W / d)
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) acc = __builtin_fma(xw[0][k][lane] * di[k], ys[k], acc);
+    rv[r0 + lane] = rr_blk - acc;
+  }
   // tile -= W_R L_C^T on the matrix cores: wavefront q takes the 16 x 16 quadrant (q >> 1, q & 1)
   {
     using d4 = __attribute__((ext_vector_type(4))) double;
@@ -144,7 +174,8 @@ dense_ldl_step_kernel(double* __restrict__ S, double* __restrict__ Lm, int n, in
 // x = S^-1 b from the factors (L strictly lower in S, d in dvec); one workgroup, b and x in LDS
 __global__ void __launch_bounds__(512)
 dense_ldl_solve_kernel(const double* __restrict__ S, int n, const double* __restrict__ dvec,
-                       const double* __restrict__ b, double b_sign, const double* __restrict__ b2, double* __restrict__ x) {
+                       const double* __restrict__ b, double b_sign, const double* __restrict__ b2, double* __restrict__ x,
+                       int forward_done) {   // forward_done: b already is L^-1 r (dense_ldl_step_kernel carried it along)
   extern __shared__ double y[];  // [n]
   constexpr int NB = DENSE_NB;
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -159,7 +190,7 @@ dense_ldl_solve_kernel(const double* __restrict__ S, int n, const double* __rest
     }
   };
   // forward: L y = b, panel by panel
-  for (int j0 = 0; j0 < n; j0 += NB) {
+  for (int j0 = 0; j0 < n && !forward_done; j0 += NB) {
     const int nb = (n - j0 < NB) ? n - j0 : NB;
     stage_block(j0, nb);
     __syncthreads();

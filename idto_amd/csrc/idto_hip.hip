@@ -132,6 +132,7 @@ struct idto_hip_ctx {
   std::vector<int> con_dofs_host;
   double *con_S = nullptr, *con_lambda = nullptr, *con_out = nullptr;  // device: [S | J y_g], lambda, [step | J^T lambda]
   double *con_d = nullptr, *con_h = nullptr;                            // dense LDL^T: pivots, [min, max | h]
+  double* con_rv = nullptr;                                            // ... and L^-1 (h - J y_g), carried along by the factorisation
   double* con_L = nullptr;                                             // ... and the factor L (dense_ldl_step_kernel only reads S's panels)
   bool con_S_factored = false;                                         // con_S holds the LDL^T factors, not S
   double* con_pin = nullptr; size_t con_pin_count = 0;                 // pinned host staging for the above
@@ -1260,7 +1261,8 @@ int idto_hip_constraint_schur_begin(idto_hip_ctx* c, const int* dofs, int nu) {
     HIP_OK(hipMemcpy(c->con_dofs, dofs, (size_t)nu * sizeof(int), hipMemcpyHostToDevice));
     if (Alloc(c, (size_t)neq * neq + neq, &c->con_S) || Alloc(c, (size_t)neq + 2, &c->con_lambda) ||
         Alloc(c, (size_t)2 * n, &c->con_out) ||
-        Alloc(c, (size_t)neq, &c->con_d) || Alloc(c, (size_t)neq + 2, &c->con_h) || Alloc(c, (size_t)neq * neq, &c->con_L))
+        Alloc(c, (size_t)neq, &c->con_d) || Alloc(c, (size_t)neq + 2, &c->con_h) || Alloc(c, (size_t)neq * neq, &c->con_L) ||
+        Alloc(c, (size_t)neq, &c->con_rv))
       return -2;
     const size_t need = (size_t)neq * neq + neq + 2 * (size_t)n + 2 * (size_t)neq + 4;
     if (c->con_pin) (void)hipHostFree(c->con_pin);
@@ -1312,11 +1314,13 @@ int idto_hip_constraint_schur(idto_hip_ctx* c, const int* dofs, int nu, double* 
 }
 
 // S = L D L^T without pivoting, one launch per panel of 32 columns (dense_ldl.h dense_ldl_step_kernel); L -> con_L
-static void LaunchDenseLdl(idto_hip_ctx* c, double* S, int neq) {
+// together with the forward substitution of the right-hand side r = b2 + b_sign b (-> con_rv = L^-1 r)
+static void LaunchDenseLdl(idto_hip_ctx* c, double* S, int neq, const double* b, double b_sign, const double* b2) {
   for (int j0 = 0; j0 < neq; j0 += DENSE_NB) {
     const int j1 = j0 + DENSE_NB, below = neq > j1 ? neq - j1 : 0;
     const int tiles = below > 0 ? (below + 31) / 32 : 1;
-    hipLaunchKernelGGL(dense_ldl_step_kernel, dim3(tiles, tiles), dim3(256), 0, c->stream, S, c->con_L, neq, j0, c->con_d, c->con_h);
+    hipLaunchKernelGGL(dense_ldl_step_kernel, dim3(tiles, tiles), dim3(256), 0, c->stream, S, c->con_L, neq, j0, c->con_d, c->con_h,
+                       b, b_sign, b2, c->con_rv);
   }
 }
 
@@ -1333,12 +1337,12 @@ int idto_hip_constraint_solve(idto_hip_ctx* c, const double* h_host, double* lam
   std::memcpy(pin + 2, h_host, (size_t)neq * sizeof(double));
   HIP_OK(hipMemcpyAsync(c->con_h, pin, (size_t)(neq + 2) * sizeof(double), hipMemcpyHostToDevice, c->stream));
   double* S = c->con_S;
-  LaunchDenseLdl(c, S, neq);
+  LaunchDenseLdl(c, S, neq, S + (size_t)neq * neq, -1.0, c->con_h + 2);
   c->con_S_factored = true;
   c->con_lambda_at = c->con_lambda + 2;
-  // lambda = S^-1 (h - J y_g)
+  // lambda = S^-1 (h - J y_g): the forward substitution went with the factorisation
   hipLaunchKernelGGL(dense_ldl_solve_kernel, dim3(1), dim3(512), (neq + 512 + DENSE_NB * (DENSE_NB + 1)) * sizeof(double), c->stream, c->con_L, neq, c->con_d,
-                     S + (size_t)neq * neq, -1.0, c->con_h + 2, c->con_lambda + 2);
+                     c->con_rv, 1.0, (const double*)nullptr, c->con_lambda + 2, 1);
   hipLaunchKernelGGL(constraint_step_kernel, dim3((n + 63) / 64), dim3(64 * STEP_WAVES), (neq + 64 * STEP_WAVES) * sizeof(double), c->stream, c->slab,
                      c->slab_stride, c->con_dofs, c->con_nu, N, c->nq, c->nv, c->stage_x, neq, c->con_lambda + 2,
                      c->con_out, c->con_out + n, c->alt_r);
@@ -1623,10 +1627,10 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
         hipLaunchKernelGGL(constraint_h_kernel, dim3((neq + 255) / 256), dim3(256), 0, c->stream, c->slab, c->slab_stride,
                            3 * c->nv * c->nq, c->con_dofs, nu, neq, c->con_h, c->alt_r);
         double* S = c->con_S;
-        LaunchDenseLdl(c, S, neq);
+        LaunchDenseLdl(c, S, neq, S + (size_t)neq * neq, -1.0, c->con_h + 2);
         c->con_S_factored = true;
         hipLaunchKernelGGL(dense_ldl_solve_kernel, dim3(1), dim3(512), (neq + 512 + DENSE_NB * (DENSE_NB + 1)) * sizeof(double),
-                           c->stream, c->con_L, neq, c->con_d, S + (size_t)neq * neq, -1.0, c->con_h + 2, c->con_lambda + 2);
+                           c->stream, c->con_L, neq, c->con_d, c->con_rv, 1.0, (const double*)nullptr, c->con_lambda + 2, 1);
         hipLaunchKernelGGL(constraint_flag_kernel, dim3(1), dim3(1), 0, c->stream, c->con_h, c->tr_state);
         c->con_lambda_at = c->con_lambda + 2;
       }
