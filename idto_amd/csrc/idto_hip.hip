@@ -106,6 +106,7 @@ struct idto_hip_ctx {
   bool tr_conv_on = false;                 // idto_hip_tr_set_convergence
   double tr_conv_tol[6] = {0, 0, 0, 0, 0, 0};
   bool asm_in_solver = true;                  // option "asm_in_solver": idto_hip_gn_step assembles g and H inside the pipelined solver's launch
+  const double* fuse_gate = nullptr;          // ... gated: problems whose word is 0 keep their g and H (idto_hip_tr_solve)
   bool fuse_asm_next = false;                 // (set by idto_hip_gn_step for the FactorSolve that follows)
   unsigned long long* pipe_rowcnt = nullptr;   // the same for the pipelined variant (its own launch count: the two
   unsigned long long pipe_launches = 0;        // variants release a row with different increments)
@@ -994,7 +995,7 @@ static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double s
     if (F.on) {
       F.nq = c->nq; F.nv = c->nv; F.rows = c->N + 1; F.first = p.r0;
       F.P = c->P; F.q = c->q; F.terms = c->terms; F.v_res = c->v; F.nplus = c->nplus;
-      F.g = c->g; F.HA = c->HA; F.HB = c->HB; F.HC = c->HC; F.alt = c->alt_r; F.ready = c->asm_ready;
+      F.g = c->g; F.HA = c->HA; F.HB = c->HB; F.HC = c->HC; F.alt = c->alt_r; F.ready = c->asm_ready; F.gate = c->fuse_gate;
       plds = std::max(plds, c->asm_terms_lds);
       c->last_assembly = 4;
     }
@@ -1535,6 +1536,7 @@ int idto_hip_tr_reject(idto_hip_ctx* c) {
   return 0;
 }
 
+static bool AsmInSolver(idto_hip_ctx* c);
 // Delta0s / Delta_out: one radius per problem of the context; rows_host: [batch][iterations][TRR_COUNT]
 static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scaling, int normalize_quaternions,
                    const double* Delta0s, double Delta_max, double eta, const int* constrained_dofs, int nu,
@@ -1676,7 +1678,20 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     HIP_OK(hipGetLastError());
     c->fd_full = lookahead && more;   // (v, N+ of the trial point = of the iterate the gated assembly runs for)
     if (!more) break;
-    if (lookahead) {
+    if (lookahead && nu == 0 && AsmInSolver(c)) {
+      // the gated assembly inside the pipelined solver's launch (penta_pipe.h PipeAsm): a problem whose step was
+      // rejected keeps g and H and the solver reads them where they are -> the same step
+      DropPrefetch(c, {IDTO_ARR_GRADIENT, IDTO_ARR_H_A, IDTO_ARR_H_B, IDTO_ARR_H_C, IDTO_ARR_HBANDS});
+      c->con_ready = false; c->con_begun = false;
+      c->fuse_asm_next = true;
+      c->fuse_gate = c->tr_state + TRS_ACCEPTED;
+      rc = idto_hip_factor_solve(c, nullptr, 1, nullptr);
+      c->fuse_gate = nullptr;
+      if (c->fuse_asm_next) {
+        c->fuse_asm_next = false;
+        if (!rc) { g_err = "tr_solve: the solver that was to assemble g and H did not run"; rc = -1; }
+      }
+    } else if (lookahead) {
       rc = LaunchAssemble(c, c->tr_state + TRS_ACCEPTED);
       if (!rc && nu == 0) rc = idto_hip_factor_solve(c, nullptr, 1, nullptr);   // (after a rejection: the same H, g -> the same step)
     } else {

@@ -306,12 +306,18 @@ struct PipeAsm {
   double* g; double* HA; double* HB; double* HC;
   AltSel alt;
   unsigned* ready;
+  const double* gate;       // idto_hip_tr_solve: a problem whose word is 0 (its step was rejected) keeps g and H, nullptr: assemble
 };
+// does this problem assemble in this launch?
+__device__ __forceinline__ bool pipe_asm_on(const PipeAsm& F, size_t o) {
+  return F.on && !(F.gate && *at_problem(F.gate, o) == 0.0);
+}
 
 __device__ __forceinline__ void pipe_assemble(const NdArgs& A, PipeAsm F) {
   extern __shared__ double lds[];
   const int a = (int)blockIdx.x - 5, i = a >> 2, part = a & 3;
   if (i >= F.rows) return;
+  if (!pipe_asm_on(F, (size_t)blockIdx.y * A.pstride)) return;
   if (A.ts && threadIdx.x == 0)   // debug stamps of role 5: [0] latest end, [1] latest start of an assembly workgroup (positive doubles order like integers)
     atomicMax(reinterpret_cast<unsigned long long*>(A.ts + 5 * 64 + 1), (unsigned long long)__double_as_longlong((double)wall_clock64()));
   if (A.ts && a == 4 && threadIdx.x == 0) A.ts[5 * 64 + 8] = (double)wall_clock64();
@@ -1146,7 +1152,7 @@ __global__ void __launch_bounds__(512) penta_pipe_kernel(NdArgs A, PipeAsm F) {
   const int role = blockIdx.x;
   if (role == A.debug_skip_role) return;
   if (role == 4) {
-    A.asm_ready = F.on ? at_problem(F.ready, (size_t)blockIdx.y * A.pstride) : nullptr;
+    A.asm_ready = pipe_asm_on(F, (size_t)blockIdx.y * A.pstride) ? at_problem(F.ready, (size_t)blockIdx.y * A.pstride) : nullptr;
     A.asm_first = F.first;
     A.wt_rows = 1;
     nd_separator<K, false>(A);
@@ -1183,7 +1189,7 @@ __global__ void __launch_bounds__(512) penta_pipe_kernel(NdArgs A, PipeAsm F) {
   P.ts = c.ts;
   P.xjoin_ll = A.ndbuf + B.ll + (1 + pair) * 4 * K;
   P.join_ll = A.ndbuf + B.joinll + (size_t)pair * B.joinll_pair;
-  P.asm_ready = F.on ? at_problem(F.ready, (size_t)blockIdx.y * A.pstride) : nullptr;
+  P.asm_ready = pipe_asm_on(F, (size_t)blockIdx.y * A.pstride) ? at_problem(F.ready, (size_t)blockIdx.y * A.pstride) : nullptr;
   P.asm_first = F.first; P.asm_rows = F.rows;
   const bool spike = role >= 2;
   const PipeLds L = pipe_layout<K>(A.n, spike);
