@@ -302,6 +302,10 @@ int idto_hip_tr_solve_batch(idto_hip_ctx* ctx, int iterations, int scaling_metho
  * two-workgroup kernel instead of the nested-dissection form (csrc/penta_nd.h: four chain workgroups,
  * two spike workgroups and a separator; default 1, used for block sizes 2 / 3 / 5 / 19 and at least 24
  * block rows; explicit multi-right-hand-side solves always use the two-workgroup factors);
+ * "solver_pipe" = 0 keeps the nested dissection on the seven-workgroup kernel instead of the pipelined chains
+ * (csrc/penta_pipe.h: five workgroups, block sizes up to 20; default 1); "asm_in_solver" = 0 gives the assembly of
+ * idto_hip_gn_step / of the trust-region loop a launch of its own instead of workgroups of the pipelined solver's
+ * launch (default 1); a launch whose workgroups were not co-resident steps these down by itself (IDTO_HIP_SOLVER_TIMEOUT);
  * "solver_debug" = 1 records per-phase cycle stamps (IDTO_ARR 15, tools/solver_phases.py);
  * "asm_stop" truncates the assembly kernel after a phase (tools/asm_phases.py). */
 int idto_hip_set_option(idto_hip_ctx* ctx, const char* name, int value);
