@@ -136,7 +136,16 @@ __device__ __forceinline__ void tr_prepare_rows_body(const TrRowsArgs& A, double
       const int sr = (j <= 2) ? 1 : K, sc = (j <= 2) ? K : 1;   // M(r, c) or M(c, r)
       const double* a = xt + j * K;
       const double* y = xy + j * K;
-      for (int c = 0; c < K; ++c) { const double m = M[r * sr + c * sc]; at += m * a[c]; ay += m * y[c]; }
+      // (eight loads in flight at a time: the rolled loop with one load per step was a chain of L2 round trips;
+      // the sums keep their order)
+      for (int c0 = 0; c0 < K; c0 += 8) {
+        double m[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m[u] = (c0 + u < K) ? M[r * sr + (c0 + u) * sc] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (c0 + u < K) { at += m[u] * a[c0 + u]; ay += m[u] * y[c0 + u]; }
+      }
     }
     pt[idx] = at; py[idx] = ay;
   }
