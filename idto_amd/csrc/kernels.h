@@ -1211,10 +1211,17 @@ __device__ __forceinline__ void assemble_terms_row(int nq, int nv, const DevProb
       ops[X_V * psz + o] = vv * wV[l * nv + l];
     }
   }
+  double* wdv = vep + nv;            // diagonal of the V-term's weights as the gradient uses them ...
+  double* wdw = wdv + nv;            // ... and of the W1-term's  (staged: the gradient's loop over r fetched them
+                                     // one global load per step, 18 round trips in a row on the slowest part)
   if (part == 0) {
+    const double* WVd = (i < N) ? P.Qv : P.Qfv;
+    const double* WWd = (i == N - 1) ? P.Qfv : P.Qv;
     for (int r = tid; r < nv; r += nt) {
       ve[r] = v_res[i * nv + r] - P.v_nom[i * nv + r];
       vep[r] = (i < N) ? v_res[(i + 1) * nv + r] - P.v_nom[(i + 1) * nv + r] : 0.0;
+      wdv[r] = WVd[r * nv + r];
+      wdw[r] = WWd[r * nv + r];
     }
   }
   __syncthreads();
@@ -1255,12 +1262,10 @@ __device__ __forceinline__ void assemble_terms_row(int nq, int nv, const DevProb
         // sum_r (e_r w_r) J[r][j] for the V- and the W1-term, two chains in lockstep
         const double* JV = ops + S_V * psz + j * nvp;
         const double* JW = ops + S_W1 * psz + j * nvp;
-        const double* WV = (i < N) ? P.Qv : P.Qfv;
-        const double* WW = (i == N - 1) ? P.Qfv : P.Qv;
-        double gv = (ve[0] * WV[0]) * JV[0], gw = (vep[0] * WW[0]) * JW[0];
+        double gv = (ve[0] * wdv[0]) * JV[0], gw = (vep[0] * wdw[0]) * JW[0];
         for (int r = 1; r < nv; ++r) {
-          gv += (ve[r] * WV[r * nv + r]) * JV[r];
-          gw += (vep[r] * WW[r * nv + r]) * JW[r];
+          gv += (ve[r] * wdv[r]) * JV[r];
+          gw += (vep[r] * wdw[r]) * JW[r];
         }
         double gj;
         if (i < N) {
