@@ -53,6 +53,15 @@ struct DevModel {
   // kernel can stage the whole model into LDS with one coalesced copy and rebase the pointers
   const double* blob;
   int blob_n;              // size in doubles
+  // id_fast.h: the instantiated tree shape this model has (0: none, id_eval<MAXC> serves it) and
+  // the gathered records of its bodies and contact pairs (inside the blob)
+  int fast_shape;
+  int fast_lo, fast_n;     // the part of the blob (doubles) a kernel of that shape needs: the records, jtype, qstart, vstart, f_seg
+  int f_maxpp;
+  const double* f_body;
+  const double* f_cbody;
+  const double* f_pairs;
+  const int* f_seg;
 };
 
 // The model with every table pointer rebased from the global blob to a copy at `dst`
@@ -71,6 +80,7 @@ IDTO_DEV DevModel rebase_model(const DevModel& M, const double* dst) {
   L.chain = i(M.chain); L.nchain = i(M.nchain); L.pkind = i(M.pkind);
   L.path_npairs = i(M.path_npairs); L.path_pairs = i(M.path_pairs);
   L.pair_ga = i(M.pair_ga); L.pair_gb = i(M.pair_gb); L.pair_sa = i(M.pair_sa); L.pair_sb = i(M.pair_sb);
+  L.f_body = d(M.f_body); L.f_cbody = d(M.f_cbody); L.f_pairs = d(M.f_pairs); L.f_seg = i(M.f_seg);
   L.blob = dst;
   return L;
 }

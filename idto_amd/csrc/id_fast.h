@@ -1,0 +1,430 @@
+// id_fast.h — the inverse-dynamics evaluation of id_eval.h as straight-line code for the tree
+// shapes of the reference's examples (reference optimizer/trajectory_optimizer.cc:228-386, the
+// same routines id_eval.h replaces).
+//
+// id_eval<MAXC> reads the joint type, the parent kind and the chain length of every slot from the
+// model tables per lane, which turns the recursion into ~240 exec-masked branches with a table
+// read from LDS in front of each, and selects the two bodies of a contact pair out of the
+// register-resident chain with compare cascades (profiles/r03_pmc_sq_summary.txt: 29 % of the
+// wavefront's cycles issue VALU work, 52 % wait).  Here the shape is a template parameter:
+//   CJ   joint of the common root body: -1 (none) or IDTO_JOINT_FLOATING, attached to the world
+//   J0   joint of chain slot 0: revolute or planar;  K0: its parent, PK_WORLD or PK_COMMON
+//   slots 1 .. MAXC-1: revolute, parent = the previous slot; every path has exactly MAXC bodies
+// and every contact pair touches at most one chain body.  BuildModel (idto_hip.hip) checks a
+// model against the instantiated shapes and gathers, on the host, one record of constants per
+// (path, slot) and per contact pair in the order this file walks them, so that every table read
+// is `base(path) + immediate` and nothing on the recursion's chain waits for an index.
+// The contact pairs of a slot are evaluated right after the slot's kinematics: a finished slot
+// keeps 12 doubles (r, hW, f, n) instead of 36, which is what made <4> spill.
+//
+// Floating point: every value is produced by the same operations in the same order as in
+// id_eval.h / oracle/rigid_body.h.  Where a term of the generic expression is a
+// product with the world's zero velocity it is replaced by the `+ 0.0` that it amounts to for
+// finite operands (x + (+-0 * finite) + 0 == x + 0 bit for bit, including the sign of a zero
+// result); the world-frame pose I * X_PF of a body attached to the world is formed on the host
+// with the same fused expressions.
+#pragma once
+
+#include "id_eval.h"
+
+namespace idto_dev {
+
+// record of one body (doubles); FB_IDX holds {qstart, vstart} as two ints
+enum { FB_XPF = 0, FB_AXIS = 12, FB_MASS = 15, FB_COM = 16, FB_INERTIA = 19, FB_DAMP = 25, FB_IDX = 31, FB_STRIDE = 34 };
+// record of one contact pair; FP_INFO holds {type A, type B, C is A, the other body is the common one} as four ints.
+// XC, SC: geometry frame and size on C (the chain slot of the pair's group; the common body for a pair without a
+// chain body); XO, SO: on the other body - for the world [I R | 0 + I p], formed on the host
+enum { FP_INFO = 0, FP_XC = 2, FP_SC = 14, FP_XO = 17, FP_SO = 29, FP_STRIDE = 34 };
+
+// x + (x of the lane whose index differs in bit 0 / bit 1): the butterfly of dev_math.h tree_sum
+// as DPP quad permutations (no LDS round trip); lanes of one evaluation are adjacent and aligned
+template <int CTRL>
+IDTO_DEV double quad_perm(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <int NP>
+IDTO_DEV V3 tree_sum_fast(V3 v) {
+  if (NP >= 2) {
+    v.x = v.x + quad_perm<0xB1>(v.x); v.y = v.y + quad_perm<0xB1>(v.y); v.z = v.z + quad_perm<0xB1>(v.z);
+  }
+  if (NP >= 4) {
+    v.x = v.x + quad_perm<0x4E>(v.x); v.y = v.y + quad_perm<0x4E>(v.y); v.z = v.z + quad_perm<0x4E>(v.z);
+  }
+  if (NP >= 8) {
+    v.x = xor_add(v.x, 4); v.y = xor_add(v.y, 4); v.z = xor_add(v.z, 4);
+  }
+  return v;
+}
+
+struct ParentKin {  // what a child needs of its parent
+  M3 R;
+  V3 p, w, v, al, a;
+};
+
+IDTO_DEV V3 sel3(bool c, V3 a, V3 b) { return mk(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
+
+// One signed-distance pair (reference TO.cc:281-385): id_eval.h contact_pair() + signed_distance()
+// with the distance test moved in front of the witness points (three divisions and two 3x3
+// products that an inactive pair never needs).  The pair's bodies are C - the chain slot of the
+// group the pair is listed in (the common body for the groups without a chain body) - and "the other
+// one": the common body (`oc`) or the world, whose geometry pose the host has already formed.  Which
+// of the two is the pair's A is `cia`.  Returns whether the pair is active; (fc, nc) is the wrench on
+// C about its origin, (fo, no) the one on the other body.
+template <bool HAS_COMMON>
+IDTO_DEV bool pair_eval(const double* pr, const DevContact& cp, const BodyState& C, const BodyState& cb, V3* fc, V3* nc,
+                        V3* fo, V3* no) {
+  const V3 zero = mk(0, 0, 0);
+  const int2 types = *reinterpret_cast<const int2*>(pr + FP_INFO);
+  const int2 flags = *reinterpret_cast<const int2*>(pr + FP_INFO + 1);
+  const int typeA = types.x, typeB = types.y;
+  const bool cia = flags.x != 0, oc = HAS_COMMON && flags.y != 0;
+  const V3 pgC = C.p + C.R * ldv3(pr + FP_XC + 9);
+  V3 pgO = ldv3(pr + FP_XO + 9);   // (the world's: 0 + I p, formed on the host)
+  if (HAS_COMMON) pgO = sel3(oc, cb.p + cb.R * pgO, pgO);
+  const V3 pgA = sel3(cia, pgC, pgO), pgB = sel3(cia, pgO, pgC);
+  const V3 sC = ldv3(pr + FP_SC), sO = ldv3(pr + FP_SO);
+  const V3 sA = sel3(cia, sC, sO), sB = sel3(cia, sO, sC);
+  double phi = 0;
+  V3 n = mk(0, 0, 1), Ca = zero, Cb = zero;
+  bool hit = false;
+  if (typeA == IDTO_GEOM_SPHERE && typeB == IDTO_GEOM_SPHERE) {
+    const V3 d = pgB - pgA;
+    const double dist = __builtin_sqrt(dot(d, d));
+    phi = (dist - sA.x) - sB.x;
+    if (!(phi > cp.threshold)) {
+      n = d / dist;
+      Ca = pgA + n * sA.x;
+      Cb = pgB - n * sB.x;
+      hit = true;
+    }
+  } else if (typeA != typeB) {  // sphere-box in either order
+    const bool sphere_is_A = (typeA == IDTO_GEOM_SPHERE);
+    M3 RX;                      // the box's rotation in the world
+    if (sphere_is_A == cia) {   // the sphere is on C: the box is on the other body
+      RX = ldm3(pr + FP_XO);    // (the world's: I R, formed on the host)
+      if (HAS_COMMON) {
+        const M3 RXc = cb.R * RX;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) RX.m[i] = oc ? RXc.m[i] : RX.m[i];
+      }
+    } else {
+      RX = C.R * ldm3(pr + FP_XC);
+    }
+    const V3 pS = sphere_is_A ? pgA : pgB;
+    const double rad = sphere_is_A ? sA.x : sB.x;
+    const V3 pX = sphere_is_A ? pgB : pgA;
+    const V3 h = sphere_is_A ? sB : sA;
+    const V3 c = tmul(RX, pS - pX);
+    V3 pc = c;
+    bool outside = false;
+    if (pc.x > h.x) { pc.x = h.x; outside = true; } else if (pc.x < -h.x) { pc.x = -h.x; outside = true; }
+    if (pc.y > h.y) { pc.y = h.y; outside = true; } else if (pc.y < -h.y) { pc.y = -h.y; outside = true; }
+    if (pc.z > h.z) { pc.z = h.z; outside = true; } else if (pc.z < -h.z) { pc.z = -h.z; outside = true; }
+    V3 g = zero, dv = zero;
+    double dist = 1.0;
+    if (outside) {
+      dv = c - pc;
+      dist = __builtin_sqrt(dot(dv, dv));
+      phi = dist - rad;
+    } else {
+      const double dx = h.x - __builtin_fabs(c.x), dy = h.y - __builtin_fabs(c.y), dz = h.z - __builtin_fabs(c.z);
+      double depth;
+      if (dx <= dy && dx <= dz) { depth = dx; g.x = (c.x >= 0) ? 1.0 : -1.0; pc.x = g.x * h.x; }
+      else if (dy <= dz) { depth = dy; g.y = (c.y >= 0) ? 1.0 : -1.0; pc.y = g.y * h.y; }
+      else { depth = dz; g.z = (c.z >= 0) ? 1.0 : -1.0; pc.z = g.z * h.z; }
+      phi = -depth - rad;
+    }
+    if (!(phi > cp.threshold)) {
+      if (outside) g = dv / dist;
+      const V3 gW = RX * g;
+      const V3 boxW = pX + RX * pc;
+      const V3 sphW = pS - gW * rad;
+      if (sphere_is_A) { n = -gW; Ca = sphW; Cb = boxW; }
+      else { n = gW; Ca = boxW; Cb = sphW; }
+      hit = true;
+    }
+  } else {  // box A on a moving body vs world-fixed axis-aligned box B: A's lowest vertex against B's top face
+    M3 RgA;
+    if (cia) RgA = C.R * ldm3(pr + FP_XC);
+    else RgA = cb.R * ldm3(pr + FP_XO);   // (A on the other body: the common one - BuildModel refuses a world-fixed A)
+    const double ztop = pgB.z + sB.z;
+    double zmin = 0;
+    V3 best = zero;
+#pragma unroll
+    for (int iv = 0; iv < 8; ++iv) {
+      const V3 cbx = mk((iv & 4) ? sA.x : -sA.x, (iv & 2) ? sA.y : -sA.y, (iv & 1) ? sA.z : -sA.z);
+      const V3 cw = pgA + RgA * cbx;
+      if (iv == 0 || cw.z < zmin) { zmin = cw.z; best = cw; }
+    }
+    phi = zmin - ztop;
+    if (!(phi > cp.threshold)) {
+      n = mk(0, 0, -1);
+      Ca = best;
+      Cb = mk(best.x, best.y, ztop);
+      hit = true;
+    }
+  }
+  if (!hit) return false;
+  // the two bodies' origins and velocities (the world's are zeros)
+  V3 Op = zero, Ow = zero, Ov = zero;
+  if (HAS_COMMON) { Op = sel3(oc, cb.p, zero); Ow = sel3(oc, cb.w, zero); Ov = sel3(oc, cb.v, zero); }
+  const V3 Ap = sel3(cia, C.p, Op), Aw = sel3(cia, C.w, Ow), Av = sel3(cia, C.v, Ov);
+  const V3 Bp = sel3(cia, Op, C.p), Bw = sel3(cia, Ow, C.w), Bv = sel3(cia, Ov, C.v);
+  const V3 nhat = n;
+  const V3 pC = (Ca + Cb) * 0.5;
+  const V3 pAC = pC - Ap, pBC = pC - Bp;
+  const V3 vAc = Av + cross(Aw, pAC);
+  const V3 vBc = Bv + cross(Bw, pBC);
+  const V3 vrel = vBc - vAc;
+  const double vn = dot(nhat, vrel);
+  const V3 vt = vrel - nhat * vn;
+  double dissipation = 0.0;
+  const double s = vn / cp.vd;
+  if (s < 0) dissipation = 1 - s;
+  else if (s < 2) dissipation = (s - 2) * (s - 2) / 4;
+  double compliant_fn;
+  const double exponent = -phi / cp.sigma;
+  if (exponent >= 37) compliant_fn = -cp.k * phi;
+  else compliant_fn = cp.sigma * cp.k * idto::detmath::log(1 + idto::detmath::exp(exponent));
+  const double fn = compliant_fn * dissipation;
+  const V3 that = (-vt) / __builtin_sqrt(cp.vs * cp.vs + dot(vt, vt));
+  const V3 ft = (that * cp.mu) * fn;
+  const V3 fB = nhat * fn + ft;
+  const V3 fA = -fB;
+  const V3 nB = cross(pBC, fB);
+  const V3 nA = cross(pAC, fA);
+  *fc = sel3(cia, fA, fB); *nc = sel3(cia, nA, nB);
+  *fo = sel3(cia, fB, fA); *no = sel3(cia, nB, nA);
+  return true;
+}
+
+// inertial_wrench() of id_eval.h with the body's constants read from its record
+IDTO_DEV void inertial_wrench_rec(const double* rec, const M3& R, V3 w, V3 al, V3 a, V3 g, V3* f_in, V3* n_in) {
+  const V3 cW = R * ldv3(rec + FB_COM);
+  const V3 t1 = cross(al, cW);
+  const V3 t2 = cross(w, cross(w, cW));
+  const V3 acom = (a + t1) + t2;
+  *f_in = (acom - g) * rec[FB_MASS];
+  const V3 wB = tmul(R, w), alB = tmul(R, al);
+  const double* I = rec + FB_INERTIA;
+  const V3 Iw = mk(fma3(I[0], wB.x, I[3], wB.y, I[4], wB.z), fma3(I[3], wB.x, I[1], wB.y, I[5], wB.z),
+                   fma3(I[4], wB.x, I[5], wB.y, I[2], wB.z));
+  const V3 Ial = mk(fma3(I[0], alB.x, I[3], alB.y, I[4], alB.z), fma3(I[3], alB.x, I[1], alB.y, I[5], alB.z),
+                    fma3(I[4], alB.x, I[5], alB.y, I[2], alB.z));
+  const V3 nB = Ial + cross(wB, Iw);
+  *n_in = R * nB + cross(cW, *f_in);
+}
+
+// The contact pairs [start, start + count) of this path's list: C is the chain slot the group
+// belongs to (the common body for the two groups without a chain body), cb the common body.
+// Wrenches on C are added to (*fext, *next), those on the other body - if it is the common one -
+// to (*cfe, *cne), in list order.  (fext, next) may be (cfe, cne): then C is the common body.
+template <bool HAS_COMMON>
+IDTO_DEV void pair_group(const double* plist, int segword, const DevContact& cp, const BodyState& C, const BodyState& cb,
+                         V3* fext, V3* next, V3* cfe, V3* cne) {
+#ifdef IDTO_FAST_NO_PAIRS
+  return;
+#endif
+  const int start = segword & 0xffff, count = segword >> 16;
+  for (int j = start; j < start + count; ++j) {
+    const double* pr = plist + j * FP_STRIDE;
+    V3 fc, nc, fo, no;
+    if (pair_eval<HAS_COMMON>(pr, cp, C, cb, &fc, &nc, &fo, &no)) {
+      *fext = *fext + fc; *next = *next + nc;
+      if (HAS_COMMON) {
+        const bool oc = reinterpret_cast<const int*>(pr + FP_INFO)[3] != 0;
+        if (oc) { *cfe = *cfe + fo; *cne = *cne + no; }
+      }
+    }
+  }
+}
+
+// The gathered tables (all inside the model blob, so that rebase_model() moves them to LDS)
+struct FastTab {
+  const double* body;    // [npaths][MAXC] records of FB_STRIDE doubles
+  const double* cbody;   // the common body's record
+  const double* pairs;   // [npaths][maxpp] records of FP_STRIDE doubles, in processing order
+  const int* seg;        // [npaths][MAXC + 2] start | count << 16: pairs without a chain body that come first, slots 0 .. MAXC-1, the rest
+  int maxpp;
+};
+
+// tau = ID(q, v, a) for the lane's path: id_eval<MAXC> for a model of shape (CJ, J0, K0).
+template <int MAXC, int NP, int CJ, int J0, int K0>
+IDTO_DEV void id_eval_fast(const FastTab& T, const double* gravity, const DevContact& cp, int path, bool full,
+                           const double* q, const double* v, const double* a, double* tau) {
+  constexpr bool HAS_COMMON = (CJ == IDTO_JOINT_FLOATING);
+  const V3 zero = mk(0, 0, 0);
+  const V3 g = full ? mk(gravity[0], gravity[1], gravity[2]) : zero;
+  const double* bt = T.body + (size_t)path * (MAXC * FB_STRIDE);
+  const double* ct = T.cbody;
+  const double* plist = T.pairs + (size_t)path * (T.maxpp * FP_STRIDE);
+  const int* seg = T.seg + path * (MAXC + 2);
+
+  // ---- every input of the lane's joints, then every sine / cosine: none of them depends on the recursion
+  int qs[MAXC], vs[MAXC];
+#pragma unroll
+  for (int s = 0; s < MAXC; ++s) {
+    const int2 ix = *reinterpret_cast<const int2*>(bt + s * FB_STRIDE + FB_IDX);
+    qs[s] = ix.x; vs[s] = ix.y;
+  }
+  int cqs = 0, cvs = 0;
+  if (HAS_COMMON) {
+    const int2 ix = *reinterpret_cast<const int2*>(ct + FB_IDX);
+    cqs = ix.x; cvs = ix.y;
+  }
+  double qj[MAXC], vj[MAXC], aj[MAXC];       // the revolute coordinate of each slot (slot 0 planar: theta)
+  double q0x = 0, q0y = 0, v0x = 0, v0y = 0, a0x = 0, a0y = 0;   // slot 0 planar: x, y
+#pragma unroll
+  for (int s = 0; s < MAXC; ++s) {
+    if (s == 0 && J0 == IDTO_JOINT_PLANAR) {
+      q0x = q[qs[0]]; q0y = q[qs[0] + 1]; qj[0] = q[qs[0] + 2];
+      v0x = v[vs[0]]; v0y = v[vs[0] + 1]; vj[0] = v[vs[0] + 2];
+      a0x = a[vs[0]]; a0y = a[vs[0] + 1]; aj[0] = a[vs[0] + 2];
+    } else {
+      qj[s] = q[qs[s]]; vj[s] = v[vs[s]]; aj[s] = a[vs[s]];
+    }
+  }
+  double cq[7], cv[6], ca[6];
+  if (HAS_COMMON) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) cq[i] = q[cqs + i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { cv[i] = v[cvs + i]; ca[i] = a[cvs + i]; }
+  }
+  double sn[MAXC], cs[MAXC];
+#pragma unroll
+  for (int s = 0; s < MAXC; ++s) idto::detmath::sincos(qj[s], &sn[s], &cs[s]);
+
+  // ---- common root body (identical in every lane of the evaluation)
+  BodyState cb;
+  cb.R = ident3(); cb.p = zero; cb.w = zero; cb.v = zero;
+  V3 cb_al = zero, cb_a = zero, cb_fin = zero, cb_nin = zero;
+  V3 cfe = zero, cne = zero;   // this path's partial contact wrench on the common body
+  if (HAS_COMMON) {
+    const M3 R_WF = ldm3(ct + FB_XPF);           // I * R_PF, formed on the host
+    const V3 d1 = ldv3(ct + FB_XPF + 9);         // I * p_PF
+    const M3 R_FM = quat_to_rot(cq);
+    const V3 d2 = R_WF * mk(cq[4], cq[5], cq[6]);
+    const V3 w_rel = R_WF * mk(cv[0], cv[1], cv[2]);
+    const V3 v_rel = R_WF * mk(cv[3], cv[4], cv[5]);
+    const V3 al_rel = R_WF * mk(ca[0], ca[1], ca[2]);
+    const V3 a_rel = R_WF * mk(ca[3], ca[4], ca[5]);
+    cb.R = R_WF * R_FM;
+    cb.p = zero + (d1 + d2);
+    cb.w = zero + w_rel;
+    cb.v = zero + v_rel;
+    cb_al = zero + al_rel;
+    cb_a = zero + a_rel;
+    inertial_wrench_rec(ct, cb.R, cb.w, cb_al, cb_a, g, &cb_fin, &cb_nin);
+    if (full) pair_group<false>(plist, seg[0], cp, cb, cb, &cfe, &cne, &cfe, &cne);
+  }
+
+  // ---- own chain: kinematics, inertial wrench and contact pairs slot by slot
+  V3 r[MAXC], hW[MAXC], ft[MAXC], nt[MAXC];   // ft, nt: inertial minus contact wrench of the slot
+  ParentKin P;
+  P.R = ident3(); P.p = zero; P.w = zero; P.v = zero; P.al = zero; P.a = zero;
+#pragma unroll
+  for (int s = 0; s < MAXC; ++s) {
+    const double* rec = bt + s * FB_STRIDE;
+    const bool world = (s == 0 && K0 == PK_WORLD);
+    if (s == 0 && K0 == PK_COMMON) { P.R = cb.R; P.p = cb.p; P.w = cb.w; P.v = cb.v; P.al = cb_al; P.a = cb_a; }
+    // (a body attached to the world: the record holds I * X_PF)
+    const M3 R_WF = world ? ldm3(rec + FB_XPF) : P.R * ldm3(rec + FB_XPF);
+    const V3 d1 = world ? ldv3(rec + FB_XPF + 9) : P.R * ldv3(rec + FB_XPF + 9);
+    BodyState bs;
+    V3 al, acc;
+    if (s == 0 && J0 == IDTO_JOINT_PLANAR) {
+      M3 R_FM = ident3();
+      R_FM.m[0] = cs[0]; R_FM.m[1] = -sn[0]; R_FM.m[3] = sn[0]; R_FM.m[4] = cs[0];
+      const V3 ex = col(R_WF, 0), ey = col(R_WF, 1), ez = col(R_WF, 2);
+      const V3 d2 = ex * q0x + ey * q0y;
+      const V3 v_rel = ex * v0x + ey * v0y;
+      const V3 a_rel = ex * a0x + ey * a0y;
+      const V3 w_rel = ez * vj[0];
+      const V3 al_rel = ez * aj[0];
+      hW[0] = zero;
+      bs.R = R_WF * R_FM;
+      r[0] = d1 + d2;
+      // (planar joints hang off the world: every product with the parent's velocity is a zero)
+      bs.p = zero + r[0];
+      bs.w = zero + w_rel;
+      bs.v = zero + v_rel;
+      al = zero + al_rel;
+      acc = zero + a_rel;
+    } else {
+      const V3 axis = ldv3(rec + FB_AXIS);
+      const M3 R_FM = axis_angle(axis, sn[s], cs[s]);
+      hW[s] = R_WF * axis;
+      const V3 w_rel = hW[s] * vj[s];
+      const V3 al_rel = hW[s] * aj[s];
+      bs.R = R_WF * R_FM;
+      r[s] = d1 + zero;
+      if (world) {
+        bs.p = zero + r[s];
+        bs.w = zero + w_rel;
+        bs.v = zero;
+        al = zero + al_rel;
+        acc = zero;
+      } else {
+        bs.p = P.p + r[s];
+        bs.w = P.w + w_rel;
+        bs.v = (P.v + cross(P.w, r[s])) + zero;
+        al = (P.al + al_rel) + cross(P.w, w_rel);
+        acc = ((P.a + cross(P.al, r[s])) + cross(P.w, cross(P.w, r[s]))) + zero;
+      }
+    }
+    V3 fin, nin;
+    inertial_wrench_rec(rec, bs.R, bs.w, al, acc, g, &fin, &nin);
+    V3 fext = zero, next = zero;
+    if (full) pair_group<HAS_COMMON>(plist, seg[1 + s], cp, bs, cb, &fext, &next, &cfe, &cne);
+    ft[s] = fin - fext;
+    nt[s] = nin - next;
+    P.R = bs.R; P.p = bs.p; P.w = bs.w; P.v = bs.v; P.al = al; P.a = acc;
+  }
+  if (HAS_COMMON && full) pair_group<false>(plist, seg[MAXC + 1], cp, cb, cb, &cfe, &cne, &cfe, &cne);
+
+  // ---- backward pass along the chain, joint torques
+  V3 child_f = zero, child_n = zero;
+  V3 root_f = zero, root_n = zero;
+#pragma unroll
+  for (int s = MAXC - 1; s >= 0; --s) {
+    const double* rec = bt + s * FB_STRIDE;
+    V3 f = ft[s], n = nt[s];
+    if (s + 1 < MAXC) { f = f + child_f; n = n + child_n; }
+    if (s == 0 && J0 == IDTO_JOINT_PLANAR) {
+      const M3 R_WF = ldm3(rec + FB_XPF);
+      const double t0 = dot(col(R_WF, 0), f), t1 = dot(col(R_WF, 1), f), t2 = dot(col(R_WF, 2), n);
+      tau[vs[0]] = full ? t0 + rec[FB_DAMP] * v0x : t0;
+      tau[vs[0] + 1] = full ? t1 + rec[FB_DAMP + 1] * v0y : t1;
+      tau[vs[0] + 2] = full ? t2 + rec[FB_DAMP + 2] * vj[0] : t2;
+    } else {
+      const double t = dot(hW[s], n);
+      tau[vs[s]] = full ? t + rec[FB_DAMP] * vj[s] : t;
+    }
+    const V3 cf = f, cn = n + cross(r[s], f);
+    if (s > 0) { child_f = cf; child_n = cn; }
+    else if (K0 == PK_COMMON) { root_f = cf; root_n = cn; }
+  }
+
+  // ---- common body: butterfly sums over the lanes of this evaluation
+  if (HAS_COMMON) {
+    const V3 ext_f = tree_sum_fast<NP>(cfe);
+    const V3 ext_n = tree_sum_fast<NP>(cne);
+    const V3 ch_f = tree_sum_fast<NP>(root_f);
+    const V3 ch_n = tree_sum_fast<NP>(root_n);
+    const V3 f = (cb_fin - ext_f) + ch_f;
+    const V3 n = (cb_nin - ext_n) + ch_n;
+    if (path == 0) {
+      const M3 R_WF = ldm3(ct + FB_XPF);
+      const V3 nF = tmul(R_WF, n), fF = tmul(R_WF, f);
+      const double t6[6] = {nF.x, nF.y, nF.z, fF.x, fF.y, fF.z};
+#pragma unroll
+      for (int i = 0; i < 6; ++i) tau[cvs + i] = full ? t6[i] + ct[FB_DAMP + i] * cv[i] : t6[i];
+    }
+  }
+}
+
+}  // namespace idto_dev

@@ -96,6 +96,7 @@ struct idto_hip_ctx {
   bool fd_full = false;                   // v / N+ in HBM belong to the resident q for every t
   int gradients_method = 0;               // 0 forward, 1 central, 2 central 4th order (solver_parameters.h:26-50)
   int fd_stop = 0;                        // same for the finite-difference kernel
+  bool fd_fast = true;                    // option "fd_fast": id_fast.h's evaluation when the model has an instantiated shape
   int asm_stop = 0;                       // profiling aid: truncate the assembly kernel after a phase
   bool two_sided = true;                  // solver: two workgroups eliminating from both ends
   bool fused = true;                      // gn_step: one persistent launch (fused.h) when eligible
@@ -330,8 +331,134 @@ int BuildModel(idto_hip_ctx* c, const idto_model_t* m) {
                o_com = addd(m->com, (size_t)3 * nb), o_in = addd(m->inertia, (size_t)6 * nb),
                o_damp = addd(m->damping, m->nv), o_gX = addd(m->geom_X, (size_t)12 * m->ngeoms),
                o_gs = addd(m->geom_size, (size_t)3 * m->ngeoms);
-  const size_t i_par = addi(m->parent, nb), i_jt = addi(m->jtype, nb), i_qs = addi(m->qstart, nb),
-               i_vs = addi(m->vstart, nb), i_gt = addi(m->geom_type, m->ngeoms), i_ch = addi(chain.data(), chain.size()),
+  // ---- id_fast.h: does the model have one of the instantiated tree shapes?  If so, gather one record of
+  // constants per (path, slot) and per contact pair in the order id_eval_fast walks them.
+  int fast_shape = 0, f_maxpp = 1;
+  size_t o_fbody = 0, o_fcbody = 0, o_fpairs = 0, fast_lo = 0;
+  std::vector<int> fseg(1, 0);
+  {
+    const int cbody = m->common_body;
+    bool ok = true;
+    for (int p = 0; p < K; ++p) ok = ok && nchain[p] == maxc;
+    const int cj = cbody >= 0 ? m->jtype[cbody] : -1;
+    if (cbody >= 0 && cj != IDTO_JOINT_FLOATING) ok = false;
+    int j0 = -1, k0 = -1;
+    for (int p = 0; p < K && ok; ++p)
+      for (int s = 0; s < maxc; ++s) {
+        const int b = chain[(size_t)p * IDTO_MAX_CHAIN + s], jt = m->jtype[b], kd = pkind[(size_t)p * IDTO_MAX_CHAIN + s];
+        if (s == 0) {
+          if (p == 0) { j0 = jt; k0 = kd; }
+          if (jt != j0 || kd != k0) ok = false;
+        } else if (jt != IDTO_JOINT_REVOLUTE || kd != PK_PREV) {
+          ok = false;
+        }
+      }
+    if (ok) {
+      if (maxc == 2 && K == 1 && cj == -1 && j0 == IDTO_JOINT_REVOLUTE && k0 == PK_WORLD) fast_shape = 1;        // acrobot
+      else if (maxc == 3 && K == 1 && cj == -1 && j0 == IDTO_JOINT_PLANAR && k0 == PK_WORLD) fast_shape = 2;     // hopper
+      else if (maxc == 3 && K == 4 && cj == IDTO_JOINT_FLOATING && j0 == IDTO_JOINT_REVOLUTE && k0 == PK_COMMON) fast_shape = 3;   // mini_cheetah
+      else if (maxc == 4 && K == 4 && cj == IDTO_JOINT_FLOATING && j0 == IDTO_JOINT_REVOLUTE && k0 == PK_WORLD) fast_shape = 4;    // allegro_hand + ball
+    }
+    // processing order of a path's pairs: [pairs without a chain body that come first | slot 0 | ... | slot maxc-1 |
+    // the other pairs without a chain body].  The sums that have an order are those onto one chain body (its pairs stay
+    // in list order) and the path's partial sum onto the common body: its pairs must keep their list order too.
+    std::vector<std::vector<int>> order(K);
+    std::vector<int>& segw = fseg;
+    segw.assign((size_t)K * (maxc + 2), 0);
+    for (int p = 0; p < K && fast_shape; ++p) {
+      std::vector<int> mine;
+      for (int j = 0; j < path_npairs[p]; ++j) mine.push_back(path_pairs[(size_t)p * maxpp + j]);
+      int lo_chain_common = 1 << 30, hi_chain_common = -1, last_slot = -1;
+      for (int pi : mine) {
+        const int nchainb = (sa[pi] >= 0) + (sb[pi] >= 0);
+        if (nchainb > 1) { fast_shape = 0; break; }
+        if (nchainb == 1 && (sa[pi] == -1 || sb[pi] == -1)) {
+          const int sl = std::max(sa[pi], sb[pi]);
+          if (sl < last_slot) { fast_shape = 0; break; }   // (slot, index) order != index order on the common body's sum
+          last_slot = sl;
+          lo_chain_common = std::min(lo_chain_common, pi);
+          hi_chain_common = std::max(hi_chain_common, pi);
+        }
+      }
+      if (!fast_shape) break;
+      std::vector<std::vector<int>> groups(maxc + 2);
+      for (int pi : mine) {
+        const int sl = std::max(sa[pi], sb[pi]);
+        if (sl >= 0) { groups[1 + sl].push_back(pi); continue; }
+        const bool touches_common = sa[pi] == -1 || sb[pi] == -1;
+        if (!touches_common || (sa[pi] == -1 && sb[pi] == -1)) { fast_shape = 0; break; }   // (world, world) / (common, common)
+        if (pi < lo_chain_common) groups[0].push_back(pi);
+        else if (pi > hi_chain_common) groups[maxc + 1].push_back(pi);
+        else { fast_shape = 0; break; }
+      }
+      if (!fast_shape) break;
+      for (int gi = 0; gi < maxc + 2; ++gi) {
+        segw[(size_t)p * (maxc + 2) + gi] = (int)order[p].size() | ((int)groups[gi].size() << 16);
+        for (int pi : groups[gi]) order[p].push_back(pi);
+      }
+    }
+    if (fast_shape) {
+      auto ident_mul = [](const double* X, double* out) {   // [I * R | I * p] with the fused forms of dev_math.h
+        static const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        for (int r = 0; r < 3; ++r) {
+          for (int cc = 0; cc < 3; ++cc)
+            out[3 * r + cc] = std::fma(I[3 * r + 2], X[6 + cc], std::fma(I[3 * r + 1], X[3 + cc], I[3 * r] * X[cc]));
+          out[9 + r] = std::fma(I[3 * r + 2], X[11], std::fma(I[3 * r + 1], X[10], I[3 * r] * X[9]));
+        }
+      };
+      auto body_record = [&](int b, bool world, double* rec) {
+        if (world) ident_mul(m->X_PF + (size_t)12 * b, rec + FB_XPF);
+        else std::memcpy(rec + FB_XPF, m->X_PF + (size_t)12 * b, 12 * sizeof(double));
+        std::memcpy(rec + FB_AXIS, m->axis + (size_t)3 * b, 3 * sizeof(double));
+        rec[FB_MASS] = m->mass[b];
+        std::memcpy(rec + FB_COM, m->com + (size_t)3 * b, 3 * sizeof(double));
+        std::memcpy(rec + FB_INERTIA, m->inertia + (size_t)6 * b, 6 * sizeof(double));
+        const int ndof = m->jtype[b] == IDTO_JOINT_FLOATING ? 6 : (m->jtype[b] == IDTO_JOINT_PLANAR ? 3 : 1);
+        for (int d = 0; d < ndof; ++d) rec[FB_DAMP + d] = m->damping[m->vstart[b] + d];
+        const int ix[2] = {m->qstart[b], m->vstart[b]};
+        std::memcpy(rec + FB_IDX, ix, sizeof(ix));
+      };
+      std::vector<double> fb((size_t)K * maxc * FB_STRIDE, 0.0), fc(FB_STRIDE, 0.0);
+      for (int p = 0; p < K; ++p)
+        for (int s = 0; s < maxc; ++s)
+          body_record(chain[(size_t)p * IDTO_MAX_CHAIN + s], pkind[(size_t)p * IDTO_MAX_CHAIN + s] == PK_WORLD,
+                      fb.data() + ((size_t)p * maxc + s) * FB_STRIDE);
+      if (cbody >= 0) body_record(cbody, true, fc.data());
+      for (int p = 0; p < K; ++p) f_maxpp = std::max(f_maxpp, (int)order[p].size());
+      std::vector<double> fp((size_t)K * f_maxpp * FP_STRIDE, 0.0);
+      for (int p = 0; p < K; ++p)
+        for (size_t j = 0; j < order[p].size(); ++j) {
+          const int pi = order[p][j], ga = m->pair_a[pi], gb = m->pair_b[pi];
+          double* rec = fp.data() + ((size_t)p * f_maxpp + j) * FP_STRIDE;
+          // C: the chain body of the pair's group, or the common body for a pair without one; the other body is
+          // the common one or the world
+          const bool a_chain = sa[pi] >= 0, b_chain = sb[pi] >= 0;
+          const bool cia = a_chain || (!b_chain && sa[pi] == -1);
+          const int gc = cia ? ga : gb, go = cia ? gb : ga, so = cia ? sb[pi] : sa[pi];
+          const int info[4] = {m->geom_type[ga], m->geom_type[gb], cia ? 1 : 0, so == -1 ? 1 : 0};
+          std::memcpy(rec + FP_INFO, info, sizeof(info));
+          std::memcpy(rec + FP_XC, m->geom_X + (size_t)12 * gc, 12 * sizeof(double));
+          std::memcpy(rec + FP_SC, m->geom_size + (size_t)3 * gc, 3 * sizeof(double));
+          if (so == -2) {   // world: [I R | 0 + I p], the expressions id_eval.h evaluates for a world-fixed geometry
+            ident_mul(m->geom_X + (size_t)12 * go, rec + FP_XO);
+            for (int e = 0; e < 3; ++e) rec[FP_XO + 9 + e] = 0.0 + rec[FP_XO + 9 + e];
+          } else {
+            std::memcpy(rec + FP_XO, m->geom_X + (size_t)12 * go, 12 * sizeof(double));
+          }
+          std::memcpy(rec + FP_SO, m->geom_size + (size_t)3 * go, 3 * sizeof(double));
+        }
+      o_fbody = addd(fb.data(), fb.size());
+      o_fcbody = addd(fc.data(), fc.size());
+      o_fpairs = addd(fp.data(), fp.size());
+    }
+    // the int tables, those fd_kernel needs beside the gathered records first: with a fast shape it stages only
+    // [fast_lo, fast_lo + fast_n) of the blob in LDS
+    fast_lo = fast_shape ? o_fbody : 0;
+  }
+  const size_t i_jt = addi(m->jtype, nb), i_qs = addi(m->qstart, nb), i_vs = addi(m->vstart, nb);
+  const size_t i_fseg = addi(fseg.data(), fseg.size());
+  const size_t i_fast_end = ints.size();
+  const size_t i_par = addi(m->parent, nb), i_gt = addi(m->geom_type, m->ngeoms), i_ch = addi(chain.data(), chain.size()),
                i_nch = addi(nchain.data(), nchain.size()), i_pk = addi(pkind.data(), pkind.size()),
                i_pnp = addi(path_npairs.data(), path_npairs.size()), i_pp = addi(path_pairs.data(), path_pairs.size()),
                i_ga = addi(m->pair_a, m->npairs), i_gb = addi(m->pair_b, m->npairs), i_sa = addi(sa.data(), sa.size()),
@@ -349,6 +476,9 @@ int BuildModel(idto_hip_ctx* c, const idto_model_t* m) {
   M.parent = bi + i_par; M.jtype = bi + i_jt; M.qstart = bi + i_qs; M.vstart = bi + i_vs; M.geom_type = bi + i_gt;
   M.chain = bi + i_ch; M.nchain = bi + i_nch; M.pkind = bi + i_pk; M.path_npairs = bi + i_pnp; M.path_pairs = bi + i_pp;
   M.pair_ga = bi + i_ga; M.pair_gb = bi + i_gb; M.pair_sa = bi + i_sa; M.pair_sb = bi + i_sb;
+  M.fast_shape = fast_shape; M.f_maxpp = f_maxpp;
+  M.fast_lo = (int)fast_lo; M.fast_n = (int)(nd + (i_fast_end + 1) / 2 - fast_lo);
+  M.f_body = bd + o_fbody; M.f_cbody = bd + o_fcbody; M.f_pairs = bd + o_fpairs; M.f_seg = bi + i_fseg;
   return 0;
 }
 
@@ -361,7 +491,8 @@ int FdEvals(const idto_hip_ctx* c, int mode) {
 int FdLds(const idto_hip_ctx* c, int mode, int ec, bool with_terms = false) {
   const int nq = c->nq, nv = c->nv, E = FdEvals(c, mode), nvp = (nv + 1) & ~1;
   const int rec = with_terms ? 6 * nvp * nq + nvp + asm_terms_stride(nq) + 1 : 0;   // the record, its weighted copy, diag R', the products (+1: 16-byte alignment)
-  return (int)sizeof(double) * (3 * nq + 2 * nv * nq + 3 * nv + 3 * E + E * nv + ec * (nq + 2 * nv) + nv + c->M.blob_n + 2 + nq / 2 + 2 + rec);
+  const int blob_n = (c->fd_fast && c->M.fast_shape) ? c->M.fast_n : c->M.blob_n;   // what fd_body stages of the model
+  return (int)sizeof(double) * (3 * nq + 2 * nv * nq + 3 * nv + 3 * E + E * nv + ec * (nq + 2 * nv) + nv + blob_n + 2 + nq / 2 + 2 + rec);
 }
 
 // fd_kernel also forms the single-record products of the Gauss-Newton assembly (diagonal weights,
@@ -386,11 +517,20 @@ int LaunchFd(idto_hip_ctx* c, int mode, int kb, int ke, AltSel alt = AltSel{null
 #define FD_LAUNCH(MC)                                                                                         \
   hipLaunchKernelGGL(fd_kernel<MC>, grid, block, lds, c->stream, c->M, c->cp, c->P, c->q, c->slab,             \
                      c->slab_stride, c->v, c->a, c->nplus, kb, mode, c->fd_stop, ec, c->pstride, terms, alt)
-  if (c->maxc <= 2) FD_LAUNCH(2);
+#define FD_LAUNCH_FAST(MC, SH)                                                                                 \
+  hipLaunchKernelGGL((fd_kernel<MC, SH>), grid, block, lds, c->stream, c->M, c->cp, c->P, c->q, c->slab,        \
+                     c->slab_stride, c->v, c->a, c->nplus, kb, mode, c->fd_stop, ec, c->pstride, terms, alt)
+  const int shape = c->fd_fast ? c->M.fast_shape : 0;   // id_fast.h: the straight-line evaluation of the model's tree shape
+  if (shape == 1) FD_LAUNCH_FAST(2, 1);
+  else if (shape == 2) FD_LAUNCH_FAST(3, 2);
+  else if (shape == 3) FD_LAUNCH_FAST(3, 3);
+  else if (shape == 4) FD_LAUNCH_FAST(4, 4);
+  else if (c->maxc <= 2) FD_LAUNCH(2);
   else if (c->maxc <= 3) FD_LAUNCH(3);
   else if (c->maxc <= 4) FD_LAUNCH(4);
   else FD_LAUNCH(8);
 #undef FD_LAUNCH
+#undef FD_LAUNCH_FAST
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -671,6 +811,10 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fd_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fd_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fd_kernel<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fd_kernel<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fd_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -1920,6 +2064,7 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "fused_debug") == 0) { c->fused_debug = value != 0; return 0; }
   if (std::strcmp(name, "asm_stop") == 0) { c->asm_stop = value; return 0; }  // profiling aid
   if (std::strcmp(name, "fd_stop") == 0) { c->fd_stop = value; return 0; }    // profiling aid
+  if (std::strcmp(name, "fd_fast") == 0) { c->fd_fast = value != 0; return 0; }
   if (std::strcmp(name, "gradients_method") == 0) {
     if (value < 0 || value > 2) { g_err = "gradients_method: 0 forward, 1 central, 2 central4 (autodiff needs Drake)"; return -1; }
     c->gradients_method = value;

@@ -8,6 +8,7 @@
 
 #include "batch.h"
 #include "id_eval.h"
+#include "id_fast.h"
 #include "trust_region.h"
 
 namespace idto_dev {
@@ -242,7 +243,14 @@ __host__ __device__ inline int asm_terms_stride(int nq) { return 6 * nq * nq + 3
 // dtau_k/dq_k | dtau_k/dq_{k+1} | tau_k] plus v_{k+1}, a_k, N+_{k+1}.
 // mode 0: tau only (one evaluation); mode 1: forward differences (TO.cc:426-563).
 // Dynamic LDS layout (doubles): see the carve-up below.
-template <int MAXC>
+// the instantiated tree shapes of id_fast.h (DevModel::fast_shape; 0 = any model: id_eval<MAXC>)
+template <int SHAPE> struct FastShape { static constexpr int MAXC = 0, NP = 1, CJ = -1, J0 = 0, K0 = 0; };
+template <> struct FastShape<1> { static constexpr int MAXC = 2, NP = 1, CJ = -1, J0 = IDTO_JOINT_REVOLUTE, K0 = PK_WORLD; };             // acrobot
+template <> struct FastShape<2> { static constexpr int MAXC = 3, NP = 1, CJ = -1, J0 = IDTO_JOINT_PLANAR, K0 = PK_WORLD; };               // hopper
+template <> struct FastShape<3> { static constexpr int MAXC = 3, NP = 4, CJ = IDTO_JOINT_FLOATING, J0 = IDTO_JOINT_REVOLUTE, K0 = PK_COMMON; };  // mini_cheetah
+template <> struct FastShape<4> { static constexpr int MAXC = 4, NP = 4, CJ = IDTO_JOINT_FLOATING, J0 = IDTO_JOINT_REVOLUTE, K0 = PK_WORLD; };   // allegro_hand + ball
+
+template <int MAXC, int SHAPE = 0>
 IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem& P, const double* __restrict__ q,
                       double* __restrict__ slab, int slab_stride, double* __restrict__ v_out,
                       double* __restrict__ a_out, double* __restrict__ nplus_out, const int k, int mode,
@@ -284,7 +292,9 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
   double* ea = ev + EC * nv;    // [EC][nv]
   double* edump = ea + EC * nv; // [nv] write-only dump row for surplus lanes
   double* mblob = edump + nv;    // [M.blob_n] the model tables
-  int* colinfo = reinterpret_cast<int*>(mblob + M.blob_n + (M.blob_n & 1));  // [nq] non-zero rows of N+ column c
+  // (a kernel of a fast shape needs the gathered records and three int tables only: DevModel::fast_lo / fast_n)
+  const int blob_lo = (SHAPE != 0) ? M.fast_lo : 0, blob_n = (SHAPE != 0) ? M.fast_n : M.blob_n;
+  int* colinfo = reinterpret_cast<int*>(mblob + blob_n + (blob_n & 1));  // [nq] non-zero rows of N+ column c
   // (terms != nullptr) the record and its weighted copy for the assembly products: 6 blocks of nq
   // columns, column stride nvp (16-byte aligned columns), + tau_k R' and the diagonal of R'
   const int nvp = (nv + 1) & ~1, psz = nvp * nq;
@@ -296,7 +306,7 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
   double* wr = rec + 6 * psz;      // [nv] diagonal of R' (fetched now: an HBM round trip off the tail's critical path)
   if (terms && mode != 0)
     for (int l = tid; l < nv; l += nt) wr[l] = P.R[l * nv + l];
-  for (int i = tid; i < M.blob_n; i += nt) mblob[i] = M.blob[i];
+  for (int i = tid; i < blob_n; i += nt) mblob[i] = M.blob[blob_lo + i];
   for (int i = tid; i < nq; i += nt) {
     qm1[i] = (k > 0) ? q[(k - 1) * nq + i] : 0.0;
     q0[i] = q[k * nq + i];
@@ -304,7 +314,7 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
   }
   for (int i = tid; i < bsz; i += nt) { N0[i] = 0.0; N1[i] = 0.0; }   // (nplus_pair fills the non-zeros behind this barrier)
   __syncthreads();
-  const DevModel Ml = rebase_model(M, mblob);
+  const DevModel Ml = rebase_model(M, mblob - blob_lo);
   // N+ is sparse: column c has its non-zeros in rows [j0, j0 + cnt) (cnt = 3 for the quaternion
   // columns, 1 otherwise); packed j0 | cnt << 16
   for (int b = tid; b < Ml.nb; b += nt) {
@@ -416,6 +426,24 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
   // Surplus groups (e >= E) re-run evaluation 0 into a dump row so that every lane
   // of a wavefront takes part in the butterfly sums inside id_eval.
   const int groups = nt / K;
+  if constexpr (SHAPE != 0) {
+    // Straight-line evaluation (id_fast.h).  The lanes of a surplus group stay idle (a group's butterfly
+    // partners are its own lanes); evaluations beyond the first round go to the LAST groups: with forward
+    // differences those hold the cheap mass-matrix columns, as do the evaluations left over (allegro:
+    // 69 evaluations on 64 groups - the wavefront of the contact-free columns takes the five extra ones).
+    using FS = FastShape<SHAPE>;
+    FastTab FT;
+    FT.body = Ml.f_body; FT.cbody = Ml.f_cbody; FT.pairs = Ml.f_pairs; FT.seg = Ml.f_seg; FT.maxpp = Ml.f_maxpp;
+    const int grp = tid / FS::NP, path = tid % FS::NP;
+    for (int e0 = 0; e0 < ce; e0 += groups) {
+      const int el = (e0 == 0) ? grp : e0 + (groups - 1 - grp);
+      if (el < ce) {
+        const bool full = central || c0 + el < 1 + nP + nT;
+        id_eval_fast<FS::MAXC, FS::NP, FS::CJ, FS::J0, FS::K0>(FT, Ml.gravity, cp, path, full, eq + el * nq, ev + el * nv,
+                                                               ea + el * nv, etau + (c0 + el) * nv);
+      }
+    }
+  } else {
   for (int e0 = 0; e0 < ce; e0 += groups) {
     const int el = e0 + tid / K;
     const int path = tid % K;
@@ -423,6 +451,7 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
     const bool full = central || c0 + ee < 1 + nP + nT;
     double* tau_dst = (el < ce) ? etau + (c0 + ee) * nv : edump;
     id_eval<MAXC>(Ml, cp, path, full, eq + ee * nq, ev + ee * nv, ea + ee * nv, tau_dst);
+  }
   }
   __syncthreads();
   }
@@ -565,16 +594,16 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
   for (int idx = tid; idx < ts / 2; idx += nt) out2[idx] = st2[idx];
 }
 
-template <int MAXC>
+template <int MAXC, int SHAPE = 0>
 __global__ void __launch_bounds__(256) fd_kernel(DevModel M, DevContact cp, DevProblem P, const double* __restrict__ q,
                           double* __restrict__ slab, int slab_stride, double* __restrict__ v_out,
                           double* __restrict__ a_out, double* __restrict__ nplus_out, int k_begin, int mode,
                           int stop_after, int echunk, size_t pstride, double* __restrict__ terms, AltSel alt) {
   const size_t o = (size_t)blockIdx.y * pstride;   // problem of the batch
   const size_t w = o + (size_t)alt_offset(alt, o);    // ... and the set of outputs (batch.h AltSel)
-  fd_body<MAXC>(M, cp, at_problem(P, o), at_problem(q, o), at_problem(slab, w), slab_stride, at_problem(v_out, w),
-                at_problem(a_out, w), at_problem(nplus_out, w), k_begin + (int)blockIdx.x, mode, stop_after, echunk,
-                terms ? at_problem(terms, w) : nullptr);
+  fd_body<MAXC, SHAPE>(M, cp, at_problem(P, o), at_problem(q, o), at_problem(slab, w), slab_stride, at_problem(v_out, w),
+                       at_problem(a_out, w), at_problem(nplus_out, w), k_begin + (int)blockIdx.x, mode, stop_after, echunk,
+                       terms ? at_problem(terms, w) : nullptr);
 }
 
 // ---------------------------------------------------------------------------

@@ -65,54 +65,50 @@ IDTO_HD void sincos(double x, double* s_out, double* c_out) {
   const double sn = r + v * (S1 + z * rs);
   const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
   const double cs = 1.0 - (0.5 * z - z * rc);
-  double s, c;
-  if (n == 0) { s = sn; c = cs; }
-  else if (n == 1) { s = cs; c = -sn; }
-  else if (n == 2) { s = -sn; c = -cs; }
-  else { s = -cs; c = sn; }
-  *s_out = s;
-  *c_out = c;
+  // quadrant n: (sn, cs), (cs, -sn), (-sn, -cs), (-cs, sn) - as selects, so that the device code has no branch here
+  // and the sines and cosines of several joints can be evaluated side by side
+  const bool swap = (n & 1) != 0;
+  const double sv = swap ? cs : sn, cv = swap ? sn : cs;
+  *s_out = (n & 2) ? -sv : sv;
+  *c_out = ((n + 1) & 2) ? -cv : cv;
 }
 
 IDTO_HD double exp(double x) {
-  if (x != x) return x;
-  if (x > 709.78) return from_bits(0x7ff0000000000000ull);
-  if (x < -745.2) return 0.0;
+  // (the special cases are selects at the end: no branch in the device code; the polynomial runs on a clamped
+  // argument so that the integer conversions below stay defined)
+  const bool isnan = x != x, over = x > 709.78, under = x < -745.2;
+  const double xc = (isnan || over || under) ? 0.0 : x;
   const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
                invln2 = 1.44269504088896338700e+00;
   const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
                P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
                P5 = 4.13813679705723846039e-08;
-  const double fk = __builtin_rint(x * invln2);
+  const double fk = __builtin_rint(xc * invln2);
   const int k = (int)fk;
-  const double hi = x - fk * ln2HI;
+  const double hi = xc - fk * ln2HI;
   const double lo = fk * ln2LO;
   const double r = hi - lo;
   const double t = r * r;
   const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
   const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
   const int k1 = k / 2, k2 = k - k1;
-  return (y * pow2i(k1)) * pow2i(k2);
+  const double res = (y * pow2i(k1)) * pow2i(k2);
+  return isnan ? x : (over ? from_bits(0x7ff0000000000000ull) : (under ? 0.0 : res));
 }
 
 // Natural logarithm for finite x > 0 (subnormals included).
-IDTO_HD double log(double x) {
+IDTO_HD double log(double x0) {
   const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
   const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
                Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
                Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
                Lg7 = 1.479819860511658591e-01;
-  if (x != x) return x;
-  if (x < 0.0) return from_bits(0x7ff8000000000000ull);
-  if (x == 0.0) return from_bits(0xfff0000000000000ull);
-  uint64_t u = to_bits(x);
-  if (u == 0x7ff0000000000000ull) return x;
-  int k = 0;
-  if ((u >> 52) == 0) {  // subnormal: scale up by 2^54
-    x = x * 18014398509481984.0;
-    u = to_bits(x);
-    k = -54;
-  }
+  const uint64_t u0 = to_bits(x0);
+  const bool isnan = x0 != x0, neg = x0 < 0.0, zero = x0 == 0.0, inf = u0 == 0x7ff0000000000000ull;
+  const bool sub = (u0 >> 52) == 0;               // subnormal: scale up by 2^54
+  const double x = sub ? x0 * 18014398509481984.0 : x0;
+  const uint64_t u = to_bits(x);
+  int k = sub ? -54 : 0;
   uint32_t hx = (uint32_t)(u >> 32);
   const uint32_t lx = (uint32_t)u;
   k += (int)(hx >> 20) - 1023;
@@ -129,7 +125,9 @@ IDTO_HD double log(double x) {
   const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
   const double R = t2 + t1;
   const double hfsq = 0.5 * f * f;
-  return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+  const double res = dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+  // special cases in the order the branches had: NaN, negative, zero, +inf
+  return isnan ? x0 : (neg ? from_bits(0x7ff8000000000000ull) : (zero ? from_bits(0xfff0000000000000ull) : (inf ? x0 : res)));
 }
 
 }  // namespace detmath
