@@ -53,6 +53,14 @@ struct DevModel {
   // kernel can stage the whole model into LDS with one coalesced copy and rebase the pointers
   const double* blob;
   int blob_n;              // size in doubles
+  // fd_kernel's prologue: the floating joints (nfloat < 0: more than four, nplus_pair looks them up), the constant part
+  // of N+ (nv x nq column-major: ones and zeros, NaN where a quaternion block goes; in the blob, read from global memory)
+  // and where the non-zeros of each column / row of N+ are (first | count << 16)
+  int nfloat;
+  int float_qs[4], float_vs[4];
+  const double* nplus_const;
+  const int* colinfo;
+  const int* rowinfo;
   // id_fast.h: the instantiated tree shape this model has (0: none, id_eval<MAXC> serves it) and
   // the gathered records of its bodies and contact pairs (inside the blob)
   int fast_shape;

@@ -31,7 +31,8 @@ namespace idto_dev {
 
 // record of one body (doubles); FB_IDX holds {qstart, vstart} as two ints
 enum { FB_XPF = 0, FB_AXIS = 12, FB_MASS = 15, FB_COM = 16, FB_INERTIA = 19, FB_DAMP = 25, FB_IDX = 31, FB_STRIDE = 34 };
-// record of one contact pair; FP_INFO holds {type A, type B, C is A, the other body is the common one} as four ints.
+// record of one contact pair; FP_INFO holds {type on C, type on the other body, C is the pair's A, the other body is
+// the common one} as four ints.
 // XC, SC: geometry frame and size on C (the chain slot of the pair's group; the common body for a pair without a
 // chain body); XO, SO: on the other body - for the world [I R | 0 + I p], formed on the host
 enum { FP_INFO = 0, FP_XC = 2, FP_SC = 14, FP_XO = 17, FP_SO = 29, FP_STRIDE = 34 };
@@ -70,40 +71,47 @@ IDTO_DEV V3 sel3(bool c, V3 a, V3 b) { return mk(c ? a.x : b.x, c ? a.y : b.y, c
 // with the distance test moved in front of the witness points (three divisions and two 3x3
 // products that an inactive pair never needs).  The pair's bodies are C - the chain slot of the
 // group the pair is listed in (the common body for the groups without a chain body) - and "the other
-// one": the common body (`oc`) or the world, whose geometry pose the host has already formed.  Which
-// of the two is the pair's A is `cia`.  Returns whether the pair is active; (fc, nc) is the wrench on
-// C about its origin, (fo, no) the one on the other body.
+// one", O: the common body (`oc`) or the world, whose geometry pose the host has already formed.
+//
+// Everything is evaluated with C in the role of the pair's body A.  When C is the pair's B
+// (`cia` false) that is the reference's computation with the roles exchanged, and it produces the same
+// bits: the direction-like intermediates (d, n, v_rel, v_t, t, f) come out exactly negated - negation
+// commutes with every rounding, (-a) - (-b) == -(a - b), (-a)(-b) == a b - the even ones (dist, v_n,
+// |v_t|^2, the force magnitudes) and the witness points are unchanged, sums of two points commute, and
+// "the wrench on the second body" is then the reference's wrench on A, i.e. again the one on O.  The single
+// expression that is not symmetric is phi = (dist - r_A) - r_B of two spheres: it takes the radii in the
+// pair's own order.  Returns whether the pair is active; (fc, nc) is the wrench on C about its origin,
+// (fo, no) the one on O.
 template <bool HAS_COMMON>
 IDTO_DEV bool pair_eval(const double* pr, const DevContact& cp, const BodyState& C, const BodyState& cb, V3* fc, V3* nc,
                         V3* fo, V3* no) {
   const V3 zero = mk(0, 0, 0);
   const int2 types = *reinterpret_cast<const int2*>(pr + FP_INFO);
   const int2 flags = *reinterpret_cast<const int2*>(pr + FP_INFO + 1);
-  const int typeA = types.x, typeB = types.y;
+  const int typeC = types.x, typeO = types.y;
   const bool cia = flags.x != 0, oc = HAS_COMMON && flags.y != 0;
   const V3 pgC = C.p + C.R * ldv3(pr + FP_XC + 9);
   V3 pgO = ldv3(pr + FP_XO + 9);   // (the world's: 0 + I p, formed on the host)
   if (HAS_COMMON) pgO = sel3(oc, cb.p + cb.R * pgO, pgO);
-  const V3 pgA = sel3(cia, pgC, pgO), pgB = sel3(cia, pgO, pgC);
   const V3 sC = ldv3(pr + FP_SC), sO = ldv3(pr + FP_SO);
-  const V3 sA = sel3(cia, sC, sO), sB = sel3(cia, sO, sC);
   double phi = 0;
-  V3 n = mk(0, 0, 1), Ca = zero, Cb = zero;
+  V3 n1 = mk(0, 0, 1), Cc = zero, Co = zero;   // unit vector from C's geometry to O's, witness points on C and on O
   bool hit = false;
-  if (typeA == IDTO_GEOM_SPHERE && typeB == IDTO_GEOM_SPHERE) {
-    const V3 d = pgB - pgA;
+  if (typeC == IDTO_GEOM_SPHERE && typeO == IDTO_GEOM_SPHERE) {
+    const V3 d = pgO - pgC;
     const double dist = __builtin_sqrt(dot(d, d));
-    phi = (dist - sA.x) - sB.x;
+    const double rA = cia ? sC.x : sO.x, rB = cia ? sO.x : sC.x;
+    phi = (dist - rA) - rB;
     if (!(phi > cp.threshold)) {
-      n = d / dist;
-      Ca = pgA + n * sA.x;
-      Cb = pgB - n * sB.x;
+      n1 = d / dist;
+      Cc = pgC + n1 * sC.x;
+      Co = pgO - n1 * sO.x;
       hit = true;
     }
-  } else if (typeA != typeB) {  // sphere-box in either order
-    const bool sphere_is_A = (typeA == IDTO_GEOM_SPHERE);
+  } else if (typeC != typeO) {  // sphere-box in either order
+    const bool sphere_is_C = (typeC == IDTO_GEOM_SPHERE);
     M3 RX;                      // the box's rotation in the world
-    if (sphere_is_A == cia) {   // the sphere is on C: the box is on the other body
+    if (sphere_is_C) {          // the box is on the other body
       RX = ldm3(pr + FP_XO);    // (the world's: I R, formed on the host)
       if (HAS_COMMON) {
         const M3 RXc = cb.R * RX;
@@ -113,10 +121,10 @@ IDTO_DEV bool pair_eval(const double* pr, const DevContact& cp, const BodyState&
     } else {
       RX = C.R * ldm3(pr + FP_XC);
     }
-    const V3 pS = sphere_is_A ? pgA : pgB;
-    const double rad = sphere_is_A ? sA.x : sB.x;
-    const V3 pX = sphere_is_A ? pgB : pgA;
-    const V3 h = sphere_is_A ? sB : sA;
+    const V3 pS = sphere_is_C ? pgC : pgO;
+    const double rad = sphere_is_C ? sC.x : sO.x;
+    const V3 pX = sphere_is_C ? pgO : pgC;
+    const V3 h = sphere_is_C ? sO : sC;
     const V3 c = tmul(RX, pS - pX);
     V3 pc = c;
     bool outside = false;
@@ -139,48 +147,46 @@ IDTO_DEV bool pair_eval(const double* pr, const DevContact& cp, const BodyState&
     }
     if (!(phi > cp.threshold)) {
       if (outside) g = dv / dist;
-      const V3 gW = RX * g;
+      const V3 gW = RX * g;             // from the box towards the sphere
       const V3 boxW = pX + RX * pc;
       const V3 sphW = pS - gW * rad;
-      if (sphere_is_A) { n = -gW; Ca = sphW; Cb = boxW; }
-      else { n = gW; Ca = boxW; Cb = sphW; }
+      if (sphere_is_C) { n1 = -gW; Cc = sphW; Co = boxW; }
+      else { n1 = gW; Cc = boxW; Co = sphW; }
       hit = true;
     }
-  } else {  // box A on a moving body vs world-fixed axis-aligned box B: A's lowest vertex against B's top face
-    M3 RgA;
-    if (cia) RgA = C.R * ldm3(pr + FP_XC);
-    else RgA = cb.R * ldm3(pr + FP_XO);   // (A on the other body: the common one - BuildModel refuses a world-fixed A)
-    const double ztop = pgB.z + sB.z;
+  } else {  // box A on a moving body (always C: BuildModel) vs world-fixed axis-aligned box B: A's lowest vertex against B's top face
+    const M3 RgA = C.R * ldm3(pr + FP_XC);
+    const double ztop = pgO.z + sO.z;
     double zmin = 0;
     V3 best = zero;
 #pragma unroll
     for (int iv = 0; iv < 8; ++iv) {
-      const V3 cbx = mk((iv & 4) ? sA.x : -sA.x, (iv & 2) ? sA.y : -sA.y, (iv & 1) ? sA.z : -sA.z);
-      const V3 cw = pgA + RgA * cbx;
+      const V3 cbx = mk((iv & 4) ? sC.x : -sC.x, (iv & 2) ? sC.y : -sC.y, (iv & 1) ? sC.z : -sC.z);
+      const V3 cw = pgC + RgA * cbx;
       if (iv == 0 || cw.z < zmin) { zmin = cw.z; best = cw; }
     }
     phi = zmin - ztop;
     if (!(phi > cp.threshold)) {
-      n = mk(0, 0, -1);
-      Ca = best;
-      Cb = mk(best.x, best.y, ztop);
+      n1 = mk(0, 0, -1);
+      Cc = best;
+      Co = mk(best.x, best.y, ztop);
       hit = true;
     }
   }
   if (!hit) return false;
-  // the two bodies' origins and velocities (the world's are zeros)
-  V3 Op = zero, Ow = zero, Ov = zero;
-  if (HAS_COMMON) { Op = sel3(oc, cb.p, zero); Ow = sel3(oc, cb.w, zero); Ov = sel3(oc, cb.v, zero); }
-  const V3 Ap = sel3(cia, C.p, Op), Aw = sel3(cia, C.w, Ow), Av = sel3(cia, C.v, Ov);
-  const V3 Bp = sel3(cia, Op, C.p), Bw = sel3(cia, Ow, C.w), Bv = sel3(cia, Ov, C.v);
-  const V3 nhat = n;
-  const V3 pC = (Ca + Cb) * 0.5;
-  const V3 pAC = pC - Ap, pBC = pC - Bp;
-  const V3 vAc = Av + cross(Aw, pAC);
-  const V3 vBc = Bv + cross(Bw, pBC);
-  const V3 vrel = vBc - vAc;
-  const double vn = dot(nhat, vrel);
-  const V3 vt = vrel - nhat * vn;
+  const V3 pC = (Cc + Co) * 0.5;
+  const V3 pCC = pC - C.p;
+  // (O the world: pC - 0 == pC and 0 + (0 x p) == +0 for a finite p)
+  V3 pOC = pC, vOc = zero;
+  if (HAS_COMMON) {
+    const V3 pOCc = pC - cb.p;
+    pOC = sel3(oc, pOCc, pC);
+    vOc = sel3(oc, cb.v + cross(cb.w, pOCc), zero);
+  }
+  const V3 vCc = C.v + cross(C.w, pCC);
+  const V3 vrel = vOc - vCc;
+  const double vn = dot(n1, vrel);
+  const V3 vt = vrel - n1 * vn;
   double dissipation = 0.0;
   const double s = vn / cp.vd;
   if (s < 0) dissipation = 1 - s;
@@ -192,12 +198,10 @@ IDTO_DEV bool pair_eval(const double* pr, const DevContact& cp, const BodyState&
   const double fn = compliant_fn * dissipation;
   const V3 that = (-vt) / __builtin_sqrt(cp.vs * cp.vs + dot(vt, vt));
   const V3 ft = (that * cp.mu) * fn;
-  const V3 fB = nhat * fn + ft;
-  const V3 fA = -fB;
-  const V3 nB = cross(pBC, fB);
-  const V3 nA = cross(pAC, fA);
-  *fc = sel3(cia, fA, fB); *nc = sel3(cia, nA, nB);
-  *fo = sel3(cia, fB, fA); *no = sel3(cia, nB, nA);
+  *fo = n1 * fn + ft;
+  *fc = -*fo;
+  *no = cross(pOC, *fo);
+  *nc = cross(pCC, *fc);
   return true;
 }
 
@@ -251,10 +255,44 @@ struct FastTab {
   int maxpp;
 };
 
+// Where an evaluation's q, v, a come from.  InLds: arrays some other phase has built.
+struct InLds {
+  const double *q, *v, *a;
+  IDTO_DEV double Q(int i) const { return q[i]; }
+  IDTO_DEV double V(int j) const { return v[j]; }
+  IDTO_DEV double A(int j) const { return a[j]; }
+};
+// InFwd: evaluation e of the forward-difference set of one record (reference TO.cc:501-540, kernels.h fd_body),
+// formed by the lane that consumes it from q_{k+1}, v_{k+1}, a_k and column `col` of N+_{k+1}, N+_k:
+//   kind 0  the record's own tau:      q1, v1, a0
+//   kind 1  q_{k+1}[col] + dq:         q1 + dq e_col,  v1 + dv n1,  a0 + da n1            (:514-521)
+//   kind 2  q_k[col] + dq:             q1,             v1 - dv n1,  a0 - da (n1 + n0)     (:534-540)
+//   kind 3  mass-matrix column col:    q1,             0,           e_col                  (:556-561)
+// sdv, sda: dv, da with the sign of the kind ((-x) y == -(x y) and a - b == a + (-b) bit for bit).
+struct InFwd {
+  const double *q1, *v1, *a0, *N1, *N0;
+  int nv, kind, col;
+  double dq, sdv, sda;
+  IDTO_DEV double Q(int i) const {
+    const double x = q1[i];
+    return (kind == 1 && i == col) ? x + dq : x;
+  }
+  IDTO_DEV double V(int j) const {
+    const double x = v1[j], n1 = N1[col * nv + j];
+    const double p = x + sdv * n1;
+    return kind == 0 ? x : (kind == 3 ? 0.0 : p);
+  }
+  IDTO_DEV double A(int j) const {
+    const double x = a0[j], n1 = N1[col * nv + j], n0 = N0[col * nv + j];
+    const double p = x + sda * (kind == 1 ? n1 : n1 + n0);
+    return kind == 0 ? x : (kind == 3 ? (j == col ? 1.0 : 0.0) : p);
+  }
+};
+
 // tau = ID(q, v, a) for the lane's path: id_eval<MAXC> for a model of shape (CJ, J0, K0).
-template <int MAXC, int NP, int CJ, int J0, int K0>
+template <int MAXC, int NP, int CJ, int J0, int K0, class In>
 IDTO_DEV void id_eval_fast(const FastTab& T, const double* gravity, const DevContact& cp, int path, bool full,
-                           const double* q, const double* v, const double* a, double* tau) {
+                           const In& in, double* tau) {
   constexpr bool HAS_COMMON = (CJ == IDTO_JOINT_FLOATING);
   const V3 zero = mk(0, 0, 0);
   const V3 g = full ? mk(gravity[0], gravity[1], gravity[2]) : zero;
@@ -280,19 +318,19 @@ IDTO_DEV void id_eval_fast(const FastTab& T, const double* gravity, const DevCon
 #pragma unroll
   for (int s = 0; s < MAXC; ++s) {
     if (s == 0 && J0 == IDTO_JOINT_PLANAR) {
-      q0x = q[qs[0]]; q0y = q[qs[0] + 1]; qj[0] = q[qs[0] + 2];
-      v0x = v[vs[0]]; v0y = v[vs[0] + 1]; vj[0] = v[vs[0] + 2];
-      a0x = a[vs[0]]; a0y = a[vs[0] + 1]; aj[0] = a[vs[0] + 2];
+      q0x = in.Q(qs[0]); q0y = in.Q(qs[0] + 1); qj[0] = in.Q(qs[0] + 2);
+      v0x = in.V(vs[0]); v0y = in.V(vs[0] + 1); vj[0] = in.V(vs[0] + 2);
+      a0x = in.A(vs[0]); a0y = in.A(vs[0] + 1); aj[0] = in.A(vs[0] + 2);
     } else {
-      qj[s] = q[qs[s]]; vj[s] = v[vs[s]]; aj[s] = a[vs[s]];
+      qj[s] = in.Q(qs[s]); vj[s] = in.V(vs[s]); aj[s] = in.A(vs[s]);
     }
   }
   double cq[7], cv[6], ca[6];
   if (HAS_COMMON) {
 #pragma unroll
-    for (int i = 0; i < 7; ++i) cq[i] = q[cqs + i];
+    for (int i = 0; i < 7; ++i) cq[i] = in.Q(cqs + i);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { cv[i] = v[cvs + i]; ca[i] = a[cvs + i]; }
+    for (int i = 0; i < 6; ++i) { cv[i] = in.V(cvs + i); ca[i] = in.A(cvs + i); }
   }
   double sn[MAXC], cs[MAXC];
 #pragma unroll

@@ -18,6 +18,7 @@
 
 #include "idto_hip.h"
 #include "kernels.h"
+#include "fd_launch.h"
 #include "penta_ldl.h"
 #include "fused.h"
 #include "penta_nd.h"
@@ -331,6 +332,33 @@ int BuildModel(idto_hip_ctx* c, const idto_model_t* m) {
                o_com = addd(m->com, (size_t)3 * nb), o_in = addd(m->inertia, (size_t)6 * nb),
                o_damp = addd(m->damping, m->nv), o_gX = addd(m->geom_X, (size_t)12 * m->ngeoms),
                o_gs = addd(m->geom_size, (size_t)3 * m->ngeoms);
+  // N+ (TO.cc:1633-1647): its constant entries, and the non-zero range of every column and row
+  const int nqm = m->nq, nvm = m->nv;
+  std::vector<double> npc((size_t)nvm * nqm, 0.0);
+  std::vector<int> colinfo(nqm, 0), rowinfo(nvm, 0);
+  int nfloat = 0, float_qs[4] = {0, 0, 0, 0}, float_vs[4] = {0, 0, 0, 0};
+  for (int b = 0; b < nb; ++b) {
+    const int qs = m->qstart[b], vs = m->vstart[b], jt = m->jtype[b];
+    if (jt == IDTO_JOINT_REVOLUTE || jt == IDTO_JOINT_PRISMATIC) {
+      npc[(size_t)qs * nvm + vs] = 1.0; colinfo[qs] = vs | 1 << 16; rowinfo[vs] = qs | 1 << 16;
+    } else if (jt == IDTO_JOINT_PLANAR) {
+      for (int kq = 0; kq < 3; ++kq) {
+        npc[(size_t)(qs + kq) * nvm + vs + kq] = 1.0; colinfo[qs + kq] = (vs + kq) | 1 << 16; rowinfo[vs + kq] = (qs + kq) | 1 << 16;
+      }
+    } else {
+      for (int r = 0; r < 3; ++r)
+        for (int cq = 0; cq < 4; ++cq) npc[(size_t)(qs + cq) * nvm + vs + r] = std::numeric_limits<double>::quiet_NaN();
+      for (int kq = 0; kq < 4; ++kq) colinfo[qs + kq] = vs | 3 << 16;
+      for (int r = 0; r < 3; ++r) rowinfo[vs + r] = qs | 4 << 16;
+      for (int kq = 0; kq < 3; ++kq) {
+        npc[(size_t)(qs + 4 + kq) * nvm + vs + 3 + kq] = 1.0;
+        colinfo[qs + 4 + kq] = (vs + 3 + kq) | 1 << 16; rowinfo[vs + 3 + kq] = (qs + 4 + kq) | 1 << 16;
+      }
+      if (nfloat >= 0 && nfloat < 4) { float_qs[nfloat] = qs; float_vs[nfloat] = vs; ++nfloat; }
+      else nfloat = -1;
+    }
+  }
+  const size_t o_npc = addd(npc.data(), npc.size());
   // ---- id_fast.h: does the model have one of the instantiated tree shapes?  If so, gather one record of
   // constants per (path, slot) and per contact pair in the order id_eval_fast walks them.
   int fast_shape = 0, f_maxpp = 1;
@@ -435,7 +463,7 @@ int BuildModel(idto_hip_ctx* c, const idto_model_t* m) {
           const bool a_chain = sa[pi] >= 0, b_chain = sb[pi] >= 0;
           const bool cia = a_chain || (!b_chain && sa[pi] == -1);
           const int gc = cia ? ga : gb, go = cia ? gb : ga, so = cia ? sb[pi] : sa[pi];
-          const int info[4] = {m->geom_type[ga], m->geom_type[gb], cia ? 1 : 0, so == -1 ? 1 : 0};
+          const int info[4] = {m->geom_type[gc], m->geom_type[go], cia ? 1 : 0, so == -1 ? 1 : 0};
           std::memcpy(rec + FP_INFO, info, sizeof(info));
           std::memcpy(rec + FP_XC, m->geom_X + (size_t)12 * gc, 12 * sizeof(double));
           std::memcpy(rec + FP_SC, m->geom_size + (size_t)3 * gc, 3 * sizeof(double));
@@ -456,6 +484,7 @@ int BuildModel(idto_hip_ctx* c, const idto_model_t* m) {
     fast_lo = fast_shape ? o_fbody : 0;
   }
   const size_t i_jt = addi(m->jtype, nb), i_qs = addi(m->qstart, nb), i_vs = addi(m->vstart, nb);
+  const size_t i_colinfo = addi(colinfo.data(), colinfo.size()), i_rowinfo = addi(rowinfo.data(), rowinfo.size());
   const size_t i_fseg = addi(fseg.data(), fseg.size());
   const size_t i_fast_end = ints.size();
   const size_t i_par = addi(m->parent, nb), i_gt = addi(m->geom_type, m->ngeoms), i_ch = addi(chain.data(), chain.size()),
@@ -476,6 +505,9 @@ int BuildModel(idto_hip_ctx* c, const idto_model_t* m) {
   M.parent = bi + i_par; M.jtype = bi + i_jt; M.qstart = bi + i_qs; M.vstart = bi + i_vs; M.geom_type = bi + i_gt;
   M.chain = bi + i_ch; M.nchain = bi + i_nch; M.pkind = bi + i_pk; M.path_npairs = bi + i_pnp; M.path_pairs = bi + i_pp;
   M.pair_ga = bi + i_ga; M.pair_gb = bi + i_gb; M.pair_sa = bi + i_sa; M.pair_sb = bi + i_sb;
+  M.nfloat = nfloat;
+  for (int i = 0; i < 4; ++i) { M.float_qs[i] = float_qs[i]; M.float_vs[i] = float_vs[i]; }
+  M.nplus_const = bd + o_npc; M.colinfo = bi + i_colinfo; M.rowinfo = bi + i_rowinfo;
   M.fast_shape = fast_shape; M.f_maxpp = f_maxpp;
   M.fast_lo = (int)fast_lo; M.fast_n = (int)(nd + (i_fast_end + 1) / 2 - fast_lo);
   M.f_body = bd + o_fbody; M.f_cbody = bd + o_fcbody; M.f_pairs = bd + o_fpairs; M.f_seg = bi + i_fseg;
@@ -514,23 +546,14 @@ int LaunchFd(idto_hip_ctx* c, int mode, int kb, int ke, AltSel alt = AltSel{null
   if (lds > 160 * 1024) { g_err = "finite-difference evaluation set does not fit in LDS"; return -1; }
   double* terms = fold ? c->terms : nullptr;
   if (mode >= 1) c->terms_valid = fold && kb == 0 && ke == c->N;
-#define FD_LAUNCH(MC)                                                                                         \
-  hipLaunchKernelGGL(fd_kernel<MC>, grid, block, lds, c->stream, c->M, c->cp, c->P, c->q, c->slab,             \
-                     c->slab_stride, c->v, c->a, c->nplus, kb, mode, c->fd_stop, ec, c->pstride, terms, alt)
-#define FD_LAUNCH_FAST(MC, SH)                                                                                 \
-  hipLaunchKernelGGL((fd_kernel<MC, SH>), grid, block, lds, c->stream, c->M, c->cp, c->P, c->q, c->slab,        \
-                     c->slab_stride, c->v, c->a, c->nplus, kb, mode, c->fd_stop, ec, c->pstride, terms, alt)
-  const int shape = c->fd_fast ? c->M.fast_shape : 0;   // id_fast.h: the straight-line evaluation of the model's tree shape
-  if (shape == 1) FD_LAUNCH_FAST(2, 1);
-  else if (shape == 2) FD_LAUNCH_FAST(3, 2);
-  else if (shape == 3) FD_LAUNCH_FAST(3, 3);
-  else if (shape == 4) FD_LAUNCH_FAST(4, 4);
-  else if (c->maxc <= 2) FD_LAUNCH(2);
-  else if (c->maxc <= 3) FD_LAUNCH(3);
-  else if (c->maxc <= 4) FD_LAUNCH(4);
-  else FD_LAUNCH(8);
-#undef FD_LAUNCH
-#undef FD_LAUNCH_FAST
+  FdLaunch fl;
+  fl.grid = grid; fl.block = block; fl.lds = lds; fl.stream = c->stream; fl.M = c->M; fl.cp = c->cp; fl.P = c->P;
+  fl.q = c->q; fl.slab = c->slab; fl.slab_stride = c->slab_stride; fl.v = c->v; fl.a = c->a; fl.nplus = c->nplus;
+  fl.k_begin = kb; fl.mode = mode; fl.stop_after = c->fd_stop; fl.echunk = ec; fl.pstride = c->pstride; fl.terms = terms;
+  fl.alt = alt;
+  fl.shape = c->fd_fast ? c->M.fast_shape : 0;   // id_fast.h: the straight-line evaluation of the model's tree shape
+  fl.maxc = c->maxc;
+  fd_launch(fl);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -807,14 +830,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
     return -1;
   }
   // kernels that need more than the default 64 KiB of dynamic LDS must opt in
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fd_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fd_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fd_kernel<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fd_kernel<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fd_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  fd_set_max_lds(max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);

@@ -16,7 +16,7 @@ from .model import CContactParams, CModel, CProblem, Model, dptr
 from .problem import ProblemDefinition, SolverParameters
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libidto_hip.so")
+LIB_PATH = os.environ.get("IDTO_HIP_LIB") or os.path.join(_HERE, "libidto_hip.so")   # (IDTO_HIP_LIB: a variant build, tools/fd_variants.sh)
 
 ARR = dict(q=0, v=1, a=2, tau=3, nplus=4, dtau_dqm=5, dtau_dqt=6, dtau_dqp=7, gradient=8, H_A=9, H_B=10, H_C=11,
            step=12, cost=13, slab=14, debug=15, hbands=16, tr_dq=17, tr_w=18, tr_scale=19, asm_terms=20, con_S=21, con_lambda=22)

@@ -1,4 +1,4 @@
-"""fd_kernel by truncation (option fd_stop): HIP-event time after 1 N+/v/a, 2 the evaluation inputs, 3 the inverse
+"""fd_kernel by truncation (option fd_stop): HIP-event time of 10 the launch alone, after 8 the loads, 9 N+, 1 v/a, 2 the evaluation inputs, 3 the inverse
 dynamics, 4 the record, 5 (barrier), 6 the lower-triangle products, 7 all products, 0 complete."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,7 @@ for name, N in (("mini_cheetah", 40), ("allegro_hand", 60), ("hopper", 50)):
     for fast in ((0, 1) if "--both" in sys.argv else (1,)):
         dev.set_option("fd_fast", fast)
         out = []
-        for stop in (1, 2, 3, 4, 6, 7, 0):
+        for stop in (10, 8, 9, 1, 2, 3, 4, 6, 7, 0):
             dev.set_option("fd_stop", stop)
             for _ in range(20): dev.eval_partials()
             dev.sync(); dev.timing_enable(True); dev.timing_reset()
