@@ -270,6 +270,11 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
   extern __shared__ double lds[];
   const int tid = threadIdx.x, nt = blockDim.x;
   if (stop_after == 10) return;   // (profiling aid: the launch alone)
+#ifdef IDTO_FD_STAMPS
+  long long st_arr[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long* idto_fd_st = (tid == 0 || tid == IDTO_FD_STAMP_TID) ? st_arr : nullptr;
+#endif
+  FD_STAMP(0);
   const int nq = M.nq, nv = M.nv, K = M.npaths;
   const int bsz = nv * nq;
   const double dt = P.dt;
@@ -315,63 +320,102 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
   double* rec = reinterpret_cast<double*>(colinfo + nq + (nq & 1));   // [P | T | M | P R' | T R' | M R'] then diag R'
   rec += (rec - lds) & 1;
 
-  // stage the model into LDS and use that copy from here on
-  double* wr = rec + 6 * psz;      // [nv] diagonal of R' (fetched now: an HBM round trip off the tail's critical path)
-  if (terms && mode != 0)
-    for (int l = tid; l < nv; l += nt) wr[l] = P.R[l * nv + l];
-  for (int i = tid; i < blob_n; i += nt) mblob[i] = M.blob[blob_lo + i];
-  for (int i = tid; i < nq; i += nt) {
-    qm1[i] = (k > 0) ? q[(k - 1) * nq + i] : 0.0;
-    q0[i] = q[k * nq + i];
-    q1[i] = q[(k + 1) * nq + i];
-  }
   // N+_k and N+_{k+1} (TO.cc:1633-1647).  The model's table holds the constant entries (NaN where a quaternion block
   // goes); the 3 x 4 block of a floating joint is formed here, entry by entry, by twelve lanes of wavefront 0 (q_k) and of
   // wavefront 1 (q_{k+1}) straight from the global q - the expressions of nplus_pair, hence the same bits - so that N+
   // is complete behind the ONE barrier that also covers the loads.  (More than four floating joints: nplus_pair.)
-  const bool sparse = M.nfloat >= 0;
-  int rowinfo_r = 0;
+  // Their quaternions are the first loads the kernel issues: the longest chain of the prologue hangs on them.
+  const bool sparse = M.nfloat == 0 || (M.nfloat > 0 && nt >= 128);
+  const int ql = tid & 63, qcfg = tid >> 6;   // wavefront 0: q_k, wavefront 1: q_{k+1}
+  const bool quat_lane = sparse && M.nfloat > 0 && qcfg < 2 && ql >= 48 && ql < 60;
+  double qf0[4];   // the quaternion of the first floating joint (read by every thread: no merge under an exec mask, no wait here)
+  {
+    const double* qq = q + (size_t)(k + (qcfg & 1)) * nq + (M.nfloat > 0 ? M.float_qs[0] : 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qf0[i] = qq[i];
+  }
+  // stage the model into LDS and use that copy from here on.  Every global read of the prologue is issued before the
+  // first of them is used: a loop `lds[i] = global[i]` waits for each of its loads in turn, and after a kernel
+  // boundary none of them is an L2 hit - ten such round trips in a row were 7k of the kernel's 48k cycles.
+  double* wr = rec + 6 * psz;      // [nv] diagonal of R' (fetched now: an HBM round trip off the tail's critical path)
+  constexpr int BU = 8;            // model words per thread in the batched part (the rest, if any, in a loop)
+  double breg[BU];
+#pragma unroll
+  for (int u = 0; u < BU; ++u) {
+    const int i = tid + u * nt;
+    breg[u] = (i < blob_n) ? M.blob[blob_lo + i] : 0.0;
+  }
+  const bool qrow = tid < nq;
+  const double g_qm1 = (qrow && k > 0) ? q[(k - 1) * nq + tid] : 0.0;
+  const double g_q0 = qrow ? q[k * nq + tid] : 0.0, g_q1 = qrow ? q[(k + 1) * nq + tid] : 0.0;
+  const double g_wr = (terms && mode != 0 && tid < nv) ? P.R[tid * nv + tid] : 0.0;
+  const double g_nc0 = (sparse && tid < bsz) ? M.nplus_const[tid] : 0.0;
+  const double g_nc1 = (sparse && tid + nt < bsz) ? M.nplus_const[tid + nt] : 0.0;
+  const int g_ci = (sparse && qrow) ? M.colinfo[tid] : 0;
+  const int rowinfo_r = (sparse && tid < nv) ? M.rowinfo[tid] : 0;
+  // (the quaternion pinned here: its loads are above this line - the compiler otherwise sinks them to their use, behind
+  // the staging stores - and, issued among the first, they are back before the others)
+  asm volatile("" : "+v"(qf0[0]), "+v"(qf0[1]), "+v"(qf0[2]), "+v"(qf0[3]));
+#pragma unroll
+  for (int u = 0; u < BU; ++u) {
+    const int i = tid + u * nt;
+    if (i < blob_n) mblob[i] = breg[u];
+  }
+  for (int i = tid + BU * nt; i < blob_n; i += nt) mblob[i] = M.blob[blob_lo + i];
+  if (qrow) { qm1[tid] = g_qm1; q0[tid] = g_q0; q1[tid] = g_q1; }
+  for (int i = tid + nt; i < nq; i += nt) {
+    qm1[i] = (k > 0) ? q[(k - 1) * nq + i] : 0.0;
+    q0[i] = q[k * nq + i];
+    q1[i] = q[(k + 1) * nq + i];
+  }
+  if (terms && mode != 0) {
+    if (tid < nv) wr[tid] = g_wr;
+    for (int l = tid + nt; l < nv; l += nt) wr[l] = P.R[l * nv + l];
+  }
   if (sparse) {
-    for (int i = tid; i < bsz; i += nt) {
+    if (tid < bsz && g_nc0 == g_nc0) { N0[tid] = g_nc0; N1[tid] = g_nc0; }
+    if (tid + nt < bsz && g_nc1 == g_nc1) { N0[tid + nt] = g_nc1; N1[tid + nt] = g_nc1; }
+    for (int i = tid + 2 * nt; i < bsz; i += nt) {
       const double cst = M.nplus_const[i];
       if (cst == cst) { N0[i] = cst; N1[i] = cst; }
     }
-    for (int i = tid; i < nq; i += nt) colinfo[i] = M.colinfo[i];
-    if (tid < nv) rowinfo_r = M.rowinfo[tid];
-    const int l = tid & 63, grp = tid >> 6, ngrp = (nt >= 128) ? 2 : 1;
-    if (grp < 2 && l >= 48 && l < 60) {
-      const int e = l - 48, r = e >> 2, c = e & 3;
-      for (int cfg = grp; cfg < 2; cfg += ngrp) {
-        double* Nout = cfg ? N1 : N0;
-        for (int f = 0; f < M.nfloat; ++f) {
-          const int qs = M.float_qs[f], vs = M.float_vs[f];
-          const double* qq = q + (size_t)(k + cfg) * nq + qs;
-          const double nrm = __builtin_sqrt(((qq[0] * qq[0] + qq[1] * qq[1]) + qq[2] * qq[2]) + qq[3] * qq[3]);
-          const double t0 = qq[0] / nrm, t1 = qq[1] / nrm, t2 = qq[2] / nrm, t3 = qq[3] / nrm;
-          const double w2 = 2.0 * t0, x2 = 2.0 * t1, y2 = 2.0 * t2, z2 = 2.0 * t3;
-          // row r of LT = L(2 q~)^T
-          const double l0 = (r == 0) ? -x2 : ((r == 1) ? -y2 : -z2);
-          const double l1 = (r == 0) ? w2 : ((r == 1) ? z2 : -y2);
-          const double l2 = (r == 0) ? -z2 : ((r == 1) ? w2 : x2);
-          const double l3 = (r == 0) ? y2 : ((r == 1) ? -x2 : w2);
-          // column c of D = (I - q~ q~^T) / |q|
-          const double tc = (c == 0) ? t0 : ((c == 1) ? t1 : ((c == 2) ? t2 : t3));
-          const double d0 = ((c == 0 ? 1.0 : 0.0) - t0 * tc) / nrm;
-          const double d1 = ((c == 1 ? 1.0 : 0.0) - t1 * tc) / nrm;
-          const double d2 = ((c == 2 ? 1.0 : 0.0) - t2 * tc) / nrm;
-          const double d3 = ((c == 3 ? 1.0 : 0.0) - t3 * tc) / nrm;
-          double acc = l0 * d0;
-          acc += l1 * d1;
-          acc += l2 * d2;
-          acc += l3 * d3;
-          Nout[(qs + c) * nv + vs + r] = acc;
-        }
+    if (qrow) colinfo[tid] = g_ci;
+    for (int i = tid + nt; i < nq; i += nt) colinfo[i] = M.colinfo[i];
+    if (quat_lane) {
+      const int e = ql - 48, r = e >> 2, c = e & 3;
+      double* Nout = qcfg ? N1 : N0;
+      for (int f = 0; f < M.nfloat; ++f) {
+        const int qs = M.float_qs[f], vs = M.float_vs[f];
+        double qq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qq[i] = (f == 0) ? qf0[i] : q[(size_t)(k + qcfg) * nq + qs + i];
+        const double nrm = __builtin_sqrt(((qq[0] * qq[0] + qq[1] * qq[1]) + qq[2] * qq[2]) + qq[3] * qq[3]);
+        const double t0 = qq[0] / nrm, t1 = qq[1] / nrm, t2 = qq[2] / nrm, t3 = qq[3] / nrm;
+        const double w2 = 2.0 * t0, x2 = 2.0 * t1, y2 = 2.0 * t2, z2 = 2.0 * t3;
+        // row r of LT = L(2 q~)^T
+        const double l0 = (r == 0) ? -x2 : ((r == 1) ? -y2 : -z2);
+        const double l1 = (r == 0) ? w2 : ((r == 1) ? z2 : -y2);
+        const double l2 = (r == 0) ? -z2 : ((r == 1) ? w2 : x2);
+        const double l3 = (r == 0) ? y2 : ((r == 1) ? -x2 : w2);
+        // column c of D = (I - q~ q~^T) / |q|
+        const double tc = (c == 0) ? t0 : ((c == 1) ? t1 : ((c == 2) ? t2 : t3));
+        const double d0 = ((c == 0 ? 1.0 : 0.0) - t0 * tc) / nrm;
+        const double d1 = ((c == 1 ? 1.0 : 0.0) - t1 * tc) / nrm;
+        const double d2 = ((c == 2 ? 1.0 : 0.0) - t2 * tc) / nrm;
+        const double d3 = ((c == 3 ? 1.0 : 0.0) - t3 * tc) / nrm;
+        double acc = l0 * d0;
+        acc += l1 * d1;
+        acc += l2 * d2;
+        acc += l3 * d3;
+        Nout[(qs + c) * nv + vs + r] = acc;
       }
     }
   } else {
     for (int i = tid; i < bsz; i += nt) { N0[i] = 0.0; N1[i] = 0.0; }   // (nplus_pair fills the non-zeros behind this barrier)
   }
+  FD_STAMP(1);
   __syncthreads();
+  FD_STAMP(2);
   if (stop_after == 8) return;    // ... after the loads
   const DevModel Ml = rebase_model(M, mblob - blob_lo);
   if (!sparse) {
@@ -415,7 +459,8 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
   }
   // the perturbation of every evaluation (TO.cc:501-521; needs q only: formed here, a barrier earlier)
   const double eps = 1.4901161193847656e-08;  // sqrt(DBL_EPSILON) = 2^-26
-  for (int e = tid; e < E; e += nt) {
+  // (by the threads from the second wavefront on: the first ones have the rows of v and a, two divisions deep as well)
+  for (int e = (nt > 64) ? (tid + nt - 64) % nt : tid; e < E; e += nt) {
     double dq = 1.0;
     if (e >= 1 && (e < 1 + nP + nT || central)) {
       const int i = (e - 1) % nq;
@@ -431,17 +476,24 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
   }
   __syncthreads();
 
-  // trajectory outputs
-  for (int r = tid; r < nv; r += nt) {
-    v_out[(k + 1) * nv + r] = v1[r];
-    a_out[k * nv + r] = a0[r];
-    if (k == 0) v_out[r] = v0[r];
-  }
-  for (int i = tid; i < bsz; i += nt) {
-    nplus_out[(size_t)(k + 1) * bsz + i] = N1[i];
-    if (k == 0) nplus_out[i] = N0[i];
-  }
+  // trajectory outputs, by the threads t0, t0 + ts, ...
+  auto trajectory_outputs = [&](int t0, int ts) {
+    for (int r = t0; r < nv; r += ts) {
+      v_out[(k + 1) * nv + r] = v1[r];
+      a_out[k * nv + r] = a0[r];
+      if (k == 0) v_out[r] = v0[r];
+    }
+    for (int i = t0; i < bsz; i += ts) {
+      nplus_out[(size_t)(k + 1) * bsz + i] = N1[i];
+      if (k == 0) nplus_out[i] = N0[i];
+    }
+  };
+  // (a fast shape with forward differences: the last wavefront writes them after its evaluations - the cheap
+  // mass-matrix columns - while the others are still in their contact pairs)
+  const bool late_outputs = (SHAPE != 0) && !central && stop_after != 1;
+  if (!late_outputs) trajectory_outputs(tid, nt);
 
+  FD_STAMP(3);
   if (stop_after == 1) return;  // (profiling aid: phase timing by truncation) after N+, v, a
   // ---- evaluation inputs (TO.cc:501-521): the perturbations were formed with N+ / v above
   // (a fast shape with forward differences: every lane forms the inputs of its own evaluation, id_fast.h InFwd)
@@ -526,16 +578,25 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
           in.kind = (el == 0) ? 0 : ((el < 1 + nP) ? 1 : ((el < 1 + nP + nT) ? 2 : 3));
           in.col = (el == 0) ? 0 : ((el < 1 + nP) ? el - 1 : ((el < 1 + nP + nT) ? el - 1 - nP : el - 1 - nP - nT));
           in.dq = edq[el];
-          in.sdv = (in.kind == 2) ? -edv[el] : edv[el];
-          in.sda = (in.kind == 2) ? -eda[el] : eda[el];
-          id_eval_fast<FS::MAXC, FS::NP, FS::CJ, FS::J0, FS::K0>(FT, Ml.gravity, cp, path, full, in, etau + el * nv);
+          in.sdv = (in.kind == 2) ? -edv[el] : ((in.kind == 1) ? edv[el] : 0.0);
+          in.sda = (in.kind == 2) ? -eda[el] : ((in.kind == 1) ? eda[el] : 0.0);
+          in.keep = (in.kind == 3) ? 0ull : ~0ull;
+          in.keep0 = (in.kind == 2) ? ~0ull : 0ull;
+          id_eval_fast<FS::MAXC, FS::NP, FS::CJ, FS::J0, FS::K0>(FT, Ml.gravity, cp, path, full, in, etau + el * nv
+#ifdef IDTO_FD_STAMPS
+                                                                 , (e0 == 0) ? idto_fd_st : nullptr
+#endif
+          );
         } else {
+#ifndef IDTO_FD_TEST_NO_INLDS
           InLds in;
           in.q = eq + el * nq; in.v = ev + el * nv; in.a = ea + el * nv;
           id_eval_fast<FS::MAXC, FS::NP, FS::CJ, FS::J0, FS::K0>(FT, Ml.gravity, cp, path, full, in, etau + (c0 + el) * nv);
+#endif
         }
       }
     }
+    if (late_outputs && tid >= nt - 64) trajectory_outputs(tid - (nt - 64), 64);
   } else {
   for (int e0 = 0; e0 < ce; e0 += groups) {
     const int el = e0 + tid / K;
@@ -549,6 +610,7 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
   __syncthreads();
   }
 
+  FD_STAMP(12);
   if (stop_after == 3) return;  // after the inverse-dynamics evaluations
   // ---- outputs
   double* sl = slab + (size_t)k * slab_stride;
@@ -558,45 +620,56 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
   double* tauk = sl + 3 * bsz;
   for (int r = tid; r < nv; r += nt) tauk[r] = etau[r];
   if (mode == 1) {
-    for (int idx = tid; idx < bsz; idx += nt) {
-      const int i = idx / nv, r = idx - i * nv;
-      const double pv = (etau[(1 + i) * nv + r] - etau[r]) / edq[1 + i];                      // TO.cc:531
-      const double tv = (k >= 1) ? (etau[(1 + nP + i) * nv + r] - etau[r]) / edq[1 + nP + i]  // TO.cc:539
-                                 : 0.0;
-      Pk[idx] = pv;
-      Tk[idx] = tv;
-      if (terms) {   // ... and (A^T W)(r, l) = A(l, r) w_l, as assemble_diag_kernel forms it, by the thread that holds A(l, r)
-        rec[i * nvp + r] = pv; rec[psz + i * nvp + r] = tv;
-        rec[3 * psz + i * nvp + r] = pv * wr[r]; rec[4 * psz + i * nvp + r] = tv * wr[r];
-        if (r == nv - 1 && nvp > nv) { rec[3 * psz + i * nvp + nv] = 0.0; rec[4 * psz + i * nvp + nv] = 0.0; }
-      }
-    }
-    // dtau_k/dq_{k-1} = (1/dt^2) M(q_{k+1}) N+_k   (TO.cc:556-561)
-    if (k >= 2) {
-      const double sc = 1 / dt / dt;
-      const double* Mcols = etau + (1 + nP + nT) * nv;  // column j = tau of mass evaluation j
-      // sum over j in the reference's order; the terms outside [j0, j0 + cnt) are exact zeros
-      for (int idx = tid; idx < bsz; idx += nt) {
-        const int c = idx / nv, r = idx - c * nv;
-        const int j0 = colinfo[c] & 0xffff, cnt = colinfo[c] >> 16;
-        double acc = (sc * Mcols[j0 * nv + r]) * N0[c * nv + j0];
-        for (int j = j0 + 1; j < j0 + cnt; ++j) acc += (sc * Mcols[j * nv + r]) * N0[c * nv + j];
-        Mk[idx] = acc;
-        if (terms) {
-          rec[2 * psz + c * nvp + r] = acc;
-          rec[5 * psz + c * nvp + r] = acc * wr[r];
-          if (r == nv - 1 && nvp > nv) rec[5 * psz + c * nvp + nv] = 0.0;
+    // Two entries of each of the three blocks per thread and pass, every LDS read of the pass before the first division:
+    // one wavefront per SIMD has nothing else to cover the reads' and the divisions' latencies with.
+    //   dtau_k/dq_{k+1} (TO.cc:531), dtau_k/dq_k (:539), dtau_k/dq_{k-1} = (1/dt^2) M(q_{k+1}) N+_k (:556-561): the sum over j
+    //   in the reference's order; the terms outside [j0, j0 + cnt) are exact zeros
+    const double sc = 1 / dt / dt;
+    const double* Mcols = etau + (1 + nP + nT) * nv;  // column j = tau of mass evaluation j
+    const double fillM = (k == 0) ? __builtin_nan("") : 0.0;
+    constexpr int RU = 2;
+    for (int base = tid; base < bsz; base += RU * nt) {
+      int ii[RU], rr[RU], j0[RU], cnt[RU];
+      bool ok[RU];
+      double tp[RU], tt[RU], t0[RU], dqp[RU], dqt[RU], w[RU], mc[RU][3], n0[RU][3];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const int idx = base + u * nt;
+        ok[u] = idx < bsz;
+        const int id = ok[u] ? idx : 0;
+        ii[u] = id / nv; rr[u] = id - ii[u] * nv;
+        const int ci = colinfo[ii[u]];
+        j0[u] = ci & 0xffff; cnt[u] = ci >> 16;
+        tp[u] = etau[(1 + ii[u]) * nv + rr[u]]; tt[u] = etau[(1 + nP + ii[u]) * nv + rr[u]]; t0[u] = etau[rr[u]];
+        dqp[u] = edq[1 + ii[u]]; dqt[u] = edq[1 + nP + ii[u]];
+        w[u] = terms ? wr[rr[u]] : 0.0;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int j = (t < cnt[u]) ? j0[u] + t : j0[u];
+          mc[u][t] = Mcols[j * nv + rr[u]];
+          n0[u][t] = N0[ii[u] * nv + j];
         }
       }
-    } else {
-      const double fill = (k == 0) ? __builtin_nan("") : 0.0;
-      for (int idx = tid; idx < bsz; idx += nt) {
-        Mk[idx] = fill;
-        if (terms) {   // (never used by the assembly for k < 2)
-          const int c = idx / nv, r = idx % nv;
-          rec[2 * psz + c * nvp + r] = 0.0;
-          rec[5 * psz + c * nvp + r] = 0.0 * wr[r];
-          if (r == nv - 1 && nvp > nv) rec[5 * psz + c * nvp + nv] = 0.0;
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        if (!ok[u]) continue;
+        const int idx = base + u * nt, i = ii[u], r = rr[u];
+        const double pv = (tp[u] - t0[u]) / dqp[u];
+        const double tv = (k >= 1) ? (tt[u] - t0[u]) / dqt[u] : 0.0;
+        double acc = (sc * mc[u][0]) * n0[u][0];
+        if (cnt[u] > 1) acc += (sc * mc[u][1]) * n0[u][1];
+        if (cnt[u] > 2) acc += (sc * mc[u][2]) * n0[u][2];
+        const double mv = (k >= 2) ? acc : fillM;
+        Pk[idx] = pv;
+        Tk[idx] = tv;
+        Mk[idx] = mv;
+        if (terms) {   // ... and (A^T W)(r, l) = A(l, r) w_l, as assemble_diag_kernel forms it, by the thread that holds A(l, r)
+          const double mr = (k >= 2) ? acc : 0.0;   // (never used by the assembly for k < 2)
+          rec[i * nvp + r] = pv; rec[psz + i * nvp + r] = tv; rec[2 * psz + i * nvp + r] = mr;
+          rec[3 * psz + i * nvp + r] = pv * w[u]; rec[4 * psz + i * nvp + r] = tv * w[u]; rec[5 * psz + i * nvp + r] = mr * w[u];
+          if (r == nv - 1 && nvp > nv) {
+            rec[3 * psz + i * nvp + nv] = 0.0; rec[4 * psz + i * nvp + nv] = 0.0; rec[5 * psz + i * nvp + nv] = 0.0;
+          }
         }
       }
     }
@@ -628,10 +701,13 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
   }
   if (!terms || mode == 0 || stop_after == 4) return;
   // ---- the assembly products of this record (see asm_terms_stride); the weighted copy was formed with the record
+  FD_STAMP(13);
   __syncthreads();
   if (stop_after == 5) return;
   const int qq = nq * nq, ts = asm_terms_stride(nq);
-  double* stage = wr + nvp;   // [ts] the products in their HBM order (written out coalesced below)
+  // (each product goes straight to its place in HBM: stores do not stall the lane, and a staging pass through LDS
+  // behind one more barrier was 2.9k of the kernel's 48k cycles)
+  double* stage = terms + (size_t)k * ts;
   // 3 x 3 register tiles: the lower-triangle tiles of CP, CT, CM, then all tiles of
   // BPT = (P R')^T T, BTM = (T R')^T M, APM = (P R')^T M  (one round of 231 tiles at nq = 19)
   constexpr int TB = 3;
@@ -680,11 +756,12 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
       for (int r = 1; r < nv; ++r) acc += (etau[r] * wr[r]) * J[r];
       stage[6 * qq + which * nq + j] = acc;
     }
-  __syncthreads();
-  // (the strict upper triangles of CP, CT, CM are never read: whatever LDS held goes out with the rest)
-  double2* out2 = reinterpret_cast<double2*>(terms + (size_t)k * ts);   // ts is even, the buffer 16-byte aligned
-  const double2* st2 = reinterpret_cast<const double2*>(stage);
-  for (int idx = tid; idx < ts / 2; idx += nt) out2[idx] = st2[idx];
+  FD_STAMP(14);
+  FD_STAMP(15);
+#ifdef IDTO_FD_STAMPS
+  if (idto_fd_st && k == 1)
+    for (int i = 0; i < 16; ++i) nplus_out[(size_t)(k + 1) * bsz + (tid == 0 ? 0 : 16) + i] = (double)(st_arr[i] - st_arr[0]);   // (over N+_2: a profiling build)
+#endif
 }
 
 template <int MAXC, int SHAPE = 0>

@@ -27,6 +27,17 @@
 
 #include "id_eval.h"
 
+// profiling build (tools/fd_variants.sh, -DIDTO_FD_STAMPS): shader-clock stamps of the phases of fd_kernel and of the
+// evaluation, taken by the lanes tid 0 and tid 192 and returned in v_out (tools/fd_stamps.py)
+#ifdef IDTO_FD_STAMPS
+#ifndef IDTO_FD_STAMP_TID
+#define IDTO_FD_STAMP_TID 192
+#endif
+#define FD_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); if (idto_fd_st) idto_fd_st[i] = (long long)__builtin_readcyclecounter(); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define FD_STAMP(i) do { } while (0)
+#endif
+
 namespace idto_dev {
 
 // record of one body (doubles); FB_IDX holds {qstart, vstart} as two ints
@@ -59,6 +70,24 @@ IDTO_DEV V3 tree_sum_fast(V3 v) {
   }
   return v;
 }
+
+// The same LDS address behind an empty asm: the compiler can no longer merge the reads through it with earlier reads
+// of the same words.  It otherwise hoists the constants of the LAST phase (damping, the joint frames of the projection,
+// the velocities of the damping term) to the top of the evaluation - nothing in between writes to LDS provably - and
+// then carries ~40 registers across the whole recursion, or spills them to scratch: six dependent scratch reloads at
+// the end of the evaluation cost 4k cycles.
+IDTO_DEV const double* lds_launder(const double* p) {
+  typedef __attribute__((address_space(3))) const double lds_cdouble;
+  unsigned a = (unsigned)(size_t)(lds_cdouble*)p;
+  asm volatile("" : "+v"(a));
+  return (const double*)(lds_cdouble*)(size_t)a;
+}
+
+// Values that are computed in the forward pass and used in the backward pass: pinned where they are computed.  The
+// compiler otherwise SINKS their computation to the use (the inertial wrench of every slot, ~110 operations each, moved
+// into the backward pass) and keeps the operands alive instead - 18 doubles per slot for 6 - which is what drove the
+// kernel over its 512 registers.
+IDTO_DEV void pin(V3& a) { asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z)); }
 
 struct ParentKin {  // what a child needs of its parent
   M3 R;
@@ -261,6 +290,7 @@ struct InLds {
   IDTO_DEV double Q(int i) const { return q[i]; }
   IDTO_DEV double V(int j) const { return v[j]; }
   IDTO_DEV double A(int j) const { return a[j]; }
+  IDTO_DEV InLds laundered() const { InLds o = *this; o.v = lds_launder(v); return o; }
 };
 // InFwd: evaluation e of the forward-difference set of one record (reference TO.cc:501-540, kernels.h fd_body),
 // formed by the lane that consumes it from q_{k+1}, v_{k+1}, a_k and column `col` of N+_{k+1}, N+_k:
@@ -268,31 +298,37 @@ struct InLds {
 //   kind 1  q_{k+1}[col] + dq:         q1 + dq e_col,  v1 + dv n1,  a0 + da n1            (:514-521)
 //   kind 2  q_k[col] + dq:             q1,             v1 - dv n1,  a0 - da (n1 + n0)     (:534-540)
 //   kind 3  mass-matrix column col:    q1,             0,           e_col                  (:556-561)
-// sdv, sda: dv, da with the sign of the kind ((-x) y == -(x y) and a - b == a + (-b) bit for bit).
+// Written without a branch or a select on a loaded value (the compiler turns those into exec-masked regions
+// with the LDS read inside: 28 dependent round trips, 6.4k cycles): every lane reads the same table entries,
+// and the kinds differ in the multipliers sdv, sda (dv, da with the sign of the kind - (-x) y == -(x y) and
+// a - b == a + (-b) bit for bit - and 0 for the kinds 0 and 3) and in bit masks on v1, a0, n0 (all ones / zero).
+// x + 0 * n and n1 + (+0) are x and n1 except that a zero -0 may come out as +0: inputs, and with them the
+// outputs, can differ from the expressions of TO.cc in the SIGN OF A ZERO only.
 struct InFwd {
   const double *q1, *v1, *a0, *N1, *N0;
   int nv, kind, col;
   double dq, sdv, sda;
+  unsigned long long keep, keep0;   // kind 3 drops v1, a0; kinds other than 2 drop n0
+  IDTO_DEV static double and_bits(double x, unsigned long long m) {
+    return __longlong_as_double((long long)((unsigned long long)__double_as_longlong(x) & m));
+  }
   IDTO_DEV double Q(int i) const {
-    const double x = q1[i];
-    return (kind == 1 && i == col) ? x + dq : x;
+    const double x = q1[i], xp = x + dq;
+    return (kind == 1 && i == col) ? xp : x;
   }
-  IDTO_DEV double V(int j) const {
-    const double x = v1[j], n1 = N1[col * nv + j];
-    const double p = x + sdv * n1;
-    return kind == 0 ? x : (kind == 3 ? 0.0 : p);
-  }
+  IDTO_DEV double V(int j) const { return and_bits(v1[j], keep) + sdv * N1[col * nv + j]; }
   IDTO_DEV double A(int j) const {
-    const double x = a0[j], n1 = N1[col * nv + j], n0 = N0[col * nv + j];
-    const double p = x + sda * (kind == 1 ? n1 : n1 + n0);
-    return kind == 0 ? x : (kind == 3 ? (j == col ? 1.0 : 0.0) : p);
+    const double unit = (kind == 3 && j == col) ? 1.0 : 0.0;   // (kind 3: a0 is masked to +0, +0 + 1 == 1)
+    return (and_bits(a0[j], keep) + unit) + sda * (N1[col * nv + j] + and_bits(N0[col * nv + j], keep0));
   }
+  IDTO_DEV InFwd laundered() const { InFwd o = *this; o.v1 = lds_launder(v1); o.N1 = lds_launder(N1); return o; }
 };
 
 // tau = ID(q, v, a) for the lane's path: id_eval<MAXC> for a model of shape (CJ, J0, K0).
 template <int MAXC, int NP, int CJ, int J0, int K0, class In>
 IDTO_DEV void id_eval_fast(const FastTab& T, const double* gravity, const DevContact& cp, int path, bool full,
-                           const In& in, double* tau) {
+                           const In& in_fwd, double* tau, long long* idto_fd_st = nullptr) {
+  const In& in = in_fwd;
   constexpr bool HAS_COMMON = (CJ == IDTO_JOINT_FLOATING);
   const V3 zero = mk(0, 0, 0);
   const V3 g = full ? mk(gravity[0], gravity[1], gravity[2]) : zero;
@@ -332,9 +368,13 @@ IDTO_DEV void id_eval_fast(const FastTab& T, const double* gravity, const DevCon
 #pragma unroll
     for (int i = 0; i < 6; ++i) { cv[i] = in.V(cvs + i); ca[i] = in.A(cvs + i); }
   }
+  FD_STAMP(4);
   double sn[MAXC], cs[MAXC];
+#ifndef IDTO_FAST_LAZY
 #pragma unroll
   for (int s = 0; s < MAXC; ++s) idto::detmath::sincos(qj[s], &sn[s], &cs[s]);
+#endif
+  FD_STAMP(5);
 
   // ---- common root body (identical in every lane of the evaluation)
   BodyState cb;
@@ -357,16 +397,21 @@ IDTO_DEV void id_eval_fast(const FastTab& T, const double* gravity, const DevCon
     cb_al = zero + al_rel;
     cb_a = zero + a_rel;
     inertial_wrench_rec(ct, cb.R, cb.w, cb_al, cb_a, g, &cb_fin, &cb_nin);
+    pin(cb_fin); pin(cb_nin);
     if (full) pair_group<false>(plist, seg[0], cp, cb, cb, &cfe, &cne, &cfe, &cne);
   }
 
+  FD_STAMP(6);
   // ---- own chain: kinematics, inertial wrench and contact pairs slot by slot
   V3 r[MAXC], hW[MAXC], ft[MAXC], nt[MAXC];   // ft, nt: inertial minus contact wrench of the slot
   ParentKin P;
   P.R = ident3(); P.p = zero; P.w = zero; P.v = zero; P.al = zero; P.a = zero;
 #pragma unroll
   for (int s = 0; s < MAXC; ++s) {
-    const double* rec = bt + s * FB_STRIDE;
+    const double* rec = lds_launder(bt + s * FB_STRIDE);   // (the slot's constants are read in the slot, not above the previous slot's pairs)
+#ifdef IDTO_FAST_LAZY
+    idto::detmath::sincos(qj[s], &sn[s], &cs[s]);
+#endif
     const bool world = (s == 0 && K0 == PK_WORLD);
     if (s == 0 && K0 == PK_COMMON) { P.R = cb.R; P.p = cb.p; P.w = cb.w; P.v = cb.v; P.al = cb_al; P.a = cb_a; }
     // (a body attached to the world: the record holds I * X_PF)
@@ -416,37 +461,48 @@ IDTO_DEV void id_eval_fast(const FastTab& T, const double* gravity, const DevCon
     }
     V3 fin, nin;
     inertial_wrench_rec(rec, bs.R, bs.w, al, acc, g, &fin, &nin);
+    pin(fin); pin(nin); pin(r[s]); pin(hW[s]);
+    if (s == MAXC - 1) FD_STAMP(8);
     V3 fext = zero, next = zero;
     if (full) pair_group<HAS_COMMON>(plist, seg[1 + s], cp, bs, cb, &fext, &next, &cfe, &cne);
     ft[s] = fin - fext;
     nt[s] = nin - next;
+    pin(ft[s]); pin(nt[s]);
     P.R = bs.R; P.p = bs.p; P.w = bs.w; P.v = bs.v; P.al = al; P.a = acc;
+    if (s == 0) FD_STAMP(7);
+    if (s == MAXC - 1) FD_STAMP(9);
   }
   if (HAS_COMMON && full) pair_group<false>(plist, seg[MAXC + 1], cp, cb, cb, &cfe, &cne, &cfe, &cne);
 
+  FD_STAMP(10);
   // ---- backward pass along the chain, joint torques
+  const In inb = in_fwd.laundered();
+  const double* btb = lds_launder(bt);
   V3 child_f = zero, child_n = zero;
   V3 root_f = zero, root_n = zero;
 #pragma unroll
   for (int s = MAXC - 1; s >= 0; --s) {
-    const double* rec = bt + s * FB_STRIDE;
+    const double* rec = btb + s * FB_STRIDE;
     V3 f = ft[s], n = nt[s];
     if (s + 1 < MAXC) { f = f + child_f; n = n + child_n; }
     if (s == 0 && J0 == IDTO_JOINT_PLANAR) {
       const M3 R_WF = ldm3(rec + FB_XPF);
       const double t0 = dot(col(R_WF, 0), f), t1 = dot(col(R_WF, 1), f), t2 = dot(col(R_WF, 2), n);
-      tau[vs[0]] = full ? t0 + rec[FB_DAMP] * v0x : t0;
-      tau[vs[0] + 1] = full ? t1 + rec[FB_DAMP + 1] * v0y : t1;
-      tau[vs[0] + 2] = full ? t2 + rec[FB_DAMP + 2] * vj[0] : t2;
+      // (the joint velocities of the damping term are read again rather than kept in registers since the forward pass:
+      // the same expression of the same LDS words, hence the same bits)
+      tau[vs[0]] = full ? t0 + rec[FB_DAMP] * inb.V(vs[0]) : t0;
+      tau[vs[0] + 1] = full ? t1 + rec[FB_DAMP + 1] * inb.V(vs[0] + 1) : t1;
+      tau[vs[0] + 2] = full ? t2 + rec[FB_DAMP + 2] * inb.V(vs[0] + 2) : t2;
     } else {
       const double t = dot(hW[s], n);
-      tau[vs[s]] = full ? t + rec[FB_DAMP] * vj[s] : t;
+      tau[vs[s]] = full ? t + rec[FB_DAMP] * inb.V(vs[s]) : t;
     }
     const V3 cf = f, cn = n + cross(r[s], f);
     if (s > 0) { child_f = cf; child_n = cn; }
     else if (K0 == PK_COMMON) { root_f = cf; root_n = cn; }
   }
 
+  FD_STAMP(11);
   // ---- common body: butterfly sums over the lanes of this evaluation
   if (HAS_COMMON) {
     const V3 ext_f = tree_sum_fast<NP>(cfe);
@@ -456,11 +512,12 @@ IDTO_DEV void id_eval_fast(const FastTab& T, const double* gravity, const DevCon
     const V3 f = (cb_fin - ext_f) + ch_f;
     const V3 n = (cb_nin - ext_n) + ch_n;
     if (path == 0) {
-      const M3 R_WF = ldm3(ct + FB_XPF);
+      const double* ctb = lds_launder(ct);
+      const M3 R_WF = ldm3(ctb + FB_XPF);
       const V3 nF = tmul(R_WF, n), fF = tmul(R_WF, f);
       const double t6[6] = {nF.x, nF.y, nF.z, fF.x, fF.y, fF.z};
 #pragma unroll
-      for (int i = 0; i < 6; ++i) tau[cvs + i] = full ? t6[i] + ct[FB_DAMP + i] * cv[i] : t6[i];
+      for (int i = 0; i < 6; ++i) tau[cvs + i] = full ? t6[i] + ctb[FB_DAMP + i] * inb.V(cvs + i) : t6[i];
     }
   }
 }

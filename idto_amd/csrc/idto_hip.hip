@@ -522,7 +522,7 @@ int FdEvals(const idto_hip_ctx* c, int mode) {
 // dynamic LDS of fd_kernel when it builds the inputs of `ec` evaluations per pass
 int FdLds(const idto_hip_ctx* c, int mode, int ec, bool with_terms = false) {
   const int nq = c->nq, nv = c->nv, E = FdEvals(c, mode), nvp = (nv + 1) & ~1;
-  const int rec = with_terms ? 6 * nvp * nq + nvp + asm_terms_stride(nq) + 1 : 0;   // the record, its weighted copy, diag R', the products (+1: 16-byte alignment)
+  const int rec = with_terms ? 6 * nvp * nq + nvp + 1 : 0;   // the record, its weighted copy, diag R' (+1: 16-byte alignment)
   const int blob_n = (c->fd_fast && c->M.fast_shape) ? c->M.fast_n : c->M.blob_n;   // what fd_body stages of the model
   return (int)sizeof(double) * (3 * nq + 2 * nv * nq + 3 * nv + 3 * E + E * nv + ec * (nq + 2 * nv) + nv + blob_n + 2 + nq / 2 + 2 + rec);
 }
