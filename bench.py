@@ -164,6 +164,29 @@ def full_iteration(cfg, model, N, device, with_cpu, iters=20):
     return out
 
 
+SHARD_NOTE = ("sharding ONE N=40 problem cannot beat one GPU: its 40 finite-difference workgroups already run side by side "
+              "on 40 of the 256 CUs, the all-gather adds a hand-over, and the block solve (a dependent chain) does not "
+              "shard - DESIGN.md §7; the aggregate of independent problems is reported as replicas_mode / config5_workload")
+
+
+def self_launch_command(argv, gpus, visible_gpus, port=None):
+    """`bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment): the command and the extra
+    environment that start it again as N ranks under torch.distributed.run on this node.  With fewer visible
+    devices than ranks the ranks share devices (local_rank % visible) and measure independent replicas - RCCL does
+    not form a communicator of two ranks on one device - and the JSON line says so."""
+    import socket
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py")] + list(argv)
+    env = {"MASTER_ADDR": "127.0.0.1", "IDTO_BENCH_SELF_LAUNCHED": "1"}
+    if visible_gpus < gpus:
+        env["IDTO_BENCH_VISIBLE_GPUS"] = str(max(1, visible_gpus))
+    return cmd, env
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,8 +206,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the N ranks here (one process per GPU over RCCL, the contract of the driver's own command)
+        import subprocess
+        cmd, extra = self_launch_command(sys.argv[1:], args.gpus, torch.cuda.device_count())
+        raise SystemExit(subprocess.run(cmd, env=dict(os.environ, **extra)).returncode)
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, "
+                         "or without a launcher")
+    visible = int(os.environ.get("IDTO_BENCH_VISIBLE_GPUS", "0"))   # set by the self-launch when ranks must share devices
+    if visible:
+        local_rank = local_rank % visible
+        args.mode = "replicas"
     dist = None
     # Data path of the sharded mode: the RCCL communicator inside libidto_hip.so (ncclAllGather on
     # the context's stream, include/idto_hip.h idto_hip_comm_*); torch.distributed is the control
@@ -236,6 +269,8 @@ def main():
     if world > 1:
         from idto_amd.multi_gpu import RcclShard, SlabExchange, device_slab_view
         try:
+            if visible:
+                raise RuntimeError(f"{world} ranks on {visible} visible device(s): no RCCL communicator between ranks of one device")
             if exchange == "rccl":
                 exch = RcclShard(dist, dev, rank, world)
                 dev.set_shard(0, N)   # (the shard is switched on below, per mode)
@@ -534,8 +569,17 @@ def main():
                          "all_kernels_avg_ms": {names[i]: kern[i][0] for i in range(4) if kern[i][1] > 0},
                          "note": "latency/dependency-bound path (SURVEY.md §8d): HBM fraction is intrinsically small"},
         }
-        if exchange_note:
-            out["config"]["note"] = exchange_note
+        notes = []
+        if world > 1:
+            notes.append(SHARD_NOTE)
+        if visible:
+            notes.append(f"{world} ranks share {visible} visible device(s): value is {world} independent replicas time-sharing "
+                         "them, NOT a multi-GPU measurement")
+            out["gpus_visible"] = visible
+        elif exchange_note:
+            notes.append(exchange_note)
+        if notes:
+            out["config"]["note"] = "; ".join(notes)
         if other_extra is not None:
             out[other_key] = other_extra
         if bit_identical is not None:

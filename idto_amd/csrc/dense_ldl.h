@@ -37,7 +37,7 @@ constexpr int DENSE_NB = 32;
 __global__ void __launch_bounds__(256)
 dense_ldl_step_kernel(double* __restrict__ S, double* __restrict__ Lm, int n, int j0, double* __restrict__ dvec,
                       double* __restrict__ stat, const double* __restrict__ b, double b_sign, const double* __restrict__ b2,
-                      double* __restrict__ rv) {
+                      double* __restrict__ rv, double* __restrict__ yv) {
   constexpr int NB = DENSE_NB, T = 32;
   const int tr = blockIdx.x, tc = blockIdx.y;
   if (tr < tc) return;
@@ -63,7 +63,8 @@ dense_ldl_step_kernel(double* __restrict__ S, double* __restrict__ Lm, int n, in
     for (int k = 0; k < NB; ++k) w[k] = (k < nb && prow < n) ? S[(size_t)(j0 + k) * n + prow] : 0.0;
   }
   // the right-hand side rides along (L y = r panel by panel: the solve kernel then only substitutes backwards):
-  // rv holds r with the panels before this one eliminated; the first step forms r = b2 + b_sign b itself
+  // rv holds r with the panels before this one eliminated (rows >= j0; a panel's own rows are never written again), yv
+  // the finished y; the first step forms r = b2 + b_sign b itself
   const bool rhs = rv != nullptr && tc == 0 && wave == 3 && lane < 32;
   double rj = 0.0, rr_blk = 0.0;
   if (rhs) {
@@ -127,7 +128,10 @@ dense_ldl_step_kernel(double* __restrict__ S, double* __restrict__ Lm, int n, in
       if (r > p) rj -= lr[p] * yp;
     }
     if (lane < NB) ys[lane] = (lane < nb) ? rj : 0.0;
-    if (tr == 0 && lane < nb) rv[j0 + lane] = rj;   // (the panel's y replaces its r)
+    // (y goes to a vector of its own: every first-column workgroup of this launch reads r_J = rv[j0 ..] when it starts,
+    // and nothing orders those reads against this store - written in place, a workgroup that started late substituted
+    // an already substituted vector)
+    if (tr == 0 && lane < nb) yv[j0 + lane] = rj;
   }
   if (r0 >= n) return;   // (the last panel: nothing below it)
   // a panel row below the block: w = S[r, J] = x (L_JJ D)^T  =>  x_k d_k = w_k - sum_{q<k} (x_q d_q) L_JJ[k][q]

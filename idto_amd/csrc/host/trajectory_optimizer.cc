@@ -1051,9 +1051,13 @@ SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solu
                             params_.Delta_max, eta, constrained ? unactuated_dofs_.data() : nullptr,
                             constrained ? (int)unactuated_dofs_.size() : 0, rows.data(), &Delta_end));
     const double total = std::chrono::duration<double>(clock::now() - start_time).count();
+    // (with the convergence criteria on the device loop stops within eight iterations of the one that met them: the
+    // rows behind it are zeros)
+    int ran = iters;
+    while (ran > 1 && rows[(std::size_t)(ran - 1) * IDTO_TR_ROW + 10] == 0.0) --ran;
     double timed = 0.0;
-    for (int i = 1; i < iters; ++i) timed += (rows[(std::size_t)i * IDTO_TR_ROW + 10] - rows[(std::size_t)(i - 1) * IDTO_TR_ROW + 10]) * 1e-8;
-    for (; k < iters; ++k) {
+    for (int i = 1; i < ran; ++i) timed += (rows[(std::size_t)i * IDTO_TR_ROW + 10] - rows[(std::size_t)(i - 1) * IDTO_TR_ROW + 10]) * 1e-8;
+    for (; k < ran; ++k) {
       const double* R = rows.data() + (std::size_t)k * IDTO_TR_ROW;
       const int flags = (int)R[14];
       if (flags & 8) {

@@ -113,6 +113,7 @@ struct idto_hip_ctx {
   unsigned long long* pipe_rowcnt = nullptr;   // the same for the pipelined variant (its own launch count: the two
   unsigned long long pipe_launches = 0;        // variants release a row with different increments)
   int solver_timeouts = 0;                // launches whose waits between workgroups ran out (FactorStatus)
+  unsigned timeouts_handled = 0;          // ... the device's count of them (status word) that FactorStatus has acted on
   int last_step_kind = 0;                 // what produced IDTO_ARR_STEP last: 1 factor_solve of -g, 2 the fused launch, 0 other
   int debug_skip_role = -1;               // test aid: a role of the nested-dissection kernels that returns at once
   int debug_pipe_tail = 0;                // measurement aid: pipelined solver with the row-by-row back substitution
@@ -612,7 +613,12 @@ int EnsureStage(idto_hip_ctx* c, size_t count) {
 // (problem `pb` of the batch, or any of them for pb < 0)
 int FactorStatus(idto_hip_ctx* c, int pb = -1) {
   const volatile unsigned* st = c->status_pin;
-  if (c->fact_id != 0 && st[2 * c->batch] == c->fact_id) {
+  // (the COUNT of launches whose waits ran out, not the id of the last one: idto_hip_tr_solve enqueues a factorisation
+  // per iteration and waits once - a timeout in any of them shows here; and a second status query about a launch
+  // that has been handled does not step the context down once more)
+  const unsigned timeouts_now = st[2 * c->batch + 1];
+  if (timeouts_now != c->timeouts_handled) {
+    c->timeouts_handled = timeouts_now;
     // A wait between the workgroups of a multi-workgroup solver ran out: its partners were not resident at the
     // same time (other contexts' kernels on the device).  The result of that launch is garbage.  Step down to a
     // variant with fewer co-resident workgroups for the rest of the context's life; the caller repeats the solve
@@ -1423,7 +1429,7 @@ int idto_hip_constraint_schur_begin(idto_hip_ctx* c, const int* dofs, int nu) {
     if (Alloc(c, (size_t)neq * neq + neq, &c->con_S) || Alloc(c, (size_t)neq + 2, &c->con_lambda) ||
         Alloc(c, (size_t)2 * n, &c->con_out) ||
         Alloc(c, (size_t)neq, &c->con_d) || Alloc(c, (size_t)neq + 2, &c->con_h) || Alloc(c, (size_t)neq * neq, &c->con_L) ||
-        Alloc(c, (size_t)neq, &c->con_rv))
+        Alloc(c, 2 * (size_t)neq, &c->con_rv))   // [r with the finished panels eliminated | y = L^-1 r]
       return -2;
     const size_t need = (size_t)neq * neq + neq + 2 * (size_t)n + 2 * (size_t)neq + 4;
     if (c->con_pin) (void)hipHostFree(c->con_pin);
@@ -1481,7 +1487,7 @@ static void LaunchDenseLdl(idto_hip_ctx* c, double* S, int neq, const double* b,
     const int j1 = j0 + DENSE_NB, below = neq > j1 ? neq - j1 : 0;
     const int tiles = below > 0 ? (below + 31) / 32 : 1;
     hipLaunchKernelGGL(dense_ldl_step_kernel, dim3(tiles, tiles), dim3(256), 0, c->stream, S, c->con_L, neq, j0, c->con_d, c->con_h,
-                       b, b_sign, b2, c->con_rv);
+                       b, b_sign, b2, c->con_rv, c->con_rv + neq);
   }
 }
 
@@ -1503,7 +1509,7 @@ int idto_hip_constraint_solve(idto_hip_ctx* c, const double* h_host, double* lam
   c->con_lambda_at = c->con_lambda + 2;
   // lambda = S^-1 (h - J y_g): the forward substitution went with the factorisation
   hipLaunchKernelGGL(dense_ldl_solve_kernel, dim3(1), dim3(512), (neq + 512 + DENSE_NB * (DENSE_NB + 1)) * sizeof(double), c->stream, c->con_L, neq, c->con_d,
-                     c->con_rv, 1.0, (const double*)nullptr, c->con_lambda + 2, 1);
+                     c->con_rv + neq, 1.0, (const double*)nullptr, c->con_lambda + 2, 1);
   hipLaunchKernelGGL(constraint_step_kernel, dim3((n + 63) / 64), dim3(64 * STEP_WAVES), (neq + 64 * STEP_WAVES) * sizeof(double), c->stream, c->slab,
                      c->slab_stride, c->con_dofs, c->con_nu, N, c->nq, c->nv, c->stage_x, neq, c->con_lambda + 2,
                      c->con_out, c->con_out + n, c->alt_r);
@@ -1570,6 +1576,7 @@ static TrRowsArgs PrepareArgs(idto_hip_ctx* c, int scaling_method, int with_lamb
   A.N = c->N;
   A.lambda = with_lambda ? c->con_lambda_at : nullptr;
   A.partial = c->tr_part;
+  A.freeze = nullptr;   // (idto_hip_tr_solve points it at the loop's sticky flags)
   return A;
 }
 
@@ -1770,7 +1777,19 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
   // (with convergence checks the last iteration, too, is followed by g at its iterate: one more pass of the loop
   // body up to tr_iter_kernel, which then only evaluates the criteria)
   const int passes = iterations + (conv.on ? 1 : 0);
+  // With the convergence criteria on, the loop is enqueued in chunks of TR_CHUNK iterations and the sticky flags
+  // are looked at in between: once a criterion holds (or an iteration failed) the iterations that are left would run
+  // every kernel in full - none of fd, cost and the solver reads the flags - only to decide nothing, and a solve that
+  // converges after 20 of max_iterations = 500 would take 25 times as long as the loop it replaces (TO.cc:2600-2612
+  // leaves the loop).  Rows of iterations that never ran are zeros.
+  constexpr int TR_CHUNK = 8;
+  if (conv.on) HIP_OK(hipMemsetAsync(c->tr_rows, 0, (size_t)B * rows_stride * sizeof(double), c->stream));
   for (int k = 0; k < passes; ++k) {
+    if (conv.on && B == 1 && k > 0 && k % TR_CHUNK == 0) {
+      HIP_OK(hipMemcpyAsync(c->tr_pin, c->tr_state, TRS_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIP_OK(hipStreamSynchronize(c->stream));
+      if (c->tr_pin[TRS_FLAGS] != 0.0) break;
+    }
     conv.check_only = (k == iterations) ? 1 : 0;
     if (nu > 0) {
       // multipliers of the iterate (TO.cc:1371-1396), all on the device: Y = H^-1 [g | J^T], S = J Y_J, J y_g
@@ -1792,7 +1811,7 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
         LaunchDenseLdl(c, S, neq, S + (size_t)neq * neq, -1.0, c->con_h + 2);
         c->con_S_factored = true;
         hipLaunchKernelGGL(dense_ldl_solve_kernel, dim3(1), dim3(512), (neq + 512 + DENSE_NB * (DENSE_NB + 1)) * sizeof(double),
-                           c->stream, c->con_L, neq, c->con_d, c->con_rv, 1.0, (const double*)nullptr, c->con_lambda + 2, 1);
+                           c->stream, c->con_L, neq, c->con_d, c->con_rv + neq, 1.0, (const double*)nullptr, c->con_lambda + 2, 1);
         hipLaunchKernelGGL(constraint_flag_kernel, dim3(1), dim3(1), 0, c->stream, c->con_h, c->tr_state);
         c->con_lambda_at = c->con_lambda + 2;
       }
@@ -1814,6 +1833,8 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     T.quat = c->tr_quat; T.q_trial = c->q_trial; T.dq = c->tr_dq;
     T.conv = conv;
     T.fact_status = c->status_dev; T.fact_id = c->fact_id;   // (the most recent factorisation: this iteration's step)
+    T.timeout_status = c->status_dev + 2 * c->batch;
+    T.rows.freeze = c->tr_state + TRS_FLAGS;
     T.pstride = c->pstride; T.rows_stride = rows_stride;
     hipLaunchKernelGGL(tr_iter_kernel, dim3(nblk, B), dim3(256), lds_iter, c->stream, T);
     HIP_OK(hipGetLastError());

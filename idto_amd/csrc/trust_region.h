@@ -91,6 +91,7 @@ struct TrRowsArgs {
   int nu, N;
   const double* lambda;
   double* partial;
+  const double* freeze;   // (resident loop) the sticky flags word: once it is non-zero D, g~, w keep the values of the last decided iteration
 };
 
 __device__ __forceinline__ void tr_prepare_rows_body(const TrRowsArgs& A, double* lds) {
@@ -104,6 +105,7 @@ __device__ __forceinline__ void tr_prepare_rows_body(const TrRowsArgs& A, double
   const double* __restrict__ slab = A.slab; const int* __restrict__ dofs = A.dofs;
   const double* __restrict__ lambda = A.lambda; double* __restrict__ partial = A.partial;
   const int i = blockIdx.x, tid = threadIdx.x, nt = blockDim.x, kk = K * K;
+  const bool frozen = A.freeze && *A.freeze != 0.0;
   double* xt = lds;            // [5 K]  D g~ of block rows i-2 .. i+2
   double* xy = xt + 5 * K;     // [5 K]  y
   double* dl = xy + 5 * K;     // [K]    D of this block row
@@ -121,7 +123,11 @@ __device__ __forceinline__ void tr_prepare_rows_body(const TrRowsArgs& A, double
       const double gm = jtl ? g[v] + jtl[v] : g[v];
       const double gti = d * gm, yi = ysign * yin[v];
       vt = d * gti; vy = yi;
-      if (j == 2) { const double wi = yi / d; dl[r] = d; gl[r] = gti; wl[r] = wi; D[v] = d; gt[v] = gti; w[v] = wi; }
+      if (j == 2) {
+        const double wi = yi / d;
+        dl[r] = d; gl[r] = gti; wl[r] = wi;
+        if (!frozen) { D[v] = d; gt[v] = gti; w[v] = wi; }
+      }
     }
     xt[idx] = vt; xy[idx] = vy;
   }
@@ -260,7 +266,9 @@ enum {
 static_assert(TRS_CUR == IDTO_TRS_CUR, "batch.h and trust_region.h disagree");
 enum { TRF_DOGLEG = 1, TRF_NONFINITE = 2, TRF_NOT_DESCENT = 4, TRF_SINGULAR_S = 8 /* constraints.h constraint_lambda_kernel */,
        TRF_CONVERGED = 16 /* a convergence criterion held after an accepted step (TO.cc:2654-2689): not an error */,
-       TRF_FACTORIZATION = 32 /* the factorisation behind this iteration's step met a bad pivot (penta_diagonal_solver.h:181-185) */ };
+       TRF_FACTORIZATION = 32 /* the factorisation behind this iteration's step met a bad pivot (penta_diagonal_solver.h:181-185) */,
+       TRF_SOLVER_TIMEOUT = 64 /* a wait between the solver's workgroups ran out in the launch behind this iteration's step: the step is
+                                  garbage, nothing is built on it (penta_ldl.h spin_wait; the host repeats the solve) */ };
 // one row of per-iteration statistics (TrajectoryOptimizerStats::push_data, TO.cc:2586-2598)
 enum { TRR_COST = 0, TRR_DELTA, TRR_RHO, TRR_QNORM, TRR_DQNORM, TRR_DQHNORM, TRR_GNORM, TRR_DLDQ, TRR_HNORM,
        TRR_ACCEPTED, TRR_CLOCK /* wall_clock64 ticks (100 MHz) */, TRR_A, TRR_B, TRR_COST_TRIAL, TRR_FLAGS,
@@ -293,6 +301,7 @@ struct TrIterArgs {
   TrConvergence conv;
   const unsigned* fact_status;   // the solver's status word (host-mapped) and the id of the factorisation this iteration's step
   unsigned fact_id;              // came from: a failure in the MIDDLE of the resident loop is flagged in its own iteration
+  const unsigned* timeout_status;   // ... and the word a launch whose waits between workgroups ran out writes its id to
   size_t pstride, rows_stride;   // batch contexts: grid.y = problem (arena stride in bytes; doubles between the problems' rows)
 };
 
@@ -315,7 +324,7 @@ __device__ inline double tr_dogleg_quadratic(double a, double b, double c, bool*
 __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
   extern __shared__ double lds[];
   __shared__ int last;
-  __shared__ double ab[2];
+  __shared__ double ab[3];
   {   // problem of the batch: every array of the loop lives in the problem's arena
     const size_t o = (size_t)blockIdx.y * T.pstride;
     TrRowsArgs& A = T.rows;
@@ -324,6 +333,7 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
     A.yin = at_problem(A.yin, o); A.q = at_problem(A.q, o); A.Dprev = at_problem(A.Dprev, o); A.D = at_problem(A.D, o);
     A.gt = at_problem(A.gt, o); A.w = at_problem(A.w, o); A.partial = at_problem(A.partial, o);
     if (A.lambda) A.lambda = at_problem(A.lambda, o);
+    if (A.freeze) A.freeze = at_problem(A.freeze, o);
     A.slab = at_problem(A.slab, o + (size_t)alt_offset(T.alt, o));   // (h = tau[unactuated] is read from the iterate's set)
     T.counter = at_problem(T.counter, o); T.out = at_problem(T.out, o); T.state = at_problem(T.state, o);
     T.q_trial = at_problem(T.q_trial, o); T.dq = at_problem(T.dq, o);
@@ -343,6 +353,7 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   // (requested now, used by thread 0 at the dogleg: the round trip to host-mapped memory overlaps the sums)
   const unsigned fact_word = (tid == 0 && T.fact_status) ? __hip_atomic_load(T.fact_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+  const unsigned timeout_word = (tid == 0 && T.timeout_status) ? __hip_atomic_load(T.timeout_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
   // the operands of the trial point (below) do not depend on the dogleg: fetch them now, four passes of 256
   // threads = tr_trial_kernel's 1024, so that their L2 round trips overlap the sums and the dogleg instead of
   // following them one pass after the other
@@ -408,6 +419,7 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
     const double Delta = T.state[TRS_DELTA];
     int flags = (int)T.state[TRS_FLAGS];
     if (T.fact_status && fact_word == T.fact_id) flags |= TRF_FACTORIZATION;
+    if (T.timeout_status && timeout_word == T.fact_id) flags |= TRF_SOLVER_TIMEOUT;
     const double cU = -(gg / gHg) / Delta;
     const double pUn = __builtin_fabs(cU) * __builtin_sqrt(gg), pHn = __builtin_sqrt(ww) / Delta;
     double a, b, active;
@@ -424,12 +436,15 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
     }
     if (!(__builtin_isfinite(a) && __builtin_isfinite(b))) flags |= TRF_NONFINITE;
     T.state[TRS_A] = a; T.state[TRS_B] = b; T.state[TRS_ACTIVE] = active; T.state[TRS_FLAGS] = (double)flags;
-    ab[0] = a; ab[1] = b;
+    ab[0] = a; ab[1] = b; ab[2] = (double)flags;
   }
   __syncthreads();
   // ---- tr_trial: dq = D (a g~ + b w), q_trial = q + dq, [dq.dq, g~.(a g~ + b w)] with the partial sums
   // of tr_trial_kernel's 1024 threads (thread v of it owns idx = v, v + 1024, ...): same bits
+  // (once a sticky flag is set - converged, or an error - the loop idles: dq and the trial point keep the values of the
+  // last decided iteration, which is what the warm start hands on: TO.cc:2361-2385)
   const double a = ab[0], b = ab[1];
+  const bool idle = ab[2] != 0.0;
   const int lane = tid & 63;
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {   // (blockDim.x == 256)
@@ -438,16 +453,14 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
     if (vt < n) {   // the prefetched first element of virtual thread vt
       const double dqs = a * pg[ps] + b * pw[ps];
       const double dq = T.scaling ? pd[ps] * dqs : dqs;
-      T.dq[vt] = dq;
-      T.q_trial[vt] = pq[ps] + dq;
+      if (!idle) { T.dq[vt] = dq; T.q_trial[vt] = pq[ps] + dq; }
       s0 += dq * dq;
       s1 += pg[ps] * dqs;
     }
     for (int idx = vt + 1024; idx < n; idx += 1024) {
       const double dqs = a * T.rows.gt[idx] + b * T.rows.w[idx];
       const double dq = T.scaling ? T.rows.D[idx] * dqs : dqs;
-      T.dq[idx] = dq;
-      T.q_trial[idx] = T.rows.q[idx] + dq;
+      if (!idle) { T.dq[idx] = dq; T.q_trial[idx] = T.rows.q[idx] + dq; }
       s0 += dq * dq;
       s1 += T.rows.gt[idx] * dqs;
     }
@@ -456,7 +469,7 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
     if (lane == 0) { scratch[vt >> 6] = s0; scratch[16 + (vt >> 6)] = s1; }
   }
   __syncthreads();
-  if (T.nquat > 0) {
+  if (T.nquat > 0 && !idle) {
     const int nsteps = n / T.nq;
     for (int idx = tid; idx < nsteps * T.nquat; idx += nt) {
       const int t = idx / T.nquat, qs = T.quat[idx - t * T.nquat];
