@@ -123,8 +123,14 @@ __device__ __forceinline__ void ldl_pivot(double (&xr)[K], double d, double inv,
   // are live at a time (the kernel is short of SGPRs; spills cost v_readlane's on this path)
   constexpr int CH = 8;
   double inv_next = 1.0, d_next = 1.0;
+  // (multipliers from the UPPER triangle - element (J, r) of the pivot row, not (r, J) of the column: L = (D^-1 U)^T then
+  // holds exactly, which is what the back substitution and the spike rows assume; penta_pipe.h does the same)
   if constexpr (J + 1 < K) {
+#ifdef IDTO_LDL_LOWER_MULTIPLIERS
     const double m1 = rdlane(xr[J + 1], J);
+#else
+    const double m1 = rdlane(xr[J], J + 1);
+#endif
     xr[J + 1] = __builtin_fma(-m1, t, xr[J + 1]);
     d_next = rdlane(xr[J + 1], J + 1);
     inv_next = fast_rcp(d_next);
@@ -134,7 +140,11 @@ __device__ __forceinline__ void ldl_pivot(double (&xr)[K], double d, double inv,
     double m[CH];
 #pragma unroll
     for (int q = 0; q < CH; ++q)
+#ifdef IDTO_LDL_LOWER_MULTIPLIERS
       if (r0 + q < K) m[q] = rdlane(xr[r0 + q], J);
+#else
+      if (r0 + q < K) m[q] = rdlane(xr[J], r0 + q);
+#endif
 #pragma unroll
     for (int q = 0; q < CH; ++q)
       if (r0 + q < K) xr[r0 + q] = __builtin_fma(-m[q], t, xr[r0 + q]);

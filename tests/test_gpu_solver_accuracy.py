@@ -1,0 +1,73 @@
+"""Accuracy of every production variant of the block penta-diagonal solver, gated.
+
+The reference factorises with a pivoted LU and states that it dropped LDL^T because of round-off
+(reference optimizer/penta_diagonal_solver.h:40-42).  The production kernels here are un-pivoted block
+LDL^T variants, so the burden of proof is on them: for each BASELINE configuration at its horizon, four
+trajectory seeds and every variant that configuration can reach (pipelined chains, the same with the row-by-row
+back substitution, nested dissection over seven workgroups, two workgroups), the Gauss-Newton step must have
+  * a forward error against an extended-precision solution of the same system (oracle_lib.refined_solution,
+    known to `unc`) of at most 4x the error of the reference's algorithm (penta_kernel: the pivoted-LU block
+    Thomas, bit-exact to the oracle's) + 16 unc, and
+  * a componentwise backward error  max_i |H p + g|_i / (|H| |p| + |g|)_i  <= 1e-12.
+tools/nd_accuracy.py prints the same quantities as a table (profiles/r04_nd_accuracy.txt)."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from idto_amd import hip
+from idto_amd.model import load_model
+from idto_amd.problem import load_config, make_problem, synthetic_trajectory
+from oracle_lib import Oracle
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("acrobot", 40, 0.0), ("spinner", 40, 0.0), ("hopper", 50, 0.01), ("mini_cheetah", 40, 0.01), ("allegro_hand", 60, 0.0)]
+# variant -> (options, the values of `last_solver` that say it ran: 4 pipelined, 2 nested dissection, 1 two workgroups
+# (5: the same inside the fused launch))
+VARIANTS = {
+    "pipe": ({"solver_pipe": 1, "solver_nd": 1, "debug_pipe_tail": 0}, (4,)),
+    "pipe_rowwise_tail": ({"solver_pipe": 1, "solver_nd": 1, "debug_pipe_tail": 1}, (4,)),
+    "nd": ({"solver_pipe": 0, "solver_nd": 1, "debug_pipe_tail": 0}, (2,)),
+    "two": ({"solver_pipe": 0, "solver_nd": 0, "debug_pipe_tail": 0}, (1, 5)),
+}
+
+
+def errors(bands, g, p, p_ref):
+    pn = np.abs(p_ref).max()
+    fwd = np.abs(p.ravel() - p_ref).max() / pn
+    ab = [np.abs(b) for b in bands]
+    bwd = (np.abs(ol.penta_multiply(*bands, p) + g.ravel()) / (ol.penta_multiply(*ab, np.abs(p)) + np.abs(g.ravel()) + 1e-300)).max()
+    return fwd, bwd
+
+
+@pytest.mark.parametrize("name,N,lower", CASES)
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_production_solvers_are_as_accurate_as_the_pivoted_lu(name, N, lower, seed):
+    cfg, model = load_config(name), load_model(name)
+    prob, sp, _ = make_problem(cfg, model, num_steps=N)
+    sp.scaling = sp.equality_constraints = False
+    q = synthetic_trajectory(cfg, model, N, seed=seed, lower=lower)
+    if name == "spinner":
+        q[:, 1] = np.linspace(1.5, 1.25, N + 1)
+    g, bands = Oracle(model, prob, sp).grad_hess(q)
+    p_ref, unc = ol.refined_solution(ol.penta_make_dense(*bands), -g.ravel())
+    dev = hip.HipPath(model, prob, sp)
+    dev.set_q(q)
+    dev.set_option("reference_solver", 1)
+    dev.gn_step()
+    fwd_lu, _ = errors(bands, g, dev.get("step"), p_ref)
+    dev.set_option("reference_solver", 0)
+    ran = []
+    for label, (opts, code) in VARIANTS.items():
+        for k, v in opts.items():
+            dev.set_option(k, v)
+        dev.gn_step()
+        p = dev.get("step")
+        if dev.get_option("last_solver") not in code:
+            continue   # this configuration does not reach the variant (block size / horizon)
+        ran.append(label)
+        fwd, bwd = errors(bands, g, p, p_ref)
+        assert fwd <= 4 * fwd_lu + 16 * unc + 1e-12, (label, "forward error", fwd, "LU", fwd_lu, "unc", unc)
+        assert bwd <= 1e-12, (label, "componentwise backward error", bwd)
+    dev.close()
+    assert ran, "no production variant ran"
