@@ -70,6 +70,36 @@ def pmc_traffic(kernel):
     return e["fetch_bytes_per_launch_x2"] + e["write_bytes_per_launch_raw"], os.path.relpath(files[-1], ROOT)
 
 
+def latency_model(kern_ms, names):
+    """The bounds that apply to these kernels (they are latency / issue bound: the HBM fraction is ~0.3 %): the model of
+    the newest profiles/r*_latency_model.json (tools/latency_model.py, from that round's committed PMC passes and in-kernel
+    timelines) against the HIP-event kernel times of THIS run (which include ~2 us of event overhead per launch)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_latency_model.json")))
+    if not files:
+        return None
+    m = json.load(open(files[-1]))
+    out = {"source": os.path.relpath(files[-1], ROOT), "script": "tools/latency_model.py"}
+    live = {names[i]: 1e3 * kern_ms[i][0] for i in range(len(names)) if i < len(kern_ms) and kern_ms[i][1] > 0}
+    fd = m.get("fd_kernel")
+    if fd and "fd_kernel" in live:
+        out["fd_kernel"] = {"bound": fd["bound"], "valu_instructions_per_wavefront": fd["valu_instructions_per_wavefront"],
+                            "issue_floor_us": fd["issue_floor_us"], "this_run_us": live["fd_kernel"],
+                            "achieved_frac": fd["issue_floor_us"] / live["fd_kernel"],
+                            "profiled_round": {k: fd[k] for k in ("rocprof_avg_us", "achieved_frac_of_issue_floor",
+                                                                  "wait_frac_of_wave_cycles", "valu_active_frac_of_wave_cycles")}}
+    so = m.get("penta_pipe_kernel")
+    if so and "penta_pipe_kernel" in live:
+        out["penta_pipe_kernel"] = {"bound": so["bound"], "row_model_us": so["row_model_us"], "pivot_chain_floor_us": so["pivot_chain_floor_us"],
+                                    "this_run_us": live["penta_pipe_kernel"],
+                                    "achieved_frac_of_pivot_chain_floor": so["pivot_chain_floor_us"] / live["penta_pipe_kernel"],
+                                    "terms_us": {k: so[k] for k in ("rows_of_the_longest_chain", "row_to_row_us", "k_pivots_us",
+                                                                    "hand_over_to_separator_us", "separator_us", "back_substitution_us")},
+                                    "note": "this_run_us includes the assembly workgroups when the launch assembles g and H itself; "
+                                            "the row model is of the solver alone"}
+    return out
+
+
 def host_cpu_limit():
     """CPUs this process may use: logical cores, affinity mask, CFS quota of the container (cgroup v2 cpu.max
     or v1 cpu.cfs_quota_us / cpu.cfs_period_us; None = unlimited)."""
@@ -543,6 +573,10 @@ def main():
             names[2] = "penta_pipe_kernel"
         if dev.get_option("last_assembly") == 1:   # products formed by fd_kernel, combined here (kernels.h)
             names[1] = "assemble_terms_kernel"
+        asm_inside = dev.get_option("last_assembly") == 4   # the solver's launch assembled g and H itself (penta_pipe.h PipeAsm)
+        if asm_inside:
+            names[1] = "(inside penta_pipe_kernel)"
+            algb[2] += algb[1]   # ... so its algorithmic bytes are the assembly's plus the solver's (2.6 MB)
         dur_s = kern[dom][0] * 1e-3
         achieved = algb[dom] / dur_s / 1e9 if dur_s > 0 else 0.0
         traffic, traffic_src = pmc_traffic(names[dom])
@@ -567,7 +601,11 @@ def main():
                          "algorithmic_bytes_per_launch": algb[dom], "avg_launch_ms": kern[dom][0],
                          "launches_timed": kern[dom][1],
                          "all_kernels_avg_ms": {names[i]: kern[i][0] for i in range(4) if kern[i][1] > 0},
-                         "note": "latency/dependency-bound path (SURVEY.md §8d): HBM fraction is intrinsically small"},
+                         "wasted_traffic_ratio": (traffic / algb[dom]) if traffic else None,
+                         "algorithmic_bytes_include_the_assembly": bool(asm_inside and dom == 2),
+                         "latency_model": latency_model(kern, names),
+                         "note": "latency/dependency-bound path (SURVEY.md §8d): the HBM fraction is intrinsically small; "
+                                 "latency_model states the bounds that apply and the achieved fraction of those"},
         }
         notes = []
         if world > 1:

@@ -1,0 +1,65 @@
+"""The multi-workgroup solver beside a neighbour that saturates the device: an MPC server that
+shares the GPU meets this first.  A second stream keeps every compute unit busy with device-filling kernels
+(element-wise passes over 256 MiB and 4096^2 matrix products) while 600 Gauss-Newton steps run on the context's own
+stream.  The solver's workgroups need their partners resident at the same time (csrc/penta_pipe.h: 5 + 4 (N + 1)
+workgroups that wait for each other); beside a neighbour of many short workgroups the dispatcher places them as
+compute units drain, so the waits must be met long before their 10-50 ms bounds:
+  * every step reproduces the bits of the unloaded device,
+  * no launch reports IDTO_HIP_SOLVER_TIMEOUT (option "solver_timeouts" stays 0, the context does not step down),
+  * no single step takes longer than 5 ms - a wait that had run into its bound would show as >= 10 ms."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from idto_amd import hip
+from idto_amd.model import load_model
+from idto_amd.problem import load_config, make_problem, synthetic_trajectory
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,N", [("mini_cheetah", 40), ("allegro_hand", 60)])
+def test_solver_beside_a_saturating_neighbour(name, N):
+    cfg, model = load_config(name), load_model(name)
+    prob, sp, _ = make_problem(cfg, model, num_steps=N)
+    sp.scaling = sp.equality_constraints = False
+    q = synthetic_trajectory(cfg, model, N, seed=0, lower=0.01)
+    dev = hip.HipPath(model, prob, sp)
+    main = torch.cuda.Stream()
+    dev.set_stream(main.cuda_stream)
+    dev.set_q(q)
+    dev.gn_step()
+    want = dev.get("step")
+    solver0 = dev.get_option("last_solver")
+    assert solver0 in (2, 4)   # a multi-workgroup variant
+
+    side = torch.cuda.Stream()
+    x = torch.rand(32 * 1024 * 1024, device="cuda", dtype=torch.float64)   # 256 MiB
+    a = torch.rand(4096, 4096, device="cuda", dtype=torch.float32)
+    worst, steps, rounds, busy_rounds = 0.0, 0, 0, 0
+    t_end = time.perf_counter() + 60.0
+    while steps < 600 and time.perf_counter() < t_end:
+        with torch.cuda.stream(side):   # ~10 ms of back-to-back device-filling kernels, enqueued ahead
+            for _ in range(12):
+                x = torch.sin(x) * 1.0001 + 0.5
+                a = (a @ a) * 1e-4
+        rounds += 1
+        for _ in range(40):
+            t0 = time.perf_counter()
+            dev.gn_step()
+            got = dev.get("step")   # (synchronises the context's stream; raises on a timeout that the retries did not cure)
+            worst = max(worst, time.perf_counter() - t0)
+            assert np.array_equal(got, want)
+            steps += 1
+        busy_rounds += 0 if side.query() else 1   # the neighbour was still running when the round's last step had finished
+    side.synchronize()
+    assert steps >= 200
+    assert 2 * busy_rounds >= rounds, f"the neighbour outlasted the steps in {busy_rounds} of {rounds} rounds only: not a test of sharing"
+    assert dev.get_option("solver_timeouts") == 0, "a wait between the solver's workgroups ran out beside the neighbour"
+    assert dev.get_option("last_solver") == solver0, "the context stepped down"
+    assert worst < 5e-3, f"slowest step {1e3 * worst:.2f} ms"
+    print(f"{name}: {steps} steps beside the neighbour ({busy_rounds} of {rounds} rounds with the neighbour still busy at their end), "
+          f"slowest {1e3 * worst:.3f} ms, no timeout")
+    dev.close()

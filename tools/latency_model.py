@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""The bounds that actually apply to the two kernels of a Gauss-Newton step - they sit at 0.3 % of the HBM roofline, so
+the HBM fraction of bench.py's `roofline` says nothing actionable - computed from the committed profiles
+of a round and written to profiles/<round>_latency_model.json, which bench.py reads (the newest one) and reports next to
+the kernel times it measures live.
+
+  fd_kernel          VALU issue floor: instructions per wavefront (SQ_INSTS_VALU / SQ_WAVES of <round>_pmc_sq_summary.txt)
+                     x 4 cycles (one wavefront per SIMD; an f64 or a 32-bit VALU instruction occupies the SIMD for 4 cycles:
+                     SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.0 quad-cycles in the same summary) at 2.4 GHz
+  penta_pipe_kernel  (a) the dependent pivot chain: (block rows of the longest chain + the separator's 2) x K pivots x the
+                     measured 80-cycle link (profiles/r03_microbench.txt, tools/micro/chain_bench.hip);
+                     (b) the row model: rows x measured row-to-row time + join + separator + back substitution, all from
+                     the in-kernel stamps of <round>_nd_timeline.txt - what the launch takes if nothing but the rows'
+                     own work is removed
+
+usage: python tools/latency_model.py r04"""
+import csv
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLOCK_MHZ = 2400.0
+PIVOT_LINK_CYCLES = 80   # profiles/r03_microbench.txt: "pivot link of penta_pipe.h: fma, readlane, reciprocal (cubic)"
+
+
+def pmc(path, kernel):
+    out = {}
+    for line in open(path):
+        m = re.match(r"(pmc_sq\d) (\S+) (\{.*\})", line.strip())
+        if m and m.group(2) == kernel:
+            out.update(eval(m.group(3)))
+    return out
+
+
+def kernel_avg_us(path, kernel):
+    for row in csv.DictReader(open(path)):
+        if kernel in row["Name"]:
+            return float(row["AverageNs"]) / 1e3
+    return None
+
+
+def timeline(path):
+    chains, sep = [], None
+    cur = None
+    for line in open(path):
+        m = re.match(r"(P0|P3|J1|J2) (producer|joiner)\s+start\s+([-\d.]+).*forward done\s+([-\d.]+)\s+backward start\s+([-\d.]+)\s+end\s+([-\d.]+)", line)
+        if m:
+            cur = {"name": m.group(1), "role": m.group(2), "start": float(m.group(3)), "forward_done": float(m.group(4)),
+                   "backward_start": float(m.group(5)), "end": float(m.group(6))}
+            chains.append(cur)
+            continue
+        m = re.search(r"elimination of row il \(start, end\):(.*)", line)
+        if m and cur is not None:
+            cur["rows"] = [(float(a), float(b)) for a, b in re.findall(r"\(\s*([-\d.]+),\s*([-\d.]+)\)", m.group(1))]
+        m = re.search(r"median: row to row ([\d.]+) us, the K pivots ([\d.]+) us", line)
+        if m and cur is not None:
+            cur["row_to_row_us"], cur["k_pivots_us"] = float(m.group(1)), float(m.group(2))
+        m = re.search(r"corrected by the separator's solution ([-\d.]+), recursion from ([-\d.]+) to ([-\d.]+)", line)
+        if m and cur is not None:
+            cur["corrected"], cur["recursion_from"], cur["recursion_to"] = (float(m.group(i)) for i in (1, 2, 3))
+        m = re.match(r"separator\s+start\s+([-\d.]+)\s+Q ready\s+([-\d.]+).*solved\+posted\s+([-\d.]+)", line)
+        if m:
+            sep = {"q_ready": float(m.group(2)), "solved": float(m.group(3))}
+    return chains, sep
+
+
+def main():
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+    P = lambda f: os.path.join(ROOT, "profiles", f"{rnd}_{f}")
+    out = {"round": rnd, "clock_mhz": CLOCK_MHZ, "sources": {}}
+    # ---- fd_kernel
+    c = pmc(P("pmc_sq_summary.txt"), "fd_kernel")
+    valu = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
+    fd_us = kernel_avg_us(P("kernel_stats.csv"), "fd_kernel")
+    floor = valu * 4 / CLOCK_MHZ
+    out["fd_kernel"] = {
+        "bound": "VALU issue, one wavefront per SIMD (4 cycles per instruction)",
+        "valu_instructions_per_wavefront": round(valu), "issue_floor_us": floor, "rocprof_avg_us": fd_us,
+        "achieved_frac_of_issue_floor": floor / fd_us if fd_us else None,
+        "wave_cycles_per_wavefront": 4 * c["SQ_WAVE_CYCLES"] / c["SQ_WAVES"],
+        "wait_frac_of_wave_cycles": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
+        "valu_active_frac_of_wave_cycles": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
+    }
+    out["sources"]["fd_kernel"] = [f"profiles/{rnd}_pmc_sq_summary.txt", f"profiles/{rnd}_kernel_stats.csv"]
+    # ---- penta_pipe_kernel
+    chains, sep = timeline(P("nd_timeline.txt"))
+    sol_us = kernel_avg_us(P("kernel_stats_assembly_in_its_own_launch.csv"), "penta_pipe_kernel")
+    K = 19
+    longest = max(chains, key=lambda ch: ch["forward_done"])
+    rows = len(longest["rows"])
+    chain_floor = (rows + 2) * K * PIVOT_LINK_CYCLES / CLOCK_MHZ
+    first_row = longest["rows"][0][0]
+    row_model = first_row + rows * longest["row_to_row_us"] + (sep["q_ready"] - longest["forward_done"]) + (sep["solved"] - sep["q_ready"]) + \
+        (max(ch["end"] for ch in chains) - sep["solved"])
+    out["penta_pipe_kernel"] = {
+        "bound": "dependent block rows of the longest chain, then the separator, then the back substitution",
+        "block_size_K": K, "rows_of_the_longest_chain": rows, "chain": longest["name"],
+        "row_to_row_us": longest["row_to_row_us"], "k_pivots_us": longest["k_pivots_us"],
+        "hand_over_to_separator_us": sep["q_ready"] - longest["forward_done"], "separator_us": sep["solved"] - sep["q_ready"],
+        "back_substitution_us": max(ch["end"] for ch in chains) - sep["solved"],
+        "row_model_us": row_model, "pivot_chain_floor_us": chain_floor, "rocprof_avg_us_solver_alone": sol_us,
+        "achieved_frac_of_row_model": row_model / sol_us if sol_us else None,
+        "achieved_frac_of_pivot_chain_floor": chain_floor / sol_us if sol_us else None,
+    }
+    out["sources"]["penta_pipe_kernel"] = [f"profiles/{rnd}_nd_timeline.txt", f"profiles/{rnd}_kernel_stats_assembly_in_its_own_launch.csv",
+                                           "profiles/r03_microbench.txt"]
+    json.dump(out, open(P("latency_model.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
