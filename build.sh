@@ -16,4 +16,4 @@ wait %1
 $HIPCC --offload-arch=gfx950 -fPIC -shared build/fd_launch.o build/idto_hip.o -o idto_amd/libidto_hip.so -L/opt/rocm/lib -lrccl
 # libidto_opt.so: the host-side TrajectoryOptimizer (C++) + its C-ABI, on top of libidto_hip.so
 g++ -O3 -std=c++17 -fPIC -shared -Wall -Iinclude idto_amd/csrc/host/trajectory_optimizer.cc \
-  idto_amd/csrc/host/idto_opt_c.cc -o idto_amd/libidto_opt.so -Lidto_amd -lidto_hip -Wl,-rpath,'$ORIGIN'
+  idto_amd/csrc/host/mpc_controller.cc idto_amd/csrc/host/idto_opt_c.cc -o idto_amd/libidto_opt.so -Lidto_amd -lidto_hip -Wl,-rpath,'$ORIGIN'

@@ -6,6 +6,7 @@
 #include <memory>
 #include <string>
 
+#include "idto/examples/mpc_controller.h"
 #include "idto/optimizer/trajectory_optimizer.h"
 
 using namespace idto::optimizer;
@@ -16,6 +17,10 @@ struct idto_opt {
 };
 struct idto_opt_warm_start {
   std::unique_ptr<WarmStart> ws;
+};
+struct idto_mpc {
+  std::unique_ptr<idto::examples::mpc::ModelPredictiveController> mpc;
+  idto_opt* opt = nullptr;
 };
 
 namespace {
@@ -233,4 +238,57 @@ int idto_opt_trust_ratio(idto_opt* o, const double* q, const double* dq, double*
   });
 }
 
+
+// ---- model-predictive-control shell
+int idto_mpc_create(idto_opt* opt, const double* warm_q, const double* warm_v, const double* warm_tau, const int* actuated,
+                    const int* q_nom_relative_to_q_init, double replan_period, idto_mpc** out) {
+  return Guard([&] {
+    TrajectoryOptimizerSolution<double> warm;
+    warm.q = Rows(warm_q, opt->N + 1, opt->nq);
+    warm.v = Rows(warm_v, opt->N + 1, opt->nv);
+    warm.tau = Rows(warm_tau, opt->N, opt->nv);
+    std::vector<int> act;
+    if (actuated) act.assign(actuated, actuated + opt->nv);
+    std::vector<bool> sel((size_t)opt->nq, false);
+    if (q_nom_relative_to_q_init)
+      for (int i = 0; i < opt->nq; ++i) sel[i] = q_nom_relative_to_q_init[i] != 0;
+    auto m = std::make_unique<idto_mpc>();
+    m->opt = opt;
+    m->mpc = std::make_unique<idto::examples::mpc::ModelPredictiveController>(opt->to.get(), warm, act, replan_period, sel);
+    *out = m.release();
+  });
+}
+void idto_mpc_destroy(idto_mpc* mpc) { delete mpc; }
+int idto_mpc_num_actuators(const idto_mpc* mpc) { return mpc->mpc->num_actuators(); }
+int idto_mpc_update(idto_mpc* mpc, double time, const double* x0, double* q_guess, double* sol_q, double* sol_v, double* sol_tau,
+                    double* first_cost, int* flag) {
+  return Guard([&] {
+    const idto_opt* o = mpc->opt;
+    if (q_guess) {   // (what UpdateAbstractState is about to use: the stored trajectory shifted to `time`, row 0 = q0)
+      std::vector<VectorXd> g((size_t)o->N + 1, VectorXd((size_t)o->nq));
+      mpc->mpc->UpdateInitialGuess(mpc->mpc->stored_trajectory(), time, &g);
+      g[0].assign(x0, x0 + o->nq);
+      Flat(g, q_guess);
+    }
+    mpc->mpc->UpdateAbstractState(time, VectorXd(x0, x0 + o->nq + o->nv));
+    const auto& sol = mpc->mpc->last_solution();
+    Flat(sol.q, sol_q); Flat(sol.v, sol_v); Flat(sol.tau, sol_tau);
+    const auto& st = mpc->mpc->last_stats();
+    if (first_cost) *first_cost = st.iteration_costs.empty() ? 0.0 : st.iteration_costs[0];
+    if (flag) *flag = 0;
+  });
+}
+int idto_mpc_state(const idto_mpc* mpc, double time, double* x) {
+  return Guard([&] { Flat(idto::examples::mpc::Interpolator::State(mpc->mpc->stored_trajectory(), time), x); });
+}
+int idto_mpc_control(const idto_mpc* mpc, double time, double* u) {
+  return Guard([&] { Flat(idto::examples::mpc::Interpolator::Control(mpc->mpc->stored_trajectory(), time), u); });
+}
+double idto_mpc_start_time(const idto_mpc* mpc) { return mpc->mpc->stored_trajectory().start_time; }
+int idto_mpc_spline_eval(const double* breaks, const double* knots, int n, int dim, const double* times, int nt, double* out) {
+  return Guard([&] {
+    const idto::examples::mpc::PiecewiseCubic sp(std::vector<double>(breaks, breaks + n), Rows(knots, n, dim));
+    for (int i = 0; i < nt; ++i) Flat(sp.value(times[i]), out + (size_t)i * dim);
+  });
+}
 }  // extern "C"

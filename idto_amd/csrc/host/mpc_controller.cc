@@ -1,0 +1,194 @@
+// mpc_controller.cc — include/idto/examples/mpc_controller.h (reference examples/mpc_controller.cc:13-178).
+#include "idto/examples/mpc_controller.h"
+
+#include <algorithm>
+#include <cmath>
+#include <stdexcept>
+
+namespace idto {
+namespace examples {
+namespace mpc {
+
+// ---- PiecewiseCubic: first derivatives m_i at the knots from the linear system of C2 continuity
+//   h_i m_{i-1} + 2 (h_{i-1} + h_i) m_i + h_{i-1} m_{i+1} = 3 (h_i d_{i-1} + h_{i-1} d_i),  d_i = (y_{i+1} - y_i) / h_i
+// closed by the not-a-knot conditions at both ends; one dense LU with partial pivoting (n <= a few hundred knots)
+// serves every component.
+PiecewiseCubic::PiecewiseCubic(const std::vector<double>& breaks, const std::vector<VectorXd>& knots) : t_(breaks) {
+  const int n = (int)breaks.size();
+  if (n < 2 || (int)knots.size() != n) throw std::invalid_argument("PiecewiseCubic: at least two knots, one value per break");
+  dim_ = (int)knots[0].size();
+  for (int i = 0; i + 1 < n; ++i)
+    if (!(breaks[i + 1] > breaks[i])) throw std::invalid_argument("PiecewiseCubic: breaks must increase");
+  y_.assign((size_t)n * dim_, 0.0);
+  m_.assign((size_t)n * dim_, 0.0);
+  for (int i = 0; i < n; ++i) {
+    if ((int)knots[i].size() != dim_) throw std::invalid_argument("PiecewiseCubic: knots of different sizes");
+    for (int c = 0; c < dim_; ++c) y_[(size_t)i * dim_ + c] = knots[i][c];
+  }
+  std::vector<double> h(n - 1);
+  for (int i = 0; i + 1 < n; ++i) h[i] = breaks[i + 1] - breaks[i];
+  auto slope = [&](int i, int c) { return (y_[(size_t)(i + 1) * dim_ + c] - y_[(size_t)i * dim_ + c]) / h[i]; };
+  if (n == 2) {   // the line
+    for (int c = 0; c < dim_; ++c) m_[c] = m_[dim_ + c] = slope(0, c);
+    return;
+  }
+  if (n == 3) {   // the parabola through the three points
+    for (int c = 0; c < dim_; ++c) {
+      const double d0 = slope(0, c), d1 = slope(1, c), a2 = (d1 - d0) / (h[0] + h[1]);
+      m_[c] = d0 - a2 * h[0];
+      m_[dim_ + c] = d0 + a2 * h[0];
+      m_[2 * dim_ + c] = d1 + a2 * h[1];
+    }
+    return;
+  }
+  std::vector<double> A((size_t)n * n, 0.0), B((size_t)n * dim_, 0.0);
+  auto a = [&](int r, int c) -> double& { return A[(size_t)r * n + c]; };
+  for (int i = 1; i + 1 < n; ++i) {
+    a(i, i - 1) = h[i]; a(i, i) = 2 * (h[i - 1] + h[i]); a(i, i + 1) = h[i - 1];
+    for (int c = 0; c < dim_; ++c) B[(size_t)i * dim_ + c] = 3 * (h[i] * slope(i - 1, c) + h[i - 1] * slope(i, c));
+  }
+  {
+    const double d = h[0] + h[1];
+    a(0, 0) = h[1]; a(0, 1) = d;
+    for (int c = 0; c < dim_; ++c) B[c] = ((h[0] + 2 * d) * h[1] * slope(0, c) + h[0] * h[0] * slope(1, c)) / d;
+    const double e = h[n - 2] + h[n - 3];
+    a(n - 1, n - 1) = h[n - 3]; a(n - 1, n - 2) = e;
+    for (int c = 0; c < dim_; ++c)
+      B[(size_t)(n - 1) * dim_ + c] = (h[n - 2] * h[n - 2] * slope(n - 3, c) + (2 * e + h[n - 2]) * h[n - 3] * slope(n - 2, c)) / e;
+  }
+  for (int p = 0; p < n; ++p) {   // Gaussian elimination with partial pivoting, all right-hand sides at once
+    int piv = p;
+    for (int r = p + 1; r < n; ++r)
+      if (std::fabs(a(r, p)) > std::fabs(a(piv, p))) piv = r;
+    if (a(piv, p) == 0.0) throw std::runtime_error("PiecewiseCubic: singular system");
+    if (piv != p) {
+      for (int c = 0; c < n; ++c) std::swap(a(p, c), a(piv, c));
+      for (int c = 0; c < dim_; ++c) std::swap(B[(size_t)p * dim_ + c], B[(size_t)piv * dim_ + c]);
+    }
+    for (int r = p + 1; r < n; ++r) {
+      const double f = a(r, p) / a(p, p);
+      if (f == 0.0) continue;
+      for (int c = p; c < n; ++c) a(r, c) -= f * a(p, c);
+      for (int c = 0; c < dim_; ++c) B[(size_t)r * dim_ + c] -= f * B[(size_t)p * dim_ + c];
+    }
+  }
+  for (int p = n - 1; p >= 0; --p)
+    for (int c = 0; c < dim_; ++c) {
+      double s = B[(size_t)p * dim_ + c];
+      for (int k = p + 1; k < n; ++k) s -= a(p, k) * m_[(size_t)k * dim_ + c];
+      m_[(size_t)p * dim_ + c] = s / a(p, p);
+    }
+}
+
+VectorXd PiecewiseCubic::value(double t) const {
+  if (t_.empty()) throw std::runtime_error("PiecewiseCubic: empty trajectory");
+  const int n = (int)t_.size();
+  t = std::min(std::max(t, t_.front()), t_.back());
+  int i = (int)(std::upper_bound(t_.begin(), t_.end(), t) - t_.begin()) - 1;
+  i = std::min(std::max(i, 0), n - 2);
+  const double h = t_[i + 1] - t_[i], s = t - t_[i];
+  VectorXd out((size_t)dim_);
+  for (int c = 0; c < dim_; ++c) {
+    const double y0 = y_[(size_t)i * dim_ + c], y1 = y_[(size_t)(i + 1) * dim_ + c];
+    const double m0 = m_[(size_t)i * dim_ + c], m1 = m_[(size_t)(i + 1) * dim_ + c];
+    const double d = (y1 - y0) / h;
+    const double c2 = (3 * d - 2 * m0 - m1) / h, c3 = (m0 + m1 - 2 * d) / (h * h);
+    out[c] = y0 + s * (m0 + s * (c2 + s * c3));
+  }
+  return out;
+}
+
+// ---- ModelPredictiveController (mpc_controller.cc:13-41)
+ModelPredictiveController::ModelPredictiveController(TrajectoryOptimizer<double>* optimizer,
+                                                     const TrajectoryOptimizerSolution<double>& warm_start_solution,
+                                                     const std::vector<int>& actuated, double replan_period,
+                                                     const std::vector<bool>& q_nom_relative_to_q_init)
+    : time_step_(optimizer->time_step()),
+      num_steps_(optimizer->num_steps() + 1),
+      nq_(optimizer->num_positions()),
+      nv_(optimizer->num_velocities()),
+      optimizer_(optimizer),
+      warm_start_(optimizer->CreateWarmStart(warm_start_solution.q)),
+      replan_period_(replan_period),
+      selector_override_(q_nom_relative_to_q_init) {
+  for (int j = 0; j < (int)actuated.size() && j < nv_; ++j)
+    if (actuated[j]) actuated_dofs_.push_back(j);
+  if (actuated_dofs_.empty())
+    for (int j = 0; j < nv_; ++j) actuated_dofs_.push_back(j);
+  nu_ = (int)actuated_dofs_.size();
+  StoreOptimizerSolution(warm_start_solution, 0.0, &stored_);
+}
+
+// UpdateAbstractState (:43-85)
+const StoredTrajectory& ModelPredictiveController::UpdateAbstractState(double time, const VectorXd& x0) {
+  const SolverParameters& params = optimizer_->params();
+  const std::vector<bool>& selector = selector_override_.empty() ? params.q_nom_relative_to_q_init : selector_override_;
+  if ((int)selector.size() != nq_)
+    throw std::invalid_argument("q_nom_relative_to_q_init must have one entry per position (mpc_controller.cc:45)");
+  if ((int)x0.size() != nq_ + nv_) throw std::invalid_argument("state estimate must be [q0; v0]");
+  const VectorXd q0(x0.begin(), x0.begin() + nq_), v0(x0.begin() + nq_, x0.end());
+  // the initial guess from the stored solution, consistent with the initial condition (:55-58)
+  std::vector<VectorXd> q_guess((size_t)num_steps_, VectorXd((size_t)nq_));
+  UpdateInitialGuess(stored_, time, &q_guess);
+  q_guess[0] = q0;
+  warm_start_->set_q(q_guess);
+  // shift the nominal trajectory for some DoFs, if requested (:60-69)
+  const ProblemDefinition& prob = optimizer_->prob();
+  const VectorXd q0_nom_old = prob.q_nom[0];
+  std::vector<VectorXd> q_nom_new = prob.q_nom;
+  for (VectorXd& qt_nom : q_nom_new)
+    for (int i = 0; i < nq_; ++i) qt_nom[i] += (selector[i] ? 1.0 : 0.0) * (q0[i] - q0_nom_old[i]);
+  const std::vector<VectorXd> v_nom = prob.v_nom;
+  optimizer_->UpdateNominalTrajectory(q_nom_new, v_nom);
+  // solve from the new initial condition (:71-75)
+  optimizer_->ResetInitialConditions(q0, v0);
+  stats_ = TrajectoryOptimizerStats<double>();
+  solution_ = TrajectoryOptimizerSolution<double>();
+  optimizer_->SolveFromWarmStart(warm_start_.get(), &solution_, &stats_);
+  StoreOptimizerSolution(solution_, time, &stored_);
+  return stored_;
+}
+
+// UpdateInitialGuess (:87-97)
+void ModelPredictiveController::UpdateInitialGuess(const StoredTrajectory& stored_trajectory, double current_time,
+                                                   std::vector<VectorXd>* q_guess) const {
+  if ((int)q_guess->size() != num_steps_) throw std::invalid_argument("UpdateInitialGuess: q_guess must have num_steps + 1 entries");
+  const double start_time = current_time - stored_trajectory.start_time;
+  for (int i = 0; i < num_steps_; ++i) (*q_guess)[i] = stored_trajectory.q.value(start_time + i * time_step_);
+}
+
+// StoreOptimizerSolution (:99-138)
+void ModelPredictiveController::StoreOptimizerSolution(const TrajectoryOptimizerSolution<double>& solution, double start_time,
+                                                       StoredTrajectory* stored_trajectory) const {
+  if ((int)solution.q.size() < num_steps_ || (int)solution.v.size() < num_steps_ || (int)solution.tau.size() < num_steps_ - 1)
+    throw std::invalid_argument("StoreOptimizerSolution: solution shorter than the horizon");
+  std::vector<double> time_steps;
+  std::vector<VectorXd> q_knots, v_knots, u_knots;
+  for (int i = 0; i < num_steps_; ++i) {
+    time_steps.push_back(i * time_step_);
+    q_knots.push_back(solution.q[i]);
+    v_knots.push_back(solution.v[i]);
+    // control inputs, which are undefined at the last time step (:122-126): u = B^T tau
+    const VectorXd& tau = solution.tau[i == num_steps_ - 1 ? i - 1 : i];
+    VectorXd u((size_t)nu_);
+    for (int j = 0; j < nu_; ++j) u[j] = tau[actuated_dofs_[j]];
+    u_knots.push_back(u);
+  }
+  stored_trajectory->start_time = start_time;
+  stored_trajectory->q = PiecewiseCubic(time_steps, q_knots);
+  stored_trajectory->v = PiecewiseCubic(time_steps, v_knots);
+  stored_trajectory->u = PiecewiseCubic(time_steps, u_knots);
+}
+
+// Interpolator::SendState / SendControl (:163-178)
+VectorXd Interpolator::State(const StoredTrajectory& traj, double time) {
+  VectorXd x = traj.q.value(time - traj.start_time);
+  const VectorXd v = traj.v.value(time - traj.start_time);
+  x.insert(x.end(), v.begin(), v.end());
+  return x;
+}
+VectorXd Interpolator::Control(const StoredTrajectory& traj, double time) { return traj.u.value(time - traj.start_time); }
+
+}  // namespace mpc
+}  // namespace examples
+}  // namespace idto

@@ -645,6 +645,10 @@ __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCf
           double mu0[K];
 #pragma unroll
           for (int r = 0; r < K; ++r) mu0[r] = 0.0;
+          // (s_setprio 3 for the eliminating wavefront while it holds the role - VERDICT r3 #3 - was measured and dropped:
+          // its K pivots stay at 1.96 us - the wavefront is bound by its own dependent chain and its LDS round trips, not
+          // by lost issue slots - and the followers it starves make a joiner's row 3.36 -> 3.80 us:
+          // profiles/r04_setprio_experiment.txt)
           pipe_pivot<K, 0, R::JH>(xr, pipe_rcp(rdlane(xr[0], 0)), mu0, 0.0, rowp, ring + slot * G::SLOT + rawpos, ring + slot * G::SLOT,
                                   lane == 63, high_rows, (cfg.ts && il == 3 && lane == 0) ? cfg.ts + 16 : nullptr);
         }

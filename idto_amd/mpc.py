@@ -4,6 +4,13 @@ the last solution, stored as cubic splines, is time-shifted into the initial gue
 trajectory is shifted for the DoFs marked `q_nom_relative_to_q_init`, the initial condition is
 reset and `SolveFromWarmStart` runs `mpc_iters` iterations from the previous trust-region
 radius.  Drake's LeafSystem plumbing (ports, abstract state) is replaced by plain method calls.
+
+Two implementations of the same shell:
+  * `DeviceModelPredictiveController` - the product: the C++ class of include/idto/examples/mpc_controller.h inside
+    libidto_opt.so through the C-ABI (idto_mpc_* of include/idto_opt.h);
+  * `ModelPredictiveController` / `Interpolator` - the same logic in numpy / scipy over the Python optimizer binding; the
+    tests hold the C++ shell against it (scipy's not-a-knot CubicSpline is the independent spline).
+Both clamp the query time to the stored trajectory's time range, as Drake's PiecewisePolynomial::value does.
 """
 from __future__ import annotations
 
@@ -49,6 +56,7 @@ class ModelPredictiveController:
             raise ValueError("q_nom_relative_to_q_init must have one entry per position (mpc_controller.cc:45)")
         q_guess = self.update_initial_guess(self.stored, t)
         q_guess[0] = q0                      # the guess must be consistent with the initial condition
+        self._last_guess = np.array(q_guess)
         self.warm_start.set_q(q_guess)
         q_nom = np.asarray(prob.q_nom, float)
         q_nom_new = q_nom + sel * (q0 - q_nom[0])           # (:62-69)
@@ -64,7 +72,7 @@ class ModelPredictiveController:
     def update_initial_guess(self, stored: StoredTrajectory, current_time: float):
         start = current_time - stored.start_time
         ts = start + self.time_step * np.arange(self.num_steps)
-        return np.asarray(stored.q(ts), float)
+        return np.asarray(stored.q(_clamp(stored.q, ts)), float)
 
     # StoreOptimizerSolution (:99-138): cubic splines with continuous second derivatives
     # (Drake's default end condition is not-a-knot, scipy's default too)
@@ -80,14 +88,94 @@ class ModelPredictiveController:
         stored.u = CubicSpline(ts, u[:n], bc_type=bc)
 
 
+def _clamp(spline, t):
+    """PiecewisePolynomial::value evaluates at the closest point of the trajectory's time range"""
+    return np.clip(t, spline.x[0], spline.x[-1])
+
+
 class Interpolator:
     """reference examples/mpc_controller.cc:140-178: x(t) and u(t) of a stored trajectory"""
 
     @staticmethod
     def state(traj: StoredTrajectory, t: float):
         s = t - traj.start_time
-        return np.concatenate([traj.q(s), traj.v(s)])
+        return np.concatenate([traj.q(_clamp(traj.q, s)), traj.v(_clamp(traj.v, s))])
 
     @staticmethod
     def control(traj: StoredTrajectory, t: float):
-        return np.asarray(traj.u(t - traj.start_time), float)
+        return np.asarray(traj.u(_clamp(traj.u, t - traj.start_time)), float)
+
+
+class DeviceModelPredictiveController:
+    """idto::examples::mpc::ModelPredictiveController + Interpolator of libidto_opt.so (include/idto_opt.h idto_mpc_*).
+    `optimizer`: an idto_amd.optimizer.TrajectoryOptimizer whose max_iterations is the example's mpc_iters."""
+
+    def __init__(self, optimizer, warm_start_solution, actuated=None, q_nom_relative_to_q_init=None, replan_period=0.0):
+        import ctypes as C
+        from . import optimizer as O
+        self._O, self._C = O, C
+        self.opt = optimizer
+        prob = optimizer.prob()
+        self.N, self.nq, self.nv = optimizer.num_steps(), len(prob.q_init), len(prob.v_init)
+        q, v, tau = (O._d(x) for x in (warm_start_solution.q, warm_start_solution.v, warm_start_solution.tau))
+        act = None if actuated is None else np.ascontiguousarray(np.asarray(actuated, dtype=np.int32))
+        sel = q_nom_relative_to_q_init
+        if sel is None:
+            sel = optimizer.params().q_nom_relative_to_q_init
+        sel = None if sel is None or len(sel) == 0 else np.ascontiguousarray(np.asarray(sel, dtype=np.int32))
+        ip = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_int))
+        h = C.c_void_p()
+        self._chk(O.lib().idto_mpc_create(optimizer._h, O.dptr(q), O.dptr(v), O.dptr(tau), ip(act), ip(sel),
+                                          float(replan_period), C.byref(h)))
+        self._h = h
+        self.nu = O.lib().idto_mpc_num_actuators(self._h)
+        self.last_cost = None
+
+    def _chk(self, rc):
+        if rc:
+            raise RuntimeError(self._O.lib().idto_opt_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._O.lib().idto_mpc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def update(self, t, q0, v0):
+        """UpdateAbstractState: returns (q_guess, q, v, tau) of this replan"""
+        O, C = self._O, self._C
+        x0 = O._d(np.concatenate([q0, v0]))
+        g = np.zeros((self.N + 1, self.nq)); q = np.zeros((self.N + 1, self.nq)); v = np.zeros((self.N + 1, self.nv))
+        tau = np.zeros((self.N, self.nv))
+        cost, flag = C.c_double(), C.c_int()
+        self._chk(O.lib().idto_mpc_update(self._h, float(t), O.dptr(x0), O.dptr(g), O.dptr(q), O.dptr(v), O.dptr(tau),
+                                          C.byref(cost), C.byref(flag)))
+        self.last_cost = cost.value
+        return g, q, v, tau
+
+    @property
+    def start_time(self):
+        return self._O.lib().idto_mpc_start_time(self._h)
+
+    def state(self, t):
+        x = np.zeros(self.nq + self.nv)
+        self._chk(self._O.lib().idto_mpc_state(self._h, float(t), self._O.dptr(x)))
+        return x
+
+    def control(self, t):
+        u = np.zeros(self.nu)
+        self._chk(self._O.lib().idto_mpc_control(self._h, float(t), self._O.dptr(u)))
+        return u
+
+
+def spline_eval(breaks, knots, times):
+    """PiecewiseCubic of include/idto/examples/mpc_controller.h (C++, host only): values at `times`"""
+    from . import optimizer as O
+    breaks, knots, times = O._d(breaks), O._d(knots), O._d(np.atleast_1d(times))
+    n, dim = knots.shape
+    out = np.zeros((len(times), dim))
+    if O.lib().idto_mpc_spline_eval(O.dptr(breaks), O.dptr(knots), n, dim, O.dptr(times), len(times), O.dptr(out)):
+        raise RuntimeError(O.lib().idto_opt_last_error().decode())
+    return out

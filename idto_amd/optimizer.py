@@ -54,6 +54,16 @@ def lib():
         L.idto_opt_eval.argtypes = [C.c_void_p, P, P, P, P, P, P, P, P]
         L.idto_opt_dogleg.argtypes = [C.c_void_p, P, C.c_double, P, P, C.POINTER(C.c_int)]
         L.idto_opt_trust_ratio.argtypes = [C.c_void_p, P, P, P]
+        I = C.POINTER(C.c_int)
+        L.idto_mpc_create.argtypes = [C.c_void_p, P, P, P, I, I, C.c_double, C.POINTER(C.c_void_p)]
+        L.idto_mpc_destroy.argtypes = [C.c_void_p]
+        L.idto_mpc_num_actuators.argtypes = [C.c_void_p]
+        L.idto_mpc_update.argtypes = [C.c_void_p, C.c_double, P, P, P, P, P, P, I]
+        L.idto_mpc_state.argtypes = [C.c_void_p, C.c_double, P]
+        L.idto_mpc_control.argtypes = [C.c_void_p, C.c_double, P]
+        L.idto_mpc_start_time.argtypes = [C.c_void_p]
+        L.idto_mpc_start_time.restype = C.c_double
+        L.idto_mpc_spline_eval.argtypes = [P, P, C.c_int, C.c_int, P, C.c_int, P]
         _lib = L
     return _lib
 
@@ -64,6 +74,8 @@ EXPORTED_SYMBOLS = [
     "idto_opt_ws_set_q", "idto_opt_ws_get", "idto_opt_ws_solve", "idto_opt_reset_initial_conditions",
     "idto_opt_update_nominal_trajectory", "idto_opt_eval", "idto_opt_dogleg", "idto_opt_trust_ratio",
 ]
+MPC_SYMBOLS = ["idto_mpc_create", "idto_mpc_destroy", "idto_mpc_num_actuators", "idto_mpc_update", "idto_mpc_state",
+               "idto_mpc_control", "idto_mpc_start_time", "idto_mpc_spline_eval"]
 
 
 def _d(a):

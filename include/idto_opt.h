@@ -66,6 +66,29 @@ int idto_opt_eval(idto_opt* opt, const double* q, double* cost, double* gradient
 int idto_opt_dogleg(idto_opt* opt, const double* q, double Delta, double* dq, double* dqH, int* active);
 int idto_opt_trust_ratio(idto_opt* opt, const double* q, const double* dq, double* rho);
 
+/* ---- the model-predictive-control shell (include/idto/examples/mpc_controller.h; reference examples/mpc_controller.h:59-214,
+ * mpc_controller.cc:13-178).  The optimizer handed in is the controller's (params.max_iterations = the example's mpc_iters) and
+ * must outlive it. */
+typedef struct idto_mpc idto_mpc;
+/* ModelPredictiveController(diagram, plant, prob, warm_start_solution, params, replan_period) (mpc_controller.cc:13-41).
+ * warm_q / warm_v: (N+1)*nq, (N+1)*nv; warm_tau: N*nv; actuated: nv flags (NULL: every DoF); q_nom_relative_to_q_init: nq flags
+ * (SolverParameters::q_nom_relative_to_q_init, solver_parameters.h:166; NULL: none). */
+int idto_mpc_create(idto_opt* opt, const double* warm_q, const double* warm_v, const double* warm_tau, const int* actuated,
+                    const int* q_nom_relative_to_q_init, double replan_period, idto_mpc** out);
+void idto_mpc_destroy(idto_mpc* mpc);
+int idto_mpc_num_actuators(const idto_mpc* mpc);
+/* UpdateAbstractState (mpc_controller.cc:43-85): replan at `time` from the state estimate x0 = [q0; v0]; outputs (any may be
+ * NULL): the initial guess that was used ((N+1)*nq), the solution, the cost of the first iteration, the solver flag. */
+int idto_mpc_update(idto_mpc* mpc, double time, const double* x0, double* q_guess, double* sol_q, double* sol_v, double* sol_tau,
+                    double* first_cost, int* flag);
+/* Interpolator::SendState / SendControl (mpc_controller.cc:163-178) on the stored trajectory: x = [q(t); v(t)], u(t) */
+int idto_mpc_state(const idto_mpc* mpc, double time, double* x);
+int idto_mpc_control(const idto_mpc* mpc, double time, double* u);
+double idto_mpc_start_time(const idto_mpc* mpc);
+/* PiecewisePolynomial::CubicWithContinuousSecondDerivatives(breaks, knots).value(t) (host only; exported for tests): n knots of
+ * `dim` components at `breaks`, evaluated at nt times (clamped to the breaks' range); out: nt*dim. */
+int idto_mpc_spline_eval(const double* breaks, const double* knots, int n, int dim, const double* times, int nt, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,10 @@ def test_optimizer_header_symbols_are_exported():
     for s in declared:
         assert hasattr(L, s), f"{s} declared in include/idto_opt.h but not exported"
     assert sorted(optimizer.EXPORTED_SYMBOLS) == declared
+    mpc = sorted(set(re.findall(r"\b(idto_mpc_[a-z_0-9]+)\s*\(", text)))   # the model-predictive-control shell
+    for s in mpc:
+        assert hasattr(L, s), f"{s} declared in include/idto_opt.h but not exported"
+    assert sorted(optimizer.MPC_SYMBOLS) == mpc
 
 
 def test_optimizer_has_no_cpu_fallback_without_gpu():
