@@ -13,6 +13,8 @@
 #include <cstring>
 #include <initializer_list>
 #include <limits>
+#include <memory>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -48,8 +50,52 @@ struct DevBuf {
 };
 }  // namespace
 
+// Host copies of what a context was created from: a batch context builds single-problem child contexts from them for
+// the trust-region loop with ENFORCED CONSTRAINTS (idto_hip_tr_solve_batch_constrained)
+struct HostModelCopy {
+  idto_model_t m;
+  std::vector<int> parent, jtype, qstart, vstart, actuated, geom_body, geom_type, pair_a, pair_b, body_path, pair_path;
+  std::vector<double> X_PF, axis, mass, com, inertia, damping, geom_X, geom_size;
+  void Set(const idto_model_t& s) {
+    m = s;
+    const int nb = s.nbodies, ng = s.ngeoms, np = s.npairs;
+    auto ci = [](const int* p, size_t n) { return p ? std::vector<int>(p, p + n) : std::vector<int>(); };
+    auto cd = [](const double* p, size_t n) { return p ? std::vector<double>(p, p + n) : std::vector<double>(); };
+    parent = ci(s.parent, nb); jtype = ci(s.jtype, nb); qstart = ci(s.qstart, nb); vstart = ci(s.vstart, nb);
+    actuated = ci(s.actuated, s.nv); geom_body = ci(s.geom_body, ng); geom_type = ci(s.geom_type, ng);
+    pair_a = ci(s.pair_a, np); pair_b = ci(s.pair_b, np); body_path = ci(s.body_path, nb); pair_path = ci(s.pair_path, np);
+    X_PF = cd(s.X_PF, (size_t)12 * nb); axis = cd(s.axis, (size_t)3 * nb); mass = cd(s.mass, nb); com = cd(s.com, (size_t)3 * nb);
+    inertia = cd(s.inertia, (size_t)6 * nb); damping = cd(s.damping, s.nv); geom_X = cd(s.geom_X, (size_t)12 * ng);
+    geom_size = cd(s.geom_size, (size_t)3 * ng);
+    m.parent = parent.data(); m.jtype = jtype.data(); m.qstart = qstart.data(); m.vstart = vstart.data();
+    m.actuated = actuated.empty() ? nullptr : actuated.data(); m.geom_body = geom_body.data(); m.geom_type = geom_type.data();
+    m.pair_a = pair_a.data(); m.pair_b = pair_b.data(); m.body_path = body_path.data(); m.pair_path = pair_path.data();
+    m.X_PF = X_PF.data(); m.axis = axis.data(); m.mass = mass.data(); m.com = com.data(); m.inertia = inertia.data();
+    m.damping = damping.data(); m.geom_X = geom_X.data(); m.geom_size = geom_size.data();
+  }
+};
+struct HostProblemCopy {
+  idto_problem_t p;
+  std::vector<double> q_init, v_init, Qq, Qv, Qf_q, Qf_v, R, q_nom, v_nom;
+  void Set(const idto_problem_t& s, int nq, int nv) {
+    p = s;
+    const size_t N1 = (size_t)s.num_steps + 1;
+    auto cd = [](const double* x, size_t n) { return x ? std::vector<double>(x, x + n) : std::vector<double>(n, 0.0); };
+    q_init = cd(s.q_init, nq); v_init = cd(s.v_init, nv); Qq = cd(s.Qq, (size_t)nq * nq); Qv = cd(s.Qv, (size_t)nv * nv);
+    Qf_q = cd(s.Qf_q, (size_t)nq * nq); Qf_v = cd(s.Qf_v, (size_t)nv * nv); R = cd(s.R, (size_t)nv * nv);
+    q_nom = cd(s.q_nom, N1 * nq); v_nom = cd(s.v_nom, N1 * nv);
+    p.q_init = q_init.data(); p.v_init = v_init.data(); p.Qq = Qq.data(); p.Qv = Qv.data(); p.Qf_q = Qf_q.data();
+    p.Qf_v = Qf_v.data(); p.R = R.data(); p.q_nom = q_nom.data(); p.v_nom = v_nom.data();
+  }
+};
+
 struct idto_hip_ctx {
   int device = 0;
+  // (batch contexts) what the context was created from, and one single-problem context per problem, made on first use
+  std::unique_ptr<HostModelCopy> host_model;
+  std::vector<std::unique_ptr<HostProblemCopy>> host_problems;
+  idto_contact_params_t host_contact{};
+  std::vector<idto_hip_ctx*> children;
   // batch: `batch` problems of the same model / horizon, one arena each (identical layout,
   // `pstride` bytes apart); the pointers below address problem 0
   int batch = 1;
@@ -684,6 +730,15 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   const int nq = c->nq, nv = c->nv, N = c->N;
   int rc = BuildModel(c, model);
   if (rc) { idto_hip_destroy(c); return rc; }
+  if (batch > 1) {
+    c->host_model = std::make_unique<HostModelCopy>();
+    c->host_model->Set(*model);
+    for (int b = 0; b < batch; ++b) {
+      c->host_problems.push_back(std::make_unique<HostProblemCopy>());
+      c->host_problems.back()->Set(problems[b], model->nq, model->nv);
+    }
+    c->host_contact = *contact;
+  }
   c->cp.k = contact->contact_stiffness; c->cp.vd = contact->dissipation_velocity;
   c->cp.vs = contact->stiction_velocity; c->cp.mu = contact->friction_coefficient;
   c->cp.sigma = contact->smoothing_factor;
@@ -877,6 +932,8 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
 
 void idto_hip_destroy(idto_hip_ctx* c) {
   if (!c) return;
+  for (idto_hip_ctx* ch : c->children) idto_hip_destroy(ch);
+  c->children.clear();
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
@@ -903,6 +960,13 @@ int idto_hip_set_problem_batch(idto_hip_ctx* c, int b, const idto_problem_t* p) 
   HIP_OK(hipSetDevice(c->device));
   c->fd_full = false;  // v_0 = v_init
   c->con_ready = false; c->con_begun = false;
+  if (b < (int)c->host_problems.size()) {
+    c->host_problems[b]->Set(*p, c->nq, c->nv);
+    if (b < (int)c->children.size() && c->children[b]) {
+      const int rc = idto_hip_set_problem_batch(c->children[b], 0, &c->host_problems[b]->p);
+      if (rc) return rc;
+    }
+  }
   return UploadProblemArrays(c, p, b);
 }
 
@@ -1924,6 +1988,67 @@ int idto_hip_tr_solve_batch(idto_hip_ctx* c, int iterations, int scaling_method,
   if (!Delta0 || !rows_host) { g_err = "tr_solve_batch: Delta0[batch] and rows_host[batch][iterations][IDTO_TR_ROW] are required"; return -1; }
   return TrSolve(c, iterations, scaling_method, scaling, normalize_quaternions, Delta0, Delta_max, eta, nullptr, 0, rows_host,
                  Delta_out);
+}
+
+// The trust-region loop with ENFORCED equality constraints for every problem of a batch context (BASELINE config 5:
+// examples/allegro_hand/allegro_hand.yaml:95 `equality_constraints : true`; reference TO.cc:1267-1396, :2495-2625).
+// The multiplier chain of an iteration - H^-1 [g | J^T] for n_eq + 1 right-hand sides, S = J H^-1 J^T, its dense
+// factorisation, the step - is a sequence of single-problem launches with buffers of its own (constraints.h, dense_ldl.h,
+// penta_apply.h), so the batch runs as one single-problem context per problem (created on first use from the host copies
+// of the model and the problems), each advanced by idto_hip_tr_solve on a stream and a host thread of its own: the
+// problems' launches overlap on the device, every problem's rows are bit for bit what idto_hip_tr_solve gives it alone,
+// and the iterates are written back into the batch's arenas.
+int idto_hip_tr_solve_batch_constrained(idto_hip_ctx* c, int iterations, int scaling_method, int scaling, int normalize_quaternions,
+                                        const double* Delta0, double Delta_max, double eta, const int* constrained_dofs, int nu,
+                                        double* rows_host, double* Delta_out) {
+  if (!Delta0 || !rows_host) { g_err = "tr_solve_batch_constrained: Delta0[batch] and rows_host[batch][iterations][IDTO_TR_ROW] are required"; return -1; }
+  if (nu <= 0 || !constrained_dofs)
+    return idto_hip_tr_solve_batch(c, iterations, scaling_method, scaling, normalize_quaternions, Delta0, Delta_max, eta, rows_host, Delta_out);
+  const int B = c->batch;
+  if (B == 1)
+    return TrSolve(c, iterations, scaling_method, scaling, normalize_quaternions, Delta0, Delta_max, eta, constrained_dofs, nu, rows_host, Delta_out);
+  if (!c->host_model) { g_err = "tr_solve_batch_constrained: the context keeps no host copy of its model"; return -1; }
+  HIP_OK(hipSetDevice(c->device));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  c->children.resize((size_t)B, nullptr);
+  for (int b = 0; b < B; ++b) {
+    if (c->children[b]) continue;
+    idto_hip_ctx* ch = nullptr;
+    const int rc = idto_hip_create(&c->host_model->m, &c->host_problems[b]->p, &c->host_contact, c->device, &ch);
+    if (rc) return rc;
+    ch->gradients_method = c->gradients_method; ch->fd_fast = c->fd_fast; ch->asm_fold = c->asm_fold;
+    ch->solver_pipe = c->solver_pipe; ch->solver_nd = c->solver_nd; ch->two_sided = c->two_sided; ch->fused = c->fused;
+    ch->reference_solver = c->reference_solver;
+    c->children[b] = ch;
+  }
+  const size_t qbytes = (size_t)(c->N + 1) * c->nq * sizeof(double), row = (size_t)iterations * TRR_COUNT;
+  std::vector<int> rcs((size_t)B, 0);
+  std::vector<std::string> errs((size_t)B);
+  auto work = [&](int b) {
+    idto_hip_ctx* ch = c->children[b];
+    auto fail = [&](int rc, const char* what) { rcs[b] = rc; errs[b] = g_err.empty() ? what : g_err; };
+    if (hipSetDevice(c->device) != hipSuccess) return fail(-2, "hipSetDevice failed");
+    ch->tr_conv_on = false;
+    if (hipMemcpyAsync(ch->q, at_problem(c->q, (size_t)b * c->pstride), qbytes, hipMemcpyDeviceToDevice, ch->stream) != hipSuccess)
+      return fail(-2, "copy of the problem's q failed");
+    ch->fd_full = false; ch->con_ready = false; ch->con_begun = false; ch->trial_resident = false;
+    int rc = idto_hip_eval_tau(ch);
+    if (rc) return fail(rc, "eval_tau failed");
+    rc = TrSolve(ch, iterations, scaling_method, scaling, normalize_quaternions, Delta0 + b, Delta_max, eta, constrained_dofs, nu,
+                 rows_host + (size_t)b * row, Delta_out ? Delta_out + b : nullptr);
+    if (rc) return fail(rc, "tr_solve failed");
+    if (hipMemcpyAsync(at_problem(c->q, (size_t)b * c->pstride), ch->q, qbytes, hipMemcpyDeviceToDevice, ch->stream) != hipSuccess ||
+        hipStreamSynchronize(ch->stream) != hipSuccess)
+      return fail(-2, "copy of the iterate failed");
+  };
+  std::vector<std::thread> threads;
+  for (int b = 1; b < B; ++b) threads.emplace_back(work, b);
+  work(0);
+  for (auto& t : threads) t.join();
+  c->fd_full = false; c->trial_resident = false; c->con_ready = false; c->con_begun = false;   // q of every problem moved
+  for (int b = 0; b < B; ++b)
+    if (rcs[b]) { g_err = "problem " + std::to_string(b) + ": " + errs[b]; return rcs[b]; }
+  return 0;
 }
 
 #define NCCL_OK(expr)                                                                 \

@@ -64,6 +64,9 @@ def lib():
                                         C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.idto_hip_tr_solve_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_double,
                                               C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.idto_hip_tr_solve_batch_constrained.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                                          C.c_double, C.c_double, C.POINTER(C.c_int), C.c_int,
+                                                          C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.idto_hip_tr_reject.argtypes = [C.c_void_p]
         L.idto_hip_tr_set_scale_memory.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.idto_hip_tr_set_convergence.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
@@ -115,7 +118,7 @@ EXPORTED_SYMBOLS = [
     "idto_hip_device_ptr", "idto_hip_array_size", "idto_hip_slab_stride", "idto_hip_math_probe",
     "idto_hip_solver_status", "idto_hip_create_batch", "idto_hip_batch_size", "idto_hip_set_problem_batch",
     "idto_hip_set_q_batch", "idto_hip_gn_step_batch", "idto_hip_get_batch", "idto_hip_solver_status_batch",
-    "idto_hip_tr_prepare", "idto_hip_tr_trial", "idto_hip_tr_accept", "idto_hip_tr_reject", "idto_hip_tr_set_scale_memory", "idto_hip_tr_set_convergence", "idto_hip_tr_solve", "idto_hip_tr_solve_batch", "idto_hip_set_unactuated_dofs",
+    "idto_hip_tr_prepare", "idto_hip_tr_trial", "idto_hip_tr_accept", "idto_hip_tr_reject", "idto_hip_tr_set_scale_memory", "idto_hip_tr_set_convergence", "idto_hip_tr_solve", "idto_hip_tr_solve_batch", "idto_hip_tr_solve_batch_constrained", "idto_hip_set_unactuated_dofs",
     "idto_hip_rccl_info", "idto_hip_comm_unique_id", "idto_hip_comm_init", "idto_hip_comm_init_all", "idto_hip_comm_destroy",
     "idto_hip_allgather_slab", "idto_hip_gn_step_sharded", "idto_hip_gn_step_multi", "idto_hip_eval_partials_multi",
 ]
@@ -279,6 +282,20 @@ class HipPath:
         self.last_tr_rows = rows
         _chk(lib().idto_hip_tr_solve_batch(self.h, int(iterations), int(scaling_method), int(scaling), int(normalize_quaternions),
                                            dptr(d0), float(Delta_max), float(eta), dptr(rows), dptr(delta)))
+        return rows, delta
+
+    def tr_solve_batch_constrained(self, iterations: int, scaling_method: int, scaling: bool, normalize_quaternions: bool, Delta0,
+                                   Delta_max: float, constrained_dofs, eta: float = 0.0):
+        """idto_hip_tr_solve_batch_constrained: the batch's loop with the equality constraints enforced on `constrained_dofs`"""
+        B = self.batch
+        rows = np.zeros((B, int(iterations), 17))
+        d0 = np.ascontiguousarray(np.broadcast_to(np.asarray(Delta0, dtype=np.float64), (B,)))
+        delta = np.zeros(B)
+        dofs = np.ascontiguousarray(np.asarray(constrained_dofs, dtype=np.int32))
+        self.last_tr_rows = rows
+        _chk(lib().idto_hip_tr_solve_batch_constrained(self.h, int(iterations), int(scaling_method), int(scaling),
+                                                       int(normalize_quaternions), dptr(d0), float(Delta_max), float(eta),
+                                                       dofs.ctypes.data_as(C.POINTER(C.c_int)), len(dofs), dptr(rows), dptr(delta)))
         return rows, delta
 
     def tr_set_convergence(self, tolerances=None):

@@ -282,12 +282,23 @@ int idto_hip_tr_solve(idto_hip_ctx* ctx, int iterations, int scaling_method, int
 /* The same loop for every problem of a batch context at once (idto_hip_create_batch): one launch set per iteration
  * with grid.y = problem, one host thread, one wait - the call pattern of an MPC server that advances several
  * warm-started problems per tick (reference examples/mpc_controller.cc:43-85, BASELINE config 5).  Every problem keeps
- * its own radius, accepts or rejects on its own, and idles on its own flags; no equality constraints (nu = 0).
+ * its own radius, accepts or rejects on its own, and idles on its own flags; no equality constraints (nu = 0; with constraints:
+ * idto_hip_tr_solve_batch_constrained).
  * Delta0[batch], Delta_out[batch] (may be NULL); rows_host[batch][iterations][IDTO_TR_ROW]: problem b's rows are
  * what idto_hip_tr_solve returns for the same problem in a context of its own, bit for bit.  Every problem's q must
  * be resident with its cost evaluated (idto_hip_set_q_batch + idto_hip_eval_tau). */
 int idto_hip_tr_solve_batch(idto_hip_ctx* ctx, int iterations, int scaling_method, int scaling, int normalize_quaternions,
                             const double* Delta0, double Delta_max, double eta, double* rows_host, double* Delta_out);
+/* ... with ENFORCED equality constraints on the `nu` degrees of freedom `constrained_dofs` (the unactuated ones:
+ * h = tau[unactuated] = 0, reference TO.cc:1267-1396; BASELINE config 5's own YAML enforces them,
+ * examples/allegro_hand/allegro_hand.yaml:95).  The multiplier chain of an iteration is a sequence of single-problem
+ * launches, so every problem of the batch is advanced by idto_hip_tr_solve in a single-problem context of its own
+ * (created on first use inside this context) on its own stream and host thread: the problems' launches overlap on the
+ * device; rows and iterates are, bit for bit, those of idto_hip_tr_solve on the same problem alone.  nu = 0 forwards to
+ * idto_hip_tr_solve_batch.  Same residency requirement: every problem's q set (idto_hip_set_q_batch). */
+int idto_hip_tr_solve_batch_constrained(idto_hip_ctx* ctx, int iterations, int scaling_method, int scaling,
+                                        int normalize_quaternions, const double* Delta0, double Delta_max, double eta,
+                                        const int* constrained_dofs, int nu, double* rows_host, double* Delta_out);
 
 /* Options: "gradients_method" = 0 forward differences (default), 1 / 2 central differences of
  * 2nd / 4th order (SolverParameters::gradients_method, reference solver_parameters.h:26-50,

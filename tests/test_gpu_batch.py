@@ -148,3 +148,52 @@ def test_trust_region_loop_of_a_batch_equals_the_single_problem_loops(name, N, B
         assert _same(bd.get("step", problem=b), dev.get("step")), b
         dev.close()
     bd.close()
+
+
+@pytest.mark.parametrize("name,N,B,iters,method", [("allegro_hand", 60, 8, 3, "double_sqrt"), ("hopper", 20, 3, 8, "double_sqrt"),
+                                                   ("spinner", 20, 4, 8, None)])
+def test_constrained_trust_region_loop_of_a_batch_equals_the_single_problem_loops(name, N, B, iters, method):
+    """idto_hip_tr_solve_batch_constrained: the batch's trust-region loop with the equality constraints ENFORCED on the
+    unactuated degrees of freedom (h = tau[unactuated] = 0 and its multipliers, reference TO.cc:1267-1396) - what BASELINE
+    config 5 iterates (examples/allegro_hand/allegro_hand.yaml:95).  Rows, final radius and final iterate of every problem ==
+    those of idto_hip_tr_solve with the same constraints on the same problem in a context of its own; the multiplier chain
+    did run (h, column 8 of the rows, is reported and falls)."""
+    from idto_amd.problem import SCALING
+    model, probs, sp, qs = _problems(name, N, B)
+    dofs = list(model.unactuated_dofs)
+    assert len(dofs) > 0
+    sm = SCALING[method] if method else -1
+    d0 = np.array([1e-1 * (1 + 0.5 * b) for b in range(B)])
+    want = []
+    for b in range(B):
+        dev = hip.HipPath(model, probs[b], sp)
+        dev.set_q(qs[b])
+        dev.eval_tau()
+        rows, delta = dev.tr_solve(iters, sm, method is not None, False, d0[b], 1e5, constrained_dofs=dofs)
+        want.append((rows, delta, dev.get("q")))
+        dev.close()
+    bd = hip.HipPath(model, probs, sp)
+    bd.set_q_batch(qs)
+    for rep in range(2):   # (the second call reuses the per-problem contexts)
+        if rep:
+            bd.set_q_batch(qs)
+        rows, delta = bd.tr_solve_batch_constrained(iters, sm, method is not None, False, d0, 1e5, dofs)
+        accepted = 0
+        for b in range(B):
+            r0, d, q = want[b]
+            cols = [c for c in range(17) if c != 10]   # (column 10 is the device clock)
+            assert np.array_equal(rows[b][:, cols], r0[:, cols]), (rep, b, rows[b][:, :3], r0[:, :3])
+            assert delta[b] == d
+            assert _same(bd.get("q", problem=b), q)
+            assert np.all(np.isfinite(r0[:, 8])) and r0[0, 8] > 0.0   # |h| of the constraints is reported
+            accepted += int(r0[:, 9].sum())
+        assert accepted > 0
+    # the batch context goes on from the final iterates
+    bd.gn_step()
+    for b in range(B):
+        dev = hip.HipPath(model, probs[b], sp)
+        dev.set_q(want[b][2])
+        dev.gn_step()
+        assert _same(bd.get("step", problem=b), dev.get("step")), b
+        dev.close()
+    bd.close()
