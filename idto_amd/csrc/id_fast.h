@@ -89,6 +89,23 @@ IDTO_DEV const double* lds_launder(const double* p) {
 // kernel over its 512 registers.
 IDTO_DEV void pin(V3& a) { asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z)); }
 
+// The 25 constants of a body's record (FB_XPF .. FB_INERTIA) read ONE SLOT AHEAD: volatile LDS reads stay where they are
+// written - before the contact pairs of the slot before - and the wait for them is placed at their first use, behind
+// those pairs; one wavefront per SIMD has nothing else to cover the ~130 cycles of an LDS round trip with
+// (profiles/r04_fd_pmc.txt: 43 % of the evaluation's cycles were waits).
+enum { FB_PREFETCH = FB_INERTIA + 6 };
+IDTO_DEV void prefetch_record(const double* rec, double (&rc)[FB_PREFETCH]) {
+#ifdef IDTO_FAST_NO_PREFETCH
+#pragma unroll
+  for (int i = 0; i < FB_PREFETCH; ++i) rc[i] = rec[i];
+#else
+  typedef __attribute__((address_space(3))) const volatile double lds_cvdouble;
+  lds_cvdouble* p = (lds_cvdouble*)rec;
+#pragma unroll
+  for (int i = 0; i < FB_PREFETCH; ++i) rc[i] = p[i];
+#endif
+}
+
 struct ParentKin {  // what a child needs of its parent
   M3 R;
   V3 p, w, v, al, a;
@@ -255,6 +272,8 @@ IDTO_DEV void inertial_wrench_rec(const double* rec, const M3& R, V3 w, V3 al, V
 // belongs to (the common body for the two groups without a chain body), cb the common body.
 // Wrenches on C are added to (*fext, *next), those on the other body - if it is the common one -
 // to (*cfe, *cne), in list order.  (fext, next) may be (cfe, cne): then C is the common body.
+// (reading a pair's record a pair ahead, as prefetch_record does for the bodies, was measured and dropped: the 32 more
+// registers per record in flight and the copies cost more than the round trips they hide - cheetah 22.5 -> 23.8 us)
 template <bool HAS_COMMON>
 IDTO_DEV void pair_group(const double* plist, int segword, const DevContact& cp, const BodyState& C, const BodyState& cb,
                          V3* fext, V3* next, V3* cfe, V3* cne) {
@@ -376,6 +395,8 @@ IDTO_DEV void id_eval_fast(const FastTab& T, const double* gravity, const DevCon
 #endif
   FD_STAMP(5);
 
+  double rc_next[FB_PREFETCH];
+  prefetch_record(bt, rc_next);   // slot 0's constants: in flight while the common body is evaluated
   // ---- common root body (identical in every lane of the evaluation)
   BodyState cb;
   cb.R = ident3(); cb.p = zero; cb.w = zero; cb.v = zero;
@@ -408,10 +429,9 @@ IDTO_DEV void id_eval_fast(const FastTab& T, const double* gravity, const DevCon
   P.R = ident3(); P.p = zero; P.w = zero; P.v = zero; P.al = zero; P.a = zero;
 #pragma unroll
   for (int s = 0; s < MAXC; ++s) {
-    const double* rec = lds_launder(bt + s * FB_STRIDE);   // (the slot's constants are read in the slot, not above the previous slot's pairs)
-#ifdef IDTO_FAST_LAZY
-    idto::detmath::sincos(qj[s], &sn[s], &cs[s]);
-#endif
+    double rec[FB_PREFETCH];
+#pragma unroll
+    for (int i = 0; i < FB_PREFETCH; ++i) rec[i] = rc_next[i];
     const bool world = (s == 0 && K0 == PK_WORLD);
     if (s == 0 && K0 == PK_COMMON) { P.R = cb.R; P.p = cb.p; P.w = cb.w; P.v = cb.v; P.al = cb_al; P.a = cb_a; }
     // (a body attached to the world: the record holds I * X_PF)
@@ -463,6 +483,7 @@ IDTO_DEV void id_eval_fast(const FastTab& T, const double* gravity, const DevCon
     inertial_wrench_rec(rec, bs.R, bs.w, al, acc, g, &fin, &nin);
     pin(fin); pin(nin); pin(r[s]); pin(hW[s]);
     if (s == MAXC - 1) FD_STAMP(8);
+    if (s + 1 < MAXC) prefetch_record(bt + (s + 1) * FB_STRIDE, rc_next);   // ... the next slot's, across this slot's pairs
     V3 fext = zero, next = zero;
     if (full) pair_group<HAS_COMMON>(plist, seg[1 + s], cp, bs, cb, &fext, &next, &cfe, &cne);
     ft[s] = fin - fext;
