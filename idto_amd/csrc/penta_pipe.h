@@ -99,12 +99,15 @@ enum {
   PF_JOINED = 29,    // joiner: the producer's contributions to the two join rows are in the stage buffers
   PF_HIDONE = 30,    // the second follower's (high) rows of row il are in the hand-over buffer (main columns)
   PF_HIDONE2 = 31,   // (spike columns)
+  PF_T0 = 40,        // [2] wall clock at the workgroup's start (pipe_giveup)
   PF_COUNT = 32
 };
 
-constexpr long long PIPE_SPIN_TICKS = 1000000;   // 10 ms of the 100 MHz wall clock before a wait inside the workgroup gives up
-// (wall time, not a number of polls: under clock throttling or a profiler's serialisation a poll count runs out early and
-// degrades the context for good)
+constexpr int PIPE_SPIN_CAP = 1 << 17;            // polls (~150 cycles each with the sleep: ~10 ms) before a wait may give up ...
+constexpr long long PIPE_AGE_TICKS = 1000000;      // ... and then only in a workgroup that is older than 10 ms of the 100 MHz wall clock
+// (the poll count alone runs out early under clock throttling or a profiler's serialisation and would degrade the context
+// for good; a launch takes ~65 us, so a workgroup of that age is stuck.  The age, not the duration of the wait: a start
+// time per wait is two more live registers in every wait loop of a register-bound kernel - measured 64.8 against 63.4 us)
 
 // flags and published words are polled: volatile accesses in the LDS address space (a volatile access through a
 // generic pointer becomes a flat load with system-scope cache bits)
@@ -120,21 +123,21 @@ struct PipeCtl {
 // the workgroup then gives up early, and the end of pipe_forward reports a failed factorisation.  (No function
 // call here: a call site inside the chain wavefronts' row loop makes every live register cross it.)
 // every poll is wave-uniform by construction (readfirstlane): scalar branches, no exec-mask loops
-__device__ __forceinline__ bool pipe_giveup(const PipeCtl& c, int n, long long& t0) {
+__device__ __forceinline__ bool pipe_giveup(const PipeCtl& c, int n) {
   if ((n & 255) != 0) return false;
   if (__builtin_amdgcn_readfirstlane(c.f[PF_ABORT]) != 0) return true;
-  const long long now = (long long)wall_clock64();
-  if (n == 256) t0 = now;
-  else if (now - t0 > PIPE_SPIN_TICKS) { c.f[PF_ABORT] = 1; return true; }
+  if (n >= PIPE_SPIN_CAP) {
+    const long long t0 = ((long long)(unsigned)c.f[PF_T0 + 1] << 32) | (unsigned)c.f[PF_T0];   // the workgroup's start (pipe setup)
+    if ((long long)wall_clock64() - t0 > PIPE_AGE_TICKS) { c.f[PF_ABORT] = 1; return true; }
+  }
   return false;
 }
-// waits until flag >= target; bounded, see PIPE_SPIN_TICKS
+// waits until flag >= target; bounded, see PIPE_SPIN_CAP
 __device__ __forceinline__ void pipe_wait(const PipeCtl& c, int flag, int target) {
   int n = 0;
-  long long t0 = 0;
   while (__builtin_amdgcn_readfirstlane(c.f[flag]) < target) {
     __builtin_amdgcn_s_sleep(1);
-    if (pipe_giveup(c, ++n, t0)) break;
+    if (pipe_giveup(c, ++n)) break;
   }
   __atomic_signal_fence(__ATOMIC_SEQ_CST);
 }
@@ -272,10 +275,9 @@ __device__ __forceinline__ void pipe_read_mult(const double* __restrict__ row, i
 __device__ __forceinline__ void pipe_wait_row(const PipeCtl& c, const double* word) {
   pipe_lds_int* hi = (pipe_lds_int*)word + 1;
   int n = 0;
-  long long t0 = 0;
   while ((__builtin_amdgcn_readfirstlane(*hi) & 0x7ff80000) == 0x7ff80000) {
     __builtin_amdgcn_s_sleep(1);
-    if (pipe_giveup(c, ++n, t0)) break;
+    if (pipe_giveup(c, ++n)) break;
   }
   __atomic_signal_fence(__ATOMIC_SEQ_CST);
 }
@@ -396,7 +398,6 @@ struct PipeWatch {
   // returns once row J is published (bounded)
   __device__ __forceinline__ void need(const PipeCtl& ctl, int J) {
     int n = 0;
-    long long t0 = 0;
     while (J >= avail) {
       const unsigned long long pub = __builtin_amdgcn_ballot_w64((*w & 0x7ff80000) != 0x7ff80000);
       const int a0 = __builtin_ctzll(~pub | (1ull << K)), a1 = __builtin_ctzll(~(pub >> 32) | (1ull << K));
@@ -406,7 +407,7 @@ struct PipeWatch {
       // itself; in the joiner workgroups two wavefronts share a SIMD, and a spinning follower takes issue slots from
       // the eliminating wavefront next to it - measured: rows 3.3 -> 4.0 us)
       if (spk_wg) __builtin_amdgcn_s_sleep(1);
-      if (pipe_giveup(ctl, ++n, t0)) { avail = K; break; }
+      if (pipe_giveup(ctl, ++n)) { avail = K; break; }
     }
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
   }
@@ -674,12 +675,11 @@ __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCf
 #pragma unroll
         for (int J = 0; J < K; ++J) {
           if (J == R::JH) high_rows();
-          long long t0 = 0;
           for (int n = 0; J >= avail;) {   // one poll covers every row the main wavefront has published
             avail = __builtin_ctzll(~__builtin_amdgcn_ballot_w64((*watch & 0x7ff80000) != 0x7ff80000) | (1ull << K));
             if (J < avail) break;
             __builtin_amdgcn_s_sleep(1);
-            if (pipe_giveup(ctl, ++n, t0)) { avail = K; break; }
+            if (pipe_giveup(ctl, ++n)) { avail = K; break; }
           }
           __atomic_signal_fence(__ATOMIC_SEQ_CST);
           rowp[J * RS] = pipe_setlane<63>(xr[J], 0x3ff00000, 0);
@@ -739,6 +739,11 @@ __device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& 
   // them) and the position `oz` of every row, the rt rows - nothing else (LDS is 150 KB here; everything else is
   // written before it is read)
   for (int idx = tid; idx < 32; idx += blockDim.x) lds[L.flags + idx] = 0.0;
+  if (tid == 0) {   // (behind the zero fill: words 40, 41 are idx 20, written by lane 20 of this same wavefront one instruction earlier)
+    const long long now = (long long)wall_clock64();
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    ctl.f[PF_T0] = (int)(unsigned)now; ctl.f[PF_T0 + 1] = (int)(now >> 32);
+  }
   for (int idx = tid; idx < 3 * (G::KR - K) * RS; idx += blockDim.x) {
     const int sl = idx / ((G::KR - K) * RS), e = idx - sl * (G::KR - K) * RS;
     ring[sl * G::SLOT + K * RS + e] = 0.0;
@@ -1147,7 +1152,7 @@ __device__ __forceinline__ void pipe_backward(const PipeArgs& A, const ChainCfg&
 //   0: P0 producer, rows 0 .. j1-1 top-down        1: P3 producer, rows n-1 .. j2+2 bottom-up
 //   2: J1 joiner, rows s-1 .. j1+2 then j1+1, j1   3: J2 joiner, rows s+2 .. j2-1 then j2, j2+1   (with their spike columns)
 //   4: the separator (penta_nd.h nd_separator)
-// Every wait is bounded (PIPE_SPIN_TICKS): a workgroup that is not resident with its partners ends with the
+// Every wait is bounded (PIPE_SPIN_CAP): a workgroup that is not resident with its partners ends with the
 // factorisation status set instead of hanging the device.
 template <int K>
 __global__ void __launch_bounds__(512) penta_pipe_kernel(NdArgs A, PipeAsm F) {

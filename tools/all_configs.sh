@@ -1,6 +1,6 @@
 #!/bin/bash
 # bench line of every BASELINE configuration (one Gauss-Newton iteration = fd + assembly + factor/solve) -> gpurun_out/${R}_all_configs.txt
-R=${ROUND:-r03}
+R=${ROUND:-r04}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 OUT=gpurun_out/${R}_all_configs.txt

@@ -4,7 +4,7 @@
 # pass its own run with --kernel-trace only, never combined with other trace domains.
 # Outputs under gpurun_out/; tools/pmc_summarize.py condenses them into gpurun_out/summary/ for profiles/.
 set -x
-R=${ROUND:-r03}
+R=${ROUND:-r04}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 rocminfo 2>/dev/null | grep -E "Marketing Name|gfx" | head -4
@@ -13,11 +13,9 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | 
 timeout 600 python bench.py 2>&1 | tail -1 | tee gpurun_out/${R}_bench.json
 timeout 120 python tools/nd_timeline.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${R}_nd_timeline.txt
 IDTO_TIMELINE_GN_STEP=1 timeout 120 python tools/nd_timeline.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${R}_nd_timeline_gn_step.txt
-{ timeout 200 python tools/nd_accuracy.py mini_cheetah 24 31 40; timeout 200 python tools/nd_accuracy.py acrobot 40 63; timeout 200 python tools/nd_accuracy.py hopper 50; } 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${R}_nd_accuracy.txt
 { timeout 60 ./tools/micro/xcd_pingpong; timeout 60 ./tools/micro/chain_bench; } 2>&1 | tee gpurun_out/${R}_microbench.txt
 timeout 300 python tools/stress_solver.py mini_cheetah 40 600 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${R}_solver_stress.txt
 timeout 120 python tools/solver_phases.py 2>&1 | grep -v amdgpu.ids | tail -28 | tee gpurun_out/${R}_solver_phases.txt
-timeout 120 python tools/fold_timing.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${R}_fd_phases.txt
 { for c in "mini_cheetah 40" "hopper 40" "allegro_hand 20" "acrobot 40" "spinner 40"; do timeout 120 python tools/full_iter_prof.py $c 2>&1 | tail -1; done; } | tee gpurun_out/${R}_full_iteration_times.txt
 ROOT=$GRAFT_REPO_ROOT
 cd /tmp

@@ -1,0 +1,35 @@
+#!/bin/bash
+# Round 4: everything tools/gpu_check.sh measures (parity tests, smoke, bench, solver timelines, rocprof kernel traces,
+# PMC passes - each PMC pass its own run with --kernel-trace only) plus what this round added: the accuracy table of all
+# five configurations, fd_kernel by truncation / in-kernel stamps / SQ counters per phase / rocprof durations per phase,
+# the table of all configurations, the solver beside a saturating neighbour.  Outputs under gpurun_out/ (summary/ for
+# profiles/); tools/latency_model.py r04 (CPU) then condenses the model bench.py reports.
+export ROUND=r04
+bash tools/gpu_check.sh
+R=r04
+export TMPDIR=/tmp
+( for m in "acrobot 40" "spinner 40" "hopper 50" "mini_cheetah 24 31 40" "allegro_hand 60"; do timeout 300 python tools/nd_accuracy.py $m; done ) 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_nd_accuracy.txt
+timeout 300 python tools/fd_stops.py --both 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${R}_fd_phases.txt
+if [ -f build/variants/stamps/libidto_hip.so ]; then
+  IDTO_HIP_LIB=build/variants/stamps/libidto_hip.so timeout 120 python tools/fd_stamps.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${R}_fd_stamps.txt
+fi
+rm -f gpurun_out/fd_pmc.txt
+timeout 600 bash tools/fd_pmc.sh mini_cheetah 40 "2 3 0" > /dev/null 2>&1
+timeout 600 bash tools/fd_pmc.sh allegro_hand 60 "2 3 0" > /dev/null 2>&1
+cp gpurun_out/fd_pmc.txt gpurun_out/${R}_fd_pmc.txt
+{ timeout 300 bash tools/fd_rocprof_stops.sh mini_cheetah 40 "10 8 1 3 0" >/dev/null 2>&1; python - <<'PY'
+import csv
+for cfg, N in (("mini_cheetah", 40),):
+    for s in (10, 8, 1, 3, 0):
+        try:
+            for r in csv.DictReader(open(f"gpurun_out/fdrp_{cfg}_{s}/r_kernel_stats.csv")):
+                if "fd_kernel" in r["Name"]:
+                    print(f"{cfg} N={N} fd_stop {s}: rocprofv3 average {float(r['AverageNs']) / 1e3:.2f} us over {r['Calls']} launches")
+        except Exception as e:
+            print(cfg, s, "missing", e)
+PY
+} | tee gpurun_out/${R}_fd_rocprof_phases.txt
+timeout 600 python -m pytest tests/test_gpu_neighbour.py -m gpu -q -s 2>&1 | grep -v amdgpu.ids | tail -5 | tee gpurun_out/${R}_solver_beside_neighbour.txt
+timeout 1500 bash tools/all_configs.sh > /dev/null 2>&1
+timeout 60 ./tools/micro/launch_bench 2>&1 | tee gpurun_out/${R}_launch_bench.txt
+ls gpurun_out | head -80
