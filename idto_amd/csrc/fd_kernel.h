@@ -588,11 +588,9 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
 #endif
           );
         } else {
-#ifndef IDTO_FD_TEST_NO_INLDS
           InLds in;
           in.q = eq + el * nq; in.v = ev + el * nv; in.a = ea + el * nv;
           id_eval_fast<FS::MAXC, FS::NP, FS::CJ, FS::J0, FS::K0>(FT, Ml.gravity, cp, path, full, in, etau + (c0 + el) * nv);
-#endif
         }
       }
     }

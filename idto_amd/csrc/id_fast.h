@@ -277,9 +277,6 @@ IDTO_DEV void inertial_wrench_rec(const double* rec, const M3& R, V3 w, V3 al, V
 template <bool HAS_COMMON>
 IDTO_DEV void pair_group(const double* plist, int segword, const DevContact& cp, const BodyState& C, const BodyState& cb,
                          V3* fext, V3* next, V3* cfe, V3* cne) {
-#ifdef IDTO_FAST_NO_PAIRS
-  return;
-#endif
   const int start = segword & 0xffff, count = segword >> 16;
   for (int j = start; j < start + count; ++j) {
     const double* pr = plist + j * FP_STRIDE;
@@ -389,10 +386,8 @@ IDTO_DEV void id_eval_fast(const FastTab& T, const double* gravity, const DevCon
   }
   FD_STAMP(4);
   double sn[MAXC], cs[MAXC];
-#ifndef IDTO_FAST_LAZY
 #pragma unroll
   for (int s = 0; s < MAXC; ++s) idto::detmath::sincos(qj[s], &sn[s], &cs[s]);
-#endif
   FD_STAMP(5);
 
   double rc_next[FB_PREFETCH];

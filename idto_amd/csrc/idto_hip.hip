@@ -567,10 +567,12 @@ int FdEvals(const idto_hip_ctx* c, int mode) {
 }
 
 // dynamic LDS of fd_kernel when it builds the inputs of `ec` evaluations per pass
-int FdLds(const idto_hip_ctx* c, int mode, int ec, bool with_terms = false) {
+// (fast: fd_kernel<MAXC, SHAPE != 0>, which stages only the shape's records of the model; the fused launch runs the
+// generic evaluation and stages the whole blob)
+int FdLds(const idto_hip_ctx* c, int mode, int ec, bool with_terms = false, bool fast = true) {
   const int nq = c->nq, nv = c->nv, E = FdEvals(c, mode), nvp = (nv + 1) & ~1;
   const int rec = with_terms ? 6 * nvp * nq + nvp + 1 : 0;   // the record, its weighted copy, diag R' (+1: 16-byte alignment)
-  const int blob_n = (c->fd_fast && c->M.fast_shape) ? c->M.fast_n : c->M.blob_n;   // what fd_body stages of the model
+  const int blob_n = (fast && c->fd_fast && c->M.fast_shape) ? c->M.fast_n : c->M.blob_n;   // what fd_body stages of the model
   return (int)sizeof(double) * (3 * nq + 2 * nv * nq + 3 * nv + 3 * E + E * nv + ec * (nq + 2 * nv) + nv + blob_n + 2 + nq / 2 + 2 + rec);
 }
 
@@ -1335,8 +1337,8 @@ static int LaunchFused(idto_hip_ctx* c) {
   const int mode = 1 + c->gradients_method;
   const int E = FdEvals(c, mode), groups = 256 / c->npaths;
   int ec = E;
-  while (ec > groups && FdLds(c, mode, ec) > 160 * 1024) ec = ((ec - 1) / groups) * groups;
-  const int fd_lds = FdLds(c, mode, ec);
+  while (ec > groups && FdLds(c, mode, ec, false, false) > 160 * 1024) ec = ((ec - 1) / groups) * groups;
+  const int fd_lds = FdLds(c, mode, ec, false, false);
   if (fd_lds > 160 * 1024) { g_err = "finite-difference evaluation set does not fit in LDS"; return -1; }
   const int lds = std::max(std::max(fd_lds, c->asm_diag_lds), std::max(p.lds, 84 * 1024));
   FusedArgs A;
@@ -2208,6 +2210,8 @@ int idto_hip_get_option(idto_hip_ctx* c, const char* name, int* value) {
   if (std::strcmp(name, "two_sided") == 0) { *value = c->two_sided; return 0; }
   if (std::strcmp(name, "reference_solver") == 0) { *value = c->reference_solver; return 0; }
   if (std::strcmp(name, "gradients_method") == 0) { *value = c->gradients_method; return 0; }
+  if (std::strcmp(name, "fast_shape") == 0) { *value = c->M.fast_shape; return 0; }   // id_fast.h: 0 none, 1 acrobot, 2 hopper, 3 mini_cheetah, 4 allegro_hand
+  if (std::strcmp(name, "fd_fast") == 0) { *value = c->fd_fast ? 1 : 0; return 0; }
   g_err = std::string("unknown option ") + name;
   return -1;
 }
