@@ -241,7 +241,10 @@ __device__ __forceinline__ void pipe_pivot(double (&xr)[K], double inv, const do
 #pragma unroll
     for (int m = (J + 2) / 2; m < (K + 1) / 2; ++m) {
       const double2 v = p2[m];
-      if (2 * m >= J + 2) mu[2 * m] = v.x;
+      // (an odd J needs only the second half of its first pair, mu[J + 1] goes unused: left to itself the compiler
+      // narrows that read to 8 bytes, and every read after it is then 8 bytes off a 16-byte boundary - ds_read2_b64
+      // with an address of its own, a v_add_u32 per read on the eliminating wavefront.  The next step "uses" it.)
+      mu[2 * m] = v.x;
       if (2 * m + 1 < K) mu[2 * m + 1] = v.y;
     }
   }
@@ -253,6 +256,7 @@ __device__ __forceinline__ void pipe_pivot(double (&xr)[K], double inv, const do
   if constexpr (J >= 1) {
 #pragma unroll
     for (int r = J + 2; r < K; ++r) xr[r] = __builtin_fma(-mu_p[r], xj_p, xr[r]);
+    if constexpr ((J & 1) == 0 && J + 1 < K) asm volatile("" ::"v"(mu_p[J]));   // (the unused half of pivot J-1's first read, see above)
   }
   // (keep the steps apart: left to itself the scheduler defers a row's updates until the row becomes the pivot
   // row - a chain of dependent FMAs into one accumulator right where the next pivot waits for it)
