@@ -29,6 +29,7 @@
 #include "constraints.h"
 #include "dense_ldl.h"
 #include "trust_region.h"
+#include "kkt.h"
 
 using namespace idto_dev;
 
@@ -234,6 +235,11 @@ struct idto_hip_ctx {
   hipEvent_t spec_ev = nullptr;
   const double* con_lambda_at = nullptr;  // where the current multipliers live (con_lambda or con_lambda + 2)
   int* una_dofs = nullptr; int una_nu = 0; // unactuated dofs for |h| of the statistics (idto_hip_set_unactuated_dofs)
+  // the equality-constraint step of the resident loop as one banded solve (kkt.h): a solver-only context of block size
+  // nq + nu on this context's stream, made on first use
+  idto_hip_ctx* kkt = nullptr; int kkt_nu = 0;
+  bool con_kkt = true;                     // option "con_kkt" (0: the Schur-complement chain of constraints.h)
+  int ldl_npos = 0;                        // (a KKT context) the solver expects the pivots [ldl_npos, nq) of a block negative
 };
 enum { IDTO_SLAB_PAD = 64 };
 
@@ -927,6 +933,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   if (const char* e = getenv("IDTO_SOLVER_ND")) c->solver_nd = (e[0] == '1');
   if (const char* e = getenv("IDTO_SOLVER_PIPE")) c->solver_pipe = (e[0] == '1');
   if (const char* e = getenv("IDTO_ASM_FOLD")) c->asm_fold = (e[0] == '1');
+  if (const char* e = getenv("IDTO_CON_KKT")) c->con_kkt = (e[0] == '1');
   (void)hipGetLastError();
   *out = c;
   return 0;
@@ -936,6 +943,7 @@ void idto_hip_destroy(idto_hip_ctx* c) {
   if (!c) return;
   for (idto_hip_ctx* ch : c->children) idto_hip_destroy(ch);
   c->children.clear();
+  if (c->kkt) { idto_hip_destroy(c->kkt); c->kkt = nullptr; }
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
@@ -1285,7 +1293,7 @@ static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, double* xo, 
   if (m_split > 0) ++c->epoch;  // (exchange buffer and flags live in the problem's arena)
   if (++c->fact_id == 0) c->fact_id = 1;  // (0 is the initial value of the status word)
 #define LDL_ARGS n, k, c->HA + qq0, c->HB + qq0, c->HC + qq0, b, sign, nrhs, xo, c->Ust, c->Hst, c->Est, c->Dst, dbg, \
-                 m_split, c->xch, c->flags, c->epoch, c->status_dev, c->fact_id, c->pstride, factor_only ? 1 : 0
+                 m_split, c->xch, c->flags, c->epoch, c->status_dev, c->fact_id, c->pstride, factor_only ? 1 : 0, c->ldl_npos
 #define LDL_LAUNCH(KM, PD, GW) \
   hipLaunchKernelGGL((penta_ldl_kernel<KM, 256, PD, GW>), grid, dim3(256), lds, c->stream, LDL_ARGS)
   switch (p.K) {
@@ -1476,15 +1484,13 @@ int idto_hip_solve_host(idto_hip_ctx* c, const double* rhs_host, int nrhs, doubl
   return FactorStatus(c);
 }
 
-int idto_hip_constraint_schur_begin(idto_hip_ctx* c, const int* dofs, int nu) {
-  HIP_OK(hipSetDevice(c->device));
+// the device arrays of the equality-constraint step for this set of degrees of freedom (made again when the set changes)
+static int ConstraintBuffers(idto_hip_ctx* c, const int* dofs, int nu) {
   if (!dofs || nu < 1 || nu > c->nv) { g_err = "constraint_schur: bad arguments"; return -1; }
   if (c->batch != 1) { g_err = "the equality-constraint step serves single-problem contexts"; return -1; }
   for (int j = 0; j < nu; ++j)
     if (dofs[j] < 0 || dofs[j] >= c->nv) { g_err = "constraint_schur: dof index out of range"; return -1; }
   const int N = c->N, n = (N + 1) * c->nq, neq = nu * N;
-  if (c->con_begun && c->con_nu == nu && std::equal(dofs, dofs + nu, c->con_dofs_host.begin()))
-    return 0;  // already enqueued for the current Hessian
   if (c->con_nu != nu || !std::equal(dofs, dofs + nu, c->con_dofs_host.begin())) {
     c->con_dofs_host.assign(dofs, dofs + nu);
     void* p = nullptr;
@@ -1503,7 +1509,19 @@ int idto_hip_constraint_schur_begin(idto_hip_ctx* c, const int* dofs, int nu) {
     HIP_OK(hipHostMalloc((void**)&c->con_pin, need * sizeof(double), hipHostMallocDefault));
     c->con_pin_count = need;
     c->con_nu = nu; c->con_neq = neq;
+    c->con_begun = false;
   }
+  return 0;
+}
+
+int idto_hip_constraint_schur_begin(idto_hip_ctx* c, const int* dofs, int nu) {
+  HIP_OK(hipSetDevice(c->device));
+  if (!dofs || nu < 1 || nu > c->nv) { g_err = "constraint_schur: bad arguments"; return -1; }
+  if (c->batch != 1) { g_err = "the equality-constraint step serves single-problem contexts"; return -1; }
+  const int N = c->N, n = (N + 1) * c->nq, neq = nu * N;
+  if (c->con_begun && c->con_nu == nu && std::equal(dofs, dofs + nu, c->con_dofs_host.begin()))
+    return 0;  // already enqueued for the current Hessian
+  if (int rc = ConstraintBuffers(c, dofs, nu)) return rc;
   c->con_ready = false; c->con_begun = false;
   if (EnsureStage(c, (size_t)(neq + 1) * n)) return -2;
   // Y = H^-1 [g | J^T]: the right-hand sides are read where they are (g; rows of the slab records), nothing is staged
@@ -1769,6 +1787,39 @@ int idto_hip_tr_reject(idto_hip_ctx* c) {
   return 0;
 }
 
+// The solver-only context of the KKT system [H J^T; J 0] (kkt.h): block size nq + nu, the parent's horizon, stream and
+// solver options; only what LaunchLdl / FactorStatus touch is allocated.
+static int MakeKkt(idto_hip_ctx* c, int nu) {
+  if (c->kkt && c->kkt_nu == nu) return 0;
+  if (c->kkt) { idto_hip_destroy(c->kkt); c->kkt = nullptr; }
+  const int K = c->nq + nu, N = c->N;
+  if (K > 32) { g_err = "tr_solve: nq + nu <= 32 for the banded equality-constraint step"; return -1; }
+  std::unique_ptr<idto_hip_ctx> k(new idto_hip_ctx);
+  k->device = c->device; k->stream = c->stream; k->own_stream = false;
+  k->batch = 1; k->nq = K; k->nv = 0; k->N = N; k->dt = c->dt;
+  k->two_sided = c->two_sided; k->solver_nd = false; k->solver_pipe = false; k->fused = false; k->asm_in_solver = false;
+  k->h_assembled = true;      // block row 0 is decoupled (q_0 is no variable, mu_0 a dummy): the chains start at row 1
+  k->ldl_npos = c->nq;
+  const size_t kk = (size_t)K * K;
+  idto_hip_ctx* kc = k.get();
+  auto fail = [&](const char* what) { g_err = what; idto_hip_destroy(k.release()); return -2; };
+  if (Alloc(kc, (size_t)3 * (N + 6) * kk, &kc->HA) || Alloc(kc, (size_t)(N + 1) * K, &kc->g) || Alloc(kc, (size_t)(N + 1) * K, &kc->step) ||
+      Alloc(kc, (size_t)(N + 1) * 32 * 36, &kc->Ust) || Alloc(kc, (size_t)(N + 1) * 32 * 36, &kc->Hst) ||
+      Alloc(kc, (size_t)(N + 1) * 32 * 36, &kc->Est) || Alloc(kc, (size_t)(N + 1) * 32, &kc->Dst) || Alloc(kc, (size_t)(N + 4) * 8 * 32, &kc->dbg))
+    return fail("hipMalloc (KKT context) failed");
+  kc->HB = kc->HA + (size_t)(N + 6) * kk;
+  kc->HC = kc->HB + (size_t)(N + 6) * kk;
+  kc->xch_count = 2 * (size_t)(3 * 32 + 1) * ldl_ks(32) + 2 * 32;
+  kc->flag_count = 16;
+  if (Alloc(kc, 2 * kc->xch_count, &kc->xch) || Alloc(kc, kc->flag_count, &kc->flags)) return fail("hipMalloc (KKT context) failed");
+  if (hipHostMalloc((void**)&kc->status_pin, 4 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&kc->status_dev, kc->status_pin, 0) != hipSuccess)
+    return fail("hipHostMalloc (KKT solver status) failed");
+  for (int i = 0; i < 4; ++i) kc->status_pin[i] = 0;
+  c->kkt = k.release(); c->kkt_nu = nu;
+  return 0;
+}
+
 static bool AsmInSolver(idto_hip_ctx* c);
 // Delta0s / Delta_out: one radius per problem of the context; rows_host: [batch][iterations][TRR_COUNT]
 static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scaling, int normalize_quaternions,
@@ -1822,6 +1873,13 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     rc = idto_hip_gn_step(c);
   }
   if (rc) return rc;
+  // (blocks of nq + nu up to the 24 x 24 instantiation: above it the two-workgroup factorisation of the padded 32 x 32
+  // blocks costs more than the Schur-complement chain - allegro, 23 + 6, N = 20: 442 against 245 us per iteration)
+  const bool use_kkt = nu > 0 && c->con_kkt && SolverBlockSize(c->nq + nu) <= 24;
+  if (use_kkt) {
+    if ((rc = ConstraintBuffers(c, constrained_dofs, nu)) != 0) return rc;
+    if ((rc = MakeKkt(c, nu)) != 0) return rc;
+  }
   const bool lookahead = c->weights_diagonal && c->asm_stop == 0 && c->fd_stop == 0;
   if (B != 1 && !lookahead) { g_err = "tr_solve on a batch context needs the two-set evaluation (diagonal cost weights)"; return -1; }
   if (adaptive && !lookahead) { g_err = "tr_solve: the adaptive scalings need the gated assembly (diagonal cost weights)"; return -1; }
@@ -1857,7 +1915,30 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
       if (c->tr_pin[TRS_FLAGS] != 0.0) break;
     }
     conv.check_only = (k == iterations) ? 1 : 0;
-    if (nu > 0) {
+    if (nu > 0 && use_kkt) {
+      // multipliers of the iterate and H^-1 (g + J^T lambda) (TO.cc:1371-1396, :2139-2149) from ONE banded solve of the
+      // KKT system (kkt.h): build its bands from H and the slab's rows of J, factorise + solve, take the result apart
+      idto_hip_ctx* kc = c->kkt;
+      KktBuildArgs Kb;
+      Kb.N = c->N; Kb.nq = c->nq; Kb.nv = c->nv; Kb.nu = nu;
+      Kb.HA = c->HA; Kb.HB = c->HB; Kb.HC = c->HC; Kb.g = c->g;
+      Kb.slab = c->slab; Kb.slab_stride = c->slab_stride; Kb.dofs = c->con_dofs;
+      Kb.KA = kc->HA; Kb.KB = kc->HB; Kb.KC = kc->HC; Kb.rhs = kc->g; Kb.alt = c->alt_r;
+      hipLaunchKernelGGL(kkt_build_kernel, dim3(c->N + 1), dim3(256), 0, c->stream, Kb);
+      HIP_OK(hipGetLastError());
+      rc = idto_hip_factor_solve(kc, nullptr, 1, nullptr);
+      if (rc) return rc;
+      KktExtractArgs Ke;
+      Ke.N = c->N; Ke.nq = c->nq; Ke.nv = c->nv; Ke.nu = nu;
+      Ke.z = kc->step; Ke.slab = c->slab; Ke.slab_stride = c->slab_stride; Ke.dofs = c->con_dofs;
+      Ke.w = c->con_out; Ke.jtl = c->con_out + n; Ke.lambda = c->con_lambda;
+      Ke.Dinv = kc->Dst; Ke.dstride = SolverBlockSize(kc->nq); Ke.first_row = SolverFirstRow(kc);
+      Ke.state = c->tr_state; Ke.alt = c->alt_r;
+      hipLaunchKernelGGL(kkt_extract_kernel, dim3(c->N + 1), dim3(64), 0, c->stream, Ke);
+      HIP_OK(hipGetLastError());
+      c->con_lambda_at = c->con_lambda;
+      c->con_ready = false; c->con_begun = false;
+    } else if (nu > 0) {
       // multipliers of the iterate (TO.cc:1371-1396), all on the device: Y = H^-1 [g | J^T], S = J Y_J, J y_g
       // (idto_hip_constraint_schur_begin), lambda = S^-1 (h - J y_g) in one workgroup, then H^-1 (g + J^T lambda)
       // and J^T lambda (constraint_step_kernel)
@@ -1900,6 +1981,7 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     T.conv = conv;
     T.fact_status = c->status_dev; T.fact_id = c->fact_id;   // (the most recent factorisation: this iteration's step)
     T.timeout_status = c->status_dev + 2 * c->batch;
+    if (nu > 0 && use_kkt) { T.fact_status = c->kkt->status_dev; T.fact_id = c->kkt->fact_id; T.timeout_status = c->kkt->status_dev + 2; }
     T.rows.freeze = c->tr_state + TRS_FLAGS;
     T.pstride = c->pstride; T.rows_stride = rows_stride;
     hipLaunchKernelGGL(tr_iter_kernel, dim3(nblk, B), dim3(256), lds_iter, c->stream, T);
@@ -1973,6 +2055,13 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     c->nplus = at_problem(c->nplus, (size_t)c->alt_off); c->slab = at_problem(c->slab, (size_t)c->alt_off);
     c->terms = at_problem(c->terms, (size_t)c->alt_off);
     c->alt_off = -c->alt_off;
+  }
+  if (use_kkt) {
+    // (a multiplier pivot that vanished - redundant constraints, TRF_SINGULAR_S in the rows: the caller's pivoted
+    // factorisation takes over - leaves garbage in the rows of H behind it, whose pivot test then fails as well)
+    const int fs = FactorStatus(c->kkt);
+    const bool singular = ((int)c->tr_pin[TRS_FLAGS] & TRF_SINGULAR_S) != 0;
+    if (fs == IDTO_HIP_SOLVER_TIMEOUT || (fs && !singular)) return fs;
   }
   return FactorStatus(c);
 }
@@ -2205,6 +2294,8 @@ int idto_hip_get_option(idto_hip_ctx* c, const char* name, int* value) {
   if (std::strcmp(name, "asm_in_solver") == 0) { *value = c->asm_in_solver; return 0; }
   if (std::strcmp(name, "solver_timeouts") == 0) { *value = c->solver_timeouts; return 0; }
   if (std::strcmp(name, "asm_fold") == 0) { *value = c->asm_fold; return 0; }
+  if (std::strcmp(name, "con_kkt") == 0) { *value = c->con_kkt; return 0; }
+  if (std::strcmp(name, "kkt_last_solver") == 0) { *value = c->kkt ? c->kkt->last_solver : 0; return 0; }
   if (std::strcmp(name, "last_assembly") == 0) { *value = c->last_assembly; return 0; }
   if (std::strcmp(name, "fused") == 0) { *value = c->fused; return 0; }
   if (std::strcmp(name, "two_sided") == 0) { *value = c->two_sided; return 0; }
@@ -2227,6 +2318,7 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "debug_skip_role") == 0) { c->debug_skip_role = value; return 0; }   // test aid
   if (std::strcmp(name, "debug_pipe_tail") == 0) { c->debug_pipe_tail = value; return 0; }   // measurement aid
   if (std::strcmp(name, "asm_fold") == 0) { c->asm_fold = value != 0; c->terms_valid = false; return 0; }
+  if (std::strcmp(name, "con_kkt") == 0) { c->con_kkt = value != 0; return 0; }
   if (std::strcmp(name, "fused_debug") == 0) { c->fused_debug = value != 0; return 0; }
   if (std::strcmp(name, "asm_stop") == 0) { c->asm_stop = value; return 0; }  // profiling aid
   if (std::strcmp(name, "fd_stop") == 0) { c->fd_stop = value; return 0; }    // profiling aid

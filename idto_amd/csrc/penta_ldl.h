@@ -234,7 +234,17 @@ struct ChainCfg {
   int factor_only;                  // stop once the factors are in HBM: every right-hand side (the first included) goes
                                     // through penta_apply_kernel, the chains' own back substitution is off the path
   SpinCtl spin;                     // where a wait between workgroups that ran out reports it
+  int npos;                         // > 0: the pivots [npos, k) of every block row belong to multiplier rows of a KKT system
+                                    // (kkt.h): negative, and judged by kkt_extract_kernel; 0: a positive definite matrix
 };
+// pivot test of a lane that holds a pivot's 1 / d (`inv`; NaN for d = 0 / inf / NaN) and the diagonal entry the pivot
+// started from: positive, finite, and not cancelled to nothing (d <= eps diag0).  Other lanes pass inv = diag0 = 1.
+// The multiplier rows of a KKT system are not tested here: a pivot of theirs that vanishes means redundant constraints,
+// not an indefinite Hessian, and is reported as such (TRF_SINGULAR_S) from the range of those pivots.
+__device__ __forceinline__ bool ldl_pivot_bad(double inv, double diag0, int lane, int k, int npos) {
+  if (npos > 0 && lane >= npos && lane < k) return false;
+  return !(inv > 0.0 && inv * diag0 < 4503599627370496.0);   // 2^52 = 1 / eps
+}
 __device__ __forceinline__ void chain_ts(const ChainCfg& cfg, int slot) {
   if (cfg.ts && threadIdx.x == 0) cfg.ts[slot] = (double)wall_clock64();
 }
@@ -873,7 +883,7 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
         // entry it started from (d <= eps * S_ll) means H is not numerically positive definite.
         // myinv = 1 / d from v_rcp + Newton: NaN for d = 0 / inf / NaN, negative for d < 0.
         if (wave == 0) {
-          const bool bad = !(myinv > 0.0 && myinv * diag0 < 4503599627370496.0);  // 2^52 = 1 / eps
+          const bool bad = ldl_pivot_bad(myinv, diag0, lane, k, cfg.npos);
           if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) {
             __hip_atomic_store(status, fact_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_fetch_add(status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1031,10 +1041,11 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
                  double* __restrict__ x, double* __restrict__ Ust, double* __restrict__ Hst,
                  double* __restrict__ Est, double* __restrict__ Dst, double* __restrict__ dbg,
                  int m_split, double* __restrict__ xch, unsigned* __restrict__ flags, unsigned epoch,
-                 unsigned* __restrict__ status, unsigned fact_id, size_t pstride, int factor_only) {
+                 unsigned* __restrict__ status, unsigned fact_id, size_t pstride, int factor_only, int npos) {
   const size_t o = (size_t)blockIdx.y * pstride;
   ChainCfg cfg = two_sided_cfg(n, m_split, (int)blockIdx.x);
   cfg.factor_only = factor_only;
+  cfg.npos = npos;
   cfg.spin = SpinCtl{status + 2 * gridDim.y, fact_id};   // (behind the per-problem status words)
   penta_ldl_body<K, NT, PADDED, GJW>(n, k, at_problem(HA, o), at_problem(HB, o), at_problem(HC, o), at_problem(b, o),
                                      rhs_sign, nrhs, at_problem(x, o), at_problem(Ust, o), at_problem(Hst, o),

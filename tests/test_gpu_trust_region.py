@@ -189,13 +189,16 @@ def test_resident_loop_rows_and_failure():
 
 @pytest.mark.parametrize("name,N,iters", [("hopper", 40, 12), ("acrobot", 40, 20), ("spinner", 40, 15), ("allegro_hand", 12, 4),
                                             ("hopper", 50, 8), ("allegro_hand", 30, 3)])   # (the last two: n_eq 150 / 180 > 128, blocked LDL^T)
-def test_resident_loop_with_equality_constraints_follows_the_host_loop(name, N, iters, monkeypatch):
+@pytest.mark.parametrize("kkt", [1, 0])
+def test_resident_loop_with_equality_constraints_follows_the_host_loop(name, N, iters, kkt, monkeypatch):
     """enforced equality constraints (the example YAMLs of acrobot, spinner, hopper, allegro): the resident loop
-    computes the multipliers on the device - H^-1 [g | J^T], S = J H^-1 J^T, a single-workgroup LDL^T of S - and
-    uses the merit function; the host loop does the same with the host's pivoted LDL^T.  Different summation
-    orders, so no bit equality, and the iteration amplifies the last-bit differences (hopper: 4e-13 after two
+    computes the multipliers on the device - kkt = 1: one banded solve of the KKT system (csrc/kkt.h; blocks of
+    nq + nu <= 24, i.e. not allegro), kkt = 0: H^-1 [g | J^T], S = J H^-1 J^T, a single-workgroup LDL^T of S - and
+    uses the merit function; the host loop forms S and uses the host's pivoted LDL^T.  Different algorithms and
+    summation orders, so no bit equality, and the iteration amplifies the differences (hopper: 4e-13 after two
     iterations, 2e-7 after twelve): the tolerances of tests/test_gpu_optimizer.py's comparison with the oracle -
     costs and merits 1e-6 relative, radii exactly the same sequence of halvings / doublings, q to 1e-5."""
+    monkeypatch.setenv("IDTO_CON_KKT", str(kkt))
     from idto_amd.optimizer import TrajectoryOptimizer, TrajectoryOptimizerSolution, TrajectoryOptimizerStats
     cfg, model = load_config(name), load_model(name)
     prob, sp, q_guess = make_problem(cfg, model, num_steps=N)
@@ -222,11 +225,14 @@ def test_resident_loop_with_equality_constraints_follows_the_host_loop(name, N, 
     assert np.abs(sa.q - sb.q).max() <= 1e-5 * max(1.0, np.abs(sb.q).max())
 
 
-def test_resident_loop_flags_a_singular_constraint_system():
+@pytest.mark.parametrize("kkt", [1, 0])
+def test_resident_loop_flags_a_singular_constraint_system(kkt):
     """the same degree of freedom constrained twice: S = J H^-1 J^T is exactly singular; the single-workgroup
-    LDL^T reports it (flag 8), nothing is accepted afterwards and the iterate stays where it was"""
+    LDL^T (kkt = 0) / the multiplier pivots of the banded KKT factorisation (kkt = 1) report it (flag 8), nothing is
+    accepted afterwards and the iterate stays where it was"""
     cfg, model, prob, sp, q = _setup("hopper", 20)
     dev = hip.HipPath(model, prob, sp)
+    dev.set_option("con_kkt", kkt)
     dev.set_q(q)
     dev.eval_tau()
     d = int(model.unactuated_dofs[0])
@@ -250,6 +256,7 @@ def test_single_workgroup_multiplier_solve(name, N):
     and the error against the refined solution is no worse than that of LAPACK's pivoted LU on the same S."""
     cfg, model, prob, sp, q = _setup(name, N)
     dev = hip.HipPath(model, prob, sp)
+    dev.set_option("con_kkt", 0)
     dofs = np.asarray(model.unactuated_dofs)
     dev.set_q(q)
     dev.eval_tau()
@@ -269,3 +276,64 @@ def test_single_workgroup_multiplier_solve(name, N):
     err_lu = np.abs(np.linalg.solve(S, r) - want).max() / scale
     assert err <= 4 * err_lu + 16 * unc + 1e-12, (err, err_lu, unc, np.linalg.cond(S))
     dev.close()
+
+
+def _kkt_reference(model, prob, sp, q, dev):
+    """lambda of the KKT system [H J^T; J 0] [w; -lambda] = [g; h] in extended precision (iterative refinement with
+    the residual in long double), H, g from the oracle, J, h from the device's partials (== the oracle's)"""
+    import scipy.linalg as sl
+    N, nq = q.shape[0] - 1, model.nq
+    dofs = np.asarray(model.unactuated_dofs)
+    nu = dofs.size
+    g, bands = Oracle(model, prob, sp).grad_hess(q)
+    H = ol.penta_make_dense(*bands)
+    dev.set_q(q)
+    dev.eval_partials()
+    tau, dm, dt_, dp = dev.get("tau"), dev.get("dtau_dqm"), dev.get("dtau_dqt"), dev.get("dtau_dqp")
+    n = (N + 1) * nq
+    J = np.zeros((N * nu, n))
+    for t in range(N):
+        for j, d in enumerate(dofs):
+            r = t * nu + j
+            if t >= 2:
+                J[r, (t - 1) * nq:t * nq] = dm[t][d]
+            if t >= 1:
+                J[r, t * nq:(t + 1) * nq] = dt_[t][d]
+            J[r, (t + 1) * nq:(t + 2) * nq] = dp[t][d]
+    M = np.block([[H, J.T], [J, np.zeros((N * nu, N * nu))]])
+    rhs = np.concatenate([g.ravel(), tau[:N][:, dofs].ravel()])
+    Ml, bl = M.astype(np.longdouble), rhs.astype(np.longdouble)
+    fac = sl.lu_factor(M)
+    x = sl.lu_solve(fac, rhs).astype(np.longdouble)
+    for _ in range(8):
+        x = x + sl.lu_solve(fac, (bl - Ml @ x).astype(np.float64)).astype(np.longdouble)
+    return -x[n:].astype(np.float64)
+
+
+@pytest.mark.parametrize("name,N,seed", [("acrobot", 40, 1), ("spinner", 40, 1), ("hopper", 40, 1), ("hopper", 40, 2), ("hopper", 50, 3),
+                                         ("hopper", 9, 1), ("acrobot", 3, 2), ("spinner", 128, 1)])
+def test_banded_kkt_multipliers_are_as_accurate_as_the_schur_complement_chain(name, N, seed):
+    """csrc/kkt.h: the multipliers from one unpivoted banded LDL^T of the KKT system against an extended-precision
+    solution of that system.  The systems are badly conditioned (1e8 .. 1e12) and BOTH device paths - this one and the
+    reference's route over S = J H^-1 J^T (constraints.h) - sit at the error that conditioning allows (1e-13 ..
+    2e-7 relative); the statement is that the banded solve is no worse than 4x the Schur-complement chain."""
+    cfg, model = load_config(name), load_model(name)
+    prob, sp, _ = make_problem(cfg, model, num_steps=N)
+    q = synthetic_trajectory(cfg, model, N, seed=seed, lower=0.01 if name == "hopper" else 0.0)
+    dofs = np.asarray(model.unactuated_dofs)
+    lam = {}
+    for kkt in (0, 1):
+        dev = hip.HipPath(model, prob, sp)
+        dev.set_option("con_kkt", kkt)
+        dev.set_q(q)
+        dev.eval_tau()
+        rows, _ = dev.tr_solve(1, SCALING["double_sqrt"], True, False, 1e-1, 1e5, constrained_dofs=dofs)
+        assert rows[0, 14] == 0
+        assert dev.get_option("kkt_last_solver") == (1 if kkt else 0)
+        lam[kkt] = dev.get("con_lambda")
+        if kkt:
+            want = _kkt_reference(model, prob, sp, q, dev)
+        dev.close()
+    scale = np.abs(want).max()
+    e_schur, e_kkt = np.abs(lam[0] - want).max() / scale, np.abs(lam[1] - want).max() / scale
+    assert e_kkt <= 4 * e_schur + 1e-12, (e_kkt, e_schur)
