@@ -32,4 +32,11 @@ PY
 timeout 600 python -m pytest tests/test_gpu_neighbour.py -m gpu -q -s 2>&1 | grep -v amdgpu.ids | tail -5 | tee gpurun_out/${R}_solver_beside_neighbour.txt
 timeout 1500 bash tools/all_configs.sh > /dev/null 2>&1
 timeout 60 ./tools/micro/launch_bench 2>&1 | tee gpurun_out/${R}_launch_bench.txt
+# the equality-constrained iteration (hopper's YAML): kernels of the banded KKT step (csrc/kkt.h) and of the
+# Schur-complement chain it replaced (option con_kkt = 0), per-kernel rocprofv3 averages
+for kkt in 1 0; do
+  IDTO_CON_KKT=$kkt bash tools/prof_full_iter.sh hopper 40 > /dev/null 2>&1
+  cp gpurun_out/prof_fi_hopper/fi_kernel_stats.csv gpurun_out/${R}_constrained_iteration_hopper_kkt${kkt}_kernel_stats.csv
+done
+for kkt in 1 0; do for c in "acrobot 40" "spinner 40" "hopper 40"; do echo -n "IDTO_CON_KKT=$kkt  "; IDTO_CON_KKT=$kkt timeout 120 python tools/full_iter_prof.py $c 2>&1 | tail -1; done; done | tee -a gpurun_out/${R}_constrained_iteration_times.txt
 ls gpurun_out | head -80
