@@ -317,7 +317,11 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
 //   Q[c][c'] = sum_il Ft_il[:, c] . Dn_il Ft_il[:, c']   and   Q[2K][c] = qy[c] = sum_il rt_il . Dn_il Ft_il[:, c].
 // Then: separator system, its two block rows eliminated in registers, back substitution, x_s and
 // x_{s+1} published.
-template <int K, bool PADDED>
+// ALT (the seven-workgroup kernel): the two wavefronts of a pair take ALTERNATE rows with all six tiles instead of
+// half the tiles of every row.  A row's operands are 24 loads per lane that miss the L2 (the spike workgroup wrote
+// them on another XCD), and at K = 23 a wavefront that loads every row took longer per row than the spike
+// workgroup needs to produce one: Q was ready 8.8 us after the last row instead of ~3 (allegro N = 60).
+template <int K, bool PADDED, bool ALT = false>
 __device__ __forceinline__ void nd_separator(const NdArgs& A) {
   extern __shared__ double lds[];
   constexpr int ks = ldl_ks(K), NF = 2 * K, NC = NF + 1, CT2 = (NC + 15) / 16, NQT = CT2 * (CT2 + 1) / 2, QS = NC * NC;
@@ -364,12 +368,14 @@ __device__ __forceinline__ void nd_separator(const NdArgs& A) {
     const double* Fst = A.ndbuf + B.fst + (size_t)w * ND_MAXROWS * B.frow;
     const unsigned long long ftarget = (A.rowtarget / A.rowunit) * 3ull;   // three wavefronts release a row
     const int fl = lane & 15, fk = lane >> 4;
-    d4q qacc[(NQT + 1) / 2];
+    constexpr int NACC = ALT ? NQT : (NQT + 1) / 2;
+    d4q qacc[NACC];
 #pragma unroll
-    for (int t = 0; t < (NQT + 1) / 2; ++t) qacc[t] = d4q{0.0, 0.0, 0.0, 0.0};
-    for (int il = 0; il < nloc; ++il) {
+    for (int t = 0; t < NACC; ++t) qacc[t] = d4q{0.0, 0.0, 0.0, 0.0};
+    for (int il = ALT ? sub : 0; il < nloc; il += ALT ? 2 : 1) {
       spin_wait([&] { return __hip_atomic_load(frow + il, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ftarget; }, A.spin);
       if (!A.wt_rows) (void)__hip_atomic_load(frow + il, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      if (A.ts && lane == 0 && w == 0 && il < 24) A.ts[6 * 64 + 24 + il] = (double)wall_clock64();   // (debug: row il of spike workgroup 0 seen)
       const double* F = Fst + (size_t)il * B.frow;
       const double* dg = A.Dst + (size_t)(mirror ? base - il : base + il) * K;
       double op[CT2][SKq], dn[SKq];
@@ -391,23 +397,31 @@ __device__ __forceinline__ void nd_separator(const NdArgs& A) {
         }
       }
 #pragma unroll
-      for (int t = 0; t < NQT; ++t) {   // tile t -> wavefront t % 2 of the pair, accumulator t / 2
-        if (t % 2 != sub) continue;
-        const int tr = nd_tile_row(t), tc = nd_tile_col(t);
+      for (int t = 0; t < NQT; ++t) {   // tile t -> wavefront t % 2 of the pair, accumulator t / 2 (ALT: every tile, accumulator t)
+        if (!ALT && t % 2 != sub) continue;
+        const int tr = nd_tile_row(t), tc = nd_tile_col(t), ai = ALT ? t : t / 2;
 #pragma unroll
         for (int sq = 0; sq < SKq; ++sq)
-          qacc[t / 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[tr][sq], op[tc][sq] * dn[sq], qacc[t / 2], 0, 0, 0);
+          qacc[ai] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[tr][sq], op[tc][sq] * dn[sq], qacc[ai], 0, 0, 0);
       }
     }
+    // (ALT: wavefront 0 of the pair stores its sums, wavefront 1 adds its own to them after a barrier)
 #pragma unroll
-    for (int t = 0; t < NQT; ++t) {
-      if (t % 2 != sub) continue;
-      const int tr = nd_tile_row(t), tc = nd_tile_col(t);
+    for (int pass = 0; pass < (ALT ? 2 : 1); ++pass) {
+      if (ALT && pass == 1) __syncthreads();
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int r = 16 * tr + fk + 4 * rg, c = 16 * tc + fl;
-        // (lower triangle, mirrored: a diagonal tile holds both (r, c) and (c, r), summed in different orders)
-        if (r < NC && c < NC && r >= c) { Q[w * QS + c * NC + r] = qacc[t / 2][rg]; Q[w * QS + r * NC + c] = qacc[t / 2][rg]; }
+      for (int t = 0; t < NQT; ++t) {
+        if (ALT ? (sub != pass) : (t % 2 != sub)) continue;
+        const int tr = nd_tile_row(t), tc = nd_tile_col(t), ai = ALT ? t : t / 2;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int r = 16 * tr + fk + 4 * rg, c = 16 * tc + fl;
+          // (lower triangle, mirrored: a diagonal tile holds both (r, c) and (c, r), summed in different orders)
+          if (r < NC && c < NC && r >= c) {
+            const double v = (ALT && pass == 1) ? Q[w * QS + c * NC + r] + qacc[ai][rg] : qacc[ai][rg];
+            Q[w * QS + c * NC + r] = v; Q[w * QS + r * NC + c] = v;
+          }
+        }
       }
     }
   }
@@ -571,7 +585,7 @@ __global__ void __launch_bounds__(256) penta_nd_kernel(NdArgs A) {
   }
   const int role = blockIdx.x;
   if (role == A.debug_skip_role) return;
-  if (role == 6) { nd_separator<K, PADDED>(A); return; }
+  if (role == 6) { nd_separator<K, PADDED, true>(A); return; }
   if (role >= 4) { nd_spike<K, PADDED>(A, role - 4); return; }
   const NdBuf B = nd_layout(K);
   ChainCfg c = {};

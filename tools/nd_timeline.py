@@ -23,6 +23,8 @@ else:
     dev.factor_solve(); dev.factor_solve()
 d = dev.get("debug")[:7 * 64].reshape(7, 64) / 100.0
 t0 = d[:4, 0].min()
+if d[6][24] > 0:
+    print("separator: rows of spike workgroup 0 seen at", " ".join("%.1f" % (x - t0) for x in d[6][24:48] if x > 0))
 if fused and dev.get_option("last_assembly") == 4:
     print("  block row 1 part 0: start %.2f, results computed and stores issued %.2f, stores acknowledged %.2f" % tuple(d[5][8:11] - t0))
     print("  chains saw their first row's inputs assembled at", " ".join("%.2f" % (d[r][7] - t0) for r in range(4)))
