@@ -245,6 +245,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, "
                          "or without a launcher")
     visible = int(os.environ.get("IDTO_BENCH_VISIBLE_GPUS", "0"))   # set by the self-launch when ranks must share devices
+    if not visible and world > 1 and 0 < torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+        visible = torch.cuda.device_count()   # (a launcher started more ranks on this node than it has devices: same fallback)
     if visible:
         local_rank = local_rank % visible
         args.mode = "replicas"
