@@ -913,7 +913,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_ldl_kernel<KM, 256, PD, GW>), \
                             hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   LDL_ATTR(2, false, 1) LDL_ATTR(3, false, 1) LDL_ATTR(5, false, 1) LDL_ATTR(19, false, 1) LDL_ATTR(23, false, 2)
-  LDL_ATTR(8, true, 1) LDL_ATTR(16, true, 1) LDL_ATTR(24, true, 2) LDL_ATTR(32, true, 3)
+  LDL_ATTR(8, true, 1) LDL_ATTR(16, true, 1) LDL_ATTR(24, true, 2) LDL_ATTR(30, true, 2) LDL_ATTR(32, true, 3)
 #undef LDL_ATTR
 #define ND_ATTR(KM, PD) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_nd_kernel<KM, PD>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   ND_ATTR(2, false) ND_ATTR(3, false) ND_ATTR(5, false) ND_ATTR(19, false) ND_ATTR(23, false)
@@ -1124,10 +1124,14 @@ static int SolverFirstRow(const idto_hip_ctx* c) { return (c->h_assembled && c->
 // go through penta_apply_kernel).
 struct LdlPlan {
   int r0, n, k, K, gj_waves, lds, m_split;
+  int lds_full;   // the chain code's carve-up with every row of the system (nested dissection, fused launch: their own row counts)
   size_t qq0;
 };
-static int SolverBlockSize(int k) {
+static int SolverBlockSize(int k, bool single_rhs_only = false) {
   // block sizes of the reference's example models are instantiated exactly, others are padded
+  // (30: the factorisation alone - no penta_apply_kernel of that size -, for the KKT systems of kkt.h: allegro's 23 + 6.
+  // The 32 x 32 instantiation needs three elimination wavefronts and spills 378 registers.)
+  if (single_rhs_only && k > 24 && k <= 30) return 30;
   return (k == 2 || k == 3 || k == 5 || k == 19 || k == 23) ? k : (k <= 8 ? 8 : k <= 16 ? 16 : k <= 24 ? 24 : 32);
 }
 static int PlanLdl(idto_hip_ctx* c, bool one_sided, LdlPlan* p) {
@@ -1136,15 +1140,16 @@ static int PlanLdl(idto_hip_ctx* c, bool one_sided, LdlPlan* p) {
   p->k = c->nq;
   p->qq0 = (size_t)p->r0 * p->k * p->k;
   if (p->k > 32) { g_err = "fast solver supports nq <= 32"; return -1; }
-  p->K = SolverBlockSize(p->k);
+  p->K = SolverBlockSize(p->k, c->ldl_npos > 0);
   const int per_wave = 64 - p->K, ncr = 2 * p->K + 1;
   p->gj_waves = (ncr + per_wave - 1) / per_wave;
-  const PentaLdlLds L = penta_ldl_layout(p->n, p->K, 1);
-  p->lds = L.end * (int)sizeof(double);
-  if (p->lds > 160 * 1024) { g_err = "right-hand sides do not fit the LDS carve-up"; return -1; }
   // two-sided elimination (two workgroups meeting at block rows m, m+1) once the horizon is long
   // enough to pay for the hand-over
   p->m_split = (c->two_sided && !one_sided && p->n >= 10) ? (p->n - 1) / 2 : 0;
+  // (a workgroup of the two-sided elimination keeps the right-hand side and rt / x of its own rows only)
+  p->lds = penta_ldl_layout(p->n, p->K, 1, ldl_two_sided_rows(p->n, p->m_split, 1)).end * (int)sizeof(double);
+  p->lds_full = penta_ldl_layout(p->n, p->K, 1).end * (int)sizeof(double);
+  if (p->lds > 160 * 1024) { g_err = "right-hand sides do not fit the LDS carve-up"; return -1; }
   // the two workgroups must not share a CU (each is one wavefront per SIMD, issue-bound): ask for
   // more than half of the 160 KB LDS so that the dispatcher cannot co-locate them
   if (p->m_split > 0) p->lds = std::max(p->lds, 84 * 1024);
@@ -1189,7 +1194,7 @@ static int NdLds(const idto_hip_ctx* c, const LdlPlan& p, int nloc_max) {
   (void)nloc_max;
   const int spike = (3 * NF * ks + 3 * KP * ks + 3 * p.K * p.K + 2 * ks + 4) * (int)sizeof(double);
   const int sep = (2 * (NF + 1) * (NF + 1) + 2 + (2 * p.K + 1) * ks + (p.K + 1) * ks + 2 * p.K * ks + p.K * ks + 6 * ks) * (int)sizeof(double);
-  return std::max(std::max(spike, sep), p.lds);
+  return std::max(std::max(spike, sep), p.lds_full);
 }
 static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double sign, double* xo) {
   NdArgs A;
@@ -1305,6 +1310,7 @@ static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, double* xo, 
     case 19: LDL_LAUNCH(19, false, 1); break;
     case 23: LDL_LAUNCH(23, false, 2); break;
     case 24: LDL_LAUNCH(24, true, 2); break;
+    case 30: LDL_LAUNCH(30, true, 2); break;
     default: LDL_LAUNCH(32, true, 3); break;
   }
 #undef LDL_LAUNCH
@@ -1348,7 +1354,7 @@ static int LaunchFused(idto_hip_ctx* c) {
   while (ec > groups && FdLds(c, mode, ec, false, false) > 160 * 1024) ec = ((ec - 1) / groups) * groups;
   const int fd_lds = FdLds(c, mode, ec, false, false);
   if (fd_lds > 160 * 1024) { g_err = "finite-difference evaluation set does not fit in LDS"; return -1; }
-  const int lds = std::max(std::max(fd_lds, c->asm_diag_lds), std::max(p.lds, 84 * 1024));
+  const int lds = std::max(std::max(fd_lds, c->asm_diag_lds), std::max(p.lds_full, 84 * 1024));
   FusedArgs A;
   A.M = c->M; A.cp = c->cp; A.P = c->P;
   A.q = c->q; A.slab = c->slab; A.slab_stride = c->slab_stride; A.v = c->v; A.a = c->a; A.nplus = c->nplus;
@@ -1873,9 +1879,10 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     rc = idto_hip_gn_step(c);
   }
   if (rc) return rc;
-  // (blocks of nq + nu up to the 24 x 24 instantiation: above it the two-workgroup factorisation of the padded 32 x 32
-  // blocks costs more than the Schur-complement chain - allegro, 23 + 6, N = 20: 442 against 245 us per iteration)
-  const bool use_kkt = nu > 0 && c->con_kkt && SolverBlockSize(c->nq + nu) <= 24;
+  // (blocks of nq + nu up to the 30 x 30 instantiation of the two-workgroup factorisation: allegro's 23 + 6, N = 60,
+  // 0.523 against 0.665 ms per iteration with the Schur-complement chain; the 32 x 32 one needs a third elimination
+  // wavefront and spills: 442 against 245 us at N = 20)
+  const bool use_kkt = nu > 0 && c->con_kkt && SolverBlockSize(c->nq + nu, true) <= 30;
   if (use_kkt) {
     if ((rc = ConstraintBuffers(c, constrained_dofs, nu)) != 0) return rc;
     if ((rc = MakeKkt(c, nu)) != 0) return rc;
@@ -1932,7 +1939,7 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
       Ke.N = c->N; Ke.nq = c->nq; Ke.nv = c->nv; Ke.nu = nu;
       Ke.z = kc->step; Ke.slab = c->slab; Ke.slab_stride = c->slab_stride; Ke.dofs = c->con_dofs;
       Ke.w = c->con_out; Ke.jtl = c->con_out + n; Ke.lambda = c->con_lambda;
-      Ke.Dinv = kc->Dst; Ke.dstride = SolverBlockSize(kc->nq); Ke.first_row = SolverFirstRow(kc);
+      Ke.Dinv = kc->Dst; Ke.dstride = SolverBlockSize(kc->nq, true); Ke.first_row = SolverFirstRow(kc);
       Ke.state = c->tr_state; Ke.alt = c->alt_r;
       hipLaunchKernelGGL(kkt_extract_kernel, dim3(c->N + 1), dim3(64), 0, c->stream, Ke);
       HIP_OK(hipGetLastError());

@@ -174,7 +174,9 @@ struct PentaLdlLds {  // offsets in doubles
   int W, Ht, Et, Iv, rt, U, G, in, dump, yh, ye, Eb, bl, bl_size, xall, end;
   int kks, rts;
 };
-__host__ __device__ inline PentaLdlLds penta_ldl_layout(int n, int K, int nrhs) {
+// `rows` (> 0, single right-hand side): the chain's local rows incl. pseudo-rows - the right-hand side and rt / x of
+// every row are indexed by LOCAL row, so a workgroup of the two-sided elimination needs its own half only
+__host__ __device__ inline PentaLdlLds penta_ldl_layout(int n, int K, int nrhs, int rows = 0) {
   PentaLdlLds L;
   const int ks = ldl_ks(K), ncr = 2 * K + nrhs;
   L.kks = K * ks;
@@ -197,10 +199,11 @@ __host__ __device__ inline PentaLdlLds penta_ldl_layout(int n, int K, int nrhs) 
   L.ye = o; o += 3 * ks;          // ... and (Et_i^T Dn rt_i) of the last three
   L.Eb = o; o += 2 * L.kks;       // E_i = A_{i+2}^T staged straight in column layout (row parity)
   L.bl = o;
-  L.bl_size = (nrhs * n * K <= 4096) ? nrhs * n * K : 0;
+  const int nr = (rows > 0 && nrhs == 1 && rows < n) ? rows : n;
+  L.bl_size = (nrhs * n * K <= 4096) ? nrhs * nr * K : 0;
   o += (L.bl_size + 1) & ~1;      // right-hand sides staged in LDS when small ...
   L.xall = o;                     // ... and rt_i / x_i of every row: [j][n + 2][ks], two leading zero rows
-  o += L.bl_size ? nrhs * (n + 2) * ks : 0;
+  o += L.bl_size ? nrhs * (nr + 2) * ks : 0;
   L.end = o;
   return L;
 }
@@ -234,6 +237,7 @@ struct ChainCfg {
   int factor_only;                  // stop once the factors are in HBM: every right-hand side (the first included) goes
                                     // through penta_apply_kernel, the chains' own back substitution is off the path
   SpinCtl spin;                     // where a wait between workgroups that ran out reports it
+  int lds_rows;                     // penta_ldl_layout's `rows` (0: every row of the system)
   int npos;                         // > 0: the pivots [npos, k) of every block row belong to multiplier rows of a KKT system
                                     // (kkt.h): negative, and judged by kkt_extract_kernel; 0: a positive definite matrix
 };
@@ -537,7 +541,7 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
   const int ncr = 2 * K + nrhs, per_wave = 64 - K;
   const int gj_waves = GJW ? GJW : (ncr + per_wave - 1) / per_wave;
   const size_t nk = (size_t)n * k;
-  const PentaLdlLds L = penta_ldl_layout(n, K, nrhs);
+  const PentaLdlLds L = penta_ldl_layout(n, K, nrhs, cfg.lds_rows);
   double* Wm = lds + L.W;
   auto stamp = [&](int i, int ph) {
     if (dbg && lane == 0)
@@ -1020,6 +1024,12 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
   penta_ldl_tail<K, NT>(n, k, nrhs, x, Ust, Hst, Est, Dst, dbg, cfg, xch, flags, epoch, L.xall, L.bl_size, L.W, nfwd);
 }
 
+// local rows (incl. the producer's two pseudo-rows, + 2 spare) either workgroup of the two-sided kernel touches
+__host__ __device__ inline int ldl_two_sided_rows(int n, int m_split, int nrhs) {
+  if (m_split <= 0 || nrhs != 1) return 0;
+  const int top = m_split + 2, bottom = n - m_split;
+  return (top > bottom ? top : bottom) + 2;
+}
 // the two roles of the two-workgroup kernel (m_split = 0: one workgroup, the whole system)
 __host__ __device__ inline ChainCfg two_sided_cfg(int n, int m_split, int side) {
   ChainCfg c = {};
@@ -1046,6 +1056,7 @@ penta_ldl_kernel(int n, int k, const double* __restrict__ HA, const double* __re
   ChainCfg cfg = two_sided_cfg(n, m_split, (int)blockIdx.x);
   cfg.factor_only = factor_only;
   cfg.npos = npos;
+  cfg.lds_rows = ldl_two_sided_rows(n, m_split, nrhs);
   cfg.spin = SpinCtl{status + 2 * gridDim.y, fact_id};   // (behind the per-problem status words)
   penta_ldl_body<K, NT, PADDED, GJW>(n, k, at_problem(HA, o), at_problem(HB, o), at_problem(HC, o), at_problem(b, o),
                                      rhs_sign, nrhs, at_problem(x, o), at_problem(Ust, o), at_problem(Hst, o),

@@ -113,10 +113,14 @@ def test_two_ranks_on_one_gpu(name, N):
     assert all(v == "ok" for v in res.values()), res
 
 
-def test_cpp_optimizer_over_a_device_list():
+def test_cpp_optimizer_over_a_device_list(monkeypatch):
     """idto::optimizer::TrajectoryOptimizer with a device list (here the one device of the box):
     the sharded evaluation of the partials (idto_hip_comm_init_all + idto_hip_eval_partials_multi)
-    inside Solve gives the iterates of the single-device optimizer, bit for bit"""
+    inside Solve gives the iterates of the single-device optimizer, bit for bit.  (hopper's YAML enforces its equality
+    constraints: the device-list optimizer runs the host loop with the Schur-complement route, so the single-device
+    one is held to that route too - IDTO_CON_KKT=0; the banded KKT step agrees with it to the tolerances of
+    tests/test_gpu_trust_region.py, not to the bit.)"""
+    monkeypatch.setenv("IDTO_CON_KKT", "0")
     from idto_amd.optimizer import TrajectoryOptimizer, TrajectoryOptimizerSolution, TrajectoryOptimizerStats
     name, N = "hopper", 20
     cfg, model = load_config(name), load_model(name)
