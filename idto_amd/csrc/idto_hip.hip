@@ -913,10 +913,10 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_ldl_kernel<KM, 256, PD, GW>), \
                             hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   LDL_ATTR(2, false, 1) LDL_ATTR(3, false, 1) LDL_ATTR(5, false, 1) LDL_ATTR(19, false, 1) LDL_ATTR(23, false, 2)
-  LDL_ATTR(8, true, 1) LDL_ATTR(16, true, 1) LDL_ATTR(24, true, 2) LDL_ATTR(30, true, 2) LDL_ATTR(32, true, 3)
+  LDL_ATTR(8, true, 1) LDL_ATTR(16, true, 1) LDL_ATTR(24, true, 2) LDL_ATTR(30, true, 2) LDL_ATTR(29, false, 2) LDL_ATTR(32, true, 3)
 #undef LDL_ATTR
 #define ND_ATTR(KM, PD) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_nd_kernel<KM, PD>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-  ND_ATTR(2, false) ND_ATTR(3, false) ND_ATTR(5, false) ND_ATTR(19, false) ND_ATTR(23, false)
+  ND_ATTR(2, false) ND_ATTR(3, false) ND_ATTR(5, false) ND_ATTR(19, false) ND_ATTR(23, false) ND_ATTR(29, false)
 #undef ND_ATTR
 #define PIPE_ATTR(KM) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_pipe_kernel<KM>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   PIPE_ATTR(2) PIPE_ATTR(3) PIPE_ATTR(5) PIPE_ATTR(19)
@@ -1131,6 +1131,7 @@ static int SolverBlockSize(int k, bool single_rhs_only = false) {
   // block sizes of the reference's example models are instantiated exactly, others are padded
   // (30: the factorisation alone - no penta_apply_kernel of that size -, for the KKT systems of kkt.h: allegro's 23 + 6.
   // The 32 x 32 instantiation needs three elimination wavefronts and spills 378 registers.)
+  if (single_rhs_only && k == 29) return 29;
   if (single_rhs_only && k > 24 && k <= 30) return 30;
   return (k == 2 || k == 3 || k == 5 || k == 19 || k == 23) ? k : (k <= 8 ? 8 : k <= 16 ? 16 : k <= 24 ? 24 : 32);
 }
@@ -1179,22 +1180,26 @@ static NdSplit nd_split(int n, bool pipe) {
   sp.j2 = n - producer_rows(hbot) - 2;             // producer P3: rows j2+2 .. n-1
   return sp;
 }
+static int NdLds(const idto_hip_ctx* c, const LdlPlan& p, int nloc_max);
 static bool NdEligible(const idto_hip_ctx* c, const LdlPlan& p) {
-  const bool inst = (p.K == 2 || p.K == 3 || p.K == 5 || p.K == 19 || p.K == 23) && p.K == p.k;
+  const bool inst = (p.K == 2 || p.K == 3 || p.K == 5 || p.K == 19 || p.K == 23 || p.K == 29) && p.K == p.k;
   // (seven workgroups per problem, one per CU: a batch that would not fit the 256 CUs at once is
   // better served by the two-workgroup form - same work per problem on fewer CUs)
   if (!(c->solver_nd && c->two_sided && inst && p.n >= 24 && 7 * c->batch <= 256)) return false;
   // the joiner chains' per-row tables hold ND_MAXROWS local rows: longer horizons (n >= 127) take the
   // two-workgroup factorisation
   NdSplit sp = nd_split(p.n, c->solver_pipe && p.K <= 20);
-  return std::max(std::max(sp.s - sp.j1, sp.j2 - sp.s), std::max(sp.j1, p.n - sp.j2 - 2)) <= ND_MAXROWS;
+  const int nloc_max = std::max(std::max(sp.s - sp.j1, sp.j2 - sp.s), std::max(sp.j1, p.n - sp.j2 - 2));
+  return nloc_max <= ND_MAXROWS && NdLds(c, p, nloc_max) <= 160 * 1024;
 }
+// (the chains keep the right-hand side and rt / x of their own rows: joiner nloc, producer nloc + 2 pseudo-rows, + 2 spare)
+static int NdChainRows(int nloc_max) { return nloc_max + 4; }
 static int NdLds(const idto_hip_ctx* c, const LdlPlan& p, int nloc_max) {
   const int ks = ldl_ks(p.K), NF = 2 * p.K, KP = 4 * ((p.K + 3) / 4);
-  (void)nloc_max;
+  const int chain = penta_ldl_layout(p.n, p.K, 1, NdChainRows(nloc_max)).end * (int)sizeof(double);
   const int spike = (3 * NF * ks + 3 * KP * ks + 3 * p.K * p.K + 2 * ks + 4) * (int)sizeof(double);
   const int sep = (2 * (NF + 1) * (NF + 1) + 2 + (2 * p.K + 1) * ks + (p.K + 1) * ks + 2 * p.K * ks + p.K * ks + 6 * ks) * (int)sizeof(double);
-  return std::max(std::max(spike, sep), p.lds_full);
+  return std::max(std::max(spike, sep), chain);
 }
 static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double sign, double* xo) {
   NdArgs A;
@@ -1211,6 +1216,7 @@ static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double s
   if (nloc_max > ND_MAXROWS) { g_err = "horizon too long for the nested-dissection solver's row tables"; return -1; }
   const int lds = NdLds(c, p, nloc_max);
   if (lds > 160 * 1024) { g_err = "nested-dissection solver: LDS carve-up too large"; return -1; }
+  A.npos = c->ldl_npos; A.lds_rows = NdChainRows(nloc_max);
   A.xch = c->xch; A.xch_pair = (int)c->xch_count; A.flags = c->flags;
   if (c->solver_pipe && p.K <= 20) {
     // pipelined chains (penta_pipe.h): five workgroups of eight wavefronts, the joiners carry their spike columns
@@ -1276,6 +1282,7 @@ static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double s
     case 3: ND_LAUNCH(3, false); break;
     case 5: ND_LAUNCH(5, false); break;
     case 23: ND_LAUNCH(23, false); break;
+    case 29: ND_LAUNCH(29, false); break;
     default: ND_LAUNCH(19, false); break;
   }
 #undef ND_LAUNCH
@@ -1311,6 +1318,7 @@ static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, double* xo, 
     case 23: LDL_LAUNCH(23, false, 2); break;
     case 24: LDL_LAUNCH(24, true, 2); break;
     case 30: LDL_LAUNCH(30, true, 2); break;
+    case 29: LDL_LAUNCH(29, false, 2); break;
     default: LDL_LAUNCH(32, true, 3); break;
   }
 #undef LDL_LAUNCH
@@ -1803,7 +1811,9 @@ static int MakeKkt(idto_hip_ctx* c, int nu) {
   std::unique_ptr<idto_hip_ctx> k(new idto_hip_ctx);
   k->device = c->device; k->stream = c->stream; k->own_stream = false;
   k->batch = 1; k->nq = K; k->nv = 0; k->N = N; k->dt = c->dt;
-  k->two_sided = c->two_sided; k->solver_nd = false; k->solver_pipe = false; k->fused = false; k->asm_in_solver = false;
+  // (seven workgroups for allegro's 29 x 29 blocks: 0.46 -> 0.29 ms per iteration; the small systems stay on two - the
+  // nested-dissection order buys them 3 us and costs acrobot's multipliers a digit: 2e-8 against 3e-9)
+  k->two_sided = c->two_sided; k->solver_nd = c->solver_nd && K == 29; k->solver_pipe = false; k->fused = false; k->asm_in_solver = false;
   k->h_assembled = true;      // block row 0 is decoupled (q_0 is no variable, mu_0 a dummy): the chains start at row 1
   k->ldl_npos = c->nq;
   const size_t kk = (size_t)K * K;
@@ -1817,7 +1827,9 @@ static int MakeKkt(idto_hip_ctx* c, int nu) {
   kc->HC = kc->HB + (size_t)(N + 6) * kk;
   kc->xch_count = 2 * (size_t)(3 * 32 + 1) * ldl_ks(32) + 2 * 32;
   kc->flag_count = 16;
-  if (Alloc(kc, 2 * kc->xch_count, &kc->xch) || Alloc(kc, kc->flag_count, &kc->flags)) return fail("hipMalloc (KKT context) failed");
+  if (Alloc(kc, 2 * kc->xch_count, &kc->xch) || Alloc(kc, kc->flag_count, &kc->flags) || Alloc(kc, 4 * (size_t)ND_MAXROWS, &kc->nd_rowcnt) ||
+      Alloc(kc, 4 * (size_t)ND_MAXROWS, &kc->pipe_rowcnt) || Alloc(kc, (size_t)nd_layout(32).end, &kc->nd_buf))
+    return fail("hipMalloc (KKT context) failed");
   if (hipHostMalloc((void**)&kc->status_pin, 4 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess ||
       hipHostGetDevicePointer((void**)&kc->status_dev, kc->status_pin, 0) != hipSuccess)
     return fail("hipHostMalloc (KKT solver status) failed");

@@ -55,6 +55,8 @@ struct NdArgs {
   int asm_first;
   int wt_rows;                   // penta_pipe_kernel: the chains publish a row's spike block, 1 / d and rt with write-through stores (read past the L2, no acquire)
   int debug_pipe_tail;           // measurement aid: penta_pipe_kernel takes the row-by-row back substitution
+  int npos;                      // > 0: a KKT system (kkt.h) - the pivots [npos, k) of every block row are not tested (ldl_pivot_bad)
+  int lds_rows;                  // the chains' carve-up holds this many local rows (penta_ldl_layout `rows`; 0: all n)
 };
 __device__ __forceinline__ void nd_ts(const NdArgs& A, int role, int slot) {
   if (A.ts && threadIdx.x == 0) A.ts[role * 64 + slot] = (double)wall_clock64();
@@ -456,11 +458,12 @@ __device__ __forceinline__ void nd_separator(const NdArgs& A) {
     const double diag0 = (lane < K) ? W[lane * ks + lane] : 1.0;
     double yacc;
     const double myinv = ldl_eliminate_wave<K, false>(xr, lane, yacc);
-    bad = bad || (lane < K && !(myinv > 0.0 && myinv * diag0 < 4503599627370496.0));
+    bad = bad || (lane < K && ldl_pivot_bad(myinv, diag0, lane, k, A.npos));
     if (lane < K) {
 #pragma unroll
       for (int r = 0; r < K; ++r) Us[lane * ks + r] = xr[r];
       dnv[lane] = myinv;
+      A.Dst[(size_t)s * K + lane] = myinv;   // (kkt_extract_kernel looks at every multiplier pivot)
     } else if (lane < 2 * K) {
 #pragma unroll
       for (int r = 0; r < K; ++r) Ht[(lane - K) * ks + r] = xr[r];
@@ -512,11 +515,12 @@ __device__ __forceinline__ void nd_separator(const NdArgs& A) {
     const double diag0 = (lane < K) ? S1[lane * ks + lane] : 1.0;
     double yacc;
     const double myinv = ldl_eliminate_wave<K, false>(xr, lane, yacc);
-    bad = bad || (lane < K && !(myinv > 0.0 && myinv * diag0 < 4503599627370496.0));
+    bad = bad || (lane < K && ldl_pivot_bad(myinv, diag0, lane, k, A.npos));
     if (lane < K) {
 #pragma unroll
       for (int r = 0; r < K; ++r) Us[(K + lane) * ks + r] = xr[r];
       dnv[ks + lane] = myinv;
+      A.Dst[(size_t)(s + 1) * K + lane] = myinv;
     } else if (lane == K) {
 #pragma unroll
       for (int r = 0; r < K; ++r) rtv[ks + r] = xr[r];
@@ -593,6 +597,7 @@ __global__ void __launch_bounds__(256) penta_nd_kernel(NdArgs A) {
   c.dbg_slot = role;
   c.ts = A.ts ? A.ts + role * 64 : nullptr;
   c.spin = A.spin;
+  c.npos = A.npos; c.lds_rows = A.lds_rows;
   int pair;
   if (role == 0) { c.mirror = 0; c.producer = 1; c.base = 0; c.nloc = A.j1; pair = 0; }
   else if (role == 1) { c.mirror = 1; c.producer = 1; c.base = A.n - 1; c.nloc = A.n - A.j2 - 2; pair = 1; }

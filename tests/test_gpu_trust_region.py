@@ -311,7 +311,7 @@ def _kkt_reference(model, prob, sp, q, dev):
 
 
 @pytest.mark.parametrize("name,N,seed", [("acrobot", 40, 1), ("spinner", 40, 1), ("hopper", 40, 1), ("hopper", 40, 2), ("hopper", 50, 3),
-                                         ("hopper", 9, 1), ("acrobot", 3, 2), ("spinner", 128, 1)])
+                                         ("hopper", 9, 1), ("acrobot", 3, 2), ("spinner", 128, 1), ("allegro_hand", 20, 1), ("allegro_hand", 60, 2)])
 def test_banded_kkt_multipliers_are_as_accurate_as_the_schur_complement_chain(name, N, seed):
     """csrc/kkt.h: the multipliers from one unpivoted banded LDL^T of the KKT system against an extended-precision
     solution of that system.  The systems are badly conditioned (1e8 .. 1e12) and BOTH device paths - this one and the
@@ -329,7 +329,7 @@ def test_banded_kkt_multipliers_are_as_accurate_as_the_schur_complement_chain(na
         dev.eval_tau()
         rows, _ = dev.tr_solve(1, SCALING["double_sqrt"], True, False, 1e-1, 1e5, constrained_dofs=dofs)
         assert rows[0, 14] == 0
-        assert dev.get_option("kkt_last_solver") == (1 if kkt else 0)
+        assert dev.get_option("kkt_last_solver") in ((1, 2) if kkt else (0,))   # two-workgroup / seven-workgroup factorisation
         lam[kkt] = dev.get("con_lambda")
         if kkt:
             want = _kkt_reference(model, prob, sp, q, dev)
