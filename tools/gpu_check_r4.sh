@@ -38,5 +38,7 @@ for kkt in 1 0; do
   IDTO_CON_KKT=$kkt bash tools/prof_full_iter.sh hopper 40 > /dev/null 2>&1
   cp gpurun_out/prof_fi_hopper/fi_kernel_stats.csv gpurun_out/${R}_constrained_iteration_hopper_kkt${kkt}_kernel_stats.csv
 done
-for kkt in 1 0; do for c in "acrobot 40" "spinner 40" "hopper 40"; do echo -n "IDTO_CON_KKT=$kkt  "; IDTO_CON_KKT=$kkt timeout 120 python tools/full_iter_prof.py $c 2>&1 | tail -1; done; done | tee -a gpurun_out/${R}_constrained_iteration_times.txt
+IDTO_CON_KKT=1 bash tools/prof_full_iter.sh allegro_hand 20 > /dev/null 2>&1
+cp gpurun_out/prof_fi_allegro_hand/fi_kernel_stats.csv gpurun_out/${R}_constrained_iteration_allegro_kkt1_kernel_stats.csv
+for kkt in 1 0; do for c in "acrobot 40" "spinner 40" "hopper 40" "allegro_hand 20"; do echo -n "IDTO_CON_KKT=$kkt  "; IDTO_CON_KKT=$kkt timeout 120 python tools/full_iter_prof.py $c 2>&1 | tail -1; done; done | tee -a gpurun_out/${R}_constrained_iteration_times.txt
 ls gpurun_out | head -80
