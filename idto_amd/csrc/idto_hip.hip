@@ -181,6 +181,8 @@ struct idto_hip_ctx {
   // equality-constraint step (constraints.h)
   int* con_dofs = nullptr; int con_nu = 0, con_neq = 0;
   std::vector<int> con_dofs_host;
+  bool con_schur_valid = false;            // con_S, con_d, ... are allocated for con_dofs_host
+  std::vector<int> kkt_dofs_host;          // (the banded KKT step's copy of the set: it shares con_dofs with the Schur route)
   double *con_S = nullptr, *con_lambda = nullptr, *con_out = nullptr;  // device: [S | J y_g], lambda, [step | J^T lambda]
   double *con_d = nullptr, *con_h = nullptr;                            // dense LDL^T: pivots, [min, max | h]
   double* con_rv = nullptr;                                            // ... and L^-1 (h - J y_g), carried along by the factorisation
@@ -801,6 +803,9 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   const size_t o_trD = carve(nvars, D), o_trg = carve(nvars, D), o_trw = carve(nvars, D), o_trdq = carve(nvars, D),
                o_qt = carve(nvars, D), o_trout = carve(16, D), o_trDp = carve(nvars, D), o_trpart = carve((size_t)9 * (N + 1), D);
   const size_t o_trstate = carve(TRS_COUNT, D), o_trcnt = carve(1, sizeof(unsigned long long));
+  // the equality-constraint step's outputs (per problem, so that the batched loop finds them at the arena stride):
+  // [H^-1 (g + J^T lambda) | J^T lambda] and the multipliers (nu <= nv; + 2: the blocked dense LDL^T's [min, max | ...])
+  const size_t o_conout = carve(2 * nvars, D), o_conlam = carve((size_t)N * nv + 4, D);
   c->pstride = (top + 255) & ~(size_t)255;
   {
     void* p = nullptr;
@@ -836,6 +841,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   c->tr_out = dp(o_trout); c->tr_Dprev = dp(o_trDp); c->tr_part = dp(o_trpart);
   c->terms = dp(o_terms);
   c->tr_state = dp(o_trstate);
+  c->con_out = dp(o_conout); c->con_lambda = dp(o_conlam);
   c->tr_cnt = reinterpret_cast<unsigned long long*>(c->arena + o_trcnt);
   {  // adaptive scaling methods start from D = 1 (TO.cc:1233-1236: scale_factors initialised to ones)
     std::vector<double> ones(nvars, 1.0);
@@ -1498,22 +1504,41 @@ int idto_hip_solve_host(idto_hip_ctx* c, const double* rhs_host, int nrhs, doubl
   return FactorStatus(c);
 }
 
-// the device arrays of the equality-constraint step for this set of degrees of freedom (made again when the set changes)
+// the constrained degrees of freedom on the device (the banded KKT step needs nothing else; batch contexts included)
+static int ConstraintDofs(idto_hip_ctx* c, const int* dofs, int nu) {
+  if (!dofs || nu < 1 || nu > c->nv) { g_err = "equality constraints: bad arguments"; return -1; }
+  for (int j = 0; j < nu; ++j)
+    if (dofs[j] < 0 || dofs[j] >= c->nv) { g_err = "equality constraints: dof index out of range"; return -1; }
+  if (c->kkt_dofs_host.size() == (size_t)nu && std::equal(dofs, dofs + nu, c->kkt_dofs_host.begin()) && c->con_dofs) return 0;
+  void* p = nullptr;
+  HIP_OK(hipMalloc(&p, (size_t)nu * sizeof(int)));
+  c->allocs.push_back(p);
+  c->con_dofs = static_cast<int*>(p);
+  HIP_OK(hipMemcpy(c->con_dofs, dofs, (size_t)nu * sizeof(int), hipMemcpyHostToDevice));
+  c->kkt_dofs_host.assign(dofs, dofs + nu);
+  c->con_dofs_host.assign(dofs, dofs + nu);
+  c->con_nu = nu; c->con_neq = nu * c->N;
+  c->con_schur_valid = false;   // (the Schur route's buffers, if any, were sized for another set)
+  c->con_begun = false;
+  return 0;
+}
+// the device arrays of the Schur-complement route for this set of degrees of freedom (made again when the set changes)
 static int ConstraintBuffers(idto_hip_ctx* c, const int* dofs, int nu) {
   if (!dofs || nu < 1 || nu > c->nv) { g_err = "constraint_schur: bad arguments"; return -1; }
   if (c->batch != 1) { g_err = "the equality-constraint step serves single-problem contexts"; return -1; }
   for (int j = 0; j < nu; ++j)
     if (dofs[j] < 0 || dofs[j] >= c->nv) { g_err = "constraint_schur: dof index out of range"; return -1; }
   const int N = c->N, n = (N + 1) * c->nq, neq = nu * N;
-  if (c->con_nu != nu || !std::equal(dofs, dofs + nu, c->con_dofs_host.begin())) {
+  if (!c->con_schur_valid || c->con_nu != nu || !std::equal(dofs, dofs + nu, c->con_dofs_host.begin())) {
     c->con_dofs_host.assign(dofs, dofs + nu);
+    c->kkt_dofs_host.clear();
+    c->con_schur_valid = true;
     void* p = nullptr;
     HIP_OK(hipMalloc(&p, (size_t)nu * sizeof(int)));
     c->allocs.push_back(p);
     c->con_dofs = static_cast<int*>(p);
     HIP_OK(hipMemcpy(c->con_dofs, dofs, (size_t)nu * sizeof(int), hipMemcpyHostToDevice));
-    if (Alloc(c, (size_t)neq * neq + neq, &c->con_S) || Alloc(c, (size_t)neq + 2, &c->con_lambda) ||
-        Alloc(c, (size_t)2 * n, &c->con_out) ||
+    if (Alloc(c, (size_t)neq * neq + neq, &c->con_S) ||
         Alloc(c, (size_t)neq, &c->con_d) || Alloc(c, (size_t)neq + 2, &c->con_h) || Alloc(c, (size_t)neq * neq, &c->con_L) ||
         Alloc(c, 2 * (size_t)neq, &c->con_rv))   // [r with the finished panels eliminated | y = L^-1 r]
       return -2;
@@ -1806,11 +1831,11 @@ int idto_hip_tr_reject(idto_hip_ctx* c) {
 static int MakeKkt(idto_hip_ctx* c, int nu) {
   if (c->kkt && c->kkt_nu == nu) return 0;
   if (c->kkt) { idto_hip_destroy(c->kkt); c->kkt = nullptr; }
-  const int K = c->nq + nu, N = c->N;
+  const int K = c->nq + nu, N = c->N, B = c->batch;
   if (K > 32) { g_err = "tr_solve: nq + nu <= 32 for the banded equality-constraint step"; return -1; }
   std::unique_ptr<idto_hip_ctx> k(new idto_hip_ctx);
   k->device = c->device; k->stream = c->stream; k->own_stream = false;
-  k->batch = 1; k->nq = K; k->nv = 0; k->N = N; k->dt = c->dt;
+  k->batch = B; k->nq = K; k->nv = 0; k->N = N; k->dt = c->dt;
   // (seven workgroups for allegro's 29 x 29 blocks: 0.46 -> 0.29 ms per iteration; the small systems stay on two - the
   // nested-dissection order buys them 3 us and costs acrobot's multipliers a digit: 2e-8 against 3e-9)
   k->two_sided = c->two_sided; k->solver_nd = c->solver_nd && K == 29; k->solver_pipe = false; k->fused = false; k->asm_in_solver = false;
@@ -1819,21 +1844,42 @@ static int MakeKkt(idto_hip_ctx* c, int nu) {
   const size_t kk = (size_t)K * K;
   idto_hip_ctx* kc = k.get();
   auto fail = [&](const char* what) { g_err = what; idto_hip_destroy(k.release()); return -2; };
-  if (Alloc(kc, (size_t)3 * (N + 6) * kk, &kc->HA) || Alloc(kc, (size_t)(N + 1) * K, &kc->g) || Alloc(kc, (size_t)(N + 1) * K, &kc->step) ||
-      Alloc(kc, (size_t)(N + 1) * 32 * 36, &kc->Ust) || Alloc(kc, (size_t)(N + 1) * 32 * 36, &kc->Hst) ||
-      Alloc(kc, (size_t)(N + 1) * 32 * 36, &kc->Est) || Alloc(kc, (size_t)(N + 1) * 32, &kc->Dst) || Alloc(kc, (size_t)(N + 4) * 8 * 32, &kc->dbg))
-    return fail("hipMalloc (KKT context) failed");
-  kc->HB = kc->HA + (size_t)(N + 6) * kk;
-  kc->HC = kc->HB + (size_t)(N + 6) * kk;
+  // one arena per problem, as in idto_hip_create_batch: the solver kernels take the problem from blockIdx.y
+  size_t top = 0;
+  auto carve = [&](size_t count, size_t elem) {
+    const size_t o = (top + 63) & ~(size_t)63;
+    top = o + std::max<size_t>(count, 1) * elem;
+    return o;
+  };
+  const size_t D = sizeof(double);
   kc->xch_count = 2 * (size_t)(3 * 32 + 1) * ldl_ks(32) + 2 * 32;
   kc->flag_count = 16;
-  if (Alloc(kc, 2 * kc->xch_count, &kc->xch) || Alloc(kc, kc->flag_count, &kc->flags) || Alloc(kc, 4 * (size_t)ND_MAXROWS, &kc->nd_rowcnt) ||
-      Alloc(kc, 4 * (size_t)ND_MAXROWS, &kc->pipe_rowcnt) || Alloc(kc, (size_t)nd_layout(32).end, &kc->nd_buf))
-    return fail("hipMalloc (KKT context) failed");
-  if (hipHostMalloc((void**)&kc->status_pin, 4 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess ||
+  const size_t o_H = carve((size_t)3 * (N + 6) * kk, D), o_g = carve((size_t)(N + 1) * K, D), o_step = carve((size_t)(N + 1) * K, D);
+  const size_t o_U = carve((size_t)(N + 1) * 32 * 36, D), o_Hs = carve((size_t)(N + 1) * 32 * 36, D), o_E = carve((size_t)(N + 1) * 32 * 36, D);
+  const size_t o_Ds = carve((size_t)(N + 1) * 32, D), o_dbg = carve((size_t)(N + 4) * 8 * 32, D);
+  const size_t o_xch = carve(2 * kc->xch_count, D), o_flags = carve(kc->flag_count, sizeof(unsigned));
+  const size_t o_ndcnt = carve(4 * ND_MAXROWS, sizeof(unsigned long long)), o_pipecnt = carve(4 * ND_MAXROWS, sizeof(unsigned long long));
+  const size_t o_ndbuf = carve((size_t)nd_layout(32).end, D);
+  kc->pstride = (top + 255) & ~(size_t)255;
+  {
+    void* p = nullptr;
+    if (hipMalloc(&p, kc->pstride * (size_t)B) != hipSuccess || hipMemset(p, 0, kc->pstride * (size_t)B) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess)
+      return fail("hipMalloc (KKT context) failed");
+    kc->allocs.push_back(p);
+    kc->arena = static_cast<char*>(p);
+  }
+  auto dp = [&](size_t o) { return reinterpret_cast<double*>(kc->arena + o); };
+  kc->HA = dp(o_H); kc->HB = kc->HA + (size_t)(N + 6) * kk; kc->HC = kc->HB + (size_t)(N + 6) * kk;
+  kc->g = dp(o_g); kc->step = dp(o_step); kc->Ust = dp(o_U); kc->Hst = dp(o_Hs); kc->Est = dp(o_E); kc->Dst = dp(o_Ds); kc->dbg = dp(o_dbg);
+  kc->xch = dp(o_xch); kc->flags = reinterpret_cast<unsigned*>(kc->arena + o_flags);
+  kc->nd_rowcnt = reinterpret_cast<unsigned long long*>(kc->arena + o_ndcnt);
+  kc->pipe_rowcnt = reinterpret_cast<unsigned long long*>(kc->arena + o_pipecnt);
+  kc->nd_buf = dp(o_ndbuf);
+  if (hipHostMalloc((void**)&kc->status_pin, (2 * (size_t)B + 2) * sizeof(unsigned), hipHostMallocDefault) != hipSuccess ||
       hipHostGetDevicePointer((void**)&kc->status_dev, kc->status_pin, 0) != hipSuccess)
     return fail("hipHostMalloc (KKT solver status) failed");
-  for (int i = 0; i < 4; ++i) kc->status_pin[i] = 0;
+  for (int i = 0; i < 2 * B + 2; ++i) kc->status_pin[i] = 0;
   c->kkt = k.release(); c->kkt_nu = nu;
   return 0;
 }
@@ -1845,7 +1891,6 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
                    double* rows_host, double* Delta_out) {
   HIP_OK(hipSetDevice(c->device));
   const int B = c->batch;
-  if (B != 1 && nu > 0) { g_err = "tr_solve: enforced constraints serve single-problem contexts"; return -1; }
   if (iterations <= 0) { g_err = "tr_solve: iterations must be positive"; return -1; }
   if (nu < 0 || (nu > 0 && !constrained_dofs)) { g_err = "tr_solve: bad constraint arguments"; return -1; }
   const int neq = nu * c->N;
@@ -1895,8 +1940,9 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
   // 0.523 against 0.665 ms per iteration with the Schur-complement chain; the 32 x 32 one needs a third elimination
   // wavefront and spills: 442 against 245 us at N = 20)
   const bool use_kkt = nu > 0 && c->con_kkt && SolverBlockSize(c->nq + nu, true) <= 30;
+  if (B != 1 && nu > 0 && !use_kkt) { g_err = "tr_solve: enforced constraints on a batch need the banded KKT step (nq + nu <= 30, option con_kkt)"; return -1; }
   if (use_kkt) {
-    if ((rc = ConstraintBuffers(c, constrained_dofs, nu)) != 0) return rc;
+    if ((rc = ConstraintDofs(c, constrained_dofs, nu)) != 0) return rc;
     if ((rc = MakeKkt(c, nu)) != 0) return rc;
   }
   const bool lookahead = c->weights_diagonal && c->asm_stop == 0 && c->fd_stop == 0;
@@ -1943,7 +1989,8 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
       Kb.HA = c->HA; Kb.HB = c->HB; Kb.HC = c->HC; Kb.g = c->g;
       Kb.slab = c->slab; Kb.slab_stride = c->slab_stride; Kb.dofs = c->con_dofs;
       Kb.KA = kc->HA; Kb.KB = kc->HB; Kb.KC = kc->HC; Kb.rhs = kc->g; Kb.alt = c->alt_r;
-      hipLaunchKernelGGL(kkt_build_kernel, dim3(c->N + 1), dim3(256), 0, c->stream, Kb);
+      Kb.pstride = c->pstride; Kb.kstride = kc->pstride;
+      hipLaunchKernelGGL(kkt_build_kernel, dim3(c->N + 1, B), dim3(256), 0, c->stream, Kb);
       HIP_OK(hipGetLastError());
       rc = idto_hip_factor_solve(kc, nullptr, 1, nullptr);
       if (rc) return rc;
@@ -1953,7 +2000,8 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
       Ke.w = c->con_out; Ke.jtl = c->con_out + n; Ke.lambda = c->con_lambda;
       Ke.Dinv = kc->Dst; Ke.dstride = SolverBlockSize(kc->nq, true); Ke.first_row = SolverFirstRow(kc);
       Ke.state = c->tr_state; Ke.alt = c->alt_r;
-      hipLaunchKernelGGL(kkt_extract_kernel, dim3(c->N + 1), dim3(64), 0, c->stream, Ke);
+      Ke.pstride = c->pstride; Ke.kstride = kc->pstride;
+      hipLaunchKernelGGL(kkt_extract_kernel, dim3(c->N + 1, B), dim3(64), 0, c->stream, Ke);
       HIP_OK(hipGetLastError());
       c->con_lambda_at = c->con_lambda;
       c->con_ready = false; c->con_begun = false;
@@ -2000,7 +2048,7 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     T.conv = conv;
     T.fact_status = c->status_dev; T.fact_id = c->fact_id;   // (the most recent factorisation: this iteration's step)
     T.timeout_status = c->status_dev + 2 * c->batch;
-    if (nu > 0 && use_kkt) { T.fact_status = c->kkt->status_dev; T.fact_id = c->kkt->fact_id; T.timeout_status = c->kkt->status_dev + 2; }
+    if (nu > 0 && use_kkt) { T.fact_status = c->kkt->status_dev; T.fact_id = c->kkt->fact_id; T.timeout_status = c->kkt->status_dev + 2 * B; }
     T.rows.freeze = c->tr_state + TRS_FLAGS;
     T.pstride = c->pstride; T.rows_stride = rows_stride;
     hipLaunchKernelGGL(tr_iter_kernel, dim3(nblk, B), dim3(256), lds_iter, c->stream, T);
@@ -2061,8 +2109,14 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipMemcpy(rows_host, c->tr_rows, (size_t)B * rows_stride * sizeof(double), hipMemcpyDeviceToHost));
     if (Delta_out) for (int b = 0; b < B; ++b) Delta_out[b] = st[(size_t)b * TRS_COUNT + TRS_DELTA];
-    for (int b = 0; b < B; ++b)
+    for (int b = 0; b < B; ++b) {
+      if (use_kkt) {   // (see the single-problem exit below)
+        const int fs = FactorStatus(c->kkt, b);
+        const bool singular = ((int)st[(size_t)b * TRS_COUNT + TRS_FLAGS] & TRF_SINGULAR_S) != 0;
+        if (fs == IDTO_HIP_SOLVER_TIMEOUT || (fs && !singular)) return fs;
+      }
       if (int fs = FactorStatus(c, b)) return fs;
+    }
     return 0;
   }
   HIP_OK(hipMemcpyAsync(c->tr_pin, c->tr_state, TRS_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -2117,6 +2171,13 @@ int idto_hip_tr_solve_batch_constrained(idto_hip_ctx* c, int iterations, int sca
   const int B = c->batch;
   if (B == 1)
     return TrSolve(c, iterations, scaling_method, scaling, normalize_quaternions, Delta0, Delta_max, eta, constrained_dofs, nu, rows_host, Delta_out);
+  // the banded KKT step (kkt.h) is a sequence of launches with grid.y = problem like everything else of the loop: one
+  // launch set per iteration for the whole batch.  The Schur-complement route (option con_kkt = 0, or nq + nu > 30) is
+  // single-problem launches: a child context, stream and host thread per problem.
+  if (c->con_kkt && SolverBlockSize(c->nq + nu, true) <= 30 && c->weights_diagonal) {
+    if (int rc = idto_hip_eval_tau(c)) return rc;   // (the loop starts from the cost of the resident q; the other route evaluates it per problem)
+    return TrSolve(c, iterations, scaling_method, scaling, normalize_quaternions, Delta0, Delta_max, eta, constrained_dofs, nu, rows_host, Delta_out);
+  }
   if (!c->host_model) { g_err = "tr_solve_batch_constrained: the context keeps no host copy of its model"; return -1; }
   HIP_OK(hipSetDevice(c->device));
   HIP_OK(hipStreamSynchronize(c->stream));

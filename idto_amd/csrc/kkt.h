@@ -45,12 +45,16 @@ struct KktBuildArgs {
   const int* dofs;                    // [nu] constrained (unactuated) degrees of freedom
   double *KA, *KB, *KC, *rhs;         // out: bands of the KKT matrix (blocks (nq + nu)^2, column-major), [g_t ; h_{t-1}]
   AltSel alt;
+  size_t pstride, kstride;            // batch (grid.y = problem): arena strides in bytes of the context and of the KKT context
 };
 
-// grid: N + 1 workgroups (block row t), any block size
+// grid: (N + 1 workgroups (block row t), problems), any block size
 __global__ void kkt_build_kernel(KktBuildArgs A) {
   const int t = blockIdx.x, nq = A.nq, nv = A.nv, nu = A.nu, N = A.N, K = nq + nu, kk = K * K, qq = nq * nq;
-  const double* slab = at_set(A.slab, A.alt);
+  const size_t o = (size_t)blockIdx.y * A.pstride, ok = (size_t)blockIdx.y * A.kstride;
+  A.HA = at_problem(A.HA, o); A.HB = at_problem(A.HB, o); A.HC = at_problem(A.HC, o); A.g = at_problem(A.g, o);
+  A.KA = at_problem(A.KA, ok); A.KB = at_problem(A.KB, ok); A.KC = at_problem(A.KC, ok); A.rhs = at_problem(A.rhs, ok);
+  const double* slab = at_problem(A.slab, o + (size_t)alt_offset(A.alt, o));
   for (int idx = threadIdx.x; idx < 3 * kk; idx += blockDim.x) {
     const int band = idx / kk, e = idx - band * kk, c = e / K, r = e - c * K;   // band 0: M_{t,t-2}, 1: M_{t,t-1}, 2: M_{t,t}
     const int s = t - 2 + band;                                                // block column
@@ -87,12 +91,16 @@ struct KktExtractArgs {
   const double* Dinv; int dstride, first_row;   // the factorisation's 1 / d: solver row i (= block row i + first_row), lane r at Dinv[i dstride + r]
   double* state;                      // the loop's state (TRS_FLAGS)
   AltSel alt;
+  size_t pstride, kstride;            // batch (grid.y = problem): arena strides in bytes of the context and of the KKT context
 };
 
-// grid: N + 1 workgroups of 64 threads (block row t); workgroup 0 also looks at the multiplier pivots
+// grid: (N + 1 workgroups of 64 threads (block row t), problems); workgroup 0 also looks at the multiplier pivots
 __global__ void __launch_bounds__(64) kkt_extract_kernel(KktExtractArgs A) {
   const int t = blockIdx.x, nq = A.nq, nv = A.nv, nu = A.nu, N = A.N, K = nq + nu, lane = threadIdx.x;
-  const double* slab = at_set(A.slab, A.alt);
+  const size_t o = (size_t)blockIdx.y * A.pstride, ok = (size_t)blockIdx.y * A.kstride;
+  A.z = at_problem(A.z, ok); A.Dinv = at_problem(A.Dinv, ok);
+  A.w = at_problem(A.w, o); A.jtl = at_problem(A.jtl, o); A.lambda = at_problem(A.lambda, o); A.state = at_problem(A.state, o);
+  const double* slab = at_problem(A.slab, o + (size_t)alt_offset(A.alt, o));
   for (int r = lane; r < nq; r += 64) {
     const int i = t * nq + r;
     A.w[i] = -A.z[(size_t)t * K + r];

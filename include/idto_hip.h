@@ -291,11 +291,12 @@ int idto_hip_tr_solve_batch(idto_hip_ctx* ctx, int iterations, int scaling_metho
                             const double* Delta0, double Delta_max, double eta, double* rows_host, double* Delta_out);
 /* ... with ENFORCED equality constraints on the `nu` degrees of freedom `constrained_dofs` (the unactuated ones:
  * h = tau[unactuated] = 0, reference TO.cc:1267-1396; BASELINE config 5's own YAML enforces them,
- * examples/allegro_hand/allegro_hand.yaml:95).  The multiplier chain of an iteration is a sequence of single-problem
- * launches, so every problem of the batch is advanced by idto_hip_tr_solve in a single-problem context of its own
- * (created on first use inside this context) on its own stream and host thread: the problems' launches overlap on the
- * device; rows and iterates are, bit for bit, those of idto_hip_tr_solve on the same problem alone.  nu = 0 forwards to
- * idto_hip_tr_solve_batch.  Same residency requirement: every problem's q set (idto_hip_set_q_batch). */
+ * examples/allegro_hand/allegro_hand.yaml:95).  With the banded KKT step (nq + nu <= 30: every example) the constrained
+ * iteration is one launch set for the whole batch, grid.y = problem, like idto_hip_tr_solve_batch; otherwise (option
+ * con_kkt = 0) the multiplier chain is single-problem launches and every problem is advanced in a single-problem context
+ * of its own (created on first use inside this context) on its own stream and host thread.  Either way rows and iterates
+ * are, bit for bit, those of idto_hip_tr_solve on the same problem alone.  nu = 0 forwards to idto_hip_tr_solve_batch.
+ * Same residency requirement: every problem's q set (idto_hip_set_q_batch). */
 int idto_hip_tr_solve_batch_constrained(idto_hip_ctx* ctx, int iterations, int scaling_method, int scaling,
                                         int normalize_quaternions, const double* Delta0, double Delta_max, double eta,
                                         const int* constrained_dofs, int nu, double* rows_host, double* Delta_out);
