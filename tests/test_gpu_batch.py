@@ -150,15 +150,18 @@ def test_trust_region_loop_of_a_batch_equals_the_single_problem_loops(name, N, B
     bd.close()
 
 
-@pytest.mark.parametrize("name,N,B,iters,method", [("allegro_hand", 60, 8, 3, "double_sqrt"), ("hopper", 20, 3, 8, "double_sqrt"),
-                                                   ("spinner", 20, 4, 8, None)])
-def test_constrained_trust_region_loop_of_a_batch_equals_the_single_problem_loops(name, N, B, iters, method):
+@pytest.mark.parametrize("name,N,B,iters,method,kkt", [("allegro_hand", 60, 8, 3, "double_sqrt", 1), ("hopper", 20, 3, 8, "double_sqrt", 1),
+                                                       ("spinner", 20, 4, 8, None, 1), ("hopper", 20, 3, 8, "double_sqrt", 0),
+                                                       ("allegro_hand", 12, 2, 3, "double_sqrt", 0)])
+def test_constrained_trust_region_loop_of_a_batch_equals_the_single_problem_loops(name, N, B, iters, method, kkt, monkeypatch):
     """idto_hip_tr_solve_batch_constrained: the batch's trust-region loop with the equality constraints ENFORCED on the
     unactuated degrees of freedom (h = tau[unactuated] = 0 and its multipliers, reference TO.cc:1267-1396) - what BASELINE
     config 5 iterates (examples/allegro_hand/allegro_hand.yaml:95).  Rows, final radius and final iterate of every problem ==
     those of idto_hip_tr_solve with the same constraints on the same problem in a context of its own; the multiplier chain
-    did run (h, column 8 of the rows, is reported and falls)."""
+    did run (h, column 8 of the rows, is reported and falls).  kkt = 1: the banded KKT step, one launch set per iteration
+    for the whole batch; kkt = 0 (IDTO_CON_KKT=0): the Schur-complement route, a child context per problem."""
     from idto_amd.problem import SCALING
+    monkeypatch.setenv("IDTO_CON_KKT", str(kkt))
     model, probs, sp, qs = _problems(name, N, B)
     dofs = list(model.unactuated_dofs)
     assert len(dofs) > 0
