@@ -919,7 +919,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_ldl_kernel<KM, 256, PD, GW>), \
                             hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   LDL_ATTR(2, false, 1) LDL_ATTR(3, false, 1) LDL_ATTR(5, false, 1) LDL_ATTR(19, false, 1) LDL_ATTR(23, false, 2)
-  LDL_ATTR(8, true, 1) LDL_ATTR(16, true, 1) LDL_ATTR(24, true, 2) LDL_ATTR(30, true, 2) LDL_ATTR(29, false, 2) LDL_ATTR(32, true, 3)
+  LDL_ATTR(8, true, 1) LDL_ATTR(16, true, 1) LDL_ATTR(24, true, 2) LDL_ATTR(30, true, 2) LDL_ATTR(29, false, 2) LDL_ATTR(4, false, 1) LDL_ATTR(32, true, 3)
 #undef LDL_ATTR
 #define ND_ATTR(KM, PD) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_nd_kernel<KM, PD>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   ND_ATTR(2, false) ND_ATTR(3, false) ND_ATTR(5, false) ND_ATTR(19, false) ND_ATTR(23, false) ND_ATTR(29, false)
@@ -1137,7 +1137,7 @@ static int SolverBlockSize(int k, bool single_rhs_only = false) {
   // block sizes of the reference's example models are instantiated exactly, others are padded
   // (30: the factorisation alone - no penta_apply_kernel of that size -, for the KKT systems of kkt.h: allegro's 23 + 6.
   // The 32 x 32 instantiation needs three elimination wavefronts and spills 378 registers.)
-  if (single_rhs_only && k == 29) return 29;
+  if (single_rhs_only && (k == 29 || k == 4)) return k;   // (exact instantiations for the KKT systems of allegro and spinner)
   if (single_rhs_only && k > 24 && k <= 30) return 30;
   return (k == 2 || k == 3 || k == 5 || k == 19 || k == 23) ? k : (k <= 8 ? 8 : k <= 16 ? 16 : k <= 24 ? 24 : 32);
 }
@@ -1325,6 +1325,7 @@ static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, double* xo, 
     case 24: LDL_LAUNCH(24, true, 2); break;
     case 30: LDL_LAUNCH(30, true, 2); break;
     case 29: LDL_LAUNCH(29, false, 2); break;
+    case 4: LDL_LAUNCH(4, false, 1); break;
     default: LDL_LAUNCH(32, true, 3); break;
   }
 #undef LDL_LAUNCH
