@@ -922,7 +922,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   LDL_ATTR(8, true, 1) LDL_ATTR(16, true, 1) LDL_ATTR(24, true, 2) LDL_ATTR(30, true, 2) LDL_ATTR(29, false, 2) LDL_ATTR(4, false, 1) LDL_ATTR(32, true, 3)
 #undef LDL_ATTR
 #define ND_ATTR(KM, PD) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_nd_kernel<KM, PD>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-  ND_ATTR(2, false) ND_ATTR(3, false) ND_ATTR(5, false) ND_ATTR(19, false) ND_ATTR(23, false) ND_ATTR(29, false)
+  ND_ATTR(2, false) ND_ATTR(3, false) ND_ATTR(5, false) ND_ATTR(19, false) ND_ATTR(23, false) ND_ATTR(29, false) ND_ATTR(8, false)
 #undef ND_ATTR
 #define PIPE_ATTR(KM) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_pipe_kernel<KM>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   PIPE_ATTR(2) PIPE_ATTR(3) PIPE_ATTR(5) PIPE_ATTR(19)
@@ -1188,7 +1188,7 @@ static NdSplit nd_split(int n, bool pipe) {
 }
 static int NdLds(const idto_hip_ctx* c, const LdlPlan& p, int nloc_max);
 static bool NdEligible(const idto_hip_ctx* c, const LdlPlan& p) {
-  const bool inst = (p.K == 2 || p.K == 3 || p.K == 5 || p.K == 19 || p.K == 23 || p.K == 29) && p.K == p.k;
+  const bool inst = (p.K == 2 || p.K == 3 || p.K == 5 || p.K == 19 || p.K == 23 || p.K == 29 || (p.K == 8 && c->ldl_npos > 0)) && p.K == p.k;
   // (seven workgroups per problem, one per CU: a batch that would not fit the 256 CUs at once is
   // better served by the two-workgroup form - same work per problem on fewer CUs)
   if (!(c->solver_nd && c->two_sided && inst && p.n >= 24 && 7 * c->batch <= 256)) return false;
@@ -1289,6 +1289,7 @@ static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double s
     case 5: ND_LAUNCH(5, false); break;
     case 23: ND_LAUNCH(23, false); break;
     case 29: ND_LAUNCH(29, false); break;
+    case 8: ND_LAUNCH(8, false); break;
     default: ND_LAUNCH(19, false); break;
   }
 #undef ND_LAUNCH
@@ -1839,7 +1840,7 @@ static int MakeKkt(idto_hip_ctx* c, int nu) {
   k->batch = B; k->nq = K; k->nv = 0; k->N = N; k->dt = c->dt;
   // (seven workgroups for allegro's 29 x 29 blocks: 0.46 -> 0.29 ms per iteration; the small systems stay on two - the
   // nested-dissection order buys them 3 us and costs acrobot's multipliers a digit: 2e-8 against 3e-9)
-  k->two_sided = c->two_sided; k->solver_nd = c->solver_nd && K == 29; k->solver_pipe = false; k->fused = false; k->asm_in_solver = false;
+  k->two_sided = c->two_sided; k->solver_nd = c->solver_nd && (K == 29 || K == 8); k->solver_pipe = false; k->fused = false; k->asm_in_solver = false;
   k->h_assembled = true;      // block row 0 is decoupled (q_0 is no variable, mu_0 a dummy): the chains start at row 1
   k->ldl_npos = c->nq;
   const size_t kk = (size_t)K * K;
