@@ -256,11 +256,12 @@ __host__ __device__ inline int asm_terms_stride(int nq) { return 6 * nq * nq + 3
 // mode 0: tau only (one evaluation); mode 1: forward differences (TO.cc:426-563).
 // Dynamic LDS layout (doubles): see the carve-up below.
 // the instantiated tree shapes of id_fast.h (DevModel::fast_shape; 0 = any model: id_eval<MAXC>)
-template <int SHAPE> struct FastShape { static constexpr int MAXC = 0, NP = 1, CJ = -1, J0 = 0, K0 = 0; };
-template <> struct FastShape<1> { static constexpr int MAXC = 2, NP = 1, CJ = -1, J0 = IDTO_JOINT_REVOLUTE, K0 = PK_WORLD; };             // acrobot
-template <> struct FastShape<2> { static constexpr int MAXC = 3, NP = 1, CJ = -1, J0 = IDTO_JOINT_PLANAR, K0 = PK_WORLD; };               // hopper
-template <> struct FastShape<3> { static constexpr int MAXC = 3, NP = 4, CJ = IDTO_JOINT_FLOATING, J0 = IDTO_JOINT_REVOLUTE, K0 = PK_COMMON; };  // mini_cheetah
-template <> struct FastShape<4> { static constexpr int MAXC = 4, NP = 4, CJ = IDTO_JOINT_FLOATING, J0 = IDTO_JOINT_REVOLUTE, K0 = PK_WORLD; };   // allegro_hand + ball
+template <int SHAPE> struct FastShape { static constexpr int MAXC = 0, NP = 1, CJ = -1, J0 = 0, K0 = 0, W2 = -1; };
+template <> struct FastShape<1> { static constexpr int MAXC = 2, NP = 1, CJ = -1, J0 = IDTO_JOINT_REVOLUTE, K0 = PK_WORLD, W2 = -1; };             // acrobot
+template <> struct FastShape<2> { static constexpr int MAXC = 3, NP = 1, CJ = -1, J0 = IDTO_JOINT_PLANAR, K0 = PK_WORLD, W2 = -1; };               // hopper
+template <> struct FastShape<3> { static constexpr int MAXC = 3, NP = 4, CJ = IDTO_JOINT_FLOATING, J0 = IDTO_JOINT_REVOLUTE, K0 = PK_COMMON, W2 = -1; };  // mini_cheetah
+template <> struct FastShape<4> { static constexpr int MAXC = 4, NP = 4, CJ = IDTO_JOINT_FLOATING, J0 = IDTO_JOINT_REVOLUTE, K0 = PK_WORLD, W2 = -1; };   // allegro_hand + ball
+template <> struct FastShape<5> { static constexpr int MAXC = 3, NP = 1, CJ = -1, J0 = IDTO_JOINT_REVOLUTE, K0 = PK_WORLD, W2 = 2; };              // spinner: two-link finger + the spinner, off the world
 
 template <int MAXC, int SHAPE = 0>
 IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem& P, const double* __restrict__ q,
@@ -582,7 +583,7 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
           in.sda = (in.kind == 2) ? -eda[el] : ((in.kind == 1) ? eda[el] : 0.0);
           in.keep = (in.kind == 3) ? 0ull : ~0ull;
           in.keep0 = (in.kind == 2) ? ~0ull : 0ull;
-          id_eval_fast<FS::MAXC, FS::NP, FS::CJ, FS::J0, FS::K0>(FT, Ml.gravity, cp, path, full, in, etau + el * nv
+          id_eval_fast<FS::MAXC, FS::NP, FS::CJ, FS::J0, FS::K0, FS::W2>(FT, Ml.gravity, cp, path, full, in, etau + el * nv
 #ifdef IDTO_FD_STAMPS
                                                                  , (e0 == 0) ? idto_fd_st : nullptr
 #endif
@@ -590,7 +591,7 @@ IDTO_DEV void fd_body(const DevModel& M, const DevContact& cp, const DevProblem&
         } else {
           InLds in;
           in.q = eq + el * nq; in.v = ev + el * nv; in.a = ea + el * nv;
-          id_eval_fast<FS::MAXC, FS::NP, FS::CJ, FS::J0, FS::K0>(FT, Ml.gravity, cp, path, full, in, etau + (c0 + el) * nv);
+          id_eval_fast<FS::MAXC, FS::NP, FS::CJ, FS::J0, FS::K0, FS::W2>(FT, Ml.gravity, cp, path, full, in, etau + (c0 + el) * nv);
         }
       }
     }

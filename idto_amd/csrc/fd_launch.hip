@@ -12,6 +12,7 @@ void fd_launch(const FdLaunch& a) {
   else if (a.shape == 2) FD_GO(3, 2);
   else if (a.shape == 3) FD_GO(3, 3);
   else if (a.shape == 4) FD_GO(4, 4);
+  else if (a.shape == 5) FD_GO(3, 5);
   else if (a.maxc <= 2) FD_GO(2, 0);
   else if (a.maxc <= 3) FD_GO(3, 0);
   else if (a.maxc <= 4) FD_GO(4, 0);
@@ -23,7 +24,7 @@ void fd_launch(const FdLaunch& a) {
 
 void fd_set_max_lds(int max_lds) {
   FD_ATTR(2, 0); FD_ATTR(3, 0); FD_ATTR(4, 0); FD_ATTR(8, 0);
-  FD_ATTR(2, 1); FD_ATTR(3, 2); FD_ATTR(3, 3); FD_ATTR(4, 4);
+  FD_ATTR(2, 1); FD_ATTR(3, 2); FD_ATTR(3, 3); FD_ATTR(4, 4); FD_ATTR(3, 5);
 }
 
 }  // namespace idto_dev

@@ -341,7 +341,11 @@ struct InFwd {
 };
 
 // tau = ID(q, v, a) for the lane's path: id_eval<MAXC> for a model of shape (CJ, J0, K0).
-template <int MAXC, int NP, int CJ, int J0, int K0, class In>
+// W2 >= 1 (the spinner: finger of two links + the spinner itself in ONE path): slot W2 hangs off the world again, and the
+// pairs of its group touch slot W2 - 1 as their other body (pair_eval's "common" argument is that slot's state; the
+// force on it is taken out of its wrench after the group - the slot has no pairs of its own, BuildModel checks, so the
+// order of the generic sum, fin - (0 + f), is kept).
+template <int MAXC, int NP, int CJ, int J0, int K0, int W2, class In>
 IDTO_DEV void id_eval_fast(const FastTab& T, const double* gravity, const DevContact& cp, int path, bool full,
                            const In& in_fwd, double* tau, long long* idto_fd_st = nullptr) {
   const In& in = in_fwd;
@@ -420,6 +424,8 @@ IDTO_DEV void id_eval_fast(const FastTab& T, const double* gravity, const DevCon
   FD_STAMP(6);
   // ---- own chain: kinematics, inertial wrench and contact pairs slot by slot
   V3 r[MAXC], hW[MAXC], ft[MAXC], nt[MAXC];   // ft, nt: inertial minus contact wrench of the slot
+  BodyState bs_prev;                           // (W2: the state of the slot before)
+  bs_prev.R = ident3(); bs_prev.p = zero; bs_prev.w = zero; bs_prev.v = zero;
   ParentKin P;
   P.R = ident3(); P.p = zero; P.w = zero; P.v = zero; P.al = zero; P.a = zero;
 #pragma unroll
@@ -427,7 +433,7 @@ IDTO_DEV void id_eval_fast(const FastTab& T, const double* gravity, const DevCon
     double rec[FB_PREFETCH];
 #pragma unroll
     for (int i = 0; i < FB_PREFETCH; ++i) rec[i] = rc_next[i];
-    const bool world = (s == 0 && K0 == PK_WORLD);
+    const bool world = (s == 0 && K0 == PK_WORLD) || (W2 >= 1 && s == W2);
     if (s == 0 && K0 == PK_COMMON) { P.R = cb.R; P.p = cb.p; P.w = cb.w; P.v = cb.v; P.al = cb_al; P.a = cb_a; }
     // (a body attached to the world: the record holds I * X_PF)
     const M3 R_WF = world ? ldm3(rec + FB_XPF) : P.R * ldm3(rec + FB_XPF);
@@ -480,10 +486,19 @@ IDTO_DEV void id_eval_fast(const FastTab& T, const double* gravity, const DevCon
     if (s == MAXC - 1) FD_STAMP(8);
     if (s + 1 < MAXC) prefetch_record(bt + (s + 1) * FB_STRIDE, rc_next);   // ... the next slot's, across this slot's pairs
     V3 fext = zero, next = zero;
-    if (full) pair_group<HAS_COMMON>(plist, seg[1 + s], cp, bs, cb, &fext, &next, &cfe, &cne);
+    if (W2 >= 1 && s == W2) {
+      V3 ofe = zero, one = zero;   // ... on the slot before
+      if (full) pair_group<true>(plist, seg[1 + s], cp, bs, bs_prev, &fext, &next, &ofe, &one);
+      ft[W2 - 1] = ft[W2 - 1] - ofe;
+      nt[W2 - 1] = nt[W2 - 1] - one;
+      pin(ft[W2 - 1]); pin(nt[W2 - 1]);
+    } else if (full) {
+      pair_group<HAS_COMMON>(plist, seg[1 + s], cp, bs, cb, &fext, &next, &cfe, &cne);
+    }
     ft[s] = fin - fext;
     nt[s] = nin - next;
     pin(ft[s]); pin(nt[s]);
+    if (W2 >= 1 && s == W2 - 1) bs_prev = bs;
     P.R = bs.R; P.p = bs.p; P.w = bs.w; P.v = bs.v; P.al = al; P.a = acc;
     if (s == 0) FD_STAMP(7);
     if (s == MAXC - 1) FD_STAMP(9);
@@ -500,7 +515,7 @@ IDTO_DEV void id_eval_fast(const FastTab& T, const double* gravity, const DevCon
   for (int s = MAXC - 1; s >= 0; --s) {
     const double* rec = btb + s * FB_STRIDE;
     V3 f = ft[s], n = nt[s];
-    if (s + 1 < MAXC) { f = f + child_f; n = n + child_n; }
+    if (s + 1 < MAXC && s + 1 != W2) { f = f + child_f; n = n + child_n; }   // (slot W2 is no child of the slot before)
     if (s == 0 && J0 == IDTO_JOINT_PLANAR) {
       const M3 R_WF = ldm3(rec + FB_XPF);
       const double t0 = dot(col(R_WF, 0), f), t1 = dot(col(R_WF, 1), f), t2 = dot(col(R_WF, 2), n);

@@ -425,19 +425,22 @@ int BuildModel(idto_hip_ctx* c, const idto_model_t* m) {
     for (int p = 0; p < K; ++p) ok = ok && nchain[p] == maxc;
     const int cj = cbody >= 0 ? m->jtype[cbody] : -1;
     if (cbody >= 0 && cj != IDTO_JOINT_FLOATING) ok = false;
-    int j0 = -1, k0 = -1;
+    int j0 = -1, k0 = -1, w2 = -1;   // w2: a later slot of the (single) path that hangs off the world again (the spinner)
     for (int p = 0; p < K && ok; ++p)
       for (int s = 0; s < maxc; ++s) {
         const int b = chain[(size_t)p * IDTO_MAX_CHAIN + s], jt = m->jtype[b], kd = pkind[(size_t)p * IDTO_MAX_CHAIN + s];
         if (s == 0) {
           if (p == 0) { j0 = jt; k0 = kd; }
           if (jt != j0 || kd != k0) ok = false;
+        } else if (jt == IDTO_JOINT_REVOLUTE && kd == PK_WORLD && K == 1 && w2 < 0) {
+          w2 = s;
         } else if (jt != IDTO_JOINT_REVOLUTE || kd != PK_PREV) {
           ok = false;
         }
       }
     if (ok) {
-      if (maxc == 2 && K == 1 && cj == -1 && j0 == IDTO_JOINT_REVOLUTE && k0 == PK_WORLD) fast_shape = 1;        // acrobot
+      if (w2 >= 0) { if (w2 == 2 && maxc == 3 && K == 1 && cj == -1 && j0 == IDTO_JOINT_REVOLUTE && k0 == PK_WORLD) fast_shape = 5; }   // spinner
+      else if (maxc == 2 && K == 1 && cj == -1 && j0 == IDTO_JOINT_REVOLUTE && k0 == PK_WORLD) fast_shape = 1;   // acrobot
       else if (maxc == 3 && K == 1 && cj == -1 && j0 == IDTO_JOINT_PLANAR && k0 == PK_WORLD) fast_shape = 2;     // hopper
       else if (maxc == 3 && K == 4 && cj == IDTO_JOINT_FLOATING && j0 == IDTO_JOINT_REVOLUTE && k0 == PK_COMMON) fast_shape = 3;   // mini_cheetah
       else if (maxc == 4 && K == 4 && cj == IDTO_JOINT_FLOATING && j0 == IDTO_JOINT_REVOLUTE && k0 == PK_WORLD) fast_shape = 4;    // allegro_hand + ball
@@ -454,7 +457,14 @@ int BuildModel(idto_hip_ctx* c, const idto_model_t* m) {
       int lo_chain_common = 1 << 30, hi_chain_common = -1, last_slot = -1;
       for (int pi : mine) {
         const int nchainb = (sa[pi] >= 0) + (sb[pi] >= 0);
-        if (nchainb > 1) { fast_shape = 0; break; }
+        if (nchainb > 1) {
+          // two chain bodies: slots (w2 - 1, w2) of the spinner's shape only, and slot w2 - 1 has no other pair (the
+          // force on it is taken out of its wrench in one subtraction, as the generic sum fin - (0 + f) is)
+          bool fine = fast_shape == 5 && std::min(sa[pi], sb[pi]) == w2 - 1 && std::max(sa[pi], sb[pi]) == w2;
+          for (int pj : mine) fine = fine && (pj == pi || (sa[pj] != w2 - 1 && sb[pj] != w2 - 1));
+          if (!fine) { fast_shape = 0; break; }
+          continue;
+        }
         if (nchainb == 1 && (sa[pi] == -1 || sb[pi] == -1)) {
           const int sl = std::max(sa[pi], sb[pi]);
           if (sl < last_slot) { fast_shape = 0; break; }   // (slot, index) order != index order on the common body's sum
@@ -516,9 +526,11 @@ int BuildModel(idto_hip_ctx* c, const idto_model_t* m) {
           // C: the chain body of the pair's group, or the common body for a pair without one; the other body is
           // the common one or the world
           const bool a_chain = sa[pi] >= 0, b_chain = sb[pi] >= 0;
-          const bool cia = a_chain || (!b_chain && sa[pi] == -1);
+          // (two chain bodies - the spinner's shape: C is the body of the later slot, the other one is handed to
+          // pair_eval where the common body goes)
+          const bool cia = (a_chain && b_chain) ? sa[pi] > sb[pi] : (a_chain || (!b_chain && sa[pi] == -1));
           const int gc = cia ? ga : gb, go = cia ? gb : ga, so = cia ? sb[pi] : sa[pi];
-          const int info[4] = {m->geom_type[gc], m->geom_type[go], cia ? 1 : 0, so == -1 ? 1 : 0};
+          const int info[4] = {m->geom_type[gc], m->geom_type[go], cia ? 1 : 0, (so == -1 || so >= 0) ? 1 : 0};
           std::memcpy(rec + FP_INFO, info, sizeof(info));
           std::memcpy(rec + FP_XC, m->geom_X + (size_t)12 * gc, 12 * sizeof(double));
           std::memcpy(rec + FP_SC, m->geom_size + (size_t)3 * gc, 3 * sizeof(double));
@@ -2383,7 +2395,7 @@ int idto_hip_get_option(idto_hip_ctx* c, const char* name, int* value) {
   if (std::strcmp(name, "two_sided") == 0) { *value = c->two_sided; return 0; }
   if (std::strcmp(name, "reference_solver") == 0) { *value = c->reference_solver; return 0; }
   if (std::strcmp(name, "gradients_method") == 0) { *value = c->gradients_method; return 0; }
-  if (std::strcmp(name, "fast_shape") == 0) { *value = c->M.fast_shape; return 0; }   // id_fast.h: 0 none, 1 acrobot, 2 hopper, 3 mini_cheetah, 4 allegro_hand
+  if (std::strcmp(name, "fast_shape") == 0) { *value = c->M.fast_shape; return 0; }   // id_fast.h: 0 none, 1 acrobot, 2 hopper, 3 mini_cheetah, 4 allegro_hand, 5 spinner
   if (std::strcmp(name, "fd_fast") == 0) { *value = c->fd_fast ? 1 : 0; return 0; }
   g_err = std::string("unknown option ") + name;
   return -1;

@@ -1,7 +1,7 @@
 """The straight-line inverse-dynamics evaluation of csrc/id_fast.h against the generic id_eval<MAXC> it specialises.
 
 BuildModel (idto_hip.hip) recognises the tree shapes that are instantiated - acrobot, hopper, mini_cheetah, allegro_hand
-(+ ball); the spinner's third body hangs off the world again and its pairs touch two chain bodies: no fast shape - and
+(+ ball), spinner (its third body hangs off the world again and its pair touches two chain bodies: shape 5) - and
 fd_kernel<MAXC, SHAPE> then evaluates with compile-time joint types, host-gathered records, contact pairs inside the
 forward recursion, inputs formed by the consuming lane.  Same operations in the same order: every output of the
 finite-difference kernel and of the assembly must have the same bits either way (the parity tests of
@@ -17,7 +17,7 @@ from oracle_lib import Oracle
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = {"acrobot": 1, "hopper": 2, "mini_cheetah": 3, "allegro_hand": 4, "spinner": 0}
+SHAPES = {"acrobot": 1, "hopper": 2, "mini_cheetah": 3, "allegro_hand": 4, "spinner": 5}
 ARRAYS = ("v", "a", "tau", "dtau_dqp", "dtau_dqt", "dtau_dqm", "gradient", "H_A", "H_B", "H_C", "step")
 
 
@@ -98,3 +98,29 @@ def test_a_pair_order_the_fast_walk_cannot_keep_falls_back_to_the_generic_evalua
         assert same(fast[k], generic[k]), (shape, k)
     orc = Oracle(m2, prob, sp)
     assert same(generic["tau"], orc.eval_traj(q)[2])
+
+
+def test_spinner_pair_between_two_chain_bodies():
+    """shape 5: the finger tip against the spinner - both bodies of the pair are slots of the one path; the pair is
+    evaluated at the later slot and its reaction taken out of the earlier slot's wrench.  On a trajectory that keeps the
+    two in contact (the contact force is there: tau changes with the stiffness) fast == generic == oracle."""
+    name, N = "spinner", 40
+    cfg, model = load_config(name), load_model(name)
+    prob, sp, _ = make_problem(cfg, model, num_steps=N)
+    sp.scaling = sp.equality_constraints = False
+    q = synthetic_trajectory(cfg, model, N, seed=3, lower=0.0)
+    q[:, 1] = np.linspace(1.5, 1.25, N + 1)
+    shape, fast = outputs(model, prob, sp, q, 1)
+    _, generic = outputs(model, prob, sp, q, 0)
+    assert shape == 5
+    for k in ARRAYS + ("tau_only", "cost"):
+        assert same(fast[k], generic[k]), k
+    g, bands = Oracle(model, prob, sp).grad_hess(q)
+    assert same(fast["gradient"], g)
+    for key, band in zip(("H_A", "H_B", "H_C"), bands[:3]):
+        assert same(fast[key], band), key
+    import copy
+    sp2 = copy.deepcopy(sp)
+    sp2.contact_stiffness = 2.0 * sp.contact_stiffness
+    _, stiffer = outputs(model, prob, sp2, q, 1)
+    assert not same(stiffer["tau_only"], fast["tau_only"])   # the pair is active somewhere along the trajectory
