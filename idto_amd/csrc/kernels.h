@@ -38,6 +38,49 @@ __global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__
   const int nterms = 3 * N + 2, nmax = nq > nv ? nq : nv;
   double* terms = lds;               // [nterms]
   double* cols = terms + nterms;     // [nterms][nmax]
+  if (diag) {
+    // (diagonal weights, the production case: the three operands of an item - value, nominal value, weight - are
+    // independent loads; four items' worth are issued before the first is waited for.  A rolled loop waited for each
+    // item's loads in turn: five round trips in a row at allegro's size.  Same expressions, same bits.)
+    constexpr int U = 4;
+    for (int idx0 = tid; idx0 < nterms * nmax; idx0 += U * nt) {
+      double ev[U], en[U], wv[U];
+      bool use[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = idx0 + u * nt;
+        const bool ok = idx < nterms * nmax;
+        const int term = ok ? idx / nmax : 0, c = ok ? idx - term * nmax : 0;
+        const int kind = (term < 3 * N) ? term % 3 : 3 + (term - 3 * N);
+        const int t = (term < 3 * N) ? term / 3 : N;
+        const int n = (kind == 0 || kind == 3) ? nq : nv;
+        use[u] = ok && c < n;
+        const int cc = use[u] ? c : 0;
+        const double* pe = (kind == 0 || kind == 3) ? q + t * nq + cc : (kind == 1 || kind == 4) ? v + t * nv + cc
+                                                                     : slab + (size_t)t * slab_stride + 3 * nv * nq + cc;
+        const double* pn = (kind == 0 || kind == 3) ? P.q_nom + t * nq + cc : (kind == 1 || kind == 4) ? P.v_nom + t * nv + cc : pe;
+        const double* W = (kind == 0) ? P.Qq0 : (kind == 1) ? P.Qv0 : (kind == 2) ? P.R0 : (kind == 3) ? P.Qfq0 : P.Qfv0;
+        ev[u] = *pe; en[u] = *pn; wv[u] = W[cc * n + cc];
+        en[u] = (kind == 2) ? 0.0 : en[u];   // (tau's nominal value is zero: e = tau - 0.0)
+      }
+      // (the loads stay where they are: without the pin the compiler sinks them into the `use` branches below, a wait each)
+      asm volatile("" : "+v"(ev[0]), "+v"(ev[1]), "+v"(ev[2]), "+v"(ev[3]), "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]));
+      asm volatile("" : "+v"(en[0]), "+v"(en[1]), "+v"(en[2]), "+v"(en[3]));
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = idx0 + u * nt;
+        if (idx >= nterms * nmax) continue;
+        double val = 0.0;
+        if (use[u]) {
+          const double dc = ev[u] - en[u];
+          double acc = 0;
+          acc += dc * wv[u];
+          val = acc * dc;
+        }
+        cols[idx] = val;
+      }
+    }
+  } else
   for (int idx = tid; idx < nterms * nmax; idx += nt) {
     const int term = idx / nmax, c = idx - term * nmax;
     // kind of the term: 0 q_t, 1 v_t, 2 tau_t (running), 3 q_N, 4 v_N (terminal)
@@ -54,11 +97,7 @@ __global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__
     if (c < n) {
       const double dc = err(c);
       double acc = 0;
-      if (diag) {
-        acc += dc * W[c * n + c];
-      } else {
-        for (int r = 0; r < n; ++r) acc += err(r) * W[c * n + r];
-      }
+      for (int r = 0; r < n; ++r) acc += err(r) * W[c * n + r];
       val = acc * dc;
     }
     cols[idx] = val;
@@ -101,7 +140,17 @@ __global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__
     }
     if (tid == 0) {   // ratio, accept / reject, radius
       double hl = 0.0;
-      for (int r = 0; r < neq && T.nu > 0; ++r) hl += cols[r];
+      if (T.nu > 0) {   // (in index order, the LDS reads eight at a time ahead of the chain of adds)
+        int r = 0;
+        for (; r + 8 <= neq; r += 8) {
+          double c8[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) c8[u] = cols[r + u];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) hl += c8[u];
+        }
+        for (; r < neq; ++r) hl += cols[r];
+      }
       terms[0] = tr_decide(T, *cost_out, hl) ? 1.0 : 0.0;
     }
   }
