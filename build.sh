@@ -11,7 +11,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Iinclude -I
 mkdir -p build
 # two translation units, compiled side by side: the finite-difference kernel and everything else
 $HIPCC $FLAGS $FD_FLAGS -c idto_amd/csrc/fd_launch.hip -o build/fd_launch.o "$@" &
-$HIPCC $FLAGS -mllvm -amdgpu-mfma-vgpr-form=1 -c idto_amd/csrc/idto_hip.hip -o build/idto_hip.o "$@"
+$HIPCC $FLAGS -mllvm -amdgpu-mfma-vgpr-form=1 $MAIN_FLAGS -c idto_amd/csrc/idto_hip.hip -o build/idto_hip.o "$@"
 wait %1
 $HIPCC --offload-arch=gfx950 -fPIC -shared build/fd_launch.o build/idto_hip.o -o idto_amd/libidto_hip.so -L/opt/rocm/lib -lrccl
 # libidto_opt.so: the host-side TrajectoryOptimizer (C++) + its C-ABI, on top of libidto_hip.so

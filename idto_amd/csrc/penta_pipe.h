@@ -240,7 +240,11 @@ __device__ __forceinline__ void pipe_pivot(double (&xr)[K], double inv, const do
     const double2* p2 = reinterpret_cast<const double2*>(slot0 + J * G::RS);
 #pragma unroll
     for (int m = (J + 2) / 2; m < (K + 1) / 2; ++m) {
+#ifdef PIPE_MULT_READLANE   // (measurement aid, tools/micro/pivot_bench.hip: faster alone on a CU, slower in the kernel)
+      double2 v; v.x = rdlane(t, 2 * m < K ? 2 * m : K - 1); v.y = rdlane(t, 2 * m + 1 < K ? 2 * m + 1 : K - 1);
+#else
       const double2 v = p2[m];
+#endif
       // (an odd J needs only the second half of its first pair, mu[J + 1] goes unused: left to itself the compiler
       // narrows that read to 8 bytes, and every read after it is then 8 bytes off a 16-byte boundary - ds_read2_b64
       // with an address of its own, a v_add_u32 per read on the eliminating wavefront.  The next step "uses" it.)
