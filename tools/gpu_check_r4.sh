@@ -43,4 +43,5 @@ cp gpurun_out/prof_fi_allegro_hand/fi_kernel_stats.csv gpurun_out/${R}_constrain
 for kkt in 1 0; do for c in "acrobot 40" "spinner 40" "hopper 40" "allegro_hand 20"; do echo -n "IDTO_CON_KKT=$kkt  "; IDTO_CON_KKT=$kkt timeout 120 python tools/full_iter_prof.py $c 2>&1 | tail -1; done; done | tee -a gpurun_out/${R}_constrained_iteration_times.txt
 # bit reproducibility of the constrained loop over fresh contexts (the KKT step's factorisations)
 { for c in "allegro_hand 60 60" "hopper 40 100" "spinner 40 60" "acrobot 40 60"; do timeout 600 python tools/stress_kkt.py $c 2>&1 | grep -v amdgpu.ids | tail -2; done; } | tee gpurun_out/${R}_kkt_stress.txt
+timeout 600 python tools/fd_sweep.py 12 2>&1 | grep -v amdgpu.ids | tail -3 | tee gpurun_out/${R}_fd_sweep.txt
 ls gpurun_out | head -80
