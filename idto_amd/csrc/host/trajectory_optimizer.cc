@@ -303,7 +303,8 @@ TO::~TrajectoryOptimizer() {
   idto_hip_destroy(hip_);
 }
 
-void TO::UploadProblem() {
+void TO::UploadProblem() const {
+  problem_dirty_ = false;
   const Vec qn = Flatten(prob_.q_nom), vn = Flatten(prob_.v_nom);
   idto_problem_t p = {};
   p.num_steps = num_steps(); p.time_step = time_step_;
@@ -321,7 +322,9 @@ void TO::ResetInitialConditions(const VectorXd& q_init, const VectorXd& v_init) 
   if ((int)q_init.size() != nq_ || (int)v_init.size() != nv_) throw std::runtime_error("ResetInitialConditions: wrong size");
   prob_.q_init = q_init;
   prob_.v_init = v_init;
-  UploadProblem();
+  problem_dirty_ = true;   // (uploaded with the next device call: dev())
+  resident_ = nullptr;     // every cached device result depends on the problem data
+  device_level_ = 0;
 }
 // TO.h:452-470
 void TO::UpdateNominalTrajectory(const std::vector<VectorXd>& q_nom, const std::vector<VectorXd>& v_nom) {
@@ -329,22 +332,24 @@ void TO::UpdateNominalTrajectory(const std::vector<VectorXd>& q_nom, const std::
     throw std::runtime_error("UpdateNominalTrajectory: wrong size");
   prob_.q_nom = q_nom;
   prob_.v_nom = v_nom;
-  UploadProblem();
+  problem_dirty_ = true;
+  resident_ = nullptr;
+  device_level_ = 0;
 }
 
 // ---- device residency: level 0 = q, 1 = + tau/cost, 2 = + partials, 3 = + gradient/Hessian
 void TO::EnsureDevice(const TrajectoryOptimizerState<T>& state, int level) const {
   if (resident_ != &state || !state.cache_.uploaded) {
     const Vec q = Flatten(state.q());
-    Check(idto_hip_set_q(hip_, q.data()));
+    Check(idto_hip_set_q(dev(), q.data()));
     resident_ = &state;
     state.cache_.uploaded = true;
     device_level_ = 0;
   }
-  if (level >= 1 && device_level_ < 1) { Check(idto_hip_eval_tau(hip_)); device_level_ = 1; }
+  if (level >= 1 && device_level_ < 1) { Check(idto_hip_eval_tau(dev())); device_level_ = 1; }
   if (level >= 2 && device_level_ < 2) {
     if (shard_ctx_.empty()) {
-      Check(idto_hip_eval_partials(hip_));
+      Check(idto_hip_eval_partials(dev()));
     } else {
       // sharded over the devices: every device gets q, evaluates its k-range, one all-gather
       const Vec q = Flatten(state.q());
@@ -353,12 +358,12 @@ void TO::EnsureDevice(const TrajectoryOptimizerState<T>& state, int level) const
     }
     device_level_ = 2;
   }
-  if (level >= 3 && device_level_ < 3) { Check(idto_hip_grad_hess(hip_)); device_level_ = 3; }
+  if (level >= 3 && device_level_ < 3) { Check(idto_hip_grad_hess(dev())); device_level_ = 3; }
 }
 
 Vec TO::Fetch(int what) const {
-  Vec out((std::size_t)idto_hip_array_size(hip_, what));
-  Check(idto_hip_get(hip_, what, out.data()));
+  Vec out((std::size_t)idto_hip_array_size(dev(), what));
+  Check(idto_hip_get(dev(), what, out.data()));
   return out;
 }
 
@@ -374,7 +379,7 @@ void TO::CalcTrajectoryData(const TrajectoryOptimizerState<T>& state) const {
     // a new point: upload, evaluate and read back in one call / one synchronisation
     const Vec q = Flatten(state.q());
     Vec tau((std::size_t)num_steps() * nv_);
-    Check(idto_hip_trial_cost(hip_, q.data(), tau.data(), &c.cost));
+    Check(idto_hip_trial_cost(dev(), q.data(), tau.data(), &c.cost));
     c.tau = Unflatten(tau, num_steps(), nv_);
     resident_ = &state;
     c.uploaded = true;
@@ -407,7 +412,7 @@ void TO::CalcDerivatives(const TrajectoryOptimizerState<T>& state) const {
   EnsureDevice(state, 2);
   const int N = num_steps();
   const Vec slab = Fetch(IDTO_ARR_SLAB);  // per k: [dtau_dqm | dtau_dqt | dtau_dqp | tau_k]
-  const int stride = idto_hip_slab_stride(hip_), bsz = nv_ * nq_;
+  const int stride = idto_hip_slab_stride(dev()), bsz = nv_ * nq_;
   c.id_partials.dtau_dqm.assign((std::size_t)N, MatrixXd(nv_, nq_));
   c.id_partials.dtau_dqt.assign((std::size_t)N, MatrixXd(nv_, nq_));
   c.id_partials.dtau_dqp.assign((std::size_t)N, MatrixXd(nv_, nq_));
@@ -444,13 +449,13 @@ void TO::CalcGradHess(const TrajectoryOptimizerState<T>& state) const {
   EnsureDevice(state, 3);
   // g and the bands are copied on a side stream while the solver - which every iteration needs
   // next (CalcDoglegPoint :2139-2149 / CalcLagrangeMultipliers :1371-1396) - already runs
-  Check(idto_hip_prefetch(hip_, IDTO_ARR_GRADIENT));
-  Check(idto_hip_prefetch(hip_, IDTO_ARR_HBANDS));
+  Check(idto_hip_prefetch(dev(), IDTO_ARR_GRADIENT));
+  Check(idto_hip_prefetch(dev(), IDTO_ARR_HBANDS));
   if (params_.equality_constraints && num_equality_constraints() > 0) {
     Scope prof2_("  launch constraint solve");
-    Check(idto_hip_constraint_schur_begin(hip_, unactuated_dofs_.data(), (int)unactuated_dofs_.size()));
+    Check(idto_hip_constraint_schur_begin(dev(), unactuated_dofs_.data(), (int)unactuated_dofs_.size()));
   } else {
-    Check(idto_hip_factor_solve(hip_, nullptr, 1, nullptr));  // IDTO_ARR_STEP = -H^-1 g
+    Check(idto_hip_factor_solve(dev(), nullptr, 1, nullptr));  // IDTO_ARR_STEP = -H^-1 g
     c.step_on_device = true;
   }
   {
@@ -596,7 +601,7 @@ const VectorXd& TO::EvalHinvMeritGradient(const TrajectoryOptimizerState<T>& s) 
     } else {
       EnsureDevice(s, 3);
       c.Hinv_gm.resize(g.size());
-      Check(idto_hip_solve_host(hip_, g.data(), 1, c.Hinv_gm.data()));
+      Check(idto_hip_solve_host(dev(), g.data(), 1, c.Hinv_gm.data()));
     }
     c.hinv = true;
   }
@@ -628,10 +633,10 @@ const VectorXd& TO::EvalLagrangeMultipliers(const TrajectoryOptimizerState<T>& s
     // otherwise - and whenever the device finds S numerically singular - on the host.
     constexpr int kDeviceLdltFrom = 256;
     int rc = 1;
-    Check(idto_hip_constraint_schur_begin(hip_, unactuated_dofs_.data(), nu));  // (no-op if CalcGradHess launched it)
+    Check(idto_hip_constraint_schur_begin(dev(), unactuated_dofs_.data(), nu));  // (no-op if CalcGradHess launched it)
     if (neq >= kDeviceLdltFrom) {
       Scope prof_("device: constraint solve");
-      rc = idto_hip_constraint_solve(hip_, h.data(), c.lambda_v.data(), c.Hinv_gm.data(), c.JT_lambda.data());
+      rc = idto_hip_constraint_solve(dev(), h.data(), c.lambda_v.data(), c.Hinv_gm.data(), c.JT_lambda.data());
       if (rc != 0 && rc != 1) Check(rc);  // (incl. IDTO_HIP_FACTORIZATION_FAILED)
     }
     if (rc == 1) {
@@ -639,14 +644,14 @@ const VectorXd& TO::EvalLagrangeMultipliers(const TrajectoryOptimizerState<T>& s
       Scope prof_("device schur + host LDLT + device step");
       std::vector<double> S((std::size_t)neq * neq);
       Vec rhs((std::size_t)neq);
-      Check(idto_hip_constraint_schur(hip_, unactuated_dofs_.data(), nu, S.data(), rhs.data()));
+      Check(idto_hip_constraint_schur(dev(), unactuated_dofs_.data(), nu, S.data(), rhs.data()));
       for (int r = 0; r < neq; ++r) rhs[r] = h[r] - rhs[r];
       {
         Scope prof_("dense LDLT (host)");
         DenseLdltSolve(&S, neq, rhs.data());
       }
       c.lambda_v = rhs;
-      Check(idto_hip_constraint_step(hip_, c.lambda_v.data(), c.Hinv_gm.data(), c.JT_lambda.data()));
+      Check(idto_hip_constraint_step(dev(), c.lambda_v.data(), c.Hinv_gm.data(), c.JT_lambda.data()));
     }
     c.lambda = true;
   }
@@ -916,7 +921,7 @@ SolverFlag TO::SolveWithLinesearch(const std::vector<VectorXd>& q_guess, Traject
     EvalGradient(state);
     EnsureDevice(state, 3);
     for (std::size_t i = 0; i < rhs.size(); ++i) rhs[i] = -g[i];
-    Check(idto_hip_solve_host(hip_, rhs.data(), 1, dq.data()));
+    Check(idto_hip_solve_host(dev(), rhs.data(), 1, dq.data()));
     const auto [alpha, ls_iters] = (params_.linesearch_method == kArmijo) ? ArmijoLinesearch(state, dq, &scratch)
                                                                          : BacktrackingLinesearch(state, dq, &scratch);
     if (ls_iters >= params_.max_linesearch_iterations) {
@@ -995,7 +1000,7 @@ bool TO::ResidentLoopEligible() const {
   const bool adaptive = scal == static_cast<int>(kAdaptiveSqrt) || scal == static_cast<int>(kAdaptiveDoubleSqrt);
   if (!adaptive) return true;
   int weights_diagonal = 0;   // (the adaptive scalings ride on the gated assembly, which serves diagonal cost weights)
-  Check(idto_hip_get_option(hip_, "weights_diagonal", &weights_diagonal));
+  Check(idto_hip_get_option(dev(), "weights_diagonal", &weights_diagonal));
   return weights_diagonal != 0;
 }
 
@@ -1009,18 +1014,19 @@ SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solu
   const double eta = 0.0;
   {
     const Vec q0 = Flatten(state.q());
-    Check(idto_hip_set_q(hip_, q0.data()));
+    Check(idto_hip_set_q(dev(), q0.data()));
   }
-  Check(idto_hip_set_unactuated_dofs(hip_, unactuated_dofs_.data(), (int)unactuated_dofs_.size()));
-  Check(idto_hip_eval_tau(hip_));
-  double cost = Fetch(IDTO_ARR_COST)[0];
+  Check(idto_hip_set_unactuated_dofs(dev(), unactuated_dofs_.data(), (int)unactuated_dofs_.size()));
+  Check(idto_hip_eval_tau(dev()));
+  // (the resident loop keeps the cost on the device and reports it in its rows: no fetch, no synchronisation here)
+  double cost = ResidentLoopEligible() ? 0.0 : Fetch(IDTO_ARR_COST)[0];
   const int scal = params_.scaling ? static_cast<int>(params_.scaling_method) : -1;
   // the adaptive scalings' memory of D belongs to the state (TO.cc:1241-1255 reads the cached scale
   // factors): ones for a fresh state, the last solve's for a warm start - never the context's leftovers
   const bool adaptive = scal == static_cast<int>(kAdaptiveSqrt) || scal == static_cast<int>(kAdaptiveDoubleSqrt);
   if (adaptive) {
     const Vec& Dmem = state.cache_.scale_factors;
-    Check(idto_hip_tr_set_scale_memory(hip_, (int)Dmem.size() == num_vars() ? Dmem.data() : nullptr));
+    Check(idto_hip_tr_set_scale_memory(dev(), (int)Dmem.size() == num_vars() ? Dmem.data() : nullptr));
   }
   if (params_.verbose) {
     std::printf("-------------------------------------------------------------------------------------\n");
@@ -1039,15 +1045,15 @@ SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solu
       const auto& t = params_.convergence_tolerances;
       const double tol[6] = {t.rel_cost_reduction, t.abs_cost_reduction, t.rel_gradient_along_dq, t.abs_gradient_along_dq,
                              t.rel_state_change, t.abs_state_change};
-      Check(idto_hip_tr_set_convergence(hip_, tol));
+      Check(idto_hip_tr_set_convergence(dev(), tol));
     } else {
-      Check(idto_hip_tr_set_convergence(hip_, nullptr));
+      Check(idto_hip_tr_set_convergence(dev(), nullptr));
     }
     const int iters = params_.max_iterations;
     std::vector<double> rows((std::size_t)iters * IDTO_TR_ROW);
     double Delta_end = Delta;
     const bool constrained = params_.equality_constraints && num_equality_constraints() > 0;
-    Check(idto_hip_tr_solve(hip_, iters, scal, params_.scaling ? 1 : 0, params_.normalize_quaternions ? 1 : 0, Delta,
+    Check(idto_hip_tr_solve(dev(), iters, scal, params_.scaling ? 1 : 0, params_.normalize_quaternions ? 1 : 0, Delta,
                             params_.Delta_max, eta, constrained ? unactuated_dofs_.data() : nullptr,
                             constrained ? (int)unactuated_dofs_.size() : 0, rows.data(), &Delta_end));
     const double total = std::chrono::duration<double>(clock::now() - start_time).count();
@@ -1101,8 +1107,8 @@ SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solu
   }
   while (k < params_.max_iterations && !converged) {
     if (!have) {
-      Check(idto_hip_gn_step(hip_));
-      Check(idto_hip_tr_prepare(hip_, scal, 0, S));   // (reports a failed factorisation)
+      Check(idto_hip_gn_step(dev()));
+      Check(idto_hip_tr_prepare(dev(), scal, 0, S));   // (reports a failed factorisation)
       have = true;
     }
     const double gg = S[0], gHg = S[1], ww = S[2], gw = S[3], gHw = S[4], wHw = S[5], qq = S[6], hh = S[7];
@@ -1125,7 +1131,7 @@ SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solu
     // speculate on acceptance (the next iteration is enqueued behind the trial point) unless the last
     // step was rejected: a rejection costs a recomputation of g and H at the old q
     const bool speculate = last_accepted && !std::getenv("IDTO_OPT_NO_SPECULATION");
-    Check(idto_hip_tr_trial(hip_, a, b, params_.scaling ? 1 : 0, params_.normalize_quaternions ? 1 : 0, 0,
+    Check(idto_hip_tr_trial(dev(), a, b, params_.scaling ? 1 : 0, params_.normalize_quaternions ? 1 : 0, 0,
                             speculate ? scal : -2, Tr));
     const double dq_norm = std::sqrt(Tr[0]), gdqs = Tr[1], cost_trial = Tr[2];
     if (!std::isfinite(Tr[0])) throw FactorizationFailedError("idto_hip: the dogleg step is not finite");
@@ -1142,11 +1148,11 @@ SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solu
     last_accepted = rho > eta;
     const double cost_k = cost;
     if (last_accepted) {   // :2550-2553
-      Check(idto_hip_tr_accept(hip_));
+      Check(idto_hip_tr_accept(dev()));
       cost = cost_trial;
       have = false;
     } else {
-      Check(idto_hip_tr_reject(hip_));
+      Check(idto_hip_tr_reject(dev()));
       if (speculate) have = false;   // the speculative launch overwrote g, H and the Newton step of q
     }
     const double iter_time = std::chrono::duration<double>(clock::now() - iter_start).count();
@@ -1161,15 +1167,23 @@ SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solu
     ++k;
   }
   // the solution: q from the device; v, tau belong to it unless the last trial point was rejected
-  if (!last_accepted) Check(idto_hip_eval_tau(hip_));
-  state.set_q(Unflatten(Fetch(IDTO_ARR_Q), num_steps() + 1, nq_));
-  solution->q = state.q();
-  solution->v = Unflatten(Fetch(IDTO_ARR_V), num_steps() + 1, nv_);
-  solution->tau = Unflatten(Fetch(IDTO_ARR_TAU), num_steps(), nv_);
-  if (k > 0) {
-    ws->dq = Fetch(IDTO_ARR_TR_DQ);
-    ws->dqH = Fetch(IDTO_ARR_TR_W);
-    for (double& x : ws->dqH) x = -x;   // dqH = Delta pH = -w (:2152)
+  if (!last_accepted) Check(idto_hip_eval_tau(dev()));
+  // (the solution's arrays with one synchronisation: idto_hip_get_many)
+  {
+    Vec qf((std::size_t)num_vars()), vf((std::size_t)(num_steps() + 1) * nv_), tf((std::size_t)num_steps() * nv_);
+    Vec dq((std::size_t)num_vars()), dqh((std::size_t)num_vars());
+    const int what[5] = {IDTO_ARR_Q, IDTO_ARR_V, IDTO_ARR_TAU, IDTO_ARR_TR_DQ, IDTO_ARR_TR_W};
+    double* const dst[5] = {qf.data(), vf.data(), tf.data(), dq.data(), dqh.data()};
+    Check(idto_hip_get_many(dev(), k > 0 ? 5 : 3, what, dst));
+    state.set_q(Unflatten(qf, num_steps() + 1, nq_));
+    solution->q = state.q();
+    solution->v = Unflatten(vf, num_steps() + 1, nv_);
+    solution->tau = Unflatten(tf, num_steps(), nv_);
+    if (k > 0) {
+      ws->dq = dq;
+      ws->dqH = dqh;
+      for (double& x : ws->dqH) x = -x;   // dqH = Delta pH = -w (:2152)
+    }
   }
   if (adaptive && k > 0) state.cache_.scale_factors = Fetch(IDTO_ARR_TR_SCALE);   // (kept across set_q: invalidate_cache)
   resident_ = nullptr;   // the device arrays were advanced without the host-side cache

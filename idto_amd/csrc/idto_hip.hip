@@ -178,6 +178,8 @@ struct idto_hip_ctx {
   double *stage_rhs = nullptr, *stage_x = nullptr;  // idto_hip_solve_host
   double* pack = nullptr;                            // [tau | cost] of idto_hip_trial_cost (device)
   double* pin = nullptr;                             // pinned host staging: q in, [tau | cost] out
+  char* prob_pin = nullptr; size_t prob_pin_bytes = 0;   // ... of the problem arrays (UploadProblemArrays)
+  double* many_pin = nullptr; size_t many_cap = 0;        // ... of idto_hip_get_many
   // equality-constraint step (constraints.h)
   int* con_dofs = nullptr; int con_nu = 0, con_neq = 0;
   std::vector<int> con_dofs_host;
@@ -237,6 +239,7 @@ struct idto_hip_ctx {
   hipEvent_t spec_ev = nullptr;
   const double* con_lambda_at = nullptr;  // where the current multipliers live (con_lambda or con_lambda + 2)
   int* una_dofs = nullptr; int una_nu = 0; // unactuated dofs for |h| of the statistics (idto_hip_set_unactuated_dofs)
+  std::vector<int> una_dofs_host;
   // the equality-constraint step of the resident loop as one banded solve (kkt.h): a solver-only context of block size
   // nq + nu on this context's stream, made on first use
   idto_hip_ctx* kkt = nullptr; int kkt_nu = 0;
@@ -288,12 +291,28 @@ int UploadProblemArrays(idto_hip_ctx* c, const idto_problem_t* p, int pb = 0) {
       std::vector<double>(p->R, p->R + (size_t)nv * nv), std::vector<double>(p->Qf_q, p->Qf_q + (size_t)nq * nq),
       std::vector<double>(p->Qf_v, p->Qf_v + (size_t)nv * nv)};
   {
-    HIP_OK(hipMemcpyAsync(at_problem(c->d_vinit, po), p->v_init, nv * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIP_OK(hipMemcpyAsync(at_problem(c->d_qnom, po), p->q_nom, (size_t)(N + 1) * nq * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIP_OK(hipMemcpyAsync(at_problem(c->d_vnom, po), p->v_nom, (size_t)(N + 1) * nv * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    for (int i = 0; i < 10; ++i)
-      HIP_OK(hipMemcpyAsync(at_problem(c->d_w[i], po), w[i].data(), w[i].size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIP_OK(hipStreamSynchronize(c->stream));  // host staging vectors die at scope exit
+    // ONE copy: v_init, q_nom, v_nom and the ten weight matrices sit next to each other in the problem's arena (64-byte
+    // aligned), a pinned host buffer mirrors that stretch (13 copies from pageable memory were 0.12 ms of an MPC re-plan)
+    char* lo = reinterpret_cast<char*>(c->d_vinit);
+    char* hi = reinterpret_cast<char*>(c->d_w[9]) + w[9].size() * sizeof(double);
+    const size_t bytes = (size_t)(hi - lo);
+    if (c->prob_pin_bytes < bytes) {
+      if (c->prob_pin) (void)hipHostFree(c->prob_pin);
+  if (c->many_pin) (void)hipHostFree(c->many_pin);
+      c->prob_pin = nullptr; c->prob_pin_bytes = 0;
+      HIP_OK(hipHostMalloc((void**)&c->prob_pin, bytes, hipHostMallocDefault));
+      c->prob_pin_bytes = bytes;
+      std::memset(c->prob_pin, 0, bytes);
+    }
+    auto put = [&](const double* dev, const double* src, size_t count) {
+      std::memcpy(c->prob_pin + (reinterpret_cast<const char*>(dev) - lo), src, count * sizeof(double));
+    };
+    put(c->d_vinit, p->v_init, nv);
+    put(c->d_qnom, p->q_nom, (size_t)(N + 1) * nq);
+    put(c->d_vnom, p->v_nom, (size_t)(N + 1) * nv);
+    for (int i = 0; i < 10; ++i) put(c->d_w[i], w[i].data(), w[i].size());
+    HIP_OK(hipMemcpyAsync(lo + po, c->prob_pin, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));  // (the pinned buffer is reused by the next upload)
   }
   auto is_diag = [](const double* W, int n) {
     for (int c2 = 0; c2 < n; ++c2)
@@ -969,6 +988,8 @@ void idto_hip_destroy(idto_hip_ctx* c) {
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->pin) (void)hipHostFree(c->pin);
+  if (c->prob_pin) (void)hipHostFree(c->prob_pin);
+  if (c->many_pin) (void)hipHostFree(c->many_pin);
   if (c->status_pin) (void)hipHostFree(c->status_pin);
   if (c->tr_pin) (void)hipHostFree(c->tr_pin);
   if (c->spec_ev) (void)hipEventDestroy(c->spec_ev);
@@ -1691,7 +1712,11 @@ int idto_hip_set_unactuated_dofs(idto_hip_ctx* c, const int* dofs, int nu) {
   if (nu < 0 || nu > c->nv || (nu > 0 && !dofs)) { g_err = "set_unactuated_dofs: bad arguments"; return -1; }
   for (int j = 0; j < nu; ++j)
     if (dofs[j] < 0 || dofs[j] >= c->nv) { g_err = "set_unactuated_dofs: dof index out of range"; return -1; }
+  // (every SolveFromWarmStart sets them: a device allocation and a copy only when the set changes - the allocation alone
+  // was 0.1 ms of an MPC re-plan, and stayed allocated until the context went)
+  if (nu == c->una_nu && (nu == 0 || (c->una_dofs && std::equal(dofs, dofs + nu, c->una_dofs_host.begin())))) return 0;
   c->una_nu = nu;
+  c->una_dofs_host.assign(dofs, dofs + nu);
   if (nu > 0 && Upload(c, dofs, (size_t)nu, &c->una_dofs)) return -2;
   return 0;
 }
@@ -2625,6 +2650,41 @@ int idto_hip_get_batch(idto_hip_ctx* c, int what, int pb, double* out) {
     fs = FactorStatus(c, pb);
   }
   return fs;
+}
+
+int idto_hip_get_many(idto_hip_ctx* c, int n, const int* what, double* const* out) {
+  HIP_OK(hipSetDevice(c->device));
+  if (n < 0 || (n > 0 && (!what || !out))) { g_err = "get_many: bad arguments"; return -1; }
+  if (c->batch != 1) { g_err = "get_many serves single-problem contexts"; return -1; }
+  std::vector<size_t> off((size_t)n + 1, 0);
+  for (int i = 0; i < n; ++i) {
+    const long count = idto_hip_array_size(c, what[i]);
+    if (count < 0 || what[i] == IDTO_ARR_STEP) { g_err = "get_many: unknown array id (or IDTO_ARR_STEP: use idto_hip_get)"; return -1; }
+    off[i + 1] = off[i] + (size_t)count;
+  }
+  if (off[n] > c->many_cap) {
+    if (c->many_pin) (void)hipHostFree(c->many_pin);
+    c->many_pin = nullptr; c->many_cap = 0;
+    HIP_OK(hipHostMalloc((void**)&c->many_pin, std::max<size_t>(off[n], 1) * sizeof(double), hipHostMallocDefault));
+    c->many_cap = off[n];
+  }
+  const size_t bsz = (size_t)c->nv * c->nq;
+  for (int i = 0; i < n; ++i) {
+    const int w = what[i];
+    for (auto& pf : c->pre) if (pf.what == w) pf.pending = false;   // (a staged copy of it is superseded)
+    double* dst = c->many_pin + off[i];
+    if (w == IDTO_ARR_TAU || (w >= IDTO_ARR_DTAU_DQM && w <= IDTO_ARR_DTAU_DQP)) {   // rows of the slab's records
+      const size_t o = w == IDTO_ARR_TAU ? 3 * bsz : (size_t)(w - IDTO_ARR_DTAU_DQM) * bsz;
+      const size_t width = w == IDTO_ARR_TAU ? (size_t)c->nv : bsz;
+      HIP_OK(hipMemcpy2DAsync(dst, width * sizeof(double), c->slab + o, (size_t)c->slab_stride * sizeof(double), width * sizeof(double),
+                              c->N, hipMemcpyDeviceToHost, c->stream));
+    } else {
+      HIP_OK(hipMemcpyAsync(dst, DevPtr(c, w), (off[i + 1] - off[i]) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+  }
+  HIP_OK(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n; ++i) std::memcpy(out[i], c->many_pin + off[i], (off[i + 1] - off[i]) * sizeof(double));
+  return 0;
 }
 
 int idto_hip_solver_status(idto_hip_ctx* c, int* failed, int* failed_rows_total) {

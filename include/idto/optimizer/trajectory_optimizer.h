@@ -117,11 +117,14 @@ class TrajectoryOptimizer<double> {
   T CalcTrustRatio(const TrajectoryOptimizerState<T>& state, const VectorXd& dq,
                    TrajectoryOptimizerState<T>* scratch_state) const;
 
-  idto_hip_ctx* device_context() const { return hip_; }
+  idto_hip_ctx* device_context() const { return dev(); }
 
  private:
   int num_vars() const { return (num_steps() + 1) * nq_; }
-  void UploadProblem();
+  void UploadProblem() const;
+  // the context, with the problem data on the device up to date (ResetInitialConditions / UpdateNominalTrajectory only
+  // mark them: an MPC re-plan calls both, examples/mpc_controller.cc:60-75, and pays for one upload)
+  idto_hip_ctx* dev() const { if (problem_dirty_) UploadProblem(); return hip_; }
   // makes the device hold `state`: level 0 q, 1 + tau/cost, 2 + dtau/dq, 3 + gradient/Hessian
   void EnsureDevice(const TrajectoryOptimizerState<T>& state, int level) const;
   std::vector<double> Fetch(int what) const;
@@ -157,6 +160,7 @@ class TrajectoryOptimizer<double> {
   std::vector<int> quaternion_starts_;
   idto_hip_ctx* hip_ = nullptr;
   std::vector<idto_hip_ctx*> shard_ctx_;    // [hip_, contexts on the other devices] when sharded over devices
+  mutable bool problem_dirty_ = false;      // prob_ changed since the last upload
   mutable const void* resident_ = nullptr;  // state whose q is on the device
   mutable int device_level_ = 0;            // what has been evaluated for it there
   // the device-resident loop met a singular constraint Schur complement at iteration resume_k_: the

@@ -113,6 +113,11 @@ int idto_hip_set_problem_batch(idto_hip_ctx* ctx, int problem, const idto_proble
 int idto_hip_set_q_batch(idto_hip_ctx* ctx, const double* q_host /* [batch][(N+1)*nq] */);
 int idto_hip_gn_step_batch(idto_hip_ctx* ctx); /* = idto_hip_gn_step: every problem of the batch */
 int idto_hip_get_batch(idto_hip_ctx* ctx, int what, int problem, double* host_out);
+/* Several arrays with ONE synchronisation: the copies are enqueued side by side into pinned staging memory (what a
+ * caller that wants the solution of a solve - q, v, tau, the step - pays for is one wait, not one per array; reference:
+ * the fields TrajectoryOptimizer<T>::SolveFromWarmStart hands back, trajectory_optimizer.cc:2627-2650).  Not for
+ * IDTO_ARR_STEP (whose idto_hip_get also reports the factorisation's status). */
+int idto_hip_get_many(idto_hip_ctx* ctx, int n, const int* what, double* const* host_out);
 int idto_hip_solver_status_batch(idto_hip_ctx* ctx, int* failed /* [batch] */);
 
 /* Replaces q_init/v_init/weights/q_nom/v_nom (ResetInitialConditions /
