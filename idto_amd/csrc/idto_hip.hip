@@ -128,6 +128,7 @@ struct idto_hip_ctx {
   bool reference_solver = false;  // bit-exact pivoted-LU block Thomas (kernels.h penta_kernel)
   int asm_diag_lds = 0;
   int asm_terms_lds = 0;
+  int asm_terms_threads = 256;              // a thread per item of the largest part (allegro: 299 items - a second pass of 43 cost 2 us)
   double* terms = nullptr;                // per-record assembly products written by fd_kernel (asm_terms_stride)
   bool asm_fold = true;                   // option "asm_fold": fd_kernel forms them, assemble_terms_kernel combines
   bool terms_valid = false;               // ... and they belong to the resident slab, for every k
@@ -919,6 +920,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   c->asm_lds = (int)sizeof(double) * (3 * nq + 5 * (int)bsz + 4 * nv + nq + std::max(nq, nv) + (int)bsz + 3 * (int)qq + nq);
   c->asm_diag_lds = (int)sizeof(double) * (14 * ((nv + 1) & ~1) * nq + 2 * (int)bsz + 10 * nv + 6 * nq + 2);
   c->asm_terms_lds = (int)sizeof(double) * (5 * ((nv + 1) & ~1) * nq + 4 * nv + nq + 2);
+  c->asm_terms_threads = std::min(512, std::max(256, (std::max(nq * (nq + 1) / 2 + nq, ((nq + 1) / 2) * nq) + 63) / 64 * 64));
   const int n = N + 1;
   c->penta_lds = (int)sizeof(double) * (10 * (int)qq + nq * (3 * nq + 1) + (n + 2) * nq + nq) + (int)sizeof(int) * nq + 16;
   c->solve_lds = (int)sizeof(double) * ((n + 2) * nq + nq);
@@ -1130,7 +1132,7 @@ static int LaunchAssemble(idto_hip_ctx* c, const double* gate) {
   const bool combine = c->weights_diagonal && c->terms_valid && c->fd_full && c->asm_stop == 0;
   c->last_assembly = combine ? 1 : (c->weights_diagonal ? 2 : 3);
   if (combine) {
-    hipLaunchKernelGGL(assemble_terms_kernel, dim3(c->N + 1, 4, c->batch), dim3(256), c->asm_terms_lds, c->stream, c->M, c->P,
+    hipLaunchKernelGGL(assemble_terms_kernel, dim3(c->N + 1, 4, c->batch), dim3(c->asm_terms_threads), c->asm_terms_lds, c->stream, c->M, c->P,
                        c->q, c->terms, c->v, c->nplus, c->g, c->HA, c->HB, c->HC, c->pstride, gate, c->alt_r);
   } else if (c->weights_diagonal) {
     hipLaunchKernelGGL(assemble_diag_kernel, dim3(c->N + 1, 4, c->batch), dim3(256), c->asm_diag_lds, c->stream, c->M,

@@ -785,7 +785,7 @@ __device__ __forceinline__ void assemble_terms_row(int nq, int nv, const DevProb
   }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 assemble_terms_kernel(DevModel M, DevProblem P, const double* __restrict__ q, const double* __restrict__ terms,
                       const double* __restrict__ v_res, const double* __restrict__ nplus_res, double* __restrict__ g,
                       double* __restrict__ HA, double* __restrict__ HB, double* __restrict__ HC, size_t pstride,

@@ -283,13 +283,29 @@ penta_ldl_tail(int n, int k, int nrhs, double* __restrict__ x, const double* __r
     // left in HBM (columns 0..K-1: the separator row next to this chain's first row).  The rows of
     // Ft are fetched while the separator is still being eliminated (this workgroup is idle then).
     const int pidx = (tid < nloc * K) ? tid : 0, pil = pidx / K, pr = pidx - pil * K;
+    // (a second element per thread - 16 local rows of 23 are more than the 256 threads - is fetched ahead in the same way)
+    const int qidx = (tid + nt < nloc * K) ? tid + nt : 0, qil = qidx / K, qr = qidx - qil * K;
     spin_wait([&] { return __hip_atomic_load(cfg.frowcnt + pil, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= cfg.frowtarget; }, cfg.spin);
+    spin_wait([&] { return __hip_atomic_load(cfg.frowcnt + qil, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= cfg.frowtarget; }, cfg.spin);
     (void)__hip_atomic_load(cfg.frowcnt + pil, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
     double f[2 * K];
     {
       const double* F = cfg.fst + (size_t)pil * cfg.fstride + pr;
 #pragma unroll
       for (int c = 0; c < 2 * K; ++c) f[c] = F[c * ks];
+      // (the loads belong BEFORE the wait for the separator - the workgroup is idle there; left to itself the compiler
+      // has moved them behind it in one build and not in the next: 2.7 against 9.5 us from the separator's flag to the
+      // back substitution at K = 23)
+#pragma unroll
+      for (int c = 0; c < 2 * K; ++c) asm volatile("" : "+v"(f[c]));
+    }
+    double f2[2 * K];
+    {
+      const double* F = cfg.fst + (size_t)qil * cfg.fstride + qr;
+#pragma unroll
+      for (int c = 0; c < 2 * K; ++c) f2[c] = F[c * ks];
+#pragma unroll
+      for (int c = 0; c < 2 * K; ++c) asm volatile("" : "+v"(f2[c]));
     }
     if (tid == 0)
       spin_wait([&] { return __hip_atomic_load(cfg.sepflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch; }, cfg.spin);
@@ -307,7 +323,13 @@ penta_ldl_tail(int n, int k, int nrhs, double* __restrict__ x, const double* __r
       for (int c = 0; c < 2 * K; ++c) acc = __builtin_fma(f[c], xs[c], acc);
       lds[xall_off + (pil + 2) * ks + pr] -= acc;
     }
-    for (int idx = tid + nt; idx < nloc * K; idx += nt) {   // (more rows than threads: the rest, unprefetched)
+    if (tid + nt < nloc * K) {
+      double acc = 0.0;
+#pragma unroll
+      for (int c = 0; c < 2 * K; ++c) acc = __builtin_fma(f2[c], xs[c], acc);
+      lds[xall_off + (qil + 2) * ks + qr] -= acc;
+    }
+    for (int idx = tid + 2 * nt; idx < nloc * K; idx += nt) {   // (still more: the rest, unprefetched)
       const int il = idx / K, r = idx - il * K;
       const double* F = cfg.fst + (size_t)il * cfg.fstride + r;
       double acc = 0.0;
