@@ -587,11 +587,13 @@ def main():
             names[2] = "penta_nd_kernel"
         elif dev.get_option("last_solver") == 4:   # ... with pipelined chains, five workgroups (csrc/penta_pipe.h)
             names[2] = "penta_pipe_kernel"
+        elif dev.get_option("last_solver") == 6:   # the small models: scalar band factorisation, one workgroup (csrc/penta_band.h)
+            names[2] = "penta_band_kernel"
         if dev.get_option("last_assembly") == 1:   # products formed by fd_kernel, combined here (kernels.h)
             names[1] = "assemble_terms_kernel"
         asm_inside = dev.get_option("last_assembly") == 4   # the solver's launch assembled g and H itself (penta_pipe.h PipeAsm)
         if asm_inside:
-            names[1] = "(inside penta_pipe_kernel)"
+            names[1] = "(inside %s)" % names[2]
             algb[2] += algb[1]   # ... so its algorithmic bytes are the assembly's plus the solver's (2.6 MB)
         dur_s = kern[dom][0] * 1e-3
         achieved = algb[dom] / dur_s / 1e9 if dur_s > 0 else 0.0

@@ -25,6 +25,7 @@
 #include "fused.h"
 #include "penta_nd.h"
 #include "penta_pipe.h"
+#include "penta_band.h"
 #include "penta_apply.h"
 #include "constraints.h"
 #include "dense_ldl.h"
@@ -151,6 +152,7 @@ struct idto_hip_ctx {
   bool fused = true;                      // gn_step: one persistent launch (fused.h) when eligible
   bool solver_nd = true;                  // solver: nested dissection over 7 workgroups (penta_nd.h) when eligible
   bool solver_pipe = true;                // ... with pipelined chains (penta_pipe.h: 5 workgroups) when the block size allows
+  int solver_band = 1;                    // small blocks: the scalar band factorisation in one workgroup (penta_band.h; see BandEligible)
   unsigned long long* nd_rowcnt = nullptr; // its per-row release counters, buffers and launch count
   unsigned* asm_ready = nullptr;               // penta_pipe.h PipeAsm: [N + 1][4] epoch words of the assembly inside the solver's launch
   bool tr_conv_on = false;                 // idto_hip_tr_set_convergence
@@ -711,7 +713,8 @@ int FactorStatus(idto_hip_ctx* c, int pb = -1) {
     // same time (other contexts' kernels on the device).  The result of that launch is garbage.  Step down to a
     // variant with fewer co-resident workgroups for the rest of the context's life; the caller repeats the solve
     // (idto_hip_get(STEP) and idto_hip_tr_prepare do it themselves).
-    if (c->solver_pipe && c->last_solver == 4) c->solver_pipe = false;
+    if (c->solver_band > 0 && c->last_solver == 6) c->solver_band = 0;   // (its wait for the launch's own assembly)
+    else if (c->solver_pipe && c->last_solver == 4) c->solver_pipe = false;
     else if (c->solver_nd && (c->last_solver == 2 || c->last_solver == 4)) c->solver_nd = false;
     else if (c->fused && c->last_solver == 5) c->fused = false;
     else if (c->two_sided) { c->solver_nd = false; c->fused = false; c->two_sided = false; }
@@ -973,6 +976,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   if (const char* e = getenv("IDTO_SOLVER_PIPE")) c->solver_pipe = (e[0] == '1');
   if (const char* e = getenv("IDTO_ASM_FOLD")) c->asm_fold = (e[0] == '1');
   if (const char* e = getenv("IDTO_CON_KKT")) c->con_kkt = (e[0] == '1');
+  if (const char* e = getenv("IDTO_SOLVER_BAND")) c->solver_band = std::atoi(e);   // (measurement aid: penta_band.h off / on / on for blocks of 5 too)
   (void)hipGetLastError();
   *out = c;
   return 0;
@@ -1242,6 +1246,57 @@ static int NdLds(const idto_hip_ctx* c, const LdlPlan& p, int nloc_max) {
   const int sep = (2 * (NF + 1) * (NF + 1) + 2 + (2 * p.K + 1) * ks + (p.K + 1) * ks + 2 * p.K * ks + p.K * ks + 6 * ks) * (int)sizeof(double);
   return std::max(std::max(spike, sep), chain);
 }
+// idto_hip_gn_step / idto_hip_tr_solve asked the solver's launch to assemble g and the bands itself (AsmInSolver): the
+// 4 (N + 1) workgroups behind the solver's own run assemble_terms_kernel's rows (penta_pipe.h PipeAsm)
+static PipeAsm TakeAsm(idto_hip_ctx* c, const LdlPlan& p) {
+  PipeAsm F{};
+  F.on = c->fuse_asm_next ? 1 : 0;
+  c->fuse_asm_next = false;
+  if (F.on) {
+    F.nq = c->nq; F.nv = c->nv; F.rows = c->N + 1; F.first = p.r0;
+    F.P = c->P; F.q = c->q; F.terms = c->terms; F.v_res = c->v; F.nplus = c->nplus;
+    F.g = c->g; F.HA = c->HA; F.HB = c->HB; F.HC = c->HC; F.alt = c->alt_r; F.ready = c->asm_ready; F.gate = c->fuse_gate;
+    c->last_assembly = 4;
+  }
+  return F;
+}
+
+// The scalar band factorisation (penta_band.h): blocks up to 5 (half width 3 k - 1 <= 14: a lane per diagonal in a row
+// of 16), one workgroup per problem, single right-hand side.
+static bool BandEligible(const idto_hip_ctx* c, const LdlPlan& p) {
+  // (option solver_band: 0 off, 1 blocks up to 4 - at 5 the pipelined kernel is faster, 41 against 47 us for hopper -, 2 up to 5)
+  if (!(c->solver_band > 0 && c->two_sided && p.K == p.k && p.k >= 2 && p.k <= (c->solver_band > 1 ? 5 : 4))) return false;
+  const int M = p.n * p.k, W = 3 * p.k;
+  // (horizons the pipelined kernel would take: shorter ones keep the fused launch / the two-workgroup factorisation)
+  return p.n >= 24 && M >= 4 * W && band_layout(M, W).end * (int)sizeof(double) <= 160 * 1024;
+}
+static int LaunchBand(idto_hip_ctx* c, const LdlPlan& p, const double* b, double sign, double* xo) {
+  BandArgs A;
+  A.n = p.n; A.k = p.k;
+  A.HA = c->HA + p.qq0; A.HB = c->HB + p.qq0; A.HC = c->HC + p.qq0;
+  A.b = b + (size_t)p.r0 * p.k; A.rhs_sign = sign; A.x = xo + (size_t)p.r0 * p.k; A.Dst = c->Dst;
+  ++c->epoch;
+  if (++c->fact_id == 0) c->fact_id = 1;
+  A.status = c->status_dev; A.fact_id = c->fact_id; A.epoch = c->epoch; A.pstride = c->pstride;
+  A.npos = c->ldl_npos;
+  A.ts = c->solver_debug ? c->dbg : nullptr;
+  c->last_solver = 6;
+  const PipeAsm F = TakeAsm(c, p);
+  const int W = 3 * p.k;
+  int lds = band_layout(p.n * p.k, W).end * (int)sizeof(double);
+  if (F.on) lds = std::max(lds, c->asm_terms_lds);
+  const dim3 grid(1 + (F.on ? 4 * (c->N + 1) : 0), c->batch);
+#define BAND_LAUNCH(WM) hipLaunchKernelGGL((penta_band_kernel<WM>), grid, dim3(256), lds, c->stream, A, F)
+  switch (W) {
+    case 6: BAND_LAUNCH(6); break;
+    case 9: BAND_LAUNCH(9); break;
+    case 12: BAND_LAUNCH(12); break;
+    default: BAND_LAUNCH(15); break;
+  }
+#undef BAND_LAUNCH
+  HIP_OK(hipGetLastError());
+  return 0;
+}
 static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double sign, double* xo) {
   NdArgs A;
   A.debug_skip_role = c->debug_skip_role;
@@ -1281,16 +1336,8 @@ static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double s
     A.epoch = c->epoch; A.status = c->status_dev; A.fact_id = c->fact_id; A.pstride = c->pstride;
     A.ts = c->solver_debug ? c->dbg : nullptr;
     // (idto_hip_gn_step: g and the bands are assembled by 4 (N + 1) more workgroups of this launch, penta_pipe.h PipeAsm)
-    PipeAsm F{};
-    F.on = c->fuse_asm_next ? 1 : 0;
-    c->fuse_asm_next = false;
-    if (F.on) {
-      F.nq = c->nq; F.nv = c->nv; F.rows = c->N + 1; F.first = p.r0;
-      F.P = c->P; F.q = c->q; F.terms = c->terms; F.v_res = c->v; F.nplus = c->nplus;
-      F.g = c->g; F.HA = c->HA; F.HB = c->HB; F.HC = c->HC; F.alt = c->alt_r; F.ready = c->asm_ready; F.gate = c->fuse_gate;
-      plds = std::max(plds, c->asm_terms_lds);
-      c->last_assembly = 4;
-    }
+    const PipeAsm F = TakeAsm(c, p);
+    if (F.on) plds = std::max(plds, c->asm_terms_lds);
     A.asm_ready = nullptr; A.asm_first = 0;
     const dim3 pgrid(5 + (F.on ? 4 * (c->N + 1) : 0), c->batch);
 #define PIPE_LAUNCH(KM) hipLaunchKernelGGL((penta_pipe_kernel<KM>), pgrid, dim3(512), plds, c->stream, A, F)
@@ -1336,6 +1383,7 @@ static int LaunchLdl(idto_hip_ctx* c, const double* b, double sign, double* xo, 
                      bool factor_only = false) {
   LdlPlan p;
   if (int rc = PlanLdl(c, one_sided, &p)) return rc;
+  if (allow_nd && !one_sided && BandEligible(c, p)) return LaunchBand(c, p, b, sign, xo);
   if (allow_nd && !one_sided && NdEligible(c, p)) return LaunchNd(c, p, b, sign, xo);
   const int n = p.n, k = p.k, m_split = p.m_split, lds = p.lds, nrhs = 1;
   const size_t qq0 = p.qq0;
@@ -1384,7 +1432,7 @@ static bool FusedEligible(const idto_hip_ctx* c) {
   {  // the nested-dissection solver is its own launch (seven workgroups): the three-launch path takes it
     LdlPlan p;
     idto_hip_ctx* cc = const_cast<idto_hip_ctx*>(c);
-    if (PlanLdl(cc, false, &p) == 0 && NdEligible(c, p)) return false;
+    if (PlanLdl(cc, false, &p) == 0 && (NdEligible(c, p) || BandEligible(c, p))) return false;   // (likewise the scalar band factorisation's)
   }
   return c->fused && c->batch == 1 && c->weights_diagonal && !c->reference_solver && !c->solver_debug && c->fd_stop == 0 &&
          c->asm_stop == 0 && c->k_begin == 0 && c->k_end == c->N && c->N >= 2 && FusedVariant(c) != 0;
@@ -1880,6 +1928,7 @@ static int MakeKkt(idto_hip_ctx* c, int nu) {
   // (seven workgroups for allegro's 29 x 29 blocks: 0.46 -> 0.29 ms per iteration; the small systems stay on two - the
   // nested-dissection order buys them 3 us and costs acrobot's multipliers a digit: 2e-8 against 3e-9)
   k->two_sided = c->two_sided; k->solver_nd = c->solver_nd && (K == 29 || K == 8); k->solver_pipe = false; k->fused = false; k->asm_in_solver = false;
+  k->solver_band = c->solver_band;
   k->h_assembled = true;      // block row 0 is decoupled (q_0 is no variable, mu_0 a dummy): the chains start at row 1
   k->ldl_npos = c->nq;
   const size_t kk = (size_t)K * K;
@@ -2412,6 +2461,7 @@ int idto_hip_get_option(idto_hip_ctx* c, const char* name, int* value) {
   if (std::strcmp(name, "weights_diagonal") == 0) { *value = c->weights_diagonal ? 1 : 0; return 0; }
   if (std::strcmp(name, "solver_nd") == 0) { *value = c->solver_nd; return 0; }
   if (std::strcmp(name, "solver_pipe") == 0) { *value = c->solver_pipe; return 0; }
+  if (std::strcmp(name, "solver_band") == 0) { *value = c->solver_band; return 0; }
   if (std::strcmp(name, "asm_in_solver") == 0) { *value = c->asm_in_solver; return 0; }
   if (std::strcmp(name, "solver_timeouts") == 0) { *value = c->solver_timeouts; return 0; }
   if (std::strcmp(name, "asm_fold") == 0) { *value = c->asm_fold; return 0; }
@@ -2435,6 +2485,7 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "fused") == 0) { c->fused = value != 0; return 0; }
   if (std::strcmp(name, "solver_nd") == 0) { c->solver_nd = value != 0; return 0; }
   if (std::strcmp(name, "solver_pipe") == 0) { c->solver_pipe = value != 0; return 0; }
+  if (std::strcmp(name, "solver_band") == 0) { c->solver_band = value; if (c->kkt) c->kkt->solver_band = value; return 0; }
   if (std::strcmp(name, "asm_in_solver") == 0) { c->asm_in_solver = value != 0; return 0; }
   if (std::strcmp(name, "debug_skip_role") == 0) { c->debug_skip_role = value; return 0; }   // test aid
   if (std::strcmp(name, "debug_pipe_tail") == 0) { c->debug_pipe_tail = value; return 0; }   // measurement aid
@@ -2461,7 +2512,7 @@ static bool AsmInSolver(idto_hip_ctx* c) {
   const bool was = c->h_assembled;
   c->h_assembled = true;   // (the plan's first row depends on it)
   LdlPlan p;
-  const bool ok = PlanLdl(c, false, &p) == 0 && p.K <= 20 && NdEligible(c, p) && 5 * c->batch <= 64;
+  const bool ok = PlanLdl(c, false, &p) == 0 && (BandEligible(c, p) || (p.K <= 20 && NdEligible(c, p) && 5 * c->batch <= 64));
   c->h_assembled = was;
   return ok;
 }

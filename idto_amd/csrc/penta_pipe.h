@@ -308,8 +308,8 @@ struct PipeArgs {
   double* ts;
 };
 
-// ---- g and the band blocks formed INSIDE the solver's launch (idto_hip_gn_step): workgroups 5 .. 5 + 4 (N + 1) - 1
-// of the grid run assemble_terms_kernel's rows (kernels.h assemble_terms_row: same expressions, same bits), store with
+// ---- g and the band blocks formed INSIDE the solver's launch (idto_hip_gn_step): the 4 (N + 1) workgroups behind the
+// solver's own (5 of penta_pipe_kernel, 1 of penta_band_kernel) run assemble_terms_kernel's rows (kernels.h assemble_terms_row: same expressions, same bits), store with
 // write-through and publish one word per (block row, part); the chains' loads of a row wait for the words of the
 // rows it touches and bypass the L2 (another XCD's L2 held the lines first).  What this buys is the launch boundary
 // between assembly and solver (~8 us a step); the assembly workgroups are gone long before the chains need
@@ -329,27 +329,30 @@ __device__ __forceinline__ bool pipe_asm_on(const PipeAsm& F, size_t o) {
   return F.on && !(F.gate && *at_problem(F.gate, o) == 0.0);
 }
 
-__device__ __forceinline__ void pipe_assemble(const NdArgs& A, PipeAsm F) {
+// (first_wg: how many workgroups of the grid's x run the solver - 5 in penta_pipe_kernel, 1 in penta_band_kernel; ts:
+// debug stamps or nullptr, in the slot behind the solver's roles)
+__device__ __forceinline__ void pipe_assemble(double* ts, const unsigned epoch, const size_t pstride, PipeAsm F, const int first_wg) {
+  struct { double* ts; unsigned epoch; size_t pstride; } A{ts, epoch, pstride};
   extern __shared__ double lds[];
-  const int a = (int)blockIdx.x - 5, i = a >> 2, part = a & 3;
+  const int a = (int)blockIdx.x - first_wg, i = a >> 2, part = a & 3;
   if (i >= F.rows) return;
   if (!pipe_asm_on(F, (size_t)blockIdx.y * A.pstride)) return;
   if (A.ts && threadIdx.x == 0)   // debug stamps of role 5: [0] latest end, [1] latest start of an assembly workgroup (positive doubles order like integers)
-    atomicMax(reinterpret_cast<unsigned long long*>(A.ts + 5 * 64 + 1), (unsigned long long)__double_as_longlong((double)wall_clock64()));
-  if (A.ts && a == 4 && threadIdx.x == 0) A.ts[5 * 64 + 8] = (double)wall_clock64();
+    atomicMax(reinterpret_cast<unsigned long long*>(A.ts + first_wg * 64 + 1), (unsigned long long)__double_as_longlong((double)wall_clock64()));
+  if (A.ts && a == 4 && threadIdx.x == 0) A.ts[first_wg * 64 + 8] = (double)wall_clock64();
   const size_t o = (size_t)blockIdx.y * A.pstride, w = o + (size_t)alt_offset(F.alt, o);
   const DevProblem P = at_problem(F.P, o);
   assemble_terms_row<true>(F.nq, F.nv, P, at_problem(F.q, o), at_problem(F.terms, w), at_problem(F.v_res, w),
                            at_problem(F.nplus, w), at_problem(F.g, o), at_problem(F.HA, o), at_problem(F.HB, o),
                            at_problem(F.HC, o), i, part, lds);
-  if (A.ts && a == 4 && threadIdx.x == 0) A.ts[5 * 64 + 9] = (double)wall_clock64();
+  if (A.ts && a == 4 && threadIdx.x == 0) A.ts[first_wg * 64 + 9] = (double)wall_clock64();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every write-through store acknowledged ...
   __syncthreads();
-  if (A.ts && a == 4 && threadIdx.x == 0) A.ts[5 * 64 + 10] = (double)wall_clock64();
+  if (A.ts && a == 4 && threadIdx.x == 0) A.ts[first_wg * 64 + 10] = (double)wall_clock64();
   if (threadIdx.x == 0)                              // ... before the word that says so
     __hip_atomic_store(at_problem(F.ready, o) + 4 * i + part, A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (A.ts && threadIdx.x == 0)
-    atomicMax(reinterpret_cast<unsigned long long*>(A.ts + 5 * 64), (unsigned long long)__double_as_longlong((double)wall_clock64()));
+    atomicMax(reinterpret_cast<unsigned long long*>(A.ts + first_wg * 64), (unsigned long long)__double_as_longlong((double)wall_clock64()));
 }
 
 // one wavefront waits for solver rows o_lo .. o_hi (clamped to the system) to be assembled: a lane per word
@@ -1164,7 +1167,7 @@ __device__ __forceinline__ void pipe_backward(const PipeArgs& A, const ChainCfg&
 // factorisation status set instead of hanging the device.
 template <int K>
 __global__ void __launch_bounds__(512) penta_pipe_kernel(NdArgs A, PipeAsm F) {
-  if (blockIdx.x >= 5) { pipe_assemble(A, F); return; }
+  if (blockIdx.x >= 5) { pipe_assemble(A.ts, A.epoch, A.pstride, F, 5); return; }
   {
     const size_t o = (size_t)blockIdx.y * A.pstride;
     A.HA = at_problem(A.HA, o); A.HB = at_problem(A.HB, o); A.HC = at_problem(A.HC, o); A.b = at_problem(A.b, o);

@@ -117,19 +117,22 @@ def test_fold_batch():
             assert _same(out[1][b][a], out[0][b][a]), (b, a)
 
 
-@pytest.mark.parametrize("name,N", [("mini_cheetah", 40), ("mini_cheetah", 24), ("hopper", 50), ("acrobot", 40), ("spinner", 40)])
-def test_assembly_inside_the_solver_launch_is_bit_identical(name, N):
-    """idto_hip_gn_step with the pipelined solver: g and the bands are formed by workgroups of the solver's own
-    launch (penta_pipe.h PipeAsm) - same bits as the assembly kernel's, and the step solved from them the same"""
+@pytest.mark.parametrize("name,N,band", [("mini_cheetah", 40, 0), ("mini_cheetah", 24, 0), ("hopper", 50, 0), ("hopper", 50, 2), ("acrobot", 40, 0),
+                                         ("acrobot", 40, 1), ("spinner", 40, 0), ("spinner", 40, 1)])
+def test_assembly_inside_the_solver_launch_is_bit_identical(name, N, band):
+    """idto_hip_gn_step with the pipelined solver (band = 0) or the scalar band factorisation (penta_band.h): g and the
+    bands are formed by workgroups of the solver's own launch (penta_pipe.h PipeAsm) - same bits as the assembly
+    kernel's, and the step solved from them the same"""
     cfg, model, prob, sp, q = _setup(name, N)
     out = {}
     for inside in (1, 0):
         dev = hip.HipPath(model, prob, sp)
+        dev.set_option("solver_band", band)
         dev.set_option("asm_in_solver", inside)
         dev.set_q(q)
         for _ in range(3):   # (epoch-valued words: repeated launches)
             dev.gn_step()
-        assert dev.get_option("last_solver") == 4
+        assert dev.get_option("last_solver") == (6 if band else 4)
         assert dev.get_option("last_assembly") == (4 if inside else 1)
         assert dev.solver_status() == (False, 0)
         out[inside] = {a: dev.get(a) for a in BANDS + ("step",)}

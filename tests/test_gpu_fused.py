@@ -12,6 +12,12 @@ from oracle_lib import Oracle
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _block_kernels_only(monkeypatch):
+    """the three-launch path these tests compare with bit by bit is the block factorisation the fused launch embeds: the scalar band factorisation (penta_band.h) stays out"""
+    monkeypatch.setenv("IDTO_SOLVER_BAND", "0")
+
 ARRAYS = ("v", "a", "tau", "nplus", "dtau_dqm", "dtau_dqt", "dtau_dqp", "gradient", "H_A", "H_B", "H_C", "step")
 
 

@@ -20,6 +20,12 @@ from test_oracle_penta import from_lower_dense
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _block_kernels_only(monkeypatch):
+    """these tests are about the multi-workgroup block kernels: the scalar band factorisation (penta_band.h, tests/test_gpu_band.py), which takes the small models' systems by default, stays out"""
+    monkeypatch.setenv("IDTO_SOLVER_BAND", "0")
+
+
 def _setup(name, N, seed=0):
     cfg, model = load_config(name), load_model(name)
     prob, sp, _ = make_problem(cfg, model, num_steps=N)

@@ -22,13 +22,14 @@ from oracle_lib import Oracle
 pytestmark = pytest.mark.gpu
 
 CASES = [("acrobot", 40, 0.0), ("spinner", 40, 0.0), ("hopper", 50, 0.01), ("mini_cheetah", 40, 0.01), ("allegro_hand", 60, 0.0)]
-# variant -> (options, the values of `last_solver` that say it ran: 4 pipelined, 2 nested dissection, 1 two workgroups
-# (5: the same inside the fused launch))
+# variant -> (options, the values of `last_solver` that say it ran: 6 scalar band (blocks up to 5), 4 pipelined, 2 nested
+# dissection, 1 two workgroups (5: the same inside the fused launch))
 VARIANTS = {
-    "pipe": ({"solver_pipe": 1, "solver_nd": 1, "debug_pipe_tail": 0}, (4,)),
-    "pipe_rowwise_tail": ({"solver_pipe": 1, "solver_nd": 1, "debug_pipe_tail": 1}, (4,)),
-    "nd": ({"solver_pipe": 0, "solver_nd": 1, "debug_pipe_tail": 0}, (2,)),
-    "two": ({"solver_pipe": 0, "solver_nd": 0, "debug_pipe_tail": 0}, (1, 5)),
+    "band": ({"solver_band": 2, "solver_pipe": 1, "solver_nd": 1, "debug_pipe_tail": 0}, (6,)),
+    "pipe": ({"solver_band": 0, "solver_pipe": 1, "solver_nd": 1, "debug_pipe_tail": 0}, (4,)),
+    "pipe_rowwise_tail": ({"solver_band": 0, "solver_pipe": 1, "solver_nd": 1, "debug_pipe_tail": 1}, (4,)),
+    "nd": ({"solver_band": 0, "solver_pipe": 0, "solver_nd": 1, "debug_pipe_tail": 0}, (2,)),
+    "two": ({"solver_band": 0, "solver_pipe": 0, "solver_nd": 0, "debug_pipe_tail": 0}, (1, 5)),
 }
 
 

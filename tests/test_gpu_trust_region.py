@@ -329,7 +329,7 @@ def test_banded_kkt_multipliers_are_as_accurate_as_the_schur_complement_chain(na
         dev.eval_tau()
         rows, _ = dev.tr_solve(1, SCALING["double_sqrt"], True, False, 1e-1, 1e5, constrained_dofs=dofs)
         assert rows[0, 14] == 0
-        assert dev.get_option("kkt_last_solver") in ((1, 2) if kkt else (0,))   # two-workgroup / seven-workgroup factorisation
+        assert dev.get_option("kkt_last_solver") in ((1, 2, 6) if kkt else (0,))   # two-workgroup / seven-workgroup / scalar band factorisation
         lam[kkt] = dev.get("con_lambda")
         if kkt:
             want = _kkt_reference(model, prob, sp, q, dev)
