@@ -31,7 +31,7 @@ for N in Ns:
         dev = hip.HipPath(model, prob, sp)
         dev.set_q(q)
         out = {}
-        for label, opts in (("pipe", {"solver_pipe": 1}), ("ptail", {"debug_pipe_tail": 1}), ("nd", {"solver_pipe": 0, "debug_pipe_tail": 0}), ("two", {"solver_nd": 0}),
+        for label, opts in (("band", {"solver_band": 2}), ("pipe", {"solver_band": 0, "solver_pipe": 1}), ("ptail", {"debug_pipe_tail": 1}), ("nd", {"solver_pipe": 0, "debug_pipe_tail": 0}), ("two", {"solver_nd": 0}),
                             ("lu", {"reference_solver": 1})):
             for k, v in opts.items():
                 dev.set_option(k, v)
@@ -50,6 +50,8 @@ for N in Ns:
         bwd = {k: (np.abs(ol.penta_multiply(*bands, v) + g.ravel()) / (ol.penta_multiply(*ab, np.abs(v)) + np.abs(g.ravel()) + 1e-300)).max() for k, v in out.items()}
         print(f"{name} N={N} seed={seed}: residual/|g| lu {res['lu']:.1e} pipe {res['pipe']:.1e} ptail {res['ptail']:.1e} nd {res['nd']:.1e} two {res['two']:.1e}")
         print(f"{name} N={N} seed={seed}: componentwise backward error lu {bwd['lu']:.1e} pipe {bwd['pipe']:.1e} ptail {bwd['ptail']:.1e} nd {bwd['nd']:.1e} two {bwd['two']:.1e}")
+        if codes["band"] == 6:   # the scalar band factorisation (csrc/penta_band.h) took this block size
+            print(f"{name} N={N} seed={seed}: band: residual/|g| {res['band']:.1e}, componentwise backward error {bwd['band']:.1e}, forward error band/lu {err['band'] / err['lu']:.2f}")
         print(f"{name} N={N} seed={seed}: lu {err['lu']:.2e}  pipe/lu {err['pipe'] / err['lu']:.2f}  nd/lu {err['nd'] / err['lu']:.2f}  "
               f"two/lu {err['two'] / err['lu']:.2f}  ptail/lu {err['ptail'] / err['lu']:.2f}  (unc {unc:.1e}; kernels that ran, "
               f"4 pipelined / 2 nested dissection / 1 two workgroups / 3 LU: pipe {codes['pipe']} ptail {codes['ptail']} nd {codes['nd']} two {codes['two']})", flush=True)
