@@ -4,7 +4,7 @@
 //
 // The block kernels (penta_ldl.h, penta_pipe.h) pay ~1.5 us per BLOCK row whatever K is - hand-overs between
 // wavefronts, a products phase on the matrix cores, barriers: 35 us for acrobot's 41 rows of 2 x 2, most of its step
-// (DESIGN.md 5.10).  Here a pivot is ~20 + 5 W instructions of one wavefront and nothing else:
+// (DESIGN.md 5.10, 5.11).  Here a pivot is ~20 + 6 W instructions of one wavefront and nothing else:
 //
 //   storage   column q of the lower band in 16 LDS cells: cell d = A[q + d][q] (d <= w = W - 1), cell 15 = the
 //             right-hand side's b_q (the matrix bordered by b as its last row), the rest zero
@@ -19,12 +19,12 @@
 //   back      x_j = y_j / d_j + p_0;  p_d -= l_{j, j - d} x_j for the w rows above (row j of L: cells (j - d, d), one
 //             LDS read that brings y_j / d_j along in lane 15), p shifted by one lane per step
 //
-// Two wavefronts take the two ends, each on a copy of ITS part of the band - the second one's mirrored (the matrix is
-// symmetric: its columns are the first one's rows), so both run the same code; the copies are padded with zero /
-// identity columns where a chain would otherwise need a mask (identity pivots in front of the mirrored chain make its
-// length a multiple of W, one behind the first chain's middle).  The first chain takes the w rows in the middle:
-// it adds the second's Schur complement (through LDS, one barrier) and goes on; back substitution from the middle
-// outwards likewise.  g and the bands may be assembled by further workgroups of the same launch (penta_pipe.h
+// Two wavefronts take the two ends, each on a copy of ITS part of the band - the second one's mirrored block by block
+// (band_mirror; the matrix is symmetric: its columns are the first one's rows), so both run the same code; the copies
+// are padded with zero / identity columns where a chain would otherwise need a mask (identity pivots in front of the
+// mirrored chain make its length a multiple of W).  The first chain takes the W rows in the middle (three whole
+// blocks): it adds the second's Schur complement (through LDS, one barrier) and goes on; back substitution from the
+// middle outwards likewise.  g and the bands may be assembled by further workgroups of the same launch (penta_pipe.h
 // PipeAsm), as in penta_pipe_kernel.
 //
 // The multiplier rows of a KKT system (kkt.h) are ordinary pivots here - negative ones; they are not tested
@@ -52,8 +52,8 @@ struct BandArgs {
 
 // The split and the LDS carve-up (doubles).  First chain: pivots 0 .. m - 1 (m a multiple of W), then the W middle rows
 // m .. lim - 1 (three whole blocks; w would do); mirrored chain: the nb rows behind them in the order band_mirror
-// gives them, `pad` identity pivots in front.  Columns of a copy: FRONT zero columns (the back substitution's reads above row 0 and its blocks of
-// four steps run into them), the chain's own, 2 W + 1 padding columns (identity behind the first chain's, zero behind
+// gives them, `pad` identity pivots in front.  Columns of a copy: FRONT zero columns (the back substitution's reads
+// above row 0 and its blocks of four steps run into them), the chain's own, 2 W + 1 padding columns (identity behind the first chain's, zero behind
 // the mirrored chain's: those only collect its Schur complement).
 struct BandLds { int m, lim, nb, pad, tcols, bcols, T, Bm, Dt, Db, D0, J, end; };
 constexpr int BAND_FRONT = 32;

@@ -320,14 +320,17 @@ int idto_hip_tr_solve_batch_constrained(idto_hip_ctx* ctx, int iterations, int s
  * two spike workgroups and a separator; default 1, used for block sizes 2 / 3 / 5 / 19 and at least 24
  * block rows; explicit multi-right-hand-side solves always use the two-workgroup factors);
  * "solver_pipe" = 0 keeps the nested dissection on the seven-workgroup kernel instead of the pipelined chains
- * (csrc/penta_pipe.h: five workgroups, block sizes up to 20; default 1); "asm_in_solver" = 0 gives the assembly of
+ * (csrc/penta_pipe.h: five workgroups, block sizes up to 20; default 1); "solver_band": the small models' scalar band
+ * factorisation in one workgroup, which takes the pipelined chains' place (csrc/penta_band.h; 0 off, 1 = blocks up to 4,
+ * the default, 2 = up to 5; IDTO_SOLVER_BAND overrides it at creation); "asm_in_solver" = 0 gives the assembly of
  * idto_hip_gn_step / of the trust-region loop a launch of its own instead of workgroups of the pipelined solver's
  * launch (default 1); a launch whose workgroups were not co-resident steps these down by itself (IDTO_HIP_SOLVER_TIMEOUT);
  * "solver_debug" = 1 records per-phase cycle stamps (IDTO_ARR 15, tools/solver_phases.py);
  * "asm_stop" truncates the assembly kernel after a phase (tools/asm_phases.py). */
 int idto_hip_set_option(idto_hip_ctx* ctx, const char* name, int value);
 /* Reads an option back; additionally "last_solver": which factorisation the last solve used
- * (1 two-workgroup block LDL^T, 2 nested dissection over seven workgroups, 3 reference-order LU). */
+ * (1 two-workgroup block LDL^T, 2 nested dissection over seven workgroups, 3 reference-order LU, 4 nested dissection
+ * with pipelined chains, 5 inside the fused launch, 6 the scalar band factorisation). */
 int idto_hip_get_option(idto_hip_ctx* ctx, const char* name, int* value);
 
 /* Device-side timing of the last `idto_hip_gn_step`-shaped launches: average
