@@ -44,5 +44,7 @@ for kkt in 1 0; do for c in "acrobot 40" "spinner 40" "hopper 40" "allegro_hand 
 # bit reproducibility of the constrained loop over fresh contexts (the KKT step's factorisations)
 { for c in "allegro_hand 60 60" "hopper 40 100" "spinner 40 60" "acrobot 40 60"; do timeout 600 python tools/stress_kkt.py $c 2>&1 | grep -v amdgpu.ids | tail -2; done; } | tee gpurun_out/${R}_kkt_stress.txt
 timeout 600 python tools/fd_sweep.py 12 2>&1 | grep -v amdgpu.ids | tail -3 | tee gpurun_out/${R}_fd_sweep.txt
+{ for c in "acrobot 40 1200" "spinner 40 1200" "acrobot 200 600"; do timeout 300 python tools/stress_solver.py $c 2>&1 | grep -v amdgpu.ids; done; } | tee gpurun_out/${R}_band_stress.txt
+timeout 200 python tools/mpc_latency.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${R}_mpc_latency.txt
 timeout 300 python tools/band_phases.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${R}_band_phases.txt
 ls gpurun_out | head -80
