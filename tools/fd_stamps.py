@@ -10,7 +10,7 @@ from idto_amd.problem import load_config, make_problem, synthetic_trajectory
 NAMES = ["start", "loads issued", "barrier 1", "v/a/edq + barrier 2 + outputs issued", "eval: inputs in registers", "eval: sincos",
          "eval: common body + its pairs", "eval: slot 0 done", "eval: last slot kinematics", "eval: last slot pairs",
          "eval: trailing pairs", "eval: backward pass", "evaluations + barrier", "record", "products", "barrier"]
-for name, N in (("mini_cheetah", 40), ("allegro_hand", 60)):
+for name, N in ((sys.argv[1], int(sys.argv[2])),) if len(sys.argv) > 2 else (("mini_cheetah", 40), ("allegro_hand", 60)):
     cfg = load_config(name); model = load_model(name)
     prob, sp, _ = make_problem(cfg, model, num_steps=N)
     q = synthetic_trajectory(cfg, model, N, seed=0, lower=0.01)
