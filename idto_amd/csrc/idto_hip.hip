@@ -943,6 +943,9 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   // kernels that need more than the default 64 KiB of dynamic LDS must opt in
   fd_set_max_lds(max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+#define BAND_ATTR(WM) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_band_kernel<WM>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  BAND_ATTR(6) BAND_ATTR(9) BAND_ATTR(12) BAND_ATTR(15)
+#undef BAND_ATTR
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cost_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
