@@ -47,4 +47,5 @@ timeout 600 python tools/fd_sweep.py 12 2>&1 | grep -v amdgpu.ids | tail -3 | te
 { for c in "acrobot 40 1200" "spinner 40 1200" "acrobot 200 600"; do timeout 300 python tools/stress_solver.py $c 2>&1 | grep -v amdgpu.ids; done; } | tee gpurun_out/${R}_band_stress.txt
 timeout 200 python tools/mpc_latency.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${R}_mpc_latency.txt
 timeout 300 python tools/band_phases.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${R}_band_phases.txt
+ROUND=$R timeout 900 bash tools/prof_band.sh > /dev/null 2>&1
 ls gpurun_out | head -80
