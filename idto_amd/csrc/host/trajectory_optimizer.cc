@@ -1017,7 +1017,8 @@ SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solu
     Check(idto_hip_set_q(dev(), q0.data()));
   }
   Check(idto_hip_set_unactuated_dofs(dev(), unactuated_dofs_.data(), (int)unactuated_dofs_.size()));
-  Check(idto_hip_eval_tau(dev()));
+  // (the resident loop starts with the partials of this q: one finite-difference launch for both)
+  Check(ResidentLoopEligible() ? idto_hip_eval_tau_partials(dev()) : idto_hip_eval_tau(dev()));
   // (the resident loop keeps the cost on the device and reports it in its rows: no fetch, no synchronisation here)
   double cost = ResidentLoopEligible() ? 0.0 : Fetch(IDTO_ARR_COST)[0];
   const int scal = params_.scaling ? static_cast<int>(params_.scaling_method) : -1;

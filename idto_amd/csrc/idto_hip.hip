@@ -144,6 +144,7 @@ struct idto_hip_ctx {
   struct Timed { hipEvent_t a, b; int which; };
   std::vector<Timed> pending;
   bool fd_full = false;                   // v / N+ in HBM belong to the resident q for every t
+  bool partials_ahead = false;            // idto_hip_eval_tau_partials has left the partials of the resident q: the next idto_hip_eval_partials is done
   int gradients_method = 0;               // 0 forward, 1 central, 2 central 4th order (solver_parameters.h:26-50)
   int fd_stop = 0;                        // same for the finite-difference kernel
   bool fd_fast = true;                    // option "fd_fast": id_fast.h's evaluation when the model has an instantiated shape
@@ -623,6 +624,7 @@ int FdLds(const idto_hip_ctx* c, int mode, int ec, bool with_terms = false, bool
 static bool FoldTerms(const idto_hip_ctx* c, int mode) { return c->asm_fold && c->weights_diagonal && mode >= 1; }
 
 int LaunchFd(idto_hip_ctx* c, int mode, int kb, int ke, AltSel alt = AltSel{nullptr, 0, 0}) {
+  c->partials_ahead = false;   // (whatever idto_hip_eval_tau_partials left is about to be overwritten; it sets the flag after its own launch)
   if (ke <= kb) return 0;
   if (mode >= 1) mode = 1 + c->gradients_method;  // 1 forward, 2 central, 3 central (4th order)
   dim3 grid(ke - kb, c->batch), block(mode >= 1 ? c->fd_threads : 64);
@@ -1016,7 +1018,7 @@ int idto_hip_set_problem_batch(idto_hip_ctx* c, int b, const idto_problem_t* p) 
   if (b < 0 || b >= c->batch) { g_err = "problem index outside the batch"; return -1; }
   if (p->num_steps != c->N || p->time_step != c->dt) { g_err = "num_steps / time_step cannot change"; return -1; }
   HIP_OK(hipSetDevice(c->device));
-  c->fd_full = false;  // v_0 = v_init
+  c->fd_full = false; c->partials_ahead = false;  // v_0 = v_init
   c->con_ready = false; c->con_begun = false;
   if (b < (int)c->host_problems.size()) {
     c->host_problems[b]->Set(*p, c->nq, c->nv);
@@ -1048,7 +1050,7 @@ int idto_hip_set_q(idto_hip_ctx* c, const double* q_host) {
   HIP_OK(hipSetDevice(c->device));
   c->trial_resident = false; c->spec_pending = false; c->spec_ready = false;
   DropPrefetch(c, {IDTO_ARR_Q});
-  c->fd_full = false;
+  c->fd_full = false; c->partials_ahead = false;
   c->con_ready = false; c->con_begun = false;
   HIP_OK(hipMemcpyAsync(c->q, q_host, (size_t)(c->N + 1) * c->nq * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIP_OK(hipStreamSynchronize(c->stream));  // the host buffer may be reused by the caller
@@ -1058,7 +1060,7 @@ int idto_hip_set_q_batch(idto_hip_ctx* c, const double* q_host) {
   HIP_OK(hipSetDevice(c->device));
   c->trial_resident = false; c->spec_pending = false; c->spec_ready = false;
   DropPrefetch(c, {IDTO_ARR_Q});
-  c->fd_full = false;
+  c->fd_full = false; c->partials_ahead = false;
   c->con_ready = false; c->con_begun = false;
   const size_t row = (size_t)(c->N + 1) * c->nq * sizeof(double);  // one trajectory per arena
   HIP_OK(hipMemcpy2DAsync(c->q, c->pstride, q_host, row, row, (size_t)c->batch, hipMemcpyHostToDevice, c->stream));
@@ -1069,7 +1071,7 @@ int idto_hip_set_q_device(idto_hip_ctx* c, const double* q_dev) {
   HIP_OK(hipSetDevice(c->device));
   c->trial_resident = false; c->spec_pending = false; c->spec_ready = false;
   DropPrefetch(c, {IDTO_ARR_Q});
-  c->fd_full = false;
+  c->fd_full = false; c->partials_ahead = false;
   c->con_ready = false; c->con_begun = false;
   HIP_OK(hipMemcpyAsync(c->q, q_dev, (size_t)(c->N + 1) * c->nq * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   return 0;
@@ -1077,10 +1079,31 @@ int idto_hip_set_q_device(idto_hip_ctx* c, const double* q_dev) {
 
 int idto_hip_eval_tau(idto_hip_ctx* c) {
   HIP_OK(hipSetDevice(c->device));
+  c->partials_ahead = false;
   c->trial_resident = false; c->spec_pending = false; c->spec_ready = false;
   DropPrefetch(c, {IDTO_ARR_V, IDTO_ARR_A, IDTO_ARR_NPLUS, IDTO_ARR_SLAB, IDTO_ARR_COST});
   int rc = LaunchFd(c, 0, 0, c->N);
   if (rc) return rc;
+  hipLaunchKernelGGL(cost_kernel, dim3(1, c->batch), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
+                     c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, (double*)nullptr, c->pstride, (double*)nullptr,
+                     TrDecideArgs{}, AltSel{nullptr, 0, 0});
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// idto_hip_eval_tau for a q whose partials are wanted next (the start of idto_hip_tr_solve / idto_hip_gn_step): ONE
+// finite-difference launch leaves v, a, N+, tau AND the partials (fd_kernel's derivative modes evaluate the nominal
+// point too: same tau, bit for bit), the cost follows; the idto_hip_eval_partials that comes next returns at once.
+int idto_hip_eval_tau_partials(idto_hip_ctx* c) {
+  HIP_OK(hipSetDevice(c->device));
+  if (!(c->k_begin == 0 && c->k_end == c->N)) return idto_hip_eval_tau(c);   // (a shard of the horizon: tau of every step is needed)
+  c->trial_resident = false; c->spec_pending = false; c->spec_ready = false;
+  DropPrefetch(c, {IDTO_ARR_V, IDTO_ARR_A, IDTO_ARR_NPLUS, IDTO_ARR_SLAB, IDTO_ARR_COST});
+  c->con_ready = false; c->con_begun = false;
+  int rc = LaunchFd(c, 1, 0, c->N);
+  if (rc) return rc;
+  c->fd_full = true;
+  c->partials_ahead = true;
   hipLaunchKernelGGL(cost_kernel, dim3(1, c->batch), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
                      c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, (double*)nullptr, c->pstride, (double*)nullptr,
                      TrDecideArgs{}, AltSel{nullptr, 0, 0});
@@ -1102,7 +1125,7 @@ int idto_hip_trial_cost(idto_hip_ctx* c, const double* q_host, double* tau_host,
   // one stream synchronisation for the whole trial point: q through pinned memory, N
   // inverse-dynamics evaluations, the cost, and [tau | cost] back in one copy
   std::memcpy(c->pin, q_host, nq_all * sizeof(double));
-  c->fd_full = false;
+  c->fd_full = false; c->partials_ahead = false;
   c->con_ready = false; c->con_begun = false;
   HIP_OK(hipMemcpyAsync(c->q, c->pin, nq_all * sizeof(double), hipMemcpyHostToDevice, c->stream));
   int rc = LaunchFd(c, 0, 0, c->N);
@@ -1120,6 +1143,11 @@ int idto_hip_trial_cost(idto_hip_ctx* c, const double* q_host, double* tau_host,
 
 int idto_hip_eval_partials(idto_hip_ctx* c) {
   HIP_OK(hipSetDevice(c->device));
+  if (c->partials_ahead && c->k_begin == 0 && c->k_end == c->N) {   // (idto_hip_eval_tau_partials: they are there)
+    c->partials_ahead = false;
+    return 0;
+  }
+  c->partials_ahead = false;
   DropPrefetch(c, {IDTO_ARR_V, IDTO_ARR_A, IDTO_ARR_NPLUS, IDTO_ARR_SLAB});
   c->con_ready = false; c->con_begun = false;
   if (TimeBegin(c, 0)) return -2;
@@ -1490,7 +1518,7 @@ static int LaunchFused(idto_hip_ctx* c) {
   }
 #undef FUSED_LAUNCH
   HIP_OK(hipGetLastError());
-  c->fd_full = true;
+  c->fd_full = true; c->partials_ahead = false;
   c->terms_valid = false;   // (the fused kernel assembles from the slab itself)
   return TimeEnd(c);
 }
@@ -1869,7 +1897,7 @@ int idto_hip_tr_trial(idto_hip_ctx* c, double a, double b, int scaling, int norm
   std::swap(c->q, c->q_trial);
   if (rc) return rc;
   HIP_OK(hipGetLastError());
-  c->fd_full = false;
+  c->fd_full = false; c->partials_ahead = false;
   c->trial_resident = true;
   HIP_OK(hipMemcpyAsync(c->tr_pin + 9, c->tr_out + 9, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   const bool speculate = speculate_scaling_method >= -1 && !with_lambda && FusedEligible(c) &&
@@ -1913,7 +1941,7 @@ int idto_hip_tr_reject(idto_hip_ctx* c) {
   // the trial point is dropped: v, a, tau (and, after a speculative launch, the partials, g, H and the
   // Newton step) in device memory do not belong to the resident q any more
   c->trial_resident = false; c->spec_pending = false; c->spec_ready = false;
-  c->fd_full = false;
+  c->fd_full = false; c->partials_ahead = false;
   c->con_ready = false; c->con_begun = false;
   return 0;
 }
@@ -2188,7 +2216,7 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     }
     if (rc) return rc;
   }
-  c->fd_full = false;
+  c->fd_full = false; c->partials_ahead = false;
   if (B != 1) {
     // every problem has its own current set: the ones whose iterate ended up in the other set get it copied over
     // (a single-problem context swaps its pointers instead, below)
@@ -2295,7 +2323,7 @@ int idto_hip_tr_solve_batch_constrained(idto_hip_ctx* c, int iterations, int sca
     ch->tr_conv_on = false;
     if (hipMemcpyAsync(ch->q, at_problem(c->q, (size_t)b * c->pstride), qbytes, hipMemcpyDeviceToDevice, ch->stream) != hipSuccess)
       return fail(-2, "copy of the problem's q failed");
-    ch->fd_full = false; ch->con_ready = false; ch->con_begun = false; ch->trial_resident = false;
+    ch->fd_full = false; ch->partials_ahead = false; ch->con_ready = false; ch->con_begun = false; ch->trial_resident = false;
     int rc = idto_hip_eval_tau(ch);
     if (rc) return fail(rc, "eval_tau failed");
     rc = TrSolve(ch, iterations, scaling_method, scaling, normalize_quaternions, Delta0 + b, Delta_max, eta, constrained_dofs, nu,
@@ -2309,7 +2337,7 @@ int idto_hip_tr_solve_batch_constrained(idto_hip_ctx* c, int iterations, int sca
   for (int b = 1; b < B; ++b) threads.emplace_back(work, b);
   work(0);
   for (auto& t : threads) t.join();
-  c->fd_full = false; c->trial_resident = false; c->con_ready = false; c->con_begun = false;   // q of every problem moved
+  c->fd_full = false; c->partials_ahead = false; c->trial_resident = false; c->con_ready = false; c->con_begun = false;   // q of every problem moved
   for (int b = 0; b < B; ++b)
     if (rcs[b]) { g_err = "problem " + std::to_string(b) + ": " + errs[b]; return rcs[b]; }
   return 0;

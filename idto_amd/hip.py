@@ -110,7 +110,7 @@ def lib():
 
 EXPORTED_SYMBOLS = [
     "idto_hip_last_error", "idto_hip_create", "idto_hip_destroy", "idto_hip_set_problem", "idto_hip_set_stream",
-    "idto_hip_get_stream", "idto_hip_set_shard", "idto_hip_set_q", "idto_hip_set_q_device", "idto_hip_eval_tau", "idto_hip_trial_cost", "idto_hip_constraint_schur",
+    "idto_hip_get_stream", "idto_hip_set_shard", "idto_hip_set_q", "idto_hip_set_q_device", "idto_hip_eval_tau", "idto_hip_eval_tau_partials", "idto_hip_trial_cost", "idto_hip_constraint_schur",
     "idto_hip_constraint_schur_begin", "idto_hip_constraint_solve", "idto_hip_constraint_step", "idto_hip_prefetch",
     "idto_hip_eval_partials", "idto_hip_grad_hess", "idto_hip_factor_solve", "idto_hip_gn_step", "idto_hip_solve_host",
     "idto_hip_set_option", "idto_hip_get_option",
@@ -320,6 +320,10 @@ class HipPath:
     # ---- path pieces (asynchronous on the context's stream)
     def eval_tau(self):
         _chk(lib().idto_hip_eval_tau(self.h))
+
+    def eval_tau_partials(self):
+        """eval_tau for a q whose partials come next: one finite-difference launch for both (the next eval_partials is done)"""
+        _chk(lib().idto_hip_eval_tau_partials(self.h))
 
     def constraint_schur(self, dofs):
         """S = J H^-1 J^T (n_eq x n_eq) and J H^-1 g for the constraint tau_t[dofs] = 0 (after grad_hess)"""

@@ -164,6 +164,10 @@ int idto_hip_set_q(idto_hip_ctx* ctx, const double* q_host);         /* H2D copy
 int idto_hip_set_q_device(idto_hip_ctx* ctx, const double* q_device); /* D2D copy */
 
 int idto_hip_eval_tau(idto_hip_ctx* ctx);
+/* The same for a q whose partials come next (idto_hip_tr_solve, idto_hip_gn_step): v, a, N+, tau, the cost AND the
+ * partials from one finite-difference launch (CalcInverseDynamicsPartialsFiniteDiff, optimizer/trajectory_optimizer.cc:426-563,
+ * evaluates the nominal point as well); the next idto_hip_eval_partials of this q returns at once. */
+int idto_hip_eval_tau_partials(idto_hip_ctx* ctx);
 
 /* One trial point of the trust-region loop in one call and one synchronisation (what
  * CalcTrustRatio, optimizer/trajectory_optimizer.cc:1979-2035, needs at q + dq): uploads q

@@ -337,3 +337,37 @@ def test_banded_kkt_multipliers_are_as_accurate_as_the_schur_complement_chain(na
     scale = np.abs(want).max()
     e_schur, e_kkt = np.abs(lam[0] - want).max() / scale, np.abs(lam[1] - want).max() / scale
     assert e_kkt <= 4 * e_schur + 1e-12, (e_kkt, e_schur)
+
+
+@pytest.mark.parametrize("name,N,constrained", [("mini_cheetah", 20, False), ("spinner", 40, True), ("hopper", 40, True), ("acrobot", 40, False)])
+def test_tau_and_partials_from_one_launch_start_the_same_loop(name, N, constrained):
+    """idto_hip_eval_tau_partials: v, a, N+, tau, cost and the partials of the resident q from ONE finite-difference
+    launch (the derivative modes evaluate the nominal point as well) - the loop that follows is the loop that
+    idto_hip_eval_tau + its own first evaluation of the partials runs, bit for bit; tau and cost are eval_tau's"""
+    cfg, model = load_config(name), load_model(name)
+    prob, sp, _ = make_problem(cfg, model, num_steps=N)
+    q = synthetic_trajectory(cfg, model, N, seed=2, lower=0.01 if name in ("hopper", "mini_cheetah") else 0.0)
+    dofs = np.asarray(model.unactuated_dofs) if constrained else ()
+    out = {}
+    for one in (1, 0):
+        dev = hip.HipPath(model, prob, sp)
+        dev.set_q(q)
+        if one:
+            dev.eval_tau_partials()
+        else:
+            dev.eval_tau()
+        tau, cost = dev.get("tau").copy(), np.asarray(dev.get("cost")).copy()
+        rows, _ = dev.tr_solve(4, SCALING["double_sqrt"], True, False, 1e-1, 1e5, constrained_dofs=dofs)
+        out[one] = (tau, cost, np.delete(rows, 10, axis=1), dev.get("q").copy())   # (column 10: the clock)
+        # the flag is used up: a Gauss-Newton step of the same context evaluates the partials again
+        dev.set_q(q)
+        dev.eval_tau_partials()
+        dev.gn_step()
+        dev.gn_step()
+        step = dev.get("step").copy()
+        dev.set_q(q)
+        dev.gn_step()
+        assert np.array_equal(step, dev.get("step"))
+        dev.close()
+    for a, b in zip(out[1], out[0]):
+        assert np.array_equal(a, b)
