@@ -184,6 +184,7 @@ struct idto_hip_ctx {
   double* pin = nullptr;                             // pinned host staging: q in, [tau | cost] out
   char* prob_pin = nullptr; size_t prob_pin_bytes = 0;   // ... of the problem arrays (UploadProblemArrays)
   double* many_pin = nullptr; size_t many_cap = 0;        // ... of idto_hip_get_many
+  double* rows_pin = nullptr; size_t rows_cap = 0;        // ... of idto_hip_tr_solve's statistics rows
   // equality-constraint step (constraints.h)
   int* con_dofs = nullptr; int con_nu = 0, con_neq = 0;
   std::vector<int> con_dofs_host;
@@ -302,7 +303,6 @@ int UploadProblemArrays(idto_hip_ctx* c, const idto_problem_t* p, int pb = 0) {
     const size_t bytes = (size_t)(hi - lo);
     if (c->prob_pin_bytes < bytes) {
       if (c->prob_pin) (void)hipHostFree(c->prob_pin);
-  if (c->many_pin) (void)hipHostFree(c->many_pin);
       c->prob_pin = nullptr; c->prob_pin_bytes = 0;
       HIP_OK(hipHostMalloc((void**)&c->prob_pin, bytes, hipHostMallocDefault));
       c->prob_pin_bytes = bytes;
@@ -1001,6 +1001,7 @@ void idto_hip_destroy(idto_hip_ctx* c) {
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->prob_pin) (void)hipHostFree(c->prob_pin);
   if (c->many_pin) (void)hipHostFree(c->many_pin);
+  if (c->rows_pin) (void)hipHostFree(c->rows_pin);
   if (c->status_pin) (void)hipHostFree(c->status_pin);
   if (c->tr_pin) (void)hipHostFree(c->tr_pin);
   if (c->spec_ev) (void)hipEventDestroy(c->spec_ev);
@@ -2037,7 +2038,16 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
   HIP_OK(hipMemset2DAsync(c->tr_cnt, c->pstride, 0, sizeof(unsigned long long), (size_t)B, c->stream));
   c->tr_target = 0;
   // state of every problem: [Delta, L(q) (resident: the caller evaluated the cost of q), ...]
-  {
+  if (B == 1) {
+    // (one problem: from the context's pinned words - the host touches them again only after the copies that end this
+    // solve, which the stream orders behind this one: no wait here, the loop is enqueued while the evaluation of the
+    // initial guess still runs)
+    static_assert(TRS_COUNT <= 16, "tr_pin holds 16 doubles");
+    double* st = c->tr_pin;
+    std::fill(st, st + TRS_COUNT, 0.0);
+    st[TRS_DELTA] = Delta0s[0]; st[TRS_ACCEPTED] = 1.0;
+    HIP_OK(hipMemcpyAsync(c->tr_state, st, TRS_COUNT * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  } else {
     std::vector<double> st((size_t)B * TRS_COUNT, 0.0);
     for (int b = 0; b < B; ++b) { st[(size_t)b * TRS_COUNT + TRS_DELTA] = Delta0s[b]; st[(size_t)b * TRS_COUNT + TRS_ACCEPTED] = 1.0; }
     HIP_OK(hipMemcpy2DAsync(c->tr_state, c->pstride, st.data(), TRS_COUNT * sizeof(double), TRS_COUNT * sizeof(double), (size_t)B,
@@ -2240,9 +2250,19 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     }
     return 0;
   }
-  HIP_OK(hipMemcpyAsync(c->tr_pin, c->tr_state, TRS_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_OK(hipStreamSynchronize(c->stream));
-  HIP_OK(hipMemcpy(rows_host, c->tr_rows, (size_t)iterations * TRR_COUNT * sizeof(double), hipMemcpyDeviceToHost));
+  {   // the state words and the statistics rows with ONE wait (the rows through pinned staging of the context)
+    const size_t nrow = (size_t)iterations * TRR_COUNT;
+    if (c->rows_cap < nrow) {
+      if (c->rows_pin) (void)hipHostFree(c->rows_pin);
+      c->rows_pin = nullptr; c->rows_cap = 0;
+      HIP_OK(hipHostMalloc((void**)&c->rows_pin, std::max<size_t>(nrow, 64 * TRR_COUNT) * sizeof(double), hipHostMallocDefault));
+      c->rows_cap = std::max<size_t>(nrow, 64 * TRR_COUNT);
+    }
+    HIP_OK(hipMemcpyAsync(c->tr_pin, c->tr_state, TRS_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipMemcpyAsync(c->rows_pin, c->tr_rows, nrow * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    std::memcpy(rows_host, c->rows_pin, nrow * sizeof(double));
+  }
   if (Delta_out) *Delta_out = c->tr_pin[TRS_DELTA];
   if (c->tr_pin[TRS_CUR] != 0.0) {   // the iterate's v, a, N+, slab, products ended up in the other set: it is "the" set now
     c->v = at_problem(c->v, (size_t)c->alt_off); c->a = at_problem(c->a, (size_t)c->alt_off);
