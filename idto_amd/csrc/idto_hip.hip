@@ -1299,6 +1299,9 @@ static bool BandEligible(const idto_hip_ctx* c, const LdlPlan& p) {
   // (option solver_band: 0 off, 1 blocks up to 4 - at 5 the pipelined kernel is faster, 41 against 47 us for hopper -, 2 up to 5)
   if (!(c->solver_band > 0 && c->two_sided && p.K == p.k && p.k >= 2 && p.k <= (c->solver_band > 1 ? 5 : 4))) return false;
   const int M = p.n * p.k, W = 3 * p.k;
+  // (a batch: two wavefronts per problem shorten ONE problem's solve; with many in flight the five workgroups' work per
+  // problem is what counts - 64 spinner problems 554k against 567k it/s, 256: 747k / 782k; acrobot 649k / 619k)
+  if (c->batch > 1 && c->solver_band < 2 && p.k > 2) return false;
   // (horizons the pipelined kernel would take: shorter ones keep the fused launch / the two-workgroup factorisation)
   return p.n >= 24 && M >= 4 * W && band_layout(M, W).end * (int)sizeof(double) <= 160 * 1024;
 }

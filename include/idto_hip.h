@@ -325,8 +325,8 @@ int idto_hip_tr_solve_batch_constrained(idto_hip_ctx* ctx, int iterations, int s
  * block rows; explicit multi-right-hand-side solves always use the two-workgroup factors);
  * "solver_pipe" = 0 keeps the nested dissection on the seven-workgroup kernel instead of the pipelined chains
  * (csrc/penta_pipe.h: five workgroups, block sizes up to 20; default 1); "solver_band": the small models' scalar band
- * factorisation in one workgroup, which takes the pipelined chains' place (csrc/penta_band.h; 0 off, 1 = blocks up to 4,
- * the default, 2 = up to 5; IDTO_SOLVER_BAND overrides it at creation); "asm_in_solver" = 0 gives the assembly of
+ * factorisation in one workgroup, which takes the pipelined chains' place (csrc/penta_band.h; 0 off, 1 = blocks up to 4 - in a
+ * batch context up to 2 -, the default, 2 = up to 5, batches included; IDTO_SOLVER_BAND overrides it at creation); "asm_in_solver" = 0 gives the assembly of
  * idto_hip_gn_step / of the trust-region loop a launch of its own instead of workgroups of the pipelined solver's
  * launch (default 1); a launch whose workgroups were not co-resident steps these down by itself (IDTO_HIP_SOLVER_TIMEOUT);
  * "solver_debug" = 1 records per-phase cycle stamps (IDTO_ARR 15, tools/solver_phases.py);
