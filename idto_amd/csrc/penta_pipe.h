@@ -710,8 +710,8 @@ __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCf
           }
         }
         pipe_post(ctl, f_rowdone + slot, il + 1);
-        // the row's spike block is in HBM: one of the three releases the separator waits for (the I/O wavefront
-        // adds two with 1 / d and rt)
+        // the row's spike block is in HBM: one of the three releases the separator waits for (the G wavefront adds two
+        // with 1 / d and rt)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(A.frowcnt + il, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -874,16 +874,10 @@ __device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& 
         A.Est[(size_t)o * K * ks + idx] = in ? row[G::oE + c] : 0.0;
       }
       if (lane < K) {
-        const double rt = row0[lane * RS + G::oRy];
-        // (1 / d and rt are what the separator reads of this row besides the spike block: write-through)
-        if (SPK) __hip_atomic_store(A.Dst + (size_t)o * K + lane, row0[lane * RS + G::oi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else A.Dst[(size_t)o * K + lane] = row0[lane * RS + G::oi];
-        lds[L.xall + (il + 2) * ks + lane] = rt;   // rt (unscaled) for the back substitution
-        if (SPK) __hip_atomic_store(A.fst + (size_t)il * A.fstride + 2 * K * ks + lane, rt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... and as column 2K of the spike block
-      }
-      if (SPK) {   // two of the three releases of the row (the spike wavefront adds the third): a drained store queue
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(A.frowcnt + il, 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (a chain with spike columns: the G wavefront sends 1 / d and rt to HBM as the pivots appear - the separator reads
+        // them, and this wavefront's copies of finished rows queue up behind the join)
+        if (!SPK) A.Dst[(size_t)o * K + lane] = row0[lane * RS + G::oi];
+        lds[L.xall + (il + 2) * ks + lane] = row0[lane * RS + G::oRy];   // rt (unscaled) for the back substitution
       }
     };
     stage_row(0);
@@ -925,16 +919,33 @@ __device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& 
     constexpr int NCG = SPK ? G::NGC : G::KE + 1;        // columns of G that exist
     constexpr int CT = (NCG + 15) / 16;
     const int fl = lane & 15, fk = lane >> 4;
+    // (a chain with spike columns: this wavefront also hands the separator 1 / d_J and rt_J of every row - lanes 0 .. 3
+    // and 4 .. 7, four pivots per k-step - and releases them; the spike wavefront releases the spike block itself)
+    const int xr4 = lane & 3;
+    const int xpos = (lane >> 2) == 0 ? G::oi : G::oRy;
     for (int t = 0; t < nloc; ++t) {
       const int slot = t % 3;
       const double* row0 = ring + slot * G::SLOT;
-      if (t + 2 < nrows) {   // (else nobody is two rows ahead)
+      const bool prod = t + 2 < nrows;   // (else nobody is two rows ahead)
+      if (!prod && SPK) {
+        pipe_wait(ctl, PF_SLOTGEN + slot, t + 1);
+        PipeWatch<K, false> watch(row0, true);
+        double* xout = (lane >> 2) == 0 ? A.Dst + (size_t)orig(t) * K : A.fst + (size_t)t * A.fstride + 2 * K * ks;
+#pragma unroll
+        for (int sq = 0; sq < SK; ++sq) {
+          watch.need(ctl, (4 * sq + 3 < K ? 4 * sq + 3 : K - 1));
+          const int r = 4 * sq + xr4;
+          if (lane < 8 && r < K) __hip_atomic_store(xout + r, row0[r * RS + xpos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (prod) {
         // The products run WHILE the row is being eliminated: k-step sq (pivot rows 4 sq .. 4 sq + 3) as soon as
         // those rows are published, so that G is complete a k-step after the row's last pivot and the followers
         // of the row after next can take it in early.
         pipe_wait(ctl, PF_SLOTGEN + slot, t + 1);
         if (SPK) pipe_wait(ctl, PF_SLOTGEN2 + slot, t + 1);
         PipeWatch<K, SPK> watch(row0, true);
+        double* xout = !SPK ? nullptr : (lane >> 2) == 0 ? A.Dst + (size_t)orig(t) * K : A.fst + (size_t)t * A.fstride + 2 * K * ks;
         d4 acc[CT][TT];
 #pragma unroll
         for (int tc = 0; tc < CT; ++tc)
@@ -943,6 +954,10 @@ __device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& 
 #pragma unroll
         for (int sq = 0; sq < SK; ++sq) {
           watch.need(ctl, (4 * sq + 3 < K ? 4 * sq + 3 : K - 1));
+          if (SPK) {
+            const int r = 4 * sq + xr4;
+            if (lane < 8 && r < K) __hip_atomic_store(xout + r, row0[r * RS + xpos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
           const double* row = row0 + (4 * sq + fk) * RS;   // (pad rows: zeros)
           double a[TT], bq[CT];
 #pragma unroll
@@ -968,6 +983,10 @@ __device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& 
               if (r < K && ci < NCG) gout[ci * GS + r] = acc[tc][tr][rg];
             }
         pipe_post(ctl, PF_GDONE + (t & 1), t + 1);
+      }
+      if (SPK) {   // two of the three releases of the row: a drained store queue
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(A.frowcnt + t, 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
@@ -1046,11 +1065,16 @@ __device__ __forceinline__ void pipe_backward(const PipeArgs& A, const ChainCfg&
       xr[r] -= a0 + a1;
     }
   };
-  for (int pass = 0; pass < (SPK ? 2 : 1); ++pass) {
-    for (int il = wave; il < nloc; il += nwaves) {
+  // (one list of tasks, [Y | Z | c] of every row, then W of every row, dealt out over the wavefronts: a loop over the
+  // rows per pass left six of eight wavefronts idle in every pass's last round - 4 rounds of ~2.4 us for a joiner's
+  // 2 x 10 tasks instead of 3)
+  for (int task = wave; task < (SPK ? 2 : 1) * nloc; task += nwaves) {
+    const int pass = task >= nloc ? 1 : 0;
+    {
+      const int il = task - pass * nloc;
       const int o = orig(il);
       double* slot = lds + il * B::BS;
-      double* Us = slot + (SPK ? B::oW : B::oYZ);   // D^-1 U staged here (row-major, stride ks); overwritten by the results
+      double* Us = slot + (pass ? B::oW : B::oYZ);   // D^-1 U staged where this task's results go (row-major, stride ks): another wavefront may be on the row's other task
       constexpr int NU = (KS2 + 63) / 64;
       double uv[NU];   // (all global loads of the task are issued before anything waits for one)
 #pragma unroll
