@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Build-time guard on what the register allocator did to the production kernels (VERDICT r4 "weak" #1 iv).
+
+DESIGN.md section 10: an inlined tail once pushed fd_kernel's SGPR spills from 105 to 146 and the kernel then computed
+wrong partials without the tail ever running - the hot kernels sit at the edge of what the allocator handles, and only
+the parity tests on a GPU would have noticed.  build.sh compiles with -Rpass-analysis=kernel-resource-usage, keeps the
+remarks under build/, and runs this script: a production instantiation with spilled vector registers, more scratch
+or more spilled scalar registers than the limits below FAILS THE BUILD (exit 1).  tests/test_build_resources.py runs
+the same check on the CPU (hipcc cross-compiles without a GPU).
+
+usage: check_resources.py [--compile] [remarks files ...]     (--compile: produce the remarks first, ~90 s)
+"""
+import os, re, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REMARKS = [os.path.join(ROOT, "build", "fd_launch.remarks"), os.path.join(ROOT, "build", "idto_hip.remarks")]
+
+# kernel (demangled, without "idto_dev::" and arguments) -> (max spilled VGPRs, max scratch bytes per lane, max spilled SGPRs)
+# Values: what profiles/r05_isa_resources.txt records, the SGPR figure with a margin of 24 (it moves by a few with every
+# edit and is harmless up to there; 41 more than today's was the incident).
+LIMITS = {
+    "fd_kernel<2, 1>": (0, 20, 83 + 24),
+    "fd_kernel<3, 2>": (0, 20, 87 + 24),
+    "fd_kernel<3, 3>": (0, 20, 105 + 24),
+    "fd_kernel<3, 5>": (0, 20, 85 + 24),
+    "fd_kernel<4, 4>": (0, 20, 107 + 24),
+    "penta_pipe_kernel<19>": (0, 36, 102 + 24),
+    "penta_pipe_kernel<2>": (0, 0, 137 + 24),
+    "penta_pipe_kernel<3>": (0, 0, 106 + 24),
+    "penta_pipe_kernel<5>": (0, 0, 126 + 24),
+    "penta_band_kernel<6>": (0, 112, 4 + 24),
+    "penta_band_kernel<9>": (0, 112, 4 + 24),
+    "penta_band_kernel<12>": (0, 112, 18 + 24),
+    "penta_band_kernel<15>": (0, 112, 22 + 24),
+    "penta_nd_kernel<23, false>": (0, 160, 428 + 24),
+    "penta_nd_kernel<29, false>": (6, 272, 650 + 24),
+    "assemble_terms_kernel": (0, 0, 6 + 24),
+    "tr_iter_kernel": (0, 0, 29 + 24),
+    "cost_kernel": (0, 0, 7 + 24),
+}
+
+
+def compile_remarks():
+    """The two translation units with the remark pass on (device code only, no object files kept)."""
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Iinclude", "-Iidto_amd/csrc", "-S",
+             "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage"]
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    jobs = [([hipcc] + flags + ["idto_amd/csrc/fd_launch.hip", "-o", "/dev/null"], REMARKS[0]),
+            ([hipcc] + flags + ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "idto_amd/csrc/idto_hip.hip", "-o", "/dev/null"], REMARKS[1])]
+    procs = [(subprocess.Popen(cmd, cwd=ROOT, stderr=open(out, "w")), out) for cmd, out in jobs]
+    for p, out in procs:
+        if p.wait() != 0:
+            sys.stderr.write(open(out).read()[-4000:])
+            raise SystemExit("check_resources: compiling for the remarks failed")
+
+
+def parse(files):
+    rows = {}
+    for f in files:
+        cur = None
+        for line in open(f, errors="replace"):
+            m = re.search(r"remark: (?:Function Name: (\S+)|\s*(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|SGPRs Spill|VGPRs Spill): (\d+))", line)
+            if not m:
+                continue
+            if m.group(1):
+                cur = m.group(1); rows[cur] = {}
+            elif cur:
+                rows[cur][m.group(2)] = int(m.group(3))
+    names = subprocess.run(["c++filt"], input="\n".join(rows), capture_output=True, text=True).stdout.split("\n")
+    out = {}
+    for mangled, name in zip(rows, names):
+        name = re.sub(r"^void ", "", name)
+        name = re.sub(r"\(.*", "", name).replace("idto_dev::", "")
+        out[name] = rows[mangled]
+    return out
+
+
+def check(files=None):
+    """-> (list of violations, table of what was checked)"""
+    res = parse(files or REMARKS)
+    bad, table = [], []
+    for k, (vs, sc, ss) in LIMITS.items():
+        if k not in res:
+            bad.append(f"{k}: not in the compiler's remarks (instantiation renamed or removed? update tools/check_resources.py)")
+            continue
+        d = res[k]
+        got = (d.get("VGPRs Spill", 0), d.get("ScratchSize [bytes/lane]", 0), d.get("SGPRs Spill", 0))
+        table.append((k, got, (vs, sc, ss)))
+        if got[0] > vs: bad.append(f"{k}: {got[0]} spilled VGPRs (limit {vs})")
+        if got[1] > sc: bad.append(f"{k}: {got[1]} B of scratch per lane (limit {sc})")
+        if got[2] > ss: bad.append(f"{k}: {got[2]} spilled SGPRs (limit {ss})")
+    return bad, table
+
+
+if __name__ == "__main__":
+    args = [a for a in sys.argv[1:] if a != "--compile"]
+    if "--compile" in sys.argv[1:]:
+        compile_remarks()
+    bad, table = check(args or None)
+    for k, got, lim in table:
+        print(f"{k:32s} spilled VGPRs {got[0]:3d} (<= {lim[0]:3d})  scratch {got[1]:4d} B (<= {lim[1]:4d})  spilled SGPRs {got[2]:3d} (<= {lim[2]:3d})")
+    if bad:
+        print("RESOURCE CHECK FAILED:\n  " + "\n  ".join(bad))
+        sys.exit(1)
+    print("resource check passed")
