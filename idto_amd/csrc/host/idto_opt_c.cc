@@ -264,18 +264,13 @@ int idto_mpc_update(idto_mpc* mpc, double time, const double* x0, double* q_gues
                     double* first_cost, int* flag) {
   return Guard([&] {
     const idto_opt* o = mpc->opt;
-    if (q_guess) {   // (what UpdateAbstractState is about to use: the stored trajectory shifted to `time`, row 0 = q0)
-      std::vector<VectorXd> g((size_t)o->N + 1, VectorXd((size_t)o->nq));
-      mpc->mpc->UpdateInitialGuess(mpc->mpc->stored_trajectory(), time, &g);
-      g[0].assign(x0, x0 + o->nq);
-      Flat(g, q_guess);
-    }
     mpc->mpc->UpdateAbstractState(time, VectorXd(x0, x0 + o->nq + o->nv));
+    if (q_guess) Flat(mpc->mpc->last_guess(), q_guess);   // (what it used: the stored trajectory shifted to `time`, row 0 = q0)
     const auto& sol = mpc->mpc->last_solution();
     Flat(sol.q, sol_q); Flat(sol.v, sol_v); Flat(sol.tau, sol_tau);
     const auto& st = mpc->mpc->last_stats();
     if (first_cost) *first_cost = st.iteration_costs.empty() ? 0.0 : st.iteration_costs[0];
-    if (flag) *flag = 0;
+    if (flag) *flag = (int)mpc->mpc->last_flag();   // (kFactorizationFailed = 2: the outputs are the previous re-plan's)
   });
 }
 int idto_mpc_state(const idto_mpc* mpc, double time, double* x) {

@@ -41,42 +41,35 @@ PiecewiseCubic::PiecewiseCubic(const std::vector<double>& breaks, const std::vec
     }
     return;
   }
-  std::vector<double> A((size_t)n * n, 0.0), B((size_t)n * dim_, 0.0);
-  auto a = [&](int r, int c) -> double& { return A[(size_t)r * n + c]; };
+  // The not-a-knot system for the knot derivatives is TRIDIAGONAL as it stands - row 0 = [h1, h0 + h1], rows i =
+  // [h_i, 2 (h_{i-1} + h_i), h_{i-1}], row n - 1 = [h_{n-2} + h_{n-3}, h_{n-3}] - and one elimination without pivoting
+  // is stable on it: after row 0 (multiplier 1) row 1's diagonal is h0 + h1 > h0 and the interior rows are diagonally
+  // dominant.  O(n dim) instead of the dense LU's O(n^3) that ran three times per re-plan.
+  std::vector<double> lo(n, 0.0), di(n, 0.0), up(n, 0.0), B((size_t)n * dim_, 0.0);
   for (int i = 1; i + 1 < n; ++i) {
-    a(i, i - 1) = h[i]; a(i, i) = 2 * (h[i - 1] + h[i]); a(i, i + 1) = h[i - 1];
+    lo[i] = h[i]; di[i] = 2 * (h[i - 1] + h[i]); up[i] = h[i - 1];
     for (int c = 0; c < dim_; ++c) B[(size_t)i * dim_ + c] = 3 * (h[i] * slope(i - 1, c) + h[i - 1] * slope(i, c));
   }
   {
     const double d = h[0] + h[1];
-    a(0, 0) = h[1]; a(0, 1) = d;
+    di[0] = h[1]; up[0] = d;
     for (int c = 0; c < dim_; ++c) B[c] = ((h[0] + 2 * d) * h[1] * slope(0, c) + h[0] * h[0] * slope(1, c)) / d;
     const double e = h[n - 2] + h[n - 3];
-    a(n - 1, n - 1) = h[n - 3]; a(n - 1, n - 2) = e;
+    di[n - 1] = h[n - 3]; lo[n - 1] = e;
     for (int c = 0; c < dim_; ++c)
       B[(size_t)(n - 1) * dim_ + c] = (h[n - 2] * h[n - 2] * slope(n - 3, c) + (2 * e + h[n - 2]) * h[n - 3] * slope(n - 2, c)) / e;
   }
-  for (int p = 0; p < n; ++p) {   // Gaussian elimination with partial pivoting, all right-hand sides at once
-    int piv = p;
-    for (int r = p + 1; r < n; ++r)
-      if (std::fabs(a(r, p)) > std::fabs(a(piv, p))) piv = r;
-    if (a(piv, p) == 0.0) throw std::runtime_error("PiecewiseCubic: singular system");
-    if (piv != p) {
-      for (int c = 0; c < n; ++c) std::swap(a(p, c), a(piv, c));
-      for (int c = 0; c < dim_; ++c) std::swap(B[(size_t)p * dim_ + c], B[(size_t)piv * dim_ + c]);
-    }
-    for (int r = p + 1; r < n; ++r) {
-      const double f = a(r, p) / a(p, p);
-      if (f == 0.0) continue;
-      for (int c = p; c < n; ++c) a(r, c) -= f * a(p, c);
-      for (int c = 0; c < dim_; ++c) B[(size_t)r * dim_ + c] -= f * B[(size_t)p * dim_ + c];
-    }
+  for (int i = 1; i < n; ++i) {
+    if (di[i - 1] == 0.0) throw std::runtime_error("PiecewiseCubic: singular system");
+    const double f = lo[i] / di[i - 1];
+    di[i] -= f * up[i - 1];
+    for (int c = 0; c < dim_; ++c) B[(size_t)i * dim_ + c] -= f * B[(size_t)(i - 1) * dim_ + c];
   }
-  for (int p = n - 1; p >= 0; --p)
+  if (di[n - 1] == 0.0) throw std::runtime_error("PiecewiseCubic: singular system");
+  for (int i = n - 1; i >= 0; --i)
     for (int c = 0; c < dim_; ++c) {
-      double s = B[(size_t)p * dim_ + c];
-      for (int k = p + 1; k < n; ++k) s -= a(p, k) * m_[(size_t)k * dim_ + c];
-      m_[(size_t)p * dim_ + c] = s / a(p, p);
+      const double s = B[(size_t)i * dim_ + c] - (i + 1 < n ? up[i] * m_[(size_t)(i + 1) * dim_ + c] : 0.0);
+      m_[(size_t)i * dim_ + c] = s / di[i];
     }
 }
 
@@ -117,6 +110,7 @@ ModelPredictiveController::ModelPredictiveController(TrajectoryOptimizer<double>
     for (int j = 0; j < nv_; ++j) actuated_dofs_.push_back(j);
   nu_ = (int)actuated_dofs_.size();
   StoreOptimizerSolution(warm_start_solution, 0.0, &stored_);
+  solution_ = warm_start_solution;
 }
 
 // UpdateAbstractState (:43-85)
@@ -126,12 +120,15 @@ const StoredTrajectory& ModelPredictiveController::UpdateAbstractState(double ti
   if ((int)selector.size() != nq_)
     throw std::invalid_argument("q_nom_relative_to_q_init must have one entry per position (mpc_controller.cc:45)");
   if ((int)x0.size() != nq_ + nv_) throw std::invalid_argument("state estimate must be [q0; v0]");
+  idto_hip_trace_mark("mpc: UpdateAbstractState begins");
   const VectorXd q0(x0.begin(), x0.begin() + nq_), v0(x0.begin() + nq_, x0.end());
   // the initial guess from the stored solution, consistent with the initial condition (:55-58)
   std::vector<VectorXd> q_guess((size_t)num_steps_, VectorXd((size_t)nq_));
   UpdateInitialGuess(stored_, time, &q_guess);
   q_guess[0] = q0;
   warm_start_->set_q(q_guess);
+  last_guess_ = q_guess;
+  idto_hip_trace_mark("mpc: initial guess from the stored splines");
   // shift the nominal trajectory for some DoFs, if requested (:60-69)
   const ProblemDefinition& prob = optimizer_->prob();
   const VectorXd q0_nom_old = prob.q_nom[0];
@@ -140,12 +137,21 @@ const StoredTrajectory& ModelPredictiveController::UpdateAbstractState(double ti
     for (int i = 0; i < nq_; ++i) qt_nom[i] += (selector[i] ? 1.0 : 0.0) * (q0[i] - q0_nom_old[i]);
   const std::vector<VectorXd> v_nom = prob.v_nom;
   optimizer_->UpdateNominalTrajectory(q_nom_new, v_nom);
+  idto_hip_trace_mark("mpc: nominal trajectory shifted");
   // solve from the new initial condition (:71-75)
   optimizer_->ResetInitialConditions(q0, v0);
+  idto_hip_trace_mark("mpc: initial conditions reset");
   stats_ = TrajectoryOptimizerStats<double>();
-  solution_ = TrajectoryOptimizerSolution<double>();
-  optimizer_->SolveFromWarmStart(warm_start_.get(), &solution_, &stats_);
+  TrajectoryOptimizerSolution<double> solution;
+  last_flag_ = optimizer_->SolveFromWarmStart(warm_start_.get(), &solution, &stats_);
+  idto_hip_trace_mark("mpc: SolveFromWarmStart returned");
+  // (a failed factorisation returns an empty solution - the previous plan stays in force and the caller is
+  // told through last_flag(); the reference, a Drake LeafSystem, has nowhere to report it and would throw from
+  // StoreOptimizerSolution with the controller's state half updated)
+  if (last_flag_ == optimizer::SolverFlag::kFactorizationFailed || (int)solution.q.size() < num_steps_) return stored_;
+  solution_ = std::move(solution);
   StoreOptimizerSolution(solution_, time, &stored_);
+  idto_hip_trace_mark("mpc: solution stored as splines");
   return stored_;
 }
 

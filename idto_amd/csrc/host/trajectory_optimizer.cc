@@ -1105,6 +1105,11 @@ SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solu
       }
     }
     if (!converged) Delta = Delta_end;
+    // (the resident loop carries the cost on the device and `cost` is still the placeholder.  Every device
+    // flag either throws or yields a converged row, so the stepwise loop below is not reached from here in normal
+    // operation - but if it ever is, after the chunked early exit's truncation say, its trust ratio must not be
+    // formed against 0: fetch the iterate's cost.)
+    if (k < params_.max_iterations && !converged) cost = Fetch(IDTO_ARR_COST)[0];
   }
   while (k < params_.max_iterations && !converged) {
     if (!have) {

@@ -7,6 +7,7 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -39,6 +40,35 @@ using namespace idto_dev;
 
 namespace {
 thread_local std::string g_err;
+
+// ---- host-side timeline (idto_hip_trace_*): wall-clock marks of what the host thread does between the C-ABI's entry
+// points, for tools/host_profile.py --mpc (one MPC re-plan accounted for in steps of 10 us).  Off: one
+// predictable branch per mark.
+struct HostTrace {
+  bool on = false;
+  std::chrono::steady_clock::time_point t0;
+  std::vector<std::pair<std::string, double>> ev;
+};
+static HostTrace g_trace;
+extern "C" void idto_hip_trace_enable(int on) {
+  g_trace.on = on != 0;
+  g_trace.ev.clear();
+  g_trace.ev.reserve(256);
+  g_trace.t0 = std::chrono::steady_clock::now();
+}
+extern "C" void idto_hip_trace_mark(const char* label) {
+  if (!g_trace.on) return;
+  g_trace.ev.emplace_back(label, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - g_trace.t0).count());
+}
+// "<microseconds since enable> <label>\n" per mark; returns the number of bytes the whole text needs
+extern "C" int idto_hip_trace_dump(char* out, int cap) {
+  std::string t;
+  char buf[64];
+  for (const auto& e : g_trace.ev) { std::snprintf(buf, sizeof buf, "%.1f ", e.second); t += buf; t += e.first; t += "\n"; }
+  if (out && cap > 0) std::snprintf(out, (size_t)cap, "%s", t.c_str());
+  return (int)t.size() + 1;
+}
+#define TRACE(label) idto_hip_trace_mark(label)
 
 #define HIP_OK(expr)                                                                              \
   do {                                                                                            \
@@ -201,6 +231,7 @@ struct idto_hip_ctx {
   bool partials_ahead = false;            // idto_hip_eval_tau_partials has left the partials of the resident q: the next idto_hip_eval_partials is done
   int gradients_method = 0;               // 0 forward, 1 central, 2 central 4th order (solver_parameters.h:26-50)
   int fd_stop = 0;                        // same for the finite-difference kernel
+  int nd_min_rows = 16;                   // option "nd_min_rows": systems of at least this many block rows take the five-workgroup / band kernels
   bool fd_fast = true;                    // option "fd_fast": id_fast.h's evaluation when the model has an instantiated shape
   int asm_stop = 0;                       // profiling aid: truncate the assembly kernel after a phase
   bool two_sided = true;                  // solver: two workgroups eliminating from both ends
@@ -243,7 +274,7 @@ struct idto_hip_ctx {
   int* con_dofs = nullptr; int con_nu = 0, con_neq = 0;
   std::vector<int> con_dofs_host;
   bool con_schur_valid = false;            // con_S, con_d, ... are allocated for con_dofs_host
-  std::vector<int> kkt_dofs_host;          // (the banded KKT step's copy of the set: it shares con_dofs with the Schur route)
+  int con_dofs_cap = 0;                    // entries con_dofs has room for
   double *con_S = nullptr, *con_lambda = nullptr, *con_out = nullptr;  // device: [S | J y_g], lambda, [step | J^T lambda]
   double *con_d = nullptr, *con_h = nullptr;                            // dense LDL^T: pivots, [min, max | h]
   double* con_rv = nullptr;                                            // ... and L^-1 (h - J y_g), carried along by the factorisation
@@ -332,9 +363,18 @@ int Alloc(idto_hip_ctx* c, size_t count, T** dev) {
   *dev = static_cast<T*>(p);
   return 0;
 }
+// a buffer of Alloc's that has been superseded: returned to the device now, not at idto_hip_destroy
+template <class T>
+void Release(idto_hip_ctx* c, T** dev) {
+  if (!*dev) return;
+  auto it = std::find(c->allocs.begin(), c->allocs.end(), static_cast<void*>(*dev));
+  if (it != c->allocs.end()) { (void)hipFree(*it); c->allocs.erase(it); }
+  *dev = nullptr;
+}
 
 // (problem `pb` of the batch: destination = problem 0's arrays shifted by pb * pstride)
 int UploadProblemArrays(idto_hip_ctx* c, const idto_problem_t* p, int pb = 0) {
+  TRACE("hip: problem upload begins");
   const int nq = c->nq, nv = c->nv, N = c->N;
   const size_t po = (size_t)pb * c->pstride;
   const double dt = c->dt;
@@ -371,6 +411,7 @@ int UploadProblemArrays(idto_hip_ctx* c, const idto_problem_t* p, int pb = 0) {
     for (int i = 0; i < 10; ++i) put(c->d_w[i], w[i].data(), w[i].size());
     HIP_OK(hipMemcpyAsync(lo + po, c->prob_pin, bytes, hipMemcpyHostToDevice, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));  // (the pinned buffer is reused by the next upload)
+    TRACE("hip: problem upload done (one copy + wait)");
   }
   auto is_diag = [](const double* W, int n) {
     for (int c2 = 0; c2 < n; ++c2)
@@ -1031,6 +1072,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   if (const char* e = getenv("IDTO_SOLVER_REFERENCE")) c->reference_solver = (e[0] == '1');
   if (const char* e = getenv("IDTO_TWO_SIDED")) c->two_sided = (e[0] == '1');   // (debugging aids: option defaults)
   if (const char* e = getenv("IDTO_FUSED")) c->fused = (e[0] == '1');
+  if (const char* e = getenv("IDTO_ND_MIN_ROWS")) c->nd_min_rows = std::max(12, std::atoi(e));
   if (const char* e = getenv("IDTO_SOLVER_ND")) c->solver_nd = (e[0] == '1');
   if (const char* e = getenv("IDTO_SOLVER_PIPE")) c->solver_pipe = (e[0] == '1');
   if (const char* e = getenv("IDTO_ASM_FOLD")) c->asm_fold = (e[0] == '1');
@@ -1102,6 +1144,7 @@ int idto_hip_set_shard(idto_hip_ctx* c, int kb, int ke) {
 }
 
 int idto_hip_set_q(idto_hip_ctx* c, const double* q_host) {
+  TRACE("hip: set_q begins");
   HIP_OK(hipSetDevice(c->device));
   c->trial_resident = false; c->spec_pending = false; c->spec_ready = false;
   DropPrefetch(c, {IDTO_ARR_Q});
@@ -1109,6 +1152,7 @@ int idto_hip_set_q(idto_hip_ctx* c, const double* q_host) {
   c->con_ready = false; c->con_begun = false;
   HIP_OK(hipMemcpyAsync(c->q, q_host, (size_t)(c->N + 1) * c->nq * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIP_OK(hipStreamSynchronize(c->stream));  // the host buffer may be reused by the caller
+  TRACE("hip: set_q done (copy + wait)");
   return 0;
 }
 int idto_hip_set_q_batch(idto_hip_ctx* c, const double* q_host) {
@@ -1159,6 +1203,7 @@ int idto_hip_eval_tau_partials(idto_hip_ctx* c) {
   if (rc) return rc;
   c->fd_full = true;
   c->partials_ahead = true;
+  TRACE("hip: eval_tau_partials: fd_kernel enqueued");
   hipLaunchKernelGGL(cost_kernel, dim3(1, c->batch), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
                      c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, (double*)nullptr, c->pstride, (double*)nullptr,
                      TrDecideArgs{}, AltSel{nullptr, 0, 0});
@@ -1316,7 +1361,11 @@ static bool NdEligible(const idto_hip_ctx* c, const LdlPlan& p) {
   const bool inst = (p.K == 2 || p.K == 3 || p.K == 5 || p.K == 19 || p.K == 23 || p.K == 29 || (p.K == 8 && c->ldl_npos > 0)) && p.K == p.k;
   // (seven workgroups per problem, one per CU: a batch that would not fit the 256 CUs at once is
   // better served by the two-workgroup form - same work per problem on fewer CUs)
-  if (!(c->solver_nd && c->two_sided && inst && p.n >= 24 && 7 * c->batch <= 256)) return false;
+  // (horizons from nd_min_rows block rows on - option "nd_min_rows", 16: the MPC examples plan over 20 steps, and the
+  // one-launch iteration that serves shorter systems takes 99 us for the cheetah there against 21 + ~40 of fd_kernel and
+  // the pipelined solver.  The seven-workgroup kernel keeps 24: its chains of 4 - 5 rows buy nothing below that.)
+  const bool pipe_kernel = c->solver_pipe && p.K <= 20;
+  if (!(c->solver_nd && c->two_sided && inst && p.n >= (pipe_kernel ? c->nd_min_rows : std::max(24, c->nd_min_rows)) && 7 * c->batch <= 256)) return false;
   // the joiner chains' per-row tables hold ND_MAXROWS local rows: longer horizons (n >= 127) take the
   // two-workgroup factorisation
   NdSplit sp = nd_split(p.n, c->solver_pipe && p.K <= 20);
@@ -1357,7 +1406,7 @@ static bool BandEligible(const idto_hip_ctx* c, const LdlPlan& p) {
   // problem is what counts - 64 spinner problems 554k against 567k it/s, 256: 747k / 782k; acrobot 649k / 619k)
   if (c->batch > 1 && c->solver_band < 2 && p.k > 2) return false;
   // (horizons the pipelined kernel would take: shorter ones keep the fused launch / the two-workgroup factorisation)
-  return p.n >= 24 && M >= 4 * W && band_layout(M, W).end * (int)sizeof(double) <= 160 * 1024;
+  return p.n >= c->nd_min_rows && M >= 4 * W && band_layout(M, W).end * (int)sizeof(double) <= 160 * 1024;
 }
 static int LaunchBand(idto_hip_ctx* c, const LdlPlan& p, const double* b, double sign, double* xo) {
   BandArgs A;
@@ -1678,50 +1727,58 @@ int idto_hip_solve_host(idto_hip_ctx* c, const double* rhs_host, int nrhs, doubl
   return FactorStatus(c);
 }
 
-// the constrained degrees of freedom on the device (the banded KKT step needs nothing else; batch contexts included)
-static int ConstraintDofs(idto_hip_ctx* c, const int* dofs, int nu) {
-  if (!dofs || nu < 1 || nu > c->nv) { g_err = "equality constraints: bad arguments"; return -1; }
+// The constrained degrees of freedom on the device: ONE copy, shared by the banded KKT step (which needs nothing else;
+// batch contexts included) and by the Schur-complement route.  (Round 4 kept a list per route and each invalidated the
+// other's: a resident KKT solve followed by the host loop - the TRF_SINGULAR_S fallback, or SolveFromWarmStart followed
+// by EvalLagrangeMultipliers - allocated con_dofs, con_S, con_L, ... again on every alternation, and Alloc never frees:
+// an MPC server on that path leaked ~2 MB per re-plan at allegro's size and paid a device-wide synchronisation each time.)
+static int DeviceDofs(idto_hip_ctx* c, const int* dofs, int nu, const char* who, bool* changed) {
+  if (!dofs || nu < 1 || nu > c->nv) { g_err = std::string(who) + ": bad arguments"; return -1; }
   for (int j = 0; j < nu; ++j)
-    if (dofs[j] < 0 || dofs[j] >= c->nv) { g_err = "equality constraints: dof index out of range"; return -1; }
-  if (c->kkt_dofs_host.size() == (size_t)nu && std::equal(dofs, dofs + nu, c->kkt_dofs_host.begin()) && c->con_dofs) return 0;
-  void* p = nullptr;
-  HIP_OK(hipMalloc(&p, (size_t)nu * sizeof(int)));
-  c->allocs.push_back(p);
-  c->con_dofs = static_cast<int*>(p);
+    if (dofs[j] < 0 || dofs[j] >= c->nv) { g_err = std::string(who) + ": dof index out of range"; return -1; }
+  *changed = !(c->con_dofs && c->con_dofs_host.size() == (size_t)nu && std::equal(dofs, dofs + nu, c->con_dofs_host.begin()));
+  if (!*changed) return 0;
+  if (c->con_dofs_cap < nu) {
+    Release(c, &c->con_dofs);
+    void* p = nullptr;
+    HIP_OK(hipMalloc(&p, (size_t)nu * sizeof(int)));
+    c->allocs.push_back(p);
+    c->con_dofs = static_cast<int*>(p);
+    c->con_dofs_cap = nu;
+  }
+  HIP_OK(hipStreamSynchronize(c->stream));   // (work that reads the previous set may still be enqueued)
   HIP_OK(hipMemcpy(c->con_dofs, dofs, (size_t)nu * sizeof(int), hipMemcpyHostToDevice));
-  c->kkt_dofs_host.assign(dofs, dofs + nu);
   c->con_dofs_host.assign(dofs, dofs + nu);
   c->con_nu = nu; c->con_neq = nu * c->N;
   c->con_schur_valid = false;   // (the Schur route's buffers, if any, were sized for another set)
   c->con_begun = false;
   return 0;
 }
-// the device arrays of the Schur-complement route for this set of degrees of freedom (made again when the set changes)
+static int ConstraintDofs(idto_hip_ctx* c, const int* dofs, int nu) {
+  bool changed = false;
+  return DeviceDofs(c, dofs, nu, "equality constraints", &changed);
+}
+// the device arrays of the Schur-complement route for this set of degrees of freedom (made again - the superseded ones
+// freed - only when the set really changes)
 static int ConstraintBuffers(idto_hip_ctx* c, const int* dofs, int nu) {
-  if (!dofs || nu < 1 || nu > c->nv) { g_err = "constraint_schur: bad arguments"; return -1; }
   if (c->batch != 1) { g_err = "the equality-constraint step serves single-problem contexts"; return -1; }
-  for (int j = 0; j < nu; ++j)
-    if (dofs[j] < 0 || dofs[j] >= c->nv) { g_err = "constraint_schur: dof index out of range"; return -1; }
+  bool changed = false;
+  if (int rc = DeviceDofs(c, dofs, nu, "constraint_schur", &changed)) return rc;
   const int N = c->N, n = (N + 1) * c->nq, neq = nu * N;
-  if (!c->con_schur_valid || c->con_nu != nu || !std::equal(dofs, dofs + nu, c->con_dofs_host.begin())) {
-    c->con_dofs_host.assign(dofs, dofs + nu);
-    c->kkt_dofs_host.clear();
-    c->con_schur_valid = true;
-    void* p = nullptr;
-    HIP_OK(hipMalloc(&p, (size_t)nu * sizeof(int)));
-    c->allocs.push_back(p);
-    c->con_dofs = static_cast<int*>(p);
-    HIP_OK(hipMemcpy(c->con_dofs, dofs, (size_t)nu * sizeof(int), hipMemcpyHostToDevice));
+  if (!c->con_schur_valid) {
+    Release(c, &c->con_S); Release(c, &c->con_d); Release(c, &c->con_h); Release(c, &c->con_L); Release(c, &c->con_rv);
     if (Alloc(c, (size_t)neq * neq + neq, &c->con_S) ||
         Alloc(c, (size_t)neq, &c->con_d) || Alloc(c, (size_t)neq + 2, &c->con_h) || Alloc(c, (size_t)neq * neq, &c->con_L) ||
         Alloc(c, 2 * (size_t)neq, &c->con_rv))   // [r with the finished panels eliminated | y = L^-1 r]
       return -2;
     const size_t need = (size_t)neq * neq + neq + 2 * (size_t)n + 2 * (size_t)neq + 4;
-    if (c->con_pin) (void)hipHostFree(c->con_pin);
-    c->con_pin = nullptr;
-    HIP_OK(hipHostMalloc((void**)&c->con_pin, need * sizeof(double), hipHostMallocDefault));
-    c->con_pin_count = need;
-    c->con_nu = nu; c->con_neq = neq;
+    if (c->con_pin_count < need) {
+      if (c->con_pin) (void)hipHostFree(c->con_pin);
+      c->con_pin = nullptr; c->con_pin_count = 0;
+      HIP_OK(hipHostMalloc((void**)&c->con_pin, need * sizeof(double), hipHostMallocDefault));
+      c->con_pin_count = need;
+    }
+    c->con_schur_valid = true;
     c->con_begun = false;
   }
   return 0;
@@ -2070,6 +2127,7 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
                    double* rows_host, double* Delta_out) {
   HIP_OK(hipSetDevice(c->device));
   const int B = c->batch;
+  TRACE("hip: tr_solve begins");
   if (iterations <= 0) { g_err = "tr_solve: iterations must be positive"; return -1; }
   if (nu < 0 || (nu > 0 && !constrained_dofs)) { g_err = "tr_solve: bad constraint arguments"; return -1; }
   const int neq = nu * c->N;
@@ -2161,6 +2219,7 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
   // leaves the loop).  Rows of iterations that never ran are zeros.
   constexpr int TR_CHUNK = 8;
   if (conv.on) HIP_OK(hipMemsetAsync(c->tr_rows, 0, (size_t)B * rows_stride * sizeof(double), c->stream));
+  TRACE("hip: tr_solve: loop state enqueued, constraint buffers ready");
   for (int k = 0; k < passes; ++k) {
     if (conv.on && B == 1 && k > 0 && k % TR_CHUNK == 0) {
       HIP_OK(hipMemcpyAsync(c->tr_pin, c->tr_state, TRS_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -2284,6 +2343,7 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     if (rc) return rc;
   }
   c->fd_full = false; c->partials_ahead = false;
+  TRACE("hip: tr_solve: every iteration enqueued");
   if (B != 1) {
     // every problem has its own current set: the ones whose iterate ended up in the other set get it copied over
     // (a single-problem context swaps its pointers instead, below)
@@ -2318,6 +2378,7 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     HIP_OK(hipMemcpyAsync(c->tr_pin, c->tr_state, TRS_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipMemcpyAsync(c->rows_pin, c->tr_rows, nrow * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
+    TRACE("hip: tr_solve: waited for the device (state words + rows back)");
     std::memcpy(rows_host, c->rows_pin, nrow * sizeof(double));
   }
   if (Delta_out) *Delta_out = c->tr_pin[TRS_DELTA];
@@ -2381,14 +2442,20 @@ int idto_hip_tr_solve_batch_constrained(idto_hip_ctx* c, int iterations, int sca
   HIP_OK(hipStreamSynchronize(c->stream));
   c->children.resize((size_t)B, nullptr);
   for (int b = 0; b < B; ++b) {
-    if (c->children[b]) continue;
-    idto_hip_ctx* ch = nullptr;
-    const int rc = idto_hip_create(&c->host_model->m, &c->host_problems[b]->p, &c->host_contact, c->device, &ch);
-    if (rc) return rc;
+    idto_hip_ctx* ch = c->children[b];
+    if (!ch) {
+      const int rc = idto_hip_create(&c->host_model->m, &c->host_problems[b]->p, &c->host_contact, c->device, &ch);
+      if (rc) return rc;
+      c->children[b] = ch;
+    }
+    // (at EVERY call, not only when the child is created - options set on the batch context afterwards, the
+    // |h| column's degrees of freedom, a solver stepped down after a time-out must reach the children, or "rows bit for
+    // bit those of idto_hip_tr_solve" breaks silently)
     ch->gradients_method = c->gradients_method; ch->fd_fast = c->fd_fast; ch->asm_fold = c->asm_fold;
     ch->solver_pipe = c->solver_pipe; ch->solver_nd = c->solver_nd; ch->two_sided = c->two_sided; ch->fused = c->fused;
-    ch->reference_solver = c->reference_solver;
-    c->children[b] = ch;
+    ch->reference_solver = c->reference_solver; ch->solver_band = c->solver_band; ch->asm_in_solver = c->asm_in_solver;
+    ch->con_kkt = c->con_kkt;
+    if (int rc = idto_hip_set_unactuated_dofs(ch, c->una_dofs_host.data(), c->una_nu)) return rc;
   }
   const size_t qbytes = (size_t)(c->N + 1) * c->nq * sizeof(double), row = (size_t)iterations * TRR_COUNT;
   std::vector<int> rcs((size_t)B, 0);
@@ -2580,6 +2647,7 @@ int idto_hip_get_option(idto_hip_ctx* c, const char* name, int* value) {
   if (std::strcmp(name, "kkt_last_solver") == 0) { *value = c->kkt ? c->kkt->last_solver : 0; return 0; }
   if (std::strcmp(name, "last_assembly") == 0) { *value = c->last_assembly; return 0; }
   if (std::strcmp(name, "fused") == 0) { *value = c->fused; return 0; }
+  if (std::strcmp(name, "nd_min_rows") == 0) { *value = c->nd_min_rows; return 0; }
   if (std::strcmp(name, "two_sided") == 0) { *value = c->two_sided; return 0; }
   if (std::strcmp(name, "reference_solver") == 0) { *value = c->reference_solver; return 0; }
   if (std::strcmp(name, "gradients_method") == 0) { *value = c->gradients_method; return 0; }
@@ -2594,6 +2662,7 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "solver_debug") == 0) { c->solver_debug = value != 0; return 0; }
   if (std::strcmp(name, "two_sided") == 0) { c->two_sided = value != 0; return 0; }
   if (std::strcmp(name, "fused") == 0) { c->fused = value != 0; return 0; }
+  if (std::strcmp(name, "nd_min_rows") == 0) { c->nd_min_rows = std::max(12, value); if (c->kkt) c->kkt->nd_min_rows = c->nd_min_rows; return 0; }
   if (std::strcmp(name, "solver_nd") == 0) { c->solver_nd = value != 0; return 0; }
   if (std::strcmp(name, "solver_pipe") == 0) { c->solver_pipe = value != 0; return 0; }
   if (std::strcmp(name, "solver_band") == 0) { c->solver_band = value; if (c->kkt) c->kkt->solver_band = value; return 0; }
@@ -2846,7 +2915,9 @@ int idto_hip_get_many(idto_hip_ctx* c, int n, const int* what, double* const* ou
       HIP_OK(hipMemcpyAsync(dst, DevPtr(c, w), (off[i + 1] - off[i]) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
   }
+  TRACE("hip: get_many: copies enqueued");
   HIP_OK(hipStreamSynchronize(c->stream));
+  TRACE("hip: get_many: waited");
   for (int i = 0; i < n; ++i) std::memcpy(out[i], c->many_pin + off[i], (off[i + 1] - off[i]) * sizeof(double));
   return 0;
 }

@@ -73,6 +73,11 @@ class ModelPredictiveController {
   const StoredTrajectory& stored_trajectory() const { return stored_; }
   const TrajectoryOptimizerStats<double>& last_stats() const { return stats_; }
   const TrajectoryOptimizerSolution<double>& last_solution() const { return solution_; }
+  // what the last UpdateAbstractState's SolveFromWarmStart returned; kFactorizationFailed: the stored trajectory and
+  // last_solution() are still the previous re-plan's
+  optimizer::SolverFlag last_flag() const { return last_flag_; }
+  // the initial guess the last UpdateAbstractState used (the stored trajectory shifted to its time, row 0 = q0)
+  const std::vector<VectorXd>& last_guess() const { return last_guess_; }
 
   // UpdateAbstractState (mpc_controller.cc:43-85) at time `time` with the state estimate x0 = [q0; v0]
   const StoredTrajectory& UpdateAbstractState(double time, const VectorXd& x0);
@@ -93,6 +98,8 @@ class ModelPredictiveController {
   StoredTrajectory stored_;
   TrajectoryOptimizerStats<double> stats_;
   TrajectoryOptimizerSolution<double> solution_;
+  optimizer::SolverFlag last_flag_{optimizer::SolverFlag::kSuccess};
+  std::vector<VectorXd> last_guess_;
   double replan_period_;
   std::vector<bool> selector_override_;
 };

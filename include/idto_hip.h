@@ -376,6 +376,15 @@ int idto_hip_slab_stride(idto_hip_ctx* ctx);
 int idto_hip_math_probe(int device, const double* x, int n, double* sqrt_out, double* recip_out,
                         double* sin_out, double* cos_out, double* exp_out, double* log_out);
 
+/* Host-side timeline: wall-clock marks of what the calling thread does inside and between the entry points above
+ * (tools/host_profile.py --mpc: one MPC re-plan, reference examples/mpc_controller.cc:43-85, accounted for step by step).
+ * enable(1) clears the marks and starts the clock; mark(label) appends "<us since enable> label"; dump writes the lines
+ * into out (NUL-terminated, truncated to cap) and returns the bytes the whole text needs.  Not thread-safe: a
+ * measurement aid for one host thread. */
+void idto_hip_trace_enable(int on);
+void idto_hip_trace_mark(const char* label);
+int idto_hip_trace_dump(char* out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -223,3 +223,40 @@ def test_long_horizons(name, N, want):
     err = lambda x: np.abs(x.ravel() - p_ref).max() / pn
     assert err(p_fast) <= 4 * err(p_lu) + 16 * unc + 1e-12, (err(p_fast), err(p_lu), unc)
     dev.close()
+
+
+@pytest.mark.parametrize("name,N", [("mini_cheetah", 20), ("mini_cheetah", 16), ("mini_cheetah", 17), ("hopper", 20), ("spinner", 16)])
+def test_pipelined_solver_takes_mpc_horizons(name, N):
+    """Round 5: systems from 16 block rows on take the five-workgroup kernel (option "nd_min_rows"): the MPC examples
+    plan over 20 steps (reference examples/mini_cheetah/mini_cheetah.yaml: num_steps 20), where the one-launch iteration
+    cost 99 us a re-plan.  Same criteria as test_nested_dissection_solver: reproducible bits, a clean status, forward
+    error within 4x the pivoted LU's against the extended-precision solution, componentwise backward error."""
+    cfg, model, prob, sp, q = _setup(name, N)
+    dev = hip.HipPath(model, prob, sp)
+    dev.set_q(q)
+    dev.gn_step()
+    assert dev.get_option("last_solver") == 4 and dev.get_option("nd_min_rows") == 16
+    p_nd = dev.get("step")
+    for _ in range(3):
+        dev.gn_step()
+        assert np.array_equal(dev.get("step"), p_nd)
+    assert dev.solver_status() == (False, 0)
+    dev.set_option("nd_min_rows", 24)        # what rounds 1 - 4 ran at this size
+    dev.gn_step()
+    assert dev.get_option("last_solver") != 4
+    p_before = dev.get("step")
+    dev.set_option("reference_solver", 1)
+    dev.factor_solve()
+    p_lu = dev.get("step")
+    orc = Oracle(model, prob, sp)
+    g, bands = orc.grad_hess(q)
+    assert np.array_equal(dev.get("gradient"), g)
+    p_ref, unc = ol.refined_solution(ol.penta_make_dense(*bands), -g.ravel())
+    pn = np.abs(p_ref).max()
+    err = lambda x: np.abs(x.ravel() - p_ref).max() / pn
+    ab = [np.abs(b) for b in bands]
+    bwd = lambda x: (np.abs(ol.penta_multiply(*bands, x) + g.ravel()) /
+                     (ol.penta_multiply(*ab, np.abs(x)) + np.abs(g.ravel()) + 1e-300)).max()
+    assert err(p_nd) <= 4 * err(p_lu) + 16 * unc + 1e-12, (err(p_nd), err(p_before), err(p_lu))
+    assert bwd(p_nd) <= 16 * bwd(p_lu) + 2e-13, (bwd(p_nd), bwd(p_lu))
+    dev.close()

@@ -371,3 +371,43 @@ def test_tau_and_partials_from_one_launch_start_the_same_loop(name, N, constrain
         dev.close()
     for a, b in zip(out[1], out[0]):
         assert np.array_equal(a, b)
+
+
+def test_alternating_kkt_and_schur_routes_do_not_allocate_again():
+    """the banded KKT step and the Schur-complement route share ONE device copy of the constrained
+    degrees of freedom; alternating between them (a resident KKT solve followed by the host loop's multipliers - the
+    TRF_SINGULAR_S fallback, or SolveFromWarmStart + EvalLagrangeMultipliers) for the SAME set must not allocate the
+    Schur buffers again (round 4 did, ~0.25 MB per alternation here and 2 MB at allegro's size, never freed), and the
+    results of both routes stay what they were."""
+    import torch
+    from idto_amd import hip
+    cfg, model = load_config("hopper"), load_model("hopper")
+    prob, sp, q0 = make_problem(cfg, model, num_steps=40)
+    dofs = np.asarray(model.unactuated_dofs)
+    dev = hip.HipPath(model, prob, sp)
+
+    def cycle():
+        dev.set_q(np.asarray(q0))
+        dev.eval_tau()
+        rows, _ = dev.tr_solve(3, 2, True, False, 1e-1, 1e5, constrained_dofs=dofs)     # banded KKT step
+        dev.set_q(np.asarray(q0))
+        dev.eval_partials(); dev.grad_hess()
+        S, Jy = dev.constraint_schur(dofs)                                             # the reference's route
+        return rows[:, :10].copy(), S.copy(), Jy.copy()
+
+    first = cycle()
+    cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(40):
+        out = cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert all(np.array_equal(a, b) for a, b in zip(first, out))
+    assert free0 - free1 < (1 << 20), f"device memory shrank by {(free0 - free1) / 1e6:.2f} MB over 40 alternations"
+    # a different set still re-sizes the buffers (and frees the superseded ones)
+    S2, _ = dev.constraint_schur(dofs[:2])
+    assert S2.shape == (2 * 40, 2 * 40)
+    S3, _ = dev.constraint_schur(dofs)
+    assert np.array_equal(S3, first[1])
+    dev.close()
