@@ -13,19 +13,36 @@ namespace mpc {
 //   h_i m_{i-1} + 2 (h_{i-1} + h_i) m_i + h_{i-1} m_{i+1} = 3 (h_i d_{i-1} + h_{i-1} d_i),  d_i = (y_{i+1} - y_i) / h_i
 // closed by the not-a-knot conditions at both ends; one dense LU with partial pivoting (n <= a few hundred knots)
 // serves every component.
-PiecewiseCubic::PiecewiseCubic(const std::vector<double>& breaks, const std::vector<VectorXd>& knots) : t_(breaks) {
+PiecewiseCubic::PiecewiseCubic(const std::vector<double>& breaks, const std::vector<VectorXd>& knots) {
+  Assign(breaks, knots, (int)knots.size());
+}
+// (an object that is assigned again keeps its storage: three splines per MPC re-plan, no allocation in the steady state)
+void PiecewiseCubic::Assign(const std::vector<double>& breaks, const std::vector<VectorXd>& knots, int count) {
   const int n = (int)breaks.size();
-  if (n < 2 || (int)knots.size() != n) throw std::invalid_argument("PiecewiseCubic: at least two knots, one value per break");
+  if (n < 2 || count != n || (int)knots.size() < n) throw std::invalid_argument("PiecewiseCubic: at least two knots, one value per break");
   dim_ = (int)knots[0].size();
-  for (int i = 0; i + 1 < n; ++i)
-    if (!(breaks[i + 1] > breaks[i])) throw std::invalid_argument("PiecewiseCubic: breaks must increase");
-  y_.assign((size_t)n * dim_, 0.0);
-  m_.assign((size_t)n * dim_, 0.0);
+  y_.resize((size_t)n * dim_);
   for (int i = 0; i < n; ++i) {
     if ((int)knots[i].size() != dim_) throw std::invalid_argument("PiecewiseCubic: knots of different sizes");
     for (int c = 0; c < dim_; ++c) y_[(size_t)i * dim_ + c] = knots[i][c];
   }
-  std::vector<double> h(n - 1);
+  Fit(breaks);
+}
+void PiecewiseCubic::AssignFlat(const std::vector<double>& breaks, const double* knots, int dim) {
+  const int n = (int)breaks.size();
+  if (n < 2 || dim < 0) throw std::invalid_argument("PiecewiseCubic: at least two knots, one value per break");
+  dim_ = dim;
+  y_.assign(knots, knots + (size_t)n * dim_);
+  Fit(breaks);
+}
+void PiecewiseCubic::Fit(const std::vector<double>& breaks) {
+  const int n = (int)breaks.size();
+  for (int i = 0; i + 1 < n; ++i)
+    if (!(breaks[i + 1] > breaks[i])) throw std::invalid_argument("PiecewiseCubic: breaks must increase");
+  t_ = breaks;
+  m_.assign((size_t)n * dim_, 0.0);
+  std::vector<double>& h = h_;
+  h.resize(n - 1);
   for (int i = 0; i + 1 < n; ++i) h[i] = breaks[i + 1] - breaks[i];
   auto slope = [&](int i, int c) { return (y_[(size_t)(i + 1) * dim_ + c] - y_[(size_t)i * dim_ + c]) / h[i]; };
   if (n == 2) {   // the line
@@ -45,7 +62,8 @@ PiecewiseCubic::PiecewiseCubic(const std::vector<double>& breaks, const std::vec
   // [h_i, 2 (h_{i-1} + h_i), h_{i-1}], row n - 1 = [h_{n-2} + h_{n-3}, h_{n-3}] - and one elimination without pivoting
   // is stable on it: after row 0 (multiplier 1) row 1's diagonal is h0 + h1 > h0 and the interior rows are diagonally
   // dominant.  O(n dim) instead of the dense LU's O(n^3) that ran three times per re-plan.
-  std::vector<double> lo(n, 0.0), di(n, 0.0), up(n, 0.0), B((size_t)n * dim_, 0.0);
+  std::vector<double>&lo = lo_, &di = di_, &up = up_, &B = B_;
+  lo.assign(n, 0.0); di.assign(n, 0.0); up.assign(n, 0.0); B.assign((size_t)n * dim_, 0.0);
   for (int i = 1; i + 1 < n; ++i) {
     lo[i] = h[i]; di[i] = 2 * (h[i - 1] + h[i]); up[i] = h[i - 1];
     for (int c = 0; c < dim_; ++c) B[(size_t)i * dim_ + c] = 3 * (h[i] * slope(i - 1, c) + h[i - 1] * slope(i, c));
@@ -142,14 +160,14 @@ const StoredTrajectory& ModelPredictiveController::UpdateAbstractState(double ti
   optimizer_->ResetInitialConditions(q0, v0);
   idto_hip_trace_mark("mpc: initial conditions reset");
   stats_ = TrajectoryOptimizerStats<double>();
-  TrajectoryOptimizerSolution<double> solution;
+  TrajectoryOptimizerSolution<double>& solution = scratch_solution_;   // (keeps the rows' storage of the re-plan before last)
   last_flag_ = optimizer_->SolveFromWarmStart(warm_start_.get(), &solution, &stats_);
   idto_hip_trace_mark("mpc: SolveFromWarmStart returned");
   // (a failed factorisation returns an empty solution - the previous plan stays in force and the caller is
   // told through last_flag(); the reference, a Drake LeafSystem, has nowhere to report it and would throw from
   // StoreOptimizerSolution with the controller's state half updated)
   if (last_flag_ == optimizer::SolverFlag::kFactorizationFailed || (int)solution.q.size() < num_steps_) return stored_;
-  solution_ = std::move(solution);
+  std::swap(solution_.q, solution.q); std::swap(solution_.v, solution.v); std::swap(solution_.tau, solution.tau);
   StoreOptimizerSolution(solution_, time, &stored_);
   idto_hip_trace_mark("mpc: solution stored as splines");
   return stored_;
@@ -168,22 +186,19 @@ void ModelPredictiveController::StoreOptimizerSolution(const TrajectoryOptimizer
                                                        StoredTrajectory* stored_trajectory) const {
   if ((int)solution.q.size() < num_steps_ || (int)solution.v.size() < num_steps_ || (int)solution.tau.size() < num_steps_ - 1)
     throw std::invalid_argument("StoreOptimizerSolution: solution shorter than the horizon");
-  std::vector<double> time_steps;
-  std::vector<VectorXd> q_knots, v_knots, u_knots;
+  std::vector<double>& time_steps = times_;
+  time_steps.resize((size_t)num_steps_);
+  for (int i = 0; i < num_steps_; ++i) time_steps[i] = i * time_step_;
+  // control inputs, which are undefined at the last time step (:122-126): u = B^T tau
+  u_flat_.resize((size_t)num_steps_ * nu_);
   for (int i = 0; i < num_steps_; ++i) {
-    time_steps.push_back(i * time_step_);
-    q_knots.push_back(solution.q[i]);
-    v_knots.push_back(solution.v[i]);
-    // control inputs, which are undefined at the last time step (:122-126): u = B^T tau
     const VectorXd& tau = solution.tau[i == num_steps_ - 1 ? i - 1 : i];
-    VectorXd u((size_t)nu_);
-    for (int j = 0; j < nu_; ++j) u[j] = tau[actuated_dofs_[j]];
-    u_knots.push_back(u);
+    for (int j = 0; j < nu_; ++j) u_flat_[(size_t)i * nu_ + j] = tau[actuated_dofs_[j]];
   }
   stored_trajectory->start_time = start_time;
-  stored_trajectory->q = PiecewiseCubic(time_steps, q_knots);
-  stored_trajectory->v = PiecewiseCubic(time_steps, v_knots);
-  stored_trajectory->u = PiecewiseCubic(time_steps, u_knots);
+  stored_trajectory->q.Assign(time_steps, solution.q, num_steps_);
+  stored_trajectory->v.Assign(time_steps, solution.v, num_steps_);
+  stored_trajectory->u.AssignFlat(time_steps, u_flat_.data(), nu_);
 }
 
 // Interpolator::SendState / SendControl (:163-178)

@@ -86,6 +86,12 @@ std::vector<Vec> Unflatten(const Vec& flat, int count, int width) {
     std::copy(flat.begin() + (std::size_t)t * width, flat.begin() + (std::size_t)(t + 1) * width, out[t].begin());
   return out;
 }
+// the same into `out`, whose rows keep their storage when the sizes repeat (the solution object of an MPC re-plan)
+void UnflattenInto(const Vec& flat, int count, int width, std::vector<Vec>* out) {
+  out->resize((std::size_t)count);
+  for (int t = 0; t < count; ++t)
+    (*out)[t].assign(flat.begin() + (std::size_t)t * width, flat.begin() + (std::size_t)(t + 1) * width);
+}
 std::vector<MatrixXd> UnflattenBlocks(const Vec& flat, int count, int rows, int cols) {
   std::vector<MatrixXd> out((std::size_t)count, MatrixXd(rows, cols));
   for (int t = 0; t < count; ++t)
@@ -274,6 +280,9 @@ TO::TrajectoryOptimizer(const idto_model_t& model, double time_step, const Probl
                              params_.friction_coefficient, params_.smoothing_factor};
   Check(idto_hip_create(&model, &p, &c, device, &hip_));
   Check(idto_hip_set_option(hip_, "gradients_method", static_cast<int>(params_.gradients_method)));
+  // (this class talks to the context through its stream-ordered entry points only: q and the problem's arrays go up from
+  // pinned staging without a wait of their own - two of the five waits of an MPC re-plan)
+  if (!std::getenv("IDTO_OPT_BLOCKING_UPLOADS")) Check(idto_hip_set_option(hip_, "async_uploads", 1));
 }
 
 TO::TrajectoryOptimizer(const idto_model_t& model, double time_step, const ProblemDefinition& prob,
@@ -1017,6 +1026,7 @@ SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solu
     Check(idto_hip_set_q(dev(), q0.data()));
   }
   Check(idto_hip_set_unactuated_dofs(dev(), unactuated_dofs_.data(), (int)unactuated_dofs_.size()));
+  idto_hip_trace_mark("opt: q and the unactuated dofs set");
   // (the resident loop starts with the partials of this q: one finite-difference launch for both)
   Check(ResidentLoopEligible() ? idto_hip_eval_tau_partials(dev()) : idto_hip_eval_tau(dev()));
   // (the resident loop keeps the cost on the device and reports it in its rows: no fetch, no synchronisation here)
@@ -1037,6 +1047,8 @@ SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solu
   bool have = false, last_accepted = true;
   double S[9] = {0};
   int k = 0;
+  Vec fq, fv, ft, fdq, fw;   // what idto_hip_tr_solve_fetch brought along
+  bool fetched = false;
   // every iteration enqueued at once, decisions on the device, one wait (idto_hip_tr_solve); the
   // stepwise loop below serves IDTO_OPT_STEPWISE=1 (and the adaptive scalings with dense cost weights)
   const bool resident_loop = ResidentLoopEligible();
@@ -1054,9 +1066,15 @@ SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solu
     std::vector<double> rows((std::size_t)iters * IDTO_TR_ROW);
     double Delta_end = Delta;
     const bool constrained = params_.equality_constraints && num_equality_constraints() > 0;
-    Check(idto_hip_tr_solve(dev(), iters, scal, params_.scaling ? 1 : 0, params_.normalize_quaternions ? 1 : 0, Delta,
-                            params_.Delta_max, eta, constrained ? unactuated_dofs_.data() : nullptr,
-                            constrained ? (int)unactuated_dofs_.size() : 0, rows.data(), &Delta_end));
+    // (the solution comes back under the loop's own wait: idto_hip_tr_solve_fetch)
+    fq.resize((std::size_t)num_vars()); fv.resize((std::size_t)(num_steps() + 1) * nv_); ft.resize((std::size_t)num_steps() * nv_);
+    fdq.resize((std::size_t)num_vars()); fw.resize((std::size_t)num_vars());
+    Check(idto_hip_tr_solve_fetch(dev(), iters, scal, params_.scaling ? 1 : 0, params_.normalize_quaternions ? 1 : 0, Delta,
+                                  params_.Delta_max, eta, constrained ? unactuated_dofs_.data() : nullptr,
+                                  constrained ? (int)unactuated_dofs_.size() : 0, rows.data(), &Delta_end, fq.data(), fv.data(),
+                                  ft.data(), fdq.data(), fw.data()));
+    fetched = true;
+    idto_hip_trace_mark("opt: idto_hip_tr_solve_fetch returned");
     const double total = std::chrono::duration<double>(clock::now() - start_time).count();
     // (with the convergence criteria on the device loop stops within eight iterations of the one that met them: the
     // rows behind it are zeros)
@@ -1112,6 +1130,7 @@ SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solu
     if (k < params_.max_iterations && !converged) cost = Fetch(IDTO_ARR_COST)[0];
   }
   while (k < params_.max_iterations && !converged) {
+    fetched = false;   // (the device moves on: what the resident loop brought along is stale)
     if (!have) {
       Check(idto_hip_gn_step(dev()));
       Check(idto_hip_tr_prepare(dev(), scal, 0, S));   // (reports a failed factorisation)
@@ -1172,25 +1191,36 @@ SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solu
     else if (rho > 0.75 && active) Delta = std::min(2 * Delta, params_.Delta_max);   // :2618-2622
     ++k;
   }
+  idto_hip_trace_mark("opt: statistics rows taken in");
   // the solution: q from the device; v, tau belong to it unless the last trial point was rejected
-  if (!last_accepted) Check(idto_hip_eval_tau(dev()));
-  // (the solution's arrays with one synchronisation: idto_hip_get_many)
+  int two_sets = 0;   // (diagonal cost weights: the trial point was evaluated into the set the iterate does not occupy)
+  if (fetched) Check(idto_hip_get_option(dev(), "weights_diagonal", &two_sets));
+  fetched = fetched && (two_sets != 0 || last_accepted);
+  if (!fetched && !last_accepted) Check(idto_hip_eval_tau(dev()));
+  // (the solution's arrays: with the resident loop's own wait - idto_hip_tr_solve_fetch - or with one synchronisation,
+  // idto_hip_get_many)
   {
-    Vec qf((std::size_t)num_vars()), vf((std::size_t)(num_steps() + 1) * nv_), tf((std::size_t)num_steps() * nv_);
-    Vec dq((std::size_t)num_vars()), dqh((std::size_t)num_vars());
-    const int what[5] = {IDTO_ARR_Q, IDTO_ARR_V, IDTO_ARR_TAU, IDTO_ARR_TR_DQ, IDTO_ARR_TR_W};
-    double* const dst[5] = {qf.data(), vf.data(), tf.data(), dq.data(), dqh.data()};
-    Check(idto_hip_get_many(dev(), k > 0 ? 5 : 3, what, dst));
-    state.set_q(Unflatten(qf, num_steps() + 1, nq_));
-    solution->q = state.q();
-    solution->v = Unflatten(vf, num_steps() + 1, nv_);
-    solution->tau = Unflatten(tf, num_steps(), nv_);
+    Vec qf, vf, tf, dq, dqh;
+    if (fetched) {
+      qf.swap(fq); vf.swap(fv); tf.swap(ft); dq.swap(fdq); dqh.swap(fw);
+    } else {
+      qf.resize((std::size_t)num_vars()); vf.resize((std::size_t)(num_steps() + 1) * nv_); tf.resize((std::size_t)num_steps() * nv_);
+      dq.resize((std::size_t)num_vars()); dqh.resize((std::size_t)num_vars());
+      const int what[5] = {IDTO_ARR_Q, IDTO_ARR_V, IDTO_ARR_TAU, IDTO_ARR_TR_DQ, IDTO_ARR_TR_W};
+      double* const dst[5] = {qf.data(), vf.data(), tf.data(), dq.data(), dqh.data()};
+      Check(idto_hip_get_many(dev(), k > 0 ? 5 : 3, what, dst));
+    }
+    UnflattenInto(qf, num_steps() + 1, nq_, &solution->q);
+    state.set_q(solution->q);
+    UnflattenInto(vf, num_steps() + 1, nv_, &solution->v);
+    UnflattenInto(tf, num_steps(), nv_, &solution->tau);
     if (k > 0) {
       ws->dq = dq;
       ws->dqH = dqh;
       for (double& x : ws->dqH) x = -x;   // dqH = Delta pH = -w (:2152)
     }
   }
+  idto_hip_trace_mark("opt: solution unpacked");
   if (adaptive && k > 0) state.cache_.scale_factors = Fetch(IDTO_ARR_TR_SCALE);   // (kept across set_q: invalidate_cache)
   resident_ = nullptr;   // the device arrays were advanced without the host-side cache
   device_level_ = 0;

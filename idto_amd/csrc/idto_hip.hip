@@ -280,6 +280,12 @@ struct idto_hip_ctx {
   double* con_rv = nullptr;                                            // ... and L^-1 (h - J y_g), carried along by the factorisation
   double* con_L = nullptr;                                             // ... and the factor L (dense_ldl_step_kernel only reads S's panels)
   bool con_S_factored = false;                                         // con_S holds the LDL^T factors, not S
+  double* fetch_dev = nullptr; double* fetch_pin = nullptr; size_t fetch_cap = 0;   // idto_hip_tr_solve_fetch's staging
+  // option "async_uploads": idto_hip_set_q / idto_hip_set_problem copy from pinned staging of the context - two buffers
+  // taken in turn, an event each - and return without waiting (everything else the context does is ordered behind them on
+  // its stream); a caller that reads device memory on ANOTHER stream keeps the default, the blocking copies
+  bool async_uploads = false;
+  char* up_pin[2] = {nullptr, nullptr}; size_t up_cap[2] = {0, 0}; hipEvent_t up_ev[2] = {nullptr, nullptr}; int up_next = 0;
   double* con_pin = nullptr; size_t con_pin_count = 0;                 // pinned host staging for the above
   bool h_assembled = false;                                            // H comes from idto_hip_grad_hess: block row 0 is the identity
   bool con_begun = false;                                              // constraint_schur_begin enqueued for the current H
@@ -372,6 +378,23 @@ void Release(idto_hip_ctx* c, T** dev) {
   *dev = nullptr;
 }
 
+// pinned staging for an upload that must not wait (option "async_uploads"): the buffer that was used the time before
+// last - its copy has long run, the event only makes that certain
+static int UploadStage(idto_hip_ctx* c, size_t bytes, char** buf, int* slot) {
+  const int s = c->up_next;
+  c->up_next ^= 1;
+  if (c->up_ev[s]) HIP_OK(hipEventSynchronize(c->up_ev[s]));
+  else HIP_OK(hipEventCreateWithFlags(&c->up_ev[s], hipEventDisableTiming));
+  if (c->up_cap[s] < bytes) {
+    if (c->up_pin[s]) (void)hipHostFree(c->up_pin[s]);
+    c->up_pin[s] = nullptr; c->up_cap[s] = 0;
+    HIP_OK(hipHostMalloc((void**)&c->up_pin[s], std::max<size_t>(bytes, 4096), hipHostMallocDefault));
+    c->up_cap[s] = std::max<size_t>(bytes, 4096);
+  }
+  *buf = c->up_pin[s]; *slot = s;
+  return 0;
+}
+
 // (problem `pb` of the batch: destination = problem 0's arrays shifted by pb * pstride)
 int UploadProblemArrays(idto_hip_ctx* c, const idto_problem_t* p, int pb = 0) {
   TRACE("hip: problem upload begins");
@@ -395,23 +418,32 @@ int UploadProblemArrays(idto_hip_ctx* c, const idto_problem_t* p, int pb = 0) {
     char* lo = reinterpret_cast<char*>(c->d_vinit);
     char* hi = reinterpret_cast<char*>(c->d_w[9]) + w[9].size() * sizeof(double);
     const size_t bytes = (size_t)(hi - lo);
-    if (c->prob_pin_bytes < bytes) {
+    char* stage = nullptr; int slot = -1;
+    if (c->async_uploads) { if (int rc = UploadStage(c, bytes, &stage, &slot)) return rc; }
+    if (!stage && c->prob_pin_bytes < bytes) {
       if (c->prob_pin) (void)hipHostFree(c->prob_pin);
       c->prob_pin = nullptr; c->prob_pin_bytes = 0;
       HIP_OK(hipHostMalloc((void**)&c->prob_pin, bytes, hipHostMallocDefault));
       c->prob_pin_bytes = bytes;
       std::memset(c->prob_pin, 0, bytes);
     }
+    if (!stage) stage = c->prob_pin;
+    else std::memset(stage, 0, bytes);   // (the alignment gaps between the arrays)
     auto put = [&](const double* dev, const double* src, size_t count) {
-      std::memcpy(c->prob_pin + (reinterpret_cast<const char*>(dev) - lo), src, count * sizeof(double));
+      std::memcpy(stage + (reinterpret_cast<const char*>(dev) - lo), src, count * sizeof(double));
     };
     put(c->d_vinit, p->v_init, nv);
     put(c->d_qnom, p->q_nom, (size_t)(N + 1) * nq);
     put(c->d_vnom, p->v_nom, (size_t)(N + 1) * nv);
     for (int i = 0; i < 10; ++i) put(c->d_w[i], w[i].data(), w[i].size());
-    HIP_OK(hipMemcpyAsync(lo + po, c->prob_pin, bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_OK(hipStreamSynchronize(c->stream));  // (the pinned buffer is reused by the next upload)
-    TRACE("hip: problem upload done (one copy + wait)");
+    HIP_OK(hipMemcpyAsync(lo + po, stage, bytes, hipMemcpyHostToDevice, c->stream));
+    if (slot >= 0) {
+      HIP_OK(hipEventRecord(c->up_ev[slot], c->stream));
+      TRACE("hip: problem upload done (one copy enqueued)");
+    } else {
+      HIP_OK(hipStreamSynchronize(c->stream));  // (the pinned buffer is reused by the next upload)
+      TRACE("hip: problem upload done (one copy + wait)");
+    }
   }
   auto is_diag = [](const double* W, int n) {
     for (int c2 = 0; c2 < n; ++c2)
@@ -1102,6 +1134,11 @@ void idto_hip_destroy(idto_hip_ctx* c) {
   if (c->tr_pin) (void)hipHostFree(c->tr_pin);
   if (c->spec_ev) (void)hipEventDestroy(c->spec_ev);
   if (c->con_pin) (void)hipHostFree(c->con_pin);
+  if (c->fetch_pin) (void)hipHostFree(c->fetch_pin);
+  for (int i = 0; i < 2; ++i) {
+    if (c->up_pin[i]) (void)hipHostFree(c->up_pin[i]);
+    if (c->up_ev[i]) (void)hipEventDestroy(c->up_ev[i]);
+  }
   if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
   for (auto& pf : c->pre) if (pf.ev) (void)hipEventDestroy(pf.ev);
   if (c->pre_pin) (void)hipHostFree(c->pre_pin);
@@ -1150,7 +1187,17 @@ int idto_hip_set_q(idto_hip_ctx* c, const double* q_host) {
   DropPrefetch(c, {IDTO_ARR_Q});
   c->fd_full = false; c->partials_ahead = false;
   c->con_ready = false; c->con_begun = false;
-  HIP_OK(hipMemcpyAsync(c->q, q_host, (size_t)(c->N + 1) * c->nq * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  const size_t qbytes = (size_t)(c->N + 1) * c->nq * sizeof(double);
+  if (c->async_uploads) {
+    char* buf = nullptr; int slot = 0;
+    if (int rc = UploadStage(c, qbytes, &buf, &slot)) return rc;
+    std::memcpy(buf, q_host, qbytes);
+    HIP_OK(hipMemcpyAsync(c->q, buf, qbytes, hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipEventRecord(c->up_ev[slot], c->stream));
+    TRACE("hip: set_q done (copy enqueued)");
+    return 0;
+  }
+  HIP_OK(hipMemcpyAsync(c->q, q_host, qbytes, hipMemcpyHostToDevice, c->stream));
   HIP_OK(hipStreamSynchronize(c->stream));  // the host buffer may be reused by the caller
   TRACE("hip: set_q done (copy + wait)");
   return 0;
@@ -2074,7 +2121,7 @@ static int MakeKkt(idto_hip_ctx* c, int nu) {
   // (seven workgroups for allegro's 29 x 29 blocks: 0.46 -> 0.29 ms per iteration; the small systems stay on two - the
   // nested-dissection order buys them 3 us and costs acrobot's multipliers a digit: 2e-8 against 3e-9)
   k->two_sided = c->two_sided; k->solver_nd = c->solver_nd && (K == 29 || K == 8); k->solver_pipe = false; k->fused = false; k->asm_in_solver = false;
-  k->solver_band = c->solver_band;
+  k->solver_band = c->solver_band; k->nd_min_rows = c->nd_min_rows;
   k->h_assembled = true;      // block row 0 is decoupled (q_0 is no variable, mu_0 a dummy): the chains start at row 1
   k->ldl_npos = c->nq;
   const size_t kk = (size_t)K * K;
@@ -2124,7 +2171,7 @@ static bool AsmInSolver(idto_hip_ctx* c);
 // Delta0s / Delta_out: one radius per problem of the context; rows_host: [batch][iterations][TRR_COUNT]
 static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scaling, int normalize_quaternions,
                    const double* Delta0s, double Delta_max, double eta, const int* constrained_dofs, int nu,
-                   double* rows_host, double* Delta_out) {
+                   double* rows_host, double* Delta_out, double* const* fetch = nullptr) {
   HIP_OK(hipSetDevice(c->device));
   const int B = c->batch;
   TRACE("hip: tr_solve begins");
@@ -2150,27 +2197,26 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
   const int n = (c->N + 1) * c->nq, nblk = c->N + 1;
   // tr_iter_kernel finds its last workgroup by counter == target: both restart with every solve, so that a
   // launch that failed in an earlier solve cannot leave them out of step
-  HIP_OK(hipMemset2DAsync(c->tr_cnt, c->pstride, 0, sizeof(unsigned long long), (size_t)B, c->stream));
   c->tr_target = 0;
   // state of every problem: [Delta, L(q) (resident: the caller evaluated the cost of q), ...]
   if (B == 1) {
-    // (one problem: from the context's pinned words - the host touches them again only after the copies that end this
-    // solve, which the stream orders behind this one: no wait here, the loop is enqueued while the evaluation of the
-    // initial guess still runs)
+    // (one problem: one launch sets the state words, the cost among them, and the counter - no wait here, the loop is
+    // enqueued while the evaluation of the initial guess still runs)
     static_assert(TRS_COUNT <= 16, "tr_pin holds 16 doubles");
-    double* st = c->tr_pin;
-    std::fill(st, st + TRS_COUNT, 0.0);
-    st[TRS_DELTA] = Delta0s[0]; st[TRS_ACCEPTED] = 1.0;
-    HIP_OK(hipMemcpyAsync(c->tr_state, st, TRS_COUNT * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(tr_begin_kernel, dim3(1), dim3(64), 0, c->stream, c->tr_state, (int)TRS_COUNT, (int)TRS_DELTA,
+                       (int)TRS_ACCEPTED, (int)TRS_COST, Delta0s[0], c->cost, c->tr_cnt);
+    HIP_OK(hipGetLastError());
   } else {
+    HIP_OK(hipMemset2DAsync(c->tr_cnt, c->pstride, 0, sizeof(unsigned long long), (size_t)B, c->stream));
     std::vector<double> st((size_t)B * TRS_COUNT, 0.0);
     for (int b = 0; b < B; ++b) { st[(size_t)b * TRS_COUNT + TRS_DELTA] = Delta0s[b]; st[(size_t)b * TRS_COUNT + TRS_ACCEPTED] = 1.0; }
     HIP_OK(hipMemcpy2DAsync(c->tr_state, c->pstride, st.data(), TRS_COUNT * sizeof(double), TRS_COUNT * sizeof(double), (size_t)B,
                             hipMemcpyHostToDevice, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));   // (the host buffer is a temporary)
   }
-  HIP_OK(hipMemcpy2DAsync(c->tr_state + TRS_COST, c->pstride, c->cost, c->pstride, sizeof(double), (size_t)B,
-                          hipMemcpyDeviceToDevice, c->stream));
+  if (B != 1)
+    HIP_OK(hipMemcpy2DAsync(c->tr_state + TRS_COST, c->pstride, c->cost, c->pstride, sizeof(double), (size_t)B,
+                            hipMemcpyDeviceToDevice, c->stream));
   const double eps = 10 * std::numeric_limits<double>::epsilon() / c->P.dt / c->P.dt;   // TO.cc:2024
   const int lds_iter = (int)sizeof(double) * std::max(23 * c->nq + 9 * 16, 9 * nblk + 9 + 32);
   // g, H and the Newton step of the first iterate (with constraints the step comes out of the multiplier chain)
@@ -2367,7 +2413,37 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     }
     return 0;
   }
-  {   // the state words and the statistics rows with ONE wait (the rows through pinned staging of the context)
+  if (fetch) {
+    // ... and the solution with them (idto_hip_tr_solve_fetch): one gathering launch, one copy, the same wait
+    const size_t nrow = (size_t)iterations * TRR_COUNT;
+    const size_t nqa = (size_t)(c->N + 1) * c->nq, nva = (size_t)(c->N + 1) * c->nv, nta = (size_t)c->N * c->nv;
+    const size_t total = TRS_COUNT + nrow + nqa + nva + nta + 2 * nqa;
+    if (c->fetch_cap < total) {
+      Release(c, &c->fetch_dev);
+      if (c->fetch_pin) (void)hipHostFree(c->fetch_pin);
+      c->fetch_pin = nullptr; c->fetch_cap = 0;
+      if (Alloc(c, total, &c->fetch_dev)) return -2;
+      HIP_OK(hipHostMalloc((void**)&c->fetch_pin, total * sizeof(double), hipHostMallocDefault));
+      c->fetch_cap = total;
+    }
+    TrGatherArgs G;
+    G.state = c->tr_state; G.rows = c->tr_rows; G.nstate = TRS_COUNT; G.nrows = (int)nrow;
+    G.q = c->q; G.v = c->v; G.slab = c->slab; G.dq = c->tr_dq; G.w = c->tr_w;
+    G.N = c->N; G.nq = c->nq; G.nv = c->nv; G.slab_stride = (int)c->slab_stride;
+    G.alt_off = lookahead ? (long long)c->alt_off : 0;
+    G.out = c->fetch_dev;
+    hipLaunchKernelGGL(tr_gather_kernel, dim3(16), dim3(256), 0, c->stream, G);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(c->fetch_pin, c->fetch_dev, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TRACE("hip: tr_solve: gather + one copy enqueued");
+    HIP_OK(hipStreamSynchronize(c->stream));
+    TRACE("hip: tr_solve: waited for the device (state words, rows and the solution back)");
+    const double* p = c->fetch_pin;
+    std::memcpy(c->tr_pin, p, TRS_COUNT * sizeof(double)); p += TRS_COUNT;
+    std::memcpy(rows_host, p, nrow * sizeof(double)); p += nrow;
+    const size_t cnt[5] = {nqa, nva, nta, nqa, nqa};
+    for (int i = 0; i < 5; ++i) { if (fetch[i]) std::memcpy(fetch[i], p, cnt[i] * sizeof(double)); p += cnt[i]; }
+  } else {   // the state words and the statistics rows with ONE wait (the rows through pinned staging of the context)
     const size_t nrow = (size_t)iterations * TRR_COUNT;
     if (c->rows_cap < nrow) {
       if (c->rows_pin) (void)hipHostFree(c->rows_pin);
@@ -2404,6 +2480,16 @@ int idto_hip_tr_solve(idto_hip_ctx* c, int iterations, int scaling_method, int s
   if (c->batch != 1) { g_err = "tr_solve serves single-problem contexts (batches: idto_hip_tr_solve_batch)"; return -1; }
   return TrSolve(c, iterations, scaling_method, scaling, normalize_quaternions, &Delta0, Delta_max, eta, constrained_dofs, nu,
                  rows_host, Delta_out);
+}
+
+int idto_hip_tr_solve_fetch(idto_hip_ctx* c, int iterations, int scaling_method, int scaling, int normalize_quaternions,
+                            double Delta0, double Delta_max, double eta, const int* constrained_dofs, int nu,
+                            double* rows_host, double* Delta_out, double* q_out, double* v_out, double* tau_out, double* dq_out,
+                            double* w_out) {
+  if (c->batch != 1) { g_err = "tr_solve_fetch serves single-problem contexts"; return -1; }
+  double* const fetch[5] = {q_out, v_out, tau_out, dq_out, w_out};
+  return TrSolve(c, iterations, scaling_method, scaling, normalize_quaternions, &Delta0, Delta_max, eta, constrained_dofs, nu,
+                 rows_host, Delta_out, fetch);
 }
 
 int idto_hip_tr_solve_batch(idto_hip_ctx* c, int iterations, int scaling_method, int scaling, int normalize_quaternions,
@@ -2648,6 +2734,7 @@ int idto_hip_get_option(idto_hip_ctx* c, const char* name, int* value) {
   if (std::strcmp(name, "last_assembly") == 0) { *value = c->last_assembly; return 0; }
   if (std::strcmp(name, "fused") == 0) { *value = c->fused; return 0; }
   if (std::strcmp(name, "nd_min_rows") == 0) { *value = c->nd_min_rows; return 0; }
+  if (std::strcmp(name, "async_uploads") == 0) { *value = c->async_uploads ? 1 : 0; return 0; }
   if (std::strcmp(name, "two_sided") == 0) { *value = c->two_sided; return 0; }
   if (std::strcmp(name, "reference_solver") == 0) { *value = c->reference_solver; return 0; }
   if (std::strcmp(name, "gradients_method") == 0) { *value = c->gradients_method; return 0; }
@@ -2662,6 +2749,7 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "solver_debug") == 0) { c->solver_debug = value != 0; return 0; }
   if (std::strcmp(name, "two_sided") == 0) { c->two_sided = value != 0; return 0; }
   if (std::strcmp(name, "fused") == 0) { c->fused = value != 0; return 0; }
+  if (std::strcmp(name, "async_uploads") == 0) { c->async_uploads = value != 0; return 0; }
   if (std::strcmp(name, "nd_min_rows") == 0) { c->nd_min_rows = std::max(12, value); if (c->kkt) c->kkt->nd_min_rows = c->nd_min_rows; return 0; }
   if (std::strcmp(name, "solver_nd") == 0) { c->solver_nd = value != 0; return 0; }
   if (std::strcmp(name, "solver_pipe") == 0) { c->solver_pipe = value != 0; return 0; }

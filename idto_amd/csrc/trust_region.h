@@ -542,6 +542,51 @@ __device__ inline bool tr_decide(const TrDecideArgs& T, double cost_trial, doubl
   return accept;
 }
 
+// The start of idto_hip_tr_solve for one problem: the loop's state words [Delta0, the cost of the resident q, accepted = 1,
+// zeros] and the iteration kernel's arrival counter in ONE launch, Delta0 as a kernel argument (round 4: a fill, a copy
+// from pinned words and a 2-D copy of the cost - three serialised device operations of ~4.5 us each at the head of
+// every MPC re-plan).
+__global__ void tr_begin_kernel(double* state, int nstate, int i_delta, int i_accepted, int i_cost, double Delta0,
+                                const double* cost, unsigned long long* cnt) {
+  const int i = threadIdx.x;
+  if (i < nstate) state[i] = i == i_delta ? Delta0 : i == i_accepted ? 1.0 : i == i_cost ? *cost : 0.0;
+  if (i == 0) *cnt = 0ull;
+}
+
+// The end of idto_hip_tr_solve for a caller that wants the solution at once (idto_hip_tr_solve_fetch): the loop's state
+// words, its statistics rows and the iterate's q, v, tau (rows of the slab), the last step dq and w = H^-1 (g + J^T lambda)
+// go into ONE contiguous staging buffer - v and tau from the set the iterate ended up in - so that a single copy and the
+// solve's own wait bring everything to the host (round 4: seven copies, ~4 us each on the device, and a second wait: 65 us
+// of an MPC re-plan).  Layout: [state TRS_COUNT | rows nrows | q | v | tau | dq | w].
+struct TrGatherArgs {
+  const double* state; const double* rows; int nstate, nrows;
+  const double* q; const double* v; const double* slab; const double* dq; const double* w;
+  int N, nq, nv, slab_stride;
+  long long alt_off;   // bytes between the two output sets (0: one set)
+  double* out;
+};
+__global__ void tr_gather_kernel(TrGatherArgs A) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+  const long long off = (A.alt_off != 0 && A.state[IDTO_TRS_CUR] != 0.0) ? A.alt_off : 0;
+  const double* v = at_problem(A.v, (size_t)off);
+  const double* slab = at_problem(A.slab, (size_t)off);
+  const int nqa = (A.N + 1) * A.nq, nva = (A.N + 1) * A.nv, nta = A.N * A.nv;
+  double* o = A.out;
+  for (int i = tid; i < A.nstate; i += nt) o[i] = A.state[i];
+  o += A.nstate;
+  for (int i = tid; i < A.nrows; i += nt) o[i] = A.rows[i];
+  o += A.nrows;
+  for (int i = tid; i < nqa; i += nt) o[i] = A.q[i];
+  o += nqa;
+  for (int i = tid; i < nva; i += nt) o[i] = v[i];
+  o += nva;
+  for (int i = tid; i < nta; i += nt) { const int t = i / A.nv, r = i - t * A.nv; o[i] = slab[(size_t)t * A.slab_stride + 3 * A.nv * A.nq + r]; }
+  o += nta;
+  for (int i = tid; i < nqa; i += nt) o[i] = A.dq[i];
+  o += nqa;
+  for (int i = tid; i < nqa; i += nt) o[i] = A.w[i];
+}
+
 // batch contexts after idto_hip_tr_solve_batch: a problem whose iterate's v, a, N+, slab and products ended up in the
 // second set of fd_kernel outputs (batch.h AltSel) gets them copied into the first (grid (x, problem))
 __global__ void tr_fold_sets_kernel(double* set_a, size_t count, const double* state, size_t pstride) {

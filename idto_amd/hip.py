@@ -118,7 +118,7 @@ EXPORTED_SYMBOLS = [
     "idto_hip_device_ptr", "idto_hip_array_size", "idto_hip_slab_stride", "idto_hip_math_probe",
     "idto_hip_solver_status", "idto_hip_create_batch", "idto_hip_batch_size", "idto_hip_set_problem_batch",
     "idto_hip_set_q_batch", "idto_hip_gn_step_batch", "idto_hip_get_batch", "idto_hip_get_many", "idto_hip_solver_status_batch",
-    "idto_hip_tr_prepare", "idto_hip_tr_trial", "idto_hip_tr_accept", "idto_hip_tr_reject", "idto_hip_tr_set_scale_memory", "idto_hip_tr_set_convergence", "idto_hip_tr_solve", "idto_hip_tr_solve_batch", "idto_hip_tr_solve_batch_constrained", "idto_hip_set_unactuated_dofs",
+    "idto_hip_tr_prepare", "idto_hip_tr_trial", "idto_hip_tr_accept", "idto_hip_tr_reject", "idto_hip_tr_set_scale_memory", "idto_hip_tr_set_convergence", "idto_hip_tr_solve", "idto_hip_tr_solve_fetch", "idto_hip_tr_solve_batch", "idto_hip_tr_solve_batch_constrained", "idto_hip_set_unactuated_dofs",
     "idto_hip_rccl_info", "idto_hip_comm_unique_id", "idto_hip_comm_init", "idto_hip_comm_init_all", "idto_hip_comm_destroy",
     "idto_hip_allgather_slab", "idto_hip_gn_step_sharded", "idto_hip_gn_step_multi", "idto_hip_eval_partials_multi",
     "idto_hip_trace_enable", "idto_hip_trace_mark", "idto_hip_trace_dump",

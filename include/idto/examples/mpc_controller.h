@@ -36,6 +36,10 @@ class PiecewiseCubic {
  public:
   PiecewiseCubic() = default;
   PiecewiseCubic(const std::vector<double>& breaks, const std::vector<VectorXd>& knots);
+  // the same through the first `count` rows of `knots` / through row-major values [break][dim], into an existing object
+  // (its storage is kept: no allocation when the sizes repeat)
+  void Assign(const std::vector<double>& breaks, const std::vector<VectorXd>& knots, int count);
+  void AssignFlat(const std::vector<double>& breaks, const double* knots, int dim);
   bool empty() const { return t_.empty(); }
   double start_time() const { return t_.front(); }
   double end_time() const { return t_.back(); }
@@ -47,6 +51,8 @@ class PiecewiseCubic {
   int dim_ = 0;
   std::vector<double> t_;
   std::vector<double> y_, m_;   // [knot][dim]: values and first derivatives at the knots
+  std::vector<double> h_, lo_, di_, up_, B_;   // work space of Fit
+  void Fit(const std::vector<double>& breaks);
 };
 
 // reference examples/mpc_controller.h:43-55
@@ -97,7 +103,8 @@ class ModelPredictiveController {
   std::unique_ptr<WarmStart> warm_start_;
   StoredTrajectory stored_;
   TrajectoryOptimizerStats<double> stats_;
-  TrajectoryOptimizerSolution<double> solution_;
+  TrajectoryOptimizerSolution<double> solution_, scratch_solution_;
+  mutable std::vector<double> times_, u_flat_;   // work space of StoreOptimizerSolution
   optimizer::SolverFlag last_flag_{optimizer::SolverFlag::kSuccess};
   std::vector<VectorXd> last_guess_;
   double replan_period_;

@@ -288,6 +288,19 @@ int idto_hip_tr_solve(idto_hip_ctx* ctx, int iterations, int scaling_method, int
                       double Delta0, double Delta_max, double eta, const int* constrained_dofs, int nu,
                       double* rows_host, double* Delta_out);
 
+/* idto_hip_tr_solve that also returns what the caller fetches next anyway - the iterate q ((N+1) nq), its v ((N+1) nv) and
+ * tau (N nv), the last step dq and w = H^-1 (g + J^T lambda) ((N+1) nq each; any pointer may be NULL) - gathered on the
+ * device into one buffer and copied under the solve's own wait (the solution fetch of
+ * TrajectoryOptimizer::SolveFromWarmStart, optimizer/trajectory_optimizer.cc:2627-2640, without a second round trip).
+ * v and tau are the iterate's when the cost weights are diagonal (two output sets) or the last trial point was
+ * accepted (rows[last][9] != 0); with dense weights after a rejected last step they are the trial point's: evaluate
+ * tau again then, as after idto_hip_tr_solve. */
+int idto_hip_tr_solve_fetch(idto_hip_ctx* ctx, int iterations, int scaling_method, int scaling, int normalize_quaternions,
+                            double Delta0, double Delta_max, double eta, const int* constrained_dofs, int nu,
+                            double* rows_host, double* Delta_out, double* q_out, double* v_out, double* tau_out,
+                            double* dq_out, double* w_out);
+
+
 /* The same loop for every problem of a batch context at once (idto_hip_create_batch): one launch set per iteration
  * with grid.y = problem, one host thread, one wait - the call pattern of an MPC server that advances several
  * warm-started problems per tick (reference examples/mpc_controller.cc:43-85, BASELINE config 5).  Every problem keeps
