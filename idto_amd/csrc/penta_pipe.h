@@ -384,7 +384,11 @@ __device__ __forceinline__ double pipe_band(const PipeArgs& A, const double* p) 
 // critical path.  `spk` (compile time): this wavefront carries the 2K spike columns, else [S | H | E | y].
 template <int K>
 struct PipeRows {
+#ifdef PIPE_RLO   // (measurement aid: the share of the wavefront that eliminates next, K = 19 only)
+  static constexpr int RLO = K == 19 ? PIPE_RLO : (K >= 3 ? (((K + 1) / 2 + 1) & ~1) : K);
+#else
   static constexpr int RLO = K >= 3 ? (((K + 1) / 2 + 1) & ~1) : K;   // even: the high rows' multipliers start 16-byte aligned
+#endif
   static constexpr int NHI = K - RLO;
   static constexpr int JH = RLO >= 6 ? 4 : (RLO >= 2 ? RLO - 2 : 0);   // pivot at which the eliminating wavefront takes the high rows in
   static constexpr int XS = NHI + (NHI & 1);                          // stride of a column in the hand-over buffer

@@ -10,7 +10,7 @@ while [ $# -ge 2 ]; do
   name=$1; extra=$2; shift 2
   mkdir -p build/variants/$name
   ( $HIPCC $FLAGS $extra -c idto_amd/csrc/fd_launch.hip -o build/variants/$name/fd_launch.o &&
-    $HIPCC --offload-arch=gfx950 -fPIC -shared build/variants/$name/fd_launch.o build/idto_hip.o -o build/variants/$name/libidto_hip.so -L/opt/rocm/lib -lrccl &&
+    $HIPCC --offload-arch=gfx950 -fPIC -shared build/variants/$name/fd_launch.o build/idto_hip.o -o build/variants/$name/libidto_hip.so -ldl &&
     echo built $name ) &
 done
 wait

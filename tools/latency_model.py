@@ -22,7 +22,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLOCK_MHZ = 2400.0
-PIVOT_LINK_CYCLES = 80   # profiles/r03_microbench.txt: "pivot link of penta_pipe.h: fma, readlane, reciprocal (cubic)"
+PIVOT_LINK_CYCLES = 80   # fallback; the round's own <round>_microbench.txt ("pivot link of penta_pipe.h ...": tools/micro/chain_bench.hip) is read when it is there
 
 
 def pmc(path, kernel):
@@ -88,9 +88,15 @@ def main():
     chains, sep = timeline(P("nd_timeline.txt"))
     sol_us = kernel_avg_us(P("kernel_stats_assembly_in_its_own_launch.csv"), "penta_pipe_kernel")
     K = 19
+    link, link_src = PIVOT_LINK_CYCLES, "profiles/r03_microbench.txt"
+    if os.path.exists(P("microbench.txt")):   # (VERDICT r4 hygiene: the chain link from this round's microbench, not round 3's)
+        for line in open(P("microbench.txt")):
+            m = re.search(r"pivot link of penta_pipe\.h.*?\s([\d.]+) cycles", line)
+            if m:
+                link, link_src = float(m.group(1)), f"profiles/{rnd}_microbench.txt"
     longest = max(chains, key=lambda ch: ch["forward_done"])
     rows = len(longest["rows"])
-    chain_floor = (rows + 2) * K * PIVOT_LINK_CYCLES / CLOCK_MHZ
+    chain_floor = (rows + 2) * K * link / CLOCK_MHZ
     first_row = longest["rows"][0][0]
     row_model = first_row + rows * longest["row_to_row_us"] + (sep["q_ready"] - longest["forward_done"]) + (sep["solved"] - sep["q_ready"]) + \
         (max(ch["end"] for ch in chains) - sep["solved"])
@@ -105,7 +111,8 @@ def main():
         "achieved_frac_of_pivot_chain_floor": chain_floor / sol_us if sol_us else None,
     }
     out["sources"]["penta_pipe_kernel"] = [f"profiles/{rnd}_nd_timeline.txt", f"profiles/{rnd}_kernel_stats_assembly_in_its_own_launch.csv",
-                                           "profiles/r03_microbench.txt"]
+                                           link_src]
+    out["penta_pipe_kernel"]["pivot_link_cycles"] = link
     json.dump(out, open(P("latency_model.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
