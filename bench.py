@@ -194,6 +194,40 @@ def full_iteration(cfg, model, N, device, with_cpu, iters=20):
     return out
 
 
+def mpc_replan(cfg, model, device, replans=50):
+    """Secondary number ("the MPC-relevant latency"): wall clock of one re-plan of the example's MPC loop
+    (reference examples/mpc_controller.cc:43-85 UpdateAbstractState: shift the stored solution, SolveFromWarmStart with the
+    YAML's mpc_iters, store the splines) through the C++ shell of include/idto/examples/mpc_controller.h - the example's own
+    horizon (its YAML's num_steps), not the bench workload's.  tools/mpc_timeline.py accounts for it mark by mark."""
+    from idto_amd.mpc import DeviceModelPredictiveController
+    from idto_amd.optimizer import TrajectoryOptimizer, TrajectoryOptimizerSolution, TrajectoryOptimizerStats
+    from idto_amd.problem import SolverParameters
+    prob, sp, q_guess = make_problem(cfg, model)
+    sp.verbose = False
+    sp.max_iterations = min(int(sp.max_iterations), 30)
+    opt = TrajectoryOptimizer(model, prob, sp, device=device)
+    sol, st = TrajectoryOptimizerSolution(), TrajectoryOptimizerStats()
+    opt.Solve(q_guess, sol, st)
+    iters = int(cfg.get("mpc_iters", 1))
+    period = 1.0 / float(cfg.get("controller_frequency", 200.0))
+    opt1 = TrajectoryOptimizer(model, prob, SolverParameters(**{**sp.__dict__, "max_iterations": iters}), device=device)
+    mpc = DeviceModelPredictiveController(opt1, sol, actuated=model.actuated, replan_period=period)
+    x = np.concatenate([np.asarray(sol.q[0]), np.asarray(sol.v[0])])
+    times = []
+    for i in range(replans + 10):
+        t = i * period
+        if i:
+            x = mpc.state(t)
+        t0 = time.perf_counter()
+        mpc.update(t, x[:model.nq], x[model.nq:])
+        times.append(time.perf_counter() - t0)
+    ts = np.sort(np.array(times[10:])) * 1e3
+    mpc.close(); opt1.close(); opt.close()
+    return {"ms_per_replan_median": float(np.median(ts)), "p10": float(ts[len(ts) // 10]), "p90": float(ts[9 * len(ts) // 10]),
+            "num_steps": int(prob.num_steps), "mpc_iters": iters, "controller_period_ms": 1e3 * period, "replans": replans,
+            "what": "idto_mpc_update (C++ ModelPredictiveController on the device), the example YAML's horizon and mpc_iters"}
+
+
 SHARD_NOTE = ("sharding ONE N=40 problem cannot beat one GPU: its 40 finite-difference workgroups already run side by side "
               "on 40 of the 256 CUs, the all-gather adds a hand-over, and the block solve (a dependent chain) does not "
               "shard - DESIGN.md §7; the aggregate of independent problems is reported as replicas_mode / config5_workload")
@@ -657,6 +691,10 @@ def main():
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         if world == 1 and not args.no_full:
             out["full_iteration"] = full_iteration(cfg, model, N, local_rank, not args.no_cpu)
+            try:
+                out["mpc_replan"] = mpc_replan(cfg, model, local_rank)
+            except Exception as e:   # (informational: never costs the bench line)
+                out["mpc_replan"] = {"error": str(e)[:200]}
         print(json.dumps(out))
     dev.close()
     if dist is not None:
