@@ -46,6 +46,7 @@ for kkt in 1 0; do for c in "acrobot 40" "spinner 40" "hopper 40" "allegro_hand 
 timeout 600 python tools/fd_sweep.py 12 2>&1 | grep -v amdgpu.ids | tail -3 | tee gpurun_out/${R}_fd_sweep.txt
 { for c in "acrobot 40 1200" "spinner 40 1200" "acrobot 200 600"; do timeout 300 python tools/stress_solver.py $c 2>&1 | grep -v amdgpu.ids; done; } | tee gpurun_out/${R}_band_stress.txt
 timeout 200 python tools/mpc_latency.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${R}_mpc_latency.txt
+timeout 120 python tools/nd_timeline.py allegro_hand 60 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${R}_nd_timeline_allegro.txt
 timeout 300 python tools/mpc_timeline.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${R}_mpc_timeline.txt
 timeout 300 python tools/band_phases.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${R}_band_phases.txt
 ROUND=$R timeout 900 bash tools/prof_band.sh > /dev/null 2>&1
