@@ -254,6 +254,8 @@ struct idto_hip_ctx {
   int debug_skip_role = -1;               // test aid: a role of the nested-dissection kernels that returns at once
   int debug_pipe_tail = 0;                // measurement aid: pipelined solver with the row-by-row back substitution
   double* nd_buf = nullptr;
+  double* nd_wst = nullptr;   // the seven-workgroup kernel's W rows (penta_pipe.h chain_recursion_tail), blocks of 21 .. 32 only
+  int nd_recursion = 1;       // option "nd_recursion": its back substitution in recursion form where the matrices fit the LDS
   unsigned long long nd_launches = 0;
   int last_solver = 0;                     // 0 none yet, 1 two-workgroup LDL^T, 2 nested dissection, 3 reference LU
   bool fused_debug = false;               // ... with per-workgroup time stamps in IDTO_ARR_DEBUG
@@ -960,6 +962,8 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   const size_t o_xch = carve(2 * c->xch_count, D);   // (two producer / joiner pairs in the nested-dissection kernel)
   const size_t o_ndcnt = carve(4 * ND_MAXROWS, sizeof(unsigned long long)), o_ndbuf = carve((size_t)nd_layout(32).end, D);
   const size_t o_pipecnt = carve(4 * ND_MAXROWS, sizeof(unsigned long long));
+  const bool nd_wst_on = nq > 20 && nq <= 32;
+  const size_t o_ndwst = carve(nd_wst_on ? 2 * (size_t)ND_MAXROWS * nd_layout(nq).frow : 1, D);
   const size_t o_asmready = carve(4 * (size_t)(N + 1), sizeof(unsigned));
   c->flag_count = 16;
   const size_t o_flags = carve(c->flag_count, sizeof(unsigned)), o_sync = carve(2, sizeof(unsigned long long));
@@ -1001,6 +1005,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   c->pipe_rowcnt = reinterpret_cast<unsigned long long*>(c->arena + o_pipecnt);
   c->asm_ready = reinterpret_cast<unsigned*>(c->arena + o_asmready);
   c->nd_buf = dp(o_ndbuf);
+  c->nd_wst = nd_wst_on ? dp(o_ndwst) : nullptr;
   c->tr_D = dp(o_trD); c->tr_gt = dp(o_trg); c->tr_w = dp(o_trw); c->tr_dq = dp(o_trdq); c->q_trial = dp(o_qt);
   c->tr_out = dp(o_trout); c->tr_Dprev = dp(o_trDp); c->tr_part = dp(o_trpart);
   c->terms = dp(o_terms);
@@ -1389,12 +1394,18 @@ struct NdSplit { int s, j1, j2; };
 // Pipelined chains (penta_pipe.h): a joiner's block row costs ~1.35x a producer's (its spike wavefronts share the
 // SIMDs) and its two join rows come after the producer's hand-over, so the producers take ~57% of the rows that are
 // not join rows: both sides then reach the join together (measured at K = 19: 2.56 / 3.45 us per row).
-static NdSplit nd_split(int n, bool pipe) {
+static NdSplit nd_split(int n, bool pipe, int K) {
   NdSplit sp;
   sp.s = (n - 2) / 2;
   const int htop = sp.s, hbot = n - sp.s - 2;
   auto producer_rows = [&](int half) {
-    if (!pipe) return (half - 2) / 2;
+    if (!pipe) {
+      // (seven workgroups: even halves - but a joiner's row costs 4.5 us against a producer's 4.2 at K = 23 (it
+      // publishes every row for its spike workgroup) and its two join rows 6 us each: one row more for the producers
+      // and both sides reach the join together, allegro N = 60: 67.7 / 66.6 us instead of 63.6 / 70.3)
+      static const int extra = [] { const char* e = std::getenv("IDTO_ND_PRODUCER_EXTRA"); return e ? std::atoi(e) : -1; }();   // (measurement aid)
+      return std::max(1, std::min((half - 2) / 2 + (extra >= 0 ? extra : (K > 20 ? 1 : 0)), half - 3));
+    }
     static const double share = [] { const char* e = std::getenv("IDTO_PIPE_SPLIT"); return e ? std::atof(e) : 0.52; }();   // (measurement aid)
     int np = (int)(share * (half - 2) + 0.6);
     return std::max(1, std::min(np, half - 3));
@@ -1415,7 +1426,7 @@ static bool NdEligible(const idto_hip_ctx* c, const LdlPlan& p) {
   if (!(c->solver_nd && c->two_sided && inst && p.n >= (pipe_kernel ? c->nd_min_rows : std::max(24, c->nd_min_rows)) && 7 * c->batch <= 256)) return false;
   // the joiner chains' per-row tables hold ND_MAXROWS local rows: longer horizons (n >= 127) take the
   // two-workgroup factorisation
-  NdSplit sp = nd_split(p.n, c->solver_pipe && p.K <= 20);
+  NdSplit sp = nd_split(p.n, c->solver_pipe && p.K <= 20, p.K);
   const int nloc_max = std::max(std::max(sp.s - sp.j1, sp.j2 - sp.s), std::max(sp.j1, p.n - sp.j2 - 2));
   return nloc_max <= ND_MAXROWS && NdLds(c, p, nloc_max) <= 160 * 1024;
 }
@@ -1487,12 +1498,13 @@ static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double s
   A.debug_skip_role = c->debug_skip_role;
   A.debug_pipe_tail = c->debug_pipe_tail;
   A.asm_ready = nullptr; A.asm_first = 0; A.wt_rows = 0;
+  A.rec_tail = 0; A.lds_doubles = 0; A.wst = nullptr;
   A.spin = SpinCtl{nullptr, 0};   // (set by the kernel: behind the per-problem status words)
   A.n = p.n; A.k = p.k;
   A.HA = c->HA + p.qq0; A.HB = c->HB + p.qq0; A.HC = c->HC + p.qq0;
   A.b = b + (size_t)p.r0 * p.k; A.rhs_sign = sign; A.x = xo + (size_t)p.r0 * p.k;
   A.Ust = c->Ust; A.Hst = c->Hst; A.Est = c->Est; A.Dst = c->Dst;
-  { const NdSplit sp = nd_split(p.n, c->solver_pipe && p.K <= 20); A.s = sp.s; A.j1 = sp.j1; A.j2 = sp.j2; }
+  { const NdSplit sp = nd_split(p.n, c->solver_pipe && p.K <= 20, p.K); A.s = sp.s; A.j1 = sp.j1; A.j2 = sp.j2; }
   const int nloc_max = std::max(std::max(A.s - A.j1, A.j2 - A.s), std::max(A.j1, A.n - A.j2 - 2));
   if (nloc_max > ND_MAXROWS) { g_err = "horizon too long for the nested-dissection solver's row tables"; return -1; }
   const int lds = NdLds(c, p, nloc_max);
@@ -1548,8 +1560,18 @@ static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double s
   if (++c->fact_id == 0) c->fact_id = 1;
   A.epoch = c->epoch; A.status = c->status_dev; A.fact_id = c->fact_id; A.pstride = c->pstride;
   A.ts = c->solver_debug ? c->dbg : nullptr;
+  // back substitution in recursion form (penta_pipe.h chain_recursion_tail) where every row's [Y | Z | c] fits the
+  // 160 KB: allegro's 23 x 23 blocks up to N = 60, its 29 x 29 KKT blocks up to N = 40
+  int nd_lds = lds;
+  if (c->nd_recursion && c->nd_wst && p.K == p.k && (p.K == 23 || p.K == 29)) {
+    const int nj = std::max(A.s - A.j1, A.j2 - A.s), np = std::max(A.j1, A.n - A.j2 - 2), all = 160 * 1024 / (int)sizeof(double);
+    if (p.K == 23 ? pipe_recursion_tail_fits<23>(all, nj, np) : pipe_recursion_tail_fits<29>(all, nj, np)) {
+      A.rec_tail = 1; A.lds_doubles = all; A.wst = c->nd_wst;
+      nd_lds = 160 * 1024;
+    }
+  }
   const dim3 grid(7, c->batch);
-#define ND_LAUNCH(KM, PD) hipLaunchKernelGGL((penta_nd_kernel<KM, PD>), grid, dim3(256), lds, c->stream, A)
+#define ND_LAUNCH(KM, PD) hipLaunchKernelGGL((penta_nd_kernel<KM, PD>), grid, dim3(256), nd_lds, c->stream, A)
   switch (p.K) {
     case 2: ND_LAUNCH(2, false); break;
     case 3: ND_LAUNCH(3, false); break;
@@ -2121,7 +2143,7 @@ static int MakeKkt(idto_hip_ctx* c, int nu) {
   // (seven workgroups for allegro's 29 x 29 blocks: 0.46 -> 0.29 ms per iteration; the small systems stay on two - the
   // nested-dissection order buys them 3 us and costs acrobot's multipliers a digit: 2e-8 against 3e-9)
   k->two_sided = c->two_sided; k->solver_nd = c->solver_nd && (K == 29 || K == 8); k->solver_pipe = false; k->fused = false; k->asm_in_solver = false;
-  k->solver_band = c->solver_band; k->nd_min_rows = c->nd_min_rows;
+  k->solver_band = c->solver_band; k->nd_min_rows = c->nd_min_rows; k->nd_recursion = c->nd_recursion;
   k->h_assembled = true;      // block row 0 is decoupled (q_0 is no variable, mu_0 a dummy): the chains start at row 1
   k->ldl_npos = c->nq;
   const size_t kk = (size_t)K * K;
@@ -2143,6 +2165,8 @@ static int MakeKkt(idto_hip_ctx* c, int nu) {
   const size_t o_xch = carve(2 * kc->xch_count, D), o_flags = carve(kc->flag_count, sizeof(unsigned));
   const size_t o_ndcnt = carve(4 * ND_MAXROWS, sizeof(unsigned long long)), o_pipecnt = carve(4 * ND_MAXROWS, sizeof(unsigned long long));
   const size_t o_ndbuf = carve((size_t)nd_layout(32).end, D);
+  const bool nd_wst_on = K > 20 && K <= 32;
+  const size_t o_ndwst = carve(nd_wst_on ? 2 * (size_t)ND_MAXROWS * nd_layout(K).frow : 1, D);
   kc->pstride = (top + 255) & ~(size_t)255;
   {
     void* p = nullptr;
@@ -2159,6 +2183,7 @@ static int MakeKkt(idto_hip_ctx* c, int nu) {
   kc->nd_rowcnt = reinterpret_cast<unsigned long long*>(kc->arena + o_ndcnt);
   kc->pipe_rowcnt = reinterpret_cast<unsigned long long*>(kc->arena + o_pipecnt);
   kc->nd_buf = dp(o_ndbuf);
+  kc->nd_wst = nd_wst_on ? dp(o_ndwst) : nullptr;
   if (hipHostMalloc((void**)&kc->status_pin, (2 * (size_t)B + 2) * sizeof(unsigned), hipHostMallocDefault) != hipSuccess ||
       hipHostGetDevicePointer((void**)&kc->status_dev, kc->status_pin, 0) != hipSuccess)
     return fail("hipHostMalloc (KKT solver status) failed");
@@ -2734,6 +2759,7 @@ int idto_hip_get_option(idto_hip_ctx* c, const char* name, int* value) {
   if (std::strcmp(name, "last_assembly") == 0) { *value = c->last_assembly; return 0; }
   if (std::strcmp(name, "fused") == 0) { *value = c->fused; return 0; }
   if (std::strcmp(name, "nd_min_rows") == 0) { *value = c->nd_min_rows; return 0; }
+  if (std::strcmp(name, "nd_recursion") == 0) { *value = c->nd_recursion; return 0; }
   if (std::strcmp(name, "async_uploads") == 0) { *value = c->async_uploads ? 1 : 0; return 0; }
   if (std::strcmp(name, "two_sided") == 0) { *value = c->two_sided; return 0; }
   if (std::strcmp(name, "reference_solver") == 0) { *value = c->reference_solver; return 0; }
@@ -2751,6 +2777,7 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "fused") == 0) { c->fused = value != 0; return 0; }
   if (std::strcmp(name, "async_uploads") == 0) { c->async_uploads = value != 0; return 0; }
   if (std::strcmp(name, "nd_min_rows") == 0) { c->nd_min_rows = std::max(12, value); if (c->kkt) c->kkt->nd_min_rows = c->nd_min_rows; return 0; }
+  if (std::strcmp(name, "nd_recursion") == 0) { c->nd_recursion = value != 0; if (c->kkt) c->kkt->nd_recursion = c->nd_recursion; return 0; }
   if (std::strcmp(name, "solver_nd") == 0) { c->solver_nd = value != 0; return 0; }
   if (std::strcmp(name, "solver_pipe") == 0) { c->solver_pipe = value != 0; return 0; }
   if (std::strcmp(name, "solver_band") == 0) { c->solver_band = value; if (c->kkt) c->kkt->solver_band = value; return 0; }

@@ -240,6 +240,17 @@ struct ChainCfg {
   int lds_rows;                     // penta_ldl_layout's `rows` (0: every row of the system)
   int npos;                         // > 0: the pivots [npos, k) of every block row belong to multiplier rows of a KKT system
                                     // (kkt.h): negative, and judged by kkt_extract_kernel; 0: a positive definite matrix
+  // the seven-workgroup kernel's back substitution in recursion form (penta_pipe.h chain_recursion_tail): the launch has
+  // lds_doubles doubles of LDS, a joiner keeps W_il = U_il^-1 Dn Ft_il in wst (rows laid out like fst), the pair's join
+  // rows of x change hands through xjoin_ll
+  int rec_tail, lds_doubles;
+  double* wst;
+  double* xjoin_ll;
+  // ... and the pair's PRODUCER forms the joiner's W rows (it is idle for longer): the joiner's rows (local row il is
+  // matrix row wp_base -/+ il), its spike workgroup's rows and counters, its wst; wflag = epoch once they are all there
+  int wp_nloc, wp_base, wp_mirror;
+  const double* wp_fst; const unsigned long long* wp_frowcnt; double* wp_wst;
+  unsigned* wflag;
 };
 // pivot test of a lane that holds a pivot's 1 / d (`inv`; NaN for d = 0 / inf / NaN) and the diagonal entry the pivot
 // started from: positive, finite, and not cancelled to nothing (d <= eps diag0).  Other lanes pass inv = diag0 = 1.
@@ -252,6 +263,11 @@ __device__ __forceinline__ bool ldl_pivot_bad(double inv, double diag0, int lane
 __device__ __forceinline__ void chain_ts(const ChainCfg& cfg, int slot) {
   if (cfg.ts && threadIdx.x == 0) cfg.ts[slot] = (double)wall_clock64();
 }
+
+// (defined in penta_pipe.h, next to the pipelined kernel's pipe_backward it runs)
+template <int K>
+__device__ void chain_recursion_tail(int n, int k, double* x, double* Ust, double* Hst, double* Est, double* Dst,
+                                     const ChainCfg& cfg, unsigned epoch, int xall_off);
 
 // ---- what follows the forward elimination of a chain (shared by penta_ldl_body and the pipelined forward pass of
 // penta_pipe.h): the nested-dissection correction of rt by the separator's solution, then the back substitution.
@@ -534,7 +550,8 @@ penta_ldl_tail(int n, int k, int nrhs, double* __restrict__ x, const double* __r
 // K = compile-time block size >= k; the k x k blocks are embedded in K x K ones padded with
 // the identity (padding rows/columns never mix with the real ones).
 // b, x: [nrhs][n*k]; Ust/Hst/Est: [n][K*K] factors (internal layout), Dst: [n][K].
-template <int K, int NT, bool PADDED, int GJW>
+// RECT: the chain may be asked (cfg.rec_tail) for its back substitution in recursion form (the seven-workgroup kernel, K > 20)
+template <int K, int NT, bool PADDED, int GJW, bool RECT = false>
 __device__ __forceinline__ void
 penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __restrict__ HB,
                const double* __restrict__ HC, const double* __restrict__ b, double rhs_sign, int nrhs,
@@ -1006,6 +1023,7 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
           if (lane == 0)
             __hip_atomic_fetch_add(cfg.rowcnt + (i - 1), cfg.rowcnt_unit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (cfg.ts && lane == 0 && i - 1 < 20) cfg.ts[24 + (i - 1)] = (double)wall_clock64();   // (the last wavefront's stamp stays: the row is out)
         }
       }
     }
@@ -1043,6 +1061,9 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
   }
   stamp(nfwd, 0);
   chain_ts(cfg, 2);
+  if constexpr (RECT && NT == 256) {
+    if (cfg.rec_tail) { chain_recursion_tail<K>(n, k, x, Ust, Hst, Est, Dst, cfg, epoch, L.xall); return; }
+  }
   penta_ldl_tail<K, NT>(n, k, nrhs, x, Ust, Hst, Est, Dst, dbg, cfg, xch, flags, epoch, L.xall, L.bl_size, L.W, nfwd);
 }
 

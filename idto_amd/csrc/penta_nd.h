@@ -57,6 +57,10 @@ struct NdArgs {
   int debug_pipe_tail;           // measurement aid: penta_pipe_kernel takes the row-by-row back substitution
   int npos;                      // > 0: a KKT system (kkt.h) - the pivots [npos, k) of every block row are not tested (ldl_pivot_bad)
   int lds_rows;                  // the chains' carve-up holds this many local rows (penta_ldl_layout `rows`; 0: all n)
+  // back substitution in recursion form (penta_pipe.h chain_recursion_tail; K > 20): the launch has lds_doubles of LDS
+  // and wst holds [2][ND_MAXROWS] rows of nd_layout(K).frow doubles for the joiners' W_il
+  int rec_tail, lds_doubles;
+  double* wst;
 };
 __device__ __forceinline__ void nd_ts(const NdArgs& A, int role, int slot) {
   if (A.ts && threadIdx.x == 0) A.ts[role * 64 + slot] = (double)wall_clock64();
@@ -216,26 +220,23 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
   };
   wait_row(0);
   issue(0);
+  // readiness of the next row: a round trip to L2 (~1 us, longer than the products of phase 1), asked a row ahead and
+  // consumed after the products.  (What it says is a row old: a workgroup that has caught up with its joiner finds
+  // the row in wait_row below instead.)
+  unsigned long long next_cnt = (1 < nloc) ? __hip_atomic_load(rowcnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
   for (int il = 0; il < nloc; ++il) {
     nd_ts(A, 4 + w, 8 + 2 * il);
     commit(il);
     __syncthreads();
-    // readiness of the next row: a round trip to L2, issued now, consumed after the products
-    const unsigned long long next_cnt =
+    if (il == 8) nd_ts(A, 4 + w, 44);
+    // (second chance for a row the look-ahead missed: asked now, looked at after the products only in that case)
+    const unsigned long long fresh_cnt =
         (il + 1 < nloc) ? __hip_atomic_load(rowcnt + il + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     // ---- phase 1: F_il = Finit - GE - (D^-1 Ht_{il-1})^T Ft_{il-1}: TT x CT tiles
     {
       const double* F1 = Fr + ((il + 1) & 1) * FB;
       double* Fo = Fr + (il & 1) * FB;
-      for (int t = wave; t < TT * CT; t += nt / 64) {
-        const int tr = t / CT, tc = t - tr * CT;
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int sq = 0; sq < SK; ++sq) {
-          const int kr = 4 * sq + fk;   // summation index: row of Ht and of Ft
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Hl[kr * ks + 16 * tr + fl], F1[(16 * tc + fl) * ks + kr], acc, 0, 0, 0);
-        }
-        // (F1 is overwritten below only in its own slot's next use; Fo is the other ring slot)
+      auto put = [&](int tr, int tc, const d4& acc) __attribute__((always_inline)) {
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const int r = 16 * tr + fk + 4 * rg, c = 16 * tc + fl;
@@ -246,15 +247,51 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
             Fo[c * ks + r] = (init - GE[c * ks + r]) - acc[rg];
           }
         }
+      };
+      if (TT == 2 && CT <= 4) {
+        // blocks of 17 .. 32: a column tile per wavefront, its two row tiles in two accumulators (the six products of
+        // a tile are a dependent chain of matrix-core instructions; 6 tiles dealt out over 4 wavefronts were two such
+        // chains one after the other on two of them)
+        if (wave < CT) {
+          const int tc = wave;
+          d4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int sq = 0; sq < SK; ++sq) {
+            const int kr = 4 * sq + fk;
+            const double f = F1[(16 * tc + fl) * ks + kr];
+            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Hl[kr * ks + fl], f, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Hl[kr * ks + 16 + fl], f, a1, 0, 0, 0);
+          }
+          put(0, tc, a0);
+          put(1, tc, a1);
+        }
+      } else {
+        for (int t = wave; t < TT * CT; t += nt / 64) {
+          const int tr = t / CT, tc = t - tr * CT;
+          d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int sq = 0; sq < SK; ++sq) {
+            const int kr = 4 * sq + fk;   // summation index: row of Ht and of Ft
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Hl[kr * ks + 16 * tr + fl], F1[(16 * tc + fl) * ks + kr], acc, 0, 0, 0);
+          }
+          // (F1 is overwritten below only in its own slot's next use; Fo is the other ring slot)
+          put(tr, tc, acc);
+        }
       }
     }
     bool prefetched = false;
-    if (il + 1 < nloc && next_cnt >= A.rowtarget) {
-      (void)__hip_atomic_load(rowcnt + il + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    if (il == 8) nd_ts(A, 4 + w, 49);
+    bool next_ready = next_cnt >= A.rowtarget;
+    if (!next_ready) next_ready = fresh_cnt >= A.rowtarget;
+    if (il + 1 < nloc && next_ready) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       issue(il + 1);
       prefetched = true;
     }
+    next_cnt = (il + 2 < nloc) ? __hip_atomic_load(rowcnt + il + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    if (il == 8) nd_ts(A, 4 + w, 45);
     __syncthreads();
+    if (il == 8) nd_ts(A, 4 + w, 46);
     // ---- phase 2
     if (wave == 0) {
       // Ft_il = L_il^-1 F_il (L^T = D^-1 U, unit): lane = column, rows in registers, multipliers are LDS broadcasts
@@ -263,12 +300,23 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
         double xr[K];
 #pragma unroll
         for (int r = 0; r < K; ++r) xr[r] = col[r];
-#pragma unroll
-        for (int j = 0; j < K; ++j) {   // multipliers: row j of D^-1 U, two per LDS read (ks is even)
+        // multipliers: row j of D^-1 U, two per LDS read (ks is even), the next row's read while this one is applied
+        // (left alone the compiler reads all K (K - 1) / 2 of them first: scratch)
+        constexpr int NP = (K + 1) / 2;
+        double2 ub[2][NP];
+        auto loadu = [&](int j, double2 (&u)[NP]) __attribute__((always_inline)) {
           const double2* u2 = reinterpret_cast<const double2*>(Ul + j * ks);
 #pragma unroll
-          for (int r2 = (j + 1) / 2; r2 < (K + 1) / 2; ++r2) {
-            const double2 m = u2[r2];
+          for (int r2 = (j + 1) / 2; r2 < NP; ++r2) u[r2] = u2[r2];
+        };
+        loadu(0, ub[0]);
+#pragma unroll
+        for (int j = 0; j < K - 1; ++j) {
+          if (j + 1 < K - 1) loadu(j + 1, ub[(j + 1) & 1]);
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int r2 = (j + 1) / 2; r2 < NP; ++r2) {
+            const double2 m = ub[j & 1][r2];
             if (2 * r2 > j) xr[2 * r2] = __builtin_fma(-m.x, xr[j], xr[2 * r2]);
             if (2 * r2 + 1 < K) xr[2 * r2 + 1] = __builtin_fma(-m.y, xr[j], xr[2 * r2 + 1]);
           }
@@ -277,6 +325,11 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
         for (int r = 0; r < K; ++r) col[r] = xr[r];
       }
     } else if (il >= 1) {
+      // (the stores first, the products while they travel, then the release: the fence waits for the stores' acknowledgements)
+      // [Ft_{il-1} | rt_{il-1}] to HBM, released by each of the three wavefronts for its own stores (the separator
+      // and the pair's producer wait for all three).  (Up to round 4 the release was one read-modify-write a row
+      // later, after a workgroup barrier: the separator saw a row two rows - 7 us at K = 23 - after it was computed.)
+      publish(il - 1, 64, 192);
       // GE for row il+1: (D^-1 Et_{il-1})^T Ft_{il-1} (El holds Est of row il-1), tiles over wavefronts 1..3
       const double* F1 = Fr + ((il + 1) & 1) * FB;
       for (int t = wave - 1; t < TT * CT; t += 3) {
@@ -293,22 +346,21 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
           if (r < K && c < NF) GE[c * ks + r] = acc[rg];
         }
       }
-      // [Ft_{il-1} | rt_{il-1}] to HBM.  Its release is ONE read-modify-write after a workgroup
-      // barrier (per-wavefront fences + relaxed increments were observed to let the separator read
-      // a row too early), and it is issued a row late, here, where wavefront 3 has slack: row il-2
-      // was stored before the barrier that ended the previous iteration.
-      if (il >= 2 && tid == 192) __hip_atomic_fetch_add(frow + (il - 2), 3ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      publish(il - 1, 64, 192);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (lane == 0) __hip_atomic_fetch_add(frow + (il - 1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (il == 8 && tid == 64 && A.ts) A.ts[(4 + w) * 64 + 47] = (double)wall_clock64();
     }
+    if (il == 8 && tid == 0 && A.ts) A.ts[(4 + w) * 64 + 48] = (double)wall_clock64();
     __syncthreads();
     nd_ts(A, 4 + w, 9 + 2 * il);
     if (il + 1 < nloc && !prefetched) { wait_row(il + 1); issue(il + 1); }
   }
-  // (row nloc-2 was stored before the barrier that ended the loop: released while the last row is stored)
-  if (nloc >= 2 && tid == 192) __hip_atomic_fetch_add(frow + (nloc - 2), 3ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  publish(nloc - 1, 0, 256);
+  if (wave >= 1) {
+    publish(nloc - 1, 64, 192);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) __hip_atomic_fetch_add(frow + (nloc - 1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   __syncthreads();
-  if (tid == 0) __hip_atomic_fetch_add(frow + (nloc - 1), 3ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   nd_ts(A, 4 + w, 1);
 }
 
@@ -584,6 +636,7 @@ __global__ void __launch_bounds__(256) penta_nd_kernel(NdArgs A) {
     A.x = at_problem(A.x, o); A.Ust = at_problem(A.Ust, o); A.Hst = at_problem(A.Hst, o); A.Est = at_problem(A.Est, o);
     A.Dst = at_problem(A.Dst, o); A.xch = at_problem(A.xch, o); A.flags = at_problem(A.flags, o);
     A.rowcnt = at_problem(A.rowcnt, o); A.ndbuf = at_problem(A.ndbuf, o);
+    if (A.wst) A.wst = at_problem(A.wst, o);
     A.spin = SpinCtl{A.status + 2 * gridDim.y, A.fact_id};
     A.status += 2 * blockIdx.y;
   }
@@ -613,9 +666,21 @@ __global__ void __launch_bounds__(256) penta_nd_kernel(NdArgs A) {
     c.fst = A.ndbuf + B.fst + (size_t)w * ND_MAXROWS * B.frow; c.fstride = B.frow;
     c.frowcnt = A.rowcnt + (2 + w) * ND_MAXROWS; c.frowtarget = (A.rowtarget / A.rowunit) * 3ull;
     c.xsep = A.ndbuf + B.xsep; c.sepflag = A.flags + 4;
+    c.xsep_ll = A.ndbuf + B.ll;
+    c.wst = A.wst ? A.wst + (size_t)w * ND_MAXROWS * B.frow : nullptr;
+  }
+  c.rec_tail = A.rec_tail && A.wst; c.lds_doubles = A.lds_doubles;
+  c.xjoin_ll = A.ndbuf + B.ll + (1 + pair) * 4 * K;
+  c.wflag = A.flags + 2 * pair + 1;   // (the row-by-row form's x_join flag, unused in recursion form)
+  if (c.rec_tail && role < 2) {       // the joiner of this producer's pair
+    c.wp_mirror = (pair == 0); c.wp_base = (pair == 0) ? A.s - 1 : A.s + 2;
+    c.wp_nloc = (pair == 0) ? A.s - A.j1 : A.j2 - A.s;
+    c.wp_fst = A.ndbuf + B.fst + (size_t)pair * ND_MAXROWS * B.frow; c.fstride = B.frow;
+    c.wp_frowcnt = A.rowcnt + (2 + pair) * ND_MAXROWS; c.frowtarget = (A.rowtarget / A.rowunit) * 3ull;
+    c.wp_wst = A.wst + (size_t)pair * ND_MAXROWS * B.frow;
   }
   constexpr int GW = ((2 * K + 1) + (64 - K) - 1) / (64 - K);
-  penta_ldl_body<K, 256, PADDED, GW>(A.n, A.k, A.HA, A.HB, A.HC, A.b, A.rhs_sign, 1, A.x, A.Ust, A.Hst, A.Est, A.Dst,
+  penta_ldl_body<K, 256, PADDED, GW, (K > 20)>(A.n, A.k, A.HA, A.HB, A.HC, A.b, A.rhs_sign, 1, A.x, A.Ust, A.Hst, A.Est, A.Dst,
                                      nullptr, c, A.xch + (size_t)pair * A.xch_pair, A.flags + 2 * pair, A.epoch, A.status,
                                      A.fact_id);
 }

@@ -300,6 +300,7 @@ struct PipeArgs {
   unsigned* status; unsigned fact_id;
   // nested dissection (spike chains): [Ft | rt] rows for the separator and their release counters
   double* fst; int fstride; unsigned long long* frowcnt;
+  double* wst;        // chain_recursion_tail (the seven-workgroup kernel): W_il = U_il^-1 Dn Ft_il of a joiner's rows, laid out like fst
   double* xjoin_ll;   // the pair's two join rows of x, joiner -> producer, epoch in every word (penta_nd.h ll_store)
   double* join_ll;    // the producer's contributions to the join rows, [2][(3K + 1) ks] values in the same form
   // g and the bands assembled by other workgroups of this launch (PipeAsm): [rows][4] words that hold the epoch once
@@ -1015,7 +1016,10 @@ __device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& 
 // LDS (everything the forward pass used is free): per local row [Y | Z] row-major (stride 2 KE), W likewise, c.
 template <int K, bool SPK>
 struct PipeBack {
-  static constexpr int KE = K + (K & 1), YS = 2 * KE > ldl_ks(K) ? 2 * KE : ldl_ks(K);   // (a row-major block also stages D^-1 U, stride ks)
+  // (a row-major block also stages D^-1 U, stride ks.  Row stride: an odd number of 16-byte units, or the rows that the
+  // lanes of the recursion read - one row per lane, ds_read_b128 - start in 2 (K = 23: 96 dwords) or 4 (K = 19: 80) of the
+  // 16 bank groups)
+  static constexpr int KE = K + (K & 1), YS0 = 2 * KE > ldl_ks(K) ? 2 * KE : ldl_ks(K), YS = YS0 + ((YS0 / 2) & 1 ? 0 : 2);
   static constexpr int oYZ = 0, oW = K * YS, oC = oW + (SPK ? K * YS : 0), BS = oC + KE;
 };
 
@@ -1030,10 +1034,14 @@ __device__ __forceinline__ double pipe_half_sum(double v) {
 template <int K, bool SPK>
 __device__ __forceinline__ bool pipe_backward_fits(const PipeLds& L, int nloc) { return nloc * PipeBack<K, SPK>::BS + 4 * PipeBack<K, SPK>::KE + 2 <= L.xall; }
 
-template <int K, bool SPK>
+// WGLOB (the seven-workgroup kernel's chains, 4 wavefronts, K = 23 / 29: 16 rows of [Y | Z | c] are 141 KB): W_il goes
+// to global memory (A.wst) instead of the LDS - it is read once, a row per thread, and those loads are issued before the
+// wait for the separator, where the row-by-row tail fetched Ft_il.  The spike rows come from another workgroup there
+// (cfg.frowcnt counts them in).
+template <int K, bool SPK, bool WGLOB = false>
 __device__ __forceinline__ void pipe_backward(const PipeArgs& A, const ChainCfg& cfg, const PipeLds& L) {
   extern __shared__ double lds[];
-  using B = PipeBack<K, SPK>;
+  using B = PipeBack<K, SPK && !WGLOB>;
   constexpr int ks = ldl_ks(K), KE = B::KE, YS = B::YS, KS2 = K * ks;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
   const bool mirror = cfg.mirror != 0, producer = cfg.producer != 0;
@@ -1072,51 +1080,122 @@ __device__ __forceinline__ void pipe_backward(const PipeArgs& A, const ChainCfg&
   // (one list of tasks, [Y | Z | c] of every row, then W of every row, dealt out over the wavefronts: a loop over the
   // rows per pass left six of eight wavefronts idle in every pass's last round - 4 rounds of ~2.4 us for a joiner's
   // 2 x 10 tasks instead of 3)
-  for (int task = wave; task < (SPK ? 2 : 1) * nloc; task += nwaves) {
-    const int pass = task >= nloc ? 1 : 0;
-    {
-      const int il = task - pass * nloc;
-      const int o = orig(il);
-      double* slot = lds + il * B::BS;
-      double* Us = slot + (pass ? B::oW : B::oYZ);   // D^-1 U staged where this task's results go (row-major, stride ks): another wavefront may be on the row's other task
-      constexpr int NU = (KS2 + 63) / 64;
-      double uv[NU];   // (all global loads of the task are issued before anything waits for one)
+  // (WGLOB: pass 1 is a row of the PARTNER joiner's - this workgroup is the pair's producer, idle for 40 us after its
+  // own forward pass, the joiner for 25 and with three more rows: W_il = U_il^-1 Dn Ft_il from the joiner's factors and
+  // the spike workgroup's row, both released through the spike row's counter, into the joiner's wst)
+  auto do_pass = [&](const int il, const int pass, const bool stage) __attribute__((always_inline)) {
+    const bool partner = WGLOB && pass == 1;
+    if (partner) {
+      spin_wait([&] { return __hip_atomic_load(cfg.wp_frowcnt + il, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= cfg.frowtarget; }, cfg.spin);
+      (void)__hip_atomic_load(cfg.wp_frowcnt + il, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int op = cfg.wp_mirror ? cfg.wp_base - il : cfg.wp_base + il;
+    const int o = partner ? (op < 0 ? 0 : op) : orig(il);
+    double* slot = lds + il * B::BS;
+    // D^-1 U staged where this task's results go (row-major, stride ks): another wavefront may be on the row's other task
+    // (a partner's row: in the wavefront's scratch behind the separator's solution)
+    double* Us = partner ? lds + L.W + 2 * KE + 2 + wave * KS2 : slot + ((pass && !WGLOB) ? B::oW : B::oYZ);
+    constexpr int NU = (KS2 + 63) / 64;
+    double uv[NU];   // (all global loads of the task are issued before anything waits for one)
+    if (stage) {
 #pragma unroll
       for (int t = 0; t < NU; ++t) uv[t] = A.Ust[(size_t)o * KS2 + (lane + 64 * t < KS2 ? lane + 64 * t : 0)];
-      const double dinv = (lane < K) ? A.Dst[(size_t)o * K + lane] : 0.0;   // lane r: 1 / d_r
-      double xr[K];
-      double* dst = dump;
-      int dstride = 0;
-      if (pass == 0) {   // columns [Dn Ht | Dn Et | Dn rt]; the two pad entries of a row of [Y | Z] (odd K) are cleared on the way
-        const double* src = (lane < K) ? A.Hst + (size_t)o * KS2 + lane : A.Est + (size_t)o * KS2 + (lane < 2 * K ? lane - K : 0);
-        const double mg = lane < 2 * K ? 1.0 : 0.0, mc = lane == 2 * K ? 1.0 : 0.0;
+    }
+    const double dinv = (lane < K) ? A.Dst[(size_t)o * K + lane] : 0.0;   // lane r: 1 / d_r
+    double xr[K];
+    double* dst = dump;
+    int dstride = 0;
+    if (pass == 0) {   // columns [Dn Ht | Dn Et | Dn rt]; the two pad entries of a row of [Y | Z] (odd K) are cleared on the way
+      const double* src = (lane < K) ? A.Hst + (size_t)o * KS2 + lane : A.Est + (size_t)o * KS2 + (lane < 2 * K ? lane - K : 0);
+      const double mg = lane < 2 * K ? 1.0 : 0.0, mc = lane == 2 * K ? 1.0 : 0.0;
 #pragma unroll
-        for (int r = 0; r < K; ++r) xr[r] = src[r * ks] * mg + (rdlane(dinv, r) * lds[L.xall + (il + 2) * ks + r]) * mc;
-        if (lane < 2 * K) { dst = slot + B::oYZ + (lane < K ? lane : KE + lane - K); dstride = YS; }
-        else if (lane == 2 * K) { dst = slot + B::oC; dstride = 1; }
-        else if ((K & 1) && lane <= 2 * K + 2) { dst = slot + B::oYZ + (lane == 2 * K + 1 ? K : KE + K); dstride = YS; }   // (xr = 0 there)
-      } else {           // columns Dn Ft (the coupling to the separator)
-        const double* fsrc = A.fst + (size_t)il * A.fstride + (size_t)(lane < 2 * K ? lane : 0) * ks;
-        const double mf = lane < 2 * K ? 1.0 : 0.0;
+      for (int r = 0; r < K; ++r) xr[r] = src[r * ks] * mg + (rdlane(dinv, r) * lds[L.xall + (il + 2) * ks + r]) * mc;
+      if (lane < 2 * K) { dst = slot + B::oYZ + (lane < K ? lane : KE + lane - K); dstride = YS; }
+      else if (lane == 2 * K) { dst = slot + B::oC; dstride = 1; }
+      else if ((K & 1) && lane <= 2 * K + 2) { dst = slot + B::oYZ + (lane == 2 * K + 1 ? K : KE + K); dstride = YS; }   // (xr = 0 there)
+    } else {           // columns Dn Ft (the coupling to the separator)
+      const double* fsrc = (WGLOB ? cfg.wp_fst : A.fst) + (size_t)il * A.fstride + (size_t)(lane < 2 * K ? lane : 0) * ks;
+      const double mf = lane < 2 * K ? 1.0 : 0.0;
 #pragma unroll
-        for (int r = 0; r < K; ++r) xr[r] = (rdlane(dinv, r) * fsrc[r]) * mf;
+      for (int r = 0; r < K; ++r) xr[r] = (rdlane(dinv, r) * fsrc[r]) * mf;
+      if (WGLOB) {
+        if (lane < 2 * K) { dst = cfg.wp_wst + (size_t)il * A.fstride + (size_t)lane * ks; dstride = 1; }
+      } else {
         if (lane < 2 * K) { dst = slot + B::oW + (lane < K ? lane : KE + lane - K); dstride = YS; }
         else if ((K & 1) && lane <= 2 * K + 1) { dst = slot + B::oW + (lane == 2 * K ? K : KE + K); dstride = YS; }
       }
+    }
+    if (stage) {
 #pragma unroll
       for (int t = 0; t < NU; ++t) if (lane + 64 * t < KS2) Us[lane + 64 * t] = uv[t];
-      __atomic_signal_fence(__ATOMIC_SEQ_CST);
-      solve(Us, xr);
-      __atomic_signal_fence(__ATOMIC_SEQ_CST);   // (the staged U may sit where the results go)
+    }
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    solve(Us, xr);
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);   // (the staged U may sit where the results go)
 #pragma unroll
-      for (int r = 0; r < K; ++r) dst[r * dstride] = xr[r];
+    for (int r = 0; r < K; ++r) dst[r * dstride] = xr[r];
+  };
+  if (WGLOB) {
+    for (int il = wave; il < nloc; il += nwaves) do_pass(il, 0, true);
+    if (cfg.wp_wst) {
+      for (int il = wave; il < cfg.wp_nloc; il += nwaves) do_pass(il, 1, true);
+      __threadfence();
+    }
+  } else {
+    for (int task = wave; task < (SPK ? 2 : 1) * nloc; task += nwaves) {
+      const int pass = task >= nloc ? 1 : 0;
+      do_pass(task - pass * nloc, pass, true);
     }
   }
   __syncthreads();
+  if (WGLOB && cfg.wp_wst && tid == 0) __hip_atomic_store(cfg.wflag, A.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   chain_ts(cfg, 3);
   if (cfg.ts && tid == 0) cfg.ts[6] = (double)wall_clock64();
   // ---- phase 2 (spike chains): once the separator is solved, c_i -= W_i [x_near ; x_far]
-  if (SPK && cfg.fst) {
+  if (WGLOB && cfg.fst) {
+    if (tid == 0) spin_wait([&] { return __hip_atomic_load(cfg.wflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.epoch; }, cfg.spin);
+    __syncthreads();
+    (void)__hip_atomic_load(cfg.wflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    if (cfg.ts && tid == 0) cfg.ts[7] = (double)wall_clock64();
+    // a thread per (row, component), two of them per thread at most (pipe_recursion_tail_fits); the rows of W are in
+    // registers before the wait
+    const int nt = blockDim.x;
+    const int pidx = (tid < nloc * K) ? tid : 0, pil = pidx / K, pr = pidx - pil * K;
+    const int qidx = (tid + nt < nloc * K) ? tid + nt : 0, qil = qidx / K, qr = qidx - qil * K;
+    double f[2 * K], f2[2 * K];
+    {
+      const double* F = A.wst + (size_t)pil * A.fstride + pr;
+#pragma unroll
+      for (int c = 0; c < 2 * K; ++c) f[c] = F[c * ks];
+#pragma unroll
+      for (int c = 0; c < 2 * K; ++c) asm volatile("" : "+v"(f[c]));
+      const double* F2 = A.wst + (size_t)qil * A.fstride + qr;
+#pragma unroll
+      for (int c = 0; c < 2 * K; ++c) f2[c] = F2[c * ks];
+#pragma unroll
+      for (int c = 0; c < 2 * K; ++c) asm volatile("" : "+v"(f2[c]));
+    }
+    double* xs = lds + L.W;
+    if (tid < 2 * KE) {
+      const int half = tid / KE, r = tid - half * KE;
+      xs[tid] = (r < K) ? ll_load(cfg.xsep_ll + 2 * ((mirror ? half : 1 - half) * K + r), A.epoch, cfg.spin) : 0.0;
+    }
+    __syncthreads();
+    if (tid < nloc * K) {
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+      for (int c = 0; c < K; ++c) { a0 = __builtin_fma(f[c], xs[c], a0); a1 = __builtin_fma(f[K + c], xs[KE + c], a1); }
+      lds[pil * B::BS + B::oC + pr] -= a0 + a1;
+    }
+    if (tid + nt < nloc * K) {
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+      for (int c = 0; c < K; ++c) { a0 = __builtin_fma(f2[c], xs[c], a0); a1 = __builtin_fma(f2[K + c], xs[KE + c], a1); }
+      lds[qil * B::BS + B::oC + qr] -= a0 + a1;
+    }
+    __syncthreads();
+  }
+  if (!WGLOB && SPK && cfg.fst) {
     double* xs = lds + L.W;
     // (the 2K threads that fetch x_sep poll their own entry, which carries the epoch: penta_nd.h ll_store)
     if (tid < 2 * KE) {
@@ -1185,6 +1264,44 @@ __device__ __forceinline__ void pipe_backward(const PipeArgs& A, const ChainCfg&
     if (il >= 1) row(il - 1, M1, c1, M0, c0);
   }
   chain_ts(cfg, 4);
+}
+
+// ---- the seven-workgroup kernel's chains (penta_nd.h, K = 23 / 29) take their back substitution in the same form.
+// Their forward pass (penta_ldl_body) leaves rt of the local rows at xall_off, in the middle of what the recursion
+// matrices will occupy: the rows move to the top of the launch's LDS first.
+template <int K>
+__host__ __device__ inline bool pipe_recursion_tail_fits(int lds_doubles, int nloc_joiner, int nloc_producer) {
+  using B = PipeBack<K, false>;
+  constexpr int ks = ldl_ks(K);
+  const int nloc = nloc_joiner > nloc_producer ? nloc_joiner : nloc_producer;
+  // (a producer also stages D^-1 U of the partner joiner's rows, a block per wavefront)
+  return nloc_joiner * B::BS + 6 * B::KE + 4 <= lds_doubles - (nloc_joiner + 2) * ks &&
+         nloc_producer * B::BS + 6 * B::KE + 4 + 4 * K * ks <= lds_doubles - (nloc_producer + 2) * ks &&
+         (nloc + 2) * ks <= 4 * 256 && nloc_joiner * K <= 2 * 256;
+}
+template <int K>
+__device__ void chain_recursion_tail(int n, int k, double* x, double* Ust, double* Hst, double* Est, double* Dst,
+                                     const ChainCfg& cfg, unsigned epoch, int xall_off) {
+  extern __shared__ double lds[];
+  using B = PipeBack<K, false>;
+  constexpr int ks = ldl_ks(K);
+  const int tid = threadIdx.x, nloc = cfg.nloc;
+  PipeLds L = {};
+  L.xall = cfg.lds_doubles - (nloc + 2) * ks;
+  L.W = nloc * B::BS + 4 * B::KE + 2;
+  {
+    double keep[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) keep[j] = (tid + 256 * j < (nloc + 2) * ks) ? lds[xall_off + tid + 256 * j] : 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (tid + 256 * j < (nloc + 2) * ks) lds[L.xall + tid + 256 * j] = keep[j];
+    __syncthreads();
+  }
+  PipeArgs P = {};
+  P.n = n; P.k = k; P.x = x; P.Ust = Ust; P.Hst = Hst; P.Est = Est; P.Dst = Dst; P.epoch = epoch;
+  P.fst = const_cast<double*>(cfg.fst); P.fstride = cfg.fstride; P.wst = cfg.wst; P.xjoin_ll = cfg.xjoin_ll;
+  pipe_backward<K, true, true>(P, cfg, L);
 }
 
 // grid (5, batch), 512 threads: blockIdx.x = role, blockIdx.y = problem of the batch

@@ -11,6 +11,9 @@ cfg, model = load_config(name), load_model(name)
 prob, sp, _ = make_problem(cfg, model, num_steps=N)
 sp.scaling = False; sp.equality_constraints = False
 dev = hip.HipPath(model, prob, sp)
+for kv in os.environ.get("IDTO_TIMELINE_OPTS", "").split(","):   # e.g. nd_recursion=0,solver_pipe=0
+    if "=" in kv:
+        dev.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 dev.set_q(synthetic_trajectory(cfg, model, N, seed=0, lower=0.01))
 for _ in range(5):
     dev.gn_step()
@@ -59,10 +62,16 @@ names = ["P0 producer", "P3 producer", "J1 joiner", "J2 joiner", "spike J1", "sp
 for r in range(4):
     x = d[r] - t0
     print(f"{names[r]:12s} start {x[0]:6.2f}  join-wait-begin {x[1]:6.2f}  join-wait-end {x[5]:6.2f}  forward done {x[2]:6.2f}  backward start {x[3]:6.2f}  end {x[4]:6.2f}")
+    if r >= 2 and d[r][24] > 0:
+        print("   rows published (factors and rt in HBM, counter released):", " ".join(at(v) for v in d[r][24:44] if v > 0))
+    if d[r][22] > 0:   # back substitution in recursion form (penta_pipe.h chain_recursion_tail)
+        print("   back substitution: recursion matrices ready %s, corrected by the separator's solution %s, recursion from %s to %s" % (at(d[r][3]), at(d[r][21]), at(d[r][22]), at(d[r][4])))
 for r in (4, 5):
     x = d[r] - t0
     rows = [(x[8 + 2 * i], x[9 + 2 * i]) for i in range(16) if d[r][8 + 2 * i] > 0]
     print(f"{names[r]:12s} start {x[0]:6.2f}  last row published {x[1]:6.2f}")
     print("   rows (ready, done):", " ".join(f"({a:5.1f},{b:5.1f})" for a, b in rows))
+    if d[r][44] > 0:
+        print("   row 8: committed %s, products done %s, next row's loads issued %s, barrier %s, helpers done %s, solve done %s" % tuple(at(d[r][i]) for i in (44, 49, 45, 46, 47, 48)))
 x = d[6] - t0
 print(f"{names[6]:12s} start {x[0]:6.2f}  Q ready {x[1]:6.2f}  W built {x[3]:6.2f}  row s {x[4]:6.2f}  S' {x[5]:6.2f}  row s+1 {x[6]:6.2f}  solved+posted {x[2]:6.2f}")
