@@ -1110,6 +1110,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   if (const char* e = getenv("IDTO_TWO_SIDED")) c->two_sided = (e[0] == '1');   // (debugging aids: option defaults)
   if (const char* e = getenv("IDTO_FUSED")) c->fused = (e[0] == '1');
   if (const char* e = getenv("IDTO_ND_MIN_ROWS")) c->nd_min_rows = std::max(12, std::atoi(e));
+  if (const char* e = getenv("IDTO_ND_RECURSION")) c->nd_recursion = std::atoi(e) != 0;
   if (const char* e = getenv("IDTO_SOLVER_ND")) c->solver_nd = (e[0] == '1');
   if (const char* e = getenv("IDTO_SOLVER_PIPE")) c->solver_pipe = (e[0] == '1');
   if (const char* e = getenv("IDTO_ASM_FOLD")) c->asm_fold = (e[0] == '1');
@@ -1549,6 +1550,7 @@ static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double s
     return 0;
   }
   A.rowcnt = c->nd_rowcnt; A.ndbuf = c->nd_buf;
+  { static const int wt = [] { const char* e = std::getenv("IDTO_ND_WT"); return e ? std::atoi(e) : 0; }(); A.wt_rows = wt; }   // (measurement aid)
   ++c->nd_launches;
   c->last_solver = 2;
   {  // I/O wavefronts of a chain workgroup (penta_ldl_body: NW = 4, one elimination wavefront, three helpers)

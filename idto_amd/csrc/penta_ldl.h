@@ -1003,24 +1003,46 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
       if (ht >= 0 && i > 0 && i <= nloc) {
         // factors of row i-1 for the backward pass, ROW-major (stride ks) so that a lane reads its
         // row with 16-byte loads; rows are scaled by 1/d_r, U keeps its strict upper triangle
+        if (cfg.rowcnt) {   // (a joiner of the seven-workgroup kernel: write-through, see below)
 #pragma unroll
-        for (int it = 0; it < WBMAX; ++it) {
-          const int idx = ht + it * hn;
-          if (idx < K * ks) {
-            const int src = wb_src[it] & 0xffff, r = wb_src[it] >> 16 & 0xff;
-            const bool in = !(wb_src[it] >> 24 & 1), up = wb_src[it] >> 25 & 1;
-            const double dr = Ivp[r];
-            Ust[(size_t)orig(i - 1) * K * ks + idx] = up ? Up[src] * dr : 0.0;
-            Hst[(size_t)orig(i - 1) * K * ks + idx] = in ? Htp[src] * dr : 0.0;
-            Est[(size_t)orig(i - 1) * K * ks + idx] = in ? Etp[src] * dr : 0.0;
+          for (int it = 0; it < WBMAX; ++it) {
+            const int idx = ht + it * hn;
+            if (idx < K * ks) {
+              const int src = wb_src[it] & 0xffff, r = wb_src[it] >> 16 & 0xff;
+              const bool in = !(wb_src[it] >> 24 & 1), up = wb_src[it] >> 25 & 1;
+              const double dr = Ivp[r];
+              const size_t at = (size_t)orig(i - 1) * K * ks + idx;
+              __hip_atomic_store(Ust + at, up ? Up[src] * dr : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(Hst + at, in ? Htp[src] * dr : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(Est + at, in ? Etp[src] * dr : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int it = 0; it < WBMAX; ++it) {
+            const int idx = ht + it * hn;
+            if (idx < K * ks) {
+              const int src = wb_src[it] & 0xffff, r = wb_src[it] >> 16 & 0xff;
+              const bool in = !(wb_src[it] >> 24 & 1), up = wb_src[it] >> 25 & 1;
+              const double dr = Ivp[r];
+              Ust[(size_t)orig(i - 1) * K * ks + idx] = up ? Up[src] * dr : 0.0;
+              Hst[(size_t)orig(i - 1) * K * ks + idx] = in ? Htp[src] * dr : 0.0;
+              Est[(size_t)orig(i - 1) * K * ks + idx] = in ? Etp[src] * dr : 0.0;
+            }
           }
         }
-        for (int r = ht; r < K; r += hn) Dst[(size_t)orig(i - 1) * K + r] = Ivp[r];
+        if (!cfg.rowcnt)
+          for (int r = ht; r < K; r += hn) Dst[(size_t)orig(i - 1) * K + r] = Ivp[r];
         if (cfg.rowcnt) {
-          // nested dissection: row i-1 (factors above, rt here) is complete in HBM once every I/O
-          // wavefront has released its stores
-          for (int r = ht; r < K; r += hn) cfg.rtpub[(size_t)(i - 1) * K + r] = lds[L.xall + (i - 1 + 2) * ks + r];
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          // nested dissection: row i-1 (factors above, 1 / d and rt here) is complete in HBM once every I/O
+          // wavefront's stores are acknowledged.  They are write-through stores: nothing stays dirty in this
+          // XCD's L2, so the release is a wait for the acknowledgements instead of a write-back of that L2
+          // (a releasing fence per I/O wavefront and row from each of 64 joiners cost a batch of 32 problems).
+          for (int r = ht; r < K; r += hn) {
+            __hip_atomic_store(Dst + (size_t)orig(i - 1) * K + r, Ivp[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(cfg.rtpub + (size_t)(i - 1) * K + r, lds[L.xall + (i - 1 + 2) * ks + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (lane == 0)
             __hip_atomic_fetch_add(cfg.rowcnt + (i - 1), cfg.rowcnt_unit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (cfg.ts && lane == 0 && i - 1 < 20) cfg.ts[24 + (i - 1)] = (double)wall_clock64();   // (the last wavefront's stamp stays: the row is out)

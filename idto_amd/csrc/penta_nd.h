@@ -53,7 +53,8 @@ struct NdArgs {
   int debug_skip_role;           // test aid: this role returns at once (its partners' waits must run out), -1: none
   const unsigned* asm_ready;     // penta_pipe.h PipeAsm: the launch assembles g and the bands itself ([rows][4] epoch words), else nullptr
   int asm_first;
-  int wt_rows;                   // penta_pipe_kernel: the chains publish a row's spike block, 1 / d and rt with write-through stores (read past the L2, no acquire)
+  int wt_rows;                   // 1 (penta_pipe_kernel): the chains publish a row's spike block, 1 / d and rt with write-through stores, the separator reads past the L2 (no acquire);
+                                 // 0 (penta_nd_kernel): write-through stores, the readers acquire and read with plain loads; 2: plain stores and a releasing fence (measurement aid IDTO_ND_WT)
   int debug_pipe_tail;           // measurement aid: penta_pipe_kernel takes the row-by-row back substitution
   int npos;                      // > 0: a KKT system (kkt.h) - the pivots [npos, k) of every block row are not tested (ldl_pivot_bad)
   int lds_rows;                  // the chains' carve-up holds this many local rows (penta_ldl_layout `rows`; 0: all n)
@@ -210,13 +211,26 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
   // prefetch a row, so nothing here may assume that the others take the same path)
   auto wait_row = [&](int il) {
     spin_wait([&] { return row_ready(il); }, A.spin);
-    (void)__hip_atomic_load(rowcnt + il, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   };
   // [Ft_il | rt_il] -> HBM (row stride B.frow, column stride ks), by the threads [t0, t0 + tn)
   auto publish = [&](int il, int t0, int tn) {
     const double* F = Fr + (il & 1) * FB;
     double* dst = Fst + (size_t)il * B.frow;
-    for (int idx = tid - t0; idx < FB + ks; idx += tn) dst[idx] = (idx < FB) ? F[idx] : rt[(il & 1) * ks + idx - FB];
+    for (int idx = tid - t0; idx < FB + ks; idx += tn) {
+      const double v = (idx < FB) ? F[idx] : rt[(il & 1) * ks + idx - FB];
+      // (write-through: nothing of the row stays dirty in this XCD's L2, and the release below needs no write-back of
+      // that L2 - three of those per row from each of 64 spike workgroups cost a batch of 32 problems 12% of its
+      // throughput.  The readers invalidate and read with plain loads: reading past the L2 word by word, as the
+      // pipelined kernel's separator does, took the separator 2 us longer per row at K = 23.)
+      if (A.wt_rows != 2) __hip_atomic_store(dst + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else dst[idx] = v;
+    }
+  };
+  auto release_row = [&](int il) {   // by each of the three wavefronts that stored a part of the row
+    if (A.wt_rows != 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) __hip_atomic_fetch_add(frow + il, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   wait_row(0);
   issue(0);
@@ -346,8 +360,7 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
           if (r < K && c < NF) GE[c * ks + r] = acc[rg];
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      if (lane == 0) __hip_atomic_fetch_add(frow + (il - 1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      release_row(il - 1);
       if (il == 8 && tid == 64 && A.ts) A.ts[(4 + w) * 64 + 47] = (double)wall_clock64();
     }
     if (il == 8 && tid == 0 && A.ts) A.ts[(4 + w) * 64 + 48] = (double)wall_clock64();
@@ -357,8 +370,7 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
   }
   if (wave >= 1) {
     publish(nloc - 1, 64, 192);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    if (lane == 0) __hip_atomic_fetch_add(frow + (nloc - 1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    release_row(nloc - 1);
   }
   __syncthreads();
   nd_ts(A, 4 + w, 1);
@@ -428,12 +440,12 @@ __device__ __forceinline__ void nd_separator(const NdArgs& A) {
     for (int t = 0; t < NACC; ++t) qacc[t] = d4q{0.0, 0.0, 0.0, 0.0};
     for (int il = ALT ? sub : 0; il < nloc; il += ALT ? 2 : 1) {
       spin_wait([&] { return __hip_atomic_load(frow + il, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ftarget; }, A.spin);
-      if (!A.wt_rows) (void)__hip_atomic_load(frow + il, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      if (A.wt_rows != 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (no second round trip for an acquiring load: the poll has seen the count)
       if (A.ts && lane == 0 && w == 0 && il < 24) A.ts[6 * 64 + 24 + il] = (double)wall_clock64();   // (debug: row il of spike workgroup 0 seen)
       const double* F = Fst + (size_t)il * B.frow;
       const double* dg = A.Dst + (size_t)(mirror ? base - il : base + il) * K;
       double op[CT2][SKq], dn[SKq];
-      if (A.wt_rows) {
+      if (A.wt_rows == 1) {
 #pragma unroll
         for (int sq = 0; sq < SKq; ++sq) {
           const int kr = 4 * sq + fk;
@@ -459,13 +471,15 @@ __device__ __forceinline__ void nd_separator(const NdArgs& A) {
           qacc[ai] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[tr][sq], op[tc][sq] * dn[sq], qacc[ai], 0, 0, 0);
       }
     }
-    // (ALT: wavefront 0 of the pair stores its sums, wavefront 1 adds its own to them after a barrier)
+    // (ALT: the wavefront of the pair that does NOT hold the last row stores its sums - it is done a row earlier -, the
+    // other one adds its own to them after a barrier)
+    const int late = (nloc - 1) & 1;   // the wavefront with the last row
 #pragma unroll
     for (int pass = 0; pass < (ALT ? 2 : 1); ++pass) {
       if (ALT && pass == 1) __syncthreads();
 #pragma unroll
       for (int t = 0; t < NQT; ++t) {
-        if (ALT ? (sub != pass) : (t % 2 != sub)) continue;
+        if (ALT ? ((sub == late) != (pass == 1)) : (t % 2 != sub)) continue;
         const int tr = nd_tile_row(t), tc = nd_tile_col(t), ai = ALT ? t : t / 2;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
