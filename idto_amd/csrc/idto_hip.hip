@@ -258,6 +258,7 @@ struct idto_hip_ctx {
   int nd_recursion = 1;       // option "nd_recursion": its back substitution in recursion form where the matrices fit the LDS
   unsigned long long nd_launches = 0;
   int last_solver = 0;                     // 0 none yet, 1 two-workgroup LDL^T, 2 nested dissection, 3 reference LU
+  bool kkt_debug = false;                 // option "solver_debug" 2
   bool fused_debug = false;               // ... with per-workgroup time stamps in IDTO_ARR_DEBUG
   double* xch = nullptr;                  // their exchange buffer / flags
   unsigned* flags = nullptr;
@@ -1401,11 +1402,14 @@ static NdSplit nd_split(int n, bool pipe, int K) {
   const int htop = sp.s, hbot = n - sp.s - 2;
   auto producer_rows = [&](int half) {
     if (!pipe) {
-      // (seven workgroups: even halves - but a joiner's row costs 4.5 us against a producer's 4.2 at K = 23 (it
-      // publishes every row for its spike workgroup) and its two join rows 6 us each: one row more for the producers
-      // and both sides reach the join together, allegro N = 60: 67.7 / 66.6 us instead of 63.6 / 70.3)
+      // (seven workgroups.  Measured: producer done at 0.6 + (np + 2) t, joiner at the join at 0.6 + d + (half - np - 2) t'
+      // with t = 4.2, t' = 4.53, d = 6.3 us at K = 23 (the joiner publishes every row and starts later) and t = 6.2,
+      // t' = 6.3, d = 8.5 at K = 29: both sides meet at np = (half - 2) / 2 + 0.27 resp. - 0.24 rows.  An odd
+      // half - 2 (every even n) therefore rounds UP at K = 23 - allegro N = 60: 67.7 / 66.6 us instead of 63.6 / 70.3 -
+      // and down at K = 29 - N = 40: 62 / 66 instead of 68 / 59.5.)
       static const int extra = [] { const char* e = std::getenv("IDTO_ND_PRODUCER_EXTRA"); return e ? std::atoi(e) : -1; }();   // (measurement aid)
-      return std::max(1, std::min((half - 2) / 2 + (extra >= 0 ? extra : (K > 20 ? 1 : 0)), half - 3));
+      const int np = extra >= 0 ? (half - 2) / 2 + extra : (half - 2 + (K > 20 && K <= 24 ? 1 : 0)) / 2;
+      return std::max(1, std::min(np, half - 3));
     }
     static const double share = [] { const char* e = std::getenv("IDTO_PIPE_SPLIT"); return e ? std::atof(e) : 0.52; }();   // (measurement aid)
     int np = (int)(share * (half - 2) + 0.6);
@@ -1437,7 +1441,7 @@ static int NdLds(const idto_hip_ctx* c, const LdlPlan& p, int nloc_max) {
   const int ks = ldl_ks(p.K), NF = 2 * p.K, KP = 4 * ((p.K + 3) / 4);
   const int chain = penta_ldl_layout(p.n, p.K, 1, NdChainRows(nloc_max)).end * (int)sizeof(double);
   const int spike = (3 * NF * ks + 3 * KP * ks + 3 * p.K * p.K + 2 * ks + 4) * (int)sizeof(double);
-  const int sep = (2 * (NF + 1) * (NF + 1) + 2 + (2 * p.K + 1) * ks + (p.K + 1) * ks + 2 * p.K * ks + p.K * ks + 6 * ks) * (int)sizeof(double);
+  const int sep = nd_sep_lds_doubles(p.K) * (int)sizeof(double);
   return std::max(std::max(spike, sep), chain);
 }
 // idto_hip_gn_step / idto_hip_tr_solve asked the solver's launch to assemble g and the bands itself (AsmInSolver): the
@@ -1521,8 +1525,7 @@ static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double s
       case 5: plds = pipe_layout<5>(p.n, true).end; break;
       default: plds = pipe_layout<19>(p.n, true).end; break;
     }
-    const int sep = (2 * (2 * p.K + 1) * (2 * p.K + 1) + 2 + (2 * p.K + 1) * ldl_ks(p.K) + (p.K + 1) * ldl_ks(p.K) +
-                     2 * p.K * ldl_ks(p.K) + p.K * ldl_ks(p.K) + 6 * ldl_ks(p.K)) * (int)sizeof(double);
+    const int sep = nd_sep_lds_doubles(p.K) * (int)sizeof(double);
     plds = std::max(plds * (int)sizeof(double), sep);
     if (plds > 160 * 1024) { g_err = "pipelined solver: LDS carve-up too large"; return -1; }
     A.rowcnt = c->pipe_rowcnt; A.ndbuf = c->nd_buf;
@@ -1567,8 +1570,8 @@ static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double s
   int nd_lds = lds;
   if (c->nd_recursion && c->nd_wst && p.K == p.k && (p.K == 23 || p.K == 29)) {
     const int nj = std::max(A.s - A.j1, A.j2 - A.s), np = std::max(A.j1, A.n - A.j2 - 2), all = 160 * 1024 / (int)sizeof(double);
-    if (p.K == 23 ? pipe_recursion_tail_fits<23>(all, nj, np) : pipe_recursion_tail_fits<29>(all, nj, np)) {
-      A.rec_tail = 1; A.lds_doubles = all; A.wst = c->nd_wst;
+    if (const int ww = p.K == 23 ? pipe_recursion_tail_fits<23>(all, nj, np) : pipe_recursion_tail_fits<29>(all, nj, np)) {
+      A.rec_tail = ww; A.lds_doubles = all; A.wst = c->nd_wst;
       nd_lds = 160 * 1024;
     }
   }
@@ -2145,7 +2148,7 @@ static int MakeKkt(idto_hip_ctx* c, int nu) {
   // (seven workgroups for allegro's 29 x 29 blocks: 0.46 -> 0.29 ms per iteration; the small systems stay on two - the
   // nested-dissection order buys them 3 us and costs acrobot's multipliers a digit: 2e-8 against 3e-9)
   k->two_sided = c->two_sided; k->solver_nd = c->solver_nd && (K == 29 || K == 8); k->solver_pipe = false; k->fused = false; k->asm_in_solver = false;
-  k->solver_band = c->solver_band; k->nd_min_rows = c->nd_min_rows; k->nd_recursion = c->nd_recursion;
+  k->solver_band = c->solver_band; k->nd_min_rows = c->nd_min_rows; k->nd_recursion = c->nd_recursion; k->solver_debug = c->kkt_debug;
   k->h_assembled = true;      // block row 0 is decoupled (q_0 is no variable, mu_0 a dummy): the chains start at row 1
   k->ldl_npos = c->nq;
   const size_t kk = (size_t)K * K;
@@ -2774,7 +2777,8 @@ int idto_hip_get_option(idto_hip_ctx* c, const char* name, int* value) {
 
 int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "reference_solver") == 0) { c->reference_solver = value != 0; return 0; }
-  if (std::strcmp(name, "solver_debug") == 0) { c->solver_debug = value != 0; return 0; }
+  // (2: the stamps of the KKT context's solver - the constrained step's banded solve - are what IDTO_ARR_DEBUG returns)
+  if (std::strcmp(name, "solver_debug") == 0) { c->solver_debug = value == 1; c->kkt_debug = value == 2; if (c->kkt) c->kkt->solver_debug = c->kkt_debug; return 0; }
   if (std::strcmp(name, "two_sided") == 0) { c->two_sided = value != 0; return 0; }
   if (std::strcmp(name, "fused") == 0) { c->fused = value != 0; return 0; }
   if (std::strcmp(name, "async_uploads") == 0) { c->async_uploads = value != 0; return 0; }
@@ -2906,7 +2910,7 @@ void* DevPtr(idto_hip_ctx* c, int what) {
     case IDTO_ARR_COST: return c->cost;
     case IDTO_ARR_SLAB: return c->slab;
     case IDTO_ARR_HBANDS: return c->HA;
-    case 15: return c->dbg;
+    case 15: return (c->kkt_debug && c->kkt) ? c->kkt->dbg : c->dbg;
     case IDTO_ARR_TR_DQ: return c->tr_dq;
     case IDTO_ARR_TR_W: return c->tr_w;
     case IDTO_ARR_TR_SCALE: return c->tr_D;

@@ -248,7 +248,7 @@ struct ChainCfg {
   double* xjoin_ll;
   // ... and the pair's PRODUCER forms the joiner's W rows (it is idle for longer): the joiner's rows (local row il is
   // matrix row wp_base -/+ il), its spike workgroup's rows and counters, its wst; wflag = epoch once they are all there
-  int wp_nloc, wp_base, wp_mirror;
+  int wp_nloc, wp_base, wp_mirror, wp_waves;
   const double* wp_fst; const unsigned long long* wp_frowcnt; double* wp_wst;
   unsigned* wflag;
 };

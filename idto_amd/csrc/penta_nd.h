@@ -26,6 +26,7 @@
 // 2 + 9 rows back, instead of 20 + 2 and 22.
 #pragma once
 
+#include <type_traits>
 #include "penta_ldl.h"
 
 namespace idto_dev {
@@ -60,7 +61,7 @@ struct NdArgs {
   int lds_rows;                  // the chains' carve-up holds this many local rows (penta_ldl_layout `rows`; 0: all n)
   // back substitution in recursion form (penta_pipe.h chain_recursion_tail; K > 20): the launch has lds_doubles of LDS
   // and wst holds [2][ND_MAXROWS] rows of nd_layout(K).frow doubles for the joiners' W_il
-  int rec_tail, lds_doubles;
+  int rec_tail, lds_doubles;   // (rec_tail: how many of a producer's wavefronts form its joiner's W rows, pipe_recursion_tail_fits)
   double* wst;
 };
 __device__ __forceinline__ void nd_ts(const NdArgs& A, int role, int slot) {
@@ -87,6 +88,13 @@ __host__ __device__ inline NdBuf nd_layout(int K) {
 // tile t of the lower triangle of a tile grid, row by row: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) ...
 __host__ __device__ constexpr int nd_tile_row(int t) { int tr = 0; while (t > tr) { t -= tr + 1; ++tr; } return tr; }
 __host__ __device__ constexpr int nd_tile_col(int t) { int tr = 0; while (t > tr) { t -= tr + 1; ++tr; } return t; }
+// f(integral_constant<int, I>) for I = I0 .. N-1: the tile loops below index register arrays with nd_tile_row / _col of
+// the loop variable, and left as functions of a run-time t the compiler EVALUATED THEM IN LOOPS and went through
+// scratch for the arrays (K = 29: 7 us for the 80 matrix-core instructions of a separator row)
+template <int I, int N, class F>
+__device__ __forceinline__ void nd_static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); nd_static_for<I + 1, N>(f); }
+}
 
 __device__ __forceinline__ void nd_wait(const unsigned* f, unsigned epoch, const SpinCtl sc) {
   if (threadIdx.x == 0)
@@ -376,6 +384,16 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
   nd_ts(A, 4 + w, 1);
 }
 
+// doubles of the separator's Q: per spike workgroup the lower-triangle tiles of Q as the matrix cores leave them
+// ([tile][register][lane]: stored and summed without a condition or a transposed copy)
+__host__ __device__ constexpr int nd_sep_q_tiles(int K) { return ((2 * K + 1 + 15) / 16) * ((2 * K + 1 + 15) / 16 + 1) / 2; }
+__host__ __device__ constexpr int nd_sep_q_doubles(int K) { return 2 * nd_sep_q_tiles(K) * 256; }
+// (the whole carve-up of nd_separator)
+__host__ __device__ inline int nd_sep_lds_doubles(int K) {
+  const int ks = ldl_ks(K);
+  return nd_sep_q_doubles(K) + (2 * K + 1) * ks + (K + 1) * ks + 2 * K * ks + K * ks + 4 * ks + 2;
+}
+
 // ---- separator workgroup
 // While the chains run: wavefronts 0, 1 accumulate Q of spike workgroup 0, wavefronts 2, 3 of spike
 // workgroup 1 - each wavefront on its own (no workgroup barrier, MFMA operands straight from the
@@ -397,8 +415,9 @@ __device__ __forceinline__ void nd_separator(const NdArgs& A) {
   const int tid = threadIdx.x, nt = 256, lane = tid & 63, wave = tid >> 6;
   const int k = A.k, kk = k * k, s = A.s;
   const NdBuf B = nd_layout(K);
-  double* Q = lds;                   // [2][QS] dense, both triangles
-  double* W = Q + 2 * QS + (QS & 1); // [2K + 1][ks] columns [S | H | y]
+  constexpr int QTS = NQT * 256;     // (nd_sep_q_doubles(K) = 2 QTS)
+  double* Qt = lds;                  // [2][NQT][4][64]: the lower-triangle tiles of Q, register rg of lane l of tile t at (4 t + rg) 64 + l
+  double* W = Qt + 2 * QTS;          // [2K + 1][ks] columns [S | H | y]
   double* S1 = W + (2 * K + 1) * ks; // [K + 1][ks] second row: [S' | y']
   double* Us = S1 + (K + 1) * ks;    // [2][K][ks] U columns of both rows
   double* Ht = Us + 2 * K * ks;      // [K][ks]
@@ -462,15 +481,25 @@ __device__ __forceinline__ void nd_separator(const NdArgs& A) {
           for (int t = 0; t < CT2; ++t) op[t][sq] = F[(16 * t + fl) * ks + kr];
         }
       }
+      if (A.ts && w == 0 && il == nloc - 1) {   // (debug: the last row's operands are in registers)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) A.ts[6 * 64 + 50] = (double)wall_clock64();
+      }
+      // tile t -> wavefront t % 2 of the pair, accumulator t / 2 (ALT: every tile, accumulator t).  The k-steps are the
+      // OUTER loop: consecutive matrix-core instructions then go to different accumulators (a tile's own k-steps are
+      // a dependent chain: 80 of them took 5.9 us at K = 29), and the scaled operand is formed once per column tile.
 #pragma unroll
-      for (int t = 0; t < NQT; ++t) {   // tile t -> wavefront t % 2 of the pair, accumulator t / 2 (ALT: every tile, accumulator t)
-        if (!ALT && t % 2 != sub) continue;
-        const int tr = nd_tile_row(t), tc = nd_tile_col(t), ai = ALT ? t : t / 2;
+      for (int sq = 0; sq < SKq; ++sq) {
+        double opd[CT2];
 #pragma unroll
-        for (int sq = 0; sq < SKq; ++sq)
-          qacc[ai] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[tr][sq], op[tc][sq] * dn[sq], qacc[ai], 0, 0, 0);
+        for (int t = 0; t < CT2; ++t) opd[t] = op[t][sq] * dn[sq];
+        nd_static_for<0, NQT>([&](auto tt) __attribute__((always_inline)) {
+          constexpr int t = decltype(tt)::value, tr = nd_tile_row(t), tc = nd_tile_col(t), ai = ALT ? t : t / 2;
+          if (ALT || t % 2 == sub) qacc[ai] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[tr][sq], opd[tc], qacc[ai], 0, 0, 0);
+        });
       }
     }
+    if (A.ts && w == 0 && lane == 0 && sub == ((nloc - 1) & 1)) A.ts[6 * 64 + 51] = (double)wall_clock64();   // (debug: ... and accumulated)
     // (ALT: the wavefront of the pair that does NOT hold the last row stores its sums - it is done a row earlier -, the
     // other one adds its own to them after a barrier)
     const int late = (nloc - 1) & 1;   // the wavefront with the last row
@@ -480,15 +509,11 @@ __device__ __forceinline__ void nd_separator(const NdArgs& A) {
 #pragma unroll
       for (int t = 0; t < NQT; ++t) {
         if (ALT ? ((sub == late) != (pass == 1)) : (t % 2 != sub)) continue;
-        const int tr = nd_tile_row(t), tc = nd_tile_col(t), ai = ALT ? t : t / 2;
+        const int ai = ALT ? t : t / 2;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-          const int r = 16 * tr + fk + 4 * rg, c = 16 * tc + fl;
-          // (lower triangle, mirrored: a diagonal tile holds both (r, c) and (c, r), summed in different orders)
-          if (r < NC && c < NC && r >= c) {
-            const double v = (ALT && pass == 1) ? Q[w * QS + c * NC + r] + qacc[ai][rg] : qacc[ai][rg];
-            Q[w * QS + c * NC + r] = v; Q[w * QS + r * NC + c] = v;
-          }
+          double* at = Qt + w * QTS + (4 * t + rg) * 64 + lane;
+          *at = (ALT && pass == 1) ? *at + qacc[ai][rg] : qacc[ai][rg];
         }
       }
     }
@@ -497,11 +522,18 @@ __device__ __forceinline__ void nd_separator(const NdArgs& A) {
   nd_ts(A, 6, 1);
   // column blocks of the two spike workgroups: w = 0 (mirrored chain J1): nearest = s (offset 0), farthest = s+1
   // (offset K); w = 1 (chain J2): nearest = s+1, farthest = s; column 2K is rt
+  // element (R, C) of the symmetric Q of spike workgroup w (the lower triangle is what the tiles hold: a diagonal tile
+  // has both (R, C) and (C, R), summed in different orders)
+  auto qat = [&](int w, int R, int C) {
+    const int hi = R > C ? R : C, lo = R > C ? C : R;
+    const int tr = hi >> 4, tc = lo >> 4, rr = hi & 15;
+    return Qt[w * QTS + (4 * (tr * (tr + 1) / 2 + tc) + (rr >> 2)) * 64 + (rr & 3) * 16 + (lo & 15)];
+  };
   auto qs = [&](int w, int rowsel, int colsel, int r, int c) {   // rowsel / colsel: 0 -> block of row s, 1 -> of s+1
     const int ro = (w == 0 ? rowsel : 1 - rowsel) * K, co = (w == 0 ? colsel : 1 - colsel) * K;
-    return Q[w * QS + (co + c) * NC + ro + r];
+    return qat(w, ro + r, co + c);
   };
-  auto qyv = [&](int w, int rowsel, int r) { return Q[w * QS + NF * NC + (w == 0 ? rowsel : 1 - rowsel) * K + r]; };
+  auto qyv = [&](int w, int rowsel, int r) { return qat(w, NF, (w == 0 ? rowsel : 1 - rowsel) * K + r); };
   for (int idx = tid; idx < K * K; idx += nt) {
     const int c = idx / K, r = idx - c * K;
     W[c * ks + r] = (W[c * ks + r] - qs(0, 0, 0, r, c)) - qs(1, 0, 0, r, c);
@@ -692,6 +724,7 @@ __global__ void __launch_bounds__(256) penta_nd_kernel(NdArgs A) {
     c.wp_fst = A.ndbuf + B.fst + (size_t)pair * ND_MAXROWS * B.frow; c.fstride = B.frow;
     c.wp_frowcnt = A.rowcnt + (2 + pair) * ND_MAXROWS; c.frowtarget = (A.rowtarget / A.rowunit) * 3ull;
     c.wp_wst = A.wst + (size_t)pair * ND_MAXROWS * B.frow;
+    c.wp_waves = A.rec_tail;
   }
   constexpr int GW = ((2 * K + 1) + (64 - K) - 1) / (64 - K);
   penta_ldl_body<K, 256, PADDED, GW, (K > 20)>(A.n, A.k, A.HA, A.HB, A.HC, A.b, A.rhs_sign, 1, A.x, A.Ust, A.Hst, A.Est, A.Dst,

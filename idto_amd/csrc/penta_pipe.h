@@ -1016,10 +1016,11 @@ __device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& 
 // LDS (everything the forward pass used is free): per local row [Y | Z] row-major (stride 2 KE), W likewise, c.
 template <int K, bool SPK>
 struct PipeBack {
-  // (a row-major block also stages D^-1 U, stride ks.  Row stride: an odd number of 16-byte units, or the rows that the
+  // (a row-major block also stages D^-1 U, stride ks.  Row stride: not a multiple of 16 dwords, or the rows that the
   // lanes of the recursion read - one row per lane, ds_read_b128 - start in 2 (K = 23: 96 dwords) or 4 (K = 19: 80) of the
-  // 16 bank groups)
-  static constexpr int KE = K + (K & 1), YS0 = 2 * KE > ldl_ks(K) ? 2 * KE : ldl_ks(K), YS = YS0 + ((YS0 / 2) & 1 ? 0 : 2);
+  // 16 bank groups; K = 29: 120 dwords, 8 groups, left alone - two more doubles per row and 11 rows of the KKT system
+  // at N = 40 no longer fit)
+  static constexpr int KE = K + (K & 1), YS0 = 2 * KE > ldl_ks(K) ? 2 * KE : ldl_ks(K), YS = YS0 + (YS0 % 8 == 0 ? 2 : 0);
   static constexpr int oYZ = 0, oW = K * YS, oC = oW + (SPK ? K * YS : 0), BS = oC + KE;
 };
 
@@ -1138,7 +1139,9 @@ __device__ __forceinline__ void pipe_backward(const PipeArgs& A, const ChainCfg&
   if (WGLOB) {
     for (int il = wave; il < nloc; il += nwaves) do_pass(il, 0, true);
     if (cfg.wp_wst) {
-      for (int il = wave; il < cfg.wp_nloc; il += nwaves) do_pass(il, 1, true);
+      // (as many wavefronts as there is LDS for their staged D^-1 U: 4 at K = 23, 2 at K = 29 N = 40)
+      if (wave < cfg.wp_waves)
+        for (int il = wave; il < cfg.wp_nloc; il += cfg.wp_waves) do_pass(il, 1, true);
       __threadfence();
     }
   } else {
@@ -1269,15 +1272,18 @@ __device__ __forceinline__ void pipe_backward(const PipeArgs& A, const ChainCfg&
 // ---- the seven-workgroup kernel's chains (penta_nd.h, K = 23 / 29) take their back substitution in the same form.
 // Their forward pass (penta_ldl_body) leaves rt of the local rows at xall_off, in the middle of what the recursion
 // matrices will occupy: the rows move to the top of the launch's LDS first.
+// -> the number of the producer's wavefronts that work on the partner's rows (each stages a block D^-1 U of its own), 0: does not fit
 template <int K>
-__host__ __device__ inline bool pipe_recursion_tail_fits(int lds_doubles, int nloc_joiner, int nloc_producer) {
+__host__ __device__ inline int pipe_recursion_tail_fits(int lds_doubles, int nloc_joiner, int nloc_producer) {
   using B = PipeBack<K, false>;
   constexpr int ks = ldl_ks(K);
   const int nloc = nloc_joiner > nloc_producer ? nloc_joiner : nloc_producer;
-  // (a producer also stages D^-1 U of the partner joiner's rows, a block per wavefront)
-  return nloc_joiner * B::BS + 6 * B::KE + 4 <= lds_doubles - (nloc_joiner + 2) * ks &&
-         nloc_producer * B::BS + 6 * B::KE + 4 + 4 * K * ks <= lds_doubles - (nloc_producer + 2) * ks &&
-         (nloc + 2) * ks <= 4 * 256 && nloc_joiner * K <= 2 * 256;
+  if (!(nloc_joiner * B::BS + 6 * B::KE + 4 <= lds_doubles - (nloc_joiner + 2) * ks && (nloc + 2) * ks <= 4 * 256 &&
+        nloc_joiner * K <= 2 * 256))
+    return 0;
+  for (int w = 4; w >= 1; w >>= 1)
+    if (nloc_producer * B::BS + 6 * B::KE + 4 + w * K * ks <= lds_doubles - (nloc_producer + 2) * ks) return w;
+  return 0;
 }
 template <int K>
 __device__ void chain_recursion_tail(int n, int k, double* x, double* Ust, double* Hst, double* Est, double* Dst,
