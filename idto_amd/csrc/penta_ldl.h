@@ -709,6 +709,8 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
   const bool ypush = (nrhs == 1 && gj_waves == 1 && 3 * K < 64);
   __syncthreads();
 
+  constexpr int XPRE = RECT ? (K * ldl_ks(K) + NT - 1) / NT : 1;
+  double xpre[XPRE] = {}, ypre = 0.0;   // (RECT: the second join row's contributions, fetched during the first)
   for (int i = 0; i < nfwd; ++i) {
     const bool pseudo = i >= nloc;  // bottom workgroup: product-only rows forming the join contributions
     double* Bn = lds + L.in;
@@ -889,8 +891,23 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
       const double* X0 = xch;         // pseudo-row 0: contributions to row m+1 (and the (m+1, m) coupling)
       const double* X1 = xch + wsz;   // pseudo-row 1: contributions to row m
       const double* Xs = (i == m_split) ? X1 : X0;
-      for (int idx = tid; idx < K * ks; idx += nt) Wm[idx] += Xs[idx];                       // S
-      for (int idx = tid; idx < nrhs * ks; idx += nt) Wm[3 * K * ks + idx] += Xs[3 * K * ks + idx];  // y
+      if (RECT && nrhs == 1) {
+        // (the second join row's contributions are asked for a row ahead: ~1.5 us of exposed load latency of that row)
+        if (i == m_split) {
+#pragma unroll
+          for (int j = 0; j < XPRE; ++j) xpre[j] = X0[(tid + j * nt < K * ks) ? tid + j * nt : 0];
+          ypre = X0[3 * K * ks + (tid < ks ? tid : 0)];
+          for (int idx = tid; idx < K * ks; idx += nt) Wm[idx] += Xs[idx];
+          if (tid < ks) Wm[3 * K * ks + tid] += Xs[3 * K * ks + tid];
+        } else {
+#pragma unroll
+          for (int j = 0; j < XPRE; ++j) if (tid + j * nt < K * ks) Wm[tid + j * nt] += xpre[j];
+          if (tid < ks) Wm[3 * K * ks + tid] += ypre;
+        }
+      } else {
+        for (int idx = tid; idx < K * ks; idx += nt) Wm[idx] += Xs[idx];                       // S
+        for (int idx = tid; idx < nrhs * ks; idx += nt) Wm[3 * K * ks + idx] += Xs[3 * K * ks + idx];  // y
+      }
       if (i == m_split)
         for (int idx = tid; idx < KK; idx += nt) {  // H(r, c) += H'(c, r)
           const int c = idx / K, r = idx - c * K;

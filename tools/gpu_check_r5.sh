@@ -47,6 +47,10 @@ timeout 600 python tools/fd_sweep.py 12 2>&1 | grep -v amdgpu.ids | tail -3 | te
 { for c in "acrobot 40 1200" "spinner 40 1200" "acrobot 200 600"; do timeout 300 python tools/stress_solver.py $c 2>&1 | grep -v amdgpu.ids; done; } | tee gpurun_out/${R}_band_stress.txt
 timeout 200 python tools/mpc_latency.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${R}_mpc_latency.txt
 timeout 120 python tools/nd_timeline.py allegro_hand 60 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${R}_nd_timeline_allegro.txt
+{ timeout 120 python tools/kkt_timeline.py allegro_hand 40; timeout 120 python tools/kkt_timeline.py allegro_hand 60; } 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${R}_kkt_timeline_allegro.txt
+{ IDTO_TIMELINE_OPTS=nd_recursion=0 timeout 120 python tools/nd_timeline.py allegro_hand 60; } 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${R}_nd_timeline_allegro_rowwise_tail.txt
+{ for c in "allegro_hand 60 20" "allegro_hand 40 20" "hopper 40 20"; do timeout 120 python tools/constrained_loop.py $c 2>&1 | grep -v amdgpu.ids | head -1; done; } | tee gpurun_out/${R}_constrained_loop_times.txt
+timeout 300 bash tools/gpu_r5_batch32.sh 2>&1 | grep -v amdgpu.ids | head -4 | tee gpurun_out/${R}_allegro_batches_write_through.txt
 timeout 300 python tools/mpc_timeline.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${R}_mpc_timeline.txt
 timeout 300 python tools/band_phases.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${R}_band_phases.txt
 ROUND=$R timeout 900 bash tools/prof_band.sh > /dev/null 2>&1

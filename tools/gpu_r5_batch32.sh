@@ -8,5 +8,3 @@ print(round(b['value']), {n: round(1e3*v,1) for n,v in k.items()}, [(e['problems
 "; }
 echo "default (write-through rows)"; line
 echo "IDTO_ND_WT=2 (plain stores, releasing fence per wavefront)"; IDTO_ND_WT=2 line
-timeout 600 python -m pytest tests/test_gpu_nd.py tests/test_gpu_solver_accuracy.py tests/test_gpu_batch.py -x -q -m gpu 2>&1 | tail -1
-IDTO_TIMELINE_OPTS="nd_recursion=1" python tools/nd_timeline.py allegro_hand 60 2>&1 | grep "producer \|last row\|^separator  \|row 8"
