@@ -1137,13 +1137,33 @@ __device__ __forceinline__ void pipe_backward(const PipeArgs& A, const ChainCfg&
     for (int r = 0; r < K; ++r) dst[r * dstride] = xr[r];
   };
   if (WGLOB) {
-    for (int il = wave; il < nloc; il += nwaves) do_pass(il, 0, true);
-    if (cfg.wp_wst) {
-      // (as many wavefronts as there is LDS for their staged D^-1 U: 4 at K = 23, 2 at K = 29 N = 40)
-      if (wave < cfg.wp_waves)
-        for (int il = wave; il < cfg.wp_nloc; il += cfg.wp_waves) do_pass(il, 1, true);
-      __threadfence();
+    // A producer's two lists: its own rows (needed when x of the join rows arrives, late) and the partner's W rows
+    // (needed BEFORE the separator answers: the joiner fetches them ahead of its wait; each can start once the spike
+    // workgroup has published the row).  A partner row that is there goes first, the own rows fill the waits - taken
+    // one list after the other, the W rows of the mirrored pair were complete 0.6 us before the separator's answer
+    // and their fetch (4 us) then sat on the path.  (As many wavefronts on the partner's rows as there is LDS for
+    // their staged D^-1 U: 4 at K = 23, 2 at K = 29 N = 40.)
+    const int ws = (cfg.wp_wst && wave < cfg.wp_waves) ? cfg.wp_waves : 0, wn = ws ? cfg.wp_nloc : 0;
+    // (the counter of the next partner row is asked BEFORE a row's work and looked at after it - its round trip is
+    // ~1 us; lane 0's answer decides for the wavefront: the lanes of one load need not see the same value)
+    auto ask = [&](int il) { return il < wn ? __hip_atomic_load(cfg.wp_frowcnt + il, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull; };
+    auto there = [&](unsigned long long cnt) { return __builtin_amdgcn_readfirstlane(cnt >= cfg.frowtarget ? 1 : 0); };
+    int own = wave, wt = wave;
+    int ready = there(ask(wt));
+    while (own < nloc || wt < wn) {
+      if (wt < wn && (ready || own >= nloc)) {
+        const unsigned long long nxt = ask(wt + ws);
+        do_pass(wt, 1, true);
+        wt += ws;
+        ready = there(nxt);
+      } else {
+        const unsigned long long nxt = ask(wt);
+        do_pass(own, 0, true);
+        own += nwaves;
+        ready = there(nxt);
+      }
     }
+    if (cfg.wp_wst) __threadfence();
   } else {
     for (int task = wave; task < (SPK ? 2 : 1) * nloc; task += nwaves) {
       const int pass = task >= nloc ? 1 : 0;

@@ -10,7 +10,7 @@ back substitution, nested dissection over seven workgroups, two workgroups), the
     Thomas, bit-exact to the oracle's) + 16 unc, and
   * a componentwise backward error  max_i |H p + g|_i / (|H| |p| + |g|)_i  <= 1e-12, or a hundred times below the
     pivoted LU's own where that is larger (allegro: the reference's algorithm - itself a recursion over precomputed
-    Y_i, Z_i - leaves 6e-10 .. 4e-9 there; the kernels' back substitutions in recursion form 2e-13 .. 2e-12, the
+    Y_i, Z_i - leaves 6e-10 .. 4e-9 there; the kernels' back substitutions in recursion form 1e-12 .. 6e-12, the
     row-by-row ones 5e-14 .. 2e-13).
 tools/nd_accuracy.py prints the same quantities as a table (profiles/r04_nd_accuracy.txt)."""
 import numpy as np
