@@ -135,13 +135,14 @@ def main():
                 m = re.search(r"allegro_hand N=60:.*penta_nd_kernel ([\d.]+)", open(stats).read())
                 nd_us = float(m.group(1)) if m else None
             out["penta_nd_kernel_23"] = {
-                "bound": "the spike workgroups (a row behind the joiners by construction, 4.1 us a row against the joiners' 4.7), then the "
-                         "separator's input, its two rows, and a row-by-row back substitution",
+                "bound": "the chains' forward pass (producers: 14 rows + 2 pseudo-rows, joiners: 13 rows + 2 join rows), then the spike "
+                         "workgroups' last two rows (they follow their joiner row by row), the separator's input and its two rows, "
+                         "and the back substitution in recursion form (DESIGN.md 5.13)",
                 "block_size_K": 23, "rows_of_a_joiner": nrows,
                 "joiner_row_us": jf / nrows, "spike_row_us": spike_row, "first_spike_row_ready_us": min(sp[0][0] for sp in spikes),
                 "joiners_forward_done_us": jf, "last_spike_row_published_us": max(pub),
                 "joiners_done_to_q_ready_us": q_ready - jf, "separator_us": solved - q_ready,
-                "back_substitution_us": end - solved, "back_substitution_per_row_us": (max(ch["J1"]["end"], ch["J2"]["end"]) - max(ch["J1"]["backward_start"], ch["J2"]["backward_start"])) / nrows,
+                "back_substitution_us": end - solved,
                 "timeline_end_us": end, "hip_event_avg_us": nd_us,
             }
             out["sources"]["penta_nd_kernel_23"] = [f"profiles/{rnd}_nd_timeline_allegro.txt", f"profiles/{rnd}_all_configs.txt"]
