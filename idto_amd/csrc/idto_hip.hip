@@ -2148,7 +2148,7 @@ static int MakeKkt(idto_hip_ctx* c, int nu) {
   // (seven workgroups for allegro's 29 x 29 blocks: 0.46 -> 0.29 ms per iteration; the small systems stay on two - the
   // nested-dissection order buys them 3 us and costs acrobot's multipliers a digit: 2e-8 against 3e-9)
   k->two_sided = c->two_sided; k->solver_nd = c->solver_nd && (K == 29 || K == 8); k->solver_pipe = false; k->fused = false; k->asm_in_solver = false;
-  k->solver_band = c->solver_band; k->nd_min_rows = c->nd_min_rows; k->nd_recursion = c->nd_recursion; k->solver_debug = c->kkt_debug;
+  k->solver_band = c->solver_band; k->nd_min_rows = c->nd_min_rows; k->nd_recursion = c->nd_recursion; k->solver_debug = c->kkt_debug; k->debug_skip_role = c->debug_skip_role;
   k->h_assembled = true;      // block row 0 is decoupled (q_0 is no variable, mu_0 a dummy): the chains start at row 1
   k->ldl_npos = c->nq;
   const size_t kk = (size_t)K * K;
@@ -2180,6 +2180,9 @@ static int MakeKkt(idto_hip_ctx* c, int nu) {
       return fail("hipMalloc (KKT context) failed");
     kc->allocs.push_back(p);
     kc->arena = static_cast<char*>(p);
+    if (getenv("IDTO_DEBUG_PTRS"))   // (investigation aid: where a faulting address lies)
+      fprintf(stderr, "kkt arena %p .. %p (pstride %zu x %d): H %zu g %zu step %zu U %zu Hs %zu E %zu Ds %zu dbg %zu xch %zu flags %zu ndcnt %zu pipecnt %zu ndbuf %zu ndwst %zu\n",
+              p, (void*)((char*)p + kc->pstride * (size_t)B), kc->pstride, B, o_H, o_g, o_step, o_U, o_Hs, o_E, o_Ds, o_dbg, o_xch, o_flags, o_ndcnt, o_pipecnt, o_ndbuf, o_ndwst);
   }
   auto dp = [&](size_t o) { return reinterpret_cast<double*>(kc->arena + o); };
   kc->HA = dp(o_H); kc->HB = kc->HA + (size_t)(N + 6) * kk; kc->HC = kc->HB + (size_t)(N + 6) * kk;
@@ -2788,7 +2791,7 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "solver_pipe") == 0) { c->solver_pipe = value != 0; return 0; }
   if (std::strcmp(name, "solver_band") == 0) { c->solver_band = value; if (c->kkt) c->kkt->solver_band = value; return 0; }
   if (std::strcmp(name, "asm_in_solver") == 0) { c->asm_in_solver = value != 0; return 0; }
-  if (std::strcmp(name, "debug_skip_role") == 0) { c->debug_skip_role = value; return 0; }   // test aid
+  if (std::strcmp(name, "debug_skip_role") == 0) { c->debug_skip_role = value; if (c->kkt) c->kkt->debug_skip_role = value; return 0; }   // test aid
   if (std::strcmp(name, "debug_pipe_tail") == 0) { c->debug_pipe_tail = value; return 0; }   // measurement aid
   if (std::strcmp(name, "asm_fold") == 0) { c->asm_fold = value != 0; c->terms_valid = false; return 0; }
   if (std::strcmp(name, "con_kkt") == 0) { c->con_kkt = value != 0; return 0; }

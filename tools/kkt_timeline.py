@@ -17,6 +17,9 @@ for kv in os.environ.get("IDTO_TIMELINE_OPTS", "").split(","):
 args = (SCALING[sp.scaling_method] if sp.scaling else -1, sp.scaling, False, sp.Delta0, sp.Delta_max)
 dev.set_q(np.asarray(q_guess)); dev.eval_tau()
 dev.tr_solve(3, *args, constrained_dofs=model.unactuated_dofs)
+for kv in os.environ.get("IDTO_TIMELINE_OPTS_LATE", "").split(","):
+    if "=" in kv:
+        dev.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 dev.set_option("solver_debug", 2)
 dev.set_q(np.asarray(q_guess)); dev.eval_tau()
 dev.tr_solve(2, *args, constrained_dofs=model.unactuated_dofs)
