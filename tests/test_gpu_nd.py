@@ -76,6 +76,38 @@ def test_nested_dissection_solver(name, N, pipe):
     dev.close()
 
 
+@pytest.mark.parametrize("N", [24, 25, 30, 33, 40, 47, 54, 60])
+def test_seven_workgroup_back_substitution_in_recursion_form_over_the_horizons(N):
+    """penta_pipe.h chain_recursion_tail: allegro's 23 x 23 blocks on the seven-workgroup kernel with the
+    back substitution in recursion form (W in global memory, formed by the pair's producer) against the row-by-row
+    tail of the same kernel and the bit-exact restatement of the reference's solver, at horizons that give the four
+    chains every mix of lengths (even / odd halves, 5 .. 16 rows)."""
+    cfg, model, prob, sp, q = _setup("allegro_hand", N)
+    dev = hip.HipPath(model, prob, sp)
+    dev.set_q(q)
+    steps = {}
+    for rec in (1, 0):
+        dev.set_option("nd_recursion", rec)
+        dev.gn_step()
+        assert dev.get_option("last_solver") == 2 and dev.solver_status() == (False, 0)
+        steps[rec] = dev.get("step")
+        for _ in range(2):   # (epoch-valued flags and counters: the bits repeat)
+            dev.factor_solve()
+            assert np.array_equal(dev.get("step"), steps[rec])
+    dev.set_option("reference_solver", 1)
+    dev.factor_solve()
+    p_lu = dev.get("step")
+    orc = Oracle(model, prob, sp)
+    g, bands = orc.grad_hess(q)
+    p_ref, unc = ol.refined_solution(ol.penta_make_dense(*bands), -g.ravel())
+    pn = np.abs(p_ref).max()
+    err = lambda x: np.abs(x.ravel() - p_ref).max() / pn
+    assert not np.array_equal(steps[1], steps[0]), "the option did not change the tail: the case tests nothing"
+    for rec in (1, 0):
+        assert err(steps[rec]) <= 4 * err(p_lu) + 16 * unc + 1e-12, (rec, err(steps[rec]), err(p_lu))
+    dev.close()
+
+
 def test_reference_penta_diagonal_case_through_nd():
     """penta_diagonal_solver_test.cc:188-257 (SPD block penta-diagonal system, known solution) at a
     size the nested-dissection kernel takes (bands written into the context, explicit right-hand side)"""

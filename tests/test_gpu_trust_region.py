@@ -188,7 +188,8 @@ def test_resident_loop_rows_and_failure():
 
 
 @pytest.mark.parametrize("name,N,iters", [("hopper", 40, 12), ("acrobot", 40, 20), ("spinner", 40, 15), ("allegro_hand", 12, 4),
-                                            ("hopper", 50, 8), ("allegro_hand", 30, 3)])   # (the last two: n_eq 150 / 180 > 128, blocked LDL^T)
+                                            ("hopper", 50, 8), ("allegro_hand", 30, 3),    # (these two: n_eq 150 / 180 > 128, blocked LDL^T)
+                                            ("allegro_hand", 40, 3)])   # (the MPC horizon: 29 x 29 KKT blocks, back substitution in recursion form)
 @pytest.mark.parametrize("kkt", [1, 0])
 def test_resident_loop_with_equality_constraints_follows_the_host_loop(name, N, iters, kkt, monkeypatch):
     """enforced equality constraints (the example YAMLs of acrobot, spinner, hopper, allegro): the resident loop
