@@ -247,10 +247,10 @@ struct ChainCfg {
   double* wst;
   double* xjoin_ll;
   // ... and the pair's PRODUCER forms the joiner's W rows (it is idle for longer): the joiner's rows (local row il is
-  // matrix row wp_base -/+ il), its spike workgroup's rows and counters, its wst; wflag = epoch once they are all there
+  // matrix row wp_base -/+ il), its spike workgroup's rows and counters, its wst; wrow[il] = epoch once row il of W is there
   int wp_nloc, wp_base, wp_mirror, wp_waves;
   const double* wp_fst; const unsigned long long* wp_frowcnt; double* wp_wst;
-  unsigned* wflag;
+  unsigned* wrow;
 };
 // pivot test of a lane that holds a pivot's 1 / d (`inv`; NaN for d = 0 / inf / NaN) and the diagonal entry the pivot
 // started from: positive, finite, and not cancelled to nothing (d <= eps diag0).  Other lanes pass inv = diag0 = 1.

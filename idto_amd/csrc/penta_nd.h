@@ -717,7 +717,8 @@ __global__ void __launch_bounds__(256) penta_nd_kernel(NdArgs A) {
   }
   c.rec_tail = A.rec_tail && A.wst; c.lds_doubles = A.lds_doubles;
   c.xjoin_ll = A.ndbuf + B.ll + (1 + pair) * 4 * K;
-  c.wflag = A.flags + 2 * pair + 1;   // (the row-by-row form's x_join flag, unused in recursion form)
+  // (one word per row of W, behind what the pair's exchange buffer holds: two augmented blocks and the join rows of x)
+  c.wrow = reinterpret_cast<unsigned*>(A.xch + (size_t)pair * A.xch_pair + ((2 * (3 * K + 1) * ldl_ks(K) + 2 * K + 1) & ~1));
   if (c.rec_tail && role < 2) {       // the joiner of this producer's pair
     c.wp_mirror = (pair == 0); c.wp_base = (pair == 0) ? A.s - 1 : A.s + 2;
     c.wp_nloc = (pair == 0) ? A.s - A.j1 : A.j2 - A.s;

@@ -1133,8 +1133,32 @@ __device__ __forceinline__ void pipe_backward(const PipeArgs& A, const ChainCfg&
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
     solve(Us, xr);
     __atomic_signal_fence(__ATOMIC_SEQ_CST);   // (the staged U may sit where the results go)
+    if (partner) {
+      // a row of W for the joiner: write-through stores, their acknowledgements, then the row's word - the joiner
+      // fetches a row as soon as its word is there (one flag for all rows left the whole fetch, 92 loads per thread and
+      // ~4 us, behind the last row).  The stores go out lanes side by side (scattered 8-byte write-through stores - a
+      // column per lane, as the registers hold it - cost four times as much): a half of the row at a time through the
+      // wavefront's scratch, which the substitution no longer needs.
+      double* Tw = Us;
+      double* wrow_dst = cfg.wp_wst + (size_t)il * A.fstride;
 #pragma unroll
-    for (int r = 0; r < K; ++r) dst[r * dstride] = xr[r];
+      for (int half = 0; half < 2; ++half) {
+        if (lane >= half * K && lane < half * K + K) {
+#pragma unroll
+          for (int r = 0; r < K; ++r) Tw[(lane - half * K) * ks + r] = xr[r];
+        }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+#pragma unroll
+        for (int t = 0; t < NU; ++t)
+          if (lane + 64 * t < KS2) __hip_atomic_store(wrow_dst + half * KS2 + lane + 64 * t, Tw[lane + 64 * t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(cfg.wrow + il, A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+#pragma unroll
+      for (int r = 0; r < K; ++r) dst[r * dstride] = xr[r];
+    }
   };
   if (WGLOB) {
     // A producer's two lists: its own rows (needed when x of the join rows arrives, late) and the partner's W rows
@@ -1163,7 +1187,6 @@ __device__ __forceinline__ void pipe_backward(const PipeArgs& A, const ChainCfg&
         ready = there(nxt);
       }
     }
-    if (cfg.wp_wst) __threadfence();
   } else {
     for (int task = wave; task < (SPK ? 2 : 1) * nloc; task += nwaves) {
       const int pass = task >= nloc ? 1 : 0;
@@ -1171,27 +1194,28 @@ __device__ __forceinline__ void pipe_backward(const PipeArgs& A, const ChainCfg&
     }
   }
   __syncthreads();
-  if (WGLOB && cfg.wp_wst && tid == 0) __hip_atomic_store(cfg.wflag, A.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   chain_ts(cfg, 3);
   if (cfg.ts && tid == 0) cfg.ts[6] = (double)wall_clock64();
   // ---- phase 2 (spike chains): once the separator is solved, c_i -= W_i [x_near ; x_far]
   if (WGLOB && cfg.fst) {
-    if (tid == 0) spin_wait([&] { return __hip_atomic_load(cfg.wflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.epoch; }, cfg.spin);
-    __syncthreads();
-    (void)__hip_atomic_load(cfg.wflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-    if (cfg.ts && tid == 0) cfg.ts[7] = (double)wall_clock64();
     // a thread per (row, component), two of them per thread at most (pipe_recursion_tail_fits); the rows of W are in
-    // registers before the wait
+    // registers before the wait for the separator.  Each thread waits for the word of ITS row (the producer sets it
+    // after the row's stores): the first elements are the early rows, fetched long before the last row exists.
     const int nt = blockDim.x;
     const int pidx = (tid < nloc * K) ? tid : 0, pil = pidx / K, pr = pidx - pil * K;
     const int qidx = (tid + nt < nloc * K) ? tid + nt : 0, qil = qidx / K, qr = qidx - qil * K;
     double f[2 * K], f2[2 * K];
     {
+      spin_wait([&] { return __hip_atomic_load(cfg.wrow + pil, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.epoch; }, cfg.spin);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       const double* F = A.wst + (size_t)pil * A.fstride + pr;
 #pragma unroll
       for (int c = 0; c < 2 * K; ++c) f[c] = F[c * ks];
 #pragma unroll
       for (int c = 0; c < 2 * K; ++c) asm volatile("" : "+v"(f[c]));
+      if (cfg.ts && tid == 0) cfg.ts[7] = (double)wall_clock64();
+      spin_wait([&] { return __hip_atomic_load(cfg.wrow + qil, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.epoch; }, cfg.spin);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       const double* F2 = A.wst + (size_t)qil * A.fstride + qr;
 #pragma unroll
       for (int c = 0; c < 2 * K; ++c) f2[c] = F2[c * ks];

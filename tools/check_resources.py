@@ -32,8 +32,8 @@ LIMITS = {
     "penta_band_kernel<9>": (0, 112, 4 + 24),
     "penta_band_kernel<12>": (0, 112, 18 + 24),
     "penta_band_kernel<15>": (0, 112, 22 + 24),
-    "penta_nd_kernel<23, false>": (0, 0, 584 + 24),
-    "penta_nd_kernel<29, false>": (6, 0, 845 + 24),
+    "penta_nd_kernel<23, false>": (0, 0, 585 + 24),
+    "penta_nd_kernel<29, false>": (6, 0, 869 + 24),
     "assemble_terms_kernel": (0, 0, 6 + 24),
     "tr_iter_kernel": (0, 0, 29 + 24),
     "cost_kernel": (0, 0, 7 + 24),
