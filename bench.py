@@ -219,7 +219,7 @@ def mpc_replan(cfg, model, device, replans=50):
         if i:
             x = mpc.state(t)
         t0 = time.perf_counter()
-        mpc.update(t, x[:model.nq], x[model.nq:])
+        mpc.update(t, x[:model.nq], x[model.nq:], copy=False)   # (the controller's own output buffers, as a C++ caller holds them)
         times.append(time.perf_counter() - t0)
     ts = np.sort(np.array(times[10:])) * 1e3
     mpc.close(); opt1.close(); opt.close()

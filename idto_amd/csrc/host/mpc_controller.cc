@@ -92,13 +92,19 @@ void PiecewiseCubic::Fit(const std::vector<double>& breaks) {
 }
 
 VectorXd PiecewiseCubic::value(double t) const {
+  VectorXd out((size_t)dim_);
+  value(t, &out);
+  return out;
+}
+void PiecewiseCubic::value(double t, VectorXd* out_ptr) const {
   if (t_.empty()) throw std::runtime_error("PiecewiseCubic: empty trajectory");
   const int n = (int)t_.size();
   t = std::min(std::max(t, t_.front()), t_.back());
   int i = (int)(std::upper_bound(t_.begin(), t_.end(), t) - t_.begin()) - 1;
   i = std::min(std::max(i, 0), n - 2);
   const double h = t_[i + 1] - t_[i], s = t - t_[i];
-  VectorXd out((size_t)dim_);
+  VectorXd& out = *out_ptr;
+  out.resize((size_t)dim_);
   for (int c = 0; c < dim_; ++c) {
     const double y0 = y_[(size_t)i * dim_ + c], y1 = y_[(size_t)(i + 1) * dim_ + c];
     const double m0 = m_[(size_t)i * dim_ + c], m1 = m_[(size_t)(i + 1) * dim_ + c];
@@ -106,7 +112,6 @@ VectorXd PiecewiseCubic::value(double t) const {
     const double c2 = (3 * d - 2 * m0 - m1) / h, c3 = (m0 + m1 - 2 * d) / (h * h);
     out[c] = y0 + s * (m0 + s * (c2 + s * c3));
   }
-  return out;
 }
 
 // ---- ModelPredictiveController (mpc_controller.cc:13-41)
@@ -141,7 +146,10 @@ const StoredTrajectory& ModelPredictiveController::UpdateAbstractState(double ti
   idto_hip_trace_mark("mpc: UpdateAbstractState begins");
   const VectorXd q0(x0.begin(), x0.begin() + nq_), v0(x0.begin() + nq_, x0.end());
   // the initial guess from the stored solution, consistent with the initial condition (:55-58)
-  std::vector<VectorXd> q_guess((size_t)num_steps_, VectorXd((size_t)nq_));
+  // (the three trajectories below live in the controller: 120 small vectors allocated and freed per re-plan were ~10 us
+  // of a 0.2 ms call)
+  std::vector<VectorXd>& q_guess = guess_scratch_;
+  if ((int)q_guess.size() != num_steps_) q_guess.assign((size_t)num_steps_, VectorXd((size_t)nq_));
   UpdateInitialGuess(stored_, time, &q_guess);
   q_guess[0] = q0;
   warm_start_->set_q(q_guess);
@@ -150,10 +158,12 @@ const StoredTrajectory& ModelPredictiveController::UpdateAbstractState(double ti
   // shift the nominal trajectory for some DoFs, if requested (:60-69)
   const ProblemDefinition& prob = optimizer_->prob();
   const VectorXd q0_nom_old = prob.q_nom[0];
-  std::vector<VectorXd> q_nom_new = prob.q_nom;
+  std::vector<VectorXd>& q_nom_new = q_nom_scratch_;
+  q_nom_new = prob.q_nom;
   for (VectorXd& qt_nom : q_nom_new)
     for (int i = 0; i < nq_; ++i) qt_nom[i] += (selector[i] ? 1.0 : 0.0) * (q0[i] - q0_nom_old[i]);
-  const std::vector<VectorXd> v_nom = prob.v_nom;
+  std::vector<VectorXd>& v_nom = v_nom_scratch_;
+  v_nom = prob.v_nom;
   optimizer_->UpdateNominalTrajectory(q_nom_new, v_nom);
   idto_hip_trace_mark("mpc: nominal trajectory shifted");
   // solve from the new initial condition (:71-75)
@@ -178,7 +188,7 @@ void ModelPredictiveController::UpdateInitialGuess(const StoredTrajectory& store
                                                    std::vector<VectorXd>* q_guess) const {
   if ((int)q_guess->size() != num_steps_) throw std::invalid_argument("UpdateInitialGuess: q_guess must have num_steps + 1 entries");
   const double start_time = current_time - stored_trajectory.start_time;
-  for (int i = 0; i < num_steps_; ++i) (*q_guess)[i] = stored_trajectory.q.value(start_time + i * time_step_);
+  for (int i = 0; i < num_steps_; ++i) stored_trajectory.q.value(start_time + i * time_step_, &(*q_guess)[i]);   // (in place: no temporary per step)
 }
 
 // StoreOptimizerSolution (:99-138)

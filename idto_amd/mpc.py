@@ -143,17 +143,31 @@ class DeviceModelPredictiveController:
     def __del__(self):
         self.close()
 
-    def update(self, t, q0, v0):
-        """UpdateAbstractState: returns (q_guess, q, v, tau) of this replan"""
+    def _buffers(self):
+        """the re-plan's input / output buffers and their ctypes pointers, made once: a re-plan is ~0.2 ms, five fresh
+        arrays, five pointer casts and two byref objects per call were 15 - 20 us of it on the Python side"""
         O, C = self._O, self._C
-        x0 = O._d(np.concatenate([q0, v0]))
-        g = np.zeros((self.N + 1, self.nq)); q = np.zeros((self.N + 1, self.nq)); v = np.zeros((self.N + 1, self.nv))
-        tau = np.zeros((self.N, self.nv))
-        cost, flag = C.c_double(), C.c_int()
-        self._chk(O.lib().idto_mpc_update(self._h, float(t), O.dptr(x0), O.dptr(g), O.dptr(q), O.dptr(v), O.dptr(tau),
-                                          C.byref(cost), C.byref(flag)))
+        b = getattr(self, "_buf", None)
+        if b is None:
+            x0 = np.zeros(self.nq + self.nv)
+            g, q = np.zeros((self.N + 1, self.nq)), np.zeros((self.N + 1, self.nq))
+            v, tau = np.zeros((self.N + 1, self.nv)), np.zeros((self.N, self.nv))
+            cost, flag = C.c_double(), C.c_int()
+            ptrs = tuple(O.dptr(a) for a in (x0, g, q, v, tau)) + (C.byref(cost), C.byref(flag))
+            b = self._buf = (x0, g, q, v, tau, cost, flag, ptrs, O.lib().idto_mpc_update)
+        return b
+
+    def update(self, t, q0, v0, copy=True):
+        """UpdateAbstractState: returns (q_guess, q, v, tau) of this replan.  copy=False: the controller's own output
+        buffers, overwritten by the next update (what a C++ caller of idto_mpc_update holds)"""
+        x0, g, q, v, tau, cost, flag, ptrs, fn = self._buffers()
+        x0[:self.nq] = q0
+        x0[self.nq:] = v0
+        if fn(self._h, t, *ptrs):
+            raise RuntimeError(self._O.lib().idto_opt_last_error().decode())
         self.last_cost = cost.value
-        return g, q, v, tau
+        self.last_flag = flag.value
+        return (g.copy(), q.copy(), v.copy(), tau.copy()) if copy else (g, q, v, tau)
 
     @property
     def start_time(self):

@@ -46,6 +46,7 @@ class PiecewiseCubic {
   int rows() const { return dim_; }
   // the value at t clamped to [start_time, end_time] (drake::trajectories::PiecewisePolynomial::value)
   VectorXd value(double t) const;
+  void value(double t, VectorXd* out) const;   // (the same into existing storage)
 
  private:
   int dim_ = 0;
@@ -107,6 +108,7 @@ class ModelPredictiveController {
   mutable std::vector<double> times_, u_flat_;   // work space of StoreOptimizerSolution
   optimizer::SolverFlag last_flag_{optimizer::SolverFlag::kSuccess};
   std::vector<VectorXd> last_guess_;
+  std::vector<VectorXd> guess_scratch_, q_nom_scratch_, v_nom_scratch_;   // (UpdateAbstractState's work trajectories: no allocation per re-plan)
   double replan_period_;
   std::vector<bool> selector_override_;
 };

@@ -175,6 +175,8 @@ def test_cpp_shell_replans_like_the_python_shell():
             traj = py.update(t, q0, v0)
             g, q, v, tau = cc.update(t, q0, v0)
             assert np.array_equal(g[0], q0) and cc.start_time == t
+            assert all(np.array_equal(a, b) and a is not b for a, b in zip((g, q, v, tau), cc._buf[1:5]))   # (copies of the controller's buffers; copy=False hands out the buffers)
+            assert cc.last_flag in (0, 3)   # (kSuccess or kMaxIterationsReached: the example runs mpc_iters iterations)
             assert np.abs(g - opt_py_guess(py, opt_py)).max() <= 1e-9 * scale
             assert np.abs(q - np.asarray(traj.q(py.time_step * np.arange(py.num_steps)))).max() <= 1e-7 * scale
             for tq in (t, t + 0.4 * period, t + 3.3 * period, t + 100.0):

@@ -34,7 +34,7 @@ for name in (sys.argv[1:] or ["mini_cheetah", "hopper", "spinner", "allegro_hand
         t = i * period
         x = mpc.state(t) if i else np.concatenate([q0, v0])
         t0 = time.perf_counter()
-        mpc.update(t, x[:model.nq], x[model.nq:])
+        mpc.update(t, x[:model.nq], x[model.nq:], copy=False)   # (the controller's own output buffers, as a C++ caller holds them)
         times.append(time.perf_counter() - t0)
     ts = np.sort(np.array(times[10:])) * 1e3
     print(f"{name}: N={prob.num_steps}, mpc_iters {iters}, constraints {'enforced' if sp.equality_constraints else 'off'}: re-plan "

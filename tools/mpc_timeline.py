@@ -58,7 +58,7 @@ for name in (sys.argv[1:] or ["mini_cheetah", "hopper", "spinner", "allegro_hand
         x = mpc.state(t) if i else np.concatenate([q0, v0])
         L.idto_hip_trace_enable(1)
         t0 = time.perf_counter()
-        mpc.update(t, x[:model.nq], x[model.nq:])
+        mpc.update(t, x[:model.nq], x[model.nq:], copy=False)   # (the controller's own output buffers, as a C++ caller holds them)
         walls.append((time.perf_counter() - t0) * 1e6)
         ev = dump()
         L.idto_hip_trace_enable(0)
