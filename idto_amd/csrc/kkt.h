@@ -55,6 +55,35 @@ __global__ void kkt_build_kernel(KktBuildArgs A) {
   A.HA = at_problem(A.HA, o); A.HB = at_problem(A.HB, o); A.HC = at_problem(A.HC, o); A.g = at_problem(A.g, o);
   A.KA = at_problem(A.KA, ok); A.KB = at_problem(A.KB, ok); A.KC = at_problem(A.KC, ok); A.rhs = at_problem(A.rhs, ok);
   const double* slab = at_problem(A.slab, o + (size_t)alt_offset(A.alt, o));
+  // a group of 32 lanes per (band, column) pair, lane = row (K <= 32); wider blocks: the general loop below.
+  // (One flat index per entry cost two divisions by run-time numbers and a third inside jac_entry: 6.6 of the kernel's
+  // 11.6 us at allegro's 29 x 29.)  The entries of J come straight from the slab's records: row (t - 1, dof) of J against
+  // block column s = t - 2 + band is block `band` of record t - 1 (dtau_{t-1}/dq_{t-2}, /dq_{t-1}, /dq_t), and the
+  // transposed entries are non-zero in the diagonal block only (jac_entry's rules: q_0 is no variable).
+  if (K <= 32 && (blockDim.x & 31) == 0) {
+    const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5, ngrp = blockDim.x >> 5;
+    const double* rec = (t >= 1) ? slab + (size_t)(t - 1) * A.slab_stride : slab;
+    for (int bc = grp; bc < 3 * K; bc += ngrp) {
+      const int band = bc / K, c = bc - band * K, s = t - 2 + band, r = lane;
+      if (r >= K) continue;
+      double v = 0.0;
+      if (s >= 0) {
+        if (r < nq && c < nq) {
+          const double* Hb = (band == 0) ? A.HA : (band == 1) ? A.HB : A.HC;
+          v = Hb[(size_t)t * qq + c * nq + r];
+        } else if (r >= nq && c < nq) {   // mu_t's row: J_{t-1, s}[dof, c]
+          const bool zero = t < 1 || (band == 0 && t - 1 < 2) || (band == 1 && t - 1 < 1);
+          if (!zero) v = rec[(size_t)band * nv * nq + c * nv + A.dofs[r - nq]];
+        } else if (r < nq) {              // mu_s's column: J_{s-1, t}^T, the diagonal block's only
+          if (band == 2 && t >= 1) v = rec[(size_t)2 * nv * nq + r * nv + A.dofs[c - nq]];
+        } else if (t == 0 && band == 2 && r == c) {
+          v = 1.0;                        // the dummy mu_0
+        }
+      }
+      double* Kb = (band == 0) ? A.KA : (band == 1) ? A.KB : A.KC;
+      Kb[(size_t)t * kk + c * K + r] = v;
+    }
+  } else
   for (int idx = threadIdx.x; idx < 3 * kk; idx += blockDim.x) {
     const int band = idx / kk, e = idx - band * kk, c = e / K, r = e - c * K;   // band 0: M_{t,t-2}, 1: M_{t,t-1}, 2: M_{t,t}
     const int s = t - 2 + band;                                                // block column
