@@ -57,7 +57,7 @@ def algorithmic_bytes(N, nq, nv):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate
-    FETCH_SIZE and WRITE_SIZE runs of this same command, tools/gpu_check.sh ->
+    FETCH_SIZE and WRITE_SIZE runs of this same command, tools/gpu.sh check ->
     tools/pmc_summarize.py): FETCH_SIZE doubled per the gfx950 correction of
     MI355X_MICROARCH.md, WRITE_SIZE raw.  None when no summary is committed."""
     import glob

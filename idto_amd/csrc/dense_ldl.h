@@ -175,6 +175,26 @@ dense_ldl_step_kernel(double* __restrict__ S, double* __restrict__ Lm, int n, in
   }
 }
 
+// H as a dense matrix (reference PentaDiagonalMatrix::MakeDense, optimizer/penta_diagonal_matrix.cc:107-140, which
+// SolveLinearSystemInPlace's kDenseLdlt branch factorises: optimizer/trajectory_optimizer.cc:2088-2093): the lower
+// triangle of the n x n column-major matrix from the lower bands A (two block rows below the diagonal), B (one), C
+// (diagonal; its lower triangle is read), blocks column-major bs x bs, block row t at t * bs * bs.  One workgroup per
+// block column; entries outside the band are zeroed (the factorisation fills the whole trailing triangle).
+__global__ void __launch_bounds__(256)
+dense_from_bands_kernel(const double* __restrict__ A, const double* __restrict__ B, const double* __restrict__ C, int nblk,
+                        int bs, double* __restrict__ S) {
+  const int s = blockIdx.x, n = nblk * bs, rows = n - s * bs;
+  for (int idx = threadIdx.x; idx < rows * bs; idx += blockDim.x) {
+    const int c = idx / rows, rr = idx % rows;          // column c of block column s, row s * bs + rr
+    const int dt = rr / bs, r = rr % bs, t = s + dt;
+    double v = 0.0;
+    if (dt == 0) v = (r >= c) ? C[(size_t)t * bs * bs + (size_t)c * bs + r] : 0.0;
+    else if (dt == 1) v = B[(size_t)t * bs * bs + (size_t)c * bs + r];
+    else if (dt == 2) v = A[(size_t)t * bs * bs + (size_t)c * bs + r];
+    S[(size_t)(s * bs + c) * n + s * bs + rr] = v;
+  }
+}
+
 // x = S^-1 b from the factors (L strictly lower in S, d in dvec); one workgroup, b and x in LDS
 __global__ void __launch_bounds__(512)
 dense_ldl_solve_kernel(const double* __restrict__ S, int n, const double* __restrict__ dvec,

@@ -133,6 +133,10 @@ int idto_opt_create_multi(const idto_model_t* model, const idto_problem_t* p, co
     params.Delta0 = sp->Delta0;
     params.Delta_max = sp->Delta_max;
     params.num_threads = sp->num_threads;
+    params.print_debug_data = sp->print_debug_data != 0;
+    params.debug_compare_against_dense = sp->debug_compare_against_dense != 0;
+    params.exact_hessian = sp->exact_hessian != 0;
+    params.save_contour_data = sp->plot_dumps != 0;
     params.contact_stiffness = c->contact_stiffness;
     params.dissipation_velocity = c->dissipation_velocity;
     params.stiction_velocity = c->stiction_velocity;

@@ -253,6 +253,9 @@ TO::TrajectoryOptimizer(const idto_model_t& model, double time_step, const Probl
       params_.gradients_method != kCentralDifferences4)
     throw std::runtime_error("TrajectoryOptimizer (HIP): gradients_method must be a finite-difference method (kAutoDiff needs Drake)");
   if (params_.exact_hessian) throw std::runtime_error("TrajectoryOptimizer (HIP): exact_hessian needs autodiff");
+  if (params_.save_contour_data || params_.save_lineplot_data || params_.linesearch_plot_every_iteration)
+    throw std::runtime_error("TrajectoryOptimizer (HIP): the plotting dumps (save_contour_data, save_lineplot_data, "
+                             "linesearch_plot_every_iteration: TO.cc:1650-1830) are not produced by this build");
   for (int b = 0; b < model.nbodies; ++b) {
     const int jt = model.jtype[b];
     if (jt == IDTO_JOINT_FLOATING) quaternion_starts_.push_back(nq_);
@@ -463,7 +466,7 @@ void TO::CalcGradHess(const TrajectoryOptimizerState<T>& state) const {
   if (params_.equality_constraints && num_equality_constraints() > 0) {
     Scope prof2_("  launch constraint solve");
     Check(idto_hip_constraint_schur_begin(dev(), unactuated_dofs_.data(), (int)unactuated_dofs_.size()));
-  } else {
+  } else if (!DenseLinearSolver()) {
     Check(idto_hip_factor_solve(dev(), nullptr, 1, nullptr));  // IDTO_ARR_STEP = -H^-1 g
     c.step_on_device = true;
   }
@@ -591,6 +594,80 @@ const MatrixXd& TO::EvalEqualityConstraintJacobian(const TrajectoryOptimizerStat
   return c.J_scaled;
 }
 
+// TO.cc:2077-2096: the block Thomas algorithm (default) or a dense LDL^T of MakeDense(), both on the device, for
+// the Hessian of `s` (unscaled: see EvalHinvMeritGradient).
+bool TO::DenseLinearSolver() const { return params_.linear_solver == SolverParameters::LinearSolverType::kDenseLdlt; }
+void TO::SolveLinearSystem(const TrajectoryOptimizerState<T>& s, const VectorXd& b, VectorXd* x, int solver) const {
+  EvalGradient(s);
+  EnsureDevice(s, 3);
+  x->resize(b.size());
+  const bool dense = solver < 0 ? DenseLinearSolver() : solver == 0;
+  if (dense) Check(idto_hip_solve_dense_ldlt(dev(), b.data(), x->data()));
+  else Check(idto_hip_solve_host(dev(), b.data(), 1, x->data()));
+}
+
+// print_debug_data's "condition number" (TO.cc:2351, :2503-2504): 1 / H.MakeDense().ldlt().rcond().  Eigen's rcond()
+// is ||H||_1 times Hager's estimate of ||H^-1||_1 with Higham's alternating-sign safeguard (Eigen/src/Core/
+// ConditionEstimator.h, rcond_invmatrix_L1_norm_estimate: at most 2 + 2 * 4 solves); restated here with the solves on the
+// device (dense LDL^T, as the reference's).  scaled: H~ = D H D, whose inverse is applied as D^-1 H^-1 D^-1.
+double TO::DebugConditionNumber(const TrajectoryOptimizerState<T>& s, bool scaled) const {
+  const int n = num_vars();
+  const PentaDiagonalMatrix<T>& H = scaled ? EvalScaledHessian(s) : EvalHessian(s);
+  const Vec* D = (scaled && params_.scaling) ? &EvalScaleFactors(s) : nullptr;
+  // the matrix 1-norm, the largest absolute column sum (= row sum: H is symmetric)
+  double norm1 = 0;
+  {
+    const int nb = H.block_rows(), bs = H.block_size();
+    for (int i = 0; i < nb; ++i)
+      for (int r = 0; r < bs; ++r) {
+        double sum = 0;
+        auto add = [&](const double* M) { for (int cc = 0; cc < bs; ++cc) sum += std::fabs(M[(std::size_t)cc * bs + r]); };
+        if (i >= 2) add(H.block(H.A(), i));
+        if (i >= 1) add(H.block(H.B(), i));
+        add(H.block(H.C(), i));
+        if (i + 1 < nb) add(H.block(H.D(), i));
+        if (i + 2 < nb) add(H.block(H.E(), i));
+        norm1 = std::max(norm1, sum);
+      }
+  }
+  if (norm1 == 0) return std::numeric_limits<double>::infinity();
+  auto solve = [&](Vec v) {
+    if (D) for (int i = 0; i < n; ++i) v[i] /= (*D)[i];
+    Vec x;
+    SolveLinearSystem(s, v, &x, /*dense*/ 0);
+    if (D) for (int i = 0; i < n; ++i) x[i] /= (*D)[i];
+    return x;
+  };
+  auto l1 = [](const Vec& v) { double a = 0; for (double x : v) a += std::fabs(x); return a; };
+  Vec v = solve(Vec((std::size_t)n, 1.0 / n));
+  double lower = l1(v);
+  if (n > 1) {
+    Vec sign((std::size_t)n), old_sign;
+    int imax = -1, old_imax = -1;
+    for (int k = 0; k < 4; ++k) {
+      for (int i = 0; i < n; ++i) sign[i] = v[i] >= 0 ? 1.0 : -1.0;
+      if (k > 0 && sign == old_sign) break;
+      v = solve(sign);   // (H is symmetric: the adjoint solve is the solve)
+      imax = 0;
+      for (int i = 1; i < n; ++i) if (std::fabs(v[i]) > std::fabs(v[imax])) imax = i;
+      if (imax == old_imax) break;
+      Vec e((std::size_t)n, 0.0);
+      e[imax] = 1.0;
+      v = solve(e);
+      const double old_lower = lower;
+      lower = l1(v);
+      if (lower <= old_lower) break;
+      old_sign = sign;
+      old_imax = imax;
+    }
+    double alt = 1.0;
+    for (int i = 0; i < n; ++i) { v[i] = alt * (1.0 + double(i) / double(n - 1)); alt = -alt; }
+    v = solve(v);
+    lower = std::max(lower, 2 * l1(v) / (3.0 * n));
+  }
+  return norm1 * lower;
+}
+
 // H^-1 g_merit with the unscaled H, where g_merit = g + J^T lambda (g when there are no equality
 // constraints).  Everything the iteration needs from a factorisation of the scaled H~ = D H D
 // follows from it:  H~^-1 g~_merit = D^-1 H^-1 g_merit.
@@ -598,12 +675,23 @@ const VectorXd& TO::EvalHinvMeritGradient(const TrajectoryOptimizerState<T>& s) 
   auto& c = s.cache_;
   if (params_.equality_constraints && num_equality_constraints() > 0) {
     EvalLagrangeMultipliers(s);
+    if (DenseLinearSolver() && !c.hinv) {
+      // the multipliers come from the block Thomas factorisation whatever `linear_solver` says (TO.cc:1385, "add options
+      // for other linear systems solvers" is a TODO there); the dogleg's Newton step takes the selected solver (:2140)
+      const Vec& g = EvalGradient(s);
+      Vec gm(g.size());
+      for (std::size_t i = 0; i < g.size(); ++i) gm[i] = g[i] + c.JT_lambda[i];
+      SolveLinearSystem(s, gm, &c.Hinv_gm);
+      c.hinv = true;
+    }
     return c.Hinv_gm;
   }
   if (!c.hinv) {
     const Vec& g = EvalGradient(s);
     Scope prof_("device solve H^-1 g");
-    if (c.step_on_device && resident_ == &s && device_level_ == 3) {
+    if (DenseLinearSolver()) {
+      SolveLinearSystem(s, g, &c.Hinv_gm);
+    } else if (c.step_on_device && resident_ == &s && device_level_ == 3) {
       // launched right behind the assembly (CalcGradHess): -H^-1 g is waiting in device memory
       c.Hinv_gm = Fetch(IDTO_ARR_STEP);
       for (double& x : c.Hinv_gm) x = -x;
@@ -735,6 +823,23 @@ bool TO::CalcDoglegPoint(const TrajectoryOptimizerState<T>& s, double Delta, Vec
   {
     const Vec* D = params_.scaling ? &EvalScaleFactors(s) : nullptr;
     for (int i = 0; i < n; ++i) pH[i] = -(D ? y[i] / (*D)[i] : y[i]) / Delta;
+  }
+  if (params_.debug_compare_against_dense) {  // :2142-2150 (the reference's reference solution: dense LDL^T)
+    Vec gm_unscaled = EvalGradient(s), yd;   // g + J^T lambda, unscaled (see EvalHinvMeritGradient)
+    if (params_.equality_constraints && num_equality_constraints() > 0) {
+      EvalLagrangeMultipliers(s);
+      for (int i = 0; i < n; ++i) gm_unscaled[i] += s.cache_.JT_lambda[i];
+    }
+    SolveLinearSystem(s, gm_unscaled, &yd, /*dense*/ 0);
+    const Vec* D = params_.scaling ? &EvalScaleFactors(s) : nullptr;
+    double num = 0, den = 0;
+    for (int i = 0; i < n; ++i) {
+      const double pd = -(D ? yd[i] / (*D)[i] : yd[i]) / Delta;
+      num += (pH[i] - pd) * (pH[i] - pd);
+      den += pd * pd;
+    }
+    last_sparse_vs_dense_ = std::sqrt(num) / std::sqrt(den);
+    std::printf("Sparse vs. Dense error: %g\n", last_sparse_vs_dense_);
   }
   dqH->resize((std::size_t)n);
   for (int i = 0; i < n; ++i) (*dqH)[i] = pH[i] * Delta;  // :2152
@@ -930,7 +1035,14 @@ SolverFlag TO::SolveWithLinesearch(const std::vector<VectorXd>& q_guess, Traject
     EvalGradient(state);
     EnsureDevice(state, 3);
     for (std::size_t i = 0; i < rhs.size(); ++i) rhs[i] = -g[i];
-    Check(idto_hip_solve_host(dev(), rhs.data(), 1, dq.data()));
+    SolveLinearSystem(state, rhs, &dq);  // :2302
+    double debug_cond = 0, debug_diag_norm = 0;
+    if (params_.print_debug_data) {
+      debug_cond = DebugConditionNumber(state, false);
+      std::vector<double> diag;
+      EvalHessian(state).ExtractDiagonal(&diag);
+      debug_diag_norm = Norm(diag);
+    }
     const auto [alpha, ls_iters] = (params_.linesearch_method == kArmijo) ? ArmijoLinesearch(state, dq, &scratch)
                                                                          : BacktrackingLinesearch(state, dq, &scratch);
     if (ls_iters >= params_.max_linesearch_iterations) {
@@ -948,6 +1060,11 @@ SolverFlag TO::SolveWithLinesearch(const std::vector<VectorXd>& q_guess, Traject
     if (params_.verbose)
       std::printf("| %6d | %8.3f | %7.4f | %6d     | %8.8f | %10.3e | %10.3e |\n", k, cost, alpha, ls_iters, iter_time,
                   g_norm / cost, h_norm);
+    if (params_.print_debug_data) {  // :2349-2365 (the quantities of the iterate the step was computed at)
+      std::printf("Condition #: %g\n|| dq ||   : %g\n||  g ||   : %g\nL'         : %g\nL          : %g\nL' / L     : %g\n"
+                  "||diag(H)||: %g\n", debug_cond, dq_norm, g_norm, dL_dq * cost, cost, dL_dq, debug_diag_norm);
+      if (k > 0) std::printf("L[k] - L[k-1]: %g\n", cost - stats->iteration_costs[(std::size_t)k - 1]);
+    }
     stats->push_data(iter_time, cost, ls_iters, alpha, std::numeric_limits<double>::quiet_NaN(), state.norm(), dq_norm,
                      dq_norm, trust_ratio, g_norm, dL_dq, h_norm, cost);  // :2373-2385
     ++k;
@@ -994,6 +1111,8 @@ SolverFlag TO::SolveFromWarmStart(WarmStart* ws, TrajectoryOptimizerSolution<T>*
 bool TO::DeviceLoopEligible() const {
   if (std::getenv("IDTO_OPT_HOST_LOOP") || force_host_loop_) return false;
   if (!shard_ctx_.empty()) return false;
+  // the dense solver and the two debugging switches live in the stepwise loop (SolveLinearSystem, CalcDoglegPoint)
+  if (DenseLinearSolver() || params_.debug_compare_against_dense || params_.print_debug_data) return false;
   const bool constrained = params_.equality_constraints && num_equality_constraints() > 0;
   if (!constrained && !params_.check_convergence) return true;
   // enforced constraints and the convergence criteria: only the resident loop (idto_hip_tr_solve) has them on the
@@ -1126,8 +1245,12 @@ SolverFlag TO::SolveOnDevice(WarmStart* ws, TrajectoryOptimizerSolution<T>* solu
     // (the resident loop carries the cost on the device and `cost` is still the placeholder.  Every device
     // flag either throws or yields a converged row, so the stepwise loop below is not reached from here in normal
     // operation - but if it ever is, after the chunked early exit's truncation say, its trust ratio must not be
-    // formed against 0: fetch the iterate's cost.)
-    if (k < params_.max_iterations && !converged) cost = Fetch(IDTO_ARR_COST)[0];
+    // formed against 0.  The iterate's cost is in the last row: L(q_k + dq) if that step was accepted, L(q_k) if not -
+    // NOT IDTO_ARR_COST, which every trial point overwrites, a rejected one included.)
+    if (k < params_.max_iterations && !converged && ran > 0) {
+      const double* R = rows.data() + (std::size_t)(ran - 1) * IDTO_TR_ROW;
+      cost = (R[9] != 0.0) ? R[13] : R[0];
+    }
   }
   while (k < params_.max_iterations && !converged) {
     fetched = false;   // (the device moves on: what the resident loop brought along is stale)
@@ -1253,6 +1376,10 @@ SolverFlag TO::SolveFromWarmStartImpl(WarmStart* ws, TrajectoryOptimizerSolution
   }
   while (k < params_.max_iterations) {
     const bool active = CalcDoglegPoint(state, Delta, &dq, &dqH);  // :2497
+    if (params_.print_debug_data) {  // :2499-2507
+      std::printf("condition_number = %g\n", DebugConditionNumber(state, false));
+      std::printf("condition_number_scaled = %g\n", DebugConditionNumber(state, true));
+    }
     // a step that is not finite can only come from a Hessian the factorisation could not handle
     if (!std::isfinite(Dot(dq, dq))) throw FactorizationFailedError("idto_hip: the dogleg step is not finite");
     const Vec& g = EvalMeritFunctionGradient(state);

@@ -7,6 +7,7 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -50,7 +51,9 @@ struct HostTrace {
   std::vector<std::pair<std::string, double>> ev;
 };
 static HostTrace g_trace;
+static std::mutex g_trace_mu;   // (idto_hip_tr_solve_batch_constrained marks from several host threads)
 extern "C" void idto_hip_trace_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_trace_mu);
   g_trace.on = on != 0;
   g_trace.ev.clear();
   g_trace.ev.reserve(256);
@@ -58,12 +61,14 @@ extern "C" void idto_hip_trace_enable(int on) {
 }
 extern "C" void idto_hip_trace_mark(const char* label) {
   if (!g_trace.on) return;
+  std::lock_guard<std::mutex> lk(g_trace_mu);
   g_trace.ev.emplace_back(label, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - g_trace.t0).count());
 }
 // "<microseconds since enable> <label>\n" per mark; returns the number of bytes the whole text needs
 extern "C" int idto_hip_trace_dump(char* out, int cap) {
   std::string t;
   char buf[64];
+  std::lock_guard<std::mutex> lk(g_trace_mu);
   for (const auto& e : g_trace.ev) { std::snprintf(buf, sizeof buf, "%.1f ", e.second); t += buf; t += e.first; t += "\n"; }
   if (out && cap > 0) std::snprintf(out, (size_t)cap, "%s", t.c_str());
   return (int)t.size() + 1;
@@ -283,6 +288,8 @@ struct idto_hip_ctx {
   double* con_rv = nullptr;                                            // ... and L^-1 (h - J y_g), carried along by the factorisation
   double* con_L = nullptr;                                             // ... and the factor L (dense_ldl_step_kernel only reads S's panels)
   bool con_S_factored = false;                                         // con_S holds the LDL^T factors, not S
+  // SolverParameters::linear_solver = kDenseLdlt (idto_hip_solve_dense_ldlt): [H dense | L], pivots, [min, max], [r | y]
+  double *dn_S = nullptr, *dn_d = nullptr, *dn_stat = nullptr, *dn_rv = nullptr; int dn_n = 0;
   double* fetch_dev = nullptr; double* fetch_pin = nullptr; size_t fetch_cap = 0;   // idto_hip_tr_solve_fetch's staging
   // option "async_uploads": idto_hip_set_q / idto_hip_set_problem copy from pinned staging of the context - two buffers
   // taken in turn, an event each - and return without waiting (everything else the context does is ordered behind them on
@@ -1110,7 +1117,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   if (const char* e = getenv("IDTO_SOLVER_REFERENCE")) c->reference_solver = (e[0] == '1');
   if (const char* e = getenv("IDTO_TWO_SIDED")) c->two_sided = (e[0] == '1');   // (debugging aids: option defaults)
   if (const char* e = getenv("IDTO_FUSED")) c->fused = (e[0] == '1');
-  if (const char* e = getenv("IDTO_ND_MIN_ROWS")) c->nd_min_rows = std::max(12, std::atoi(e));
+  if (const char* e = getenv("IDTO_ND_MIN_ROWS")) c->nd_min_rows = std::max(16, std::atoi(e));
   if (const char* e = getenv("IDTO_ND_RECURSION")) c->nd_recursion = std::atoi(e) != 0;
   if (const char* e = getenv("IDTO_SOLVER_ND")) c->solver_nd = (e[0] == '1');
   if (const char* e = getenv("IDTO_SOLVER_PIPE")) c->solver_pipe = (e[0] == '1');
@@ -1801,6 +1808,54 @@ int idto_hip_solve_host(idto_hip_ctx* c, const double* rhs_host, int nrhs, doubl
   return FactorStatus(c);
 }
 
+static void LaunchDenseLdl(idto_hip_ctx* c, double* S, double* L, double* d, double* stat, double* rv, int neq, const double* b,
+                           double b_sign, const double* b2);
+static std::atomic<long> g_dense_solves{0};
+long idto_hip_dense_solve_count() { return g_dense_solves.load(); }   // (tests: which branch of SolveLinearSystemInPlace ran)
+
+// SolveLinearSystemInPlace's kDenseLdlt branch (reference optimizer/trajectory_optimizer.cc:2088-2093): H.MakeDense(),
+// LDL^T, solve.  The debugging / cross-checking solver of the reference (its default is the block Thomas algorithm): the
+// resident bands are spread into an n x n matrix (dense_from_bands_kernel), factorised by the blocked LDL^T of
+// dense_ldl.h - one launch per panel of 32 columns, the right-hand side's forward substitution carried along - and
+// substituted backwards by one workgroup.  Without pivoting (Eigen's ldlt() pivots on the diagonal): H is positive
+// definite whenever the block Thomas branch succeeds; a pivot that is not positive and finite is reported as
+// IDTO_HIP_FACTORIZATION_FAILED, where the reference's DRAKE_DEMAND(info() == Success) aborts.
+int idto_hip_solve_dense_ldlt(idto_hip_ctx* c, const double* rhs_host, double* x_host) {
+  HIP_OK(hipSetDevice(c->device));
+  if (!rhs_host || !x_host) { g_err = "solve_dense_ldlt: bad arguments"; return -1; }
+  if (c->batch != 1) { g_err = "solve_dense_ldlt serves single-problem contexts"; return -1; }
+  const int nblk = c->N + 1, bs = c->nq, n = nblk * bs;
+  ++g_dense_solves;
+  if (c->dn_n != n) {
+    Release(c, &c->dn_S); Release(c, &c->dn_d); Release(c, &c->dn_stat); Release(c, &c->dn_rv);
+    c->dn_n = 0;
+    if (Alloc(c, 2 * (size_t)n * n, &c->dn_S) || Alloc(c, (size_t)n, &c->dn_d) || Alloc(c, (size_t)2, &c->dn_stat) ||
+        Alloc(c, 3 * (size_t)n, &c->dn_rv))   // [r with the finished panels eliminated | y = L^-1 r | x]
+      return -2;
+    c->dn_n = n;
+  }
+  if (EnsureStage(c, (size_t)n)) return -2;
+  c->con_ready = false; c->con_begun = false;  // the staging buffers are shared with the constraint step
+  const double stat0[2] = {std::numeric_limits<double>::infinity(), 0.0};
+  HIP_OK(hipMemcpyAsync(c->stage_rhs, rhs_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_OK(hipMemcpyAsync(c->dn_stat, stat0, sizeof(stat0), hipMemcpyHostToDevice, c->stream));
+  double *S = c->dn_S, *L = c->dn_S + (size_t)n * n, *x = c->dn_rv + 2 * (size_t)n;
+  hipLaunchKernelGGL(dense_from_bands_kernel, dim3(nblk), dim3(256), 0, c->stream, c->HA, c->HB, c->HC, nblk, bs, S);
+  LaunchDenseLdl(c, S, L, c->dn_d, c->dn_stat, c->dn_rv, n, c->stage_rhs, 1.0, nullptr);
+  hipLaunchKernelGGL(dense_ldl_solve_kernel, dim3(1), dim3(512), (n + 512 + DENSE_NB * (DENSE_NB + 1)) * sizeof(double), c->stream,
+                     L, n, c->dn_d, c->dn_rv + n, 1.0, (const double*)nullptr, x, 1);
+  HIP_OK(hipGetLastError());
+  double stat[2];
+  HIP_OK(hipMemcpyAsync(x_host, x, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(hipMemcpyAsync(stat, c->dn_stat, sizeof(stat), hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  if (!(stat[0] > 0.0) || !std::isfinite(stat[1])) {
+    g_err = "solve_dense_ldlt: a pivot of the dense LDL^T is not positive and finite";
+    return IDTO_HIP_FACTORIZATION_FAILED;
+  }
+  return 0;
+}
+
 // The constrained degrees of freedom on the device: ONE copy, shared by the banded KKT step (which needs nothing else;
 // batch contexts included) and by the Schur-complement route.  (Round 4 kept a list per route and each invalidated the
 // other's: a resident KKT solve followed by the host loop - the TRF_SINGULAR_S fallback, or SolveFromWarmStart followed
@@ -1910,13 +1965,17 @@ int idto_hip_constraint_schur(idto_hip_ctx* c, const int* dofs, int nu, double* 
 
 // S = L D L^T without pivoting, one launch per panel of 32 columns (dense_ldl.h dense_ldl_step_kernel); L -> con_L
 // together with the forward substitution of the right-hand side r = b2 + b_sign b (-> con_rv = L^-1 r)
-static void LaunchDenseLdl(idto_hip_ctx* c, double* S, int neq, const double* b, double b_sign, const double* b2) {
+static void LaunchDenseLdl(idto_hip_ctx* c, double* S, double* L, double* d, double* stat, double* rv, int neq, const double* b,
+                           double b_sign, const double* b2) {
   for (int j0 = 0; j0 < neq; j0 += DENSE_NB) {
     const int j1 = j0 + DENSE_NB, below = neq > j1 ? neq - j1 : 0;
     const int tiles = below > 0 ? (below + 31) / 32 : 1;
-    hipLaunchKernelGGL(dense_ldl_step_kernel, dim3(tiles, tiles), dim3(256), 0, c->stream, S, c->con_L, neq, j0, c->con_d, c->con_h,
-                       b, b_sign, b2, c->con_rv, c->con_rv + neq);
+    hipLaunchKernelGGL(dense_ldl_step_kernel, dim3(tiles, tiles), dim3(256), 0, c->stream, S, L, neq, j0, d, stat,
+                       b, b_sign, b2, rv, rv + neq);
   }
+}
+static void LaunchDenseLdl(idto_hip_ctx* c, double* S, int neq, const double* b, double b_sign, const double* b2) {
+  LaunchDenseLdl(c, S, c->con_L, c->con_d, c->con_h, c->con_rv, neq, b, b_sign, b2);
 }
 
 int idto_hip_constraint_solve(idto_hip_ctx* c, const double* h_host, double* lambda_host, double* step_host,
@@ -2785,7 +2844,7 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "two_sided") == 0) { c->two_sided = value != 0; return 0; }
   if (std::strcmp(name, "fused") == 0) { c->fused = value != 0; return 0; }
   if (std::strcmp(name, "async_uploads") == 0) { c->async_uploads = value != 0; return 0; }
-  if (std::strcmp(name, "nd_min_rows") == 0) { c->nd_min_rows = std::max(12, value); if (c->kkt) c->kkt->nd_min_rows = c->nd_min_rows; return 0; }
+  if (std::strcmp(name, "nd_min_rows") == 0) { c->nd_min_rows = std::max(16, value); /* (below 16 block rows nd_split leaves a joiner chains of three rows with one row of their own: untested, not offered) */ if (c->kkt) c->kkt->nd_min_rows = c->nd_min_rows; return 0; }
   if (std::strcmp(name, "nd_recursion") == 0) { c->nd_recursion = value != 0; if (c->kkt) c->kkt->nd_recursion = c->nd_recursion; return 0; }
   if (std::strcmp(name, "solver_nd") == 0) { c->solver_nd = value != 0; return 0; }
   if (std::strcmp(name, "solver_pipe") == 0) { c->solver_pipe = value != 0; return 0; }

@@ -1055,6 +1055,8 @@ penta_ldl_body(int n, int k, const double* __restrict__ HA, const double* __rest
           // wavefront's stores are acknowledged.  They are write-through stores: nothing stays dirty in this
           // XCD's L2, so the release is a wait for the acknowledgements instead of a write-back of that L2
           // (a releasing fence per I/O wavefront and row from each of 64 joiners cost a batch of 32 problems).
+          // Ordered by the hardware, not by the HIP memory model: see penta_nd.h release_row for the assumption
+          // (gfx942 / gfx950: agent-scope stores write through, vmcnt counts their acknowledgements).
           for (int r = ht; r < K; r += hn) {
             __hip_atomic_store(Dst + (size_t)orig(i - 1) * K + r, Ivp[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(cfg.rtpub + (size_t)(i - 1) * K + r, lds[L.xall + (i - 1 + 2) * ks + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

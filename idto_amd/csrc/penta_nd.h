@@ -25,6 +25,9 @@
 // Dependent chain for n = 40, K = 19: 9 + 2 rows, one trailing spike row, the separator (2 rows) and
 // 2 + 9 rows back, instead of 20 + 2 and 22.
 #pragma once
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "penta_nd.h / penta_pipe.h / penta_ldl.h order their row hand-overs by write-through stores + s_waitcnt vmcnt(0) (see release_row): gfx942 / gfx950 only"
+#endif
 
 #include <type_traits>
 #include "penta_ldl.h"
@@ -235,6 +238,15 @@ __device__ __forceinline__ void nd_spike(const NdArgs& A, const int w) {
       else dst[idx] = v;
     }
   };
+  // HARDWARE ASSUMPTION (gfx942 / gfx950 only, enforced by the #error at the top of this file): an agent-scope relaxed
+  // atomic store is a `global_store ... sc1` that writes through this XCD's L2, and `s_waitcnt vmcnt(0)` returns once
+  // every such store has been acknowledged at the agent's coherence point.  That is what LLVM's own release sequence
+  // for these targets ends with (AMDGPUUsage, memory model gfx942: `buffer_wbl2 sc1; s_waitcnt vmcnt(0)`) minus the
+  // write-back of the whole L2 - which has nothing of this row to write back, every store of the row being
+  // write-through.  The relaxed increment that follows is therefore ordered behind the row at agent scope by the
+  // hardware, not by the HIP memory model; readers poll it, execute an acquiring fence (L2 invalidate) and load.
+  // IDTO_ND_WT=2 brings the formal release back (plain stores + a releasing fence): tools/nd_stress.py and
+  // tools/stress_solver.py run both and compare bits.
   auto release_row = [&](int il) {   // by each of the three wavefronts that stored a part of the row
     if (A.wt_rows != 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");

@@ -85,6 +85,7 @@ def lib():
             getattr(L, "idto_hip_" + f).argtypes = [C.c_void_p]
         L.idto_hip_factor_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.idto_hip_solve_host.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double)]
+        L.idto_hip_solve_dense_ldlt.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.idto_hip_constraint_schur.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double),
                                                 C.POINTER(C.c_double)]
         L.idto_hip_constraint_schur_begin.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
@@ -113,6 +114,7 @@ EXPORTED_SYMBOLS = [
     "idto_hip_get_stream", "idto_hip_set_shard", "idto_hip_set_q", "idto_hip_set_q_device", "idto_hip_eval_tau", "idto_hip_eval_tau_partials", "idto_hip_trial_cost", "idto_hip_constraint_schur",
     "idto_hip_constraint_schur_begin", "idto_hip_constraint_solve", "idto_hip_constraint_step", "idto_hip_prefetch",
     "idto_hip_eval_partials", "idto_hip_grad_hess", "idto_hip_factor_solve", "idto_hip_gn_step", "idto_hip_solve_host",
+    "idto_hip_solve_dense_ldlt", "idto_hip_dense_solve_count",
     "idto_hip_set_option", "idto_hip_get_option",
     "idto_hip_timing_enable", "idto_hip_timing_reset", "idto_hip_timing_get", "idto_hip_sync", "idto_hip_get",
     "idto_hip_device_ptr", "idto_hip_array_size", "idto_hip_slab_stride", "idto_hip_math_probe",
@@ -380,6 +382,13 @@ class HipPath:
         rhs = np.ascontiguousarray(np.atleast_2d(np.asarray(rhs, dtype=np.float64)))
         x = np.zeros_like(rhs)
         _chk(lib().idto_hip_solve_host(self.h, dptr(rhs), rhs.shape[0], dptr(x)))
+        return x
+
+    def solve_dense_ldlt(self, rhs):
+        """H x = rhs by a dense LDL^T of MakeDense() (SolverParameters::linear_solver = kDenseLdlt, TO.cc:2088-2093)"""
+        rhs = np.ascontiguousarray(np.asarray(rhs, dtype=np.float64).ravel())
+        x = np.zeros_like(rhs)
+        _chk(lib().idto_hip_solve_dense_ldlt(self.h, dptr(rhs), dptr(x)))
         return x
 
     def set_option(self, name: str, value: int):

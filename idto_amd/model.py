@@ -66,7 +66,9 @@ class CSolverParams(C.Structure):
                 ("max_linesearch_iterations", C.c_int), ("gradients_method", C.c_int),
                 ("linear_solver", C.c_int), ("normalize_quaternions", C.c_int), ("verbose", C.c_int),
                 ("scaling", C.c_int), ("scaling_method", C.c_int), ("equality_constraints", C.c_int),
-                ("Delta0", C.c_double), ("Delta_max", C.c_double), ("num_threads", C.c_int)]
+                ("Delta0", C.c_double), ("Delta_max", C.c_double), ("num_threads", C.c_int),
+                ("print_debug_data", C.c_int), ("debug_compare_against_dense", C.c_int), ("exact_hessian", C.c_int),
+                ("plot_dumps", C.c_int)]
 
 
 class CStats(C.Structure):

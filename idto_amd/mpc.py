@@ -110,8 +110,13 @@ class DeviceModelPredictiveController:
     """idto::examples::mpc::ModelPredictiveController + Interpolator of libidto_opt.so (include/idto_opt.h idto_mpc_*).
     `optimizer`: an idto_amd.optimizer.TrajectoryOptimizer whose max_iterations is the example's mpc_iters."""
 
-    def __init__(self, optimizer, warm_start_solution, actuated=None, q_nom_relative_to_q_init=None, replan_period=0.0):
+    def __init__(self, optimizer, warm_start_solution, actuated=None, q_nom_relative_to_q_init=None, replan_period=0.0,
+                 strict=True):
+        """strict: update() raises when a re-plan's factorisation fails (the C++ controller keeps the previous plan and
+        reports SolverFlag::kFactorizationFailed through last_flag(); a caller that ignores the flag would otherwise
+        run on the old plan with no signal).  strict=False: return the previous plan, `last_flag == 2`."""
         import ctypes as C
+        self.strict = bool(strict)
         from . import optimizer as O
         self._O, self._C = O, C
         self.opt = optimizer
@@ -167,6 +172,9 @@ class DeviceModelPredictiveController:
             raise RuntimeError(self._O.lib().idto_opt_last_error().decode())
         self.last_cost = cost.value
         self.last_flag = flag.value
+        if flag.value == 2 and self.strict:   # SolverFlag::kFactorizationFailed: (q, v, tau) are the PREVIOUS plan's
+            raise RuntimeError("MPC re-plan at t = %g: the factorisation failed; the previous plan stays in force "
+                               "(strict=False returns it, last_flag == 2 says so)" % t)
         return (g.copy(), q.copy(), v.copy(), tau.copy()) if copy else (g, q, v, tau)
 
     @property

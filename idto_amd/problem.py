@@ -73,6 +73,11 @@ class SolverParameters:
     linear_solver: str = "pentadiagonal_lu"
     normalize_quaternions: bool = False
     verbose: bool = True
+    print_debug_data: bool = False
+    debug_compare_against_dense: bool = False
+    linesearch_plot_every_iteration: bool = False
+    save_contour_data: bool = False
+    save_lineplot_data: bool = False
     contact_stiffness: float = 100.0
     dissipation_velocity: float = 0.1
     stiction_velocity: float = 0.05
@@ -105,6 +110,10 @@ class SolverParameters:
         s.scaling_method = SCALING[self.scaling_method]
         s.equality_constraints = int(self.equality_constraints)
         s.num_threads = int(self.num_threads)
+        s.print_debug_data = int(self.print_debug_data)
+        s.debug_compare_against_dense = int(self.debug_compare_against_dense)
+        s.exact_hessian = int(self.exact_hessian)
+        s.plot_dumps = int(self.linesearch_plot_every_iteration or self.save_contour_data or self.save_lineplot_data)
         return s
 
     def contact_to_c(self):
@@ -172,6 +181,9 @@ def make_problem(cfg: dict, model: Model | None = None, num_steps: int | None = 
     sp.Delta0 = float(cfg.get("Delta0", sp.Delta0))
     sp.Delta_max = float(cfg.get("Delta_max", sp.Delta_max))
     sp.num_threads = int(cfg.get("num_threads", 1))
+    for k in ("print_debug_data", "linesearch_plot_every_iteration", "save_contour_data", "save_lineplot_data",
+              "exact_hessian"):   # examples/yaml_config.h:141-160, example_base.cc:452-493
+        setattr(sp, k, bool(cfg.get(k, getattr(sp, k))))
     for k in ("contact_stiffness", "dissipation_velocity", "smoothing_factor", "friction_coefficient",
               "stiction_velocity"):
         if k in cfg:

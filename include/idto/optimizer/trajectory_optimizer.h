@@ -17,11 +17,16 @@
 // trust-region loop :2449-2651) run on the host.  There is no CPU implementation of the hot
 // path: construction throws std::runtime_error if no HIP device is available.
 //
-// Differences from the reference, all reported through exceptions exactly where the reference
-// throws/aborts: gradients_method must be one of the finite-difference methods (forward,
-// central, central4; kAutoDiff needs Drake's AutoDiffXd plant, reference TO.cc:410-423 has
-// the same kind of runtime check),
-// exact_hessian is not supported.
+// Differences from the reference, reported through exceptions in the constructor: gradients_method must
+// be one of the finite-difference methods (forward, central, central4; kAutoDiff needs Drake's AutoDiffXd
+// plant, reference TO.cc:410-423 has the same kind of runtime check), exact_hessian is not supported
+// (it needs autodiff as well).  Every other field of SolverParameters is honoured: linear_solver =
+// kDenseLdlt routes SolveLinearSystemInPlace (:2088-2093) to a dense LDL^T of MakeDense() on the device
+// (idto_hip_solve_dense_ldlt), debug_compare_against_dense prints the reference's "Sparse vs. Dense error"
+// per dogleg point (:2142-2150), print_debug_data its condition numbers (:2349-2365, :2499-2507); these
+// three take the stepwise loop (one synchronisation per quantity), not the device-resident one.
+// The plotting dumps (save_contour_data, save_lineplot_data, linesearch_plot_every_iteration: CSV files for
+// the 2-DoF toy examples' figures, TO.cc:1650-1830) are not produced: the constructor throws if one is set.
 #pragma once
 
 #include <memory>
@@ -134,6 +139,11 @@ class TrajectoryOptimizer<double> {
   void CalcDerivatives(const TrajectoryOptimizerState<T>& state) const;
   void CalcGradHess(const TrajectoryOptimizerState<T>& state) const;
   const VectorXd& EvalHinvMeritGradient(const TrajectoryOptimizerState<T>& state) const;
+  // SolveLinearSystemInPlace (TO.cc:2077-2096) for the Hessian of `state`: params().linear_solver (solver < 0), the
+  // dense LDL^T (0) or the block Thomas algorithm (1)
+  bool DenseLinearSolver() const;
+  void SolveLinearSystem(const TrajectoryOptimizerState<T>& state, const VectorXd& b, VectorXd* x, int solver = -1) const;
+  double DebugConditionNumber(const TrajectoryOptimizerState<T>& state, bool scaled) const;
   void NormalizeQuaternions(TrajectoryOptimizerState<T>* state) const;
   std::pair<double, int> ArmijoLinesearch(const TrajectoryOptimizerState<T>& state, const VectorXd& dq,
                                           TrajectoryOptimizerState<T>* scratch) const;
@@ -167,6 +177,7 @@ class TrajectoryOptimizer<double> {
   // host loop (pivoted LDL^T) finishes the solve from that iterate
   mutable bool force_host_loop_ = false;
   mutable int resume_k_ = 0;
+  mutable double last_sparse_vs_dense_ = -1.0;   // debug_compare_against_dense: the figure CalcDoglegPoint printed last
 };
 
 }  // namespace optimizer

@@ -186,6 +186,14 @@ int idto_hip_gn_step(idto_hip_ctx* ctx);
  * host-side trust-region loop obtains H^-1 [J^T | g] for CalcLagrangeMultipliers
  * (optimizer/trajectory_optimizer.cc:1371-1396) and CalcDoglegPoint (:2108-2202). */
 int idto_hip_solve_host(idto_hip_ctx* ctx, const double* rhs_host, int nrhs, double* x_host);
+/* SolveLinearSystemInPlace with SolverParameters::linear_solver = kDenseLdlt (reference
+ * optimizer/trajectory_optimizer.cc:2088-2093: H.MakeDense().ldlt().solve(b)): the resident Hessian
+ * as a dense (N+1)*nq square matrix, a blocked LDL^T of it on the device (csrc/dense_ldl.h) and the
+ * solution of H x = rhs for ONE host right-hand side; synchronises.  The reference's cross-check of
+ * the block Thomas solver (debug_compare_against_dense, :2142-2150) is this call next to
+ * idto_hip_solve_host.  IDTO_HIP_FACTORIZATION_FAILED when a pivot is not positive and finite. */
+int idto_hip_solve_dense_ldlt(idto_hip_ctx* ctx, const double* rhs_host, double* x_host);
+long idto_hip_dense_solve_count(void);   /* calls of the above in this process (the tests' proof of which branch ran) */
 
 /* Equality-constraint step of the trust-region iteration, kept on the device (reference
  * CalcEqualityConstraintJacobian / CalcLagrangeMultipliers, optimizer/trajectory_optimizer.cc:
@@ -307,8 +315,12 @@ int idto_hip_tr_solve_fetch(idto_hip_ctx* ctx, int iterations, int scaling_metho
  * its own radius, accepts or rejects on its own, and idles on its own flags; no equality constraints (nu = 0; with constraints:
  * idto_hip_tr_solve_batch_constrained).
  * Delta0[batch], Delta_out[batch] (may be NULL); rows_host[batch][iterations][IDTO_TR_ROW]: problem b's rows are
- * what idto_hip_tr_solve returns for the same problem in a context of its own, bit for bit.  Every problem's q must
- * be resident with its cost evaluated (idto_hip_set_q_batch + idto_hip_eval_tau). */
+ * what idto_hip_tr_solve returns for the same problem in a context of its own - bit for bit when both contexts run the
+ * same linear solver, to the solver's round-off otherwise: from 16 block rows on (option "nd_min_rows") a
+ * single-problem context takes the scalar band factorisation for blocks up to 5, while a batch of more than two
+ * problems keeps the block kernels; option "solver_band" = 0 on both contexts puts them on the same kernel
+ * (tests/test_gpu_batch.py does that for the spinner).  Every problem's q must be resident with its cost evaluated
+ * (idto_hip_set_q_batch + idto_hip_eval_tau). */
 int idto_hip_tr_solve_batch(idto_hip_ctx* ctx, int iterations, int scaling_method, int scaling, int normalize_quaternions,
                             const double* Delta0, double Delta_max, double eta, double* rows_host, double* Delta_out);
 /* ... with ENFORCED equality constraints on the `nu` degrees of freedom `constrained_dofs` (the unactuated ones:
@@ -317,7 +329,8 @@ int idto_hip_tr_solve_batch(idto_hip_ctx* ctx, int iterations, int scaling_metho
  * iteration is one launch set for the whole batch, grid.y = problem, like idto_hip_tr_solve_batch; otherwise (option
  * con_kkt = 0) the multiplier chain is single-problem launches and every problem is advanced in a single-problem context
  * of its own (created on first use inside this context) on its own stream and host thread.  Either way rows and iterates
- * are, bit for bit, those of idto_hip_tr_solve on the same problem alone.  nu = 0 forwards to idto_hip_tr_solve_batch.
+ * are those of idto_hip_tr_solve on the same problem alone (bit for bit under the same linear solver: see
+ * idto_hip_tr_solve_batch).  nu = 0 forwards to idto_hip_tr_solve_batch.
  * Same residency requirement: every problem's q set (idto_hip_set_q_batch). */
 int idto_hip_tr_solve_batch_constrained(idto_hip_ctx* ctx, int iterations, int scaling_method, int scaling,
                                         int normalize_quaternions, const double* Delta0, double Delta_max, double eta,

@@ -130,6 +130,10 @@ typedef struct idto_solver_params {
   int equality_constraints;         /* 1 */
   double Delta0, Delta_max;         /* 1e-1, 1e5 */
   int num_threads;                  /* 1 */
+  int print_debug_data;             /* 0: condition numbers etc. per iteration (solver_parameters.h:101-103) */
+  int debug_compare_against_dense;  /* 0: "Sparse vs. Dense error" per dogleg point (:105-110) */
+  int exact_hessian;                /* 0; 1 is rejected (needs autodiff) */
+  int plot_dumps;                   /* 0; save_contour_data | save_lineplot_data | linesearch_plot_every_iteration: rejected */
 } idto_solver_params_t;
 
 /* Per-iteration statistics, the 13 series of TrajectoryOptimizerStats

@@ -11,6 +11,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "timing: wall-clock bounds on a shared device (GPU box, `-m timing`; not part of `-m gpu`)")
 
 
 @pytest.fixture(scope="session", autouse=True)

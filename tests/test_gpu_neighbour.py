@@ -6,7 +6,10 @@ workgroups that wait for each other); beside a neighbour of many short workgroup
 compute units drain, so the waits must be met long before their 10-50 ms bounds:
   * every step reproduces the bits of the unloaded device,
   * no launch reports IDTO_HIP_SOLVER_TIMEOUT (option "solver_timeouts" stays 0, the context does not step down),
-  * no single step takes longer than 5 ms - a wait that had run into its bound would show as >= 10 ms."""
+  * (marker `timing`, outside the `-m gpu` suite: `pytest -m timing tests/test_gpu_neighbour.py`) no single step takes longer
+    than 50 ms of wall clock.  Wall clock on a shared device is scheduling, not waiting - boxes of the pool have let a whole
+    batch of the neighbour's kernels, 10 - 20 ms, go first - so the bound lives apart from the parity suite, whose
+    assertions are all deterministic: bits, the timeout counter, the solver variant."""
 import time
 
 import numpy as np
@@ -17,11 +20,24 @@ from idto_amd import hip
 from idto_amd.model import load_model
 from idto_amd.problem import load_config, make_problem, synthetic_trajectory
 
-pytestmark = pytest.mark.gpu
+CASES = [("mini_cheetah", 40), ("allegro_hand", 60), ("acrobot", 40)]   # (five / seven workgroups; the band kernel's one + its assembly)
 
 
-@pytest.mark.parametrize("name,N", [("mini_cheetah", 40), ("allegro_hand", 60), ("acrobot", 40)])   # (five / seven workgroups; the band kernel's one + its assembly)
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,N", CASES)
 def test_solver_beside_a_saturating_neighbour(name, N):
+    beside_a_neighbour(name, N)
+
+
+@pytest.mark.timing
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a device")
+@pytest.mark.parametrize("name,N", CASES)
+def test_slowest_step_beside_a_saturating_neighbour(name, N):
+    worst = beside_a_neighbour(name, N)
+    assert worst < 0.05, f"slowest step {1e3 * worst:.2f} ms"
+
+
+def beside_a_neighbour(name, N):
     cfg, model = load_config(name), load_model(name)
     prob, sp, _ = make_problem(cfg, model, num_steps=N)
     sp.scaling = sp.equality_constraints = False
@@ -63,11 +79,7 @@ def test_solver_beside_a_saturating_neighbour(name, N):
     assert 2 * busy_rounds >= rounds, f"the neighbour outlasted the steps in {busy_rounds} of {rounds} rounds only: not a test of sharing"
     assert dev.get_option("solver_timeouts") == 0, "a wait between the solver's workgroups ran out beside the neighbour"
     assert dev.get_option("last_solver") == solver0, "the context stepped down"
-    # (a bound on waiting, not on scheduling: alone this test measures 1.0 - 1.5 ms - one neighbour kernel - on every box, but
-    # run behind the rest of the suite some boxes of the pool let a whole batch of the neighbour's kernels, ~10 - 20 ms, go
-    # first; what matters is that no wait ran out - the 10 ms give-up of penta_pipe.h counts a workgroup's age once it
-    # RUNS - and that nothing hangs)
-    assert worst < 0.2, f"slowest step {1e3 * worst:.2f} ms"
     print(f"{name}: {steps} steps beside the neighbour ({busy_rounds} of {rounds} rounds with the neighbour still busy at their end), "
           f"slowest {1e3 * worst:.3f} ms, no timeout")
     dev.close()
+    return worst

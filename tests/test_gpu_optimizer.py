@@ -192,10 +192,107 @@ def test_reset_initial_conditions():  # python_bindings/test/warm_start_test.py:
 
 
 def test_unsupported_options_fail_loudly():
-    model, prob, sp, _ = spinner_python_test_problem()
-    sp.gradients_method = "autodiff"
-    with pytest.raises(RuntimeError, match="finite-difference"):
-        TrajectoryOptimizer(model, prob, sp)
+    """Every SolverParameters field the build does not honour is rejected in the constructor (reference
+    optimizer/solver_parameters.h:64-167; include/idto/optimizer/trajectory_optimizer.h lists them)."""
+    for field, value, match in (("gradients_method", "autodiff", "finite-difference"),
+                                ("exact_hessian", True, "exact_hessian"),
+                                ("save_contour_data", True, "plotting"), ("save_lineplot_data", True, "plotting"),
+                                ("linesearch_plot_every_iteration", True, "plotting")):
+        model, prob, sp, _ = spinner_python_test_problem()
+        setattr(sp, field, value)
+        with pytest.raises(RuntimeError, match=match):
+            TrajectoryOptimizer(model, prob, sp)
+
+
+@pytest.mark.parametrize("name,method,eq,scaling", [("spinner", "trust_region", False, True),
+                                                    ("hopper", "trust_region", True, True),
+                                                    ("mini_cheetah", "trust_region", True, False),
+                                                    ("acrobot", "linesearch", False, False)])
+def test_dense_ldlt_linear_solver_tracks_the_oracle(name, method, eq, scaling):
+    """SolverParameters::linear_solver = kDenseLdlt (reference SolveLinearSystemInPlace, TO.cc:2088-2093:
+    H.MakeDense().ldlt().solve(b)) is honoured: the dogleg's Newton step (:2140) and the linesearch direction
+    (:2302) come from a dense LDL^T of MakeDense() on the device (idto_hip_solve_dense_ldlt).  Checked against
+    the oracle run with the same setting (oracle/traj_opt.h:711-716, pivoted dense LDL^T on the CPU)."""
+    cfg = load_config(name)
+    model = load_model(name)
+    prob, sp, q_guess = make_problem(cfg, model, num_steps=20)
+    sp.max_iterations, sp.verbose, sp.num_threads = 5, False, 1
+    sp.method, sp.equality_constraints, sp.scaling = method, eq, scaling
+    sp.linear_solver = "dense_ldlt"
+    ref = Oracle(model, prob, sp).solve(q_guess)
+    opt = TrajectoryOptimizer(model, prob, sp)
+    calls0 = dense_solve_count()
+    sol, st, flag = solve(opt, q_guess)
+    assert dense_solve_count() - calls0 >= 5, "the dense LDL^T was not the solver that ran"
+    rc = ref["stats"]
+    assert st.iteration_costs.size == len(rc.iteration_costs)
+    assert np.allclose(st.iteration_costs, rc.iteration_costs, rtol=1e-6), (st.iteration_costs, rc.iteration_costs)
+    assert np.abs(sol.q - ref["q"]).max() <= 1e-5 * max(1.0, np.abs(ref["q"]).max())
+    # ... and the default solver's iterates are the same to the conditioning of H (the two branches solve one system)
+    sp.linear_solver = "pentadiagonal_lu"
+    sol2, st2, _ = solve(TrajectoryOptimizer(model, prob, sp), q_guess)
+    assert np.allclose(st.iteration_costs, st2.iteration_costs, rtol=1e-6)
+
+
+def dense_solve_count():
+    from idto_amd import hip
+    hip.lib().idto_hip_dense_solve_count.restype = __import__("ctypes").c_long
+    return hip.lib().idto_hip_dense_solve_count()
+
+
+@pytest.mark.parametrize("name,N", [("mini_cheetah", 40), ("hopper", 50), ("acrobot", 40), ("allegro_hand", 12)])
+def test_dense_ldlt_solve_accuracy(name, N):
+    """idto_hip_solve_dense_ldlt alone: H x = b against the extended-precision solution, next to the
+    block-Thomas production solver on the same Hessian (what debug_compare_against_dense prints)."""
+    import oracle_lib as ol
+    from idto_amd import hip
+    from idto_amd.problem import synthetic_trajectory
+    cfg, model = load_config(name), load_model(name)
+    prob, sp, _ = make_problem(cfg, model, num_steps=N)
+    sp.scaling = sp.equality_constraints = False
+    q = synthetic_trajectory(cfg, model, N, seed=1, lower=0.02)
+    dev = hip.HipPath(model, prob, sp, device=0)
+    dev.set_q(q)
+    dev.gn_step()
+    g = dev.get("gradient").ravel()
+    bands = Oracle(model, prob, sp).grad_hess(q)[1]
+    x_ref, unc = ol.refined_solution(ol.penta_make_dense(*bands), g)
+    xd, xt = dev.solve_dense_ldlt(g), dev.solve_host(g).ravel()
+    scale = np.abs(x_ref).max()
+    err_d, err_t = np.abs(xd - x_ref).max() / scale, np.abs(xt - x_ref).max() / scale
+    # the reference found "LDLT is the most stable solver to round-off errors" (TO.cc:2143-2146): the dense
+    # factorisation must be at least as close to the exact solution as the banded one (x4 slack)
+    assert err_d <= 4 * err_t + 16 * unc + 1e-13, (err_d, err_t, unc)
+    dev.close()
+
+
+def test_debug_switches_print_what_the_reference_prints(capfd):
+    """debug_compare_against_dense (TO.cc:2142-2150) and print_debug_data (:2499-2507) on the hopper: the relative
+    distance of the banded solve from the dense one per dogleg point, and Eigen's rcond-style condition estimates."""
+    import re
+    cfg, model = load_config("hopper"), load_model("hopper")
+    prob, sp, q_guess = make_problem(cfg, model, num_steps=20)
+    sp.max_iterations, sp.verbose = 3, False
+    sp.debug_compare_against_dense = sp.print_debug_data = True
+    opt = TrajectoryOptimizer(model, prob, sp)
+    sol, st, flag = solve(opt, q_guess)
+    out = capfd.readouterr().out
+    errs = [float(x) for x in re.findall(r"Sparse vs. Dense error: (\S+)", out)]
+    assert len(errs) == 3 and all(0 <= e < 1e-6 for e in errs), out
+    conds = [float(x) for x in re.findall(r"condition_number = (\S+)", out)]
+    scaled = [float(x) for x in re.findall(r"condition_number_scaled = (\S+)", out)]
+    assert len(conds) == 3 and len(scaled) == 3
+    # the estimate is a lower bound of the 1-norm condition number, within a small factor of it in practice
+    orc = Oracle(model, prob, sp)
+    import oracle_lib as ol
+    Hd = ol.penta_make_dense(*orc.grad_hess(q_guess)[1])
+    true = np.linalg.cond(Hd, 1)
+    assert true / 10 <= conds[0] <= true * 1.001, (conds[0], true)
+    assert all(sc < c for sc, c in zip(scaled, conds)), "scaling must improve the conditioning (TO.cc:1212-1223)"
+    # switches off: same iterates through the resident loop
+    sp.debug_compare_against_dense = sp.print_debug_data = False
+    sol2, st2, _ = solve(TrajectoryOptimizer(model, prob, sp), q_guess)
+    assert np.allclose(st.iteration_costs, st2.iteration_costs, rtol=1e-6)
 
 
 @pytest.mark.parametrize("name,ls,eq", [("acrobot", "armijo", False), ("acrobot", "backtracking", False),

@@ -8,10 +8,12 @@ back substitution, nested dissection over seven workgroups, two workgroups), the
   * a forward error against an extended-precision solution of the same system (oracle_lib.refined_solution,
     known to `unc`) of at most 4x the error of the reference's algorithm (penta_kernel: the pivoted-LU block
     Thomas, bit-exact to the oracle's) + 16 unc, and
-  * a componentwise backward error  max_i |H p + g|_i / (|H| |p| + |g|)_i  <= 1e-12, or a hundred times below the
-    pivoted LU's own where that is larger (allegro: the reference's algorithm - itself a recursion over precomputed
-    Y_i, Z_i - leaves 6e-10 .. 4e-9 there; the kernels' back substitutions in recursion form 1e-12 .. 6e-12, the
-    row-by-row ones 5e-14 .. 2e-13).
+  * a componentwise backward error  max_i |H p + g|_i / (|H| |p| + |g|)_i  <= 1e-12 for the variants that substitute
+    row by row (backward stable: 5e-14 .. 2e-13 measured); for the back substitutions in recursion form <= 1e-12, or a
+    hundred times below the pivoted LU's own where that is larger, and <= 1e-11 whatever the LU does (allegro: the
+    reference's algorithm - itself a recursion over precomputed Y_i, Z_i - leaves 6e-10 .. 4e-9 there, the kernels'
+    recursion 1e-12 .. 6e-12: the trade of DESIGN.md's solver section, 10-100x less backward stable than row by row for
+    13 us of the allegro step, still 100-1000x better than the reference's own algorithm).
 tools/nd_accuracy.py prints the same quantities as a table (profiles/r04_nd_accuracy.txt)."""
 import numpy as np
 import pytest
@@ -35,6 +37,9 @@ VARIANTS = {
     "nd_rowwise_tail": ({"solver_band": 0, "solver_pipe": 0, "solver_nd": 1, "debug_pipe_tail": 0, "nd_recursion": 0}, (2,)),
     "two": ({"solver_band": 0, "solver_pipe": 0, "solver_nd": 0, "debug_pipe_tail": 0}, (1, 5)),
 }
+
+
+ROWWISE = ("band", "pipe_rowwise_tail", "nd_rowwise_tail", "two")
 
 
 def errors(bands, g, p, p_ref):
@@ -73,6 +78,9 @@ def test_production_solvers_are_as_accurate_as_the_pivoted_lu(name, N, lower, se
         ran.append(label)
         fwd, bwd = errors(bands, g, p, p_ref)
         assert fwd <= 4 * fwd_lu + 16 * unc + 1e-12, (label, "forward error", fwd, "LU", fwd_lu, "unc", unc)
-        assert bwd <= max(1e-12, 0.01 * bwd_lu), (label, "componentwise backward error", bwd, "LU", bwd_lu)
+        # recursion-form tails: a hundred times below the pivoted LU's own backward error where that exceeds 1e-12 (allegro),
+        # and never above 1e-11 in absolute terms; the row-by-row substitutions (backward stable) hold 1e-12 everywhere
+        cap = 1e-12 if label in ROWWISE else min(1e-11, max(1e-12, 0.01 * bwd_lu))
+        assert bwd <= cap, (label, "componentwise backward error", bwd, "cap", cap, "LU", bwd_lu)
     dev.close()
     assert ran, "no production variant ran"

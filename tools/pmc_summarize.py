@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarises the rocprofv3 outputs of tools/gpu_check.sh into small files for profiles/:
+"""Summarises the rocprofv3 outputs of tools/gpu.sh check into small files for profiles/:
   <round>_kernel_stats.csv   copy of the --stats kernel summary
   <round>_pmc_traffic.json   per kernel: launches, average FETCH_SIZE / WRITE_SIZE per launch
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  gfx950 correction
