@@ -840,6 +840,7 @@ bool TO::CalcDoglegPoint(const TrajectoryOptimizerState<T>& s, double Delta, Vec
     }
     last_sparse_vs_dense_ = std::sqrt(num) / std::sqrt(den);
     std::printf("Sparse vs. Dense error: %g\n", last_sparse_vs_dense_);
+    std::fflush(stdout);
   }
   dqH->resize((std::size_t)n);
   for (int i = 0; i < n; ++i) (*dqH)[i] = pH[i] * Delta;  // :2152
@@ -1064,6 +1065,7 @@ SolverFlag TO::SolveWithLinesearch(const std::vector<VectorXd>& q_guess, Traject
       std::printf("Condition #: %g\n|| dq ||   : %g\n||  g ||   : %g\nL'         : %g\nL          : %g\nL' / L     : %g\n"
                   "||diag(H)||: %g\n", debug_cond, dq_norm, g_norm, dL_dq * cost, cost, dL_dq, debug_diag_norm);
       if (k > 0) std::printf("L[k] - L[k-1]: %g\n", cost - stats->iteration_costs[(std::size_t)k - 1]);
+      std::fflush(stdout);
     }
     stats->push_data(iter_time, cost, ls_iters, alpha, std::numeric_limits<double>::quiet_NaN(), state.norm(), dq_norm,
                      dq_norm, trust_ratio, g_norm, dL_dq, h_norm, cost);  // :2373-2385
@@ -1379,6 +1381,7 @@ SolverFlag TO::SolveFromWarmStartImpl(WarmStart* ws, TrajectoryOptimizerSolution
     if (params_.print_debug_data) {  // :2499-2507
       std::printf("condition_number = %g\n", DebugConditionNumber(state, false));
       std::printf("condition_number_scaled = %g\n", DebugConditionNumber(state, true));
+      std::fflush(stdout);
     }
     // a step that is not finite can only come from a Hessian the factorisation could not handle
     if (!std::isfinite(Dot(dq, dq))) throw FactorizationFailedError("idto_hip: the dogleg step is not finite");

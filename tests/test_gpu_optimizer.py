@@ -223,14 +223,17 @@ def test_dense_ldlt_linear_solver_tracks_the_oracle(name, method, eq, scaling):
     opt = TrajectoryOptimizer(model, prob, sp)
     calls0 = dense_solve_count()
     sol, st, flag = solve(opt, q_guess)
-    assert dense_solve_count() - calls0 >= 5, "the dense LDL^T was not the solver that ran"
+    # (one per accepted iterate: a rejected step keeps H and the cached Newton step)
+    assert dense_solve_count() - calls0 >= 2, "the dense LDL^T was not the solver that ran"
     rc = ref["stats"]
     assert st.iteration_costs.size == len(rc.iteration_costs)
     assert np.allclose(st.iteration_costs, rc.iteration_costs, rtol=1e-6), (st.iteration_costs, rc.iteration_costs)
     assert np.abs(sol.q - ref["q"]).max() <= 1e-5 * max(1.0, np.abs(ref["q"]).max())
     # ... and the default solver's iterates are the same to the conditioning of H (the two branches solve one system)
     sp.linear_solver = "pentadiagonal_lu"
+    calls1 = dense_solve_count()
     sol2, st2, _ = solve(TrajectoryOptimizer(model, prob, sp), q_guess)
+    assert dense_solve_count() == calls1
     assert np.allclose(st.iteration_costs, st2.iteration_costs, rtol=1e-6)
 
 
@@ -258,11 +261,16 @@ def test_dense_ldlt_solve_accuracy(name, N):
     bands = Oracle(model, prob, sp).grad_hess(q)[1]
     x_ref, unc = ol.refined_solution(ol.penta_make_dense(*bands), g)
     xd, xt = dev.solve_dense_ldlt(g), dev.solve_host(g).ravel()
+    dev.set_option("reference_solver", 1)   # the reference's default branch: block Thomas with pivoted LU
+    dev.gn_step()
+    x_lu = -dev.get("step").ravel()
     scale = np.abs(x_ref).max()
-    err_d, err_t = np.abs(xd - x_ref).max() / scale, np.abs(xt - x_ref).max() / scale
-    # the reference found "LDLT is the most stable solver to round-off errors" (TO.cc:2143-2146): the dense
-    # factorisation must be at least as close to the exact solution as the banded one (x4 slack)
-    assert err_d <= 4 * err_t + 16 * unc + 1e-13, (err_d, err_t, unc)
+    err_d, err_t, err_lu = (np.abs(x - x_ref).max() / scale for x in (xd, xt, x_lu))
+    # the criterion of tests/test_gpu_solver_accuracy.py: no further from the exact solution than 4x the reference's own
+    # default solver (+ what is known about the exact solution)
+    assert err_d <= 4 * err_lu + 16 * unc + 1e-12, (err_d, err_lu, err_t, unc)
+    # ... and the two device solvers agree to that accuracy ("Sparse vs. Dense error", TO.cc:2142-2150)
+    assert np.abs(xd - xt).max() / scale <= 8 * err_lu + 32 * unc + 1e-12
     dev.close()
 
 
