@@ -119,12 +119,20 @@ def host_cpu_limit():
     return {"logical_cores": os.cpu_count() or 1, "affinity": len(os.sched_getaffinity(0)), "cfs_quota_cpus": quota}
 
 
-def cpu_baseline(config, N, budget_s=20.0):
+# timed Gauss-Newton iterations per repeat of a cpu_baseline leg at N = 40 (scaled by 40 / N): FIXED, the same for every leg
+# and every run - a shared time budget gave the 8-thread leg 291 iterations and the others 1,064 - 2,000, and the best-leg
+# denominator of the headline ratio moved +-5 % between runs.  ~1.5 s of one thread per repeat.
+CPU_BASELINE_ITERS = {"mini_cheetah": 300, "allegro_hand": 120, "hopper": 2500, "spinner": 6000, "acrobot": 8000}
+
+
+def cpu_baseline(config, N, repeats=3):
     """The CPU oracle (a port of the reference algorithm, OpenMP where the reference has it: TO.cc:209,
     :476) timed on this box's host cores on a bounded sample of the same workload.  Every leg runs in a
     process of its own (tools/cpu_baseline.py) so that its OpenMP runtime starts with pinned threads
     (OMP_PROC_BIND=close, OMP_PLACES=cores) that spin between the parallel regions (OMP_WAIT_POLICY=
-    active): this process already carries torch's OpenMP runtime and an environment that has been read."""
+    active): this process already carries torch's OpenMP runtime and an environment that has been read.
+    Every leg times the SAME fixed number of iterations `repeats` times; a leg's rate is the median, its spread
+    (max - min) / median is reported, and the baseline is the best leg's median."""
     import subprocess
     cores = os.cpu_count() or 1
     limit = host_cpu_limit()
@@ -137,10 +145,11 @@ def cpu_baseline(config, N, budget_s=20.0):
     legs = sorted({1, min(4, usable), min(8, usable), min(16, usable), min(N, usable)})
     env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores", OMP_WAIT_POLICY="active", OMP_DYNAMIC="false")
     env.pop("OMP_NUM_THREADS", None)
-    rates, notes, parts1, best = {}, [], None, None
+    rates, spreads, notes, parts1, best = {}, {}, [], None, None
+    iters = max(20, int(CPU_BASELINE_ITERS.get(config, 300) * 40 / max(N, 1)))
     for nt in legs:
         cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--config", config, "--num-steps", str(N),
-               "--threads", str(nt), "--budget", f"{budget_s / len(legs):.2f}"]
+               "--threads", str(nt), "--iters", str(iters), "--repeats", str(repeats)]
         try:
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120)
             leg = json.loads(r.stdout.strip().splitlines()[-1])
@@ -148,7 +157,8 @@ def cpu_baseline(config, N, budget_s=20.0):
             notes.append(f"num_threads={nt}: failed ({type(e).__name__})")
             continue
         rates[str(nt)] = leg["iters_per_s"]
-        notes.append(f"{leg['iters']} iterations at num_threads={nt}: {leg['iters_per_s']:.1f} it/s")
+        spreads[str(nt)] = leg.get("spread")
+        notes.append(f"num_threads={nt}: {leg['iters_per_s']:.1f} it/s (spread {100 * leg.get('spread', 0):.1f} %)")
         if nt == 1:
             parts1 = leg.get("parts_s")
         if best is None or leg["iters_per_s"] > best[0]:
@@ -156,10 +166,11 @@ def cpu_baseline(config, N, budget_s=20.0):
     if best is None:
         raise RuntimeError("cpu_baseline: no leg ran: " + "; ".join(notes))
     out = {"value": best[0], "unit": "GN iters/s", "cores": best[1], "kind": "port",
-           "iters_per_s_by_num_threads": rates,
+           "iters_per_s_by_num_threads": rates, "spread_by_num_threads": spreads,
+           "iterations_per_repeat": iters, "repeats": repeats, "statistic": "median of the repeats; spread = (max - min) / median",
            "omp": "one process per leg, OMP_PROC_BIND=close OMP_PLACES=cores OMP_WAIT_POLICY=active",
            "host_cpu_limit": limit,
-           "sample": "same trajectory as the GPU run; " + "; ".join(notes) +
+           "sample": f"same trajectory as the GPU run, {iters} Gauss-Newton iterations x {repeats} repeats per leg; " + "; ".join(notes) +
                      f" (host has {cores} logical cores, {usable} usable by this process; the OpenMP loops run over t, so at most N threads work)"}
     if parts1:
         # the reference's two parallel loops against what it runs serially: the ceiling of any thread count

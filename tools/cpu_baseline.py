@@ -5,7 +5,7 @@ num_threads value, in a process of its own so that the OpenMP runtime starts wit
 asks for (bench.py's own process has torch's OpenMP runtime loaded and an environment that is already
 read).  Prints one JSON line.  Test / measurement infrastructure only: nothing under idto_amd/ uses it.
 
-  python tools/cpu_baseline.py --config mini_cheetah --num-steps 40 --threads 8 --budget 4
+  python tools/cpu_baseline.py --config mini_cheetah --num-steps 40 --threads 8 --iters 300 --repeats 3
 
 The caller sets OMP_PROC_BIND / OMP_PLACES / OMP_WAIT_POLICY in the environment (bench.py: close / cores
 / active); they are echoed in the output.
@@ -27,7 +27,10 @@ def main():
     ap.add_argument("--config", default="mini_cheetah")
     ap.add_argument("--num-steps", type=int, default=40)
     ap.add_argument("--threads", type=int, default=1)
-    ap.add_argument("--budget", type=float, default=4.0, help="seconds of timed work")
+    ap.add_argument("--iters", type=int, default=0, help="timed iterations per repeat (fixed by the caller: every leg and "
+                    "every run times the same sample); 0: derive from --budget")
+    ap.add_argument("--repeats", type=int, default=3, help="repeats of the timed sample; the median is the leg's rate")
+    ap.add_argument("--budget", type=float, default=4.0, help="seconds of timed work when --iters is 0")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
@@ -45,12 +48,14 @@ def main():
     orc = Oracle(model, prob, sp)
     orc.time_gn_steps(q, 2)                           # warm-up (thread pool, caches)
     t1 = orc.time_gn_steps(q, 5)
-    iters = max(5, min(2000, int(args.budget / t1)))
-    t = orc.time_gn_steps(q, iters)
+    iters = args.iters if args.iters > 0 else max(5, min(2000, int(args.budget / t1)))
+    ts = sorted(orc.time_gn_steps(q, iters) for _ in range(max(1, args.repeats)))
+    t = ts[len(ts) // 2]
     # where one step's time goes: the two OpenMP loops (tau, finite differences) against the serial
     # rest (N+, v, a, assembly, factor + solve) -- the Amdahl ceiling of the reference's parallelisation
     parts = orc.time_gn_parts(q, max(3, iters // 4)) if hasattr(orc, "time_gn_parts") else None
-    out = {"num_threads": args.threads, "iters": iters, "s_per_iter": t, "iters_per_s": 1.0 / t,
+    out = {"num_threads": args.threads, "iters": iters, "repeats": len(ts), "s_per_iter": t, "iters_per_s": 1.0 / t,
+           "iters_per_s_repeats": [1.0 / x for x in ts], "spread": (ts[-1] - ts[0]) / t,
            "omp": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES", "OMP_WAIT_POLICY", "OMP_DYNAMIC")},
            "affinity_cores": len(os.sched_getaffinity(0))}
     if parts:
