@@ -66,6 +66,74 @@ def timeline(path):
     return chains, sep
 
 
+def pipe8_prediction(chains, sep, n_rows=40, K=19):
+    """cost a third dissection level - eight chains of ~4-5 rows instead of four of ~10 - BEFORE building it,
+    from the terms this round's timeline measures (solver alone, no assembly in front).  Build only if <= 44 us.
+
+    Terms (all from <round>_nd_timeline.txt): t0 first pivot of a chain; r_P / r_J row-to-row time of a chain without /
+    with spike columns; pseudo = the spike-less chain's pseudo-rows and their stores; join_wait, join_rows = the pair's
+    meeting (contributions in LDS; the two join rows); hand = last join row -> Q summed at the separator; sep = the
+    separator's two rows + solve + post; hop = separator's answer -> a chain corrected; rec = recursion per row; phop =
+    join rows of x -> the pair's other chain.
+
+    Two ways to get eight chains:
+      flat    three separators s1 s2 s3 at the quarter points, four twisted pairs; the reduced system [s1 s2 s3] is block
+              tridiagonal in 2K x 2K blocks: s1 and s3 eliminated side by side, their Schur complements handed to s2, s2
+              solved, s1 / s3 substituted, then the chains.
+      nested  today's separator kept, each half gets a sub-separator of its own (two twisted pairs per half); the
+              sub-separator's two rows carry 2K fill columns to the main separator.
+    In both, every chain next to a separator carries spike columns (r_J, not r_P), and the join rows of a segment between
+    TWO separators carry 4K spike columns: their elimination is taken at (1 + 2K / (3K + 1)) x today's join row - the
+    spike wavefronts' share doubles; generous, since 4K columns do not fit the three spike wavefronts' lanes (2 x 38 > 64)
+    nor the LDS carve-up (163.2 of 163.8 KB at K = 19 today)."""
+    P = next(c for c in chains if c["role"] == "producer")
+    J = max((c for c in chains if c["role"] == "joiner"), key=lambda c: c["forward_done"])
+    t0 = J["rows"][0][0]
+    r_P, r_J = P["row_to_row_us"], J["row_to_row_us"]
+    pseudo = P["forward_done"] - P["rows"][-1][1]
+    pre = len(J["rows"]) - 2
+    join_start = J["rows"][pre][0]                    # first join row's elimination begins
+    join_wait = join_start - J["rows"][pre - 1][1]    # last pre-join row done -> first join row under way
+    join_rows = J["forward_done"] - join_start
+    hand = sep["q_ready"] - J["forward_done"]
+    sep_us = sep["solved"] - sep["q_ready"]
+    hop = J["corrected"] - sep["solved"]
+    rec = (J["recursion_to"] - J["recursion_from"]) / len(J["rows"])
+    phop = P["recursion_from"] - (J["recursion_from"] + 2 * rec)
+    wide = 1.0 + 2.0 * K / (3.0 * K + 1.0)
+    today = t0 + pre * r_J + join_wait + join_rows + hand + sep_us + hop + (J["recursion_from"] - J["corrected"]) + \
+        2 * rec + phop + len(P["rows"]) * rec
+    # ---- flat: 40 - 6 = 34 rows in segments of 8, 9, 9, 8; an inner segment (9 rows): 3 + 4 pre-join rows, 2 join rows
+    outer = t0 + max(3 * r_P + pseudo, 3 * r_J) + join_wait + join_rows
+    inner = t0 + 4 * r_J + join_wait + wide * join_rows
+    elim = sep_us - 1.5                                # a separator's two rows without its solve + post (timeline: 1.5 us)
+    q13 = max(outer, inner) + hand                     # s1 / s3 have their Q
+    s2_in = q13 + elim + hand                          # their Schur complements summed at s2
+    x2 = s2_in + sep_us
+    x13 = x2 + hop + 1.5                               # s1 / s3: one mat-vec, two triangular solves, post
+    flat = x13 + hop + 2 * rec + phop + 4 * rec
+    # ---- nested: a half = 19 rows = sub-separator (2) + segments of 8 (outer) and 9 (between the two separators)
+    sub_q = max(outer, inner) + hand
+    sub_done = sub_q + elim * wide                     # its two rows carry 2K more columns
+    main_q = sub_done + hand
+    xm = main_q + sep_us
+    xs = xm + hop + 1.5
+    nested = xs + hop + 2 * rec + phop + 4 * rec
+    return {
+        "what": "eight chains instead of four (a third dissection level), predicted from this round's measured terms; solver alone",
+        "terms_us": {"first_pivot": t0, "row_without_spikes": r_P, "row_with_spikes": r_J, "pseudo_rows": pseudo, "join_wait": join_wait,
+                     "two_join_rows": join_rows, "hand_over_to_separator": hand, "separator": sep_us, "answer_to_chain": hop,
+                     "recursion_per_row": rec, "join_rows_of_x_to_the_other_chain": phop, "join_row_factor_with_4K_spike_columns": wide},
+        "model_of_todays_kernel_us": today, "timeline_of_todays_kernel_us": max(c["end"] for c in chains),
+        "flat_three_separators_us": flat, "nested_sub_separators_us": nested,
+        "segments_forward_done_us": {"one_separator": outer, "two_separators": inner},
+        "threshold_us": 44.0, "build": bool(min(flat, nested) <= 44.0),
+        "why": "halving the chains saves ~6 rows (16-20 us) and buys a second reduced-system level: one more hand-over + "
+               "separator elimination + hand-over going up, one more answer + substitution going down, and join rows with "
+               "twice the spike columns in every segment that sits between two separators - within 2-3 us of what the rows save",
+    }
+
+
 def main():
     rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
     P = lambda f: os.path.join(ROOT, "profiles", f"{rnd}_{f}")
@@ -113,6 +181,8 @@ def main():
     out["sources"]["penta_pipe_kernel"] = [f"profiles/{rnd}_nd_timeline.txt", f"profiles/{rnd}_kernel_stats_assembly_in_its_own_launch.csv",
                                            link_src]
     out["penta_pipe_kernel"]["pivot_link_cycles"] = link
+    out["penta_pipe8_predicted"] = pipe8_prediction(chains, sep)
+    out["sources"]["penta_pipe8_predicted"] = [f"profiles/{rnd}_nd_timeline.txt"]
     # ---- penta_nd_kernel<23> (allegro_hand N = 60: the seven-workgroup kernel of penta_nd.h), from its own timeline
     # (tools/nd_timeline.py allegro_hand 60 -> <round>_nd_timeline_allegro.txt): VERDICT r4 "weak" #3 asked where its 127 us go
     if os.path.exists(P("nd_timeline_allegro.txt")):
