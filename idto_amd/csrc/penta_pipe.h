@@ -59,8 +59,23 @@ struct PipeGeo {
   static_assert(RS >= used && RS % 32 == 16, "row stride");
 };
 
+// The follower that eliminates next ("low" follower) takes rows 0 .. RLO-1 of the next block row, the wavefront that
+// has just eliminated takes the rest and hands them over through LDS (PipeRows below).  K >= 17: RLO = 16, ONE row tile
+// of the matrix cores - the low follower forms Ht^T Dn [Ht | Et | rt] (spike wavefronts: Ht^T Dn Ft) for its 16 rows
+// with v_mfma_f64_16x16x4, a k-step per four published pivots (pipe_follow_mfma), instead of K rank-one updates
+// with broadcast multipliers.
+template <int K>
+constexpr int pipe_rlo() { return K >= 17 ? 16 : (K >= 3 ? (((K + 1) / 2 + 1) & ~1) : K); }
+template <int K>
+constexpr bool pipe_mfma_follow() { return K >= 17; }
+// the low follower's products leave the matrix cores as tiles (lane = (k-row, column), register = row); the wavefront
+// turns them into its own layout (lane = column, register = row) through a scratch of its own: PIPE_HPC product columns
+// (three column tiles) + one column that stays zero (lanes whose column takes no update), column stride PIPE_HS (16 rows;
+// 36 dwords: eight lanes' 16-byte reads cover the 32 banks once)
+constexpr int PIPE_HPC = 48, PIPE_HS = 18, PIPE_HPN = (PIPE_HPC + 1) * PIPE_HS;
+
 struct PipeLds {   // offsets in doubles
-  int ring, stage, gbuf, xhi, jbuf, xall, W, flags, end;
+  int ring, stage, gbuf, xhi, hp, jbuf, xall, W, flags, end;
 };
 template <int K>
 __host__ __device__ inline PipeLds pipe_layout(int n, bool spike) {
@@ -68,12 +83,15 @@ __host__ __device__ inline PipeLds pipe_layout(int n, bool spike) {
   PipeLds L;
   int o = 0;
   L.ring = o; o += 3 * G::SLOT;
-  L.stage = o; o += 2 * (G::NCX + (spike ? 2 * K : 0)) * G::GS + 2;   // (+ a dump double)
+  // (the main columns only: the spike wavefronts take their first two rows' inputs straight from the band arrays.
+  // Rounds 3-5 reserved 2 x 2K more columns here that nothing wrote or read: 12 KB at K = 19)
+  L.stage = o; o += 2 * G::NCX * G::GS + 2;   // (+ a dump double)
   L.gbuf = o; o += 2 * G::NGC * G::GS;
   {   // the second follower's rows of the next block row, [column][row] (+ a dump column)
-    constexpr int NHI = K >= 3 ? K - ((((K + 1) / 2) + 1) & ~1) : 0;
+    constexpr int NHI = K - pipe_rlo<K>();
     L.xhi = o; o += (G::NCX + (spike ? 2 * K : 0) + 1) * (NHI + (NHI & 1)) + 2;
   }
+  L.hp = o; o += pipe_mfma_follow<K>() ? (spike ? 2 : 1) * PIPE_HPN : 0;   // pipe_follow_mfma's scratch: main wavefronts, spike wavefronts
   (void)n;
   L.jbuf = o; o += spike ? (3 * K + 2) * G::KE : 0;   // a joiner: the producer's contributions to its two join rows, columns [S | H | y], [S | y]
   L.xall = o; o += (ND_MAXROWS + 2) * G::GS;   // rt of the chain's local rows (two leading zero rows)
@@ -268,6 +286,51 @@ __device__ __forceinline__ void pipe_pivot(double (&xr)[K], double inv, const do
   if constexpr (J + 1 < K) pipe_pivot<K, J + 1, JH>(xr, inv_next, mu, xj, rowp, rawp, slot0, is63, hook, dbg);
 }
 
+// ---- wave A, spike columns: pivot J of Ft = L^-1 F (lane = spike column, xr = the column's K rows).  The multipliers
+// T_J[c] = (D^-1 U)[J][c], c > J, are the MAIN wavefront's published row (`arow`, position c): nothing of this
+// wavefront's own goes into them, so they are read AHEAD of their use exactly as pipe_pivot does with its own -
+// T_J[J+2 ..] at pivot J for pivot J + 1 (`mu_p`, `xj_p`), and T_J[J+1], the one the next pivot's value waits for, a whole
+// pivot earlier (`m1`) - and a pivot here is K - J - 1 FMAs and two stores with ONE FMA on the dependent chain, not an LDS
+// round trip followed by the FMAs.  (Rounds 3-5 read them at their use: 125 ns a pivot, 2.4 us a row against the main
+// wavefront's 1.9.  The spike chain ran a row behind and set a joiner's pace through the G wavefront, which needs both rows:
+// 3.3 us a row.)  `need(J)`: returns once the main wavefront has published pivot J; asked one pivot ahead, for the read of m1.
+template <int K, int J, int JH, class Hook, class Need>
+__device__ __forceinline__ void pipe_spike_pivot(double (&xr)[K], const double (&mu_p)[K], const double xj_p, const double m1,
+                                                 double* __restrict__ rowp, double* __restrict__ fout, const bool store,
+                                                 const double* __restrict__ arow, Hook hook, Need need) {
+  using G = PipeGeo<K>;
+  if constexpr (J == JH) hook();
+  if constexpr (J + 2 < K) need(J + 2);   // (pivots J, J + 1 were asked for a step ago)
+  const double xj = xr[J];
+  if constexpr (J + 1 < K) {
+    if constexpr (J >= 1) xr[J + 1] = __builtin_fma(-mu_p[J + 1], xj_p, xr[J + 1]);   // pivot J-1's term
+    xr[J + 1] = __builtin_fma(-m1, xj, xr[J + 1]);                                      // pivot J's: the row is complete
+  }
+  rowp[J * G::RS] = pipe_setlane<63>(xj, 0x3ff00000, 0);
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  // (and to HBM for the separator's Q / this chain's own correction: column `lane`, row J; write-through - the
+  // separator sits on another XCD - so that the row's release is a drained store queue, not a fence)
+  if (store) __hip_atomic_store(fout + J, xj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  double mu[K];
+  double m1n = 0.0;
+  if constexpr (J + 2 < K) {
+    const double2* p2 = reinterpret_cast<const double2*>(arow + J * G::RS);
+#pragma unroll
+    for (int m = (J + 2) / 2; m < (K + 1) / 2; ++m) {
+      const double2 v = p2[m];
+      mu[2 * m] = v.x;
+      if (2 * m + 1 < K) mu[2 * m + 1] = v.y;
+    }
+    m1n = arow[(J + 1) * G::RS + J + 2];
+  }
+  if constexpr (J >= 1) {
+#pragma unroll
+    for (int r = J + 2; r < K; ++r) xr[r] = __builtin_fma(-mu_p[r], xj_p, xr[r]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (J + 1 < K) pipe_spike_pivot<K, J + 1, JH>(xr, mu, xj, m1n, rowp, fout, store, arow, hook, need);
+}
+
 // K uniform multipliers [pos0, pos0 + K) of a published row (pos0 even): LDS broadcast reads, two per instruction
 template <int K>
 __device__ __forceinline__ void pipe_read_mult(const double* __restrict__ row, int pos0, double (&mu)[K]) {
@@ -385,11 +448,8 @@ __device__ __forceinline__ double pipe_band(const PipeArgs& A, const double* p) 
 // critical path.  `spk` (compile time): this wavefront carries the 2K spike columns, else [S | H | E | y].
 template <int K>
 struct PipeRows {
-#ifdef PIPE_RLO   // (measurement aid: the share of the wavefront that eliminates next, K = 19 only)
-  static constexpr int RLO = K == 19 ? PIPE_RLO : (K >= 3 ? (((K + 1) / 2 + 1) & ~1) : K);
-#else
-  static constexpr int RLO = K >= 3 ? (((K + 1) / 2 + 1) & ~1) : K;   // even: the high rows' multipliers start 16-byte aligned
-#endif
+  static constexpr int RLO = pipe_rlo<K>();   // even: the high rows' multipliers start 16-byte aligned
+  static constexpr bool MFMA = pipe_mfma_follow<K>();
   static constexpr int NHI = K - RLO;
   static constexpr int JH = RLO >= 6 ? 4 : (RLO >= 2 ? RLO - 2 : 0);   // pivot at which the eliminating wavefront takes the high rows in
   static constexpr int XS = NHI + (NHI & 1);                          // stride of a column in the hand-over buffer
@@ -458,6 +518,61 @@ __device__ __forceinline__ void pipe_follow(const PipeCtl& ctl, const double* __
   }
 }
 
+// The low follower on the matrix cores (K >= 17).  xr[r] -= sum_J (Ht[J][r] / d_J) * v[J][c] for the 16 rows r of one row
+// tile and this lane's column c, where v = [Ht | Et | rt] unscaled (main wavefront: positions oRH ..., contiguous) or the
+// spike row Ft (oF ...).  k-step sq = pivots 4 sq .. 4 sq + 3 of the ring slot, as soon as they are published: A operand
+// the scaled rows D^-1 Ht (position oH + row; lane (fk, fl) reads row 4 sq + fk, entry fl), B operand three column tiles of
+// v; pad rows of the slot are zeros.  What a pivot costs this wavefront: a quarter of (4 LDS reads of 8 bytes with a
+// lane's own address + 3 matrix-core instructions) - against 5 broadcast reads of 16 bytes (1 KB of LDS bandwidth
+// each) + 1 + 10 FMAs of pipe_follow; a joiner's followers read 35 such broadcasts per pivot, 280 cycles of the LDS
+// pipeline against a pivot period of 250 (the solver's forward pass), which is what made a joiner's row 3.3 us
+// where the eliminating wavefront needs 2.0.  The K terms of an entry are summed on their own (in the accumulator) and
+// subtracted once, as before.  Columns of the tiles that no lane owns (pads, the words next to the spike row) are
+// garbage in, garbage out: a column of B only reaches the same column of the product.  `pc`: this lane's product column
+// (PIPE_HPC: none - the scratch's zero column).
+template <int K, bool spk, bool SPKWG, class Mid>
+__device__ __forceinline__ void pipe_follow_mfma(const PipeCtl& ctl, const double* __restrict__ prow, double* __restrict__ hp, const int pc,
+                                                 double (&xr)[K], Mid mid, double* dbg = nullptr) {
+  using G = PipeGeo<K>;
+  using d4 = __attribute__((ext_vector_type(4))) double;
+  constexpr int RS = G::RS, SK = (K + 3) / 4, CT = PIPE_HPC / 16, HS = PIPE_HS;
+  static_assert(2 * G::KE + 1 <= PIPE_HPC && 2 * K <= PIPE_HPC, "product columns");
+  static_assert(G::oRH + PIPE_HPC <= RS && G::oF + PIPE_HPC <= G::oRH, "B operand reads stay inside the row");
+  const int lane = threadIdx.x & 63, fl = lane & 15, fk = lane >> 4;
+  PipeWatch<K, spk> watch(prow, SPKWG);
+  d4 acc[CT];
+#pragma unroll
+  for (int tc = 0; tc < CT; ++tc) acc[tc] = d4{0.0, 0.0, 0.0, 0.0};
+  const double* op = prow + fk * RS + fl;
+#pragma unroll
+  for (int sq = 0; sq < SK; ++sq) {
+    watch.need(ctl, (4 * sq + 3 < K ? 4 * sq + 3 : K - 1));
+    const double* row = op + 4 * sq * RS;
+    const double a = row[G::oH];
+    double b[CT];
+#pragma unroll
+    for (int tc = 0; tc < CT; ++tc) b[tc] = row[(spk ? G::oF : G::oRH) + 16 * tc];
+#pragma unroll
+    for (int tc = 0; tc < CT; ++tc) acc[tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[tc], acc[tc], 0, 0, 0);
+    if (sq == SK / 2) mid();
+    if (dbg && sq >= 1 && sq <= 3) dbg[sq - 1] = (double)wall_clock64();   // (option "solver_debug")
+  }
+  // tiles -> this lane's column (the wavefront's own scratch: its LDS operations execute in order, no wait in between)
+#pragma unroll
+  for (int tc = 0; tc < CT; ++tc)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) hp[(16 * tc + fl) * HS + fk + 4 * rg] = acc[tc][rg];
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  const double2* h2 = reinterpret_cast<const double2*>(hp + pc * HS);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const double2 v = h2[q];
+    xr[2 * q] -= v.x;
+    xr[2 * q + 1] -= v.y;
+  }
+  if (dbg) dbg[3] = (double)wall_clock64();
+}
+
 template <int K, bool SPK, bool spk>
 __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCfg& cfg, const PipeLds& L, const PipeCtl& ctl,
                                                 const int sigma) {
@@ -490,11 +605,15 @@ __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCf
     else { pos = (lane == 63) ? G::og : G::odump + (lane & 7); scol = -1; gcol = -1; src = -1; has_col = false; }
   }
   const int srcp = src >= 0 ? src : G::oz;
+  // pipe_follow_mfma: the column of the product [Ht | Et | rt] (positions oRH ... of a row) / Ft that updates this lane's column
+  const int hpc = src < 0 ? PIPE_HPC : (spk ? src - G::oF : src - G::oRH);
   const int xcol = has_col ? scol : NCS;   // (lanes without a column: a dump column of the hand-over buffer)
   const int f_slotgen = spk ? PF_SLOTGEN2 : PF_SLOTGEN, f_rowdone = spk ? PF_ROWDONE2 : PF_ROWDONE;
   const int f_initd = spk ? PF_INITD2 : PF_INITD, f_hidone = spk ? PF_HIDONE2 : PF_HIDONE;
   double xr[K];
   double diag0 = 1.0;
+  int pending_release = -1;
+  (void)pending_release;
   auto publishes = [&](int il) { return il >= 0 && il < nloc; };   // (a producer's pseudo-rows publish nothing)
   // the inputs of row il -> xr (staged by the I/O wavefront)
   auto init_row = [&](int il) {
@@ -521,16 +640,16 @@ __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCf
     }
     pipe_wait(ctl, PF_STAGED + (il & 1), il + 1);
     if (has_col) {
-      const double2* s2 = reinterpret_cast<const double2*>(stg + (il & 1) * NCS * GS + scol * GS);
+      const double2* s2 = reinterpret_cast<const double2*>(stg + (il & 1) * G::NCX * GS + scol * GS);
 #pragma unroll
       for (int r2 = 0; r2 < K / 2; ++r2) { const double2 v = s2[r2]; xr[2 * r2] = v.x; xr[2 * r2 + 1] = v.y; }
-      if (K & 1) xr[K - 1] = stg[(il & 1) * NCS * GS + scol * GS + K - 1];
+      if (K & 1) xr[K - 1] = stg[(il & 1) * G::NCX * GS + scol * GS + K - 1];
     } else {
 #pragma unroll
       for (int r = 0; r < K; ++r) xr[r] = 0.0;
     }
     // the diagonal entry of the band block this lane's pivot starts from (pivot test after the elimination)
-    diag0 = (!spk && lane < K) ? stg[(il & 1) * NCS * GS + lane * GS + lane] : 1.0;
+    diag0 = (!spk && lane < K) ? stg[(il & 1) * G::NCX * GS + lane * GS + lane] : 1.0;
     if (!spk) pipe_post(ctl, f_initd + (il & 1), il + 1);
   };
   // x[r] -= G[r] for r < nr (rows of this lane's column of G = Et^T Dn [Et | rt | Ft] of row il - 2, gbuf[il & 1])
@@ -605,6 +724,14 @@ __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCf
       pipe_wait(ctl, PF_SLOTGEN + pslot, il);
       if (spk) pipe_wait(ctl, PF_SLOTGEN2 + pslot, il);
       pstamp(2);
+      if constexpr (R::MFMA) {
+        pipe_follow_mfma<K, spk, SPK>(ctl, ring + pslot * G::SLOT, lds + L.hp + (spk ? PIPE_HPN : 0), hpc, xr,
+                                      [&] { pstamp(4); if (!subg_done) subg(); },
+                                      (!spk && cfg.ts && il == 4 && lane == 0) ? cfg.ts + 20 : nullptr);
+        pstamp(5);
+        if (!subg_done) subg();
+        pstamp(6);
+      } else {
       double acc[RLO];
 #pragma unroll
       for (int r = 0; r < RLO; ++r) acc[r] = 0.0;
@@ -617,6 +744,7 @@ __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCf
 #pragma unroll
       for (int r = 0; r < RLO; ++r) xr[r] -= acc[r];
       pstamp(6);
+      }
     }
     if (!subg_done) subg();
     auto high_rows = [&]() {
@@ -683,6 +811,7 @@ __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCf
         }
       } else {
         // spike columns: Ft = L^-1 F with the multipliers D^-1 U the main wavefront publishes; rows go out unscaled
+        if (cfg.ts && il == 4 && lane == 0) cfg.ts[16] = (double)wall_clock64();   // option "solver_debug": the spike wavefront's row 4 begins ...
         const double* arow = ring + slot * G::SLOT;
         double* fout = A.fst + (size_t)il * A.fstride + pipe_opaque(lane * ks);
         pipe_wait(ctl, PF_SLOTGEN + slot, il + 1);
@@ -700,11 +829,8 @@ __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCf
           __atomic_signal_fence(__ATOMIC_SEQ_CST);
           rowp[J * RS] = pipe_setlane<63>(xr[J], 0x3ff00000, 0);
           __atomic_signal_fence(__ATOMIC_SEQ_CST);
-          // (and to HBM for the separator's Q / this chain's own correction: column `lane`, row J; write-through - the
-          // separator sits on another XCD - so that the row's release below is a drained store queue, not a fence)
           if (lane < 2 * K) __hip_atomic_store(fout + J, xr[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (J + 1 < K) {
-            // multipliers T_J[c], c = J+1 .. K-1 (pairs from the even position below J+1)
             const double2* p2 = reinterpret_cast<const double2*>(arow + J * RS);
 #pragma unroll
             for (int m = (J + 1) / 2; m < (K + 1) / 2; ++m) {
@@ -715,10 +841,21 @@ __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCf
           }
         }
         pipe_post(ctl, f_rowdone + slot, il + 1);
+        if (cfg.ts && il == 4 && lane == 0) cfg.ts[17] = (double)wall_clock64();   // ... its last pivot is published ...
         // the row's spike block is in HBM: one of the three releases the separator waits for (the G wavefront adds two
         // with 1 / d and rt)
+#ifdef PIPE_DEFER_RELEASE
+        if (il + 3 >= nloc) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_fetch_add(A.frowcnt + il, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          pending_release = il;
+        }
+#else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(A.frowcnt + il, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+        if (cfg.ts && il == 4 && lane == 0) cfg.ts[18] = (double)wall_clock64();   // ... and released to the separator
       }
     }
     // ---- follower of row il + 1: the HIGH rows of row il + 2 for the wavefront that eliminates it; half-way,
@@ -726,6 +863,14 @@ __device__ __forceinline__ void pipe_chain_wave(const PipeArgs& A, const ChainCf
     bool inited = false;
     follow_high(il + 2, [&] { if (il + 3 < nrows) init_row(il + 3); inited = true; });
     if (!inited && il + 3 < nrows) init_row(il + 3);
+    if (spk && cfg.ts && il == 4 && lane == 0) cfg.ts[19] = (double)wall_clock64();   // (the spike wavefront of row 4 has followed row 5)
+#ifdef PIPE_DEFER_RELEASE
+    if (spk && pending_release >= 0) {   // the stores of that row were issued a row ago: acknowledged by now
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(A.frowcnt + pending_release, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pending_release = -1;
+    }
+#endif
   }
 }
 
@@ -766,6 +911,8 @@ __device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& 
   }
   for (int idx = tid; idx < 3 * K; idx += blockDim.x) ring[(idx / K) * G::SLOT + (idx % K) * RS + G::oz] = 0.0;
   for (int idx = tid; idx < (ND_MAXROWS + 2) * GS; idx += blockDim.x) lds[L.xall + idx] = 0.0;
+  if (pipe_mfma_follow<K>())   // pipe_follow_mfma: the scratch's zero column (main, spike)
+    for (int idx = tid; idx < (SPK ? 2 : 1) * PIPE_HS; idx += blockDim.x) lds[L.hp + (idx / PIPE_HS) * PIPE_HPN + PIPE_HPC * PIPE_HS + idx % PIPE_HS] = 0.0;
   __syncthreads();
   chain_ts(cfg, 0);
 
@@ -790,7 +937,7 @@ __device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& 
       const int e = lane + 64 * s;
       const bool valid = e < G::NCX * K;
       const int c = valid ? e / K : 0, r = valid ? e - c * K : 0;
-      s_dst[s] = valid ? c * GS + r : 2 * NCS * GS;   // (one dump double behind the two staging buffers)
+      s_dst[s] = valid ? c * GS + r : 2 * G::NCX * GS;   // (one dump double behind the two staging buffers)
       s_off[s] = 0;
       if (!valid) continue;
       if (c < K) { s_off[s] = dHC + c * k + r; mAny |= 1ull << s; }
@@ -803,7 +950,7 @@ __device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& 
       const int o = orig(il);
       const double* base = A.HA + (size_t)o * kk;
       const double* bp = A.b + (size_t)o * k;
-      double* dst = stg + (il & 1) * NCS * GS;
+      double* dst = stg + (il & 1) * G::NCX * GS;
       // join rows of a joiner have no coupling beyond the join, a producer's pseudo-rows have all-zero inputs
       unsigned long long kill = ~mAny;
       if (pseudo) kill = ~0ull;
@@ -828,7 +975,7 @@ __device__ __forceinline__ void pipe_forward(const PipeArgs& A, const ChainCfg& 
       for (int s = 0; s < PM; ++s) {
         double v = (mY >> s & 1) ? A.rhs_sign * val[s] : val[s];
         v = (kill >> s & 1) ? 0.0 : v;
-        if (s_dst[s] < 2 * NCS * GS) dst[s_dst[s]] = v;
+        if (s_dst[s] < 2 * G::NCX * GS) dst[s_dst[s]] = v;
       }
     };
     // The producer's Schur-complement contributions to the joiner's two join rows (its two pseudo-rows; penta_nd.h

@@ -55,6 +55,10 @@ if dev.get_option("last_solver") == 4:   # pipelined chains (csrc/penta_pipe.h):
         print("   back substitution: recursion matrices ready %s, corrected by the separator's solution %s, recursion from %s to %s" % (at(dr[3]), at(dr[21]), at(dr[22]), at(dr[4])))
         print("   row 4 as follower: inputs wanted %s, follow from %s, half of its rows applied %s, last row read %s, ready to eliminate %s"
               % tuple(at(dr[8 + i]) for i in (0, 2, 4, 5, 6)))
+        print("   row 4 as follower, k-steps 1, 2, 3 done at %s %s %s, own column back from the tiles %s" % tuple(at(dr[20 + i]) for i in range(4)))
+        if r >= 2:
+            print("   spike wavefront, row 4: begins %s, last pivot published %s, released to the separator %s, row 5 followed (high rows of row 6) %s"
+                  % tuple(at(dr[16 + i]) for i in range(4)))
     x = d[6] - t0
     print(f"separator    start {x[0]:6.2f}  Q ready {x[1]:6.2f}  W built {x[3]:6.2f}  row s {x[4]:6.2f}  S' {x[5]:6.2f}  row s+1 {x[6]:6.2f}  solved+posted {x[2]:6.2f}")
     sys.exit(0)
