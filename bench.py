@@ -634,6 +634,8 @@ def main():
             names[2] = "penta_pipe_kernel"
         elif dev.get_option("last_solver") == 6:   # the small models: scalar band factorisation, one workgroup (csrc/penta_band.h)
             names[2] = "penta_band_kernel"
+        elif dev.get_option("last_solver") == 7:   # ... and their whole step in one workgroup of one launch (csrc/gn_small.h)
+            names[3] = "gn_small_kernel"
         if dev.get_option("last_assembly") == 1:   # products formed by fd_kernel, combined here (kernels.h)
             names[1] = "assemble_terms_kernel"
         asm_inside = dev.get_option("last_assembly") == 4   # the solver's launch assembled g and H itself (penta_pipe.h PipeAsm)

@@ -1,0 +1,336 @@
+// gn_small.h — the whole Gauss-Newton step of a SMALL model in ONE workgroup of ONE launch.
+//
+// acrobot (2 DoF) and the spinner (3 DoF, one contact pair) at N = 40 are 280 / 400 inverse-dynamics evaluations, 82 /
+// 123 unknowns: the two-launch step (fd_kernel on 40 workgroups, then penta_band_kernel with 164 assembly workgroups
+// in front of its one solver workgroup) spends most of its 28 / 39 us on what lies BETWEEN workgroups - a kernel
+// boundary, the cold first touch behind it, the assembly's write-through stores, their acknowledgement, the solver's
+// poll and its loads (penta_band.h: "g, H assembled 5.2 us after the launch's start") - and on the CPU port's side of
+// the table eight threads are faster (43.8k against 35.4k it/s for acrobot).  Here every phase of
+// reference optimizer/trajectory_optimizer.cc's iteration runs in the LDS of one compute unit:
+//
+//   A  loads        model records, q (all N + 1 rows), the weights' diagonals                          (one round of loads)
+//   B  v, a, dq     TO.cc:178-202, :501-521 - fd_body's expressions (fd_kernel.h), a thread per (t, row) / (k, evaluation)
+//   C  evaluations  lane = (k, e): id_eval_fast<SHAPE> (id_fast.h) with fd_body's InFwd gather, all N (1 + 3 nq) at once
+//   D  records      dtau_k/dq_{k-1,k,k+1} (TO.cc:527-561) -> the slab (API: IDTO_ARR_DTAU_*) and LDS
+//   E  assembly     g, the bands (TO.cc:1021-1165): assemble_diag_body's sums (kernels.h), a thread per output entry
+//   F  solve        penta_band_body (penta_band.h): the scalar band LDL^T, two wavefronts
+//
+// Same expressions in the same order as the kernels it stands in for, hence the same bits:
+// tests/test_gpu_small.py holds every array of the step == the two-launch path (which is == the oracle).
+// Serves: models of fast shape 1 / 5 (all joints revolute: N+ is the constant table, nq = nv <= 4), forward differences,
+// diagonal cost weights, single-problem contexts or batches (grid.y = problem); anything else keeps the two launches.
+#pragma once
+
+#include "kernels.h"
+#include "penta_band.h"
+
+namespace idto_dev {
+
+struct SmallArgs {
+  DevModel M;
+  DevContact cp;
+  DevProblem P;
+  const double* q;
+  double* slab; int slab_stride;
+  double *v, *a, *nplus;
+  double *g, *HA, *HB, *HC;
+  size_t pstride;
+  AltSel alt;
+  BandArgs B;       // the solver's view (sub-system from block row 1 on)
+  int lds_small;    // where this kernel's own arrays start (doubles): behind the band solver's carve-up
+  double* ts;       // option "solver_debug" 4: wall-clock stamps of the phases (100 MHz), else nullptr
+};
+
+// doubles of dynamic LDS behind the band solver's carve-up (gn_small_kernel's own arrays, in its order)
+__host__ __device__ inline int gn_small_doubles(int N, int K, int fast_n) {
+  const int E = 1 + 3 * K;
+  return 2 * (N + 1) * K + N * K + 3 * N * E + N * E * K + K * K + 3 * N * K * K + 5 * K + (K & 1) + fast_n + (fast_n & 1) +
+         3 * (N + 1) * K * K + 3 * (N + 1) * K + 2 * K * K + (K * K & 1) + K + 2;
+}
+
+template <int SHAPE, int W, int NT>
+__global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
+  extern __shared__ double lds[];
+  using FS = FastShape<SHAPE>;
+  static_assert(FS::NP == 1 && FS::CJ < 0, "one path, no common body");
+  constexpr int K = W / 3;                      // nq = nv
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const size_t o = (size_t)blockIdx.y * S.pstride, w = o + (size_t)alt_offset(S.alt, o);
+  const DevProblem P = at_problem(S.P, o);
+  const double* q = at_problem(S.q, o);
+  double* slab = at_problem(S.slab, w);
+  double* v_out = at_problem(S.v, w);
+  double* a_out = at_problem(S.a, w);
+  double* nplus_out = at_problem(S.nplus, w);
+  double* g = at_problem(S.g, o);
+  double* HA = at_problem(S.HA, o);
+  double* HB = at_problem(S.HB, o);
+  double* HC = at_problem(S.HC, o);
+  const DevModel& M = S.M;
+  const int N = P.N, nq = K, nv = K, bsz = K * K, qq = K * K;
+  const int nP = nq, nT = nq, nM = nv, E = 1 + nP + nT + nM;
+  const double dt = P.dt;
+
+  // ---- carve-up (doubles), behind the band solver's
+  double* qs = lds + S.lds_small;          // [(N + 1) K]
+  double* vs = qs + (N + 1) * K;           // [(N + 1) K]
+  double* as = vs + (N + 1) * K;           // [N K]
+  double* edq = as + N * K;                // [N E], then dq / dt, dq / dt^2
+  double* edv = edq + N * E;
+  double* eda = edv + N * E;
+  double* etau = eda + N * E;              // [N E K]
+  double* Nid = etau + N * E * K;          // [K K] N+ (constant for these models)
+  double* rP = Nid + bsz;                  // [N K K] dtau_k/dq_{k+1}, column-major blocks
+  double* rT = rP + N * bsz;               // dtau_k/dq_k
+  double* rM = rT + N * bsz;               // dtau_k/dq_{k-1} (zero for k < 2, as the assembly wants it)
+  double* wR = rM + N * bsz;               // diagonals: R', Qv', Qfv', Qq', Qfq' (TO.cc:1103-1107, pre-scaled on the host)
+  double* wQV = wR + K;
+  double* wQFV = wQV + K;
+  double* wQ = wQFV + K;
+  double* wFQ = wQ + K;
+  double* mblob = wFQ + K + (K & 1);       // [M.fast_n] the fast shape's records
+  double* hA = mblob + M.fast_n + (M.fast_n & 1);   // [(N + 1) K K] x 3: the bands, where the solver stages them from
+  double* hB = hA + (N + 1) * qq;
+  double* hC = hB + (N + 1) * qq;
+  double* hg = hC + (N + 1) * qq;                   // [(N + 1) K]
+  double* qn = hg + (N + 1) * K;                    // [(N + 1) K] q_nom, v_nom
+  double* vn = qn + (N + 1) * K;
+  double* wQf = vn + (N + 1) * K;                   // [K K] x 2: Qq', Qfq' (the C blocks start from their entries)
+  double* wFQf = wQf + qq;
+  int* colinfo = reinterpret_cast<int*>(wFQf + qq + (qq & 1));   // [K] non-zero rows of N+ column c, [K] non-zero columns of row r
+  int* rowinfo = colinfo + K;
+
+  auto stamp = [&](int i) { if (S.ts && tid == 0 && blockIdx.y == 0) S.ts[i] = (double)wall_clock64(); };
+  stamp(0);
+  // ---- A: every global load of the step (but the nominal trajectory, first used in E)
+  for (int i = tid; i < M.fast_n; i += nt) mblob[i] = M.blob[M.fast_lo + i];
+  for (int i = tid; i < (N + 1) * K; i += nt) qs[i] = q[i];
+  for (int i = tid; i < bsz; i += nt) { Nid[i] = M.nplus_const[i]; wQf[i] = P.Qq[i]; wFQf[i] = P.Qfq[i]; }
+  for (int i = tid; i < (N + 1) * K; i += nt) { qn[i] = P.q_nom[i]; vn[i] = P.v_nom[i]; }
+  const BandLds BL = band_layout(S.B.n * K, W);
+  band_pad(lds, BL, tid, nt);   // (the solver's copies: their padding now, behind this phase's barrier)
+  if (tid < K) {
+    wR[tid] = P.R[tid * nv + tid]; wQV[tid] = P.Qv[tid * nv + tid]; wQFV[tid] = P.Qfv[tid * nv + tid];
+    wQ[tid] = P.Qq[tid * nq + tid]; wFQ[tid] = P.Qfq[tid * nq + tid];
+    colinfo[tid] = M.colinfo[tid];
+    rowinfo[tid] = M.rowinfo[tid];
+  }
+  __syncthreads();
+  stamp(1);
+  const DevModel Ml = rebase_model(M, mblob - M.fast_lo);
+
+  // ---- B: v_t = N+ (q_t - q_{t-1}) / dt (fd_body's sparse form: the row's non-zero range), then a_k and the perturbations
+  for (int idx = tid; idx < (N + 1) * K; idx += nt) {
+    const int t = idx / K, r = idx - t * K;
+    double vr;
+    if (t == 0) {
+      vr = P.v_init[r];
+    } else {
+      const int ri = rowinfo[r], c0 = ri & 0xffff, c1 = c0 + (ri >> 16);
+      double acc = Nid[c0 * nv + r] * (qs[t * K + c0] - qs[(t - 1) * K + c0]);
+      for (int c = c0 + 1; c < c1; ++c) acc += Nid[c * nv + r] * (qs[t * K + c] - qs[(t - 1) * K + c]);
+      vr = acc / dt;
+    }
+    vs[idx] = vr;
+    v_out[idx] = vr;
+  }
+  const double eps = 1.4901161193847656e-08;  // sqrt(DBL_EPSILON)
+  for (int idx = tid; idx < N * E; idx += nt) {
+    const int k = idx / E, e = idx - k * E;
+    double dq = 1.0;
+    if (e >= 1 && e < 1 + nP + nT) {
+      const int i = (e - 1) % nq;
+      const double qi = (e < 1 + nP) ? qs[(k + 1) * K + i] : qs[k * K + i];
+      dq = eps * __builtin_fmax(1.0, __builtin_fabs(qi));
+      const double temp = qi + dq;
+      dq = temp - qi;
+    }
+    edq[idx] = dq;
+    const double dv = dq / dt;
+    edv[idx] = dv;
+    eda[idx] = dv / dt;
+  }
+  for (int i = tid; i < (N + 1) * bsz; i += nt) nplus_out[i] = Nid[i % bsz];
+  __syncthreads();
+  for (int idx = tid; idx < N * K; idx += nt) {
+    const double ar = (vs[idx + K] - vs[idx]) / dt;
+    as[idx] = ar;
+    a_out[idx] = ar;
+  }
+  __syncthreads();
+  stamp(2);
+
+  // ---- C: the evaluations, lane = (k, e)
+  {
+    FastTab FT;
+    FT.body = Ml.f_body; FT.cbody = Ml.f_cbody; FT.pairs = Ml.f_pairs; FT.seg = Ml.f_seg; FT.maxpp = Ml.f_maxpp;
+    for (int idx = tid; idx < N * E; idx += nt) {
+      const int k = idx / E, el = idx - k * E;
+      InFwd in;
+      in.q1 = qs + (k + 1) * K; in.v1 = vs + (k + 1) * K; in.a0 = as + k * K; in.N1 = Nid; in.N0 = Nid; in.nv = nv;
+      in.kind = (el == 0) ? 0 : ((el < 1 + nP) ? 1 : ((el < 1 + nP + nT) ? 2 : 3));
+      in.col = (el == 0) ? 0 : ((el < 1 + nP) ? el - 1 : ((el < 1 + nP + nT) ? el - 1 - nP : el - 1 - nP - nT));
+      in.dq = edq[idx];
+      in.sdv = (in.kind == 2) ? -edv[idx] : ((in.kind == 1) ? edv[idx] : 0.0);
+      in.sda = (in.kind == 2) ? -eda[idx] : ((in.kind == 1) ? eda[idx] : 0.0);
+      in.keep = (in.kind == 3) ? 0ull : ~0ull;
+      in.keep0 = (in.kind == 2) ? ~0ull : 0ull;
+      id_eval_fast<FS::MAXC, FS::NP, FS::CJ, FS::J0, FS::K0, FS::W2>(FT, Ml.gravity, S.cp, 0, el < 1 + nP + nT, in, etau + idx * K);
+    }
+  }
+  __syncthreads();
+  stamp(3);
+
+  // ---- D: the records (fd_body, mode 1)
+  {
+    const double sc = 1 / dt / dt;
+    for (int idx = tid; idx < N * bsz; idx += nt) {
+      const int k = idx / bsz, rem = idx - k * bsz, i = rem / nv, r = rem - i * nv;
+      const double* et = etau + k * E * K;
+      const int ci = colinfo[i], j0 = ci & 0xffff, cnt = ci >> 16;
+      const double tp = et[(1 + i) * nv + r], tt = et[(1 + nP + i) * nv + r], t0 = et[r];
+      const double dqp = edq[k * E + 1 + i], dqt = edq[k * E + 1 + nP + i];
+      const double* Mcols = et + (1 + nP + nT) * nv;
+      const double pv = (tp - t0) / dqp;
+      const double tv = (k >= 1) ? (tt - t0) / dqt : 0.0;
+      double acc = (sc * Mcols[j0 * nv + r]) * Nid[i * nv + j0];
+      if (cnt > 1) acc += (sc * Mcols[(j0 + 1) * nv + r]) * Nid[i * nv + j0 + 1];
+      if (cnt > 2) acc += (sc * Mcols[(j0 + 2) * nv + r]) * Nid[i * nv + j0 + 2];
+      const double fillM = (k == 0) ? __builtin_nan("") : 0.0;
+      double* sl = slab + (size_t)k * S.slab_stride;
+      sl[rem] = (k >= 2) ? acc : fillM;          // dtau_k/dq_{k-1}
+      sl[bsz + rem] = tv;                        // dtau_k/dq_k
+      sl[2 * bsz + rem] = pv;                    // dtau_k/dq_{k+1}
+      rP[idx] = pv; rT[idx] = tv; rM[idx] = (k >= 2) ? acc : 0.0;
+    }
+    for (int idx = tid; idx < N * nv; idx += nt) {
+      const int k = idx / nv, r = idx - k * nv;
+      slab[(size_t)k * S.slab_stride + 3 * bsz + r] = etau[k * E * K + r];
+    }
+  }
+  __syncthreads();
+  stamp(4);
+
+  // ---- E: g and the bands (assemble_diag_body: same terms, same order).  A thread per (block row, r, c) forms C_i(r, c),
+  // B_i(r, c), A_i(r, c) from the same nine operand columns; a thread per (block row, j) the gradient entry.  Straight-line:
+  // every operand is loaded whatever the row (block indices clamped), every sum is formed, and the row's conditions
+  // (TO.cc:1127-1161: which terms exist at i = N - 1, N, below 2 / 3) SELECT among them - a branch per condition put an LDS
+  // round trip behind every term (4.5 us for acrobot's 574 entries, 11.5 us for the spinner's 1230).  The weighted operand
+  // X(l, r) = A(l, r) w_l is formed here, the very product the staged copy of assemble_diag_body holds.
+  {
+    const double idt = 1 / dt, midt = -1 / dt;
+    const int per = qq + nq;   // items per block row
+    for (int idx = tid; idx < (N + 1) * per; idx += nt) {
+      const int i = idx / per, e = idx - i * per;
+      double* Cg = HC + (size_t)i * qq;
+      double* Bg = HB + (size_t)i * qq;
+      double* Ag = HA + (size_t)i * qq;
+      double* Cl = hC + i * qq;   // (the same entries once more in LDS: the solver's staging reads them there)
+      double* Bl = hB + i * qq;
+      double* Al = hA + i * qq;
+      const int im1 = i >= 1 ? i - 1 : 0, i0 = i < N ? i : N - 1, ip1 = i < N - 1 ? i + 1 : N - 1;
+      const double* Pm1 = rP + im1 * bsz;   // S_PM1
+      const double* Tm1 = rT + im1 * bsz;   // S_TM1
+      const double* Mm1 = rM + im1 * bsz;   // S_MM1 (i >= 3)
+      const double* T0 = rT + i0 * bsz;     // S_T0  (i < N)
+      const double* M0 = rM + i0 * bsz;     // S_M0  (i < N; rM is zero below k = 2)
+      const double* Mp1 = rM + ip1 * bsz;   // S_MP1 (i < N - 1)
+      if (e < qq) {
+        const int c = e / nq, r = e - c * nq;
+        double pr[K], pc[K], tr_[K], tc[K], mr[K], mc[K], tm[K], m0[K], mm[K], nr[K], nc[K], wv[K], ww[K], wr[K];
+#pragma unroll
+        for (int l = 0; l < K; ++l) {
+          pr[l] = Pm1[r * K + l]; pc[l] = Pm1[c * K + l]; tr_[l] = T0[r * K + l]; tc[l] = T0[c * K + l];
+          mr[l] = Mp1[r * K + l]; mc[l] = Mp1[c * K + l]; tm[l] = Tm1[c * K + l]; m0[l] = M0[c * K + l]; mm[l] = Mm1[c * K + l];
+          nr[l] = Nid[r * K + l]; nc[l] = Nid[c * K + l];
+          wv[l] = (i < N) ? wQV[l] : wQFV[l]; ww[l] = (i < N - 1) ? wQV[l] : wQFV[l]; wr[l] = wR[l];
+        }
+        const double w0 = (i < N) ? wQf[c * nq + r] : wFQf[c * nq + r];
+        double xP[K], xT[K], xM[K], xV[K], xW1[K], sV[K], sW[K];
+#pragma unroll
+        for (int l = 0; l < K; ++l) {
+          xP[l] = pr[l] * wr[l]; xT[l] = tr_[l] * wr[l]; xM[l] = mr[l] * wr[l];
+          xV[l] = (idt * nr[l]) * wv[l]; xW1[l] = (midt * nr[l]) * ww[l];
+          sV[l] = idt * nc[l]; sW[l] = midt * nc[l];
+        }
+        auto dot = [&](const double (&x)[K], const double (&y)[K]) __attribute__((always_inline)) {
+          double acc = x[0] * y[0];
+#pragma unroll
+          for (int l = 1; l < K; ++l) acc = acc + x[l] * y[l];
+          return acc;
+        };
+        const double dVV = dot(xV, sV), dPP = dot(xP, pc), dTT = dot(xT, tc), dMM = dot(xM, mc), dWW = dot(xW1, sW);
+        const double dPT = dot(xP, tm), dTM = dot(xT, m0), dVW = dot(xV, sW), dPM = dot(xP, mm);
+        // C_i (TO.cc:1127-1137 / :1157-1161)
+        const double c2 = (w0 + dVV) + dPP;
+        const double c3 = c2 + dTT;
+        const double c4 = (i < N - 1) ? c3 + dMM : c3;
+        const double cN = (i < N) ? c4 + dWW : c2;
+        // B_i (TO.cc:1140-1147), A_i (:1150-1153)
+        const double b2 = (i < N) ? dPT + dTM : dPT;
+        const double bN = (i >= 2) ? b2 + dVW : 0.0;
+        const double aN = (i >= 3) ? dPM : 0.0;
+        const double Cv = (i == 0) ? ((r == c) ? 1.0 : 0.0) : cN;
+        const double Bv = (i == 0) ? 0.0 : bN, Av = (i == 0) ? 0.0 : aN;
+        if (r >= c) {   // the lower triangle's thread writes both mirror images (MakeSymmetric)
+          Cg[c * nq + r] = Cv; Cg[r * nq + c] = Cv;
+          Cl[c * nq + r] = Cv; Cl[r * nq + c] = Cv;
+        }
+        Bg[e] = Bv; Bl[e] = Bv;
+        Ag[e] = Av; Al[e] = Av;
+      } else {   // gradient block (TO.cc:1046-1080)
+        const int j = e - qq;
+        double pj[K], tj[K], mj[K], nj[K], ev[K], evp[K], em1[K], e0[K], ep1[K];
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+          pj[r] = Pm1[j * K + r]; tj[r] = T0[j * K + r]; mj[r] = Mp1[j * K + r]; nj[r] = Nid[j * K + r];
+          ev[r] = vs[i * K + r] - vn[i * nv + r];
+          evp[r] = vs[(i < N ? i + 1 : N) * K + r] - vn[(i < N ? i + 1 : N) * nv + r];
+          em1[r] = etau[im1 * E * K + r]; e0[r] = etau[i0 * E * K + r]; ep1[r] = etau[ip1 * E * K + r];
+        }
+        const double qe = qs[i * K + j] - qn[i * nq + j];
+        // sum_r (e_r w_r) J[r]
+        auto vwm = [&](const double (&ee)[K], const double* wgt, const double (&J)[K], const double sj) __attribute__((always_inline)) {
+          double acc = (ee[0] * wgt[0]) * (sj * J[0]);
+#pragma unroll
+          for (int r = 1; r < K; ++r) acc += (ee[r] * wgt[r]) * (sj * J[r]);
+          return acc;
+        };
+        auto vwr = [&](const double (&ee)[K], const double* wgt, const double (&J)[K]) __attribute__((always_inline)) {
+          double acc = (ee[0] * wgt[0]) * J[0];
+#pragma unroll
+          for (int r = 1; r < K; ++r) acc += (ee[r] * wgt[r]) * J[r];
+          return acc;
+        };
+        const double gV = vwm(ev, wQV, nj, idt), gVf = vwm(ev, wQFV, nj, idt);
+        const double gW = vwm(evp, (i == N - 1) ? wQFV : wQV, nj, midt);
+        const double gP = vwr(em1, wR, pj), gT = vwr(e0, wR, tj), gM = vwr(ep1, wR, mj);
+        double ga = qe * wQ[j];
+        ga = ga + gV;
+        ga = ga + gW;
+        ga = ga + gP;
+        ga = ga + gT;
+        ga = (i != N - 1) ? ga + gM : ga;
+        double gb = gP;
+        gb = gb + qe * wFQ[j];
+        gb = gb + gVf;
+        const double gj = (i == 0) ? 0.0 : ((i < N) ? ga : gb);
+        g[(size_t)i * nq + j] = gj;
+        hg[i * nq + j] = gj;
+      }
+    }
+  }
+  // ---- F: the band solve, from the bands just written (this workgroup's own stores: a barrier's release / acquire at
+  // workgroup scope orders them; nothing of g or H was read by this compute unit before)
+  __syncthreads();
+  stamp(5);
+  PipeAsm F{};
+  BandArgs B = S.B;   // the solver stages from the LDS copies (generic pointers into LDS: no problem offset), writes to memory
+  B.x = at_problem(B.x, o); B.Dst = at_problem(B.Dst, o);
+  B.pstride = 0;
+  B.HA = hA + qq; B.HB = hB + qq; B.HC = hC + qq; B.b = hg + K;   // (from block row 1 on: row 0 is the identity)
+  penta_band_body<W, true>(B, F);
+  stamp(6);
+}
+
+}  // namespace idto_dev

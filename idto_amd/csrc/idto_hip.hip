@@ -31,6 +31,7 @@
 #include "penta_nd.h"
 #include "penta_pipe.h"
 #include "penta_band.h"
+#include "gn_small.h"
 #include "penta_apply.h"
 #include "constraints.h"
 #include "dense_ldl.h"
@@ -243,6 +244,7 @@ struct idto_hip_ctx {
   bool fused = true;                      // gn_step: one persistent launch (fused.h) when eligible
   bool solver_nd = true;                  // solver: nested dissection over 7 workgroups (penta_nd.h) when eligible
   bool solver_pipe = true;                // ... with pipelined chains (penta_pipe.h: 5 workgroups) when the block size allows
+  int gn_small = 1;                       // option "gn_small": the whole step of a small model in one workgroup (gn_small.h; see SmallEligible)
   int solver_band = 1;                    // small blocks: the scalar band factorisation in one workgroup (penta_band.h; see BandEligible)
   unsigned long long* nd_rowcnt = nullptr; // its per-row release counters, buffers and launch count
   unsigned* asm_ready = nullptr;               // penta_pipe.h PipeAsm: [N + 1][4] epoch words of the assembly inside the solver's launch
@@ -1088,6 +1090,8 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
 #define BAND_ATTR(WM) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_band_kernel<WM>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   BAND_ATTR(6) BAND_ATTR(9) BAND_ATTR(12) BAND_ATTR(15)
 #undef BAND_ATTR
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_small_kernel<1, 6, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_small_kernel<5, 9, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cost_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -1708,6 +1712,66 @@ static int LaunchFused(idto_hip_ctx* c) {
   HIP_OK(hipGetLastError());
   c->fd_full = true; c->partials_ahead = false;
   c->terms_valid = false;   // (the fused kernel assembles from the slab itself)
+  return TimeEnd(c);
+}
+
+// gn_small.h: fd + assembly + band solve of a small all-revolute model in ONE workgroup per problem.  What it stands in
+// for must be what the two launches would have run: forward differences from the straight-line evaluation, diagonal
+// weights, the whole horizon, the scalar band factorisation (BandEligible), nothing switched to a measurement mode.
+static int SmallLds(const idto_hip_ctx* c, const LdlPlan& p, int* lds_small) {
+  int band = band_layout(p.n * p.k, 3 * p.k).end;
+  band += band & 1;
+  if (lds_small) *lds_small = band;
+  return (band + gn_small_doubles(c->N, c->nq, c->M.fast_n)) * (int)sizeof(double);
+}
+static bool SmallEligible(const idto_hip_ctx* c) {
+  if (!c->gn_small || !c->fd_fast || c->gradients_method != 0 || !c->weights_diagonal || c->reference_solver) return false;
+  if (!(c->M.fast_shape == 1 || c->M.fast_shape == 5) || c->M.nfloat != 0 || c->nq != c->nv || c->npaths != 1) return false;
+  if (!((c->M.fast_shape == 1 && c->nq == 2) || (c->M.fast_shape == 5 && c->nq == 3))) return false;   // (the instantiations)
+  if (c->k_begin != 0 || c->k_end != c->N || c->fd_stop || c->asm_stop || c->solver_debug || c->ldl_npos > 0) return false;
+  LdlPlan p;
+  idto_hip_ctx* cc = const_cast<idto_hip_ctx*>(c);
+  const bool assembled = c->h_assembled;
+  cc->h_assembled = true;   // (the kernel assembles H itself: block row 0 is the identity, the solver starts at row 1)
+  const bool ok = c->N >= 2 && PlanLdl(cc, false, &p) == 0 && BandEligible(c, p) && p.r0 == 1 && SmallLds(c, p, nullptr) <= 160 * 1024;
+  cc->h_assembled = assembled;
+  return ok;
+}
+static int LaunchSmall(idto_hip_ctx* c) {
+  DropPrefetch(c, {IDTO_ARR_V, IDTO_ARR_A, IDTO_ARR_NPLUS, IDTO_ARR_SLAB, IDTO_ARR_GRADIENT, IDTO_ARR_H_A, IDTO_ARR_H_B,
+                   IDTO_ARR_H_C, IDTO_ARR_HBANDS, IDTO_ARR_STEP});
+  c->con_ready = false; c->con_begun = false;
+  if (!c->h_assembled) {  // x_0 = -g_0 = 0 is not written by the solver (SolverFirstRow)
+    HIP_OK(hipMemset2DAsync(c->step, c->pstride, 0, (size_t)c->nq * sizeof(double), (size_t)c->batch, c->stream));
+    c->h_assembled = true;
+  }
+  LdlPlan p;
+  if (int rc = PlanLdl(c, false, &p)) return rc;
+  SmallArgs A;
+  A.M = c->M; A.cp = c->cp; A.P = c->P; A.q = c->q; A.slab = c->slab; A.slab_stride = c->slab_stride;
+  A.v = c->v; A.a = c->a; A.nplus = c->nplus; A.g = c->g; A.HA = c->HA; A.HB = c->HB; A.HC = c->HC;
+  A.pstride = c->pstride; A.alt = AltSel{nullptr, 0, 0};
+  BandArgs& B = A.B;
+  B.n = p.n; B.k = p.k;
+  B.HA = c->HA + p.qq0; B.HB = c->HB + p.qq0; B.HC = c->HC + p.qq0;
+  B.b = c->g + (size_t)p.r0 * p.k; B.rhs_sign = -1.0; B.x = c->step + (size_t)p.r0 * p.k; B.Dst = c->Dst;
+  ++c->epoch;
+  if (++c->fact_id == 0) c->fact_id = 1;
+  B.status = c->status_dev; B.fact_id = c->fact_id; B.epoch = c->epoch; B.pstride = c->pstride;
+  B.npos = 0; B.ts = nullptr;
+  A.ts = std::getenv("IDTO_SMALL_STAMPS") ? c->dbg : nullptr;
+  const int lds = SmallLds(c, p, &A.lds_small);
+  c->last_solver = 7;
+  c->last_step_kind = 2;
+  c->last_assembly = 5;
+  if (TimeBegin(c, 3)) return -2;
+  // (256 threads, one wavefront per SIMD: the evaluation needs more than the 256 registers a lane has at two per SIMD -
+  // 512 threads spilled 19 / 67 registers to scratch inside it and the step was slower than the two launches)
+  if (c->nq == 2) hipLaunchKernelGGL((gn_small_kernel<1, 6, 256>), dim3(1, c->batch), dim3(256), lds, c->stream, A);
+  else hipLaunchKernelGGL((gn_small_kernel<5, 9, 256>), dim3(1, c->batch), dim3(256), lds, c->stream, A);
+  HIP_OK(hipGetLastError());
+  c->fd_full = true; c->partials_ahead = false;
+  c->terms_valid = false;   // (no single-record products: a later idto_hip_grad_hess assembles from the slab)
   return TimeEnd(c);
 }
 
@@ -2818,6 +2882,7 @@ int idto_hip_get_option(idto_hip_ctx* c, const char* name, int* value) {
   if (std::strcmp(name, "solver_nd") == 0) { *value = c->solver_nd; return 0; }
   if (std::strcmp(name, "solver_pipe") == 0) { *value = c->solver_pipe; return 0; }
   if (std::strcmp(name, "solver_band") == 0) { *value = c->solver_band; return 0; }
+  if (std::strcmp(name, "gn_small") == 0) { *value = c->gn_small; return 0; }
   if (std::strcmp(name, "asm_in_solver") == 0) { *value = c->asm_in_solver; return 0; }
   if (std::strcmp(name, "solver_timeouts") == 0) { *value = c->solver_timeouts; return 0; }
   if (std::strcmp(name, "asm_fold") == 0) { *value = c->asm_fold; return 0; }
@@ -2849,6 +2914,7 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "solver_nd") == 0) { c->solver_nd = value != 0; return 0; }
   if (std::strcmp(name, "solver_pipe") == 0) { c->solver_pipe = value != 0; return 0; }
   if (std::strcmp(name, "solver_band") == 0) { c->solver_band = value; if (c->kkt) c->kkt->solver_band = value; return 0; }
+  if (std::strcmp(name, "gn_small") == 0) { c->gn_small = value != 0; return 0; }
   if (std::strcmp(name, "asm_in_solver") == 0) { c->asm_in_solver = value != 0; return 0; }
   if (std::strcmp(name, "debug_skip_role") == 0) { c->debug_skip_role = value; if (c->kkt) c->kkt->debug_skip_role = value; return 0; }   // test aid
   if (std::strcmp(name, "debug_pipe_tail") == 0) { c->debug_pipe_tail = value; return 0; }   // measurement aid
@@ -2885,6 +2951,7 @@ int idto_hip_gn_step(idto_hip_ctx* c) {
   if (c->spec_ready) return 0;   // already enqueued for this q by idto_hip_tr_trial (speculation)
   c->spec_pending = false;
   if (FusedEligible(c)) return LaunchFused(c);
+  if (SmallEligible(c)) return LaunchSmall(c);
   int rc = idto_hip_eval_partials(c);
   if (rc) return rc;
   if (AsmInSolver(c)) {

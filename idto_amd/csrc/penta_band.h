@@ -191,10 +191,23 @@ __device__ __forceinline__ int band_mirror(int i, int M) {
   return (M / KB - 1 - t) * KB + (i - t * KB);
 }
 
-// grid: (1 + assembly workgroups, problems); 256 threads: wavefronts 0 / 1 = the chains, all four stage
-template <int W>
-__global__ void __launch_bounds__(256) penta_band_kernel(BandArgs A, PipeAsm F) {
-  if (blockIdx.x >= 1) { pipe_assemble(A.ts, A.epoch, A.pstride, F, 1); return; }
+// the solver's workgroup (problem = blockIdx.y): wavefronts 0 / 1 = the chains, every wavefront stages; any block size of
+// at least two wavefronts (penta_band_kernel: 256 threads; gn_small.h calls it at the end of its 512-thread workgroup,
+// with F.on = 0: g and the bands are in memory)
+// the copies' padding: zeros, a one on the diagonal of the identity columns (the first chain's from lim on, the mirrored
+// chain's pad); the cells of real columns the staging loads do not write (16 - W - 2 of them per column) are zero too
+__device__ __forceinline__ void band_pad(double* lds, const BandLds& L, int tid, int nt) {
+  for (int e = tid; e < (L.tcols + L.bcols) * 16; e += nt) {
+    const bool second = e >= L.tcols * 16;
+    const int ee = second ? e - L.tcols * 16 : e, col = (ee >> 4) - BAND_FRONT, d = ee & 15;
+    const bool ident = second ? (col >= 0 && col < L.pad) : col >= L.lim;
+    lds[L.T + e] = (ident && d == 0) ? 1.0 : 0.0;
+  }
+}
+
+// PADDED: the caller has run band_pad behind a barrier of its own (gn_small.h: with its first loads)
+template <int W, bool PADDED = false>
+__device__ __forceinline__ void penta_band_body(BandArgs A, const PipeAsm F) {
   extern __shared__ double lds[];
   constexpr int w = W - 1, KB = W / 3;
   const size_t o = (size_t)blockIdx.y * A.pstride;
@@ -206,16 +219,11 @@ __global__ void __launch_bounds__(256) penta_band_kernel(BandArgs A, PipeAsm F) 
   const BandLds L = band_layout(M, W);
   const int m = L.m, lim = L.lim, nb = L.nb, pad = L.pad;
   if (A.ts && tid == 0) A.ts[0] = (double)wall_clock64();
-  // the copies' padding while the assembly (if it is this launch's) is still under way: zeros, a one on the diagonal of
-  // the identity columns (the first chain's from lim on, the mirrored chain's pad); the cells of real columns the loads
-  // below do not write (16 - W - 2 of them per column) are zero too
-  for (int e = tid; e < (L.tcols + L.bcols) * 16; e += nt) {
-    const bool second = e >= L.tcols * 16;
-    const int ee = second ? e - L.tcols * 16 : e, col = (ee >> 4) - BAND_FRONT, d = ee & 15;
-    const bool ident = second ? (col >= 0 && col < pad) : col >= lim;
-    lds[L.T + e] = (ident && d == 0) ? 1.0 : 0.0;
+  // the copies' padding while the assembly (if it is this launch's) is still under way
+  if (!PADDED) {
+    band_pad(lds, L, tid, nt);
+    __syncthreads();
   }
-  __syncthreads();
   if (pipe_asm_on(F, o)) {   // g and the bands come from this very launch: all of them, then plain loads
     const unsigned* ready = at_problem(F.ready, o);
     const SpinCtl sc{A.status + 2 * (gridDim.y - blockIdx.y), A.fact_id};
@@ -332,6 +340,13 @@ __global__ void __launch_bounds__(256) penta_band_kernel(BandArgs A, PipeAsm F) 
     __hip_atomic_store(A.status, A.fact_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_fetch_add(A.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+}
+
+// grid: (1 + assembly workgroups, problems); 256 threads
+template <int W>
+__global__ void __launch_bounds__(256) penta_band_kernel(BandArgs A, PipeAsm F) {
+  if (blockIdx.x >= 1) { pipe_assemble(A.ts, A.epoch, A.pstride, F, 1); return; }
+  penta_band_body<W>(A, F);
 }
 
 }  // namespace idto_dev

@@ -91,6 +91,7 @@ def test_gauss_newton_step_is_as_accurate_as_the_pivoted_lu(name, N, lower, band
     pn = np.abs(p_ref).max()
     dev = hip.HipPath(model, prob, sp)
     dev.set_option("solver_band", band)
+    dev.set_option("gn_small", 0)   # (this file tests penta_band_kernel as a launch of its own; the one-workgroup step: tests/test_gpu_small.py)
     dev.set_q(q)
     dev.gn_step()
     assert dev.get_option("last_solver") == 6
@@ -121,6 +122,7 @@ def test_band_in_a_batch_and_failure_report(name, N, band):
         qs.append(synthetic_trajectory(cfg, model, N, seed=b, lower=0.01))
     batch = hip.HipPath(model, probs, sp)
     batch.set_option("solver_band", band)
+    batch.set_option("gn_small", 0)
     batch.set_q_batch(np.array(qs))
     for _ in range(2):
         batch.gn_step()
@@ -128,6 +130,7 @@ def test_band_in_a_batch_and_failure_report(name, N, band):
     for b in range(B):
         one = hip.HipPath(model, probs[b], sp)
         one.set_option("solver_band", band)
+        one.set_option("gn_small", 0)
         one.set_q(qs[b])
         one.gn_step()
         assert one.get_option("last_solver") == 6

@@ -128,6 +128,7 @@ def test_assembly_inside_the_solver_launch_is_bit_identical(name, N, band):
     for inside in (1, 0):
         dev = hip.HipPath(model, prob, sp)
         dev.set_option("solver_band", band)
+        dev.set_option("gn_small", 0)   # (the two-launch step is what this test is about)
         dev.set_option("asm_in_solver", inside)
         dev.set_q(q)
         for _ in range(3):   # (epoch-valued words: repeated launches)

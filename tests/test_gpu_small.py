@@ -1,0 +1,96 @@
+"""The one-workgroup Gauss-Newton step of the small models (csrc/gn_small.h: finite differences, assembly and the band
+solve of acrobot / spinner in ONE launch of ONE workgroup per problem) against the two launches it stands in for
+(fd_kernel + penta_band_kernel with the assembly inside, which tests/test_gpu_parity.py holds == the oracle): every
+array of the step bit for bit - v, a, N+, tau, the three partial blocks (NaN block included), g, the bands, the step -
+and g, H against the oracle directly.  Reference: optimizer/trajectory_optimizer.cc:178-245, :426-563, :1021-1165,
+optimizer/penta_diagonal_solver.h:124-248."""
+import numpy as np
+import pytest
+
+from idto_amd import hip
+from idto_amd.model import load_model
+from idto_amd.problem import load_config, make_problem, synthetic_trajectory
+from oracle_lib import Oracle
+
+pytestmark = pytest.mark.gpu
+ARRAYS = ("v", "a", "nplus", "tau", "dtau_dqm", "dtau_dqt", "dtau_dqp", "gradient", "H_A", "H_B", "H_C", "step")
+
+
+def same(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+def setup(name, N, seed):
+    cfg, model = load_config(name), load_model(name)
+    prob, sp, _ = make_problem(cfg, model, num_steps=N)
+    sp.scaling = sp.equality_constraints = False
+    q = synthetic_trajectory(cfg, model, N, seed=seed, lower=0.0)
+    if name == "spinner":
+        q[:, 1] = np.linspace(1.5, 1.25, N + 1)   # the finger reaches the spinner: the contact pair is active
+    return cfg, model, prob, sp, q
+
+
+@pytest.mark.parametrize("name", ["acrobot", "spinner"])
+@pytest.mark.parametrize("N", [16, 23, 40, 64])
+def test_one_workgroup_step_equals_the_two_launches(name, N):
+    cfg, model, prob, sp, q = setup(name, N, seed=N)
+    dev = hip.HipPath(model, prob, sp)
+    dev.set_q(q)
+    dev.gn_step()
+    assert dev.get_option("last_solver") == 7, "gn_small_kernel did not run"
+    got = {k: dev.get(k) for k in ARRAYS}
+    dev.set_option("gn_small", 0)
+    dev.set_q(q)
+    dev.gn_step()
+    assert dev.get_option("last_solver") == 6
+    for k in ARRAYS:
+        assert same(got[k], dev.get(k)), k
+    assert dev.solver_status() == (False, 0)
+    if name == "spinner":
+        assert np.abs(got["tau"]).max() > 1.0   # (the contact force is in it)
+    g, bands = Oracle(model, prob, sp).grad_hess(q)
+    assert np.array_equal(got["gradient"].ravel(), g)
+    for key, b in zip(("H_A", "H_B", "H_C"), bands[:3]):
+        assert np.array_equal(got[key], b), key
+    dev.close()
+
+
+@pytest.mark.parametrize("name", ["acrobot", "spinner"])
+def test_one_workgroup_step_in_a_batch(name):
+    """grid.y = problem: three problems with different trajectories == each of them alone"""
+    N, B = 40, 3
+    cfg, model, prob, sp, _ = setup(name, N, seed=0)
+    qs = [setup(name, N, seed=s)[4] for s in range(B)]
+    bd = hip.HipPath(model, [prob] * B, sp)
+    if name == "spinner":
+        bd.set_option("solver_band", 2)   # (a batch keeps blocks of 3 on the block kernels by default)
+    bd.set_q_batch(qs)
+    bd.gn_step()
+    assert bd.get_option("last_solver") == 7
+    for b in range(B):
+        dev = hip.HipPath(model, prob, sp)
+        dev.set_q(qs[b])
+        dev.gn_step()
+        for k in ("tau", "gradient", "H_C", "step"):
+            assert same(bd.get(k, problem=b), dev.get(k)), (b, k)
+        dev.close()
+    bd.close()
+
+
+def test_what_the_kernel_does_not_serve_keeps_the_two_launches():
+    cfg, model, prob, sp, q = setup("acrobot", 40, seed=1)
+    dev = hip.HipPath(model, prob, sp)
+    dev.set_q(q)
+    dev.set_option("gradients_method", 1)   # central differences
+    dev.gn_step()
+    assert dev.get_option("last_solver") == 6
+    dev.set_option("gradients_method", 0)
+    dev.gn_step()
+    assert dev.get_option("last_solver") == 7
+    dev.close()
+    cfg, model, prob, sp, q = setup("hopper", 50, seed=1)   # a planar joint, blocks of 5
+    dev = hip.HipPath(model, prob, sp)
+    dev.set_q(q)
+    dev.gn_step()
+    assert dev.get_option("last_solver") != 7
+    dev.close()

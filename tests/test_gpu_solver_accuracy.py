@@ -30,8 +30,9 @@ CASES = [("acrobot", 40, 0.0), ("spinner", 40, 0.0), ("hopper", 50, 0.01), ("min
 # variant -> (options, the values of `last_solver` that say it ran: 6 scalar band (blocks up to 5), 4 pipelined, 2 nested
 # dissection, 1 two workgroups (5: the same inside the fused launch))
 VARIANTS = {
-    "band": ({"solver_band": 2, "solver_pipe": 1, "solver_nd": 1, "debug_pipe_tail": 0}, (6,)),
-    "pipe": ({"solver_band": 0, "solver_pipe": 1, "solver_nd": 1, "debug_pipe_tail": 0}, (4,)),
+    "band": ({"solver_band": 2, "solver_pipe": 1, "solver_nd": 1, "debug_pipe_tail": 0, "gn_small": 0}, (6,)),
+    "band_in_the_one_workgroup_step": ({"solver_band": 2, "solver_pipe": 1, "solver_nd": 1, "debug_pipe_tail": 0, "gn_small": 1}, (7,)),
+    "pipe": ({"gn_small": 0, "solver_band": 0, "solver_pipe": 1, "solver_nd": 1, "debug_pipe_tail": 0}, (4,)),
     "pipe_rowwise_tail": ({"solver_band": 0, "solver_pipe": 1, "solver_nd": 1, "debug_pipe_tail": 1}, (4,)),
     "nd": ({"solver_band": 0, "solver_pipe": 0, "solver_nd": 1, "debug_pipe_tail": 0, "nd_recursion": 1}, (2,)),
     "nd_rowwise_tail": ({"solver_band": 0, "solver_pipe": 0, "solver_nd": 1, "debug_pipe_tail": 0, "nd_recursion": 0}, (2,)),
@@ -39,7 +40,7 @@ VARIANTS = {
 }
 
 
-ROWWISE = ("band", "pipe_rowwise_tail", "nd_rowwise_tail", "two")
+ROWWISE = ("band", "band_in_the_one_workgroup_step", "pipe_rowwise_tail", "nd_rowwise_tail", "two")
 
 
 def errors(bands, g, p, p_ref):
