@@ -39,6 +39,7 @@ struct SmallArgs {
   BandArgs B;       // the solver's view (sub-system from block row 1 on)
   int lds_small;    // where this kernel's own arrays start (doubles): behind the band solver's carve-up
   double* ts;       // option "solver_debug" 4: wall-clock stamps of the phases (100 MHz), else nullptr
+  const BandStageItem* stage; int nstage;   // penta_band.h band_stage_table for this horizon, sources relative to the LDS copy of [A | B | C | g]
 };
 
 // doubles of dynamic LDS behind the band solver's carve-up (gn_small_kernel's own arrays, in its order)
@@ -217,6 +218,15 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
   // (TO.cc:1127-1161: which terms exist at i = N - 1, N, below 2 / 3) SELECT among them - a branch per condition put an LDS
   // round trip behind every term (4.5 us for acrobot's 574 entries, 11.5 us for the spinner's 1230).  The weighted operand
   // X(l, r) = A(l, r) w_l is formed here, the very product the staged copy of assemble_diag_body holds.
+  // (the solver's staging table: this thread's first items, on their way while the sums below are formed)
+  constexpr int NST = 6;
+  BandStageItem st[NST];
+#pragma unroll
+  for (int u = 0; u < NST; ++u) {
+    const int e = tid + u * nt;
+    const int4 raw = *reinterpret_cast<const int4*>(S.stage + (e < S.nstage ? e : 0));
+    st[u].src = raw.x; st[u].rhs = raw.y; st[u].dst = e < S.nstage ? raw.z : -1; st[u].dst0 = e < S.nstage ? raw.w : -1;
+  }
   {
     const double idt = 1 / dt, midt = -1 / dt;
     const int per = qq + nq;   // items per block row
@@ -328,8 +338,21 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
   BandArgs B = S.B;   // the solver stages from the LDS copies (generic pointers into LDS: no problem offset), writes to memory
   B.x = at_problem(B.x, o); B.Dst = at_problem(B.Dst, o);
   B.pstride = 0;
+  B.ts = (S.ts && blockIdx.y == 0) ? S.ts + 8 : nullptr;   // (the solver's own stamps behind this kernel's)
   B.HA = hA + qq; B.HB = hB + qq; B.HC = hC + qq; B.b = hg + K;   // (from block row 1 on: row 0 is the identity)
-  penta_band_body<W, true>(B, F);
+  {   // the solver's two copies of the band, by the table (penta_band_body's staging loop, its index arithmetic done once on the host)
+    auto put = [&](const BandStageItem& it) __attribute__((always_inline)) {
+      const double raw = hA[it.src >= 0 ? it.src : 0];
+      const double val = it.src >= 0 ? raw * (it.rhs ? B.rhs_sign : 1.0) : 0.0;
+      if (it.dst >= 0) lds[it.dst] = val;
+      if (it.dst0 >= 0) lds[it.dst0] = val;
+    };
+#pragma unroll
+    for (int u = 0; u < NST; ++u) put(st[u]);
+    for (int e = tid + NST * nt; e < S.nstage; e += nt) put(S.stage[e]);
+  }
+  __syncthreads();
+  penta_band_body<W, true, true>(B, F);
   stamp(6);
 }
 

@@ -244,6 +244,7 @@ struct idto_hip_ctx {
   bool fused = true;                      // gn_step: one persistent launch (fused.h) when eligible
   bool solver_nd = true;                  // solver: nested dissection over 7 workgroups (penta_nd.h) when eligible
   bool solver_pipe = true;                // ... with pipelined chains (penta_pipe.h: 5 workgroups) when the block size allows
+  BandStageItem* small_stage = nullptr; int small_stage_n = 0, small_stage_N = -1;   // gn_small.h: the solver's staging table for horizon small_stage_N
   int gn_small = 1;                       // option "gn_small": the whole step of a small model in one workgroup (gn_small.h; see SmallEligible)
   int solver_band = 1;                    // small blocks: the scalar band factorisation in one workgroup (penta_band.h; see BandEligible)
   unsigned long long* nd_rowcnt = nullptr; // its per-row release counters, buffers and launch count
@@ -1761,6 +1762,16 @@ static int LaunchSmall(idto_hip_ctx* c) {
   B.npos = 0; B.ts = nullptr;
   A.ts = std::getenv("IDTO_SMALL_STAMPS") ? c->dbg : nullptr;
   const int lds = SmallLds(c, p, &A.lds_small);
+  if (c->small_stage_N != c->N) {   // (once per horizon)
+    const int qq = c->nq * c->nq, nb = c->N + 1;
+    std::vector<BandStageItem> tab((size_t)band_stage_table(p.n, p.k, 0, 0, 0, 0, nullptr));
+    band_stage_table(p.n, p.k, qq, nb * qq + qq, 2 * nb * qq + qq, 3 * nb * qq + c->nq, tab.data());
+    Release(c, &c->small_stage);
+    if (Alloc(c, tab.size(), &c->small_stage)) return -2;
+    HIP_OK(hipMemcpy(c->small_stage, tab.data(), tab.size() * sizeof(BandStageItem), hipMemcpyHostToDevice));
+    c->small_stage_n = (int)tab.size(); c->small_stage_N = c->N;
+  }
+  A.stage = c->small_stage; A.nstage = c->small_stage_n;
   c->last_solver = 7;
   c->last_step_kind = 2;
   c->last_assembly = 5;

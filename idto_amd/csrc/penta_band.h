@@ -174,21 +174,61 @@ struct BandChain {
 };
 
 // where entry (p, q), p >= q, of the band matrix is in the blocks (column-major K x K; C_t both triangles); in: it exists
-template <int KB>
-__device__ __forceinline__ const double* band_entry(const BandArgs& A, int p, int q, bool& in) {
+// (offset inside the band array `band`: 0 C, 1 B, 2 A)
+__host__ __device__ inline int band_entry_off(int KB, int p, int q, bool& in, int& band) {
   const int t = p / KB, r = p - t * KB, s = q / KB, c = q - s * KB, bd = t - s;
   in = bd <= 2;
+  band = bd;
+  return t * (KB * KB) + c * KB + r;
+}
+template <int KB>
+__device__ __forceinline__ const double* band_entry(const BandArgs& A, int p, int q, bool& in) {
+  int bd;
+  const int off = band_entry_off(KB, p, q, in, bd);
   const double* blk = bd == 0 ? A.HC : bd == 1 ? A.HB : A.HA;
-  return blk + (size_t)t * (KB * KB) + c * KB + r;
+  return blk + off;
 }
 
 // The mirrored chain's order: the BLOCKS from the last one backwards, the rows inside a block as they are - a KKT
 // system's multiplier rows still come behind their block's variables (the other way round they would be zero pivots;
 // kkt.h).  The map is its own inverse; the half width stays 3 K - 1.
-template <int KB>
-__device__ __forceinline__ int band_mirror(int i, int M) {
+__host__ __device__ inline int band_mirror_rt(int KB, int i, int M) {
   const int t = i / KB;
   return (M / KB - 1 - t) * KB + (i - t * KB);
+}
+template <int KB>
+__device__ __forceinline__ int band_mirror(int i, int M) { return band_mirror_rt(KB, i, M); }
+
+// The staging pass as a TABLE (gn_small.h: the bands sit in the workgroup's own LDS, the index arithmetic below - seven
+// integer divisions an item - was 1.3 / 2.5 us of acrobot's / the spinner's step): for item e of penta_band_body's staging
+// loop {source, is the right-hand side, destination, second destination (the diagonal entry by row) or -1}; source: the
+// element's offset in [A | B | C | b] laid out as `offA, offB, offC, offb` say, or -1 for a zero.  Same decisions, same order.
+struct BandStageItem { int src, rhs, dst, dst0; };
+inline int band_stage_table(int n, int KB, int offA, int offB, int offC, int offb, BandStageItem* out) {
+  const int W = 3 * KB, M = n * KB;
+  const BandLds L = band_layout(M, W);
+  const int nitem = (L.lim + L.nb) * (W + 1);
+  if (!out) return nitem;
+  for (int e = 0; e < nitem; ++e) {
+    const int qc = e / (W + 1), d = e - qc * (W + 1);
+    const bool second = qc >= L.lim;
+    const int i = second ? qc - L.lim : qc;
+    const bool rhs = d == W;
+    const int dd = rhs ? 0 : d;
+    const bool ent = !rhs && i + dd < (second ? M : L.lim);
+    const int pa = second ? band_mirror_rt(KB, ent ? i + dd : i, M) : i + dd, pb = second ? band_mirror_rt(KB, i, M) : i;
+    const int hi = pa > pb ? pa : pb, lo = pa > pb ? pb : pa;
+    bool blk_in = false;
+    int bd = 0;
+    const int off = band_entry_off(KB, ent ? hi : 0, ent ? lo : 0, blk_in, bd);
+    BandStageItem it;
+    it.rhs = rhs ? 1 : 0;
+    it.src = rhs ? offb + pb : ((ent && blk_in) ? (bd == 0 ? offC : bd == 1 ? offB : offA) + off : -1);
+    it.dst = (second ? L.Bm + (BAND_FRONT + L.pad + i) * 16 : L.T + (BAND_FRONT + i) * 16) + (rhs ? 15 : d);
+    it.dst0 = d == 0 ? L.D0 + pb : -1;
+    out[e] = it;
+  }
+  return nitem;
 }
 
 // the solver's workgroup (problem = blockIdx.y): wavefronts 0 / 1 = the chains, every wavefront stages; any block size of
@@ -205,8 +245,9 @@ __device__ __forceinline__ void band_pad(double* lds, const BandLds& L, int tid,
   }
 }
 
-// PADDED: the caller has run band_pad behind a barrier of its own (gn_small.h: with its first loads)
-template <int W, bool PADDED = false>
+// PADDED: the caller has run band_pad behind a barrier of its own (gn_small.h: with its first loads); STAGED: and filled
+// the copies (band_stage_table), likewise
+template <int W, bool PADDED = false, bool STAGED = false>
 __device__ __forceinline__ void penta_band_body(BandArgs A, const PipeAsm F) {
   extern __shared__ double lds[];
   constexpr int w = W - 1, KB = W / 3;
@@ -236,7 +277,7 @@ __device__ __forceinline__ void penta_band_body(BandArgs A, const PipeAsm F) {
   // ---- the two copies: loads of the entries that exist, eight per thread in flight (addresses clamped, results
   // selected: no load behind a branch).  Item: column (the first chain's lim, then the mirrored chain's nb), cell of
   // the column (0 .. w: the entry, W: the right-hand side -> cell 15)
-  const int nitem = (lim + nb) * (W + 1);
+  const int nitem = STAGED ? 0 : (lim + nb) * (W + 1);
   constexpr int NB = W <= 6 ? 4 : (W <= 9 ? 8 : 16);   // (one batch covers horizons of ~45 steps)
   for (int e0 = tid; e0 < nitem; e0 += NB * nt) {
     double v[NB];
@@ -269,7 +310,7 @@ __device__ __forceinline__ void penta_band_body(BandArgs A, const PipeAsm F) {
       if (dst0[u] >= 0) lds[dst0[u]] = v[u];
     }
   }
-  __syncthreads();
+  if (!STAGED) __syncthreads();
   if (A.ts && tid == 0) A.ts[2] = (double)wall_clock64();
   double* Tc = lds + L.T + BAND_FRONT * 16;    // column 0 of the first chain's copy
   double* Bc = lds + L.Bm + BAND_FRONT * 16;   // index 0 (the first identity pivot) of the mirrored chain's
