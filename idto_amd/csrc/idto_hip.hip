@@ -1473,13 +1473,15 @@ static PipeAsm TakeAsm(idto_hip_ctx* c, const LdlPlan& p) {
 
 // The scalar band factorisation (penta_band.h): blocks up to 5 (half width 3 k - 1 <= 14: a lane per diagonal in a row
 // of 16), one workgroup per problem, single right-hand side.
-static bool BandEligible(const idto_hip_ctx* c, const LdlPlan& p) {
+static bool BandEligible(const idto_hip_ctx* c, const LdlPlan& p, bool whole_step = false) {
   // (option solver_band: 0 off, 1 blocks up to 4 - at 5 the pipelined kernel is faster, 41 against 47 us for hopper -, 2 up to 5)
   if (!(c->solver_band > 0 && c->two_sided && p.K == p.k && p.k >= 2 && p.k <= (c->solver_band > 1 ? 5 : 4))) return false;
   const int M = p.n * p.k, W = 3 * p.k;
   // (a batch: two wavefronts per problem shorten ONE problem's solve; with many in flight the five workgroups' work per
   // problem is what counts - 64 spinner problems 554k against 567k it/s, 256: 747k / 782k; acrobot 649k / 619k)
-  if (c->batch > 1 && c->solver_band < 2 && p.k > 2) return false;
+  // (gn_small.h - `whole_step` - is one workgroup per problem for EVERYTHING: there the batch argument points the other
+  // way, 64 acrobot problems 650k -> 2.89M it/s)
+  if (c->batch > 1 && c->solver_band < 2 && p.k > 2 && !whole_step) return false;
   // (horizons the pipelined kernel would take: shorter ones keep the fused launch / the two-workgroup factorisation)
   return p.n >= c->nd_min_rows && M >= 4 * W && band_layout(M, W).end * (int)sizeof(double) <= 160 * 1024;
 }
@@ -1734,7 +1736,7 @@ static bool SmallEligible(const idto_hip_ctx* c) {
   idto_hip_ctx* cc = const_cast<idto_hip_ctx*>(c);
   const bool assembled = c->h_assembled;
   cc->h_assembled = true;   // (the kernel assembles H itself: block row 0 is the identity, the solver starts at row 1)
-  const bool ok = c->N >= 2 && PlanLdl(cc, false, &p) == 0 && BandEligible(c, p) && p.r0 == 1 && SmallLds(c, p, nullptr) <= 160 * 1024;
+  const bool ok = c->N >= 2 && PlanLdl(cc, false, &p) == 0 && BandEligible(c, p, true) && p.r0 == 1 && SmallLds(c, p, nullptr) <= 160 * 1024;
   cc->h_assembled = assembled;
   return ok;
 }

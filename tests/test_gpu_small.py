@@ -62,8 +62,6 @@ def test_one_workgroup_step_in_a_batch(name):
     cfg, model, prob, sp, _ = setup(name, N, seed=0)
     qs = [setup(name, N, seed=s)[4] for s in range(B)]
     bd = hip.HipPath(model, [prob] * B, sp)
-    if name == "spinner":
-        bd.set_option("solver_band", 2)   # (a batch keeps blocks of 3 on the block kernels by default)
     bd.set_q_batch(qs)
     bd.gn_step()
     assert bd.get_option("last_solver") == 7
