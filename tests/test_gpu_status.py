@@ -158,3 +158,49 @@ def test_unsupported_box_box_pair_is_refused():
     with pytest.raises(hip.HipError, match="box-box"):
         hip.HipPath(bad, prob, sp)
     hip.HipPath(model, prob, sp).close()
+
+
+def test_the_dense_solver_and_the_one_workgroup_step_report_it_too():
+    """Round 6's two new ways to a step: `linear_solver = kDenseLdlt` (idto_hip_solve_dense_ldlt: where the reference's
+    DRAKE_DEMAND(Hldlt.info() == Eigen::Success) aborts, TO.cc:2088-2093) and gn_small_kernel (acrobot's whole step in one
+    workgroup, csrc/gn_small.h: the band solver's pivot test inside it)."""
+    from idto_amd.optimizer import TrajectoryOptimizer, TrajectoryOptimizerSolution, TrajectoryOptimizerStats
+    model, prob, sp, q, q_guess = _semidefinite_problem(N=40)
+    dev = hip.HipPath(model, prob, sp)
+    dev.set_q(q)
+    dev.gn_step()
+    assert dev.get_option("last_solver") == 7
+    failed, rows = dev.solver_status()
+    assert failed and rows >= 1
+    with pytest.raises(hip.FactorizationFailed):
+        dev.get("step")
+    with pytest.raises(hip.FactorizationFailed):
+        dev.solve_dense_ldlt(np.ones((dev.N + 1) * dev.nq))
+    dev.close()
+    sp.max_iterations, sp.linear_solver = 3, "dense_ldlt"
+    opt = TrajectoryOptimizer(model, prob, sp)
+    sol, st = TrajectoryOptimizerSolution(), TrajectoryOptimizerStats()
+    assert opt.Solve(q_guess, sol, st) == "kFactorizationFailed"
+    opt.close()
+
+
+def test_mpc_replan_with_a_failed_factorisation_is_not_silent():
+    """the C++ controller keeps the previous plan when a re-plan's factorisation fails and says so through
+    last_flag(); the Python wrapper raises (strict, the default) instead of handing the stale plan back as if it were new."""
+    from idto_amd.mpc import DeviceModelPredictiveController
+    from idto_amd.optimizer import TrajectoryOptimizer, TrajectoryOptimizerSolution
+    model, prob, sp, q, q_guess = _semidefinite_problem(N=20)
+    sp.max_iterations = 1
+    opt = TrajectoryOptimizer(model, prob, sp)
+    plan = TrajectoryOptimizerSolution()   # (any plan to shift: the re-plan's factorisation is what fails)
+    plan.q, plan.v, plan.tau = np.asarray(q_guess, float), np.zeros((21, model.nv)), np.zeros((20, model.nv))
+    x = np.concatenate([plan.q[0], plan.v[0]])
+    strict = DeviceModelPredictiveController(opt, plan, actuated=model.actuated, replan_period=0.01)
+    with pytest.raises(RuntimeError, match="factorisation failed"):
+        strict.update(0.01, x[:model.nq], x[model.nq:])
+    assert strict.last_flag == 2
+    strict.close()
+    lenient = DeviceModelPredictiveController(opt, plan, actuated=model.actuated, replan_period=0.01, strict=False)
+    g, qq, v, tau = lenient.update(0.01, x[:model.nq], x[model.nq:])
+    assert lenient.last_flag == 2 and np.isfinite(qq).all()
+    lenient.close(); opt.close()
