@@ -133,6 +133,7 @@ check)
   bash tools/gpu.sh mpc
   bash tools/gpu.sh batch32
   timeout 300 python tools/band_phases.py 2>&1 | quiet | tee gpurun_out/${R}_band_phases.txt
+  IDTO_SMALL_STAMPS=1 timeout 120 python tools/small_phases.py 2>&1 | quiet | grep "phases\|inside" | tee gpurun_out/${R}_small_phases.txt
   ROUND=$R timeout 900 bash tools/prof_band.sh > /dev/null 2>&1
   timeout 600 python -m pytest tests/test_gpu_neighbour.py -m "gpu or timing" -q -s 2>&1 | quiet | tail -8 | tee gpurun_out/${R}_solver_beside_neighbour.txt
   ls gpurun_out | head -100

@@ -1,6 +1,7 @@
 """Phases of gn_small_kernel (csrc/gn_small.h) by its own wall-clock stamps: IDTO_SMALL_STAMPS=1 python tools/small_phases.py"""
 import sys, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from idto_amd import hip
 from idto_amd.model import load_model
