@@ -335,6 +335,8 @@ struct idto_hip_ctx {
   AltSel alt_r{nullptr, 0, 0}, alt_w{nullptr, 0, 1};
   unsigned long long* tr_cnt = nullptr;
   unsigned long long tr_target = 0;
+  double *tr_part_ll = nullptr, *tr_part2 = nullptr;   // tr_iter_kernel: the block rows' sums with the launch's epoch in every word; dq.dq, g~.dqs per row
+  unsigned tr_epoch = 0;
   double* tr_rows = nullptr;
   int tr_rows_cap = 0;
   double *tr_D = nullptr, *tr_gt = nullptr, *tr_w = nullptr, *tr_dq = nullptr, *q_trial = nullptr, *tr_out = nullptr;
@@ -980,7 +982,8 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   const size_t o_flags = carve(c->flag_count, sizeof(unsigned)), o_sync = carve(2, sizeof(unsigned long long));
   const size_t nvars = (size_t)(N + 1) * nq;
   const size_t o_trD = carve(nvars, D), o_trg = carve(nvars, D), o_trw = carve(nvars, D), o_trdq = carve(nvars, D),
-               o_qt = carve(nvars, D), o_trout = carve(16, D), o_trDp = carve(nvars, D), o_trpart = carve((size_t)9 * (N + 1), D);
+               o_qt = carve(nvars, D), o_trout = carve(16, D), o_trDp = carve(nvars, D), o_trpart = carve((size_t)9 * (N + 1), D),
+               o_trpll = carve((size_t)2 * (TR_NSUM * (N + 1) + 2), D), o_trp2 = carve((size_t)2 * (N + 1), D);
   const size_t o_trstate = carve(TRS_COUNT, D), o_trcnt = carve(1, sizeof(unsigned long long));
   // the equality-constraint step's outputs (per problem, so that the batched loop finds them at the arena stride):
   // [H^-1 (g + J^T lambda) | J^T lambda] and the multipliers (nu <= nv; + 2: the blocked dense LDL^T's [min, max | ...])
@@ -1019,6 +1022,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   c->nd_wst = nd_wst_on ? dp(o_ndwst) : nullptr;
   c->tr_D = dp(o_trD); c->tr_gt = dp(o_trg); c->tr_w = dp(o_trw); c->tr_dq = dp(o_trdq); c->q_trial = dp(o_qt);
   c->tr_out = dp(o_trout); c->tr_Dprev = dp(o_trDp); c->tr_part = dp(o_trpart);
+  c->tr_part_ll = dp(o_trpll); c->tr_part2 = dp(o_trp2);
   c->terms = dp(o_terms);
   c->tr_state = dp(o_trstate);
   c->con_out = dp(o_conout); c->con_lambda = dp(o_conlam);
@@ -1072,7 +1076,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   const int n = N + 1;
   c->penta_lds = (int)sizeof(double) * (10 * (int)qq + nq * (3 * nq + 1) + (n + 2) * nq + nq) + (int)sizeof(int) * nq + 16;
   c->solve_lds = (int)sizeof(double) * ((n + 2) * nq + nq);
-  c->cost_lds = (int)sizeof(double) * (3 * N + 2) * (1 + std::max(nq, nv));
+  c->cost_lds = (int)sizeof(double) * ((3 * N + 2) * (1 + std::max(nq, nv)) + 2 * (N + 1) + 2);
   const int max_lds = 160 * 1024;
   // (cost_kernel is a single block holding one column of every cost term; penta_apply_kernel keeps
   // the right-hand side of each of its four wavefronts: both bound the horizon as well)
@@ -1889,6 +1893,12 @@ static void LaunchDenseLdl(idto_hip_ctx* c, double* S, double* L, double* d, dou
                            double b_sign, const double* b2);
 static std::atomic<long> g_dense_solves{0};
 long idto_hip_dense_solve_count() { return g_dense_solves.load(); }   // (tests: which branch of SolveLinearSystemInPlace ran)
+#ifdef IDTO_TR_STAMPS
+// (measurement build, tools/tr_stamps.py) the trust-region kernels' phase stamps of the last iteration, 100 MHz ticks
+extern "C" int idto_hip_debug_tr_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(idto_dev::g_tr_stamps), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // SolveLinearSystemInPlace's kDenseLdlt branch (reference optimizer/trajectory_optimizer.cc:2088-2093): H.MakeDense(),
 // LDL^T, solve.  The debugging / cross-checking solver of the reference (its default is the block Thomas algorithm): the
@@ -2145,12 +2155,13 @@ static TrRowsArgs PrepareArgs(idto_hip_ctx* c, int scaling_method, int with_lamb
   A.lambda = with_lambda ? c->con_lambda_at : nullptr;
   A.partial = c->tr_part;
   A.freeze = nullptr;   // (idto_hip_tr_solve points it at the loop's sticky flags)
+  A.part_ll = nullptr; A.epoch = 0u; A.dq_old = nullptr;   // (... and these at the hand-over between tr_iter_kernel's workgroups)
   return A;
 }
 
 static int EnqueuePrepare(idto_hip_ctx* c, int scaling_method, int with_lambda) {
   const int n = (c->N + 1) * c->nq;
-  const int lds = (23 * c->nq + 9 * 16) * (int)sizeof(double);
+  const int lds = tr_rows_lds(c->nq) * (int)sizeof(double);
   hipLaunchKernelGGL(tr_prepare_rows_kernel, dim3(c->N + 1), dim3(256), lds, c->stream,
                      PrepareArgs(c, scaling_method, with_lambda));
   hipLaunchKernelGGL(tr_prepare_sum_kernel, dim3(1), dim3(256), 0, c->stream, c->N + 1, c->tr_part, c->tr_out, c->tr_D,
@@ -2205,7 +2216,7 @@ int idto_hip_tr_trial(idto_hip_ctx* c, double a, double b, int scaling, int norm
   c->spec_pending = false; c->spec_ready = false;
   const int n = (c->N + 1) * c->nq;
   DropPrefetch(c, {IDTO_ARR_V, IDTO_ARR_A, IDTO_ARR_NPLUS, IDTO_ARR_SLAB, IDTO_ARR_COST});
-  hipLaunchKernelGGL(tr_trial_kernel, dim3(1), dim3(1024), 2 * 16 * sizeof(double), c->stream, n, c->nq, c->tr_D, c->tr_gt,
+  hipLaunchKernelGGL(tr_trial_kernel, dim3(1), dim3(1024), (size_t)2 * (n + c->N + 1) * sizeof(double), c->stream, n, c->nq, c->tr_D, c->tr_gt,
                      c->tr_w, a, b, scaling, c->q, c->q_trial, c->tr_dq, c->tr_quat,
                      normalize_quaternions ? c->tr_nquat : 0, c->tr_out + 9);
   HIP_OK(hipGetLastError());
@@ -2387,7 +2398,7 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     HIP_OK(hipMemcpy2DAsync(c->tr_state + TRS_COST, c->pstride, c->cost, c->pstride, sizeof(double), (size_t)B,
                             hipMemcpyDeviceToDevice, c->stream));
   const double eps = 10 * std::numeric_limits<double>::epsilon() / c->P.dt / c->P.dt;   // TO.cc:2024
-  const int lds_iter = (int)sizeof(double) * std::max(23 * c->nq + 9 * 16, 9 * nblk + 9 + 32);
+  const int lds_iter = (int)sizeof(double) * (tr_rows_lds(c->nq) + TR_NSUM * nblk + 2 + TR_NSUM + 3 * c->nq);
   // g, H and the Newton step of the first iterate (with constraints the step comes out of the multiplier chain)
   int rc = 0;
   if (nu > 0) {
@@ -2500,9 +2511,10 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     TrIterArgs T;
     T.rows = PrepareArgs(c, scaling_method, nu > 0 ? 1 : 0);
     T.alt = c->alt_r;
-    T.counter = c->tr_cnt;
-    c->tr_target += (unsigned long long)nblk;
-    T.target = c->tr_target;
+    T.rows.part_ll = c->tr_part_ll;
+    T.rows.epoch = ++c->tr_epoch;
+    if (T.rows.epoch == 0u) T.rows.epoch = ++c->tr_epoch;   // (0 is what an arena that was never written holds)
+    T.part2 = c->tr_part2;
     T.out = c->tr_out; T.state = c->tr_state;
     T.n = n; T.nq = c->nq; T.scaling = scaling;
     T.nquat = normalize_quaternions ? c->tr_nquat : 0;
@@ -2513,7 +2525,7 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     if (nu > 0 && use_kkt) { T.fact_status = c->kkt->status_dev; T.fact_id = c->kkt->fact_id; T.timeout_status = c->kkt->status_dev + 2 * B; }
     T.rows.freeze = c->tr_state + TRS_FLAGS;
     T.pstride = c->pstride; T.rows_stride = rows_stride;
-    hipLaunchKernelGGL(tr_iter_kernel, dim3(nblk, B), dim3(256), lds_iter, c->stream, T);
+    hipLaunchKernelGGL(tr_iter_kernel, dim3(nblk + 1, B), dim3(256), lds_iter, c->stream, T);
     HIP_OK(hipGetLastError());
     if (k == iterations) break;   // (the check-only pass)
     // tau (with its partials: the trial point is the next iterate unless rejected) and the cost at the
@@ -2524,6 +2536,7 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     Dc.eta = eta; Dc.Delta_max = Delta_max; Dc.eps = eps;
     Dc.lambda = nu > 0 ? c->con_lambda_at : nullptr; Dc.dofs = nu > 0 ? c->con_dofs : nullptr;
     Dc.nu = nu; Dc.N = c->N; Dc.slab_stride = c->slab_stride; Dc.tau_off = 3 * c->nv * c->nq;
+    Dc.part2 = c->tr_part2; Dc.nblk = nblk;
     const bool more = k + 1 < passes;
     std::swap(c->q, c->q_trial);
     rc = LaunchFd(c, (lookahead && more) ? 1 : 0, 0, c->N, c->alt_w);

@@ -26,6 +26,7 @@ __global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__
     if (T.state) {   // (the trust-region decision of THIS problem: trust_region.h tr_decide)
       T.state = at_problem(T.state, o); T.out = at_problem(T.out, o); T.q = at_problem(T.q, o);
       T.q_trial = at_problem(T.q_trial, o); T.rows += (size_t)blockIdx.y * T.rows_stride;
+      T.part2 = at_problem(T.part2, o);
       if (T.lambda) T.lambda = at_problem(T.lambda, o);
     }
   }
@@ -34,14 +35,72 @@ __global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__
   // non-zero product (the others are exact zeros).  Then one thread per term adds the columns in
   // order, and thread 0 the terms in order (TO.cc:147-176).
   extern __shared__ double lds[];
+  TR_STAMP(16);
+  // (trust-region loop) what the decision and an accepted step's q <- q_trial need and nothing in this launch writes:
+  // requested here, their round trips run under the cost's own
+  constexpr int QPF = 2;
+  double dS[11], dst[TRS_COUNT], qpf[QPF], p2v = 0.0;
+  if (T.state) {
+    dS[9] = dS[10] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dS[k] = (threadIdx.x == 0) ? T.out[k] : 0.0;
+    // (dq.dq and g~.D^-1 dq come per block row from tr_iter_kernel's workgroups: added up below, in block order)
+    if ((int)threadIdx.x < 2 * T.nblk) p2v = T.part2[threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < TRS_COUNT; ++k) dst[k] = (threadIdx.x == 0) ? T.state[k] : 0.0;
+#pragma unroll
+    for (int u = 0; u < QPF; ++u) { const int idx = threadIdx.x + u * blockDim.x; qpf[u] = (idx < T.n) ? T.q_trial[idx] : 0.0; }
+  }
   const int N = P.N, nq = M.nq, nv = M.nv, tid = threadIdx.x, nt = blockDim.x;
   const int nterms = 3 * N + 2, nmax = nq > nv ? nq : nv;
   double* terms = lds;               // [nterms]
   double* cols = terms + nterms;     // [nterms][nmax]
-  if (diag) {
-    // (diagonal weights, the production case: the three operands of an item - value, nominal value, weight - are
-    // independent loads; four items' worth are issued before the first is waited for.  A rolled loop waited for each
-    // item's loads in turn: five round trips in a row at allegro's size.  Same expressions, same bits.)
+  double* p2l = cols + nterms * nmax;   // [2 (N + 1) + 2] (trust-region loop)
+  if (diag && nmax <= 32 && (nt & 31) == 0) {
+    // Diagonal weights, the production case.  Thread (c = tid & 31, tl = tid >> 5) takes column c of the (up to) three
+    // terms of the steps t = tl, tl + nt / 32, ...: the loads of a step are consecutive in c, every operand's address is
+    // a multiply-add of (t, c) - no division, no branch per kind - and the loads of a pass are all in flight before the
+    // first is used.  (One thread per (term, column) item of a flat index spent 800 instructions a wavefront on
+    // idx / nmax, term % 3 and five-way pointer selects: 16 wavefronts on one CU, the phase was issue-bound at 4.4 us of
+    // this kernel's 7.5.)  Same expressions per item as below, same bits.
+    const int c = tid & 31, tl = tid >> 5, tstep = nt >> 5;
+    const bool cq = c < nq, cv = c < nv;
+    const int cqi = cq ? c : 0, cvi = cv ? c : 0;
+    // (the weights of this thread's column: five loads, once)
+    const double wq = P.Qq0[cqi * nq + cqi], wv = P.Qv0[cvi * nv + cvi], wr = P.R0[cvi * nv + cvi];
+    const double wfq = P.Qfq0[cqi * nq + cqi], wfv = P.Qfv0[cvi * nv + cvi];
+    const double* tau0 = slab + 3 * nv * nq;
+    constexpr int TU = 2;   // steps per pass (N = 40 .. 60 at 32 steps a time: one pass, one round trip)
+    for (int t0 = tl; t0 <= N; t0 += TU * tstep) {
+      double eq[TU], nq_[TU], ev[TU], nv_[TU], et[TU];
+#pragma unroll
+      for (int u = 0; u < TU; ++u) {
+        const int t = t0 + u * tstep;
+        const bool ok = t <= N, run = t < N;
+        const int tt = ok ? t : 0;
+        eq[u] = q[tt * nq + cqi]; nq_[u] = P.q_nom[tt * nq + cqi];
+        ev[u] = v[tt * nv + cvi]; nv_[u] = P.v_nom[tt * nv + cvi];
+        et[u] = tau0[(size_t)(run ? t : 0) * slab_stride + cvi];
+      }
+#pragma unroll
+      for (int u = 0; u < TU; ++u) {
+        const int t = t0 + u * tstep;
+        const bool ok = t <= N, run = t < N;
+        double valq, valv, valt;
+        { const double dc = eq[u] - nq_[u]; double acc = 0; acc += dc * (run ? wq : wfq); valq = cq ? acc * dc : 0.0; }
+        { const double dc = ev[u] - nv_[u]; double acc = 0; acc += dc * (run ? wv : wfv); valv = cv ? acc * dc : 0.0; }
+        { const double dc = et[u] - 0.0; double acc = 0; acc += dc * wr; valt = cv ? acc * dc : 0.0; }
+        if (ok && c < nmax) {
+          const int term = run ? 3 * t : 3 * N;
+          cols[term * nmax + c] = valq;
+          cols[(term + 1) * nmax + c] = valv;
+          if (run) cols[(term + 2) * nmax + c] = valt;
+        }
+      }
+    }
+  } else if (diag) {
+    // (blocks wider than 32 - none of the examples -: one thread per (term, column) item; the three operands of an item -
+    // value, nominal value, weight - are independent loads, four items' worth are issued before the first is waited for)
     constexpr int U = 4;
     for (int idx0 = tid; idx0 < nterms * nmax; idx0 += U * nt) {
       double ev[U], en[U], wv[U];
@@ -102,7 +161,12 @@ __global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__
     }
     cols[idx] = val;
   }
+  if (T.state) {
+    if (tid < 2 * T.nblk) p2l[tid] = p2v;
+    for (int idx = tid + nt; idx < 2 * T.nblk; idx += nt) p2l[idx] = T.part2[idx];
+  }
   __syncthreads();
+  TR_STAMP(17);
   for (int term = tid; term < nterms; term += nt) {
     const int n = (term < 3 * N) ? ((term % 3 == 0) ? nq : nv) : ((term == 3 * N) ? nq : nv);
     double tot = 0;
@@ -110,10 +174,24 @@ __global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__
     terms[term] = tot;
   }
   __syncthreads();
+  TR_STAMP(18);
+  if (T.state && (tid == 64 || tid == 128)) {   // (beside thread 0's chain of adds)
+    const int k = tid == 64 ? 0 : 1;
+    double acc = 0.0;
+    for (int b = 0; b < T.nblk; ++b) acc += p2l[2 * b + k];
+    p2l[2 * T.nblk + k] = acc;
+  }
+  double cost = 0;
   if (tid == 0) {
-    double cost = 0;
     int i = 0;
-    for (; i + 8 <= 3 * N; i += 8) {   // the terms in order, the LDS reads eight at a time ahead of the chain of adds
+    for (; i + 16 <= 3 * N; i += 16) {   // the terms in order, the LDS reads sixteen at a time ahead of the chain of adds
+      double t16[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t16[u] = terms[i + u];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) cost += t16[u];
+    }
+    for (; i + 8 <= 3 * N; i += 8) {
       double t8[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) t8[u] = terms[i + u];
@@ -128,8 +206,11 @@ __global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__
     if (cost_copy) *cost_copy = cost;   // (single-problem contexts: next to the other trust-region scalars)
     if (pack) pack[N * nv] = cost;
   }
+  TR_STAMP(19);
   if (T.state) {   // (idto_hip_tr_solve) this was the trial point of a trust-region iteration
     const int neq = T.nu * T.N;
+    __syncthreads();
+    if (tid == 0) { dS[9] = p2l[2 * T.nblk]; dS[10] = p2l[2 * T.nblk + 1]; T.out[9] = dS[9]; T.out[10] = dS[10]; }
     if (T.nu > 0) {   // h(q + dq) . lambda: products by everybody, added in index order by thread 0
       __syncthreads();
       for (int r = tid; r < neq; r += nt) {
@@ -151,13 +232,18 @@ __global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__
         }
         for (; r < neq; ++r) hl += cols[r];
       }
-      terms[0] = tr_decide(T, *cost_out, hl) ? 1.0 : 0.0;
+      terms[0] = tr_decide(T, cost, hl, dS, dst) ? 1.0 : 0.0;
     }
+    TR_STAMP(20);
   }
   if (T.state) {
     __syncthreads();
-    if (terms[0] != 0.0)
-      for (int idx = tid; idx < T.n; idx += nt) T.q[idx] = T.q_trial[idx];
+    if (terms[0] != 0.0) {
+#pragma unroll
+      for (int u = 0; u < QPF; ++u) { const int idx = tid + u * nt; if (idx < T.n) T.q[idx] = qpf[u]; }
+      for (int idx = tid + QPF * nt; idx < T.n; idx += nt) T.q[idx] = T.q_trial[idx];
+    }
+    TR_STAMP(21);
   }
   // [tau_0 .. tau_{N-1} | cost] contiguous: what a trial point of the trust-region loop reads back
   if (pack)

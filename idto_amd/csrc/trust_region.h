@@ -19,6 +19,16 @@
 
 namespace idto_dev {
 
+// Measurement build only (-DIDTO_TR_STAMPS, tools/tr_stamps.py): wall-clock stamps of the trust-region kernels' phases
+#ifdef IDTO_TR_STAMPS
+__device__ unsigned long long g_tr_stamps[64];
+#define TR_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.y == 0) g_tr_stamps[i] = wall_clock64(); } while (0)
+#define TR_STAMP_B0(i) do { if (blockIdx.x == 0) TR_STAMP(i); } while (0)
+#else
+#define TR_STAMP(i) do { } while (0)
+#define TR_STAMP_B0(i) do { } while (0)
+#endif
+
 // block-wide sums of NS values per thread; result valid in thread 0
 template <int NS>
 __device__ __forceinline__ void block_sums(double (&val)[NS], double* scratch /* [NS * 16] */) {
@@ -90,10 +100,36 @@ struct TrRowsArgs {
   const int* dofs;
   int nu, N;
   const double* lambda;
-  double* partial;
+  double* partial;        // [nblk][9] (stepwise calls: tr_prepare_sum_kernel adds them)
   const double* freeze;   // (resident loop) the sticky flags word: once it is non-zero D, g~, w keep the values of the last decided iteration
+  // resident loop (tr_iter_kernel): ten sums per block row - the tenth is (g + J^T lambda) . dq_old over the row, for the
+  // convergence criteria - handed to every workgroup of the launch with the launch's epoch in every word (ll_store)
+  double* part_ll;        // [nblk][TR_NSUM][2], or null: `partial` is written
+  unsigned epoch;
+  const double* dq_old;   // the step that led to this iterate, or null
 };
+constexpr int TR_NSUM = 10;
+// LDS of tr_prepare_rows_body, in doubles (nt = 256): its arrays, then the scratch of the sums
+__host__ __device__ constexpr int tr_rows_lds(int K) { return 24 * K + TR_NSUM * 32; }
 
+// (penta_nd.h has the same pair; this header comes first)
+__device__ __forceinline__ void tr_ll_store(double* slot2, double v, unsigned epoch) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v), e = (unsigned long long)epoch << 32;
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(slot2);
+  __hip_atomic_store(q, (b & 0xffffffffull) | e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 1, (b >> 32) | e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool tr_ll_try(const double* slot2, unsigned epoch, double& v) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(slot2);
+  const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v = __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
+  return (unsigned)(a >> 32) == epoch && (unsigned)(b >> 32) == epoch;
+}
+
+// U: how many entries of a band block's row a thread keeps in registers (K <= U and 5 K <= blockDim.x: every
+// configuration of the five examples and their KKT systems); wider blocks take the loop that loads as it multiplies.
+template <int U>
 __device__ __forceinline__ void tr_prepare_rows_body(const TrRowsArgs& A, double* lds) {
   const int nblk = A.nblk, K = A.K, scaling_method = A.scaling_method, slab_stride = A.slab_stride, tau_off = A.tau_off;
   const int nu = A.nu, N = A.N;
@@ -113,7 +149,29 @@ __device__ __forceinline__ void tr_prepare_rows_body(const TrRowsArgs& A, double
   double* py = pt + 5 * K;     // [5 K]  ... of H y
   double* gl = py + 5 * K;     // [K]    g~ of this block row
   double* wl = gl + K;         // [K]    w
-  double* scratch = wl + K;
+  double* gml = wl + K;        // [K]    g + J^T lambda
+  double* scratch = gml + K;   // (tr_rows_lds)
+  // The band blocks' rows and q of this block row have addresses that depend on nothing computed here, and everything
+  // this launch reads was written by the launch before it - cold in this XCD's L2.  Requested first, they share the
+  // round trip of D, g~, w below (as the products' own loads behind the barrier they were a second cold round trip
+  // of 2 us, and q a third).
+  const bool pre = K <= U && 5 * K <= nt;
+  double m[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) m[u] = 0.0;
+  if (pre && tid < 5 * K) {
+    const int j = tid / K, r = tid - j * K, bi = i - 2 + j;
+    if (bi >= 0 && bi < nblk) {
+      const double* M = (j == 0) ? HA + (size_t)i * kk : (j == 1) ? HB + (size_t)i * kk : (j == 2) ? HC + (size_t)i * kk
+                      : (j == 3) ? HB + (size_t)(i + 1) * kk : HA + (size_t)(i + 2) * kk;
+      const int sr = (j <= 2) ? 1 : K, sc = (j <= 2) ? K : 1;   // M(r, c) or M(c, r)
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (u < K) m[u] = M[r * sr + u * sc];
+    }
+  }
+  const double qi_pre = (tid < K) ? q[i * K + tid] : 0.0;
+  const double dqo_pre = (tid < K && A.dq_old) ? A.dq_old[i * K + tid] : 0.0;
   for (int idx = tid; idx < 5 * K; idx += nt) {
     const int j = idx / K, r = idx - j * K, bi = i - 2 + j;
     double vt = 0.0, vy = 0.0;
@@ -125,13 +183,14 @@ __device__ __forceinline__ void tr_prepare_rows_body(const TrRowsArgs& A, double
       vt = d * gti; vy = yi;
       if (j == 2) {
         const double wi = yi / d;
-        dl[r] = d; gl[r] = gti; wl[r] = wi;
+        dl[r] = d; gl[r] = gti; wl[r] = wi; gml[r] = gm;
         if (!frozen) { D[v] = d; gt[v] = gti; w[v] = wi; }
       }
     }
     xt[idx] = vt; xy[idx] = vy;
   }
   __syncthreads();
+  TR_STAMP_B0(1);
   // band block j multiplies x_{i-2+j}: A_i, B_i, C_i, B_{i+1}^T, A_{i+2}^T (blocks column-major)
   for (int idx = tid; idx < 5 * K; idx += nt) {
     const int j = idx / K, r = idx - j * K, bi = i - 2 + j;
@@ -142,28 +201,34 @@ __device__ __forceinline__ void tr_prepare_rows_body(const TrRowsArgs& A, double
       const int sr = (j <= 2) ? 1 : K, sc = (j <= 2) ? K : 1;   // M(r, c) or M(c, r)
       const double* a = xt + j * K;
       const double* y = xy + j * K;
-      // (eight loads in flight at a time: the rolled loop with one load per step was a chain of L2 round trips;
-      // the sums keep their order)
-      for (int c0 = 0; c0 < K; c0 += 8) {
-        double m[8];
+      if (pre) {   // (idx == tid: the row this thread fetched above; the sums keep their order)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) m[u] = (c0 + u < K) ? M[r * sr + (c0 + u) * sc] : 0.0;
+        for (int u = 0; u < U; ++u)
+          if (u < K) { at += m[u] * a[u]; ay += m[u] * y[u]; }
+      } else
+      // (eight loads in flight at a time: the rolled loop with one load per step was a chain of L2 round trips)
+      for (int c0 = 0; c0 < K; c0 += 8) {
+        double m8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m8[u] = (c0 + u < K) ? M[r * sr + (c0 + u) * sc] : 0.0;
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-          if (c0 + u < K) { at += m[u] * a[c0 + u]; ay += m[u] * y[c0 + u]; }
+          if (c0 + u < K) { at += m8[u] * a[c0 + u]; ay += m8[u] * y[c0 + u]; }
       }
     }
     pt[idx] = at; py[idx] = ay;
   }
   __syncthreads();
-  double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  TR_STAMP_B0(2);
+  double s[TR_NSUM] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (tid < K) {
     const int r = tid, v = i * K + r;
     const double d = dl[r];
     const double Hg = d * ((((pt[r] + pt[K + r]) + pt[2 * K + r]) + pt[3 * K + r]) + pt[4 * K + r]);
     const double Hw = d * ((((py[r] + py[K + r]) + py[2 * K + r]) + py[3 * K + r]) + py[4 * K + r]);
-    const double gti = gl[r], wi = wl[r], qi = q[v];
+    const double gti = gl[r], wi = wl[r], qi = qi_pre;
     s[0] = gti * gti; s[1] = gti * Hg; s[2] = wi * wi; s[3] = gti * wi; s[4] = gti * Hw; s[5] = wi * Hw; s[6] = qi * qi;
+    s[9] = gml[r] * dqo_pre;
   }
   if (nu > 0 && i < N) {   // h = tau_i[unactuated] (TO.cc:1274-1278); lambda only when the constraints are enforced
     for (int j = tid; j < nu; j += nt) {
@@ -172,14 +237,50 @@ __device__ __forceinline__ void tr_prepare_rows_body(const TrRowsArgs& A, double
       if (lambda) s[8] += h * lambda[i * nu + j];
     }
   }
-  block_sums<9>(s, scratch);
-  if (tid == 0)
-    for (int k = 0; k < 9; ++k) partial[i * 9 + k] = s[k];
+  if (K <= 32 && nu <= 32) {
+    // Only lanes < 32 of the first wavefront hold anything but 0.0.  block_sums' result for them - the shuffle tree
+    // x_l += x_{l+32}, += x_{l+16}, ... += x_{l+1}, then 0.0 + the wavefronts' results - by one thread per sum from LDS,
+    // same association, same bits (adding the other lanes' and wavefronts' +0.0 changes nothing: a sum that starts
+    // with `+ 0.0` is never -0.0).  The nine trees of 54 dependent ds_bpermute round trips were 4 us of this kernel.
+    double* V = scratch;   // [TR_NSUM][32]
+    if (tid < 32) {
+#pragma unroll
+      for (int k = 0; k < TR_NSUM; ++k) V[k * 32 + tid] = s[k];
+    }
+    __syncthreads();
+    if (tid < TR_NSUM) {
+      double x[32];
+#pragma unroll
+      for (int l = 0; l < 32; ++l) x[l] = V[tid * 32 + l] + 0.0;
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1)
+#pragma unroll
+        for (int l = 0; l < off; ++l) x[l] += x[l + off];
+      const double tot = 0.0 + x[0];
+      if (A.part_ll) tr_ll_store(A.part_ll + 2 * (i * TR_NSUM + tid), tot, A.epoch);
+      else if (tid < 9) partial[i * 9 + tid] = tot;
+    }
+  } else {
+    block_sums<TR_NSUM>(s, scratch);
+    if (tid == 0)
+      for (int k = 0; k < TR_NSUM; ++k) {
+        if (A.part_ll) tr_ll_store(A.part_ll + 2 * (i * TR_NSUM + k), s[k], A.epoch);
+        else if (k < 9) partial[i * 9 + k] = s[k];
+      }
+  }
+  TR_STAMP_B0(3);
+}
+
+__device__ __forceinline__ void tr_prepare_rows(const TrRowsArgs& A, double* lds) {
+  if (A.K <= 4) tr_prepare_rows_body<4>(A, lds);
+  else if (A.K <= 8) tr_prepare_rows_body<8>(A, lds);
+  else if (A.K <= 20) tr_prepare_rows_body<20>(A, lds);
+  else tr_prepare_rows_body<32>(A, lds);
 }
 
 __global__ void __launch_bounds__(256) tr_prepare_rows_kernel(TrRowsArgs A) {
   extern __shared__ double lds[];
-  tr_prepare_rows_body(A, lds);
+  tr_prepare_rows(A, lds);
 }
 
 __global__ void tr_prepare_sum_kernel(int nblk, const double* __restrict__ partial, double* __restrict__ out,
@@ -199,20 +300,22 @@ __global__ void __launch_bounds__(1024)
 tr_trial_kernel(int n, int nq, const double* __restrict__ D, const double* __restrict__ gt, const double* __restrict__ w,
                 double a, double b, int scaling, const double* __restrict__ q, double* __restrict__ q_trial,
                 double* __restrict__ dq_out, const int* __restrict__ quat, int nquat, double* __restrict__ out) {
-  extern __shared__ double lds[];
-  const int tid = threadIdx.x, nt = blockDim.x;
-  double s[2] = {0, 0};
+  extern __shared__ double lds[];   // [2 n] the terms, [2 nsteps] their sums per time step
+  const int tid = threadIdx.x, nt = blockDim.x, nsteps = n / nq;
+  double* x0 = lds;
+  double* x1 = lds + n;
+  double* r0 = lds + 2 * n;
+  double* r1 = r0 + nsteps;
   for (int idx = tid; idx < n; idx += nt) {
     const double dqs = a * gt[idx] + b * w[idx];
     const double dq = scaling ? D[idx] * dqs : dqs;
     dq_out[idx] = dq;
     q_trial[idx] = q[idx] + dq;
-    s[0] += dq * dq;
-    s[1] += gt[idx] * dqs;
+    x0[idx] = dq * dq;
+    x1[idx] = gt[idx] * dqs;
   }
+  __syncthreads();
   if (nquat > 0) {
-    __syncthreads();
-    const int nsteps = n / nq;
     for (int idx = tid; idx < nsteps * nquat; idx += nt) {
       const int t = idx / nquat, qs = quat[idx - t * nquat];
       double* qq = q_trial + (size_t)t * nq + qs;
@@ -220,8 +323,19 @@ tr_trial_kernel(int n, int nq, const double* __restrict__ D, const double* __res
       for (int k = 0; k < 4; ++k) qq[k] /= nrm;
     }
   }
-  block_sums<2>(s, lds);
-  if (tid == 0) { out[0] = s[0]; out[1] = s[1]; }
+  // the two sums in the order of the resident loop (tr_iter_kernel: a time step's terms in order by its workgroup,
+  // cost_kernel: the time steps in order)
+  for (int t = tid; t < nsteps; t += nt) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int r = 0; r < nq; ++r) { s0 += x0[t * nq + r]; s1 += x1[t * nq + r]; }
+    r0[t] = s0; r1[t] = s1;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int t = 0; t < nsteps; ++t) { s0 += r0[t]; s1 += r1[t]; }
+    out[0] = s0; out[1] = s1;
+  }
 }
 
 // h(q_trial) . lambda  (the merit function at the trial point uses the multipliers of the current
@@ -288,11 +402,10 @@ struct TrConvergence {
 };
 
 struct TrIterArgs {
-  TrRowsArgs rows;
+  TrRowsArgs rows;               // (.part_ll, .epoch, .dq_old: the hand-over of the ten sums per block row)
   AltSel alt;                    // rows.slab is set A's: h = tau[unactuated] is read from the iterate's set
-  unsigned long long* counter;   // monotonic: workgroups of tr_iter_kernel that have published their partial sums
-  unsigned long long target;     // ... its value once every workgroup of THIS launch has
-  double* out;                   // [11] the nine inner products, then dq.dq and g~.D^-1 dq
+  double* part2;                 // [nblk][2] dq.dq and g~.(a g~ + b w) of each block row: cost_kernel adds them in block order
+  double* out;                   // [11] the nine inner products (then, by cost_kernel, dq.dq and g~.D^-1 dq)
   double* state;                 // [TRS_COUNT]
   int n, nq, scaling, nquat;
   const int* quat;
@@ -301,7 +414,7 @@ struct TrIterArgs {
   TrConvergence conv;
   const unsigned* fact_status;   // the solver's status word (host-mapped) and the id of the factorisation this iteration's step
   unsigned fact_id;              // came from: a failure in the MIDDLE of the resident loop is flagged in its own iteration
-  const unsigned* timeout_status;   // ... and the word a launch whose waits between workgroups ran out writes its id to
+  unsigned* timeout_status;      // ... and the word a launch whose waits between workgroups ran out writes its id to
   size_t pstride, rows_stride;   // batch contexts: grid.y = problem (arena stride in bytes; doubles between the problems' rows)
 };
 
@@ -321,105 +434,173 @@ __device__ inline double tr_dogleg_quadratic(double a, double b, double c, bool*
   return s;
 }
 
+// One workgroup per block row (= time step), and every workgroup goes all the way:
+//   1. its rows of D, g~, w, H~ g~, H~ w and their ten sums (tr_prepare_rows), published with the launch's epoch in every
+//      word;
+//   2. it polls the sums of ALL block rows (the data itself: one memory round trip behind the last writer, no counter,
+//      no fence, no cache invalidation), adds them in block order and evaluates the convergence criteria and the dogleg -
+//      every workgroup the same scalars from the same bits; workgroup 0 alone writes them to the state and the statistics;
+//   3. dq and the trial point of ITS rows from the D, g~, w, q it still holds, and the row's dq.dq, g~.dqs.
+// (Until round 6 the last workgroup to arrive did 2 and 3 for everybody: behind its acquire it fetched g~, w, D, q of
+// the whole trajectory cold - 200 cache lines through one CU's miss queue, 5 of this kernel's 13.5 us at cheetah's size,
+// 8 of 18.5 at allegro's.)  The workgroups of a problem wait for each other, so they must be resident together: N + 1 <=
+// a few hundred workgroups of 256 threads, dispatched in order - in a batch the problems behind the dispatch front are
+// complete and finish, so the front moves.  The wait is bounded (spin_wait's clock): on expiry the loop idles with
+// TRF_SOLVER_TIMEOUT.
+template <class Ready>
+__device__ __forceinline__ bool tr_spin(Ready ready, unsigned* word, unsigned id) {
+  unsigned n = 0;
+  long long t0 = 0;
+  while (!ready()) {
+    __builtin_amdgcn_s_sleep(1);
+    if (((++n) & 1023u) == 0) {
+      const long long now = (long long)wall_clock64();
+      if (t0 == 0) t0 = now;
+      else if (now - t0 > 5000000) {   // 50 ms (penta_ldl.h SPIN_LIMIT_TICKS)
+        if (word) {
+          __hip_atomic_store(word, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_fetch_add(word + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return false;
+      }
+    }
+  }
+  return true;
+}
+
 __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
   extern __shared__ double lds[];
-  __shared__ int last;
   __shared__ double ab[3];
+  __shared__ int timed_out;
   {   // problem of the batch: every array of the loop lives in the problem's arena
     const size_t o = (size_t)blockIdx.y * T.pstride;
     TrRowsArgs& A = T.rows;
     A.HA = at_problem(A.HA, o); A.HB = at_problem(A.HB, o); A.HC = at_problem(A.HC, o); A.g = at_problem(A.g, o);
     if (A.jtl) A.jtl = at_problem(A.jtl, o);
     A.yin = at_problem(A.yin, o); A.q = at_problem(A.q, o); A.Dprev = at_problem(A.Dprev, o); A.D = at_problem(A.D, o);
-    A.gt = at_problem(A.gt, o); A.w = at_problem(A.w, o); A.partial = at_problem(A.partial, o);
+    A.gt = at_problem(A.gt, o); A.w = at_problem(A.w, o); A.part_ll = at_problem(A.part_ll, o);
     if (A.lambda) A.lambda = at_problem(A.lambda, o);
     if (A.freeze) A.freeze = at_problem(A.freeze, o);
     A.slab = at_problem(A.slab, o + (size_t)alt_offset(T.alt, o));   // (h = tau[unactuated] is read from the iterate's set)
-    T.counter = at_problem(T.counter, o); T.out = at_problem(T.out, o); T.state = at_problem(T.state, o);
+    T.part2 = at_problem(T.part2, o); T.out = at_problem(T.out, o); T.state = at_problem(T.state, o);
     T.q_trial = at_problem(T.q_trial, o); T.dq = at_problem(T.dq, o);
+    A.dq_old = T.conv.on ? T.dq : nullptr;
     T.conv.rows += (size_t)blockIdx.y * T.rows_stride;
     if (T.fact_status) T.fact_status += 2 * blockIdx.y;
   }
-  tr_prepare_rows_body(T.rows, lds);
-  const int tid = threadIdx.x, nt = blockDim.x, nblk = T.rows.nblk, n = T.n;
-  if (tid == 0) {   // (block_sums left a barrier behind the partial sums of thread 0)
-    __atomic_thread_fence(__ATOMIC_RELEASE);   // agent scope: the partial sums, D, g~, w of this block row
-    const unsigned long long prev =
-        __hip_atomic_fetch_add(T.counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    last = (prev + 1 == T.target);
-  }
-  __syncthreads();
-  if (!last) return;
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  // (requested now, used by thread 0 at the dogleg: the round trip to host-mapped memory overlaps the sums)
-  const unsigned fact_word = (tid == 0 && T.fact_status) ? __hip_atomic_load(T.fact_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
-  const unsigned timeout_word = (tid == 0 && T.timeout_status) ? __hip_atomic_load(T.timeout_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
-  // the operands of the trial point (below) do not depend on the dogleg: fetch them now, four passes of 256
-  // threads = tr_trial_kernel's 1024, so that their L2 round trips overlap the sums and the dogleg instead of
-  // following them one pass after the other
-  constexpr int NPASS = 4;
-  double pg[NPASS], pw[NPASS], pd[NPASS], pq[NPASS];
-#pragma unroll
-  for (int ps = 0; ps < NPASS; ++ps) {
-    const int idx = tid + 256 * ps;
-    pg[ps] = pw[ps] = pd[ps] = pq[ps] = 0.0;
-    if (idx < n) {
-      pg[ps] = T.rows.gt[idx]; pw[ps] = T.rows.w[idx]; pq[ps] = T.rows.q[idx];
-      if (T.scaling) pd[ps] = T.rows.D[idx];
-    }
-  }
-  // ---- tr_prepare_sum: the partial sums in block order
-  double* part = lds;            // [9 nblk]
-  double* S = part + 9 * nblk;   // [9]
-  double* scratch = S + 9;       // [2 * 16]
-  for (int idx = tid; idx < 9 * nblk; idx += nt) part[idx] = T.rows.partial[idx];
-  for (int idx = tid; idx < n; idx += nt) const_cast<double*>(T.rows.Dprev)[idx] = T.rows.D[idx];   // the adaptive methods' memory
-  __syncthreads();
-  if (tid < 9) {
-    double acc = 0.0;
-    for (int i = 0; i < nblk; ++i) acc += part[i * 9 + tid];
-    S[tid] = acc;
-    T.out[tid] = acc;
-  }
-  __syncthreads();
-  // ---- the convergence criteria of the step the previous iteration accepted (TrConvergence): g.dq with the merit
-  // function's gradient at THIS iterate and the dq that led here (still in T.dq: the trial point below overwrites it)
-  if (T.conv.on) {
-    double sgd = 0.0;
-    for (int idx = tid; idx < n; idx += nt) {
-      const double gm = T.rows.jtl ? T.rows.g[idx] + T.rows.jtl[idx] : T.rows.g[idx];
-      sgd += gm * T.dq[idx];
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) sgd += __shfl_down(sgd, off);
-    if ((tid & 63) == 0) scratch[tid >> 6] = sgd;
-    __syncthreads();
+#ifdef IDTO_TR_STAMPS
+  if (T.conv.check_only) return;   // (measurement build: the stamps of the last DECIDING iteration stay)
+#endif
+  TR_STAMP_B0(0);
+  const int tid = threadIdx.x, nt = blockDim.x, nblk = T.rows.nblk, K = T.rows.K, i = blockIdx.x;
+  const bool first = blockIdx.x == 0;
+  if (i == nblk) {
+    // The launch's extra workgroup.  The solver's status words live in host-mapped memory: a read is a round trip over
+    // PCIe, 3.7 us - and every barrier of a workgroup stands behind the loads its wavefronts have in flight (the old last
+    // workgroup spent its "sums" phase there).  One thread reads them for the problem, at the launch's start, and hands
+    // them to the block rows' workgroups with their sums; it is back before the rows are.
     if (tid == 0) {
-      int flags = (int)T.state[TRS_FLAGS];
-      if (T.state[TRS_CHECK] != 0.0 && (flags & ~TRF_CONVERGED) == 0) {
-        double gdq = 0.0;
-        for (int wv = 0; wv < nt / 64; ++wv) gdq += scratch[wv];
-        const double cost = T.state[TRS_COST], prev = T.state[TRS_PREVCOST];
+      unsigned fact_word = 0u, timeout_word = 0u;
+      if (T.fact_status && T.timeout_status == T.fact_status + 2) {   // (a single problem: the four words are adjacent, one read)
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        const u4 wds = *reinterpret_cast<const volatile u4*>(T.fact_status);
+        fact_word = wds[0]; timeout_word = wds[2];
+      } else {
+        if (T.fact_status) fact_word = __hip_atomic_load(T.fact_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (T.timeout_status) timeout_word = __hip_atomic_load(T.timeout_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      tr_ll_store(T.rows.part_ll + 2 * (TR_NSUM * nblk), (double)fact_word, T.rows.epoch);
+      tr_ll_store(T.rows.part_ll + 2 * (TR_NSUM * nblk + 1), (double)timeout_word, T.rows.epoch);
+    }
+    return;
+  }
+  // The loop's state words: nobody writes them before every workgroup has published its sums (workgroup 0, after its
+  // poll below), and a wavefront's loads return in order - these are back before its first store of step 1.
+  double st[TRS_COUNT];
+#pragma unroll
+  for (int k = 0; k < TRS_COUNT; ++k) st[k] = (tid == 0) ? T.state[k] : 0.0;
+  const bool frozen = T.rows.freeze && *T.rows.freeze != 0.0;
+  const double qi = (tid < K) ? T.rows.q[i * K + tid] : 0.0;
+  // ---- 1. this block row
+  tr_prepare_rows(T.rows, lds);
+  TR_STAMP_B0(3);
+  const double* dl = lds + 10 * K;   // (tr_prepare_rows_body's arrays: D, g~, w of this block row)
+  const double* gl = lds + 21 * K;
+  const double* wl = lds + 22 * K;
+  double* part = lds + tr_rows_lds(K);       // [TR_NSUM nblk + 2]: the block rows' sums, the solver's two status words
+  double* S = part + TR_NSUM * nblk + 2;     // [TR_NSUM]
+  double* rowx = S + TR_NSUM;                // [3 K] dq.dq, g~.dqs terms of the row; its trial point
+  // ---- 2. the sums of every block row: polled where they are written, four per thread in flight
+  {
+    const int cnt = TR_NSUM * nblk + 2;
+    bool fine = true;
+    for (int base = 0; base < cnt; base += 4 * nt) {
+      double v[4] = {0.0, 0.0, 0.0, 0.0};
+      bool got[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) got[u] = base + tid + u * nt >= cnt;
+      fine &= tr_spin([&] {
+        bool all = true;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (!got[u]) { got[u] = tr_ll_try(T.rows.part_ll + 2 * (base + tid + u * nt), T.rows.epoch, v[u]); all &= got[u]; }
+        return all;
+      }, T.timeout_status, T.fact_id);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int idx = base + tid + u * nt; if (idx < cnt) part[idx] = v[u]; }
+    }
+    if (tid == 0) timed_out = 0;
+    __syncthreads();
+    if (!fine) timed_out = 1;
+  }
+  __syncthreads();
+  TR_STAMP_B0(4);
+  if (tid < TR_NSUM) {   // in block order (the LDS reads eight at a time ahead of the chain of adds)
+    double acc = 0.0;
+    int b = 0;
+    for (; b + 8 <= nblk; b += 8) {
+      double t8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t8[u] = part[(b + u) * TR_NSUM + tid];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += t8[u];
+    }
+    for (; b < nblk; ++b) acc += part[b * TR_NSUM + tid];
+    S[tid] = acc;
+    if (first && tid < 9) T.out[tid] = acc;
+  }
+  // the adaptive methods' memory (every workgroup has read its neighbours' by now)
+  if (tid < K && !frozen) const_cast<double*>(T.rows.Dprev)[i * K + tid] = dl[tid];
+  __syncthreads();
+  TR_STAMP_B0(5);
+  // ---- the convergence criteria of the step the previous iteration accepted (TrConvergence): g.dq with the merit
+  // function's gradient at THIS iterate and the dq that led here (S[9])
+  if (T.conv.on) {
+    if (tid == 0) {
+      int flags = (int)st[TRS_FLAGS];
+      if (st[TRS_CHECK] != 0.0 && (flags & ~TRF_CONVERGED) == 0) {
+        const double gdq = S[9];
+        const double cost = st[TRS_COST], prev = st[TRS_PREVCOST];
         int reason = 0;
         if (__builtin_fabs(prev - cost) < T.conv.abs_cost + T.conv.rel_cost * cost) reason |= 1;
         if (__builtin_fabs(gdq) < T.conv.abs_grad + T.conv.rel_grad * cost) reason |= 2;
-        if (T.state[TRS_DQN] < T.conv.abs_state + T.conv.rel_state * __builtin_sqrt(S[6])) reason |= 4;
-        const int k_prev = (int)T.state[TRS_ITER] - 1;
-        if (k_prev >= 0) T.conv.rows[(size_t)k_prev * TRR_COUNT + TRR_REASON] = (double)reason;
-        if (reason) T.state[TRS_FLAGS] = (double)(flags | TRF_CONVERGED);
+        if (st[TRS_DQN] < T.conv.abs_state + T.conv.rel_state * __builtin_sqrt(S[6])) reason |= 4;
+        const int k_prev = (int)st[TRS_ITER] - 1;
+        if (first && k_prev >= 0) T.conv.rows[(size_t)k_prev * TRR_COUNT + TRR_REASON] = (double)reason;
+        if (reason) st[TRS_FLAGS] = (double)(flags | TRF_CONVERGED);
       }
-      T.state[TRS_CHECK] = 0.0;
+      if (first) { T.state[TRS_FLAGS] = st[TRS_FLAGS]; T.state[TRS_CHECK] = 0.0; }
     }
-    __syncthreads();
     if (T.conv.check_only) return;
   }
+  TR_STAMP_B0(6);
   // ---- CalcDoglegPoint normalised by Delta: pU = cU g~ (TO.cc:2157), pH = -w / Delta (:2139-2149)
   if (tid == 0) {
     const double gg = S[0], gHg = S[1], ww = S[2], gw = S[3];
-    const double Delta = T.state[TRS_DELTA];
-    int flags = (int)T.state[TRS_FLAGS];
-    if (T.fact_status && fact_word == T.fact_id) flags |= TRF_FACTORIZATION;
-    if (T.timeout_status && timeout_word == T.fact_id) flags |= TRF_SOLVER_TIMEOUT;
+    const double Delta = st[TRS_DELTA];
+    int flags = (int)st[TRS_FLAGS];
+    if (T.fact_status && (unsigned)part[TR_NSUM * nblk] == T.fact_id) flags |= TRF_FACTORIZATION;
+    if ((T.timeout_status && (unsigned)part[TR_NSUM * nblk + 1] == T.fact_id) || timed_out) flags |= TRF_SOLVER_TIMEOUT;
     const double cU = -(gg / gHg) / Delta;
     const double pUn = __builtin_fabs(cU) * __builtin_sqrt(gg), pHn = __builtin_sqrt(ww) / Delta;
     double a, b, active;
@@ -435,59 +616,44 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
       a = Delta * (1.0 - sq) * cU; b = -sq; active = 1.0;
     }
     if (!(__builtin_isfinite(a) && __builtin_isfinite(b))) flags |= TRF_NONFINITE;
-    T.state[TRS_A] = a; T.state[TRS_B] = b; T.state[TRS_ACTIVE] = active; T.state[TRS_FLAGS] = (double)flags;
+    if (first) { T.state[TRS_A] = a; T.state[TRS_B] = b; T.state[TRS_ACTIVE] = active; T.state[TRS_FLAGS] = (double)flags; }
     ab[0] = a; ab[1] = b; ab[2] = (double)flags;
   }
   __syncthreads();
-  // ---- tr_trial: dq = D (a g~ + b w), q_trial = q + dq, [dq.dq, g~.(a g~ + b w)] with the partial sums
-  // of tr_trial_kernel's 1024 threads (thread v of it owns idx = v, v + 1024, ...): same bits
+  TR_STAMP_B0(7);
+  // ---- 3. dq = D (a g~ + b w), q_trial = q + dq of this block row; the row's dq.dq and g~.(a g~ + b w), added in row
+  // order (tr_trial_kernel: the same order)
   // (once a sticky flag is set - converged, or an error - the loop idles: dq and the trial point keep the values of the
   // last decided iteration, which is what the warm start hands on: TO.cc:2361-2385)
   const double a = ab[0], b = ab[1];
   const bool idle = ab[2] != 0.0;
-  const int lane = tid & 63;
-#pragma unroll
-  for (int ps = 0; ps < NPASS; ++ps) {   // (blockDim.x == 256)
-    const int vt = tid + 256 * ps;
-    double s0 = 0.0, s1 = 0.0;
-    if (vt < n) {   // the prefetched first element of virtual thread vt
-      const double dqs = a * pg[ps] + b * pw[ps];
-      const double dq = T.scaling ? pd[ps] * dqs : dqs;
-      if (!idle) { T.dq[vt] = dq; T.q_trial[vt] = pq[ps] + dq; }
-      s0 += dq * dq;
-      s1 += pg[ps] * dqs;
-    }
-    for (int idx = vt + 1024; idx < n; idx += 1024) {
-      const double dqs = a * T.rows.gt[idx] + b * T.rows.w[idx];
-      const double dq = T.scaling ? T.rows.D[idx] * dqs : dqs;
-      if (!idle) { T.dq[idx] = dq; T.q_trial[idx] = T.rows.q[idx] + dq; }
-      s0 += dq * dq;
-      s1 += T.rows.gt[idx] * dqs;
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { s0 += __shfl_down(s0, off); s1 += __shfl_down(s1, off); }
-    if (lane == 0) { scratch[vt >> 6] = s0; scratch[16 + (vt >> 6)] = s1; }
+  if (tid < K) {
+    const double dqs = a * gl[tid] + b * wl[tid];
+    const double dq = T.scaling ? dl[tid] * dqs : dqs;
+    if (!idle) T.dq[i * K + tid] = dq;
+    rowx[tid] = dq * dq; rowx[K + tid] = gl[tid] * dqs; rowx[2 * K + tid] = qi + dq;
   }
   __syncthreads();
-  if (T.nquat > 0 && !idle) {
-    const int nsteps = n / T.nq;
-    for (int idx = tid; idx < nsteps * T.nquat; idx += nt) {
-      const int t = idx / T.nquat, qs = T.quat[idx - t * T.nquat];
-      double* qq = T.q_trial + (size_t)t * T.nq + qs;
-      const double nrm = __builtin_sqrt(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
-      for (int k = 0; k < 4; ++k) qq[k] /= nrm;
-    }
+  if (T.nquat > 0 && tid < T.nquat && i < T.n / T.nq) {   // (quaternions of this time step, normalised where they stand)
+    double* qq = rowx + 2 * K + T.quat[tid];
+    const double nrm = __builtin_sqrt(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
+    for (int k = 0; k < 4; ++k) qq[k] /= nrm;
   }
-  if (tid == 0) {
+  if (tid == 64) {
     double x0 = 0.0, x1 = 0.0;
-    for (int wv = 0; wv < 16; ++wv) { x0 += scratch[wv]; x1 += scratch[16 + wv]; }
-    T.out[9] = x0; T.out[10] = x1;
+    for (int r = 0; r < K; ++r) { x0 += rowx[r]; x1 += rowx[K + r]; }
+    T.part2[2 * i] = x0; T.part2[2 * i + 1] = x1;
   }
+  if (T.nquat > 0) __syncthreads();
+  if (tid < K && !idle) T.q_trial[i * K + tid] = rowx[2 * K + tid];
+  TR_STAMP_B0(9);
 }
 
 struct TrDecideArgs {
   double* state;        // [TRS_COUNT]
-  const double* out;    // [11] from tr_iter_kernel
+  double* out;          // [11]: [0..8] from tr_iter_kernel; [9], [10] = dq.dq, g~.D^-1 dq are added up here from
+  const double* part2;  // ... tr_iter_kernel's [nblk][2] per block row, in block order
+  int nblk;
   double* rows;         // [iterations][TRR_COUNT]
   size_t rows_stride;   // doubles between the rows of consecutive problems of a batch
   double* q;            // the iterate, overwritten by q_trial when the step is accepted
@@ -501,13 +667,14 @@ struct TrDecideArgs {
 };
 
 // thread 0 of cost_kernel's workgroup, with the cost of the trial point (and h(q + dq).lambda when
-// constraints are enforced); returns whether the step is accepted
-__device__ inline bool tr_decide(const TrDecideArgs& T, double cost_trial, double hl_trial) {
-  const double* S = T.out;
+// constraints are enforced); returns whether the step is accepted.  S = T.out[0..10] and st = T.state[0..TRS_COUNT) as the
+// caller fetched them at its entry (nothing writes them in between: their round trip runs under the cost's loads)
+__device__ inline bool tr_decide(const TrDecideArgs& T, double cost_trial, double hl_trial, const double (&S)[11],
+                                 const double (&st)[TRS_COUNT]) {
   const double gg = S[0], gHg = S[1], ww = S[2], gw = S[3], gHw = S[4], wHw = S[5], qq = S[6], hh = S[7];
-  const double a = T.state[TRS_A], b = T.state[TRS_B], Delta = T.state[TRS_DELTA], cost = T.state[TRS_COST];
-  int flags = (int)T.state[TRS_FLAGS];
-  const int k = (int)T.state[TRS_ITER];
+  const double a = st[TRS_A], b = st[TRS_B], Delta = st[TRS_DELTA], cost = st[TRS_COST];
+  int flags = (int)st[TRS_FLAGS];
+  const int k = (int)st[TRS_ITER];
   const double gdqs = S[10];
   if (!__builtin_isfinite(S[9])) flags |= TRF_NONFINITE;
   const double dL_dq = gdqs / cost;   // :2517-2524
@@ -533,12 +700,12 @@ __device__ inline bool tr_decide(const TrDecideArgs& T, double cost_trial, doubl
     }
     if (accept) T.state[TRS_COST] = cost_trial;   // :2550-2553
     if (rho < 0.25) T.state[TRS_DELTA] = Delta * 0.25;                                                        // :2614-2617
-    else if (rho > 0.75 && T.state[TRS_ACTIVE] != 0.0) T.state[TRS_DELTA] = __builtin_fmin(2 * Delta, T.Delta_max);   // :2618-2622
+    else if (rho > 0.75 && st[TRS_ACTIVE] != 0.0) T.state[TRS_DELTA] = __builtin_fmin(2 * Delta, T.Delta_max);   // :2618-2622
   }
   T.state[TRS_FLAGS] = (double)flags;
   T.state[TRS_ITER] = (double)(k + 1);
   T.state[TRS_ACCEPTED] = accept ? 1.0 : 0.0;
-  if (accept) T.state[TRS_CUR] = (T.state[TRS_CUR] != 0.0) ? 0.0 : 1.0;   // the trial point's set is the iterate's now
+  if (accept) T.state[TRS_CUR] = (st[TRS_CUR] != 0.0) ? 0.0 : 1.0;   // the trial point's set is the iterate's now
   return accept;
 }
 
