@@ -447,27 +447,6 @@ __device__ inline double tr_dogleg_quadratic(double a, double b, double c, bool*
 // a few hundred workgroups of 256 threads, dispatched in order - in a batch the problems behind the dispatch front are
 // complete and finish, so the front moves.  The wait is bounded (spin_wait's clock): on expiry the loop idles with
 // TRF_SOLVER_TIMEOUT.
-template <class Ready>
-__device__ __forceinline__ bool tr_spin(Ready ready, unsigned* word, unsigned id) {
-  unsigned n = 0;
-  long long t0 = 0;
-  while (!ready()) {
-    __builtin_amdgcn_s_sleep(1);
-    if (((++n) & 1023u) == 0) {
-      const long long now = (long long)wall_clock64();
-      if (t0 == 0) t0 = now;
-      else if (now - t0 > 5000000) {   // 50 ms (penta_ldl.h SPIN_LIMIT_TICKS)
-        if (word) {
-          __hip_atomic_store(word, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          __hip_atomic_fetch_add(word + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        return false;
-      }
-    }
-  }
-  return true;
-}
-
 __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
   extern __shared__ double lds[];
   __shared__ double ab[3];
@@ -536,16 +515,33 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
     bool fine = true;
     for (int base = 0; base < cnt; base += 4 * nt) {
       double v[4] = {0.0, 0.0, 0.0, 0.0};
-      bool got[4];
+      unsigned pending = 0u;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) got[u] = base + tid + u * nt >= cnt;
-      fine &= tr_spin([&] {
-        bool all = true;
+      for (int u = 0; u < 4; ++u) pending |= (base + tid + u * nt < cnt) ? (1u << u) : 0u;
+      unsigned polls = 0;
+      long long t0 = 0;
+      while (pending) {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          if (!got[u]) { got[u] = tr_ll_try(T.rows.part_ll + 2 * (base + tid + u * nt), T.rows.epoch, v[u]); all &= got[u]; }
-        return all;
-      }, T.timeout_status, T.fact_id);
+          if (pending & (1u << u)) {
+            double x;
+            if (tr_ll_try(T.rows.part_ll + 2 * (base + tid + u * nt), T.rows.epoch, x)) { v[u] = x; pending &= ~(1u << u); }
+          }
+        if (!pending) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (((++polls) & 1023u) == 0) {   // (bounded like the solvers' waits: penta_ldl.h spin_wait, 50 ms)
+          const long long now = (long long)wall_clock64();
+          if (t0 == 0) t0 = now;
+          else if (now - t0 > 5000000) {
+            if (T.timeout_status) {
+              __hip_atomic_store(T.timeout_status, T.fact_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              __hip_atomic_fetch_add(T.timeout_status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            fine = false;
+            break;
+          }
+        }
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) { const int idx = base + tid + u * nt; if (idx < cnt) part[idx] = v[u]; }
     }
