@@ -63,6 +63,9 @@ vals = {
     "R6_BATCH64": f"{b['batch_mode'][1]['value'] / 1e3:.0f}k",
     "R6_FULLITER": f"{b['full_iteration']['ms_per_iteration']:.3f}", "R6_FULLITER_CPU": f"{b['full_iteration']['cpu_port_ms_per_iteration']:.1f} ms",
     "R6_MPC": f"{mpc.group(1)} (p10 {mpc.group(2)}, p90 {mpc.group(3)})",
+    "R6_TRITER_US": f"{avg_us(P('full_iteration_kernel_stats.csv'), 'tr_iter_kernel'):.1f}",
+    "R6_COST_US": f"{avg_us(P('full_iteration_kernel_stats.csv'), 'cost_kernel'):.1f}",
+    "R6_FULLITER_OTHERS": ", ".join(f"{k} {float(v):.3f}" for k, v in fi.items() if k != "mini_cheetah"),
 }
 src = os.path.join(ROOT, "tools", "design", "DESIGN.in.md")
 text = open(src).read()
