@@ -355,6 +355,7 @@ struct idto_hip_ctx {
   // nq + nu on this context's stream, made on first use
   idto_hip_ctx* kkt = nullptr; int kkt_nu = 0;
   bool con_kkt = true;                     // option "con_kkt" (0: the Schur-complement chain of constraints.h)
+  bool kkt_fold = true;                    // option "kkt_fold" (0: kkt_extract_kernel in a launch of its own in front of tr_iter_kernel)
   int ldl_npos = 0;                        // (a KKT context) the solver expects the pivots [ldl_npos, nq) of a block negative
 };
 enum { IDTO_SLAB_PAD = 64 };
@@ -983,7 +984,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   const size_t nvars = (size_t)(N + 1) * nq;
   const size_t o_trD = carve(nvars, D), o_trg = carve(nvars, D), o_trw = carve(nvars, D), o_trdq = carve(nvars, D),
                o_qt = carve(nvars, D), o_trout = carve(16, D), o_trDp = carve(nvars, D), o_trpart = carve((size_t)9 * (N + 1), D),
-               o_trpll = carve((size_t)2 * (TR_NSUM * (N + 1) + 2), D), o_trp2 = carve((size_t)2 * (N + 1), D);
+               o_trpll = carve((size_t)2 * (TR_NSUM * (N + 1) + 3), D), o_trp2 = carve((size_t)2 * (N + 1), D);
   const size_t o_trstate = carve(TRS_COUNT, D), o_trcnt = carve(1, sizeof(unsigned long long));
   // the equality-constraint step's outputs (per problem, so that the batched loop finds them at the arena stride):
   // [H^-1 (g + J^T lambda) | J^T lambda] and the multipliers (nu <= nv; + 2: the blocked dense LDL^T's [min, max | ...])
@@ -1132,6 +1133,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   if (const char* e = getenv("IDTO_SOLVER_PIPE")) c->solver_pipe = (e[0] == '1');
   if (const char* e = getenv("IDTO_ASM_FOLD")) c->asm_fold = (e[0] == '1');
   if (const char* e = getenv("IDTO_CON_KKT")) c->con_kkt = (e[0] == '1');
+  if (const char* e = getenv("IDTO_KKT_FOLD")) c->kkt_fold = (e[0] == '1');
   if (const char* e = getenv("IDTO_SOLVER_BAND")) c->solver_band = std::atoi(e);   // (measurement aid: penta_band.h off / on / on for blocks of 5 too)
   (void)hipGetLastError();
   *out = c;
@@ -2156,6 +2158,7 @@ static TrRowsArgs PrepareArgs(idto_hip_ctx* c, int scaling_method, int with_lamb
   A.partial = c->tr_part;
   A.freeze = nullptr;   // (idto_hip_tr_solve points it at the loop's sticky flags)
   A.part_ll = nullptr; A.epoch = 0u; A.dq_old = nullptr;   // (... and these at the hand-over between tr_iter_kernel's workgroups)
+  A.kx = TrKkt{};
   return A;
 }
 
@@ -2398,7 +2401,7 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     HIP_OK(hipMemcpy2DAsync(c->tr_state + TRS_COST, c->pstride, c->cost, c->pstride, sizeof(double), (size_t)B,
                             hipMemcpyDeviceToDevice, c->stream));
   const double eps = 10 * std::numeric_limits<double>::epsilon() / c->P.dt / c->P.dt;   // TO.cc:2024
-  const int lds_iter = (int)sizeof(double) * (tr_rows_lds(c->nq) + TR_NSUM * nblk + 2 + TR_NSUM + 3 * c->nq);
+  const int lds_iter = (int)sizeof(double) * (tr_rows_lds(c->nq) + TR_NSUM * nblk + 3 + TR_NSUM + 3 * c->nq);
   // g, H and the Newton step of the first iterate (with constraints the step comes out of the multiplier chain)
   int rc = 0;
   if (nu > 0) {
@@ -2453,6 +2456,8 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
       if (c->tr_pin[TRS_FLAGS] != 0.0) break;
     }
     conv.check_only = (k == iterations) ? 1 : 0;
+    bool kkt_fold = false;
+    KktExtractArgs kkt_ex{};
     if (nu > 0 && use_kkt) {
       // multipliers of the iterate and H^-1 (g + J^T lambda) (TO.cc:1371-1396, :2139-2149) from ONE banded solve of the
       // KKT system (kkt.h): build its bands from H and the slab's rows of J, factorise + solve, take the result apart
@@ -2467,6 +2472,8 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
       HIP_OK(hipGetLastError());
       rc = idto_hip_factor_solve(kc, nullptr, 1, nullptr);
       if (rc) return rc;
+      // (taking z apart - w, J^T lambda, lambda, the multiplier pivots' range - is folded into tr_iter_kernel below; option
+      // "kkt_fold" 0 keeps kkt_extract_kernel's launch: tests hold the two against each other)
       KktExtractArgs Ke;
       Ke.N = c->N; Ke.nq = c->nq; Ke.nv = c->nv; Ke.nu = nu;
       Ke.z = kc->step; Ke.slab = c->slab; Ke.slab_stride = c->slab_stride; Ke.dofs = c->con_dofs;
@@ -2474,7 +2481,9 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
       Ke.Dinv = kc->Dst; Ke.dstride = SolverBlockSize(kc->nq, true); Ke.first_row = SolverFirstRow(kc);
       Ke.state = c->tr_state; Ke.alt = c->alt_r;
       Ke.pstride = c->pstride; Ke.kstride = kc->pstride;
-      hipLaunchKernelGGL(kkt_extract_kernel, dim3(c->N + 1, B), dim3(64), 0, c->stream, Ke);
+      kkt_fold = c->kkt_fold;
+      if (kkt_fold) kkt_ex = Ke;
+      else hipLaunchKernelGGL(kkt_extract_kernel, dim3(c->N + 1, B), dim3(64), 0, c->stream, Ke);
       HIP_OK(hipGetLastError());
       c->con_lambda_at = c->con_lambda;
       c->con_ready = false; c->con_begun = false;
@@ -2525,6 +2534,12 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     if (nu > 0 && use_kkt) { T.fact_status = c->kkt->status_dev; T.fact_id = c->kkt->fact_id; T.timeout_status = c->kkt->status_dev + 2 * B; }
     T.rows.freeze = c->tr_state + TRS_FLAGS;
     T.pstride = c->pstride; T.rows_stride = rows_stride;
+    T.kdinv = nullptr; T.kdstride = 0; T.kfirst_row = 0; T.kstride = 0;
+    if (kkt_fold) {
+      T.rows.kx.z = kkt_ex.z; T.rows.kx.KK = c->nq + nu; T.rows.kx.nv = c->nv;
+      T.rows.kx.w_out = kkt_ex.w; T.rows.kx.jtl_out = kkt_ex.jtl; T.rows.kx.lambda_out = kkt_ex.lambda;
+      T.kdinv = kkt_ex.Dinv; T.kdstride = kkt_ex.dstride; T.kfirst_row = kkt_ex.first_row; T.kstride = kkt_ex.kstride;
+    }
     hipLaunchKernelGGL(tr_iter_kernel, dim3(nblk + 1, B), dim3(256), lds_iter, c->stream, T);
     HIP_OK(hipGetLastError());
     if (k == iterations) break;   // (the check-only pass)
@@ -2913,6 +2928,7 @@ int idto_hip_get_option(idto_hip_ctx* c, const char* name, int* value) {
   if (std::strcmp(name, "solver_timeouts") == 0) { *value = c->solver_timeouts; return 0; }
   if (std::strcmp(name, "asm_fold") == 0) { *value = c->asm_fold; return 0; }
   if (std::strcmp(name, "con_kkt") == 0) { *value = c->con_kkt; return 0; }
+  if (std::strcmp(name, "kkt_fold") == 0) { *value = c->kkt_fold; return 0; }
   if (std::strcmp(name, "kkt_last_solver") == 0) { *value = c->kkt ? c->kkt->last_solver : 0; return 0; }
   if (std::strcmp(name, "last_assembly") == 0) { *value = c->last_assembly; return 0; }
   if (std::strcmp(name, "fused") == 0) { *value = c->fused; return 0; }
@@ -2946,6 +2962,7 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "debug_pipe_tail") == 0) { c->debug_pipe_tail = value; return 0; }   // measurement aid
   if (std::strcmp(name, "asm_fold") == 0) { c->asm_fold = value != 0; c->terms_valid = false; return 0; }
   if (std::strcmp(name, "con_kkt") == 0) { c->con_kkt = value != 0; return 0; }
+  if (std::strcmp(name, "kkt_fold") == 0) { c->kkt_fold = value != 0; return 0; }
   if (std::strcmp(name, "fused_debug") == 0) { c->fused_debug = value != 0; return 0; }
   if (std::strcmp(name, "asm_stop") == 0) { c->asm_stop = value; return 0; }  // profiling aid
   if (std::strcmp(name, "fd_stop") == 0) { c->fd_stop = value; return 0; }    // profiling aid

@@ -87,6 +87,27 @@ __device__ __forceinline__ double scale_factor(int scaling_method, double hii, d
 // tr_prepare_sum_kernel refreshes afterwards), then the rows of H~ g~ and H~ w with one thread per
 // (row, band block) and a sum over the five band blocks in LDS, and writes its nine partial sums;
 // tr_prepare_sum_kernel adds the partial sums in block order (deterministic).
+// slab record k: [dtau_k/dq_{k-1} | dtau_k/dq_k | dtau_k/dq_{k+1} | tau_k], blocks nv x nq stored column by column:
+// J[(t, dof), col] for a global column index col in [0, (N+1) nq)  (constraints.h jac_entry - that header comes later)
+__device__ __forceinline__ double tr_jac_entry(const double* __restrict__ slab, int slab_stride, int nq, int nv, int t,
+                                               int dof, int N, int col) {
+  const int tc = col / nq, i = col - tc * nq;
+  const int which = tc - t + 1;  // 0: q_{t-1}, 1: q_t, 2: q_{t+1}
+  if (which < 0 || which > 2) return 0.0;
+  if ((which == 0 && t < 2) || (which == 1 && t < 1)) return 0.0;  // q_0 is not a variable of tau_t's rows (TO.cc:1316-1322)
+  return slab[(size_t)t * slab_stride + (size_t)which * nv * nq + i * nv + dof];
+}
+
+// The banded KKT step (kkt.h) taken apart where it is used: z_t = [-w_t ; lambda_{t-1}] is the solver's x.  With .z set,
+// tr_prepare_rows_body forms H^-1 (g + J^T lambda) = -z and J^T lambda of the five block rows it stages itself -
+// kkt_extract_kernel's expressions, same bits - and writes its own block row's to w_out / jtl_out / lambda_out for
+// the kernels that follow (a launch of its own for that was 4.6 us of every constrained iteration).
+struct TrKkt {
+  const double* z;     // null: off (yin, jtl, lambda are read)
+  int KK, nv;          // nq + nu; the model's nv
+  double *w_out, *jtl_out, *lambda_out;
+};
+
 struct TrRowsArgs {
   int nblk, K;
   const double *HA, *HB, *HC, *g, *jtl, *yin;
@@ -107,6 +128,7 @@ struct TrRowsArgs {
   double* part_ll;        // [nblk][TR_NSUM][2], or null: `partial` is written
   unsigned epoch;
   const double* dq_old;   // the step that led to this iterate, or null
+  TrKkt kx;
 };
 constexpr int TR_NSUM = 10;
 // LDS of tr_prepare_rows_body, in doubles (nt = 256): its arrays, then the scratch of the sums
@@ -178,13 +200,25 @@ __device__ __forceinline__ void tr_prepare_rows_body(const TrRowsArgs& A, double
     if (bi >= 0 && bi < nblk) {
       const int v = bi * K + r;
       const double d = (scaling_method >= 0) ? scale_factor(scaling_method, HC[(size_t)bi * kk + r * K + r], Dprev[v]) : 1.0;
-      const double gm = jtl ? g[v] + jtl[v] : g[v];
-      const double gti = d * gm, yi = ysign * yin[v];
+      double jt = 0.0, yv;
+      if (A.kx.z) {   // (kkt_extract_kernel's sums: ascending time step, then dof)
+        for (int s = (bi >= 1 ? bi - 1 : 0); s <= bi + 1 && s < N; ++s)
+          for (int jj = 0; jj < nu; ++jj)
+            jt += tr_jac_entry(slab, slab_stride, K, A.kx.nv, s, dofs[jj], N, v) * A.kx.z[(size_t)(s + 1) * A.kx.KK + K + jj];
+        yv = -A.kx.z[(size_t)bi * A.kx.KK + r];
+        if (j == 2) { A.kx.w_out[v] = yv; A.kx.jtl_out[v] = jt; }
+      } else {
+        if (jtl) jt = jtl[v];
+        yv = yin[v];
+      }
+      const double gm = (jtl || A.kx.z) ? g[v] + jt : g[v];
+      const double gti = d * gm, yi = ysign * yv;
       vt = d * gti; vy = yi;
       if (j == 2) {
         const double wi = yi / d;
         dl[r] = d; gl[r] = gti; wl[r] = wi; gml[r] = gm;
-        if (!frozen) { D[v] = d; gt[v] = gti; w[v] = wi; }
+        // (the resident loop's workgroups write these once they know that the iteration counts: tr_iter_kernel)
+        if (!frozen && !A.part_ll) { D[v] = d; gt[v] = gti; w[v] = wi; }
       }
     }
     xt[idx] = vt; xy[idx] = vy;
@@ -234,7 +268,8 @@ __device__ __forceinline__ void tr_prepare_rows_body(const TrRowsArgs& A, double
     for (int j = tid; j < nu; j += nt) {
       const double h = slab[(size_t)i * slab_stride + tau_off + dofs[j]];
       s[7] += h * h;
-      if (lambda) s[8] += h * lambda[i * nu + j];
+      if (A.kx.z) s[8] += h * A.kx.z[(size_t)(i + 1) * A.kx.KK + K + j];   // lambda_i = the multiplier rows of z_{i+1}
+      else if (lambda) s[8] += h * lambda[i * nu + j];
     }
   }
   if (K <= 32 && nu <= 32) {
@@ -416,6 +451,10 @@ struct TrIterArgs {
   unsigned fact_id;              // came from: a failure in the MIDDLE of the resident loop is flagged in its own iteration
   unsigned* timeout_status;      // ... and the word a launch whose waits between workgroups ran out writes its id to
   size_t pstride, rows_stride;   // batch contexts: grid.y = problem (arena stride in bytes; doubles between the problems' rows)
+  // (rows.kx.z set) the KKT factorisation's 1 / d - solver row i (= block row i + first_row), lane r at Dinv[i dstride + r] -
+  // for the multiplier pivots' range (TRF_SINGULAR_S), and the KKT context's arena stride
+  const double* kdinv; int kdstride, kfirst_row;
+  size_t kstride;
 };
 
 // (TO.cc:2204-2242 SolveDoglegQuadratic; *ok = false where the reference throws)
@@ -464,6 +503,11 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
     T.part2 = at_problem(T.part2, o); T.out = at_problem(T.out, o); T.state = at_problem(T.state, o);
     T.q_trial = at_problem(T.q_trial, o); T.dq = at_problem(T.dq, o);
     A.dq_old = T.conv.on ? T.dq : nullptr;
+    if (A.kx.z) {
+      const size_t ok = (size_t)blockIdx.y * T.kstride;
+      A.kx.z = at_problem(A.kx.z, ok); T.kdinv = at_problem(T.kdinv, ok);
+      A.kx.w_out = at_problem(A.kx.w_out, o); A.kx.jtl_out = at_problem(A.kx.jtl_out, o); A.kx.lambda_out = at_problem(A.kx.lambda_out, o);
+    }
     T.conv.rows += (size_t)blockIdx.y * T.rows_stride;
     if (T.fact_status) T.fact_status += 2 * blockIdx.y;
   }
@@ -491,6 +535,29 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
       tr_ll_store(T.rows.part_ll + 2 * (TR_NSUM * nblk), (double)fact_word, T.rows.epoch);
       tr_ll_store(T.rows.part_ll + 2 * (TR_NSUM * nblk + 1), (double)timeout_word, T.rows.epoch);
     }
+    if (tid < 64) {
+      // (KKT step) the multiplier pivots - 1 / d is what the factorisation keeps -: negative, finite, and min |d| / max |d| >
+      // 1e-13; anything else = redundant constraints, the host's pivoted factorisation takes over (kkt_extract_kernel's
+      // criterion, constraint_lambda_kernel's on the pivots of S)
+      bool bad = false;
+      if (T.rows.kx.z) {
+        const int nu = T.rows.nu, N = T.rows.N;
+        double imn = __builtin_inf(), imx = 0.0;
+        bool finite = true;
+        for (int idx = tid; idx < N * nu; idx += 64) {
+          const int bt = 1 + idx / nu, j = idx - (bt - 1) * nu;
+          const double iv = -T.kdinv[(size_t)(bt - T.kfirst_row) * T.kdstride + K + j];
+          finite = finite && __builtin_isfinite(iv) && iv > 0.0;
+          imn = __builtin_fmin(imn, iv); imx = __builtin_fmax(imx, iv);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          imn = __builtin_fmin(imn, __shfl_xor(imn, off)); imx = __builtin_fmax(imx, __shfl_xor(imx, off));
+        }
+        bad = __builtin_amdgcn_ballot_w64(!finite) != 0ull || !(imn > 1e-13 * imx);   // (|d|: max = 1 / imn, min = 1 / imx)
+      }
+      if (tid == 0) tr_ll_store(T.rows.part_ll + 2 * (TR_NSUM * nblk + 2), bad ? 1.0 : 0.0, T.rows.epoch);
+    }
     return;
   }
   // The loop's state words: nobody writes them before every workgroup has published its sums (workgroup 0, after its
@@ -506,12 +573,12 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
   const double* dl = lds + 10 * K;   // (tr_prepare_rows_body's arrays: D, g~, w of this block row)
   const double* gl = lds + 21 * K;
   const double* wl = lds + 22 * K;
-  double* part = lds + tr_rows_lds(K);       // [TR_NSUM nblk + 2]: the block rows' sums, the solver's two status words
-  double* S = part + TR_NSUM * nblk + 2;     // [TR_NSUM]
+  double* part = lds + tr_rows_lds(K);       // [TR_NSUM nblk + 3]: the block rows' sums, the solver's two status words, "singular"
+  double* S = part + TR_NSUM * nblk + 3;     // [TR_NSUM]
   double* rowx = S + TR_NSUM;                // [3 K] dq.dq, g~.dqs terms of the row; its trial point
   // ---- 2. the sums of every block row: polled where they are written, four per thread in flight
   {
-    const int cnt = TR_NSUM * nblk + 2;
+    const int cnt = TR_NSUM * nblk + 3;
     bool fine = true;
     for (int base = 0; base < cnt; base += 4 * nt) {
       double v[4] = {0.0, 0.0, 0.0, 0.0};
@@ -565,8 +632,16 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
     S[tid] = acc;
     if (first && tid < 9) T.out[tid] = acc;
   }
-  // the adaptive methods' memory (every workgroup has read its neighbours' by now)
-  if (tid < K && !frozen) const_cast<double*>(T.rows.Dprev)[i * K + tid] = dl[tid];
+  // D, g~, w of this block row and the adaptive methods' memory (every workgroup has read its neighbours' by now) - unless
+  // the loop idles already, or this iteration's multipliers came from a singular system
+  const bool singular = part[TR_NSUM * nblk + 2] != 0.0;
+  if (tid < K && !frozen && !singular) {
+    const int v = i * K + tid;
+    T.rows.D[v] = dl[tid]; T.rows.gt[v] = gl[tid]; T.rows.w[v] = wl[tid];
+    const_cast<double*>(T.rows.Dprev)[v] = dl[tid];
+  }
+  if (T.rows.kx.z && i >= 1 && tid < T.rows.nu)   // lambda_{i-1}: the multiplier rows of z_i
+    T.rows.kx.lambda_out[(size_t)(i - 1) * T.rows.nu + tid] = T.rows.kx.z[(size_t)i * T.rows.kx.KK + K + tid];
   __syncthreads();
   TR_STAMP_B0(5);
   // ---- the convergence criteria of the step the previous iteration accepted (TrConvergence): g.dq with the merit
@@ -597,6 +672,7 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
     int flags = (int)st[TRS_FLAGS];
     if (T.fact_status && (unsigned)part[TR_NSUM * nblk] == T.fact_id) flags |= TRF_FACTORIZATION;
     if ((T.timeout_status && (unsigned)part[TR_NSUM * nblk + 1] == T.fact_id) || timed_out) flags |= TRF_SOLVER_TIMEOUT;
+    if (singular) flags |= TRF_SINGULAR_S;
     const double cU = -(gg / gHg) / Delta;
     const double pUn = __builtin_fabs(cU) * __builtin_sqrt(gg), pHn = __builtin_sqrt(ww) / Delta;
     double a, b, active;

@@ -226,6 +226,29 @@ def test_resident_loop_with_equality_constraints_follows_the_host_loop(name, N, 
     assert np.abs(sa.q - sb.q).max() <= 1e-5 * max(1.0, np.abs(sb.q).max())
 
 
+@pytest.mark.parametrize("name,N,iters", [("acrobot", 40, 20), ("spinner", 40, 12), ("hopper", 40, 10), ("allegro_hand", 20, 3)])
+def test_kkt_solution_taken_apart_inside_the_iteration_kernel(name, N, iters):
+    """the banded KKT step's solution z = [-w ; lambda] is taken apart by tr_iter_kernel's workgroups (option kkt_fold,
+    the default) with kkt_extract_kernel's expressions: the loop's rows, the iterate, the multipliers and J^T lambda are
+    the bits of the loop that runs kkt_extract_kernel in a launch of its own"""
+    cfg, model, prob, sp, q = _setup(name, N)
+    out = []
+    for fold in (1, 0):
+        dev = hip.HipPath(model, prob, sp)
+        dev.set_option("kkt_fold", fold)
+        dev.set_q(q)
+        dev.eval_tau()
+        rows, delta = dev.tr_solve(iters, SCALING["double_sqrt"], True, False, 1e-1, 1e5, constrained_dofs=model.unactuated_dofs)
+        out.append((rows.copy(), delta, dev.get("q"), dev.get("tr_w"), dev.get("tr_dq"), dev.get("tr_scale"), dev.get("con_lambda")))
+        dev.close()
+    a, b = out
+    cols = [c for c in range(a[0].shape[1]) if c != 10]   # (column 10 is the device clock)
+    assert np.array_equal(a[0][:, cols], b[0][:, cols]) and a[1] == b[1]
+    assert a[0][:, 9].any() and (a[0][:, 14] == 0).all()
+    for x, y in zip(a[2:], b[2:]):
+        assert np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("kkt", [1, 0])
 def test_resident_loop_flags_a_singular_constraint_system(kkt):
     """the same degree of freedom constrained twice: S = J H^-1 J^T is exactly singular; the single-workgroup
