@@ -40,13 +40,21 @@ struct SmallArgs {
   int lds_small;    // where this kernel's own arrays start (doubles): behind the band solver's carve-up
   double* ts;       // option "solver_debug" 4: wall-clock stamps of the phases (100 MHz), else nullptr
   const BandStageItem* stage; int nstage;   // penta_band.h band_stage_table for this horizon, sources relative to the LDS copy of [A | B | C | g]
+  // Inside the resident trust-region loop (idto_hip_tr_solve, T.state set): `q` is the TRIAL point of the iteration; behind
+  // the records the workgroup evaluates the cost (cost_kernel's sums in cost_kernel's order), decides (tr_decide) and -
+  // accepted - goes on to g, H and the next step; rejected, it stops there: g, H and the step are the iterate's.  One launch
+  // stands in for fd_kernel, cost_kernel and the solver's launch with the gated assembly in front.
+  TrDecideArgs T;
+  int tau_only;        // the loop's last iteration: tau and the cost of the trial point, the decision; no partials, no step
+  double* cost_out;
 };
 
 // doubles of dynamic LDS behind the band solver's carve-up (gn_small_kernel's own arrays, in its order)
 __host__ __device__ inline int gn_small_doubles(int N, int K, int fast_n) {
   const int E = 1 + 3 * K;
   return 2 * (N + 1) * K + N * K + 3 * N * E + N * E * K + K * K + 3 * N * K * K + 5 * K + (K & 1) + fast_n + (fast_n & 1) +
-         3 * (N + 1) * K * K + 3 * (N + 1) * K + 2 * K * K + (K * K & 1) + K + 2;
+         3 * (N + 1) * K * K + 3 * (N + 1) * K + 2 * K * K + (K * K & 1) + K + 2 +
+         5 * K + (K & 1) + (3 * N + 2) * (K + 1) + 2 * (N + 1) + 2 + 24;   // (the trust-region loop's cost and decision)
 }
 
 template <int SHAPE, int W, int NT>
@@ -98,11 +106,30 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
   double* vn = qn + (N + 1) * K;
   double* wQf = vn + (N + 1) * K;                   // [K K] x 2: Qq', Qfq' (the C blocks start from their entries)
   double* wFQf = wQf + qq;
-  int* colinfo = reinterpret_cast<int*>(wFQf + qq + (qq & 1));   // [K] non-zero rows of N+ column c, [K] non-zero columns of row r
+  double* cw0 = wFQf + qq + (qq & 1);               // [5 K] the cost's diagonals: Qq, Qv, R, Qfq, Qfv as the YAML has them
+  double* cterms = cw0 + 5 * K + (K & 1);           // [3 N + 2] the cost's terms
+  double* ccols = cterms + 3 * N + 2;               // [(3 N + 2) K] ... their columns
+  double* cp2 = ccols + (3 * N + 2) * K;            // [2 (N + 1) + 2] dq.dq, g~.D^-1 dq per block row (tr_iter_kernel), their sums
+  double* cst = cp2 + 2 * (N + 1) + 2;              // [24] the nine inner products and the loop's state words, as the launch found them
+  int* colinfo = reinterpret_cast<int*>(cst + 24);  // [K] non-zero rows of N+ column c, [K] non-zero columns of row r
   int* rowinfo = colinfo + K;
 
   auto stamp = [&](int i) { if (S.ts && tid == 0 && blockIdx.y == 0) S.ts[i] = (double)wall_clock64(); };
   stamp(0);
+  TrDecideArgs T = S.T;
+  double dS[11], dst[TRS_COUNT], p2v = 0.0;
+  if (T.state) {   // (what the decision needs and nothing in this launch writes: requested first - cost_kernel does the same -,
+                   // parked in LDS behind phase A's loads: they would not survive the evaluation in registers)
+    T.state = at_problem(T.state, o); T.out = at_problem(T.out, o); T.q = at_problem(T.q, o);
+    T.rows += (size_t)blockIdx.y * T.rows_stride; T.part2 = at_problem(T.part2, o);
+    if (T.lambda) T.lambda = at_problem(T.lambda, o);
+    dS[9] = dS[10] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dS[k] = (tid == 0) ? T.out[k] : 0.0;
+#pragma unroll
+    for (int k = 0; k < TRS_COUNT; ++k) dst[k] = (tid == 0) ? T.state[k] : 0.0;
+    if (tid < 2 * T.nblk) p2v = T.part2[tid];
+  }
   // ---- A: every global load of the step (but the nominal trajectory, first used in E)
   for (int i = tid; i < M.fast_n; i += nt) mblob[i] = M.blob[M.fast_lo + i];
   for (int i = tid; i < (N + 1) * K; i += nt) qs[i] = q[i];
@@ -115,6 +142,20 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
     wQ[tid] = P.Qq[tid * nq + tid]; wFQ[tid] = P.Qfq[tid * nq + tid];
     colinfo[tid] = M.colinfo[tid];
     rowinfo[tid] = M.rowinfo[tid];
+    if (T.state) {
+      cw0[tid] = P.Qq0[tid * nq + tid]; cw0[K + tid] = P.Qv0[tid * nv + tid]; cw0[2 * K + tid] = P.R0[tid * nv + tid];
+      cw0[3 * K + tid] = P.Qfq0[tid * nq + tid]; cw0[4 * K + tid] = P.Qfv0[tid * nv + tid];
+    }
+  }
+  if (T.state) {
+    if (tid == 0) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) cst[k] = dS[k];
+#pragma unroll
+      for (int k = 0; k < TRS_COUNT; ++k) cst[9 + k] = dst[k];
+    }
+    if (tid < 2 * T.nblk) cp2[tid] = p2v;
+    for (int idx = tid + nt; idx < 2 * T.nblk; idx += nt) cp2[idx] = T.part2[idx];
   }
   __syncthreads();
   stamp(1);
@@ -167,6 +208,7 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
     FT.body = Ml.f_body; FT.cbody = Ml.f_cbody; FT.pairs = Ml.f_pairs; FT.seg = Ml.f_seg; FT.maxpp = Ml.f_maxpp;
     for (int idx = tid; idx < N * E; idx += nt) {
       const int k = idx / E, el = idx - k * E;
+      if (S.tau_only && el != 0) continue;
       InFwd in;
       in.q1 = qs + (k + 1) * K; in.v1 = vs + (k + 1) * K; in.a0 = as + k * K; in.N1 = Nid; in.N0 = Nid; in.nv = nv;
       in.kind = (el == 0) ? 0 : ((el < 1 + nP) ? 1 : ((el < 1 + nP + nT) ? 2 : 3));
@@ -185,7 +227,7 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
   // ---- D: the records (fd_body, mode 1)
   {
     const double sc = 1 / dt / dt;
-    for (int idx = tid; idx < N * bsz; idx += nt) {
+    for (int idx = tid; idx < (S.tau_only ? 0 : N * bsz); idx += nt) {
       const int k = idx / bsz, rem = idx - k * bsz, i = rem / nv, r = rem - i * nv;
       const double* et = etau + k * E * K;
       const int ci = colinfo[i], j0 = ci & 0xffff, cnt = ci >> 16;
@@ -211,6 +253,71 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
   }
   __syncthreads();
   stamp(4);
+
+  // ---- (trust-region loop) the cost of the trial point and the decision: cost_kernel's items, sums and order
+  // (kernels.h; diagonal weights: e^T W e per term as sum_c ((0 + e_c w_c) e_c), the columns in order, the terms in order)
+  if (T.state) {
+    for (int idx = tid; idx < (N + 1) * K; idx += nt) {
+      const int t = idx / K, c = idx - t * K;
+      const bool run = t < N;
+      const double eq = qs[idx], nq_ = qn[idx], ev = vs[idx], nv_ = vn[idx];
+      const double et = run ? etau[t * E * K + c] : 0.0;
+      double valq, valv, valt;
+      { const double dc = eq - nq_; double acc = 0; acc += dc * (run ? cw0[c] : cw0[3 * K + c]); valq = acc * dc; }
+      { const double dc = ev - nv_; double acc = 0; acc += dc * (run ? cw0[K + c] : cw0[4 * K + c]); valv = acc * dc; }
+      { const double dc = et - 0.0; double acc = 0; acc += dc * cw0[2 * K + c]; valt = acc * dc; }
+      const int term = run ? 3 * t : 3 * N;
+      ccols[term * K + c] = valq;
+      ccols[(term + 1) * K + c] = valv;
+      if (run) ccols[(term + 2) * K + c] = valt;
+    }
+    __syncthreads();
+    for (int term = tid; term < 3 * N + 2; term += nt) {
+      double tot = 0;
+#pragma unroll
+      for (int c = 0; c < K; ++c) tot += ccols[term * K + c];
+      cterms[term] = tot;
+    }
+    __syncthreads();
+    if (tid == 64 || tid == 128) {   // (beside thread 0's chain of adds)
+      const int k = tid == 64 ? 0 : 1;
+      double acc = 0.0;
+      for (int b = 0; b < T.nblk; ++b) acc += cp2[2 * b + k];
+      cp2[2 * T.nblk + k] = acc;
+    }
+    double cost = 0;
+    if (tid == 0) {
+      for (int i = 0; i < 3 * N; ++i) cost += cterms[i];
+      cost *= P.dt;
+      cost += cterms[3 * N];
+      cost += cterms[3 * N + 1];
+      *at_problem(S.cost_out, o) = cost;
+    }
+    const int neq = T.nu * T.N;
+    __syncthreads();
+    if (T.nu > 0) {   // h(q + dq) . lambda: products by everybody, added in index order by thread 0
+      for (int r = tid; r < neq; r += nt) {
+        const int t = r / T.nu, j = r - t * T.nu;
+        ccols[r] = etau[t * E * K + T.dofs[j]] * T.lambda[r];
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) dS[k] = cst[k];
+#pragma unroll
+      for (int k = 0; k < TRS_COUNT; ++k) dst[k] = cst[9 + k];
+      dS[9] = cp2[2 * T.nblk]; dS[10] = cp2[2 * T.nblk + 1]; T.out[9] = dS[9]; T.out[10] = dS[10];
+      double hl = 0.0;
+      for (int r = 0; r < (T.nu > 0 ? neq : 0); ++r) hl += ccols[r];
+      cterms[0] = tr_decide(T, cost, hl, dS, dst) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    const bool accepted = cterms[0] != 0.0;
+    if (accepted)
+      for (int idx = tid; idx < (N + 1) * K; idx += nt) T.q[idx] = qs[idx];
+    if (!accepted || S.tau_only) return;   // (a rejected step keeps g, H and the step of the iterate)
+  }
 
   // ---- E: g and the bands (assemble_diag_body: same terms, same order).  A thread per (block row, r, c) forms C_i(r, c),
   // B_i(r, c), A_i(r, c) from the same nine operand columns; a thread per (block row, j) the gradient entry.  Straight-line:

@@ -356,6 +356,7 @@ struct idto_hip_ctx {
   idto_hip_ctx* kkt = nullptr; int kkt_nu = 0;
   bool con_kkt = true;                     // option "con_kkt" (0: the Schur-complement chain of constraints.h)
   bool kkt_fold = true;                    // option "kkt_fold" (0: kkt_extract_kernel in a launch of its own in front of tr_iter_kernel)
+  bool tr_small = true;                    // option "tr_small" (0: fd_kernel, cost_kernel and the solver's launch per iteration also for the small models)
   int ldl_npos = 0;                        // (a KKT context) the solver expects the pivots [ldl_npos, nq) of a block negative
 };
 enum { IDTO_SLAB_PAD = 64 };
@@ -1134,6 +1135,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   if (const char* e = getenv("IDTO_ASM_FOLD")) c->asm_fold = (e[0] == '1');
   if (const char* e = getenv("IDTO_CON_KKT")) c->con_kkt = (e[0] == '1');
   if (const char* e = getenv("IDTO_KKT_FOLD")) c->kkt_fold = (e[0] == '1');
+  if (const char* e = getenv("IDTO_TR_SMALL")) c->tr_small = (e[0] == '1');
   if (const char* e = getenv("IDTO_SOLVER_BAND")) c->solver_band = std::atoi(e);   // (measurement aid: penta_band.h off / on / on for blocks of 5 too)
   (void)hipGetLastError();
   *out = c;
@@ -1746,9 +1748,11 @@ static bool SmallEligible(const idto_hip_ctx* c) {
   cc->h_assembled = assembled;
   return ok;
 }
-static int LaunchSmall(idto_hip_ctx* c) {
+// tr: inside idto_hip_tr_solve - the launch evaluates the trial point c->q_trial into the output set `alt`, decides, and
+// goes on to g, H and the step only for an accepted step (gn_small.h SmallArgs::T); last: tau, cost and decision only
+static int LaunchSmall(idto_hip_ctx* c, const TrDecideArgs* tr = nullptr, bool last = false, AltSel alt = AltSel{nullptr, 0, 0}) {
   DropPrefetch(c, {IDTO_ARR_V, IDTO_ARR_A, IDTO_ARR_NPLUS, IDTO_ARR_SLAB, IDTO_ARR_GRADIENT, IDTO_ARR_H_A, IDTO_ARR_H_B,
-                   IDTO_ARR_H_C, IDTO_ARR_HBANDS, IDTO_ARR_STEP});
+                   IDTO_ARR_H_C, IDTO_ARR_HBANDS, IDTO_ARR_STEP, IDTO_ARR_COST});
   c->con_ready = false; c->con_begun = false;
   if (!c->h_assembled) {  // x_0 = -g_0 = 0 is not written by the solver (SolverFirstRow)
     HIP_OK(hipMemset2DAsync(c->step, c->pstride, 0, (size_t)c->nq * sizeof(double), (size_t)c->batch, c->stream));
@@ -1759,7 +1763,9 @@ static int LaunchSmall(idto_hip_ctx* c) {
   SmallArgs A;
   A.M = c->M; A.cp = c->cp; A.P = c->P; A.q = c->q; A.slab = c->slab; A.slab_stride = c->slab_stride;
   A.v = c->v; A.a = c->a; A.nplus = c->nplus; A.g = c->g; A.HA = c->HA; A.HB = c->HB; A.HC = c->HC;
-  A.pstride = c->pstride; A.alt = AltSel{nullptr, 0, 0};
+  A.pstride = c->pstride; A.alt = alt;
+  A.T = tr ? *tr : TrDecideArgs{}; A.tau_only = last ? 1 : 0; A.cost_out = c->cost;
+  if (tr) A.q = c->q_trial;
   BandArgs& B = A.B;
   B.n = p.n; B.k = p.k;
   B.HA = c->HA + p.qq0; B.HB = c->HB + p.qq0; B.HC = c->HC + p.qq0;
@@ -1783,15 +1789,15 @@ static int LaunchSmall(idto_hip_ctx* c) {
   c->last_solver = 7;
   c->last_step_kind = 2;
   c->last_assembly = 5;
-  if (TimeBegin(c, 3)) return -2;
+  if (!tr && TimeBegin(c, 3)) return -2;
   // (256 threads, one wavefront per SIMD: the evaluation needs more than the 256 registers a lane has at two per SIMD -
   // 512 threads spilled 19 / 67 registers to scratch inside it and the step was slower than the two launches)
   if (c->nq == 2) hipLaunchKernelGGL((gn_small_kernel<1, 6, 256>), dim3(1, c->batch), dim3(256), lds, c->stream, A);
   else hipLaunchKernelGGL((gn_small_kernel<5, 9, 256>), dim3(1, c->batch), dim3(256), lds, c->stream, A);
   HIP_OK(hipGetLastError());
-  c->fd_full = true; c->partials_ahead = false;
+  c->fd_full = !last; c->partials_ahead = false;
   c->terms_valid = false;   // (no single-record products: a later idto_hip_grad_hess assembles from the slab)
-  return TimeEnd(c);
+  return tr ? 0 : TimeEnd(c);
 }
 
 static int FactorSolve(idto_hip_ctx* c, const double* rhs, int nrhs, double* x, const RhsSource* src);
@@ -2433,6 +2439,7 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     c->alt_r = AltSel{c->tr_state, c->alt_off, 0};
     c->alt_w = AltSel{c->tr_state, c->alt_off, 1};
   }
+  const bool tr_small = c->tr_small && nu == 0 && lookahead && SmallEligible(c) && c->h_assembled;
   TrConvergence conv{};
   conv.on = c->tr_conv_on ? 1 : 0;
   conv.rel_cost = c->tr_conv_tol[0]; conv.abs_cost = c->tr_conv_tol[1]; conv.rel_grad = c->tr_conv_tol[2];
@@ -2553,6 +2560,14 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     Dc.nu = nu; Dc.N = c->N; Dc.slab_stride = c->slab_stride; Dc.tau_off = 3 * c->nv * c->nq;
     Dc.part2 = c->tr_part2; Dc.nblk = nblk;
     const bool more = k + 1 < passes;
+    if (tr_small) {
+      // a small all-revolute model: the trial point's evaluation, its cost, the decision and - accepted - g, H and the next
+      // step in ONE workgroup of ONE launch (gn_small.h), the bits of the three launches below
+      rc = LaunchSmall(c, &Dc, !more, c->alt_w);
+      if (rc) return rc;
+      if (!more) break;
+      continue;
+    }
     std::swap(c->q, c->q_trial);
     rc = LaunchFd(c, (lookahead && more) ? 1 : 0, 0, c->N, c->alt_w);
     if (!rc)
@@ -2929,6 +2944,7 @@ int idto_hip_get_option(idto_hip_ctx* c, const char* name, int* value) {
   if (std::strcmp(name, "asm_fold") == 0) { *value = c->asm_fold; return 0; }
   if (std::strcmp(name, "con_kkt") == 0) { *value = c->con_kkt; return 0; }
   if (std::strcmp(name, "kkt_fold") == 0) { *value = c->kkt_fold; return 0; }
+  if (std::strcmp(name, "tr_small") == 0) { *value = c->tr_small; return 0; }
   if (std::strcmp(name, "kkt_last_solver") == 0) { *value = c->kkt ? c->kkt->last_solver : 0; return 0; }
   if (std::strcmp(name, "last_assembly") == 0) { *value = c->last_assembly; return 0; }
   if (std::strcmp(name, "fused") == 0) { *value = c->fused; return 0; }
@@ -2963,6 +2979,7 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "asm_fold") == 0) { c->asm_fold = value != 0; c->terms_valid = false; return 0; }
   if (std::strcmp(name, "con_kkt") == 0) { c->con_kkt = value != 0; return 0; }
   if (std::strcmp(name, "kkt_fold") == 0) { c->kkt_fold = value != 0; return 0; }
+  if (std::strcmp(name, "tr_small") == 0) { c->tr_small = value != 0; return 0; }
   if (std::strcmp(name, "fused_debug") == 0) { c->fused_debug = value != 0; return 0; }
   if (std::strcmp(name, "asm_stop") == 0) { c->asm_stop = value; return 0; }  // profiling aid
   if (std::strcmp(name, "fd_stop") == 0) { c->fd_stop = value; return 0; }    // profiling aid

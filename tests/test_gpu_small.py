@@ -92,3 +92,32 @@ def test_what_the_kernel_does_not_serve_keeps_the_two_launches():
     dev.gn_step()
     assert dev.get_option("last_solver") != 7
     dev.close()
+
+
+@pytest.mark.parametrize("name,N,iters,method", [("acrobot", 40, 25, "double_sqrt"), ("spinner", 40, 15, "sqrt"), ("acrobot", 16, 12, None),
+                                                  ("spinner", 23, 10, "double_sqrt"), ("acrobot", 30, 25, "adaptive_double_sqrt")])
+def test_trust_region_iteration_in_one_workgroup(name, N, iters, method):
+    """inside idto_hip_tr_solve the small models' launch also takes the cost of the trial point and the decision (option
+    tr_small, the default): per iteration tr_iter_kernel + gn_small_kernel instead of fd_kernel, cost_kernel and the solver's
+    launch.  Every row of statistics (but the device clock), the iterate, tau, v, the step and the scale factors are the
+    bits of the loop with the three launches; the acrobot runs reject steps (the launch then stops behind the decision)."""
+    from idto_amd.problem import SCALING
+    cfg, model, prob, sp, q = setup(name, N, seed=3)
+    out = []
+    for small in (1, 0):
+        dev = hip.HipPath(model, prob, sp)
+        dev.set_option("tr_small", small)
+        dev.set_q(q)
+        dev.eval_tau()
+        rows, delta = dev.tr_solve(iters, SCALING[method] if method else -1, method is not None, False, 1e-1, 1e5)
+        assert dev.get_option("last_solver") == (7 if small else 6)
+        out.append((rows.copy(), delta) + tuple(dev.get(n) for n in ("q", "v", "tau", "step", "gradient", "H_C", "tr_dq", "tr_w", "tr_scale", "cost")))
+        dev.close()
+    a, b = out
+    cols = [c for c in range(a[0].shape[1]) if c != 10]   # (column 10 is the device clock)
+    assert np.array_equal(a[0][:, cols], b[0][:, cols]) and a[1] == b[1]
+    assert a[0][:, 9].any()
+    if name == "acrobot" and iters >= 25:
+        assert not a[0][:, 9].all(), "no step was rejected: the early exit was not exercised"
+    for x, y in zip(a[2:], b[2:]):
+        assert same(np.asarray(x), np.asarray(y))
