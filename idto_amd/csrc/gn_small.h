@@ -47,22 +47,29 @@ struct SmallArgs {
   TrDecideArgs T;
   int tau_only;        // the loop's last iteration: tau and the cost of the trial point, the decision; no partials, no step
   double* cost_out;
+  // ... with enforced equality constraints (template parameter WS = 3 (nq + nu) > W): the step is the banded KKT solve of
+  // kkt.h - kkt_build_kernel's bands formed in LDS from the bands, the records and tau this workgroup holds, `B` the KKT
+  // context's solver view (x = z, Dst), T.dofs the constrained degrees of freedom
+  int kkt_r0;          // first block row the KKT solver works on
+  size_t kstride;      // the KKT context's arena stride (bytes)
 };
 
 // doubles of dynamic LDS behind the band solver's carve-up (gn_small_kernel's own arrays, in its order)
-__host__ __device__ inline int gn_small_doubles(int N, int K, int fast_n) {
+__host__ __device__ inline int gn_small_doubles(int N, int K, int fast_n, int KK = 0) {
   const int E = 1 + 3 * K;
+  if (KK > K) return gn_small_doubles(N, K, fast_n) + 3 * (N + 1) * KK * KK + (N + 1) * KK;
   return 2 * (N + 1) * K + N * K + 3 * N * E + N * E * K + K * K + 3 * N * K * K + 5 * K + (K & 1) + fast_n + (fast_n & 1) +
          3 * (N + 1) * K * K + 3 * (N + 1) * K + 2 * K * K + (K * K & 1) + K + 2 +
          5 * K + (K & 1) + (3 * N + 2) * (K + 1) + 2 * (N + 1) + 2 + 24;   // (the trust-region loop's cost and decision)
 }
 
-template <int SHAPE, int W, int NT>
+template <int SHAPE, int W, int NT, int WS = W>
 __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
   extern __shared__ double lds[];
   using FS = FastShape<SHAPE>;
   static_assert(FS::NP == 1 && FS::CJ < 0, "one path, no common body");
   constexpr int K = W / 3;                      // nq = nv
+  constexpr int KK = WS / 3, NU = KK - K;       // the solver's block: nq (+ nu multiplier rows of the KKT system)
   const int tid = threadIdx.x, nt = blockDim.x;
   const size_t o = (size_t)blockIdx.y * S.pstride, w = o + (size_t)alt_offset(S.alt, o);
   const DevProblem P = at_problem(S.P, o);
@@ -111,7 +118,11 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
   double* ccols = cterms + 3 * N + 2;               // [(3 N + 2) K] ... their columns
   double* cp2 = ccols + (3 * N + 2) * K;            // [2 (N + 1) + 2] dq.dq, g~.D^-1 dq per block row (tr_iter_kernel), their sums
   double* cst = cp2 + 2 * (N + 1) + 2;              // [24] the nine inner products and the loop's state words, as the launch found them
-  int* colinfo = reinterpret_cast<int*>(cst + 24);  // [K] non-zero rows of N+ column c, [K] non-zero columns of row r
+  double* kA = cst + 24;                            // (NU > 0) [(N + 1) KK KK] x 3: the KKT bands, [(N + 1) KK] its right-hand side
+  double* kB = kA + (NU > 0 ? (N + 1) * KK * KK : 0);
+  double* kC = kB + (NU > 0 ? (N + 1) * KK * KK : 0);
+  double* kr = kC + (NU > 0 ? (N + 1) * KK * KK : 0);
+  int* colinfo = reinterpret_cast<int*>(kr + (NU > 0 ? (N + 1) * KK : 0));   // [K] non-zero rows of N+ column c, [K] non-zero columns of row r
   int* rowinfo = colinfo + K;
 
   auto stamp = [&](int i) { if (S.ts && tid == 0 && blockIdx.y == 0) S.ts[i] = (double)wall_clock64(); };
@@ -135,7 +146,7 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
   for (int i = tid; i < (N + 1) * K; i += nt) qs[i] = q[i];
   for (int i = tid; i < bsz; i += nt) { Nid[i] = M.nplus_const[i]; wQf[i] = P.Qq[i]; wFQf[i] = P.Qfq[i]; }
   for (int i = tid; i < (N + 1) * K; i += nt) { qn[i] = P.q_nom[i]; vn[i] = P.v_nom[i]; }
-  const BandLds BL = band_layout(S.B.n * K, W);
+  const BandLds BL = band_layout(S.B.n * KK, WS);
   band_pad(lds, BL, tid, nt);   // (the solver's copies: their padding now, behind this phase's barrier)
   if (tid < K) {
     wR[tid] = P.R[tid * nv + tid]; wQV[tid] = P.Qv[tid * nv + tid]; wQFV[tid] = P.Qfv[tid * nv + tid];
@@ -443,13 +454,47 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
   stamp(5);
   PipeAsm F{};
   BandArgs B = S.B;   // the solver stages from the LDS copies (generic pointers into LDS: no problem offset), writes to memory
-  B.x = at_problem(B.x, o); B.Dst = at_problem(B.Dst, o);
   B.pstride = 0;
   B.ts = (S.ts && blockIdx.y == 0) ? S.ts + 8 : nullptr;   // (the solver's own stamps behind this kernel's)
-  B.HA = hA + qq; B.HB = hB + qq; B.HC = hC + qq; B.b = hg + K;   // (from block row 1 on: row 0 is the identity)
+  const double* sbase = hA;   // what the staging table's sources are relative to
+  if constexpr (NU > 0) {
+    // the KKT system of kkt.h (kkt_build_kernel's entries: M_{t,t-2}, M_{t,t-1}, M_{t,t} with the rows of J out of the
+    // records of step t - 1, right-hand side [g_t ; h_{t-1}]) from what this workgroup holds
+    constexpr int kk2 = KK * KK;
+    for (int idx = tid; idx < (N + 1) * 3 * kk2; idx += nt) {
+      const int t = idx / (3 * kk2), rem = idx - t * 3 * kk2, band = rem / kk2, e = rem - band * kk2, c = e / KK, r = e - c * KK;
+      const int sc = t - 2 + band;   // block column
+      double v = 0.0;
+      if (sc >= 0) {
+        if (r < K && c < K) {
+          v = (band == 0 ? hA : band == 1 ? hB : hC)[t * qq + c * K + r];
+        } else if (r >= K && c < K) {   // mu_t's row: J_{t-1, sc}[dof, c]
+          const bool zero = t < 1 || (band == 0 && t - 1 < 2) || (band == 1 && t - 1 < 1);
+          if (!zero) v = (band == 0 ? rM : band == 1 ? rT : rP)[(t - 1) * bsz + c * nv + T.dofs[r - K]];
+        } else if (r < K) {             // mu_sc's column: J_{sc-1, t}^T, the diagonal block's only
+          if (band == 2 && t >= 1) v = rP[(t - 1) * bsz + r * nv + T.dofs[c - K]];
+        } else if (t == 0 && band == 2 && r == c) {
+          v = 1.0;                      // the dummy mu_0
+        }
+      }
+      (band == 0 ? kA : band == 1 ? kB : kC)[t * kk2 + e] = v;
+    }
+    for (int idx = tid; idx < (N + 1) * KK; idx += nt) {
+      const int t = idx / KK, r = idx - t * KK;
+      kr[idx] = (r < K) ? hg[t * K + r] : (t >= 1 ? etau[(t - 1) * E * K + T.dofs[r - K]] : 0.0);   // h = tau_{t-1}[dof]
+    }
+    __syncthreads();
+    const size_t ok = (size_t)blockIdx.y * S.kstride;
+    B.x = at_problem(B.x, ok); B.Dst = at_problem(B.Dst, ok);
+    B.HA = kA + S.kkt_r0 * kk2; B.HB = kB + S.kkt_r0 * kk2; B.HC = kC + S.kkt_r0 * kk2; B.b = kr + S.kkt_r0 * KK;
+    sbase = kA;
+  } else {
+    B.x = at_problem(B.x, o); B.Dst = at_problem(B.Dst, o);
+    B.HA = hA + qq; B.HB = hB + qq; B.HC = hC + qq; B.b = hg + K;   // (from block row 1 on: row 0 is the identity)
+  }
   {   // the solver's two copies of the band, by the table (penta_band_body's staging loop, its index arithmetic done once on the host)
     auto put = [&](const BandStageItem& it) __attribute__((always_inline)) {
-      const double raw = hA[it.src >= 0 ? it.src : 0];
+      const double raw = sbase[it.src >= 0 ? it.src : 0];
       const double val = it.src >= 0 ? raw * (it.rhs ? B.rhs_sign : 1.0) : 0.0;
       if (it.dst >= 0) lds[it.dst] = val;
       if (it.dst0 >= 0) lds[it.dst0] = val;
@@ -459,7 +504,7 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
     for (int e = tid + NST * nt; e < S.nstage; e += nt) put(S.stage[e]);
   }
   __syncthreads();
-  penta_band_body<W, true, true>(B, F);
+  penta_band_body<WS, true, true>(B, F);
   stamp(6);
 }
 

@@ -1099,6 +1099,8 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
 #undef BAND_ATTR
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_small_kernel<1, 6, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_small_kernel<5, 9, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_small_kernel<1, 6, 256, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_small_kernel<5, 9, 256, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cost_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -1729,11 +1731,12 @@ static int LaunchFused(idto_hip_ctx* c) {
 // gn_small.h: fd + assembly + band solve of a small all-revolute model in ONE workgroup per problem.  What it stands in
 // for must be what the two launches would have run: forward differences from the straight-line evaluation, diagonal
 // weights, the whole horizon, the scalar band factorisation (BandEligible), nothing switched to a measurement mode.
+// (p: the plan of the system the launch solves - H's, or the KKT context's with blocks of nq + nu)
 static int SmallLds(const idto_hip_ctx* c, const LdlPlan& p, int* lds_small) {
   int band = band_layout(p.n * p.k, 3 * p.k).end;
   band += band & 1;
   if (lds_small) *lds_small = band;
-  return (band + gn_small_doubles(c->N, c->nq, c->M.fast_n)) * (int)sizeof(double);
+  return (band + gn_small_doubles(c->N, c->nq, c->M.fast_n, p.k)) * (int)sizeof(double);
 }
 static bool SmallEligible(const idto_hip_ctx* c) {
   if (!c->gn_small || !c->fd_fast || c->gradients_method != 0 || !c->weights_diagonal || c->reference_solver) return false;
@@ -1750,7 +1753,9 @@ static bool SmallEligible(const idto_hip_ctx* c) {
 }
 // tr: inside idto_hip_tr_solve - the launch evaluates the trial point c->q_trial into the output set `alt`, decides, and
 // goes on to g, H and the step only for an accepted step (gn_small.h SmallArgs::T); last: tau, cost and decision only
-static int LaunchSmall(idto_hip_ctx* c, const TrDecideArgs* tr = nullptr, bool last = false, AltSel alt = AltSel{nullptr, 0, 0}) {
+// kkt: with enforced constraints - the step is the banded KKT solve, z into c->kkt's step (gn_small.h SmallArgs::kkt_r0)
+static int LaunchSmall(idto_hip_ctx* c, const TrDecideArgs* tr = nullptr, bool last = false, AltSel alt = AltSel{nullptr, 0, 0},
+                       bool kkt = false) {
   DropPrefetch(c, {IDTO_ARR_V, IDTO_ARR_A, IDTO_ARR_NPLUS, IDTO_ARR_SLAB, IDTO_ARR_GRADIENT, IDTO_ARR_H_A, IDTO_ARR_H_B,
                    IDTO_ARR_H_C, IDTO_ARR_HBANDS, IDTO_ARR_STEP, IDTO_ARR_COST});
   c->con_ready = false; c->con_begun = false;
@@ -1759,8 +1764,10 @@ static int LaunchSmall(idto_hip_ctx* c, const TrDecideArgs* tr = nullptr, bool l
     c->h_assembled = true;
   }
   LdlPlan p;
-  if (int rc = PlanLdl(c, false, &p)) return rc;
+  idto_hip_ctx* sc = kkt ? c->kkt : c;   // whose system the launch solves
+  if (int rc = PlanLdl(sc, false, &p)) return rc;
   SmallArgs A;
+  A.kkt_r0 = p.r0; A.kstride = sc->pstride;
   A.M = c->M; A.cp = c->cp; A.P = c->P; A.q = c->q; A.slab = c->slab; A.slab_stride = c->slab_stride;
   A.v = c->v; A.a = c->a; A.nplus = c->nplus; A.g = c->g; A.HA = c->HA; A.HB = c->HB; A.HC = c->HC;
   A.pstride = c->pstride; A.alt = alt;
@@ -1768,31 +1775,33 @@ static int LaunchSmall(idto_hip_ctx* c, const TrDecideArgs* tr = nullptr, bool l
   if (tr) A.q = c->q_trial;
   BandArgs& B = A.B;
   B.n = p.n; B.k = p.k;
-  B.HA = c->HA + p.qq0; B.HB = c->HB + p.qq0; B.HC = c->HC + p.qq0;
-  B.b = c->g + (size_t)p.r0 * p.k; B.rhs_sign = -1.0; B.x = c->step + (size_t)p.r0 * p.k; B.Dst = c->Dst;
-  ++c->epoch;
-  if (++c->fact_id == 0) c->fact_id = 1;
-  B.status = c->status_dev; B.fact_id = c->fact_id; B.epoch = c->epoch; B.pstride = c->pstride;
-  B.npos = 0; B.ts = nullptr;
+  B.HA = sc->HA + p.qq0; B.HB = sc->HB + p.qq0; B.HC = sc->HC + p.qq0;
+  B.b = sc->g + (size_t)p.r0 * p.k; B.rhs_sign = -1.0; B.x = sc->step + (size_t)p.r0 * p.k; B.Dst = sc->Dst;
+  ++sc->epoch;
+  if (++sc->fact_id == 0) sc->fact_id = 1;
+  B.status = sc->status_dev; B.fact_id = sc->fact_id; B.epoch = sc->epoch; B.pstride = sc->pstride;
+  B.npos = sc->ldl_npos; B.ts = nullptr;
   A.ts = std::getenv("IDTO_SMALL_STAMPS") ? c->dbg : nullptr;
   const int lds = SmallLds(c, p, &A.lds_small);
-  if (c->small_stage_N != c->N) {   // (once per horizon)
-    const int qq = c->nq * c->nq, nb = c->N + 1;
+  if (sc->small_stage_N != c->N) {   // (once per horizon; the KKT system's table lives in its own context)
+    const int qq = p.k * p.k, nb = c->N + 1;
     std::vector<BandStageItem> tab((size_t)band_stage_table(p.n, p.k, 0, 0, 0, 0, nullptr));
-    band_stage_table(p.n, p.k, qq, nb * qq + qq, 2 * nb * qq + qq, 3 * nb * qq + c->nq, tab.data());
-    Release(c, &c->small_stage);
-    if (Alloc(c, tab.size(), &c->small_stage)) return -2;
-    HIP_OK(hipMemcpy(c->small_stage, tab.data(), tab.size() * sizeof(BandStageItem), hipMemcpyHostToDevice));
-    c->small_stage_n = (int)tab.size(); c->small_stage_N = c->N;
+    band_stage_table(p.n, p.k, p.r0 * qq, nb * qq + p.r0 * qq, 2 * nb * qq + p.r0 * qq, 3 * nb * qq + p.r0 * p.k, tab.data());
+    Release(sc, &sc->small_stage);
+    if (Alloc(sc, tab.size(), &sc->small_stage)) return -2;
+    HIP_OK(hipMemcpy(sc->small_stage, tab.data(), tab.size() * sizeof(BandStageItem), hipMemcpyHostToDevice));
+    sc->small_stage_n = (int)tab.size(); sc->small_stage_N = c->N;
   }
-  A.stage = c->small_stage; A.nstage = c->small_stage_n;
+  A.stage = sc->small_stage; A.nstage = sc->small_stage_n;
   c->last_solver = 7;
   c->last_step_kind = 2;
   c->last_assembly = 5;
   if (!tr && TimeBegin(c, 3)) return -2;
   // (256 threads, one wavefront per SIMD: the evaluation needs more than the 256 registers a lane has at two per SIMD -
   // 512 threads spilled 19 / 67 registers to scratch inside it and the step was slower than the two launches)
-  if (c->nq == 2) hipLaunchKernelGGL((gn_small_kernel<1, 6, 256>), dim3(1, c->batch), dim3(256), lds, c->stream, A);
+  if (kkt && c->nq == 2) hipLaunchKernelGGL((gn_small_kernel<1, 6, 256, 9>), dim3(1, c->batch), dim3(256), lds, c->stream, A);
+  else if (kkt) hipLaunchKernelGGL((gn_small_kernel<5, 9, 256, 12>), dim3(1, c->batch), dim3(256), lds, c->stream, A);
+  else if (c->nq == 2) hipLaunchKernelGGL((gn_small_kernel<1, 6, 256>), dim3(1, c->batch), dim3(256), lds, c->stream, A);
   else hipLaunchKernelGGL((gn_small_kernel<5, 9, 256>), dim3(1, c->batch), dim3(256), lds, c->stream, A);
   HIP_OK(hipGetLastError());
   c->fd_full = !last; c->partials_ahead = false;
@@ -2439,7 +2448,14 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     c->alt_r = AltSel{c->tr_state, c->alt_off, 0};
     c->alt_w = AltSel{c->tr_state, c->alt_off, 1};
   }
-  const bool tr_small = c->tr_small && nu == 0 && lookahead && SmallEligible(c) && c->h_assembled;
+  // (the small models' one-workgroup launch, gn_small.h: unconstrained, or with ONE enforced constraint through the banded
+  // KKT step - the instantiations: acrobot 2 + 1, spinner 3 + 1 - whose context the scalar band solver takes)
+  bool tr_small = c->tr_small && lookahead && SmallEligible(c) && c->h_assembled;
+  if (tr_small && nu > 0) {
+    LdlPlan kp;
+    tr_small = use_kkt && nu == 1 && c->kkt->batch == c->batch && PlanLdl(c->kkt, false, &kp) == 0 && BandEligible(c->kkt, kp, true) &&
+               kp.k == c->nq + 1 && SmallLds(c, kp, nullptr) <= 160 * 1024;
+  }
   TrConvergence conv{};
   conv.on = c->tr_conv_on ? 1 : 0;
   conv.rel_cost = c->tr_conv_tol[0]; conv.abs_cost = c->tr_conv_tol[1]; conv.rel_grad = c->tr_conv_tol[2];
@@ -2468,17 +2484,21 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     if (nu > 0 && use_kkt) {
       // multipliers of the iterate and H^-1 (g + J^T lambda) (TO.cc:1371-1396, :2139-2149) from ONE banded solve of the
       // KKT system (kkt.h): build its bands from H and the slab's rows of J, factorise + solve, take the result apart
+      // (tr_small: from the second iteration on the launch that evaluated, decided and assembled has solved it too)
       idto_hip_ctx* kc = c->kkt;
+      const bool solved = tr_small && k > 0;
       KktBuildArgs Kb;
       Kb.N = c->N; Kb.nq = c->nq; Kb.nv = c->nv; Kb.nu = nu;
       Kb.HA = c->HA; Kb.HB = c->HB; Kb.HC = c->HC; Kb.g = c->g;
       Kb.slab = c->slab; Kb.slab_stride = c->slab_stride; Kb.dofs = c->con_dofs;
       Kb.KA = kc->HA; Kb.KB = kc->HB; Kb.KC = kc->HC; Kb.rhs = kc->g; Kb.alt = c->alt_r;
       Kb.pstride = c->pstride; Kb.kstride = kc->pstride;
-      hipLaunchKernelGGL(kkt_build_kernel, dim3(c->N + 1, B), dim3(256), 0, c->stream, Kb);
-      HIP_OK(hipGetLastError());
-      rc = idto_hip_factor_solve(kc, nullptr, 1, nullptr);
-      if (rc) return rc;
+      if (!solved) {
+        hipLaunchKernelGGL(kkt_build_kernel, dim3(c->N + 1, B), dim3(256), 0, c->stream, Kb);
+        HIP_OK(hipGetLastError());
+        rc = idto_hip_factor_solve(kc, nullptr, 1, nullptr);
+        if (rc) return rc;
+      }
       // (taking z apart - w, J^T lambda, lambda, the multiplier pivots' range - is folded into tr_iter_kernel below; option
       // "kkt_fold" 0 keeps kkt_extract_kernel's launch: tests hold the two against each other)
       KktExtractArgs Ke;
@@ -2563,7 +2583,7 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     if (tr_small) {
       // a small all-revolute model: the trial point's evaluation, its cost, the decision and - accepted - g, H and the next
       // step in ONE workgroup of ONE launch (gn_small.h), the bits of the three launches below
-      rc = LaunchSmall(c, &Dc, !more, c->alt_w);
+      rc = LaunchSmall(c, &Dc, !more, c->alt_w, nu > 0);
       if (rc) return rc;
       if (!more) break;
       continue;

@@ -121,3 +121,28 @@ def test_trust_region_iteration_in_one_workgroup(name, N, iters, method):
         assert not a[0][:, 9].all(), "no step was rejected: the early exit was not exercised"
     for x, y in zip(a[2:], b[2:]):
         assert same(np.asarray(x), np.asarray(y))
+
+
+@pytest.mark.parametrize("name,N,iters", [("acrobot", 40, 25), ("spinner", 40, 15), ("acrobot", 23, 12), ("spinner", 30, 10)])
+def test_constrained_trust_region_iteration_in_one_workgroup(name, N, iters):
+    """... and with the example YAMLs' enforced constraint (one unactuated degree of freedom each): the launch forms the
+    banded KKT system of csrc/kkt.h in LDS and solves it instead of H p = -g.  Rows, iterate, multipliers, tau: the bits
+    of the loop that runs fd_kernel, cost_kernel, the assembly, kkt_build_kernel and the band solver as launches."""
+    from idto_amd.problem import SCALING
+    cfg, model, prob, sp, q = setup(name, N, seed=5)
+    assert len(model.unactuated_dofs) == 1
+    out = []
+    for small in (1, 0):
+        dev = hip.HipPath(model, prob, sp)
+        dev.set_option("tr_small", small)
+        dev.set_q(q)
+        dev.eval_tau()
+        rows, delta = dev.tr_solve(iters, SCALING["double_sqrt"], True, False, 1e-1, 1e5, constrained_dofs=model.unactuated_dofs)
+        out.append((rows.copy(), delta) + tuple(dev.get(n) for n in ("q", "v", "tau", "gradient", "H_C", "tr_dq", "tr_w", "tr_scale", "cost", "con_lambda")))
+        dev.close()
+    a, b = out
+    cols = [c for c in range(a[0].shape[1]) if c != 10]   # (column 10 is the device clock)
+    assert np.array_equal(a[0][:, cols], b[0][:, cols]) and a[1] == b[1]
+    assert a[0][:, 9].any() and (a[0][:, 14] == 0).all()
+    for x, y in zip(a[2:], b[2:]):
+        assert same(np.asarray(x), np.asarray(y))
