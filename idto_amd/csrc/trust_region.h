@@ -473,6 +473,98 @@ __device__ inline double tr_dogleg_quadratic(double a, double b, double c, bool*
   return s;
 }
 
+// The launch's extra workgroup (tr_iter_kernel: block nblk; gn_small.h's folded iteration: block 1).  Its three words go
+// behind the block rows' sums: slots TR_NSUM nblk, + 1, + 2 of part_ll.
+__device__ __forceinline__ void tr_status_reader(const TrIterArgs& T, int nblk, int K, int tid) {
+  // The launch's extra workgroup.  The solver's status words live in host-mapped memory: a read is a round trip over
+  // PCIe, 3.7 us - and every barrier of a workgroup stands behind the loads its wavefronts have in flight (the old last
+  // workgroup spent its "sums" phase there).  One thread reads them for the problem, at the launch's start, and hands
+  // them to the block rows' workgroups with their sums; it is back before the rows are.
+  if (tid == 0) {
+    unsigned fact_word = 0u, timeout_word = 0u;
+    if (T.fact_status && T.timeout_status == T.fact_status + 2) {   // (a single problem: the four words are adjacent, one read)
+      typedef unsigned u4 __attribute__((ext_vector_type(4)));
+      const u4 wds = *reinterpret_cast<const volatile u4*>(T.fact_status);
+      fact_word = wds[0]; timeout_word = wds[2];
+    } else {
+      if (T.fact_status) fact_word = __hip_atomic_load(T.fact_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (T.timeout_status) timeout_word = __hip_atomic_load(T.timeout_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    tr_ll_store(T.rows.part_ll + 2 * (TR_NSUM * nblk), (double)fact_word, T.rows.epoch);
+    tr_ll_store(T.rows.part_ll + 2 * (TR_NSUM * nblk + 1), (double)timeout_word, T.rows.epoch);
+  }
+  if (tid < 64) {
+    // (KKT step) the multiplier pivots - 1 / d is what the factorisation keeps -: negative, finite, and min |d| / max |d| >
+    // 1e-13; anything else = redundant constraints, the host's pivoted factorisation takes over (kkt_extract_kernel's
+    // criterion, constraint_lambda_kernel's on the pivots of S)
+    bool bad = false;
+    if (T.rows.kx.z) {
+      const int nu = T.rows.nu, N = T.rows.N;
+      double imn = __builtin_inf(), imx = 0.0;
+      bool finite = true;
+      for (int idx = tid; idx < N * nu; idx += 64) {
+        const int bt = 1 + idx / nu, j = idx - (bt - 1) * nu;
+        const double iv = -T.kdinv[(size_t)(bt - T.kfirst_row) * T.kdstride + K + j];
+        finite = finite && __builtin_isfinite(iv) && iv > 0.0;
+        imn = __builtin_fmin(imn, iv); imx = __builtin_fmax(imx, iv);
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        imn = __builtin_fmin(imn, __shfl_xor(imn, off)); imx = __builtin_fmax(imx, __shfl_xor(imx, off));
+      }
+      bad = __builtin_amdgcn_ballot_w64(!finite) != 0ull || !(imn > 1e-13 * imx);   // (|d|: max = 1 / imn, min = 1 / imx)
+    }
+    if (tid == 0) tr_ll_store(T.rows.part_ll + 2 * (TR_NSUM * nblk + 2), bad ? 1.0 : 0.0, T.rows.epoch);
+  }
+}
+
+// Thread 0 of a workgroup that holds the sums of all block rows S[TR_NSUM] and the loop's state words st[] as the launch
+// found them: the convergence criteria of the step the previous iteration accepted (TrConvergence: g.dq with the merit
+// function's gradient at THIS iterate and the dq that led here, S[9]), then - unless the pass only checks -
+// CalcDoglegPoint normalised by Delta: pU = cU g~ (TO.cc:2157), pH = -w / Delta (:2139-2149).  `write`: this workgroup
+// writes the state and the statistics; extra: TRF_* bits the caller found (factorisation, timeout, singular system).
+// ab = [a, b, flags]; st[] is brought up to date.
+__device__ inline void tr_conv_dogleg(const TrIterArgs& T, const double* S, double (&st)[TRS_COUNT], bool write, int extra, double* ab) {
+  if (T.conv.on) {
+    int flags = (int)st[TRS_FLAGS];
+    if (st[TRS_CHECK] != 0.0 && (flags & ~TRF_CONVERGED) == 0) {
+      const double gdq = S[9];
+      const double cost = st[TRS_COST], prev = st[TRS_PREVCOST];
+      int reason = 0;
+      if (__builtin_fabs(prev - cost) < T.conv.abs_cost + T.conv.rel_cost * cost) reason |= 1;
+      if (__builtin_fabs(gdq) < T.conv.abs_grad + T.conv.rel_grad * cost) reason |= 2;
+      if (st[TRS_DQN] < T.conv.abs_state + T.conv.rel_state * __builtin_sqrt(S[6])) reason |= 4;
+      const int k_prev = (int)st[TRS_ITER] - 1;
+      if (write && k_prev >= 0) T.conv.rows[(size_t)k_prev * TRR_COUNT + TRR_REASON] = (double)reason;
+      if (reason) st[TRS_FLAGS] = (double)(flags | TRF_CONVERGED);
+    }
+    st[TRS_CHECK] = 0.0;
+    if (write) { T.state[TRS_FLAGS] = st[TRS_FLAGS]; T.state[TRS_CHECK] = 0.0; }
+    if (T.conv.check_only) return;
+  }
+  const double gg = S[0], gHg = S[1], ww = S[2], gw = S[3];
+  const double Delta = st[TRS_DELTA];
+  int flags = (int)st[TRS_FLAGS] | extra;
+  const double cU = -(gg / gHg) / Delta;
+  const double pUn = __builtin_fabs(cU) * __builtin_sqrt(gg), pHn = __builtin_sqrt(ww) / Delta;
+  double a, b, active;
+  if (1.0 <= pUn) {          // :2160-2168
+    a = (Delta / pUn) * cU; b = 0.0; active = 1.0;
+  } else if (1.0 >= pHn) {   // :2171-2178
+    a = 0.0; b = -1.0; active = 0.0;
+  } else {                   // :2180-2199
+    const double pUpU = cU * cU * gg, pHpH = ww / (Delta * Delta), pUpH = -cU * gw / Delta;
+    bool ok = true;
+    const double sq = tr_dogleg_quadratic(pHpH - 2 * pUpH + pUpU, 2 * (pUpH - pUpU), pUpU - 1.0, &ok);
+    if (!ok) flags |= TRF_DOGLEG;
+    a = Delta * (1.0 - sq) * cU; b = -sq; active = 1.0;
+  }
+  if (!(__builtin_isfinite(a) && __builtin_isfinite(b))) flags |= TRF_NONFINITE;
+  st[TRS_A] = a; st[TRS_B] = b; st[TRS_ACTIVE] = active; st[TRS_FLAGS] = (double)flags;
+  if (write) { T.state[TRS_A] = a; T.state[TRS_B] = b; T.state[TRS_ACTIVE] = active; T.state[TRS_FLAGS] = (double)flags; }
+  ab[0] = a; ab[1] = b; ab[2] = (double)flags;
+}
+
 // One workgroup per block row (= time step), and every workgroup goes all the way:
 //   1. its rows of D, g~, w, H~ g~, H~ w and their ten sums (tr_prepare_rows), published with the launch's epoch in every
 //      word;
@@ -517,49 +609,7 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
   TR_STAMP_B0(0);
   const int tid = threadIdx.x, nt = blockDim.x, nblk = T.rows.nblk, K = T.rows.K, i = blockIdx.x;
   const bool first = blockIdx.x == 0;
-  if (i == nblk) {
-    // The launch's extra workgroup.  The solver's status words live in host-mapped memory: a read is a round trip over
-    // PCIe, 3.7 us - and every barrier of a workgroup stands behind the loads its wavefronts have in flight (the old last
-    // workgroup spent its "sums" phase there).  One thread reads them for the problem, at the launch's start, and hands
-    // them to the block rows' workgroups with their sums; it is back before the rows are.
-    if (tid == 0) {
-      unsigned fact_word = 0u, timeout_word = 0u;
-      if (T.fact_status && T.timeout_status == T.fact_status + 2) {   // (a single problem: the four words are adjacent, one read)
-        typedef unsigned u4 __attribute__((ext_vector_type(4)));
-        const u4 wds = *reinterpret_cast<const volatile u4*>(T.fact_status);
-        fact_word = wds[0]; timeout_word = wds[2];
-      } else {
-        if (T.fact_status) fact_word = __hip_atomic_load(T.fact_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (T.timeout_status) timeout_word = __hip_atomic_load(T.timeout_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-      tr_ll_store(T.rows.part_ll + 2 * (TR_NSUM * nblk), (double)fact_word, T.rows.epoch);
-      tr_ll_store(T.rows.part_ll + 2 * (TR_NSUM * nblk + 1), (double)timeout_word, T.rows.epoch);
-    }
-    if (tid < 64) {
-      // (KKT step) the multiplier pivots - 1 / d is what the factorisation keeps -: negative, finite, and min |d| / max |d| >
-      // 1e-13; anything else = redundant constraints, the host's pivoted factorisation takes over (kkt_extract_kernel's
-      // criterion, constraint_lambda_kernel's on the pivots of S)
-      bool bad = false;
-      if (T.rows.kx.z) {
-        const int nu = T.rows.nu, N = T.rows.N;
-        double imn = __builtin_inf(), imx = 0.0;
-        bool finite = true;
-        for (int idx = tid; idx < N * nu; idx += 64) {
-          const int bt = 1 + idx / nu, j = idx - (bt - 1) * nu;
-          const double iv = -T.kdinv[(size_t)(bt - T.kfirst_row) * T.kdstride + K + j];
-          finite = finite && __builtin_isfinite(iv) && iv > 0.0;
-          imn = __builtin_fmin(imn, iv); imx = __builtin_fmax(imx, iv);
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-          imn = __builtin_fmin(imn, __shfl_xor(imn, off)); imx = __builtin_fmax(imx, __shfl_xor(imx, off));
-        }
-        bad = __builtin_amdgcn_ballot_w64(!finite) != 0ull || !(imn > 1e-13 * imx);   // (|d|: max = 1 / imn, min = 1 / imx)
-      }
-      if (tid == 0) tr_ll_store(T.rows.part_ll + 2 * (TR_NSUM * nblk + 2), bad ? 1.0 : 0.0, T.rows.epoch);
-    }
-    return;
-  }
+  if (i == nblk) { tr_status_reader(T, nblk, K, tid); return; }
   // The loop's state words: nobody writes them before every workgroup has published its sums (workgroup 0, after its
   // poll below), and a wavefront's loads return in order - these are back before its first store of step 1.
   double st[TRS_COUNT];
@@ -644,53 +694,16 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
     T.rows.kx.lambda_out[(size_t)(i - 1) * T.rows.nu + tid] = T.rows.kx.z[(size_t)i * T.rows.kx.KK + K + tid];
   __syncthreads();
   TR_STAMP_B0(5);
-  // ---- the convergence criteria of the step the previous iteration accepted (TrConvergence): g.dq with the merit
-  // function's gradient at THIS iterate and the dq that led here (S[9])
-  if (T.conv.on) {
-    if (tid == 0) {
-      int flags = (int)st[TRS_FLAGS];
-      if (st[TRS_CHECK] != 0.0 && (flags & ~TRF_CONVERGED) == 0) {
-        const double gdq = S[9];
-        const double cost = st[TRS_COST], prev = st[TRS_PREVCOST];
-        int reason = 0;
-        if (__builtin_fabs(prev - cost) < T.conv.abs_cost + T.conv.rel_cost * cost) reason |= 1;
-        if (__builtin_fabs(gdq) < T.conv.abs_grad + T.conv.rel_grad * cost) reason |= 2;
-        if (st[TRS_DQN] < T.conv.abs_state + T.conv.rel_state * __builtin_sqrt(S[6])) reason |= 4;
-        const int k_prev = (int)st[TRS_ITER] - 1;
-        if (first && k_prev >= 0) T.conv.rows[(size_t)k_prev * TRR_COUNT + TRR_REASON] = (double)reason;
-        if (reason) st[TRS_FLAGS] = (double)(flags | TRF_CONVERGED);
-      }
-      if (first) { T.state[TRS_FLAGS] = st[TRS_FLAGS]; T.state[TRS_CHECK] = 0.0; }
-    }
-    if (T.conv.check_only) return;
-  }
-  TR_STAMP_B0(6);
-  // ---- CalcDoglegPoint normalised by Delta: pU = cU g~ (TO.cc:2157), pH = -w / Delta (:2139-2149)
+  // ---- the convergence criteria of the step the previous iteration accepted, then the dogleg (tr_conv_dogleg)
   if (tid == 0) {
-    const double gg = S[0], gHg = S[1], ww = S[2], gw = S[3];
-    const double Delta = st[TRS_DELTA];
-    int flags = (int)st[TRS_FLAGS];
-    if (T.fact_status && (unsigned)part[TR_NSUM * nblk] == T.fact_id) flags |= TRF_FACTORIZATION;
-    if ((T.timeout_status && (unsigned)part[TR_NSUM * nblk + 1] == T.fact_id) || timed_out) flags |= TRF_SOLVER_TIMEOUT;
-    if (singular) flags |= TRF_SINGULAR_S;
-    const double cU = -(gg / gHg) / Delta;
-    const double pUn = __builtin_fabs(cU) * __builtin_sqrt(gg), pHn = __builtin_sqrt(ww) / Delta;
-    double a, b, active;
-    if (1.0 <= pUn) {          // :2160-2168
-      a = (Delta / pUn) * cU; b = 0.0; active = 1.0;
-    } else if (1.0 >= pHn) {   // :2171-2178
-      a = 0.0; b = -1.0; active = 0.0;
-    } else {                   // :2180-2199
-      const double pUpU = cU * cU * gg, pHpH = ww / (Delta * Delta), pUpH = -cU * gw / Delta;
-      bool ok = true;
-      const double sq = tr_dogleg_quadratic(pHpH - 2 * pUpH + pUpU, 2 * (pUpH - pUpU), pUpU - 1.0, &ok);
-      if (!ok) flags |= TRF_DOGLEG;
-      a = Delta * (1.0 - sq) * cU; b = -sq; active = 1.0;
-    }
-    if (!(__builtin_isfinite(a) && __builtin_isfinite(b))) flags |= TRF_NONFINITE;
-    if (first) { T.state[TRS_A] = a; T.state[TRS_B] = b; T.state[TRS_ACTIVE] = active; T.state[TRS_FLAGS] = (double)flags; }
-    ab[0] = a; ab[1] = b; ab[2] = (double)flags;
+    int extra = 0;
+    if (T.fact_status && (unsigned)part[TR_NSUM * nblk] == T.fact_id) extra |= TRF_FACTORIZATION;
+    if ((T.timeout_status && (unsigned)part[TR_NSUM * nblk + 1] == T.fact_id) || timed_out) extra |= TRF_SOLVER_TIMEOUT;
+    if (singular) extra |= TRF_SINGULAR_S;
+    tr_conv_dogleg(T, S, st, first, extra, ab);
   }
+  if (T.conv.on && T.conv.check_only) return;
+  TR_STAMP_B0(6);
   __syncthreads();
   TR_STAMP_B0(7);
   // ---- 3. dq = D (a g~ + b w), q_trial = q + dq of this block row; the row's dq.dq and g~.(a g~ + b w), added in row
