@@ -52,7 +52,14 @@ struct SmallArgs {
   // context's solver view (x = z, Dst), T.dofs the constrained degrees of freedom
   int kkt_r0;          // first block row the KKT solver works on
   size_t kstride;      // the KKT context's arena stride (bytes)
+  // ... and tr_iter_kernel's part in front of it all (I.state set; grid.x = 2, block 1 is tr_status_reader): scale factors,
+  // g~, w, the band products, the ten sums per block row in tr_prepare_rows_body's order, the block rows in order, the
+  // convergence criteria and the dogleg (tr_conv_dogleg), dq and the trial point - which then never leaves the workgroup.
+  // The whole iteration is ONE launch.
+  TrIterArgs I;
 };
+// LDS of the folded iteration (doubles); it has to fit the band solver's carve-up (the host checks)
+__host__ __device__ constexpr int gn_small_fold_doubles(int N, int K) { return 26 * (N + 1) * K + 18 * (N + 1) + 32; }
 
 // doubles of dynamic LDS behind the band solver's carve-up (gn_small_kernel's own arrays, in its order)
 __host__ __device__ inline int gn_small_doubles(int N, int K, int fast_n, int KK = 0) {
@@ -72,6 +79,14 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
   constexpr int KK = WS / 3, NU = KK - K;       // the solver's block: nq (+ nu multiplier rows of the KKT system)
   const int tid = threadIdx.x, nt = blockDim.x;
   const size_t o = (size_t)blockIdx.y * S.pstride, w = o + (size_t)alt_offset(S.alt, o);
+  if (blockIdx.x == 1) {   // (folded iteration) the solver's status words over PCIe, the multiplier pivots' range
+    TrIterArgs I = S.I;
+    I.rows.part_ll = at_problem(I.rows.part_ll, o);
+    if (I.fact_status) I.fact_status += 2 * blockIdx.y;
+    if (I.rows.kx.z) I.kdinv = at_problem(I.kdinv, (size_t)blockIdx.y * I.kstride);
+    tr_status_reader(I, I.rows.nblk, K, tid);
+    return;
+  }
   const DevProblem P = at_problem(S.P, o);
   const double* q = at_problem(S.q, o);
   double* slab = at_problem(S.slab, w);
@@ -122,6 +137,8 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
   double* kB = kA + (NU > 0 ? (N + 1) * KK * KK : 0);
   double* kC = kB + (NU > 0 ? (N + 1) * KK * KK : 0);
   double* kr = kC + (NU > 0 ? (N + 1) * KK * KK : 0);
+  double* fz = lds;   // [gn_small_fold_doubles <= S.lds_small] the folded iteration's arrays: in the band solver's carve-up, which
+                      // is padded and filled long after them
   int* colinfo = reinterpret_cast<int*>(kr + (NU > 0 ? (N + 1) * KK : 0));   // [K] non-zero rows of N+ column c, [K] non-zero columns of row r
   int* rowinfo = colinfo + K;
 
@@ -135,15 +152,191 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
     T.rows += (size_t)blockIdx.y * T.rows_stride; T.part2 = at_problem(T.part2, o);
     if (T.lambda) T.lambda = at_problem(T.lambda, o);
     dS[9] = dS[10] = 0.0;
+    if (!S.I.state) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) dS[k] = (tid == 0) ? T.out[k] : 0.0;
+      for (int k = 0; k < 9; ++k) dS[k] = (tid == 0) ? T.out[k] : 0.0;
 #pragma unroll
-    for (int k = 0; k < TRS_COUNT; ++k) dst[k] = (tid == 0) ? T.state[k] : 0.0;
-    if (tid < 2 * T.nblk) p2v = T.part2[tid];
+      for (int k = 0; k < TRS_COUNT; ++k) dst[k] = (tid == 0) ? T.state[k] : 0.0;
+      if (tid < 2 * T.nblk) p2v = T.part2[tid];
+    }
+  }
+  const bool fold = S.I.state != nullptr;
+  bool fold_idle = false;
+  if (fold) {
+    // ---- T: tr_iter_kernel's part for the iterate (trust_region.h: tr_prepare_rows_body's expressions and orders, the
+    // block rows' sums in order, tr_conv_dogleg, the trial point) - every block row in this one workgroup
+    TrIterArgs I = S.I;
+    {
+      TrRowsArgs& A = I.rows;
+      A.HA = HA; A.HB = HB; A.HC = HC; A.g = g;
+      if (A.jtl) A.jtl = at_problem(A.jtl, o);
+      A.yin = at_problem(A.yin, o); A.q = at_problem(A.q, o); A.Dprev = at_problem(A.Dprev, o); A.D = at_problem(A.D, o);
+      A.gt = at_problem(A.gt, o); A.w = at_problem(A.w, o); A.part_ll = at_problem(A.part_ll, o);
+      if (A.lambda) A.lambda = at_problem(A.lambda, o);
+      if (A.freeze) A.freeze = at_problem(A.freeze, o);
+      A.slab = at_problem(A.slab, o + (size_t)alt_offset(I.alt, o));   // (the ITERATE's set)
+      I.out = at_problem(I.out, o); I.state = at_problem(I.state, o);
+      I.q_trial = at_problem(I.q_trial, o); I.dq = at_problem(I.dq, o);
+      I.conv.rows += (size_t)blockIdx.y * I.rows_stride;
+      if (A.kx.z) {
+        A.kx.z = at_problem(A.kx.z, (size_t)blockIdx.y * I.kstride);
+        A.kx.w_out = at_problem(A.kx.w_out, o); A.kx.jtl_out = at_problem(A.kx.jtl_out, o); A.kx.lambda_out = at_problem(A.kx.lambda_out, o);
+      }
+    }
+    const TrRowsArgs& A = I.rows;
+    const int nvar = (N + 1) * K, nblk = N + 1, nu = A.nu, method = A.scaling_method;
+    double* fD = fz;                  // [nvar] each: D, g~, w, D g~, y, g + J^T lambda, q of the iterate, dq_old
+    double* fgt = fD + nvar;
+    double* fw = fgt + nvar;
+    double* fxt = fw + nvar;
+    double* fy = fxt + nvar;
+    double* fgm = fy + nvar;
+    double* fq = fgm + nvar;
+    double* fdqo = fq + nvar;
+    double* fpt = fdqo + nvar;        // [5 nvar] x 2: the band blocks' partial products, (block row, band block, row)
+    double* fpy = fpt + 5 * nvar;
+    double* fsv = fpy + 5 * nvar;     // [nblk][8][K]: lanes r < K of a block row's sums 0 .. 6 and 9
+    double* fh = fsv + 8 * nvar;      // [nblk][4] x 2: h h and h lambda of the block row's constrained degrees of freedom (lanes)
+    double* fhl = fh + 4 * nblk;
+    double* fpart = fhl + 4 * nblk;   // [nblk][TR_NSUM]
+    double* fS = fpart + 10 * nblk;   // [TR_NSUM], then [a, b, flags], the reader's three words
+    double* fab = fS + TR_NSUM;
+    double* fwd = fab + 3;
+    double st[TRS_COUNT];
+#pragma unroll
+    for (int k = 0; k < TRS_COUNT; ++k) st[k] = (tid == 0) ? I.state[k] : 0.0;
+    const bool frozen = A.freeze && *A.freeze != 0.0;
+    for (int e = tid; e < 8 * nblk; e += nt) fh[e] = 0.0;   // (fh, fhl)
+    for (int v = tid; v < nvar; v += nt) {
+      const int t = v / K, r = v - t * K;
+      const double d = (method >= 0) ? scale_factor(method, HC[(size_t)t * qq + r * K + r], A.Dprev[v]) : 1.0;
+      double jt = 0.0, yv;
+      if (A.kx.z) {   // (kkt_extract_kernel's sums: ascending time step, then dof)
+        for (int sx = (t >= 1 ? t - 1 : 0); sx <= t + 1 && sx < N; ++sx)
+          for (int jj = 0; jj < nu; ++jj)
+            jt += tr_jac_entry(A.slab, A.slab_stride, K, A.kx.nv, sx, A.dofs[jj], N, v) * A.kx.z[(size_t)(sx + 1) * A.kx.KK + K + jj];
+        yv = -A.kx.z[(size_t)t * A.kx.KK + r];
+        A.kx.w_out[v] = yv; A.kx.jtl_out[v] = jt;
+      } else {
+        if (A.jtl) jt = A.jtl[v];
+        yv = A.yin[v];
+      }
+      const double gm = (A.jtl || A.kx.z) ? g[v] + jt : g[v];
+      const double gti = d * gm, yi = A.ysign * yv;
+      fD[v] = d; fgt[v] = gti; fw[v] = yi / d; fxt[v] = d * gti; fy[v] = yi; fgm[v] = gm;
+      fq[v] = A.q[v];
+      fdqo[v] = I.conv.on ? I.dq[v] : 0.0;
+    }
+    if (A.kx.z)
+      for (int e = tid; e < N * nu; e += nt) {   // lambda_{t-1}: the multiplier rows of z_t
+        const int t = 1 + e / nu, j = e - (t - 1) * nu;
+        A.kx.lambda_out[e] = A.kx.z[(size_t)t * A.kx.KK + K + j];
+      }
+    __syncthreads();
+    // band block j multiplies x_{i-2+j}: A_i, B_i, C_i, B_{i+1}^T, A_{i+2}^T (blocks column-major)
+    for (int e = tid; e < 5 * nvar; e += nt) {
+      const int i = e / (5 * K), rem = e - i * 5 * K, j = rem / K, r = rem - j * K, bi = i - 2 + j;
+      double at = 0.0, ay = 0.0;
+      if (bi >= 0 && bi < nblk) {
+        const double* Mb = (j == 0) ? HA + (size_t)i * qq : (j == 1) ? HB + (size_t)i * qq : (j == 2) ? HC + (size_t)i * qq
+                         : (j == 3) ? HB + (size_t)(i + 1) * qq : HA + (size_t)(i + 2) * qq;
+        const int sr = (j <= 2) ? 1 : K, sc = (j <= 2) ? K : 1;   // M(r, c) or M(c, r)
+        double m[K];
+#pragma unroll
+        for (int c = 0; c < K; ++c) m[c] = Mb[r * sr + c * sc];
+#pragma unroll
+        for (int c = 0; c < K; ++c) { at += m[c] * fxt[bi * K + c]; ay += m[c] * fy[bi * K + c]; }
+      }
+      fpt[e] = at; fpy[e] = ay;
+    }
+    __syncthreads();
+    for (int v = tid; v < nvar; v += nt) {   // lane r of block row i: s[0..6], s[9]
+      const int i = v / K, r = v - i * K;
+      const double* pt = fpt + i * 5 * K;
+      const double* py = fpy + i * 5 * K;
+      const double d = fD[v];
+      const double Hg = d * ((((pt[r] + pt[K + r]) + pt[2 * K + r]) + pt[3 * K + r]) + pt[4 * K + r]);
+      const double Hw = d * ((((py[r] + py[K + r]) + py[2 * K + r]) + py[3 * K + r]) + py[4 * K + r]);
+      const double gti = fgt[v], wi = fw[v], qi = fq[v];
+      double* sv = fsv + i * 8 * K + r;
+      sv[0] = gti * gti; sv[K] = gti * Hg; sv[2 * K] = wi * wi; sv[3 * K] = gti * wi; sv[4 * K] = gti * Hw; sv[5 * K] = wi * Hw;
+      sv[6 * K] = qi * qi; sv[7 * K] = fgm[v] * fdqo[v];
+    }
+    if (nu > 0)
+      for (int e = tid; e < N * nu; e += nt) {   // lane j of block row i < N: h = tau_i[unactuated] (TO.cc:1274-1278)
+        const int i = e / nu, j = e - i * nu;
+        const double h = A.slab[(size_t)i * A.slab_stride + A.tau_off + A.dofs[j]];
+        fh[4 * i + j] = h * h;
+        if (A.kx.z) fhl[4 * i + j] = h * A.kx.z[(size_t)(i + 1) * A.kx.KK + K + j];
+        else if (A.lambda) fhl[4 * i + j] = h * A.lambda[i * nu + j];
+      }
+    __syncthreads();
+    // a block row's sums: tr_prepare_rows_body's tree over the 32 lanes of which at most four hold anything but 0.0 -
+    // x_l + 0.0, then (x_0 + x_2) + (x_1 + x_3), then 0.0 + that (the levels above add 0.0 to a sum that is not -0.0)
+    for (int e = tid; e < 10 * nblk; e += nt) {
+      const int i = e / 10, k = e - i * 10;
+      const double* src = (k == 7) ? fh + 4 * i : (k == 8) ? fhl + 4 * i : fsv + (i * 8 + (k == 9 ? 7 : k)) * K;
+      const int lanes = (k == 7 || k == 8) ? 4 : K;
+      double x[4];
+#pragma unroll
+      for (int l = 0; l < 4; ++l) x[l] = (l < lanes ? src[l < lanes ? l : 0] : 0.0) + 0.0;
+      fpart[e] = 0.0 + ((x[0] + x[2]) + (x[1] + x[3]));
+    }
+    if (tid < 3) {   // the reader's words (it started with this workgroup)
+      double x = 0.0;
+      unsigned polls = 0;
+      while (!tr_ll_try(A.part_ll + 2 * (TR_NSUM * nblk + tid), A.epoch, x)) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++polls > (1u << 17)) { x = (tid == 1) ? (double)I.fact_id : 0.0; break; }   // (reported as a timeout)
+      }
+      fwd[tid] = x;
+    }
+    __syncthreads();
+    if (tid < TR_NSUM) {
+      double acc = 0.0;
+      for (int b = 0; b < nblk; ++b) acc += fpart[b * TR_NSUM + tid];
+      fS[tid] = acc;
+      if (tid < 9) I.out[tid] = acc;
+    }
+    __syncthreads();
+    const bool singular = fwd[2] != 0.0;
+    if (tid == 0) {
+      int extra = 0;
+      if (I.fact_status && (unsigned)fwd[0] == I.fact_id) extra |= TRF_FACTORIZATION;
+      if (I.timeout_status && (unsigned)fwd[1] == I.fact_id) extra |= TRF_SOLVER_TIMEOUT;
+      if (singular) extra |= TRF_SINGULAR_S;
+      tr_conv_dogleg(I, fS, st, true, extra, fab);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) cst[k] = fS[k];   // (what the decision below takes from tr_iter_kernel's launch)
+#pragma unroll
+      for (int k = 0; k < TRS_COUNT; ++k) cst[9 + k] = st[k];
+    }
+    __syncthreads();
+    const double a = fab[0], b = fab[1];
+    fold_idle = fab[2] != 0.0;
+    for (int v = tid; v < nvar; v += nt) {
+      const double dqs = a * fgt[v] + b * fw[v];
+      const double dq = I.scaling ? fD[v] * dqs : dqs;
+      if (!fold_idle) { I.dq[v] = dq; I.q_trial[v] = fq[v] + dq; }
+      qs[v] = fold_idle ? I.q_trial[v] : fq[v] + dq;   // (an idling loop keeps the trial point of its last decided iteration)
+      fpt[v] = dq * dq; fpy[v] = fgt[v] * dqs;
+      if (!frozen && !singular) {
+        A.D[v] = fD[v]; A.gt[v] = fgt[v]; A.w[v] = fw[v];
+        const_cast<double*>(A.Dprev)[v] = fD[v];
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < nblk; i += nt) {   // the row's dq.dq and g~.(a g~ + b w), in row order
+      double x0 = 0.0, x1 = 0.0;
+#pragma unroll
+      for (int r = 0; r < K; ++r) { x0 += fpt[i * K + r]; x1 += fpy[i * K + r]; }
+      cp2[2 * i] = x0; cp2[2 * i + 1] = x1;
+    }
   }
   // ---- A: every global load of the step (but the nominal trajectory, first used in E)
   for (int i = tid; i < M.fast_n; i += nt) mblob[i] = M.blob[M.fast_lo + i];
-  for (int i = tid; i < (N + 1) * K; i += nt) qs[i] = q[i];
+  if (!fold)
+    for (int i = tid; i < (N + 1) * K; i += nt) qs[i] = q[i];
   for (int i = tid; i < bsz; i += nt) { Nid[i] = M.nplus_const[i]; wQf[i] = P.Qq[i]; wFQf[i] = P.Qfq[i]; }
   for (int i = tid; i < (N + 1) * K; i += nt) { qn[i] = P.q_nom[i]; vn[i] = P.v_nom[i]; }
   const BandLds BL = band_layout(S.B.n * KK, WS);
@@ -158,7 +351,7 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
       cw0[3 * K + tid] = P.Qfq0[tid * nq + tid]; cw0[4 * K + tid] = P.Qfv0[tid * nv + tid];
     }
   }
-  if (T.state) {
+  if (T.state && !fold) {
     if (tid == 0) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) cst[k] = dS[k];

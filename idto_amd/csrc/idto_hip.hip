@@ -357,6 +357,7 @@ struct idto_hip_ctx {
   bool con_kkt = true;                     // option "con_kkt" (0: the Schur-complement chain of constraints.h)
   bool kkt_fold = true;                    // option "kkt_fold" (0: kkt_extract_kernel in a launch of its own in front of tr_iter_kernel)
   bool tr_small = true;                    // option "tr_small" (0: fd_kernel, cost_kernel and the solver's launch per iteration also for the small models)
+  bool tr_fold = true;                     // option "tr_fold" (0: tr_iter_kernel stays a launch of its own in front of the small models' launch)
   int ldl_npos = 0;                        // (a KKT context) the solver expects the pivots [ldl_npos, nq) of a block negative
 };
 enum { IDTO_SLAB_PAD = 64 };
@@ -1138,6 +1139,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   if (const char* e = getenv("IDTO_CON_KKT")) c->con_kkt = (e[0] == '1');
   if (const char* e = getenv("IDTO_KKT_FOLD")) c->kkt_fold = (e[0] == '1');
   if (const char* e = getenv("IDTO_TR_SMALL")) c->tr_small = (e[0] == '1');
+  if (const char* e = getenv("IDTO_TR_FOLD")) c->tr_fold = (e[0] == '1');
   if (const char* e = getenv("IDTO_SOLVER_BAND")) c->solver_band = std::atoi(e);   // (measurement aid: penta_band.h off / on / on for blocks of 5 too)
   (void)hipGetLastError();
   *out = c;
@@ -1754,8 +1756,9 @@ static bool SmallEligible(const idto_hip_ctx* c) {
 // tr: inside idto_hip_tr_solve - the launch evaluates the trial point c->q_trial into the output set `alt`, decides, and
 // goes on to g, H and the step only for an accepted step (gn_small.h SmallArgs::T); last: tau, cost and decision only
 // kkt: with enforced constraints - the step is the banded KKT solve, z into c->kkt's step (gn_small.h SmallArgs::kkt_r0)
+// iter: ... and tr_iter_kernel's part for the iterate in front (SmallArgs::I; a second workgroup reads the status words)
 static int LaunchSmall(idto_hip_ctx* c, const TrDecideArgs* tr = nullptr, bool last = false, AltSel alt = AltSel{nullptr, 0, 0},
-                       bool kkt = false) {
+                       bool kkt = false, const TrIterArgs* iter = nullptr) {
   DropPrefetch(c, {IDTO_ARR_V, IDTO_ARR_A, IDTO_ARR_NPLUS, IDTO_ARR_SLAB, IDTO_ARR_GRADIENT, IDTO_ARR_H_A, IDTO_ARR_H_B,
                    IDTO_ARR_H_C, IDTO_ARR_HBANDS, IDTO_ARR_STEP, IDTO_ARR_COST});
   c->con_ready = false; c->con_begun = false;
@@ -1772,6 +1775,8 @@ static int LaunchSmall(idto_hip_ctx* c, const TrDecideArgs* tr = nullptr, bool l
   A.v = c->v; A.a = c->a; A.nplus = c->nplus; A.g = c->g; A.HA = c->HA; A.HB = c->HB; A.HC = c->HC;
   A.pstride = c->pstride; A.alt = alt;
   A.T = tr ? *tr : TrDecideArgs{}; A.tau_only = last ? 1 : 0; A.cost_out = c->cost;
+  if (iter) A.I = *iter; else { A.I = TrIterArgs{}; A.I.state = nullptr; }
+  const unsigned gx = iter ? 2u : 1u;
   if (tr) A.q = c->q_trial;
   BandArgs& B = A.B;
   B.n = p.n; B.k = p.k;
@@ -1799,10 +1804,10 @@ static int LaunchSmall(idto_hip_ctx* c, const TrDecideArgs* tr = nullptr, bool l
   if (!tr && TimeBegin(c, 3)) return -2;
   // (256 threads, one wavefront per SIMD: the evaluation needs more than the 256 registers a lane has at two per SIMD -
   // 512 threads spilled 19 / 67 registers to scratch inside it and the step was slower than the two launches)
-  if (kkt && c->nq == 2) hipLaunchKernelGGL((gn_small_kernel<1, 6, 256, 9>), dim3(1, c->batch), dim3(256), lds, c->stream, A);
-  else if (kkt) hipLaunchKernelGGL((gn_small_kernel<5, 9, 256, 12>), dim3(1, c->batch), dim3(256), lds, c->stream, A);
-  else if (c->nq == 2) hipLaunchKernelGGL((gn_small_kernel<1, 6, 256>), dim3(1, c->batch), dim3(256), lds, c->stream, A);
-  else hipLaunchKernelGGL((gn_small_kernel<5, 9, 256>), dim3(1, c->batch), dim3(256), lds, c->stream, A);
+  if (kkt && c->nq == 2) hipLaunchKernelGGL((gn_small_kernel<1, 6, 256, 9>), dim3(gx, c->batch), dim3(256), lds, c->stream, A);
+  else if (kkt) hipLaunchKernelGGL((gn_small_kernel<5, 9, 256, 12>), dim3(gx, c->batch), dim3(256), lds, c->stream, A);
+  else if (c->nq == 2) hipLaunchKernelGGL((gn_small_kernel<1, 6, 256>), dim3(gx, c->batch), dim3(256), lds, c->stream, A);
+  else hipLaunchKernelGGL((gn_small_kernel<5, 9, 256>), dim3(gx, c->batch), dim3(256), lds, c->stream, A);
   HIP_OK(hipGetLastError());
   c->fd_full = !last; c->partials_ahead = false;
   c->terms_valid = false;   // (no single-record products: a later idto_hip_grad_hess assembles from the slab)
@@ -2456,6 +2461,12 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     tr_small = use_kkt && nu == 1 && c->kkt->batch == c->batch && PlanLdl(c->kkt, false, &kp) == 0 && BandEligible(c->kkt, kp, true) &&
                kp.k == c->nq + 1 && SmallLds(c, kp, nullptr) <= 160 * 1024;
   }
+  bool tr_fold_fits = false;
+  if (tr_small) {   // (the folded iteration's arrays live in the band solver's carve-up)
+    LdlPlan sp;
+    int band = 0;
+    if (PlanLdl(nu > 0 ? c->kkt : c, false, &sp) == 0) { (void)SmallLds(c, sp, &band); tr_fold_fits = gn_small_fold_doubles(c->N, c->nq) <= band; }
+  }
   TrConvergence conv{};
   conv.on = c->tr_conv_on ? 1 : 0;
   conv.rel_cost = c->tr_conv_tol[0]; conv.abs_cost = c->tr_conv_tol[1]; conv.rel_grad = c->tr_conv_tol[2];
@@ -2567,7 +2578,9 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
       T.rows.kx.w_out = kkt_ex.w; T.rows.kx.jtl_out = kkt_ex.jtl; T.rows.kx.lambda_out = kkt_ex.lambda;
       T.kdinv = kkt_ex.Dinv; T.kdstride = kkt_ex.dstride; T.kfirst_row = kkt_ex.first_row; T.kstride = kkt_ex.kstride;
     }
-    hipLaunchKernelGGL(tr_iter_kernel, dim3(nblk + 1, B), dim3(256), lds_iter, c->stream, T);
+    // (the small models' launch below takes this kernel's part too - option "tr_fold" -: the whole iteration is one launch)
+    const bool fold = tr_small && tr_fold_fits && c->tr_fold && k < iterations && T.nquat == 0 && T.rows.nu <= 4;
+    if (!fold) hipLaunchKernelGGL(tr_iter_kernel, dim3(nblk + 1, B), dim3(256), lds_iter, c->stream, T);
     HIP_OK(hipGetLastError());
     if (k == iterations) break;   // (the check-only pass)
     // tau (with its partials: the trial point is the next iterate unless rejected) and the cost at the
@@ -2583,7 +2596,7 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     if (tr_small) {
       // a small all-revolute model: the trial point's evaluation, its cost, the decision and - accepted - g, H and the next
       // step in ONE workgroup of ONE launch (gn_small.h), the bits of the three launches below
-      rc = LaunchSmall(c, &Dc, !more, c->alt_w, nu > 0);
+      rc = LaunchSmall(c, &Dc, !more, c->alt_w, nu > 0, fold ? &T : nullptr);
       if (rc) return rc;
       if (!more) break;
       continue;
@@ -2965,6 +2978,7 @@ int idto_hip_get_option(idto_hip_ctx* c, const char* name, int* value) {
   if (std::strcmp(name, "con_kkt") == 0) { *value = c->con_kkt; return 0; }
   if (std::strcmp(name, "kkt_fold") == 0) { *value = c->kkt_fold; return 0; }
   if (std::strcmp(name, "tr_small") == 0) { *value = c->tr_small; return 0; }
+  if (std::strcmp(name, "tr_fold") == 0) { *value = c->tr_fold; return 0; }
   if (std::strcmp(name, "kkt_last_solver") == 0) { *value = c->kkt ? c->kkt->last_solver : 0; return 0; }
   if (std::strcmp(name, "last_assembly") == 0) { *value = c->last_assembly; return 0; }
   if (std::strcmp(name, "fused") == 0) { *value = c->fused; return 0; }
@@ -3000,6 +3014,7 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "con_kkt") == 0) { c->con_kkt = value != 0; return 0; }
   if (std::strcmp(name, "kkt_fold") == 0) { c->kkt_fold = value != 0; return 0; }
   if (std::strcmp(name, "tr_small") == 0) { c->tr_small = value != 0; return 0; }
+  if (std::strcmp(name, "tr_fold") == 0) { c->tr_fold = value != 0; return 0; }
   if (std::strcmp(name, "fused_debug") == 0) { c->fused_debug = value != 0; return 0; }
   if (std::strcmp(name, "asm_stop") == 0) { c->asm_stop = value; return 0; }  // profiling aid
   if (std::strcmp(name, "fd_stop") == 0) { c->fd_stop = value; return 0; }    // profiling aid

@@ -104,23 +104,25 @@ def test_trust_region_iteration_in_one_workgroup(name, N, iters, method):
     from idto_amd.problem import SCALING
     cfg, model, prob, sp, q = setup(name, N, seed=3)
     out = []
-    for small in (1, 0):
+    for small, fold in ((1, 1), (1, 0), (0, 0)):   # (fold: tr_iter_kernel's part in the same launch - the iteration is ONE launch)
         dev = hip.HipPath(model, prob, sp)
         dev.set_option("tr_small", small)
+        dev.set_option("tr_fold", fold)
         dev.set_q(q)
         dev.eval_tau()
         rows, delta = dev.tr_solve(iters, SCALING[method] if method else -1, method is not None, False, 1e-1, 1e5)
         assert dev.get_option("last_solver") == (7 if small else 6)
         out.append((rows.copy(), delta) + tuple(dev.get(n) for n in ("q", "v", "tau", "step", "gradient", "H_C", "tr_dq", "tr_w", "tr_scale", "cost")))
         dev.close()
-    a, b = out
-    cols = [c for c in range(a[0].shape[1]) if c != 10]   # (column 10 is the device clock)
-    assert np.array_equal(a[0][:, cols], b[0][:, cols]) and a[1] == b[1]
-    assert a[0][:, 9].any()
-    if name == "acrobot" and iters >= 25:
-        assert not a[0][:, 9].all(), "no step was rejected: the early exit was not exercised"
-    for x, y in zip(a[2:], b[2:]):
-        assert same(np.asarray(x), np.asarray(y))
+    b = out[-1]
+    cols = [c for c in range(b[0].shape[1]) if c != 10]   # (column 10 is the device clock)
+    for a in out[:-1]:
+        assert np.array_equal(a[0][:, cols], b[0][:, cols]) and a[1] == b[1]
+        assert a[0][:, 9].any()
+        if name == "acrobot" and iters >= 25:
+            assert not a[0][:, 9].all(), "no step was rejected: the early exit was not exercised"
+        for x, y in zip(a[2:], b[2:]):
+            assert same(np.asarray(x), np.asarray(y))
 
 
 @pytest.mark.parametrize("name,N,iters", [("acrobot", 40, 25), ("spinner", 40, 15), ("acrobot", 23, 12), ("spinner", 30, 10)])
@@ -132,17 +134,19 @@ def test_constrained_trust_region_iteration_in_one_workgroup(name, N, iters):
     cfg, model, prob, sp, q = setup(name, N, seed=5)
     assert len(model.unactuated_dofs) == 1
     out = []
-    for small in (1, 0):
+    for small, fold in ((1, 1), (1, 0), (0, 0)):
         dev = hip.HipPath(model, prob, sp)
         dev.set_option("tr_small", small)
+        dev.set_option("tr_fold", fold)
         dev.set_q(q)
         dev.eval_tau()
         rows, delta = dev.tr_solve(iters, SCALING["double_sqrt"], True, False, 1e-1, 1e5, constrained_dofs=model.unactuated_dofs)
         out.append((rows.copy(), delta) + tuple(dev.get(n) for n in ("q", "v", "tau", "gradient", "H_C", "tr_dq", "tr_w", "tr_scale", "cost", "con_lambda")))
         dev.close()
-    a, b = out
-    cols = [c for c in range(a[0].shape[1]) if c != 10]   # (column 10 is the device clock)
-    assert np.array_equal(a[0][:, cols], b[0][:, cols]) and a[1] == b[1]
-    assert a[0][:, 9].any() and (a[0][:, 14] == 0).all()
-    for x, y in zip(a[2:], b[2:]):
-        assert same(np.asarray(x), np.asarray(y))
+    b = out[-1]
+    cols = [c for c in range(b[0].shape[1]) if c != 10]   # (column 10 is the device clock)
+    for a in out[:-1]:
+        assert np.array_equal(a[0][:, cols], b[0][:, cols]) and a[1] == b[1]
+        assert a[0][:, 9].any() and (a[0][:, 14] == 0).all()
+        for x, y in zip(a[2:], b[2:]):
+            assert same(np.asarray(x), np.asarray(y))

@@ -11,9 +11,10 @@ for name in sys.argv[1:] or ["acrobot", "spinner"]:
     cfg, model = load_config(name), load_model(name)
     prob, sp, q_guess = make_problem(cfg, model, num_steps=40)
     for con in (False, True):
-        for small in (1, 0):
+        for small, fold in ((1, 1), (1, 0), (0, 0)):
             dev = hip.HipPath(model, prob, sp)
             dev.set_option("tr_small", small)
+            dev.set_option("tr_fold", fold)
             ts = []
             for _ in range(6):
                 dev.set_q(np.asarray(q_guess).ravel())
@@ -22,6 +23,6 @@ for name in sys.argv[1:] or ["acrobot", "spinner"]:
                 rows, _ = dev.tr_solve(iters, SCALING["double_sqrt"], True, False, 1e-1, 1e5,
                                        constrained_dofs=model.unactuated_dofs if con else ())
                 ts.append(time.perf_counter() - t0)
-            print(f"{name} constraints {'enforced' if con else 'off'} tr_small={small}: {1e3 * np.median(ts[1:]) / iters:.4f} ms/iteration "
+            print(f"{name} constraints {'enforced' if con else 'off'} tr_small={small} tr_fold={fold}: {1e3 * np.median(ts[1:]) / iters:.4f} ms/iteration "
                   f"(accepted {int(rows[:, 9].sum())}/{iters}, solver {dev.get_option('last_solver')})")
             dev.close()
