@@ -70,7 +70,9 @@ __host__ __device__ inline int gn_small_doubles(int N, int K, int fast_n, int KK
          5 * K + (K & 1) + (3 * N + 2) * (K + 1) + 2 * (N + 1) + 2 + 24;   // (the trust-region loop's cost and decision)
 }
 
-template <int SHAPE, int W, int NT, int WS = W>
+// TR: the instantiation that serves the trust-region loop (T / I / tau_only are looked at); the plain step's has none of that
+// code - with it in, the plain step lost 1.2 us to the register allocation alone (acrobot 20.9 -> 22.2 us).
+template <int SHAPE, int W, int NT, int WS = W, bool TR = false>
 __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
   extern __shared__ double lds[];
   using FS = FastShape<SHAPE>;
@@ -79,7 +81,7 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
   constexpr int KK = WS / 3, NU = KK - K;       // the solver's block: nq (+ nu multiplier rows of the KKT system)
   const int tid = threadIdx.x, nt = blockDim.x;
   const size_t o = (size_t)blockIdx.y * S.pstride, w = o + (size_t)alt_offset(S.alt, o);
-  if (blockIdx.x == 1) {   // (folded iteration) the solver's status words over PCIe, the multiplier pivots' range
+  if (TR && blockIdx.x == 1) {   // (folded iteration) the solver's status words over PCIe, the multiplier pivots' range
     TrIterArgs I = S.I;
     I.rows.part_ll = at_problem(I.rows.part_ll, o);
     if (I.fact_status) I.fact_status += 2 * blockIdx.y;
@@ -145,8 +147,10 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
   auto stamp = [&](int i) { if (S.ts && tid == 0 && blockIdx.y == 0) S.ts[i] = (double)wall_clock64(); };
   stamp(0);
   TrDecideArgs T = S.T;
+  if (!TR) T.state = nullptr;
+  const int tau_only = TR ? S.tau_only : 0;
   double dS[11], dst[TRS_COUNT], p2v = 0.0;
-  if (T.state) {   // (what the decision needs and nothing in this launch writes: requested first - cost_kernel does the same -,
+  if (TR && T.state) {   // (what the decision needs and nothing in this launch writes: requested first - cost_kernel does the same -,
                    // parked in LDS behind phase A's loads: they would not survive the evaluation in registers)
     T.state = at_problem(T.state, o); T.out = at_problem(T.out, o); T.q = at_problem(T.q, o);
     T.rows += (size_t)blockIdx.y * T.rows_stride; T.part2 = at_problem(T.part2, o);
@@ -160,9 +164,9 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
       if (tid < 2 * T.nblk) p2v = T.part2[tid];
     }
   }
-  const bool fold = S.I.state != nullptr;
+  const bool fold = TR && S.I.state != nullptr;
   bool fold_idle = false;
-  if (fold) {
+  if constexpr (TR) if (fold) {
     // ---- T: tr_iter_kernel's part for the iterate (trust_region.h: tr_prepare_rows_body's expressions and orders, the
     // block rows' sums in order, tr_conv_dogleg, the trial point) - every block row in this one workgroup
     TrIterArgs I = S.I;
@@ -346,12 +350,12 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
     wQ[tid] = P.Qq[tid * nq + tid]; wFQ[tid] = P.Qfq[tid * nq + tid];
     colinfo[tid] = M.colinfo[tid];
     rowinfo[tid] = M.rowinfo[tid];
-    if (T.state) {
+    if (TR && T.state) {
       cw0[tid] = P.Qq0[tid * nq + tid]; cw0[K + tid] = P.Qv0[tid * nv + tid]; cw0[2 * K + tid] = P.R0[tid * nv + tid];
       cw0[3 * K + tid] = P.Qfq0[tid * nq + tid]; cw0[4 * K + tid] = P.Qfv0[tid * nv + tid];
     }
   }
-  if (T.state && !fold) {
+  if (TR && T.state && !fold) {
     if (tid == 0) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) cst[k] = dS[k];
@@ -412,7 +416,7 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
     FT.body = Ml.f_body; FT.cbody = Ml.f_cbody; FT.pairs = Ml.f_pairs; FT.seg = Ml.f_seg; FT.maxpp = Ml.f_maxpp;
     for (int idx = tid; idx < N * E; idx += nt) {
       const int k = idx / E, el = idx - k * E;
-      if (S.tau_only && el != 0) continue;
+      if (tau_only && el != 0) continue;
       InFwd in;
       in.q1 = qs + (k + 1) * K; in.v1 = vs + (k + 1) * K; in.a0 = as + k * K; in.N1 = Nid; in.N0 = Nid; in.nv = nv;
       in.kind = (el == 0) ? 0 : ((el < 1 + nP) ? 1 : ((el < 1 + nP + nT) ? 2 : 3));
@@ -431,7 +435,7 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
   // ---- D: the records (fd_body, mode 1)
   {
     const double sc = 1 / dt / dt;
-    for (int idx = tid; idx < (S.tau_only ? 0 : N * bsz); idx += nt) {
+    for (int idx = tid; idx < (tau_only ? 0 : N * bsz); idx += nt) {
       const int k = idx / bsz, rem = idx - k * bsz, i = rem / nv, r = rem - i * nv;
       const double* et = etau + k * E * K;
       const int ci = colinfo[i], j0 = ci & 0xffff, cnt = ci >> 16;
@@ -460,7 +464,7 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
 
   // ---- (trust-region loop) the cost of the trial point and the decision: cost_kernel's items, sums and order
   // (kernels.h; diagonal weights: e^T W e per term as sum_c ((0 + e_c w_c) e_c), the columns in order, the terms in order)
-  if (T.state) {
+  if constexpr (TR) if (T.state) {
     for (int idx = tid; idx < (N + 1) * K; idx += nt) {
       const int t = idx / K, c = idx - t * K;
       const bool run = t < N;
@@ -520,7 +524,7 @@ __global__ void __launch_bounds__(NT) gn_small_kernel(SmallArgs S) {
     const bool accepted = cterms[0] != 0.0;
     if (accepted)
       for (int idx = tid; idx < (N + 1) * K; idx += nt) T.q[idx] = qs[idx];
-    if (!accepted || S.tau_only) return;   // (a rejected step keeps g, H and the step of the iterate)
+    if (!accepted || tau_only) return;   // (a rejected step keeps g, H and the step of the iterate)
   }
 
   // ---- E: g and the bands (assemble_diag_body: same terms, same order).  A thread per (block row, r, c) forms C_i(r, c),

@@ -1100,8 +1100,10 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
 #undef BAND_ATTR
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_small_kernel<1, 6, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_small_kernel<5, 9, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_small_kernel<1, 6, 256, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_small_kernel<5, 9, 256, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_small_kernel<1, 6, 256, 6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_small_kernel<5, 9, 256, 9, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_small_kernel<1, 6, 256, 9, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_small_kernel<5, 9, 256, 12, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cost_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -1804,8 +1806,10 @@ static int LaunchSmall(idto_hip_ctx* c, const TrDecideArgs* tr = nullptr, bool l
   if (!tr && TimeBegin(c, 3)) return -2;
   // (256 threads, one wavefront per SIMD: the evaluation needs more than the 256 registers a lane has at two per SIMD -
   // 512 threads spilled 19 / 67 registers to scratch inside it and the step was slower than the two launches)
-  if (kkt && c->nq == 2) hipLaunchKernelGGL((gn_small_kernel<1, 6, 256, 9>), dim3(gx, c->batch), dim3(256), lds, c->stream, A);
-  else if (kkt) hipLaunchKernelGGL((gn_small_kernel<5, 9, 256, 12>), dim3(gx, c->batch), dim3(256), lds, c->stream, A);
+  if (kkt && c->nq == 2) hipLaunchKernelGGL((gn_small_kernel<1, 6, 256, 9, true>), dim3(gx, c->batch), dim3(256), lds, c->stream, A);
+  else if (kkt) hipLaunchKernelGGL((gn_small_kernel<5, 9, 256, 12, true>), dim3(gx, c->batch), dim3(256), lds, c->stream, A);
+  else if (tr && c->nq == 2) hipLaunchKernelGGL((gn_small_kernel<1, 6, 256, 6, true>), dim3(gx, c->batch), dim3(256), lds, c->stream, A);
+  else if (tr) hipLaunchKernelGGL((gn_small_kernel<5, 9, 256, 9, true>), dim3(gx, c->batch), dim3(256), lds, c->stream, A);
   else if (c->nq == 2) hipLaunchKernelGGL((gn_small_kernel<1, 6, 256>), dim3(gx, c->batch), dim3(256), lds, c->stream, A);
   else hipLaunchKernelGGL((gn_small_kernel<5, 9, 256>), dim3(gx, c->batch), dim3(256), lds, c->stream, A);
   HIP_OK(hipGetLastError());

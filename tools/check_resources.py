@@ -36,11 +36,14 @@ LIMITS = {
     "penta_band_kernel<15>": (0, 112, 70 + 24),
     # (round 6, second half: the kernel also carries the trust-region loop's cost and decision - 130 / 137 scalar registers
     # spilled to lanes; the plain step's time is what it was, profiles/r06_all_configs.txt)
-    # (... and tr_iter_kernel's part in front: the whole trust-region iteration of a small model is this one launch)
-    "gn_small_kernel<1, 6, 256, 6>": (0, 152, 175 + 24),
-    "gn_small_kernel<5, 9, 256, 9>": (0, 152, 175 + 24),
-    "gn_small_kernel<1, 6, 256, 9>": (0, 152, 220 + 24),     # (with the enforced constraint: the KKT system's blocks of nq + 1)
-    "gn_small_kernel<5, 9, 256, 12>": (0, 152, 228 + 24),
+    "gn_small_kernel<1, 6, 256, 6, false>": (0, 152, 52 + 24),
+    "gn_small_kernel<5, 9, 256, 9, false>": (0, 152, 56 + 24),
+    # (the trust-region loop's instantiations: cost and decision behind the records, tr_iter_kernel's part in front - a whole
+    # iteration of a small model in one launch -, with the enforced constraint the KKT system's blocks of nq + 1)
+    "gn_small_kernel<1, 6, 256, 6, true>": (0, 152, 175 + 24),
+    "gn_small_kernel<5, 9, 256, 9, true>": (0, 152, 175 + 24),
+    "gn_small_kernel<1, 6, 256, 9, true>": (0, 152, 220 + 24),
+    "gn_small_kernel<5, 9, 256, 12, true>": (0, 152, 228 + 24),
     "penta_nd_kernel<23, false>": (0, 0, 585 + 24),
     # ("a guard whose limit equals today's spill count guards nothing".  What it guards is the scratch column:
     # the six registers are spilled to ACCUMULATION registers - v_accvgpr_write / _read, no memory - which a kernel of one
