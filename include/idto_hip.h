@@ -355,6 +355,13 @@ int idto_hip_tr_solve_batch_constrained(idto_hip_ctx* ctx, int iterations, int s
  * batch context up to 2 -, the default, 2 = up to 5, batches included; IDTO_SOLVER_BAND overrides it at creation); "asm_in_solver" = 0 gives the assembly of
  * idto_hip_gn_step / of the trust-region loop a launch of its own instead of workgroups of the pipelined solver's
  * launch (default 1); a launch whose workgroups were not co-resident steps these down by itself (IDTO_HIP_SOLVER_TIMEOUT);
+ * "gn_small" = 0 keeps the small all-revolute models (acrobot, spinner) on fd_kernel + the band solver's launch instead of the
+ * one-workgroup step (csrc/gn_small.h; default 1); inside idto_hip_tr_solve: "tr_small" = 0 keeps fd_kernel, cost_kernel and
+ * the solver's launch per iteration for them, "tr_fold" = 0 keeps tr_iter_kernel a launch of its own in front of the
+ * one-workgroup launch (defaults 1: a whole trust-region iteration of a small model, its enforced constraint included, is
+ * ONE launch), "kkt_fold" = 0 takes the banded KKT step's solution apart in a launch of its own (kkt_extract_kernel) instead of
+ * inside tr_iter_kernel; all of these leave every result bit for bit as it is (tests/test_gpu_small.py,
+ * tests/test_gpu_trust_region.py);
  * "solver_debug" = 1 records per-phase cycle stamps (IDTO_ARR 15, tools/solver_phases.py);
  * "asm_stop" truncates the assembly kernel after a phase (tools/asm_phases.py). */
 int idto_hip_set_option(idto_hip_ctx* ctx, const char* name, int value);

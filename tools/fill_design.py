@@ -65,6 +65,7 @@ vals = {
     "R6_MPC": f"{mpc.group(1)} (p10 {mpc.group(2)}, p90 {mpc.group(3)})",
     "R6_TRITER_US": f"{avg_us(P('full_iteration_kernel_stats.csv'), 'tr_iter_kernel'):.1f}",
     "R6_COST_US": f"{avg_us(P('full_iteration_kernel_stats.csv'), 'cost_kernel'):.1f}",
+    "R6_SMALL_ITER": "; ".join(l.strip() for l in open(P("small_iteration_times.txt")) if "ms/iteration" in l).replace(" ms/iteration", " ms"),
     "R6_FULLITER_OTHERS": ", ".join(f"{k} {float(v):.3f}" for k, v in fi.items() if k != "mini_cheetah"),
 }
 src = os.path.join(ROOT, "tools", "design", "DESIGN.in.md")

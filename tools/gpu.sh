@@ -136,6 +136,7 @@ check)
     for m in mini_cheetah acrobot allegro_hand; do IDTO_HIP_LIB=build/variants/trstamps/libidto_hip.so timeout 200 python tools/tr_stamps.py $m 2>&1 | quiet; done | tee gpurun_out/${R}_tr_stamps.txt
   fi
   timeout 300 python tools/band_phases.py 2>&1 | quiet | tee gpurun_out/${R}_band_phases.txt
+  timeout 300 python tools/small_iter_time.py 2>&1 | quiet | tee gpurun_out/${R}_small_iteration_times.txt
   IDTO_SMALL_STAMPS=1 timeout 120 python tools/small_phases.py 2>&1 | quiet | grep "phases\|inside" | tee gpurun_out/${R}_small_phases.txt
   ROUND=$R timeout 900 bash tools/prof_band.sh > /dev/null 2>&1
   timeout 600 python -m pytest tests/test_gpu_neighbour.py -m "gpu or timing" -q -s 2>&1 | quiet | tail -8 | tee gpurun_out/${R}_solver_beside_neighbour.txt
