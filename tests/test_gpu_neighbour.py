@@ -83,3 +83,55 @@ def beside_a_neighbour(name, N):
           f"slowest {1e3 * worst:.3f} ms, no timeout")
     dev.close()
     return worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,N,iters", [("mini_cheetah", 40, 6), ("allegro_hand", 60, 3), ("hopper", 40, 8)])
+def test_trust_region_loop_beside_a_saturating_neighbour(name, N, iters):
+    """Since round 6 the workgroups of tr_iter_kernel wait for each other too (every block row's workgroup polls the sums
+    of all of them: N + 1 workgroups of 256 threads + the status reader).  The whole resident loop beside the neighbour:
+    the rows of statistics and the iterate are the unloaded device's bits, no wait runs out, nothing steps down."""
+    from idto_amd.problem import SCALING
+    cfg, model = load_config(name), load_model(name)
+    prob, sp, _ = make_problem(cfg, model, num_steps=N)
+    sp.equality_constraints = False
+    q = synthetic_trajectory(cfg, model, N, seed=0, lower=0.01)
+    dev = hip.HipPath(model, prob, sp)
+    main = torch.cuda.Stream()
+    dev.set_stream(main.cuda_stream)
+    dofs = model.unactuated_dofs if name == "hopper" else ()   # (hopper: with its enforced constraints, the banded KKT step)
+
+    def solve():
+        dev.set_q(q)
+        dev.eval_tau()
+        rows, delta = dev.tr_solve(iters, SCALING["double_sqrt"], True, False, 1e-1, 1e5, constrained_dofs=dofs)
+        return np.delete(rows, 10, axis=1), delta, dev.get("q")   # (column 10 is the device clock)
+
+    want = solve()
+    assert want[0][:, 9].any() and (want[0][:, 13] == 0).all()
+    side = torch.cuda.Stream()
+    x = torch.rand(32 * 1024 * 1024, device="cuda", dtype=torch.float64)
+    a = torch.rand(4096, 4096, device="cuda", dtype=torch.float32)
+    with torch.cuda.stream(side):
+        x = torch.sin(x) * 1.0001 + 0.5
+        a = (a @ a) * 1e-4
+    side.synchronize()
+    solves, rounds, busy_rounds = 0, 0, 0
+    t_end = time.perf_counter() + 60.0
+    while solves < 120 and time.perf_counter() < t_end:
+        with torch.cuda.stream(side):
+            for _ in range(12):
+                x = torch.sin(x) * 1.0001 + 0.5
+                a = (a @ a) * 1e-4
+        rounds += 1
+        for _ in range(6):
+            got = solve()
+            assert np.array_equal(got[0], want[0]) and got[1] == want[1] and np.array_equal(got[2], want[2])
+            solves += 1
+        busy_rounds += 0 if side.query() else 1
+    side.synchronize()
+    assert solves >= 40
+    assert 2 * busy_rounds >= rounds, f"the neighbour outlasted the solves in {busy_rounds} of {rounds} rounds only: not a test of sharing"
+    assert dev.get_option("solver_timeouts") == 0, "a wait between workgroups ran out beside the neighbour"
+    print(f"{name}: {solves} solves of {iters} iterations beside the neighbour ({busy_rounds} of {rounds} rounds busy at their end), no timeout")
+    dev.close()

@@ -59,6 +59,8 @@ stress)
     done
     for c in "allegro_hand 60 400" "mini_cheetah 40 400" "mini_cheetah 24 400"; do timeout 600 python tools/nd_stress.py $c 2>&1 | quiet | tail -2; done
     for c in "allegro_hand 60 60" "allegro_hand 40 60" "hopper 40 100"; do timeout 600 python tools/stress_kkt.py $c 2>&1 | quiet | tail -2; done
+    # (the resident trust-region loop: tr_iter_kernel's hand-over between its workgroups, the small models' one-launch iteration)
+    for c in "mini_cheetah 40 8 300" "allegro_hand 60 3 150" "hopper 40 10 300 c" "acrobot 40 20 300 c" "spinner 40 12 300" "allegro_hand 20 3 150 c"; do timeout 600 python tools/stress_tr.py $c 2>&1 | quiet | tail -1; done
   } | tee gpurun_out/${R}_solver_stress.txt
   ;;
 batch32)
