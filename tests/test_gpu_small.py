@@ -94,9 +94,10 @@ def test_what_the_kernel_does_not_serve_keeps_the_two_launches():
     dev.close()
 
 
+@pytest.mark.parametrize("conv", [False, True])
 @pytest.mark.parametrize("name,N,iters,method", [("acrobot", 40, 25, "double_sqrt"), ("spinner", 40, 15, "sqrt"), ("acrobot", 16, 12, None),
                                                   ("spinner", 23, 10, "double_sqrt"), ("acrobot", 30, 25, "adaptive_double_sqrt")])
-def test_trust_region_iteration_in_one_workgroup(name, N, iters, method):
+def test_trust_region_iteration_in_one_workgroup(name, N, iters, method, conv):
     """inside idto_hip_tr_solve the small models' launch also takes the cost of the trial point and the decision (option
     tr_small, the default): per iteration tr_iter_kernel + gn_small_kernel instead of fd_kernel, cost_kernel and the solver's
     launch.  Every row of statistics (but the device clock), the iterate, tau, v, the step and the scale factors are the
@@ -108,6 +109,8 @@ def test_trust_region_iteration_in_one_workgroup(name, N, iters, method):
         dev = hip.HipPath(model, prob, sp)
         dev.set_option("tr_small", small)
         dev.set_option("tr_fold", fold)
+        if conv:
+            dev.tr_set_convergence([0.0, 0.0, 0.0, 0.0, 0.0, 0.0])   # (criteria that never hold: the chunks of eight iterations, the check-only pass)
         dev.set_q(q)
         dev.eval_tau()
         rows, delta = dev.tr_solve(iters, SCALING[method] if method else -1, method is not None, False, 1e-1, 1e5)
@@ -125,8 +128,9 @@ def test_trust_region_iteration_in_one_workgroup(name, N, iters, method):
             assert same(np.asarray(x), np.asarray(y))
 
 
+@pytest.mark.parametrize("conv", [False, True])
 @pytest.mark.parametrize("name,N,iters", [("acrobot", 40, 25), ("spinner", 40, 15), ("acrobot", 23, 12), ("spinner", 30, 10)])
-def test_constrained_trust_region_iteration_in_one_workgroup(name, N, iters):
+def test_constrained_trust_region_iteration_in_one_workgroup(name, N, iters, conv):
     """... and with the example YAMLs' enforced constraint (one unactuated degree of freedom each): the launch forms the
     banded KKT system of csrc/kkt.h in LDS and solves it instead of H p = -g.  Rows, iterate, multipliers, tau: the bits
     of the loop that runs fd_kernel, cost_kernel, the assembly, kkt_build_kernel and the band solver as launches."""
@@ -138,6 +142,8 @@ def test_constrained_trust_region_iteration_in_one_workgroup(name, N, iters):
         dev = hip.HipPath(model, prob, sp)
         dev.set_option("tr_small", small)
         dev.set_option("tr_fold", fold)
+        if conv:
+            dev.tr_set_convergence([0.0, 0.0, 0.0, 0.0, 0.0, 0.0])   # (criteria that never hold: the chunks of eight iterations, the check-only pass)
         dev.set_q(q)
         dev.eval_tau()
         rows, delta = dev.tr_solve(iters, SCALING["double_sqrt"], True, False, 1e-1, 1e5, constrained_dofs=model.unactuated_dofs)
