@@ -20,6 +20,17 @@ def avg_us(path, kernel):
     raise SystemExit(f"{kernel} not in {path}")
 
 
+def small_iter_table():
+    """profiles/<round>_small_iteration_times.txt as a table: us per iteration by launch structure"""
+    t = {}
+    for m in re.finditer(r"(\w+) constraints (off|enforced) tr_small=(\d) tr_fold=(\d): ([\d.]+) ms", open(P("small_iteration_times.txt")).read()):
+        t.setdefault((m.group(1), m.group(2)), {})[(m.group(3), m.group(4))] = 1e3 * float(m.group(5))
+    rows = ["| µs per iteration (N = 40, scaling on) | ONE launch (`tr_fold`) | two: `tr_iter_kernel` + `gn_small_kernel` | the loop of 4 / 7 launches |", "|---|---|---|---|"]
+    for (name, con), v in t.items():
+        rows.append(f"| {name}, constraint {con} | **{v[('1', '1')]:.1f}** | {v[('1', '0')]:.1f} | {v[('0', '0')]:.1f} |")
+    return "\n" + "\n".join(rows) + "\n"
+
+
 b = json.load(open(P("bench.json")))
 lm = json.load(open(P("latency_model.json")))
 tr = json.load(open(P("pmc_traffic.json")))
@@ -65,7 +76,7 @@ vals = {
     "R6_MPC": f"{mpc.group(1)} (p10 {mpc.group(2)}, p90 {mpc.group(3)})",
     "R6_TRITER_US": f"{avg_us(P('full_iteration_kernel_stats.csv'), 'tr_iter_kernel'):.1f}",
     "R6_COST_US": f"{avg_us(P('full_iteration_kernel_stats.csv'), 'cost_kernel'):.1f}",
-    "R6_SMALL_ITER": "; ".join(l.strip() for l in open(P("small_iteration_times.txt")) if "ms/iteration" in l).replace(" ms/iteration", " ms"),
+    "R6_SMALL_ITER": small_iter_table(),
     "R6_FULLITER_OTHERS": ", ".join(f"{k} {float(v):.3f}" for k, v in fi.items() if k != "mini_cheetah"),
 }
 src = os.path.join(ROOT, "tools", "design", "DESIGN.in.md")
