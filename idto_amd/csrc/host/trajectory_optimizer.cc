@@ -1126,6 +1126,9 @@ bool TO::DeviceLoopEligible() const {
 // every iteration enqueued at once, decisions on the device, one wait (idto_hip_tr_solve)
 bool TO::ResidentLoopEligible() const {
   if (params_.max_iterations <= 0 || std::getenv("IDTO_OPT_STEPWISE")) return false;
+  int resident_ok = 1;   // (0 once the iteration kernel's workgroups timed out waiting for each other on this context)
+  Check(idto_hip_get_option(dev(), "tr_resident_ok", &resident_ok));
+  if (!resident_ok) return false;
   const int scal = params_.scaling ? static_cast<int>(params_.scaling_method) : -1;
   const bool adaptive = scal == static_cast<int>(kAdaptiveSqrt) || scal == static_cast<int>(kAdaptiveDoubleSqrt);
   if (!adaptive) return true;

@@ -358,6 +358,7 @@ struct idto_hip_ctx {
   bool kkt_fold = true;                    // option "kkt_fold" (0: kkt_extract_kernel in a launch of its own in front of tr_iter_kernel)
   bool tr_small = true;                    // option "tr_small" (0: fd_kernel, cost_kernel and the solver's launch per iteration also for the small models)
   bool tr_fold = true;                     // option "tr_fold" (0: tr_iter_kernel stays a launch of its own in front of the small models' launch)
+  bool tr_resident_ok = true;              // false once tr_iter_kernel's wait between its workgroups ran out (FactorStatus): idto_hip_tr_solve then refuses
   int ldl_npos = 0;                        // (a KKT context) the solver expects the pivots [ldl_npos, nq) of a block negative
 };
 enum { IDTO_SLAB_PAD = 64 };
@@ -855,7 +856,18 @@ int FactorStatus(idto_hip_ctx* c, int pb = -1) {
   // that has been handled does not step the context down once more)
   const unsigned timeouts_now = st[2 * c->batch + 1];
   if (timeouts_now != c->timeouts_handled) {
+    const bool iteration_kernel = ((timeouts_now ^ c->timeouts_handled) >> 16) != 0u;   // (trust_region.h tr_iter_kernel's own wait)
     c->timeouts_handled = timeouts_now;
+    if (iteration_kernel) {
+      // the workgroups of tr_iter_kernel did not find each other resident within their bound: the resident loop is off for
+      // the rest of the context's life (option "tr_resident_ok" reads 0), the caller's loop returns to the host twice an
+      // iteration - kernels without a wait between workgroups
+      c->tr_resident_ok = false;
+      ++c->solver_timeouts;
+      g_err = "the trust-region iteration's workgroups timed out waiting for each other (device shared with other kernels); "
+              "the resident loop is off for this context: repeat the call";
+      return IDTO_HIP_SOLVER_TIMEOUT;
+    }
     // A wait between the workgroups of a multi-workgroup solver ran out: its partners were not resident at the
     // same time (other contexts' kernels on the device).  The result of that launch is garbage.  Step down to a
     // variant with fewer co-resident workgroups for the rest of the context's life; the caller repeats the solve
@@ -1140,6 +1152,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   if (const char* e = getenv("IDTO_ASM_FOLD")) c->asm_fold = (e[0] == '1');
   if (const char* e = getenv("IDTO_CON_KKT")) c->con_kkt = (e[0] == '1');
   if (const char* e = getenv("IDTO_KKT_FOLD")) c->kkt_fold = (e[0] == '1');
+  if (const char* e = getenv("IDTO_DEBUG_SKIP_ROLE")) c->debug_skip_role = std::atoi(e);   // test aid (tests/test_gpu_timeout.py)
   if (const char* e = getenv("IDTO_TR_SMALL")) c->tr_small = (e[0] == '1');
   if (const char* e = getenv("IDTO_TR_FOLD")) c->tr_fold = (e[0] == '1');
   if (const char* e = getenv("IDTO_SOLVER_BAND")) c->solver_band = std::atoi(e);   // (measurement aid: penta_band.h off / on / on for blocks of 5 too)
@@ -2383,6 +2396,11 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
   const int B = c->batch;
   TRACE("hip: tr_solve begins");
   if (iterations <= 0) { g_err = "tr_solve: iterations must be positive"; return -1; }
+  if (!c->tr_resident_ok) {
+    g_err = "tr_solve: the iteration kernel's workgroups timed out on this context before (option tr_resident_ok): use "
+            "idto_hip_tr_prepare / trial / accept / reject";
+    return -1;
+  }
   if (nu < 0 || (nu > 0 && !constrained_dofs)) { g_err = "tr_solve: bad constraint arguments"; return -1; }
   const int neq = nu * c->N;
   if (nu > 0) {
@@ -2577,6 +2595,7 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     T.rows.freeze = c->tr_state + TRS_FLAGS;
     T.pstride = c->pstride; T.rows_stride = rows_stride;
     T.kdinv = nullptr; T.kdstride = 0; T.kfirst_row = 0; T.kstride = 0;
+    T.debug_skip_row = c->debug_skip_role >= 100 ? c->debug_skip_role - 100 : -1;
     if (kkt_fold) {
       T.rows.kx.z = kkt_ex.z; T.rows.kx.KK = c->nq + nu; T.rows.kx.nv = c->nv;
       T.rows.kx.w_out = kkt_ex.w; T.rows.kx.jtl_out = kkt_ex.jtl; T.rows.kx.lambda_out = kkt_ex.lambda;
@@ -2983,6 +3002,7 @@ int idto_hip_get_option(idto_hip_ctx* c, const char* name, int* value) {
   if (std::strcmp(name, "kkt_fold") == 0) { *value = c->kkt_fold; return 0; }
   if (std::strcmp(name, "tr_small") == 0) { *value = c->tr_small; return 0; }
   if (std::strcmp(name, "tr_fold") == 0) { *value = c->tr_fold; return 0; }
+  if (std::strcmp(name, "tr_resident_ok") == 0) { *value = c->tr_resident_ok; return 0; }
   if (std::strcmp(name, "kkt_last_solver") == 0) { *value = c->kkt ? c->kkt->last_solver : 0; return 0; }
   if (std::strcmp(name, "last_assembly") == 0) { *value = c->last_assembly; return 0; }
   if (std::strcmp(name, "fused") == 0) { *value = c->fused; return 0; }

@@ -455,6 +455,7 @@ struct TrIterArgs {
   // for the multiplier pivots' range (TRF_SINGULAR_S), and the KKT context's arena stride
   const double* kdinv; int kdstride, kfirst_row;
   size_t kstride;
+  int debug_skip_row;   // test aid (option "debug_skip_role" 100 + i): block row i's workgroup returns at once - a partner that is not resident
 };
 
 // (TO.cc:2204-2242 SolveDoglegQuadratic; *ok = false where the reference throws)
@@ -610,6 +611,7 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
   const int tid = threadIdx.x, nt = blockDim.x, nblk = T.rows.nblk, K = T.rows.K, i = blockIdx.x;
   const bool first = blockIdx.x == 0;
   if (i == nblk) { tr_status_reader(T, nblk, K, tid); return; }
+  if (i == T.debug_skip_row) return;
   // The loop's state words: nobody writes them before every workgroup has published its sums (workgroup 0, after its
   // poll below), and a wavefront's loads return in order - these are back before its first store of step 1.
   double st[TRS_COUNT];
@@ -651,8 +653,10 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
           if (t0 == 0) t0 = now;
           else if (now - t0 > 5000000) {
             if (T.timeout_status) {
+              // (the count's upper half: THIS kernel's wait, not a solver's - the host then leaves the solvers as they are and
+              // takes the loop that returns to it twice an iteration, which has no wait between workgroups: idto_hip.hip FactorStatus)
               __hip_atomic_store(T.timeout_status, T.fact_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-              __hip_atomic_fetch_add(T.timeout_status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              __hip_atomic_fetch_add(T.timeout_status + 1, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             fine = false;
             break;
