@@ -358,6 +358,7 @@ struct idto_hip_ctx {
   bool kkt_fold = true;                    // option "kkt_fold" (0: kkt_extract_kernel in a launch of its own in front of tr_iter_kernel)
   bool tr_small = true;                    // option "tr_small" (0: fd_kernel, cost_kernel and the solver's launch per iteration also for the small models)
   bool tr_fold = true;                     // option "tr_fold" (0: tr_iter_kernel stays a launch of its own in front of the small models' launch)
+  bool kkt_in_asm = true;                  // option "kkt_in_asm" (0: kkt_build_kernel stays a launch of its own behind the assembly)
   bool tr_resident_ok = true;              // false once tr_iter_kernel's wait between its workgroups ran out (FactorStatus): idto_hip_tr_solve then refuses
   int ldl_npos = 0;                        // (a KKT context) the solver expects the pivots [ldl_npos, nq) of a block negative
 };
@@ -1155,6 +1156,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   if (const char* e = getenv("IDTO_DEBUG_SKIP_ROLE")) c->debug_skip_role = std::atoi(e);   // test aid (tests/test_gpu_timeout.py)
   if (const char* e = getenv("IDTO_TR_SMALL")) c->tr_small = (e[0] == '1');
   if (const char* e = getenv("IDTO_TR_FOLD")) c->tr_fold = (e[0] == '1');
+  if (const char* e = getenv("IDTO_KKT_IN_ASM")) c->kkt_in_asm = (e[0] == '1');
   if (const char* e = getenv("IDTO_SOLVER_BAND")) c->solver_band = std::atoi(e);   // (measurement aid: penta_band.h off / on / on for blocks of 5 too)
   (void)hipGetLastError();
   *out = c;
@@ -1351,7 +1353,9 @@ int idto_hip_eval_partials(idto_hip_ctx* c) {
 }
 
 // g and the bands of H from the resident slab / products (gate: see assemble_terms_kernel)
-static int LaunchAssemble(idto_hip_ctx* c, const double* gate) {
+// sink: (the constrained loop) the banded KKT system's bands and right-hand side are written along (kernels.h KktSink) -
+// by the kernel that combines the records' products only; *sink_used says whether that was the one
+static int LaunchAssemble(idto_hip_ctx* c, const double* gate, const KktSink* sink = nullptr, size_t kstride = 0, bool* sink_used = nullptr) {
   if (!c->h_assembled) {  // x_0 = -g_0 = 0 is no longer written by the solver (SolverFirstRow)
     HIP_OK(hipMemset2DAsync(c->step, c->pstride, 0, (size_t)c->nq * sizeof(double), (size_t)c->batch, c->stream));
     c->h_assembled = true;
@@ -1359,9 +1363,11 @@ static int LaunchAssemble(idto_hip_ctx* c, const double* gate) {
   c->con_ready = false; c->con_begun = false;
   const bool combine = c->weights_diagonal && c->terms_valid && c->fd_full && c->asm_stop == 0;
   c->last_assembly = combine ? 1 : (c->weights_diagonal ? 2 : 3);
+  if (sink_used) *sink_used = combine && sink;
   if (combine) {
     hipLaunchKernelGGL(assemble_terms_kernel, dim3(c->N + 1, 4, c->batch), dim3(c->asm_terms_threads), c->asm_terms_lds, c->stream, c->M, c->P,
-                       c->q, c->terms, c->v, c->nplus, c->g, c->HA, c->HB, c->HC, c->pstride, gate, c->alt_r);
+                       c->q, c->terms, c->v, c->nplus, c->g, c->HA, c->HB, c->HC, c->pstride, gate, c->alt_r,
+                       sink ? *sink : KktSink{}, kstride);
   } else if (c->weights_diagonal) {
     hipLaunchKernelGGL(assemble_diag_kernel, dim3(c->N + 1, 4, c->batch), dim3(256), c->asm_diag_lds, c->stream, c->M,
                        c->P, c->q, c->slab, c->slab_stride, c->g, c->HA, c->HB, c->HC, c->asm_stop,
@@ -2483,6 +2489,7 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     tr_small = use_kkt && nu == 1 && c->kkt->batch == c->batch && PlanLdl(c->kkt, false, &kp) == 0 && BandEligible(c->kkt, kp, true) &&
                kp.k == c->nq + 1 && SmallLds(c, kp, nullptr) <= 160 * 1024;
   }
+  bool kkt_built = false;
   bool tr_fold_fits = false;
   if (tr_small) {   // (the folded iteration's arrays live in the band solver's carve-up)
     LdlPlan sp;
@@ -2520,6 +2527,8 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
       // (tr_small: from the second iteration on the launch that evaluated, decided and assembled has solved it too)
       idto_hip_ctx* kc = c->kkt;
       const bool solved = tr_small && k > 0;
+      const bool built = kkt_built;   // (the assembly of the previous iteration wrote the KKT system along: option "kkt_in_asm")
+      kkt_built = false;
       KktBuildArgs Kb;
       Kb.N = c->N; Kb.nq = c->nq; Kb.nv = c->nv; Kb.nu = nu;
       Kb.HA = c->HA; Kb.HB = c->HB; Kb.HC = c->HC; Kb.g = c->g;
@@ -2527,7 +2536,7 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
       Kb.KA = kc->HA; Kb.KB = kc->HB; Kb.KC = kc->HC; Kb.rhs = kc->g; Kb.alt = c->alt_r;
       Kb.pstride = c->pstride; Kb.kstride = kc->pstride;
       if (!solved) {
-        hipLaunchKernelGGL(kkt_build_kernel, dim3(c->N + 1, B), dim3(256), 0, c->stream, Kb);
+        if (!built) hipLaunchKernelGGL(kkt_build_kernel, dim3(c->N + 1, B), dim3(256), 0, c->stream, Kb);
         HIP_OK(hipGetLastError());
         rc = idto_hip_factor_solve(kc, nullptr, 1, nullptr);
         if (rc) return rc;
@@ -2649,7 +2658,17 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
         if (!rc) { g_err = "tr_solve: the solver that was to assemble g and H did not run"; rc = -1; }
       }
     } else if (lookahead) {
-      rc = LaunchAssemble(c, c->tr_state + TRS_ACCEPTED);
+      if (nu > 0 && use_kkt && c->kkt_in_asm) {
+        // (the next iteration's KKT system written by this assembly: a rejected step keeps g, H - and the system, which the
+        // solvers only read)
+        idto_hip_ctx* kc = c->kkt;
+        KktSink S{};
+        S.KA = kc->HA; S.KB = kc->HB; S.KC = kc->HC; S.rhs = kc->g; S.K = c->nq + nu; S.nu = nu;
+        S.slab = c->slab; S.slab_stride = (int)c->slab_stride; S.dofs = c->con_dofs;
+        rc = LaunchAssemble(c, c->tr_state + TRS_ACCEPTED, &S, kc->pstride, &kkt_built);
+      } else {
+        rc = LaunchAssemble(c, c->tr_state + TRS_ACCEPTED);
+      }
       if (!rc && nu == 0) rc = idto_hip_factor_solve(c, nullptr, 1, nullptr);   // (after a rejection: the same H, g -> the same step)
     } else {
       rc = idto_hip_gn_step(c);   // (dense cost weights: the partials again, at the iterate)
@@ -3002,6 +3021,7 @@ int idto_hip_get_option(idto_hip_ctx* c, const char* name, int* value) {
   if (std::strcmp(name, "kkt_fold") == 0) { *value = c->kkt_fold; return 0; }
   if (std::strcmp(name, "tr_small") == 0) { *value = c->tr_small; return 0; }
   if (std::strcmp(name, "tr_fold") == 0) { *value = c->tr_fold; return 0; }
+  if (std::strcmp(name, "kkt_in_asm") == 0) { *value = c->kkt_in_asm; return 0; }
   if (std::strcmp(name, "tr_resident_ok") == 0) { *value = c->tr_resident_ok; return 0; }
   if (std::strcmp(name, "kkt_last_solver") == 0) { *value = c->kkt ? c->kkt->last_solver : 0; return 0; }
   if (std::strcmp(name, "last_assembly") == 0) { *value = c->last_assembly; return 0; }
@@ -3039,6 +3059,7 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "kkt_fold") == 0) { c->kkt_fold = value != 0; return 0; }
   if (std::strcmp(name, "tr_small") == 0) { c->tr_small = value != 0; return 0; }
   if (std::strcmp(name, "tr_fold") == 0) { c->tr_fold = value != 0; return 0; }
+  if (std::strcmp(name, "kkt_in_asm") == 0) { c->kkt_in_asm = value != 0; return 0; }
   if (std::strcmp(name, "fused_debug") == 0) { c->fused_debug = value != 0; return 0; }
   if (std::strcmp(name, "asm_stop") == 0) { c->asm_stop = value; return 0; }  // profiling aid
   if (std::strcmp(name, "fd_stop") == 0) { c->fd_stop = value; return 0; }    // profiling aid

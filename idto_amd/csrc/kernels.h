@@ -693,13 +693,24 @@ IDTO_DEV void asm_put(double* p, double v) {
   else *p = v;
 }
 
+// The banded KKT system of the equality-constrained step (kkt.h: blocks of K = nq + nu, M_{t,t-2}, M_{t,t-1}, M_{t,t} and the
+// right-hand side [g_t ; h_{t-1}]) written by the assembly as it goes: every entry of g and H it produces goes into
+// the KKT bands too, part 3's workgroup adds the rows of J (the records of step t - 1), the dummy multiplier's identity
+// and h - kkt_build_kernel's entries, whose launch (5.7 us of hopper's iteration, 11 of allegro's) this saves.  KC == nullptr: off.
+struct KktSink {
+  double *KA, *KB, *KC, *rhs;
+  int K, nu;
+  const double* slab; int slab_stride;   // fd_kernel's records of the iterate the assembly runs for
+  const int* dofs;
+};
+
 // block row i, part `part` (all threads of the workgroup; `lds`: asm_terms_lds bytes)
 template <bool WT>
 __device__ __forceinline__ void assemble_terms_row(int nq, int nv, const DevProblem& P, const double* __restrict__ q,
                                                    const double* __restrict__ terms, const double* __restrict__ v_res,
                                                    const double* __restrict__ nplus_res, double* __restrict__ g,
                                                    double* __restrict__ HA, double* __restrict__ HB, double* __restrict__ HC,
-                                                   int i, int part, double* lds) {
+                                                   int i, int part, double* lds, const KktSink S = KktSink{}) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int N = P.N;
   const int bsz = nv * nq, qq = nq * nq;
@@ -708,14 +719,46 @@ __device__ __forceinline__ void assemble_terms_row(int nq, int nv, const DevProb
   double* Cg = HC + (size_t)i * qq;
   double* Bg = HB + (size_t)i * qq;
   double* Ag = HA + (size_t)i * qq;
+  const int KS = S.K, kks = KS * KS;
+  double* Ck = S.KC ? S.KC + (size_t)i * kks : nullptr;
+  double* Bk = S.KC ? S.KB + (size_t)i * kks : nullptr;
+  double* Ak = S.KC ? S.KA + (size_t)i * kks : nullptr;
+  if (S.KC && part == 3) {
+    // the entries of the KKT block row that are not H's (kkt_build_kernel's rules: the rows of J against block column
+    // sc = i - 2 + band come from record i - 1's block `band`, q_0 is no variable; the transposed entries are the diagonal
+    // block's only; mu_0 is a dummy with an identity block), and h = tau_{i-1}[dof]
+    const double* rec = (i >= 1) ? S.slab + (size_t)(i - 1) * S.slab_stride : S.slab;
+    for (int e = tid; e < 3 * kks; e += nt) {
+      const int band = e / kks, ee = e - band * kks, c = ee / KS, r = ee - c * KS, sc = i - 2 + band;
+      if (r < nq && c < nq) continue;   // (H's entries: the parts that form them write them)
+      double v = 0.0;
+      if (sc >= 0) {
+        if (r >= nq && c < nq) {
+          const bool zero = i < 1 || (band == 0 && i - 1 < 2) || (band == 1 && i - 1 < 1);
+          if (!zero) v = rec[(size_t)band * nv * nq + c * nv + S.dofs[r - nq]];
+        } else if (r < nq) {
+          if (band == 2 && i >= 1) v = rec[(size_t)2 * nv * nq + r * nv + S.dofs[c - nq]];
+        } else if (i == 0 && band == 2 && r == c) {
+          v = 1.0;
+        }
+      }
+      (band == 0 ? Ak : band == 1 ? Bk : Ck)[ee] = v;
+    }
+    for (int r = nq + tid; r < KS; r += nt)
+      S.rhs[(size_t)i * KS + r] = (i >= 1) ? S.slab[(size_t)(i - 1) * S.slab_stride + 3 * nv * nq + S.dofs[r - nq]] : 0.0;
+  }
   if (i == 0) {
     if (part == 0) {
       for (int idx = tid; idx < qq; idx += nt) {
         asm_put<WT>(Cg + idx, (idx / nq == idx % nq) ? 1.0 : 0.0);
         asm_put<WT>(Bg + idx, 0.0);
         asm_put<WT>(Ag + idx, 0.0);
+        if (Ck) {   // (kkt_build_kernel: block columns before the first do not exist - zeros)
+          const int c = idx / nq, r = idx - c * nq;
+          Ck[c * KS + r] = (c == r) ? 1.0 : 0.0; Bk[c * KS + r] = 0.0; Ak[c * KS + r] = 0.0;
+        }
       }
-      for (int j = tid; j < nq; j += nt) asm_put<WT>(g + j, 0.0);
+      for (int j = tid; j < nq; j += nt) { asm_put<WT>(g + j, 0.0); if (Ck) S.rhs[j] = 0.0; }
     }
     return;
   }
@@ -724,7 +767,11 @@ __device__ __forceinline__ void assemble_terms_row(int nq, int nv, const DevProb
   const double* T0 = terms + (size_t)(i < N ? i : 0) * ts;     // record i   (i < N)
   const double* Tp1 = terms + (size_t)(i < N - 1 ? i + 1 : 0) * ts;
   if (part == 3) {   // A_i (TO.cc:1150-1153): P_{i-1}^T R' M_{i-1}, nothing to add
-    for (int e = tid; e < qq; e += nt) asm_put<WT>(Ag + e, (i >= 3) ? Tm1[5 * qq + e] : 0.0);
+    for (int e = tid; e < qq; e += nt) {
+      const double out = (i >= 3) ? Tm1[5 * qq + e] : 0.0;
+      asm_put<WT>(Ag + e, out);
+      if (Ak) { const int c = e / nq; Ak[c * KS + e - c * nq] = out; }
+    }
     return;
   }
   // The product terms of the thread's FIRST item (its only one when the workgroup has a thread per item) are requested
@@ -821,6 +868,7 @@ __device__ __forceinline__ void assemble_terms_row(int nq, int nv, const DevProb
         }
         asm_put<WT>(Cg + e, out);
         asm_put<WT>(Cg + r * nq + c, out);
+        if (Ck) { Ck[c * KS + r] = out; Ck[r * KS + c] = out; }
       } else {   // gradient block (TO.cc:1046-1080)
         const int j = item - ntri;
         const double gP = first ? pre0 : Tm1[6 * qq + j];                              // P_{i-1}^T R' tau_{i-1}
@@ -850,6 +898,7 @@ __device__ __forceinline__ void assemble_terms_row(int nq, int nv, const DevProb
           gj = gj + gv;
         }
         asm_put<WT>(g + (size_t)i * nq + j, gj);
+        if (Ck) S.rhs[(size_t)i * KS + j] = gj;
       }
     }
   } else {
@@ -867,6 +916,7 @@ __device__ __forceinline__ void assemble_terms_row(int nq, int nv, const DevProb
         out = out + term(X_V, S_W, r, c);
       }
       asm_put<WT>(Bg + e, out);
+      if (Bk) Bk[c * KS + r] = out;
     }
   }
 }
@@ -875,16 +925,21 @@ __global__ void __launch_bounds__(512)
 assemble_terms_kernel(DevModel M, DevProblem P, const double* __restrict__ q, const double* __restrict__ terms,
                       const double* __restrict__ v_res, const double* __restrict__ nplus_res, double* __restrict__ g,
                       double* __restrict__ HA, double* __restrict__ HB, double* __restrict__ HC, size_t pstride,
-                      const double* __restrict__ gate, AltSel alt) {
-  if (gate && *at_problem(gate, (size_t)blockIdx.z * pstride) == 0.0) return;   // (idto_hip_tr_solve: this problem's step was rejected, its g and H stay)
+                      const double* __restrict__ gate, AltSel alt, KktSink S, size_t kstride) {
+  if (gate && *at_problem(gate, (size_t)blockIdx.z * pstride) == 0.0) return;   // (idto_hip_tr_solve: this problem's step was rejected, its g and H stay - and so does its KKT system)
   {
     const size_t o = (size_t)blockIdx.z * pstride, w = o + (size_t)alt_offset(alt, o);
     P = at_problem(P, o); q = at_problem(q, o); terms = at_problem(terms, w); v_res = at_problem(v_res, w);
     nplus_res = at_problem(nplus_res, w); g = at_problem(g, o);
     HA = at_problem(HA, o); HB = at_problem(HB, o); HC = at_problem(HC, o);
+    if (S.KC) {
+      const size_t ok = (size_t)blockIdx.z * kstride;
+      S.KA = at_problem(S.KA, ok); S.KB = at_problem(S.KB, ok); S.KC = at_problem(S.KC, ok); S.rhs = at_problem(S.rhs, ok);
+      S.slab = at_problem(S.slab, w);
+    }
   }
   extern __shared__ double lds[];
-  assemble_terms_row<false>(M.nq, M.nv, P, q, terms, v_res, nplus_res, g, HA, HB, HC, (int)blockIdx.x, (int)blockIdx.y, lds);
+  assemble_terms_row<false>(M.nq, M.nv, P, q, terms, v_res, nplus_res, g, HA, HB, HC, (int)blockIdx.x, (int)blockIdx.y, lds, S);
 }
 
 // ---------------------------------------------------------------------------

@@ -435,3 +435,25 @@ def test_alternating_kkt_and_schur_routes_do_not_allocate_again():
     S3, _ = dev.constraint_schur(dofs)
     assert np.array_equal(S3, first[1])
     dev.close()
+
+
+@pytest.mark.parametrize("name,N,iters", [("hopper", 40, 12), ("allegro_hand", 20, 4), ("acrobot", 40, 20), ("spinner", 30, 10), ("hopper", 50, 8)])
+def test_kkt_system_written_by_the_assembly(name, N, iters):
+    """the banded KKT system of the next iteration is written by the gated assembly as it goes (option kkt_in_asm, the
+    default; kernels.h KktSink) instead of by kkt_build_kernel in a launch of its own: every entry is a copy, so rows,
+    iterate and multipliers are the bits of the loop with that launch; the runs reject steps (the system then stays)."""
+    cfg, model, prob, sp, q = _setup(name, N)
+    out = []
+    for fused in (1, 0):
+        dev = hip.HipPath(model, prob, sp)
+        dev.set_option("kkt_in_asm", fused)
+        dev.set_option("tr_small", 0)   # (acrobot, spinner: the multi-launch loop this option lives in)
+        dev.set_q(q)
+        dev.eval_tau()
+        rows, delta = dev.tr_solve(iters, SCALING["double_sqrt"], True, False, 1e-1, 1e5, constrained_dofs=model.unactuated_dofs)
+        out.append((np.delete(rows, 10, axis=1), delta, dev.get("q"), dev.get("tau"), dev.get("con_lambda"), dev.get("tr_w")))
+        dev.close()
+    a, b = out
+    assert a[0][:, 9].any() and (a[0][:, 13] == 0).all()
+    for x, y in zip(a, b):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
