@@ -207,6 +207,7 @@ struct idto_hip_ctx {
   // state
   double *q = nullptr, *v = nullptr, *a = nullptr, *nplus = nullptr, *slab = nullptr;
   double *g = nullptr, *HA = nullptr, *HB = nullptr, *HC = nullptr, *step = nullptr, *cost = nullptr;
+  double *g2 = nullptr, *HA2 = nullptr, *HB2 = nullptr, *HC2 = nullptr;   // the trial point's g and H while a deciding launch runs (penta_pipe.h PipeAsm::g2)
   double *Kst = nullptr, *LUst = nullptr, *Yst = nullptr, *Zst = nullptr;
   int* pivst = nullptr;
   double *Ust = nullptr, *Hst = nullptr, *Est = nullptr, *Dst = nullptr;  // LDL^T factors (padded K x K blocks)
@@ -359,6 +360,9 @@ struct idto_hip_ctx {
   bool tr_small = true;                    // option "tr_small" (0: fd_kernel, cost_kernel and the solver's launch per iteration also for the small models)
   bool tr_fold = true;                     // option "tr_fold" (0: tr_iter_kernel stays a launch of its own in front of the small models' launch)
   bool kkt_in_asm = true;                  // option "kkt_in_asm" (0: kkt_build_kernel stays a launch of its own behind the assembly)
+  bool decide_in_solver = true;            // option "decide_in_solver" (0: cost_kernel stays a launch of its own in front of the pipelined solver's)
+  const TrDecideArgs* fuse_decide = nullptr;   // (during idto_hip_tr_solve's call of the solver) the decision the launch is to make
+  double* decide_word = nullptr; unsigned decide_epoch = 0;   // ... and the word it publishes it in (per problem, epoch in every word)
   bool tr_resident_ok = true;              // false once tr_iter_kernel's wait between its workgroups ran out (FactorStatus): idto_hip_tr_solve then refuses
   int ldl_npos = 0;                        // (a KKT context) the solver expects the pivots [ldl_npos, nq) of a block negative
 };
@@ -979,6 +983,8 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   // two extra zero blocks (five are reserved): the solver prefetches rows i+1, i+2 without bounds
   // checks (one allocation: the solver addresses all three bands from HA with 32-bit offsets)
   const size_t o_H = carve((size_t)3 * (N + 6) * qq, D);
+  // (a second g and H: the trial point's, formed by the solver's launch while it decides on the point - penta_pipe.h PipeAsm::g2)
+  const size_t o_H2 = carve((size_t)3 * (N + 6) * qq, D), o_g2 = carve((size_t)(N + 1) * nq, D);
   const size_t o_step = carve((size_t)(N + 1) * nq, D), o_cost = carve(1, D);
   const size_t o_K = carve((size_t)(N + 1) * qq, D), o_LU = carve((size_t)(N + 1) * qq, D);
   const size_t o_Y = carve((size_t)(N + 1) * qq, D), o_Z = carve((size_t)(N + 1) * qq, D);
@@ -999,7 +1005,8 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   const size_t nvars = (size_t)(N + 1) * nq;
   const size_t o_trD = carve(nvars, D), o_trg = carve(nvars, D), o_trw = carve(nvars, D), o_trdq = carve(nvars, D),
                o_qt = carve(nvars, D), o_trout = carve(16, D), o_trDp = carve(nvars, D), o_trpart = carve((size_t)9 * (N + 1), D),
-               o_trpll = carve((size_t)2 * (TR_NSUM * (N + 1) + 3), D), o_trp2 = carve((size_t)2 * (N + 1), D);
+               o_trpll = carve((size_t)2 * (TR_NSUM * (N + 1) + 3), D), o_trp2 = carve((size_t)2 * (N + 1), D),
+               o_decide = carve(4, D);
   const size_t o_trstate = carve(TRS_COUNT, D), o_trcnt = carve(1, sizeof(unsigned long long));
   // the equality-constraint step's outputs (per problem, so that the batched loop finds them at the arena stride):
   // [H^-1 (g + J^T lambda) | J^T lambda] and the multipliers (nu <= nv; + 2: the blocked dense LDL^T's [min, max | ...])
@@ -1023,6 +1030,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   c->HA = dp(o_H);
   c->HB = c->HA + (size_t)(N + 6) * qq;
   c->HC = c->HB + (size_t)(N + 6) * qq;
+  c->HA2 = dp(o_H2); c->HB2 = c->HA2 + (size_t)(N + 6) * qq; c->HC2 = c->HB2 + (size_t)(N + 6) * qq; c->g2 = dp(o_g2);
   c->step = dp(o_step); c->cost = dp(o_cost);
   c->Kst = dp(o_K); c->LUst = dp(o_LU); c->Yst = dp(o_Y); c->Zst = dp(o_Z);
   c->pivst = reinterpret_cast<int*>(c->arena + o_piv);
@@ -1038,7 +1046,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   c->nd_wst = nd_wst_on ? dp(o_ndwst) : nullptr;
   c->tr_D = dp(o_trD); c->tr_gt = dp(o_trg); c->tr_w = dp(o_trw); c->tr_dq = dp(o_trdq); c->q_trial = dp(o_qt);
   c->tr_out = dp(o_trout); c->tr_Dprev = dp(o_trDp); c->tr_part = dp(o_trpart);
-  c->tr_part_ll = dp(o_trpll); c->tr_part2 = dp(o_trp2);
+  c->tr_part_ll = dp(o_trpll); c->tr_part2 = dp(o_trp2); c->decide_word = dp(o_decide);
   c->terms = dp(o_terms);
   c->tr_state = dp(o_trstate);
   c->con_out = dp(o_conout); c->con_lambda = dp(o_conlam);
@@ -1135,6 +1143,8 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   ND_ATTR(2, false) ND_ATTR(3, false) ND_ATTR(5, false) ND_ATTR(19, false) ND_ATTR(23, false) ND_ATTR(29, false) ND_ATTR(8, false)
 #undef ND_ATTR
 #define PIPE_ATTR(KM) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_pipe_kernel<KM>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_pipe_kernel<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&penta_pipe_kernel<19, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
   PIPE_ATTR(2) PIPE_ATTR(3) PIPE_ATTR(5) PIPE_ATTR(19)
 #undef PIPE_ATTR
 #define FUSED_ATTR(MC, KM, PD, GW)                                                                 \
@@ -1157,6 +1167,7 @@ int idto_hip_create_batch(const idto_model_t* model, const idto_problem_t* probl
   if (const char* e = getenv("IDTO_TR_SMALL")) c->tr_small = (e[0] == '1');
   if (const char* e = getenv("IDTO_TR_FOLD")) c->tr_fold = (e[0] == '1');
   if (const char* e = getenv("IDTO_KKT_IN_ASM")) c->kkt_in_asm = (e[0] == '1');
+  if (const char* e = getenv("IDTO_DECIDE_IN_SOLVER")) c->decide_in_solver = (e[0] == '1');
   if (const char* e = getenv("IDTO_SOLVER_BAND")) c->solver_band = std::atoi(e);   // (measurement aid: penta_band.h off / on / on for blocks of 5 too)
   (void)hipGetLastError();
   *out = c;
@@ -1503,6 +1514,20 @@ static PipeAsm TakeAsm(idto_hip_ctx* c, const LdlPlan& p) {
   }
   return F;
 }
+// ... and (the pipelined chains' launch inside idto_hip_tr_solve) to decide on the trial point first
+static void TakeDecide(idto_hip_ctx* c, PipeAsm* F) {
+  if (!(F->on && c->fuse_decide)) return;
+  F->decide = 1;
+  F->dq = c->q_trial; F->dv = c->v; F->dslab = c->slab; F->dslab_stride = (int)c->slab_stride; F->dcost = c->cost;
+  F->ddiag = c->weights_diagonal ? 1 : 0;
+  F->dT = *c->fuse_decide; F->dalt = c->alt_w;
+  F->dword = c->decide_word;
+  F->g2 = c->g2; F->HA2 = c->HA2; F->HB2 = c->HB2; F->HC2 = c->HC2;
+  F->curpre = c->decide_word + 2;
+  if (++c->decide_epoch == 0u) c->decide_epoch = 1u;
+  F->depoch = c->decide_epoch;
+  c->fuse_decide = nullptr;
+}
 
 // The scalar band factorisation (penta_band.h): blocks up to 5 (half width 3 k - 1 <= 14: a lane per diagonal in a row
 // of 16), one workgroup per problem, single right-hand side.
@@ -1584,11 +1609,17 @@ static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double s
     A.epoch = c->epoch; A.status = c->status_dev; A.fact_id = c->fact_id; A.pstride = c->pstride;
     A.ts = c->solver_debug ? c->dbg : nullptr;
     // (idto_hip_gn_step: g and the bands are assembled by 4 (N + 1) more workgroups of this launch, penta_pipe.h PipeAsm)
-    const PipeAsm F = TakeAsm(c, p);
+    PipeAsm F = TakeAsm(c, p);
+    if (p.K == 5 || p.K == 19) TakeDecide(c, &F);
     if (F.on) plds = std::max(plds, c->asm_terms_lds);
+    if (F.decide) plds = std::max(plds, c->cost_lds);
     A.asm_ready = nullptr; A.asm_first = 0;
-    const dim3 pgrid(5 + (F.on ? 4 * (c->N + 1) : 0), c->batch);
+    const dim3 pgrid(5 + (F.on ? 4 * (c->N + 1) : 0) + (F.decide ? 1 : 0), c->batch);
 #define PIPE_LAUNCH(KM) hipLaunchKernelGGL((penta_pipe_kernel<KM>), pgrid, dim3(512), plds, c->stream, A, F)
+#define PIPE_LAUNCH_DEC(KM) hipLaunchKernelGGL((penta_pipe_kernel<KM, true>), pgrid, dim3(512), plds, c->stream, A, F)
+    if (F.decide) {
+      if (p.K == 5) PIPE_LAUNCH_DEC(5); else PIPE_LAUNCH_DEC(19);
+    } else
     switch (p.K) {
       case 2: PIPE_LAUNCH(2); break;
       case 3: PIPE_LAUNCH(3); break;
@@ -1596,6 +1627,7 @@ static int LaunchNd(idto_hip_ctx* c, const LdlPlan& p, const double* b, double s
       default: PIPE_LAUNCH(19); break;
     }
 #undef PIPE_LAUNCH
+#undef PIPE_LAUNCH_DEC
     HIP_OK(hipGetLastError());
     return 0;
   }
@@ -2394,6 +2426,7 @@ static int MakeKkt(idto_hip_ctx* c, int nu) {
 }
 
 static bool AsmInSolver(idto_hip_ctx* c);
+static bool DecideInSolver(idto_hip_ctx* c);
 // Delta0s / Delta_out: one radius per problem of the context; rows_host: [batch][iterations][TRR_COUNT]
 static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scaling, int normalize_quaternions,
                    const double* Delta0s, double Delta_max, double eta, const int* constrained_dofs, int nu,
@@ -2605,6 +2638,7 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     T.pstride = c->pstride; T.rows_stride = rows_stride;
     T.kdinv = nullptr; T.kdstride = 0; T.kfirst_row = 0; T.kstride = 0;
     T.debug_skip_row = c->debug_skip_role >= 100 ? c->debug_skip_role - 100 : -1;
+    T.curpre = c->decide_word + 2;
     if (kkt_fold) {
       T.rows.kx.z = kkt_ex.z; T.rows.kx.KK = c->nq + nu; T.rows.kx.nv = c->nv;
       T.rows.kx.w_out = kkt_ex.w; T.rows.kx.jtl_out = kkt_ex.jtl; T.rows.kx.lambda_out = kkt_ex.lambda;
@@ -2635,14 +2669,17 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
     }
     std::swap(c->q, c->q_trial);
     rc = LaunchFd(c, (lookahead && more) ? 1 : 0, 0, c->N, c->alt_w);
-    if (!rc)
+    c->fd_full = lookahead && more;   // (v, N+ of the trial point = of the iterate the gated assembly runs for)
+    // the cost of the trial point and the decision: a launch of their own (cost_kernel), or one more workgroup of the
+    // pipelined solver's launch that follows (penta_pipe.h PipeAsm::decide, option "decide_in_solver")
+    const bool decide_in_solver = !rc && more && lookahead && nu == 0 && c->decide_in_solver && AsmInSolver(c) && DecideInSolver(c);
+    if (!rc && !decide_in_solver)
       hipLaunchKernelGGL(cost_kernel, dim3(1, B), dim3(1024), c->cost_lds, c->stream, c->M, c->P, c->q, c->v, c->slab,
                          c->slab_stride, c->cost, c->weights_diagonal ? 1 : 0, (double*)nullptr, c->pstride,
                          (double*)nullptr, Dc, c->alt_w);
     std::swap(c->q, c->q_trial);
     if (rc) return rc;
     HIP_OK(hipGetLastError());
-    c->fd_full = lookahead && more;   // (v, N+ of the trial point = of the iterate the gated assembly runs for)
     if (!more) break;
     if (lookahead && nu == 0 && AsmInSolver(c)) {
       // the gated assembly inside the pipelined solver's launch (penta_pipe.h PipeAsm): a problem whose step was
@@ -2651,8 +2688,13 @@ static int TrSolve(idto_hip_ctx* c, int iterations, int scaling_method, int scal
       c->con_ready = false; c->con_begun = false;
       c->fuse_asm_next = true;
       c->fuse_gate = c->tr_state + TRS_ACCEPTED;
+      c->fuse_decide = decide_in_solver ? &Dc : nullptr;
       rc = idto_hip_factor_solve(c, nullptr, 1, nullptr);
       c->fuse_gate = nullptr;
+      if (c->fuse_decide) {
+        c->fuse_decide = nullptr;
+        if (!rc) { g_err = "tr_solve: the solver's launch that was to decide on the trial point did not run"; rc = -1; }
+      }
       if (c->fuse_asm_next) {
         c->fuse_asm_next = false;
         if (!rc) { g_err = "tr_solve: the solver that was to assemble g and H did not run"; rc = -1; }
@@ -3022,6 +3064,7 @@ int idto_hip_get_option(idto_hip_ctx* c, const char* name, int* value) {
   if (std::strcmp(name, "tr_small") == 0) { *value = c->tr_small; return 0; }
   if (std::strcmp(name, "tr_fold") == 0) { *value = c->tr_fold; return 0; }
   if (std::strcmp(name, "kkt_in_asm") == 0) { *value = c->kkt_in_asm; return 0; }
+  if (std::strcmp(name, "decide_in_solver") == 0) { *value = c->decide_in_solver; return 0; }
   if (std::strcmp(name, "tr_resident_ok") == 0) { *value = c->tr_resident_ok; return 0; }
   if (std::strcmp(name, "kkt_last_solver") == 0) { *value = c->kkt ? c->kkt->last_solver : 0; return 0; }
   if (std::strcmp(name, "last_assembly") == 0) { *value = c->last_assembly; return 0; }
@@ -3060,6 +3103,7 @@ int idto_hip_set_option(idto_hip_ctx* c, const char* name, int value) {
   if (std::strcmp(name, "tr_small") == 0) { c->tr_small = value != 0; return 0; }
   if (std::strcmp(name, "tr_fold") == 0) { c->tr_fold = value != 0; return 0; }
   if (std::strcmp(name, "kkt_in_asm") == 0) { c->kkt_in_asm = value != 0; return 0; }
+  if (std::strcmp(name, "decide_in_solver") == 0) { c->decide_in_solver = value != 0; return 0; }
   if (std::strcmp(name, "fused_debug") == 0) { c->fused_debug = value != 0; return 0; }
   if (std::strcmp(name, "asm_stop") == 0) { c->asm_stop = value; return 0; }  // profiling aid
   if (std::strcmp(name, "fd_stop") == 0) { c->fd_stop = value; return 0; }    // profiling aid
@@ -3082,6 +3126,18 @@ static bool AsmInSolver(idto_hip_ctx* c) {
   c->h_assembled = true;   // (the plan's first row depends on it)
   LdlPlan p;
   const bool ok = PlanLdl(c, false, &p) == 0 && (BandEligible(c, p) || (p.K <= 20 && NdEligible(c, p) && 5 * c->batch <= 64));
+  c->h_assembled = was;
+  return ok;
+}
+
+// (AsmInSolver holds) is the launch the pipelined chains' - the kernel that can also decide on the trial point - and one
+// of its DEC instantiations?
+static bool DecideInSolver(idto_hip_ctx* c) {
+  const bool was = c->h_assembled;
+  c->h_assembled = true;
+  LdlPlan p;
+  const bool ok = PlanLdl(c, false, &p) == 0 && !BandEligible(c, p) && NdEligible(c, p) && c->solver_pipe && (p.K == 5 || p.K == 19) &&
+                  c->cost_lds <= 160 * 1024;
   c->h_assembled = was;
   return ok;
 }

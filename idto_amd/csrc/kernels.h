@@ -14,22 +14,15 @@ namespace idto_dev {
 // ---------------------------------------------------------------------------
 // Cost L(q) from resident q, v, tau (TO.cc:147-176).  One block per problem; the final sum
 // is accumulated serially in the reference's order.
-__global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__ q, const double* __restrict__ v,
-                            const double* __restrict__ slab, int slab_stride, double* __restrict__ cost_out,
-                            int diag, double* __restrict__ pack, size_t pstride, double* __restrict__ cost_copy,
-                            TrDecideArgs T, AltSel alt) {
-  {
-    const size_t o = (size_t)blockIdx.y * pstride, w = o + (size_t)alt_offset(alt, o);
-    P = at_problem(P, o); q = at_problem(q, o); v = at_problem(v, w); slab = at_problem(slab, w);
-    cost_out = at_problem(cost_out, o);
-    if (pack) pack = at_problem(pack, o);
-    if (T.state) {   // (the trust-region decision of THIS problem: trust_region.h tr_decide)
-      T.state = at_problem(T.state, o); T.out = at_problem(T.out, o); T.q = at_problem(T.q, o);
-      T.q_trial = at_problem(T.q_trial, o); T.rows += (size_t)blockIdx.y * T.rows_stride;
-      T.part2 = at_problem(T.part2, o);
-      if (T.lambda) T.lambda = at_problem(T.lambda, o);
-    }
-  }
+// cost_body: the workgroup's work, every pointer the problem's already (cost_kernel below; one more workgroup of the
+// pipelined solver's launch inside the trust-region loop, penta_pipe.h PipeDecide).  Returns - with T.state set - whether
+// the step was accepted (the same value in every thread).
+// TU: time steps a thread takes per pass of the columns (32 x TU x blockDim.x / 1024 steps a pass: one pass = one round trip)
+template <int TU = 2>
+__device__ __forceinline__ bool cost_body(const int nq_, const int nv_, const DevProblem& P, const double* __restrict__ q,
+                                          const double* __restrict__ v, const double* __restrict__ slab, int slab_stride,
+                                          double* __restrict__ cost_out, int diag, double* __restrict__ pack,
+                                          double* __restrict__ cost_copy, const TrDecideArgs& T) {
   // e^T W e per term as the reference's Eigen expression evaluates it: tot = sum_c (sum_r e_r W[r][c]) e_c.
   // One thread per (term, column c); `diag`: the weights are diagonal, the inner sum is its one
   // non-zero product (the others are exact zeros).  Then one thread per term adds the columns in
@@ -51,7 +44,7 @@ __global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__
 #pragma unroll
     for (int u = 0; u < QPF; ++u) { const int idx = threadIdx.x + u * blockDim.x; qpf[u] = (idx < T.n) ? T.q_trial[idx] : 0.0; }
   }
-  const int N = P.N, nq = M.nq, nv = M.nv, tid = threadIdx.x, nt = blockDim.x;
+  const int N = P.N, nq = nq_, nv = nv_, tid = threadIdx.x, nt = blockDim.x;
   const int nterms = 3 * N + 2, nmax = nq > nv ? nq : nv;
   double* terms = lds;               // [nterms]
   double* cols = terms + nterms;     // [nterms][nmax]
@@ -70,7 +63,6 @@ __global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__
     const double wq = P.Qq0[cqi * nq + cqi], wv = P.Qv0[cvi * nv + cvi], wr = P.R0[cvi * nv + cvi];
     const double wfq = P.Qfq0[cqi * nq + cqi], wfv = P.Qfv0[cvi * nv + cvi];
     const double* tau0 = slab + 3 * nv * nq;
-    constexpr int TU = 2;   // steps per pass (N = 40 .. 60 at 32 steps a time: one pass, one round trip)
     for (int t0 = tl; t0 <= N; t0 += TU * tstep) {
       double eq[TU], nq_[TU], ev[TU], nv_[TU], et[TU];
 #pragma unroll
@@ -236,9 +228,11 @@ __global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__
     }
     TR_STAMP(20);
   }
+  bool accepted = false;
   if (T.state) {
     __syncthreads();
-    if (terms[0] != 0.0) {
+    accepted = terms[0] != 0.0;
+    if (accepted) {
 #pragma unroll
       for (int u = 0; u < QPF; ++u) { const int idx = tid + u * nt; if (idx < T.n) T.q[idx] = qpf[u]; }
       for (int idx = tid + QPF * nt; idx < T.n; idx += nt) T.q[idx] = T.q_trial[idx];
@@ -251,6 +245,26 @@ __global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__
       const int t = idx / nv, r = idx - t * nv;
       pack[idx] = slab[(size_t)t * slab_stride + 3 * nv * nq + r];
     }
+  return accepted;
+}
+
+__global__ void cost_kernel(DevModel M, DevProblem P, const double* __restrict__ q, const double* __restrict__ v,
+                            const double* __restrict__ slab, int slab_stride, double* __restrict__ cost_out,
+                            int diag, double* __restrict__ pack, size_t pstride, double* __restrict__ cost_copy,
+                            TrDecideArgs T, AltSel alt) {
+  {
+    const size_t o = (size_t)blockIdx.y * pstride, w = o + (size_t)alt_offset(alt, o);
+    P = at_problem(P, o); q = at_problem(q, o); v = at_problem(v, w); slab = at_problem(slab, w);
+    cost_out = at_problem(cost_out, o);
+    if (pack) pack = at_problem(pack, o);
+    if (T.state) {   // (the trust-region decision of THIS problem: trust_region.h tr_decide)
+      T.state = at_problem(T.state, o); T.out = at_problem(T.out, o); T.q = at_problem(T.q, o);
+      T.q_trial = at_problem(T.q_trial, o); T.rows += (size_t)blockIdx.y * T.rows_stride;
+      T.part2 = at_problem(T.part2, o);
+      if (T.lambda) T.lambda = at_problem(T.lambda, o);
+    }
+  }
+  (void)cost_body(M.nq, M.nv, P, q, v, slab, slab_stride, cost_out, diag, pack, cost_copy, T);
 }
 
 // ---------------------------------------------------------------------------

@@ -387,28 +387,82 @@ struct PipeAsm {
   AltSel alt;
   unsigned* ready;
   const double* gate;       // idto_hip_tr_solve: a problem whose word is 0 (its step was rejected) keeps g and H, nullptr: assemble
+  // (DEC instantiations of penta_pipe_kernel, inside idto_hip_tr_solve) the decision is made IN this launch: one more
+  // workgroup - the one behind the assembly's - evaluates the trial point's cost and decides (kernels.h cost_body:
+  // cost_kernel's work, whose launch this saves); the assembly's workgroups start cold under it instead of behind it
+  int decide;               // 0: `gate` (or nothing) as above
+  const double* dq;         // q of the trial point: the cost's, and the assembly's for an accepted step (the copy into the
+                            // iterate's array is the deciding workgroup's, not ordered against anybody in this launch)
+  const double* dv; const double* dslab; int dslab_stride; double* dcost; int ddiag;
+  TrDecideArgs dT; AltSel dalt;   // (the trial point's outputs live in the set the iterate does not occupy)
+  double* dword; unsigned depoch; // the decision, the launch's epoch in every word: 1 + accepted + 2 (current set AFTER it)
+  // The assembly does not wait for the decision: it forms g and H of the TRIAL point at once into a second set of
+  // arrays (same layout), the chains take their system from there once the step is accepted (from g, H as they stand
+  // when it is rejected), and the assembly's workgroups form the accepted point's g and H once more into the primary
+  // arrays behind the decision - off everybody's critical path - for the kernels that follow.
+  double* g2; double* HA2; double* HB2; double* HC2;
+  const double* curpre;     // the current-set word as the iteration's tr_iter_kernel found it (the deciding workgroup flips the word itself mid-launch)
 };
-// does this problem assemble in this launch?
-__device__ __forceinline__ bool pipe_asm_on(const PipeAsm& F, size_t o) {
-  return F.on && !(F.gate && *at_problem(F.gate, o) == 0.0);
+// does this problem assemble in this launch?  (cur: the set that holds the iterate, where the launch itself decides)
+template <bool DEC = false>
+__device__ __forceinline__ bool pipe_asm_on(const PipeAsm& F, size_t o, const SpinCtl sc = SpinCtl{nullptr, 0}, int* cur = nullptr) {
+  if (!F.on) return false;
+  if (DEC && F.decide) {
+    double x = 0.0;
+    if ((threadIdx.x & 63) == 0) {
+      const double* word = at_problem(F.dword, o);
+      if (!spin_wait([&] { return tr_ll_try(word, F.depoch, x); }, sc)) x = 1.0;   // (no decision within the bound: nothing is assembled, the timeout is reported)
+    }
+    const int code = __builtin_amdgcn_readfirstlane((int)x) - 1;
+    if (cur) *cur = code >> 1;
+    return (code & 1) != 0;
+  }
+  return !(F.gate && *at_problem(F.gate, o) == 0.0);
+}
+
+// the deciding workgroup (PipeAsm::decide): cost_kernel's work for the problem, then the word the others poll
+__device__ __forceinline__ void pipe_decide_role(const PipeAsm& F, const size_t pstride) {
+  const size_t o = (size_t)blockIdx.y * pstride, w = o + (size_t)alt_offset(F.dalt, o);
+  const DevProblem P = at_problem(F.P, o);
+  TrDecideArgs T = F.dT;
+  T.state = at_problem(T.state, o); T.out = at_problem(T.out, o); T.q = at_problem(T.q, o);
+  T.q_trial = at_problem(T.q_trial, o); T.rows += (size_t)blockIdx.y * T.rows_stride;
+  T.part2 = at_problem(T.part2, o);
+  if (T.lambda) T.lambda = at_problem(T.lambda, o);
+  const double cur_old = T.state[TRS_CUR];
+  const bool acc = cost_body<4>(F.nq, F.nv, P, at_problem(F.dq, o), at_problem(F.dv, w), at_problem(F.dslab, w), F.dslab_stride,
+                             at_problem(F.dcost, o), F.ddiag, nullptr, nullptr, T);
+  if (threadIdx.x == 0) {
+    const int cur_new = acc ? (cur_old != 0.0 ? 0 : 1) : (cur_old != 0.0 ? 1 : 0);   // (tr_decide: an accepted step's set is the iterate's now)
+    tr_ll_store(at_problem(F.dword, o), (double)(1 + (acc ? 1 : 0) + 2 * cur_new), F.depoch);
+  }
 }
 
 // (first_wg: how many workgroups of the grid's x run the solver - 5 in penta_pipe_kernel, 1 in penta_band_kernel; ts:
 // debug stamps or nullptr, in the slot behind the solver's roles)
-__device__ __forceinline__ void pipe_assemble(double* ts, const unsigned epoch, const size_t pstride, PipeAsm F, const int first_wg) {
+template <bool DEC = false>
+__device__ __forceinline__ void pipe_assemble(double* ts, const unsigned epoch, const size_t pstride, PipeAsm F, const int first_wg,
+                                              const SpinCtl sc = SpinCtl{nullptr, 0}) {
   struct { double* ts; unsigned epoch; size_t pstride; } A{ts, epoch, pstride};
   extern __shared__ double lds[];
-  const int a = (int)blockIdx.x - first_wg, i = a >> 2, part = a & 3;
+  const bool decided = DEC && F.decide;
+  const int a0 = (int)blockIdx.x - first_wg;
+  if (decided && a0 == 0) { pipe_decide_role(F, pstride); return; }   // (the first workgroup behind the chains': dispatched early)
+  const int a = decided ? a0 - 1 : a0, i = a >> 2, part = a & 3;
   if (i >= F.rows) return;
-  if (!pipe_asm_on(F, (size_t)blockIdx.y * A.pstride)) return;
+  const size_t o = (size_t)blockIdx.y * A.pstride;
+  if (!decided && !pipe_asm_on<false>(F, o)) return;
   if (A.ts && threadIdx.x == 0)   // debug stamps of role 5: [0] latest end, [1] latest start of an assembly workgroup (positive doubles order like integers)
     atomicMax(reinterpret_cast<unsigned long long*>(A.ts + first_wg * 64 + 1), (unsigned long long)__double_as_longlong((double)wall_clock64()));
   if (A.ts && a == 4 && threadIdx.x == 0) A.ts[first_wg * 64 + 8] = (double)wall_clock64();
-  const size_t o = (size_t)blockIdx.y * A.pstride, w = o + (size_t)alt_offset(F.alt, o);
+  // (deciding launch: the trial point's records - the set the iterate does NOT occupy as the launch finds the state - and
+  // its q; results into the second set of arrays)
+  const size_t w = o + (size_t)(decided ? (((*at_problem(F.curpre, o) != 0.0) != (F.dalt.which != 0)) ? F.dalt.off : 0) : alt_offset(F.alt, o));
   const DevProblem P = at_problem(F.P, o);
-  assemble_terms_row<true>(F.nq, F.nv, P, at_problem(F.q, o), at_problem(F.terms, w), at_problem(F.v_res, w),
-                           at_problem(F.nplus, w), at_problem(F.g, o), at_problem(F.HA, o), at_problem(F.HB, o),
-                           at_problem(F.HC, o), i, part, lds);
+  const double* qa = at_problem(decided ? F.dq : F.q, o);
+  assemble_terms_row<true>(F.nq, F.nv, P, qa, at_problem(F.terms, w), at_problem(F.v_res, w), at_problem(F.nplus, w),
+                           at_problem(decided ? F.g2 : F.g, o), at_problem(decided ? F.HA2 : F.HA, o),
+                           at_problem(decided ? F.HB2 : F.HB, o), at_problem(decided ? F.HC2 : F.HC, o), i, part, lds);
   if (A.ts && a == 4 && threadIdx.x == 0) A.ts[first_wg * 64 + 9] = (double)wall_clock64();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every write-through store acknowledged ...
   __syncthreads();
@@ -417,6 +471,14 @@ __device__ __forceinline__ void pipe_assemble(double* ts, const unsigned epoch, 
     __hip_atomic_store(at_problem(F.ready, o) + 4 * i + part, A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (A.ts && threadIdx.x == 0)
     atomicMax(reinterpret_cast<unsigned long long*>(A.ts + first_wg * 64), (unsigned long long)__double_as_longlong((double)wall_clock64()));
+  if (decided) {
+    // behind the decision: an accepted point's g and H once more, into the arrays every later kernel reads (same
+    // operands, same code, same bits; nobody in this launch waits for it)
+    if (!pipe_asm_on<true>(F, o, sc)) return;
+    __syncthreads();
+    assemble_terms_row<false>(F.nq, F.nv, P, qa, at_problem(F.terms, w), at_problem(F.v_res, w), at_problem(F.nplus, w),
+                              at_problem(F.g, o), at_problem(F.HA, o), at_problem(F.HB, o), at_problem(F.HC, o), i, part, lds);
+  }
 }
 
 // one wavefront waits for solver rows o_lo .. o_hi (clamped to the system) to be assembled: a lane per word
@@ -1507,9 +1569,12 @@ __device__ void chain_recursion_tail(int n, int k, double* x, double* Ust, doubl
 //   4: the separator (penta_nd.h nd_separator)
 // Every wait is bounded (PIPE_SPIN_CAP): a workgroup that is not resident with its partners ends with the
 // factorisation status set instead of hanging the device.
-template <int K>
+template <int K, bool DEC = false>
 __global__ void __launch_bounds__(512) penta_pipe_kernel(NdArgs A, PipeAsm F) {
-  if (blockIdx.x >= 5) { pipe_assemble(A.ts, A.epoch, A.pstride, F, 5); return; }
+  if (blockIdx.x >= 5) {
+    pipe_assemble<DEC>(A.ts, A.epoch, A.pstride, F, 5, SpinCtl{A.status + 2 * gridDim.y, A.fact_id});
+    return;
+  }
   {
     const size_t o = (size_t)blockIdx.y * A.pstride;
     A.HA = at_problem(A.HA, o); A.HB = at_problem(A.HB, o); A.HC = at_problem(A.HC, o); A.b = at_problem(A.b, o);
@@ -1521,8 +1586,16 @@ __global__ void __launch_bounds__(512) penta_pipe_kernel(NdArgs A, PipeAsm F) {
   }
   const int role = blockIdx.x;
   if (role == A.debug_skip_role) return;
+  // does this launch assemble the system?  (a deciding launch: known once its decision is out - an accepted trial point's
+  // g and H stand in the second set of arrays, which the launch's assembly fills without waiting)
+  const bool asm_on = pipe_asm_on<DEC>(F, (size_t)blockIdx.y * A.pstride, A.spin);
+  if (DEC && F.decide && asm_on) {
+    const size_t o = (size_t)blockIdx.y * A.pstride, qq0 = (size_t)F.first * F.nq * F.nq;
+    A.HA = at_problem(F.HA2, o) + qq0; A.HB = at_problem(F.HB2, o) + qq0; A.HC = at_problem(F.HC2, o) + qq0;
+    A.b = at_problem(F.g2, o) + (size_t)F.first * F.nq;
+  }
   if (role == 4) {
-    A.asm_ready = pipe_asm_on(F, (size_t)blockIdx.y * A.pstride) ? at_problem(F.ready, (size_t)blockIdx.y * A.pstride) : nullptr;
+    A.asm_ready = asm_on ? at_problem(F.ready, (size_t)blockIdx.y * A.pstride) : nullptr;
     A.asm_first = F.first;
     A.wt_rows = 1;
     nd_separator<K, false>(A);
@@ -1559,7 +1632,7 @@ __global__ void __launch_bounds__(512) penta_pipe_kernel(NdArgs A, PipeAsm F) {
   P.ts = c.ts;
   P.xjoin_ll = A.ndbuf + B.ll + (1 + pair) * 4 * K;
   P.join_ll = A.ndbuf + B.joinll + (size_t)pair * B.joinll_pair;
-  P.asm_ready = pipe_asm_on(F, (size_t)blockIdx.y * A.pstride) ? at_problem(F.ready, (size_t)blockIdx.y * A.pstride) : nullptr;
+  P.asm_ready = asm_on ? at_problem(F.ready, (size_t)blockIdx.y * A.pstride) : nullptr;
   P.asm_first = F.first; P.asm_rows = F.rows;
   const bool spike = role >= 2;
   const PipeLds L = pipe_layout<K>(A.n, spike);

@@ -455,6 +455,8 @@ struct TrIterArgs {
   // for the multiplier pivots' range (TRF_SINGULAR_S), and the KKT context's arena stride
   const double* kdinv; int kdstride, kfirst_row;
   size_t kstride;
+  double* curpre;       // (or null) a copy of the current-set word as THIS iteration finds it: the deciding solver launch's
+                        // assembly locates the trial point's records by it while the word itself may already have been flipped
   int debug_skip_row;   // test aid (option "debug_skip_role" 100 + i): block row i's workgroup returns at once - a partner that is not resident
 };
 
@@ -594,6 +596,7 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
     if (A.freeze) A.freeze = at_problem(A.freeze, o);
     A.slab = at_problem(A.slab, o + (size_t)alt_offset(T.alt, o));   // (h = tau[unactuated] is read from the iterate's set)
     T.part2 = at_problem(T.part2, o); T.out = at_problem(T.out, o); T.state = at_problem(T.state, o);
+    if (T.curpre) T.curpre = at_problem(T.curpre, o);
     T.q_trial = at_problem(T.q_trial, o); T.dq = at_problem(T.dq, o);
     A.dq_old = T.conv.on ? T.dq : nullptr;
     if (A.kx.z) {
@@ -705,6 +708,7 @@ __global__ void __launch_bounds__(256) tr_iter_kernel(TrIterArgs T) {
     if ((T.timeout_status && (unsigned)part[TR_NSUM * nblk + 1] == T.fact_id) || timed_out) extra |= TRF_SOLVER_TIMEOUT;
     if (singular) extra |= TRF_SINGULAR_S;
     tr_conv_dogleg(T, S, st, first, extra, ab);
+    if (first && T.curpre) *T.curpre = st[TRS_CUR];
   }
   if (T.conv.on && T.conv.check_only) return;
   TR_STAMP_B0(6);

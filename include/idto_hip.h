@@ -361,7 +361,8 @@ int idto_hip_tr_solve_batch_constrained(idto_hip_ctx* ctx, int iterations, int s
  * one-workgroup launch (defaults 1: a whole trust-region iteration of a small model, its enforced constraint included, is
  * ONE launch), "kkt_fold" = 0 takes the banded KKT step's solution apart in a launch of its own (kkt_extract_kernel) instead of
  * inside tr_iter_kernel, "kkt_in_asm" = 0 builds the KKT system in a launch of its own (kkt_build_kernel) instead of
- * having the gated assembly write it along; all of these leave every result bit for bit as it is (tests/test_gpu_small.py,
+ * having the gated assembly write it along, "decide_in_solver" = 0 keeps cost_kernel a launch of its own in front of the
+ * pipelined solver's instead of one more workgroup of that launch; all of these leave every result bit for bit as it is (tests/test_gpu_small.py,
  * tests/test_gpu_trust_region.py);
  * "solver_debug" = 1 records per-phase cycle stamps (IDTO_ARR 15, tools/solver_phases.py);
  * "asm_stop" truncates the assembly kernel after a phase (tools/asm_phases.py). */

@@ -455,5 +455,35 @@ def test_kkt_system_written_by_the_assembly(name, N, iters):
         dev.close()
     a, b = out
     assert a[0][:, 9].any() and (a[0][:, 13] == 0).all()
+@pytest.mark.parametrize("name,N,iters,method,batch", [("mini_cheetah", 40, 10, "double_sqrt", 1), ("hopper", 40, 15, "double_sqrt", 1),
+                                                        ("mini_cheetah", 24, 8, "sqrt", 1), ("hopper", 50, 12, None, 1),
+                                                        ("mini_cheetah", 40, 6, "double_sqrt", 3), ("hopper", 40, 10, "adaptive_double_sqrt", 1)])
+def test_decision_inside_the_solvers_launch(name, N, iters, method, batch):
+    """the trial point's cost and the accept / reject decision by one more workgroup of the pipelined solver's launch
+    (option decide_in_solver, the default; penta_pipe.h PipeAsm::decide, kernels.h cost_body - cost_kernel's work): the
+    assembly's workgroups and the chains poll its word.  Rows, iterate, tau, the step: the bits of the loop that runs
+    cost_kernel as a launch of its own; hopper's runs reject steps (the chains then read g and H where they are)."""
+    cfg, model, prob, sp, q = _setup(name, N)
+    out = []
+    for inside in (1, 0):
+        if batch == 1:
+            dev = hip.HipPath(model, prob, sp)
+            dev.set_option("decide_in_solver", inside)
+            dev.set_q(q)
+            dev.eval_tau()
+            rows, delta = dev.tr_solve(iters, SCALING[method] if method else -1, method is not None, False, 1e-1, 1e5)
+            assert dev.get_option("last_solver") == 4
+        else:
+            qs = [synthetic_trajectory(cfg, model, N, seed=7 + b, lower=0.01) for b in range(batch)]
+            dev = hip.HipPath(model, [prob] * batch, sp)
+            dev.set_option("decide_in_solver", inside)
+            dev.set_q_batch(np.stack(qs))
+            dev.eval_tau()
+            rows, delta = dev.tr_solve_batch(iters, SCALING[method], True, False, [1e-1] * batch, 1e5)
+        rows = np.delete(rows, 10, axis=-1)   # (the device clock)
+        out.append((rows, np.asarray(delta)) + tuple(dev.get(n) for n in ("q", "tau", "step", "gradient", "cost")))
+        dev.close()
+    a, b = out
+    assert a[0][..., 9].any() and (a[0][..., 13] == 0).all()
     for x, y in zip(a, b):
         assert np.array_equal(np.asarray(x), np.asarray(y))
