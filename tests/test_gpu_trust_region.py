@@ -457,7 +457,10 @@ def test_kkt_system_written_by_the_assembly(name, N, iters):
     assert a[0][:, 9].any() and (a[0][:, 13] == 0).all()
 @pytest.mark.parametrize("name,N,iters,method,batch", [("mini_cheetah", 40, 10, "double_sqrt", 1), ("hopper", 40, 15, "double_sqrt", 1),
                                                         ("mini_cheetah", 24, 8, "sqrt", 1), ("hopper", 50, 12, None, 1),
-                                                        ("mini_cheetah", 40, 6, "double_sqrt", 3), ("hopper", 40, 10, "adaptive_double_sqrt", 1)])
+                                                        ("mini_cheetah", 40, 6, "double_sqrt", 3), ("hopper", 40, 10, "adaptive_double_sqrt", 1),
+                                                        # (12 x 170 workgroups of one per CU: more than the device holds at once - the ones that
+                                                        # wait only wait for workgroups dispatched before them)
+                                                        ("mini_cheetah", 40, 4, "double_sqrt", 12), ("hopper", 40, 8, "double_sqrt", 12)])
 def test_decision_inside_the_solvers_launch(name, N, iters, method, batch):
     """the trial point's cost and the accept / reject decision by one more workgroup of the pipelined solver's launch
     (option decide_in_solver, the default; penta_pipe.h PipeAsm::decide, kernels.h cost_body - cost_kernel's work): the
